@@ -1,0 +1,183 @@
+/*
+ * monkeynet_hip.h -- C-ABI of libmonkeynet_hip.so: the MI355X (gfx950) kernels behind Monkey-Net's
+ * frame-generation hot path (KPDetector + DenseMotionModule + MotionTransferGenerator, forward/backward).
+ *
+ * The reference (AliaksandrSiarohin/monkey-net) has no FFI: its boundary is the Python module API of
+ * modules/<name>.py, and all device arithmetic lives in torch functionals.  Each entry point below replaces one
+ * torch call site (or a tight group of them) of the reference; the citation says which (paths relative to
+ * the reference root).  The Python drop-in `monkey-net_amd/modules/` binds these symbols with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated; nothing is allocated inside the library:
+ *     scratch comes from the caller (`ws`, sized by the matching *_workspace_floats query);
+ *   - activations are NHWC with the time axis folded into N (frame = b*D + d) and a channel stride `ld*`
+ *     (floats per pixel, a multiple of 4, >= the logical channel count; pad channels are kept zero);
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - return value: 0 on success, <0 on error (MNK_E*); mnk_last_error() gives the message of the last
+ *     failure on the calling thread.  No global state except the optional profiling recorder.
+ */
+#ifndef MONKEYNET_HIP_H
+#define MONKEYNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNK_OK 0
+#define MNK_EINVAL (-1)     /* invalid argument                              */
+#define MNK_ELAUNCH (-2)    /* hipLaunchKernel / runtime failure             */
+#define MNK_EWORKSPACE (-3) /* workspace too small                           */
+
+int mnk_version(void);
+const char* mnk_last_error(void);
+/* 1 when the library was built against the real HIP runtime for gfx950, 0 for the CPU test emulator */
+int mnk_is_device_build(void);
+
+/* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ------------------- */
+int mnk_prof_enable(int on);
+int mnk_prof_reset(void);
+int mnk_prof_num_kernels(void);
+const char* mnk_prof_kernel_name(int kernel_id);
+/* launches, summed milliseconds and summed algorithmic work (FLOP for MFMA kernels, bytes otherwise) */
+int mnk_prof_query(int kernel_id, uint64_t* launches, double* total_ms, double* total_work);
+
+/* ---- layout --------------------------------------------------------------------------------------------
+ * (B,C,D,H,W) <-> folded NHWC.  `step` > 1 applies the nearest down-scaling F.interpolate(scale_factor=
+ * (1,1/step,1/step)) of modules/keypoint_detector.py:98-99, dense_motion_module.py:43-44,
+ * movement_embedding.py:43-44 (index pick x[..., ::step, ::step]). */
+int mnk_ncdhw_to_nhwc(const float* src, float* dst, int B, int C, int D, int H, int W, int step, int ld_dst,
+                      void* stream);
+int mnk_nhwc_to_ncdhw(const float* src, int ld_src, float* dst, int B, int C, int D, int H, int W, void* stream);
+/* dst[r, dst_off + c] = src[r, src_off + c], c < C (torch.cat / slicing: modules/util.py:185, generator.py:73) */
+int mnk_copy_channels(const float* src, int ld_src, int src_off, float* dst, int ld_dst, int dst_off, int C,
+                      long rows, int accumulate, void* stream);
+/* dst[n,h,w,c] = sum of the 2x2 block of src (backward of the nearest x2 up-sampling, modules/util.py:84) */
+int mnk_sumpool2x2(const float* src, int ld_src, float* dst, int ld_dst, int N, int Hs, int Ws, int C, void* stream);
+/* nearest resize of a channel block into a slice of another tensor (generator.py:72 kp_skips) and its adjoint */
+int mnk_resize_nearest(const float* src, int ld_src, int Hs, int Ws, float* dst, int ld_dst, int dst_off, int Hd,
+                       int Wd, int N, int C, void* stream);
+int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                           int Hs, int Ws, int N, int C, void* stream);
+
+/* ---- BatchNorm (sync_batchnorm/batchnorm.py:48-78,113-125; F.batch_norm semantics: (var+eps)^-1/2) -------
+ * statistics: sums[0..C) = sum x, sums[C..2C) = sum x^2 over `rows` pixels.  The caller may all-reduce
+ * `sums` across ranks (RCCL) before mnk_bn_finalize -- that is the SyncBN exchange. */
+size_t mnk_bn_workspace_floats(long rows, int ld);
+int mnk_bn_stats(const float* x, int ld, long rows, int C, float* sums, float* ws, size_t ws_floats, void* stream);
+/* mean = sum/count, var = sumsq/count - mean^2, invstd = (var+eps)^-1/2, scale = gamma*invstd;
+ * running_mean/var updated with momentum and the unbiased variance (batchnorm.py:119-123) */
+int mnk_bn_finalize(const float* sums, double count, const float* gamma, float* running_mean, float* running_var,
+                    float momentum, float eps, int C, int update_running, float* mean, float* invstd, float* scale,
+                    void* stream);
+int mnk_bn_eval_coeffs(const float* gamma, const float* running_mean, const float* running_var, float eps, int C,
+                       float* mean, float* invstd, float* scale, void* stream);
+/* z = [avgpool2x2] [relu] ((y-mean)*scale + beta)   (modules/util.py:56-57,62,81,87,100-101,106-107) */
+int mnk_bn_act_fwd(const float* y, int ld_y, const float* mean, const float* scale, const float* beta, float* z,
+                   int ld_z, int z_off, int N, int H, int W, int C, int relu, int pool, void* stream);
+/* backward, pass 1: sums[0..C) = sum g, sums[C..2C) = sum g*xhat with g = dL/d(BN output), xhat = (y-mean)*invstd.
+ * These are also dbeta and dgamma. */
+int mnk_bn_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                         const float* invstd, const float* scale, const float* beta, int N, int H, int W, int C,
+                         int relu, int pool, float* sums, float* ws, size_t ws_floats, void* stream);
+/* backward, pass 2: dy = scale*(g - sum_g/count - xhat*sum_gx/count) (training) or g*scale (eval).
+ * `sums`/`count` may be the all-reduced (SyncBN) values. */
+int mnk_bn_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                         const float* invstd, const float* scale, const float* beta, const float* sums, double count,
+                         int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu, int pool,
+                         void* stream);
+
+/* ---- 3x3 convolution, pad 1, stride 1 (nn.Conv3d (1,3,3): modules/util.py:52-55,79,98,176) -------------
+ * implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).  The input is the channel concatenation of up to two
+ * NHWC sources (torch.cat of modules/util.py:185 never materialised); `ups` = 1 reads both sources through the
+ * nearest x2 up-sampling of modules/util.py:84.  Weights are first re-packed to [Cout][tap][C0p+C1p],
+ * CXp = C rounded up to 16 (zero filled). */
+size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1);
+int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream);
+/* dgrad weights for input channels [c_start, c_start+c_count): wp[ci][tap][Coutp] = w[co][c_start+ci][8-tap] */
+int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream);
+size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
+int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
+                    const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
+                    int Cout, float* ws, size_t ws_floats, void* stream);
+/* dw[co][c_start+ci][ky][kx] = sum_pixels dy[p][co] * x[p+tap][ci]; x is one source (C channels) */
+size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout);
+int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
+                      int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream);
+
+/* ---- grouped 1x1 convolution (SameBlock3D, modules/util.py:118, dense_motion_module.py:24-28) ----------- */
+int mnk_gconv1x1_fwd(const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, long rows,
+                     int groups, int gsize, void* stream);
+int mnk_gconv1x1_bwd_data(const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, long rows, int groups,
+                          int gsize, void* stream);
+size_t mnk_gconv1x1_workspace_floats(long rows, int groups, int gsize);
+int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy, float* dw, float* dbias, long rows,
+                            int groups, int gsize, float* ws, size_t ws_floats, void* stream);
+
+/* ---- 1x1 convolution + sigmoid, NHWC in -> (B,C,D,H,W) out (generator.py:48,79-80) ---------------------- */
+int mnk_conv1x1_sigmoid_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B,
+                            int D, int H, int W, int Cout, void* stream);
+size_t mnk_conv1x1_workspace_floats(long rows, int Cin, int Cout);
+int mnk_conv1x1_sigmoid_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout,
+                            float* dx, int ld_dx, float* dw, float* dbias, int B, int D, int H, int W, int Cout,
+                            float* ws, size_t ws_floats, void* stream);
+
+/* ---- heat-map -> key-point (modules/keypoint_detector.py:43-78,103-107) ---------------------------------
+ * softmax over H*W of heat*inv_temperature, +1e-7, mean (x,y) and centred 2x2 covariance.
+ * mean [N][K][2], var [N][K][4], stat [N][K][2] = (row max of the scaled logits, softmax denominator). */
+int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, float inv_temperature, float* mean,
+                       float* var, float* stat, void* stream);
+int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, float inv_temperature,
+                       const float* mean, const float* stat, const float* dmean, const float* dvar, float* dheat,
+                       int ld_d, void* stream);
+
+/* ---- key-point -> movement embedding (modules/movement_embedding.py:42-92, keypoint_detector.py:7-40) ----
+ * one kernel renders, per slot (background first when add_bg): [heat-map (driving - source when
+ * heatmap_diff), (dx,dy) maps, source image translated by kp_source - kp_driving].  Frames f = b*d + j use
+ * source key-points / image of batch entry b.  var_* == NULL selects a constant variance `const_var`.
+ * norm_const <= 0 selects 'sum' normalisation (movement_embedding.py:34-38); then `norm` [2][Nf][K] must hold
+ * the sums from mnk_gaussian_sums. */
+int mnk_gaussian_sums(const float* mean, const float* var, float const_var, int Nkp, int h, int w, float* sums,
+                      void* stream);
+int mnk_movement_embedding_fwd(const float* img, int ld_img, int Cimg, const float* mean_d, const float* var_d,
+                               const float* mean_s, const float* var_s, float const_var, int Nb, int d, int h, int w,
+                               int K, int add_bg, int use_heatmap, int use_difference, int use_deformed,
+                               int heatmap_diff, float norm_const, const float* norm_d, const float* norm_s,
+                               float* out, int ld_out, void* stream);
+/* gradients w.r.t. the key-points: dmean_d/dvar_d [Nb*d][K][2|4], dmean_s/dvar_s [Nb][K][2|4] (accumulated over
+ * the d frames of a batch entry).  All four outputs are overwritten. */
+int mnk_movement_embedding_bwd(const float* img, int ld_img, int Cimg, const float* mean_d, const float* var_d,
+                               const float* mean_s, const float* var_s, float const_var, int Nb, int d, int h, int w,
+                               int K, int add_bg, int use_heatmap, int use_difference, int use_deformed,
+                               int heatmap_diff, float norm_const, const float* norm_d, const float* norm_s,
+                               const float* dout, int ld_out, float* dmean_d, float* dvar_d, float* dmean_s,
+                               float* dvar_s, void* stream);
+
+/* ---- dense-motion head (modules/dense_motion_module.py:52-76) --------------------------------------------
+ * pred [N][h][w][ld]: channels [0,K+1) mask logits (use_mask), last 2 correction (use_correction);
+ * delta [N][K+1][2] = kp_source.mean - kp_driving.mean (slot 0 = background = 0);
+ * field [N][h][w][2] = sum_k softmax(mask)_k * delta_k + correction + identity grid. */
+int mnk_motion_field_fwd(const float* pred, int ld, const float* delta, int N, int h, int w, int K, int use_mask,
+                         int use_correction, float* field, void* stream);
+int mnk_motion_field_bwd(const float* pred, int ld, const float* delta, const float* dfield, int N, int h, int w,
+                         int K, int use_mask, int use_correction, float* dpred, int ld_d, float* ddelta,
+                         void* stream);
+
+/* ---- bilinear warp (MotionTransferGenerator.deform_input, modules/generator.py:51-58) --------------------
+ * out[n,y,x,off+c] = bilinear(inp[n], field'[n,y,x]) with zeros padding, align_corners=True (torch 0.4.1),
+ * field' = field resized to (h,w): mode 0 = nearest index pick, 1 = bilinear align_corners=False
+ * ('trilinear' with unchanged depth). */
+int mnk_deform_fwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
+                   float* out, int ld_out, int out_off, int N, void* stream);
+/* dinp (same layout as inp) must be zero-initialised by the caller when d_inp != NULL; dfield [N][hf][wf][2]
+ * is ACCUMULATED into (several skips share one field). */
+int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
+                   const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONKEYNET_HIP_H */

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Build libmonkeynet_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+ROOT="$(cd "$HERE/../.." && pwd)"
+OUT="$HERE/build"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-unused-variable ${MNK_EXTRA_FLAGS}"
+OBJS=""
+pids=""
+for f in "$HERE"/*.hip; do
+  o="$OUT/$(basename "$f").o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/mnk_common.h" -nt "$o" ] || [ "$ROOT/include/monkeynet_hip.h" -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids="$pids $!"
+  fi
+  OBJS="$OBJS $o"
+done
+for p in $pids; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/../libmonkeynet_hip.so" $OBJS
+echo "$HERE/../libmonkeynet_hip.so"

@@ -1,0 +1,610 @@
+// 3x3 / pad 1 / stride 1 convolution on folded NHWC frames as an implicit GEMM on the gfx950 fp32 matrix
+// cores (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD, 157 TFLOP/s chip peak).
+//
+// Replaces nn.Conv3d(kernel (1,3,3), padding (0,1,1)) of the reference (modules/util.py:52-55,79,98,176) in
+// forward, data-gradient (same kernel, flipped/transposed packed weights) and weight-gradient form.
+//
+//   forward / dgrad GEMM:  Y[m][co] = sum_{tap,ci} X[pix(m)+off(tap)][ci] * Wp[co][tap][ci]
+//       M = N*H*W pixels (rows, NHWC so ci is contiguous), N = Cout, K = 9 * (C0p + C1p)
+//       both operands are K-contiguous, so each lane fetches its MFMA fragment as one ds_read_b128:
+//       lane (i = l&31, kk = l>>5) holds k = 8*kh + 4*kk + e (e = 0..3) of row i -- a permutation of K inside the
+//       16-wide K step that is applied identically to A and B, hence harmless.
+//   weight-gradient GEMM:  dW[co][(tap,ci)] = sum_p dY[p][co] * X[p+off(tap)][ci]   (K = pixels, split over blocks)
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN (128x128 default) staged through LDS in 16-deep K steps,
+// double buffered with register prefetch (one barrier per step); wave tile = (BM/WM) x (BN/WN) as 32x32 MFMA
+// tiles, i.e. 64 accumulator VGPRs for 64x64.  LDS rows are padded to 20 floats (80 B = 5 x 16 B, odd) so the
+// 16-lane groups of a ds_read_b128 hit 16 distinct 16-B slots (no bank conflicts).
+// Small problems (deep hourglass levels: 4x4 / 2x2 maps with 1024 channels) are split along K across blockIdx.z
+// with a deterministic second-pass reduction (no atomics), which also applies bias and the residual add.
+#include "mnk_common.h"
+
+using namespace mnk;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;        // K step (floats)
+constexpr int LDS_K = 20;     // padded LDS row (floats)
+
+struct ConvArgs {
+    const float* x0;
+    const float* x1;
+    int ld0, ld1, C0, C1, C0p, C1p;
+    int ups;
+    const float* wp;  // [Cout][9][C0p + C1p]
+    const float* bias;
+    const float* residual;
+    int ld_res;
+    float* y;
+    int ld_y;
+    int N, H, W, Cout;
+    long M;
+    int chunks;        // (C0p + C1p) / 16
+    int ksteps;        // 9 * chunks
+    int ksteps_per_split;
+    int splits;
+    float* ws;         // [splits][M][ldw] partial sums when splits > 1
+    int ldw;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) conv3x3_igemm_kernel(ConvArgs a) {
+    constexpr int RA = BM / 64;               // A rows per thread per K step
+    constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(WM * WN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_K];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * a.ksteps_per_split;
+    int s_end = s_begin + a.ksteps_per_split;
+    if (s_end > a.ksteps) s_end = a.ksteps;
+
+    // ---- per-thread global->LDS assignment --------------------------------------------------------------
+    const int lrow = t >> 2, lq = t & 3;      // row inside a 64-row slab, float4 column (4 channels)
+    int pn[RA], ph[RA], pw[RA];
+    bool pvalid[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        long m = m0 + lrow + 64 * j;
+        pvalid[j] = m < a.M;
+        long mm = pvalid[j] ? m : 0;
+        pw[j] = (int)(mm % a.W);
+        long tt = mm / a.W;
+        ph[j] = (int)(tt % a.H);
+        pn[j] = (int)(tt / a.H);
+    }
+    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+    const int KT = 9 * (a.C0p + a.C1p);
+
+    float4 ra[RA], rb[RB];
+
+    auto load_step = [&](int s) {
+        const int tap = s / a.chunks;
+        const int chunk = s - tap * a.chunks;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int cbase = chunk * BK;
+        const float* src;
+        int ld, C;
+        if (cbase < a.C0p) {
+            src = a.x0;
+            ld = a.ld0;
+            C = a.C0;
+        } else {
+            cbase -= a.C0p;
+            src = a.x1;
+            ld = a.ld1;
+            C = a.C1;
+        }
+        const int ch = cbase + lq * 4;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int hh = ph[j] + dy, ww = pw[j] + dx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pvalid[j] && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W && ch < C) {
+                const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
+                v = *reinterpret_cast<const float4*>(src + (((long)pn[j] * Hs + hs) * Ws + wsrc) * ld + ch);
+                const int rem = C - ch;   // pad channels of the producer may hold anything: mask them
+                if (rem < 4) {
+                    if (rem < 2) v.y = 0.f;
+                    if (rem < 3) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int r = lrow + 64 * j;
+            const int co = n0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < BN && co < a.Cout)
+                v = *reinterpret_cast<const float4*>(a.wp + (long)co * KT + (long)s * BK + lq * 4);
+            rb[j] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+            if (lrow + 64 * j < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64 * j][lq * 4]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fi = lane & 31, fk = lane >> 5;
+    const int a_row0 = wm * (BM / WM) + fi, b_row0 = wn * (BN / WN) + fi;
+
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+    }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) load_step(s + 1);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            float4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const float4*>(&As[buf][a_row0 + 32 * i][kh * 8 + fk * 4]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_row0 + 32 * j][kh * 8 + fk * 4]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (s + 1 < s_end) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row][col], col = lane&31 (-> co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> pixel) ------
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn * (BN / WN) + 32 * j + fi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r];
+                if (a.splits > 1) {
+                    if (co < a.ldw) a.ws[((long)split * a.M + m) * a.ldw + co] = v;
+                } else if (co < a.ld_y) {
+                    if (co < a.Cout) {
+                        if (a.bias) v += a.bias[co];
+                        if (a.residual) v += a.residual[m * a.ld_res + co];
+                    } else {
+                        v = 0.f;
+                    }
+                    a.y[m * a.ld_y + co] = v;
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float* __restrict__ ws, int splits, long M,
+                                                                    int ldw, const float* __restrict__ bias,
+                                                                    const float* __restrict__ residual, int ld_res,
+                                                                    float* __restrict__ y, int ld_y, int Cout) {
+    const long total = M * ld_y;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / ld_y;
+        int co = (int)(i - m * ld_y);
+        float v = 0.f;
+        if (co < Cout) {
+            for (int s = 0; s < splits; ++s) v += ws[((long)s * M + m) * ldw + co];
+            if (bias) v += bias[co];
+            if (residual) v += residual[m * ld_res + co];
+        }
+        y[i] = v;
+    }
+}
+
+// ---- weight packing ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                                       int C0, int C1, int C0p, int C1p) {
+    const int Kc = C0p + C1p, Cin = C0 + C1;
+    const long total = (long)Cout * 9 * Kc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int k = (int)(i % Kc);
+        long t = i / Kc;
+        int tap = (int)(t % 9);
+        int co = (int)(t / 9);
+        int ci = -1;
+        if (k < C0p) {
+            if (k < C0) ci = k;
+        } else if (k - C0p < C1) {
+            ci = C0 + k - C0p;
+        }
+        wp[i] = ci >= 0 ? w[((long)co * Cin + ci) * 9 + tap] : 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                                         int Cin_total, int c_start, int c_count, int Coutp) {
+    const long total = (long)c_count * 9 * Coutp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int co = (int)(i % Coutp);
+        long t = i / Coutp;
+        int tap = (int)(t % 9);
+        int ci = (int)(t / 9);
+        wp[i] = co < Cout ? w[((long)co * Cin_total + c_start + ci) * 9 + (8 - tap)] : 0.f;
+    }
+}
+
+// ---- weight gradient ----------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    int ld_x, C, Cp, ups;
+    const float* dy;
+    int ld_dy, Cout;
+    int N, H, W;
+    long M;              // pixels
+    long pix_per_split;  // multiple of 16
+    int NT;              // 9 * Cp
+    float* ws;           // [splits][Cout][NT]
+};
+
+constexpr int WG_LD = 132;   // LDS row stride (floats) for the k-major 16 x 128 tiles
+
+__global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
+    constexpr int BM = 128, BN = 128;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][WG_LD];   // dy tile   [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][WG_LD];   // x-shifted [pixel][(tap,ci)]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int co0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const long p_begin = (long)split * a.pix_per_split;
+    long p_end = p_begin + a.pix_per_split;
+    if (p_end > a.M) p_end = a.M;
+    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+
+    // loader: thread covers pixel rows kr = t/32 + 8*j (j = 0,1), float4 column c4 = t%32
+    const int kr = t >> 5, c4 = t & 31;
+    // B column -> (tap, ci): fixed per thread
+    const int nb = n0 + c4 * 4;
+    const bool nb_ok = nb < a.NT;
+    const int tapb = nb_ok ? nb / a.Cp : 0;
+    const int cib = nb - tapb * a.Cp;
+    const int dyb = tapb / 3 - 1, dxb = tapb % 3 - 1;
+    const int coa = co0 + c4 * 4;
+
+    float4 ra[2], rb[2];
+    auto load_step = [&](long p0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long p = p0 + kr + 8 * j;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+            if (p < p_end) {
+                if (coa < a.Cout) {   // ld_dy is a multiple of 4 and pad channels of dy are zero
+                    va = *reinterpret_cast<const float4*>(a.dy + p * a.ld_dy + coa);
+                    const int rem = a.Cout - coa;
+                    if (rem < 4) {
+                        if (rem < 2) va.y = 0.f;
+                        if (rem < 3) va.z = 0.f;
+                        va.w = 0.f;
+                    }
+                }
+                if (nb_ok && cib < a.C) {
+                    const int w = (int)(p % a.W);
+                    const long tt = p / a.W;
+                    const int h = (int)(tt % a.H);
+                    const long n = tt / a.H;
+                    const int hh = h + dyb, ww = w + dxb;
+                    if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
+                        const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
+                        vb = *reinterpret_cast<const float4*>(a.x + ((n * Hs + hs) * Ws + wsrc) * a.ld_x + cib);
+                        const int rem = a.C - cib;
+                        if (rem < 4) {
+                            if (rem < 2) vb.y = 0.f;
+                            if (rem < 3) vb.z = 0.f;
+                            vb.w = 0.f;
+                        }
+                    }
+                }
+            }
+            ra[j] = va;
+            rb[j] = vb;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<float4*>(&As[buf][kr + 8 * j][c4 * 4]) = ra[j];
+            *reinterpret_cast<float4*>(&Bs[buf][kr + 8 * j][c4 * 4]) = rb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fi = lane & 31, fk = lane >> 5;
+    if (p_begin < p_end) {
+        load_step(p_begin);
+        store_step(0);
+    }
+    __syncthreads();
+    int it = 0;
+    for (long p0 = p_begin; p0 < p_end; p0 += BK, ++it) {
+        const int buf = it & 1;
+        if (p0 + BK < p_end) load_step(p0 + BK);
+#pragma unroll
+        for (int e = 0; e < BK / 2; ++e) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = As[buf][2 * e + fk][wm * 64 + 32 * i + fi];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[buf][2 * e + fk][wn * 64 + 32 * j + fi];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (p0 + BK < p_end) store_step(buf ^ 1);
+        __syncthreads();
+    }
+    // rows = co, cols = (tap,ci)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + 32 * j + fi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (co < a.Cout && n < a.NT) a.ws[((long)split * a.Cout + co) * a.NT + n] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[co][c_start+ci][tap] = sum_splits ws[s][co][tap*Cp+ci]
+__global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout,
+                                                                   int C, int Cp, float* __restrict__ dw,
+                                                                   int Cin_total, int c_start) {
+    const int NT = 9 * Cp;
+    const long total = (long)Cout * NT;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n = (int)(i % NT);
+        int co = (int)(i / NT);
+        int tap = n / Cp, ci = n - tap * Cp;
+        if (ci >= C) continue;
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += ws[(long)s * total + i];
+        dw[((long)co * Cin_total + c_start + ci) * 9 + tap] = v;
+    }
+}
+
+struct Plan {
+    int bm, bn, gm, gn, splits, ksteps, ksteps_per_split, ldw;
+};
+
+static Plan make_plan(long M, int Cout, int chunks) {
+    Plan p;
+    p.bm = 128;
+    p.bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    p.gm = ceil_div(M, p.bm);
+    p.gn = ceil_div(Cout, p.bn);
+    p.ksteps = 9 * chunks;
+    long tiles = (long)p.gm * p.gn;
+    int splits = 1;
+    if (tiles < 192) {
+        splits = (int)((512 + tiles - 1) / tiles);
+        int max_splits = p.ksteps / 6;      // keep >= 6 K steps (96 deep) per split
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    p.ksteps_per_split = (p.ksteps + splits - 1) / splits;
+    p.splits = (p.ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;
+    p.ldw = round_up(Cout, 4);
+    return p;
+}
+
+struct WPlan {
+    int gm, gn, splits;
+    long pix_per_split;
+};
+
+static WPlan make_wplan(long M, int Cout, int Cp) {
+    WPlan p;
+    p.gm = ceil_div(Cout, 128);
+    p.gn = ceil_div(9 * Cp, 128);
+    long tiles = (long)p.gm * p.gn;
+    long steps = (M + BK - 1) / BK;
+    long splits = 1;
+    if (tiles < 512) {
+        splits = (1024 + tiles - 1) / tiles;
+        long max_splits = steps / 8;        // >= 128 pixels per split
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    long steps_per = (steps + splits - 1) / splits;
+    p.pix_per_split = steps_per * BK;
+    p.splits = (int)((steps + steps_per - 1) / steps_per);
+    return p;
+}
+
+static inline int grid_for(long total, int cap = 4096) {
+    long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < cap ? b : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1) {
+    if (Cout <= 0 || C0 <= 0 || C1 < 0) return 0;
+    return (size_t)Cout * 9 * (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0));
+}
+
+int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream) {
+    MNK_REQUIRE(w && wp && Cout > 0 && C0 > 0 && C1 >= 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int C0p = round_up(C0, 16), C1p = C1 > 0 ? round_up(C1, 16) : 0;
+    const long total = (long)Cout * 9 * (C0p + C1p);
+    ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, C0, C1, C0p, C1p);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream) {
+    MNK_REQUIRE(w && wp && Cout > 0 && Cin_total > 0 && c_start >= 0 && c_count > 0 && c_start + c_count <= Cin_total);
+    hipStream_t s = (hipStream_t)stream;
+    const int Coutp = round_up(Cout, 16);
+    const long total = (long)c_count * 9 * Coutp;
+    ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, Cin_total, c_start,
+                       c_count, Coutp);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
+    Plan p = make_plan((long)N * H * W, Cout, chunks);
+    return p.splits > 1 ? (size_t)p.splits * N * H * W * p.ldw : 0;
+}
+
+int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
+                    const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
+                    int Cout, float* ws, size_t ws_floats, void* stream) {
+    MNK_REQUIRE(x0 && wp && y && N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
+    MNK_REQUIRE(ld0 % 4 == 0 && ld0 >= C0 && ld_y % 4 == 0 && ld_y >= Cout && ld_y <= round_up(Cout, 32));
+    MNK_REQUIRE(C1 == 0 || (x1 && ld1 % 4 == 0 && ld1 >= C1));
+    MNK_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0));
+    MNK_REQUIRE(!residual || (ld_res >= Cout));
+    ConvArgs a;
+    a.x0 = x0;
+    a.x1 = x1;
+    a.ld0 = ld0;
+    a.ld1 = ld1;
+    a.C0 = C0;
+    a.C1 = C1;
+    a.C0p = round_up(C0, 16);
+    a.C1p = C1 > 0 ? round_up(C1, 16) : 0;
+    a.ups = ups;
+    a.wp = wp;
+    a.bias = bias;
+    a.residual = residual;
+    a.ld_res = ld_res;
+    a.y = y;
+    a.ld_y = ld_y;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.Cout = Cout;
+    a.M = (long)N * H * W;
+    a.chunks = (a.C0p + a.C1p) / 16;
+    Plan p = make_plan(a.M, Cout, a.chunks);
+    a.ksteps = p.ksteps;
+    a.ksteps_per_split = p.ksteps_per_split;
+    a.splits = p.splits;
+    a.ws = ws;
+    a.ldw = p.ldw;
+    if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * a.M * p.ldw)) {
+        set_error("mnk_conv3x3_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * a.M * p.ldw);
+        return MNK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p.gm, p.gn, p.splits);
+    {
+        ProfScope prof(K_CONV_FWD, s, 2.0 * (double)a.M * Cout * 9.0 * (C0 + C1));
+        if (p.bn == 128)
+            hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+        else if (p.bn == 64)
+            hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
+    }
+    if (p.splits > 1) {
+        ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
+        hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * ld_y)), dim3(256), 0, s, ws, p.splits, a.M,
+                           p.ldw, bias, residual, ld_res, y, ld_y, Cout);
+    }
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return 0;
+    const int Cp = round_up(C, 16);
+    WPlan p = make_wplan((long)N * H * W, Cout, Cp);
+    return (size_t)p.splits * Cout * 9 * Cp;
+}
+
+int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
+                      int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream) {
+    MNK_REQUIRE(x && dy && dw && ws && N > 0 && H > 0 && W > 0 && C > 0 && Cout > 0);
+    MNK_REQUIRE(ld_x % 4 == 0 && ld_x >= C && ld_dy % 4 == 0 && ld_dy >= Cout);
+    MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (H % 2 == 0 && W % 2 == 0)));
+    WgradArgs a;
+    a.x = x;
+    a.ld_x = ld_x;
+    a.C = C;
+    a.Cp = round_up(C, 16);
+    a.ups = ups;
+    a.dy = dy;
+    a.ld_dy = ld_dy;
+    a.Cout = Cout;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.M = (long)N * H * W;
+    a.NT = 9 * a.Cp;
+    WPlan p = make_wplan(a.M, Cout, a.Cp);
+    a.pix_per_split = p.pix_per_split;
+    a.ws = ws;
+    if (ws_floats < (size_t)p.splits * Cout * a.NT) {
+        set_error("mnk_conv3x3_wgrad: workspace too small");
+        return MNK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope prof(K_CONV_WGRAD, s, 2.0 * (double)a.M * Cout * 9.0 * C);
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
+    }
+    {
+        ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * a.NT)), dim3(256), 0, s, ws, p.splits,
+                           Cout, C, a.Cp, dw, Cin_total, c_start);
+    }
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+}

@@ -1,0 +1,220 @@
+// Layout kernels: (B,C,D,H,W) <-> folded NHWC, channel-slice copies, 2x2 sum-pool, nearest resize.
+// All HBM-bound; one thread per pixel (or per pixel x channel-quad), coalesced along the fastest axis.
+#include "mnk_common.h"
+
+using namespace mnk;
+
+// PyTorch 'nearest' source index (upsample_nearest: floor(dst * in/out), clamped)
+__device__ __forceinline__ int nearest_src(int dst, int in_size, int out_size) {
+    float scale = (float)in_size / (float)out_size;
+    int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
+__global__ void __launch_bounds__(256) ncdhw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int B, int C, int D, int H, int W, int step, int ld) {
+    const int Ho = H / step, Wo = W / step;
+    const long total = (long)B * D * Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int wo = (int)(i % Wo);
+        long t = i / Wo;
+        int ho = (int)(t % Ho);
+        t /= Ho;
+        int d = (int)(t % D);
+        int b = (int)(t / D);
+        const float* s = src + (((long)b * C * D + d) * H + (long)ho * step) * W + (long)wo * step;
+        float* o = dst + i * ld;
+        for (int c = 0; c < C; ++c) o[c] = s[(long)c * D * H * W];
+        for (int c = C; c < ld; ++c) o[c] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_ncdhw_kernel(const float* __restrict__ src, int ld,
+                                                            float* __restrict__ dst, int B, int C, int D, int H,
+                                                            int W) {
+    const long total = (long)B * D * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int w = (int)(i % W);
+        long t = i / W;
+        int h = (int)(t % H);
+        t /= H;
+        int d = (int)(t % D);
+        int b = (int)(t / D);
+        const float* s = src + i * ld;
+        float* o = dst + (((long)b * C * D + d) * H + h) * W + w;
+        for (int c = 0; c < C; ++c) o[(long)c * D * H * W] = s[c];
+    }
+}
+
+__global__ void __launch_bounds__(256) copy_channels_kernel(const float* __restrict__ src, int ld_src, int src_off,
+                                                            float* __restrict__ dst, int ld_dst, int dst_off, int C,
+                                                            long rows, int accumulate) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C;
+        int c = (int)(i - r * C);
+        float v = src[r * ld_src + src_off + c];
+        float* o = dst + r * ld_dst + dst_off + c;
+        *o = accumulate ? *o + v : v;
+    }
+}
+
+__global__ void __launch_bounds__(256) sumpool2x2_kernel(const float* __restrict__ src, int ld_src,
+                                                         float* __restrict__ dst, int ld_dst, int N, int Hs, int Ws,
+                                                         int C) {
+    const int Hd = Hs / 2, Wd = Ws / 2;
+    const int cq = ld_dst / 4;  // ld_dst is a multiple of 4 and pad channels of src are zero
+    const long total = (long)N * Hd * Wd * cq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int q = (int)(i % cq);
+        long p = i / cq;
+        int w = (int)(p % Wd);
+        long t = p / Wd;
+        int h = (int)(t % Hd);
+        int n = (int)(t / Hd);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q * 4 < C) {
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float4 v = *reinterpret_cast<const float4*>(
+                        src + (((long)n * Hs + 2 * h + dy) * Ws + 2 * w + dx) * ld_src + q * 4);
+                    acc.x += v.x;
+                    acc.y += v.y;
+                    acc.z += v.z;
+                    acc.w += v.w;
+                }
+        }
+        *reinterpret_cast<float4*>(dst + p * ld_dst + q * 4) = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) resize_nearest_kernel(const float* __restrict__ src, int ld_src, int Hs, int Ws,
+                                                             float* __restrict__ dst, int ld_dst, int dst_off, int Hd,
+                                                             int Wd, int N, int C) {
+    const long total = (long)N * Hd * Wd * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int w = (int)(p % Wd);
+        long t = p / Wd;
+        int h = (int)(t % Hd);
+        int n = (int)(t / Hd);
+        int hs = nearest_src(h, Hs, Hd), ws = nearest_src(w, Ws, Wd);
+        dst[p * ld_dst + dst_off + c] = src[(((long)n * Hs + hs) * Ws + ws) * ld_src + c];
+    }
+}
+
+// adjoint of the gather above, written as a gather over source pixels (deterministic, no atomics):
+// each source pixel sums the destination pixels whose nearest source it is.
+__global__ void __launch_bounds__(256) resize_nearest_bwd_kernel(const float* __restrict__ ddst, int ld_dst,
+                                                                 int dst_off, int Hd, int Wd,
+                                                                 float* __restrict__ dsrc, int ld_src, int Hs, int Ws,
+                                                                 int N, int C) {
+    const long total = (long)N * Hs * Ws * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int ws = (int)(p % Ws);
+        long t = p / Ws;
+        int hs = (int)(t % Hs);
+        int n = (int)(t / Hs);
+        // candidate destination range: dst with floor(dst*Hs/Hd) == hs  (searched in a small window)
+        int h_lo = (int)((long)hs * Hd / Hs) - 1, h_hi = (int)(((long)hs + 1) * Hd / Hs) + 1;
+        int w_lo = (int)((long)ws * Wd / Ws) - 1, w_hi = (int)(((long)ws + 1) * Wd / Ws) + 1;
+        if (h_lo < 0) h_lo = 0;
+        if (w_lo < 0) w_lo = 0;
+        if (h_hi > Hd - 1) h_hi = Hd - 1;
+        if (w_hi > Wd - 1) w_hi = Wd - 1;
+        float acc = 0.f;
+        for (int h = h_lo; h <= h_hi; ++h) {
+            if (nearest_src(h, Hs, Hd) != hs) continue;
+            for (int w = w_lo; w <= w_hi; ++w) {
+                if (nearest_src(w, Ws, Wd) != ws) continue;
+                acc += ddst[(((long)n * Hd + h) * Wd + w) * ld_dst + dst_off + c];
+            }
+        }
+        dsrc[p * ld_src + c] = acc;
+    }
+}
+
+static inline int grid_for(long total, int cap = 2048) {
+    long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < cap ? b : cap);
+}
+
+extern "C" {
+
+int mnk_ncdhw_to_nhwc(const float* src, float* dst, int B, int C, int D, int H, int W, int step, int ld_dst,
+                      void* stream) {
+    MNK_REQUIRE(src && dst && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && step >= 1 && ld_dst >= C);
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)B * D * (H / step) * (W / step);
+    ProfScope prof(K_LAYOUT, s, (double)total * (C + ld_dst) * 4);
+    hipLaunchKernelGGL(ncdhw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, dst, B, C, D, H, W, step,
+                       ld_dst);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_nhwc_to_ncdhw(const float* src, int ld_src, float* dst, int B, int C, int D, int H, int W, void* stream) {
+    MNK_REQUIRE(src && dst && B > 0 && C > 0 && D > 0 && H > 0 && W > 0 && ld_src >= C);
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)B * D * H * W;
+    ProfScope prof(K_LAYOUT, s, (double)total * (C + ld_src) * 4);
+    hipLaunchKernelGGL(nhwc_to_ncdhw_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, ld_src, dst, B, C, D, H, W);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_copy_channels(const float* src, int ld_src, int src_off, float* dst, int ld_dst, int dst_off, int C,
+                      long rows, int accumulate, void* stream) {
+    MNK_REQUIRE(src && dst && C > 0 && rows > 0 && src_off >= 0 && dst_off >= 0 && src_off + C <= ld_src &&
+                dst_off + C <= ld_dst);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LAYOUT, s, (double)rows * C * 8);
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, src, ld_src, src_off, dst,
+                       ld_dst, dst_off, C, rows, accumulate);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_sumpool2x2(const float* src, int ld_src, float* dst, int ld_dst, int N, int Hs, int Ws, int C, void* stream) {
+    MNK_REQUIRE(src && dst && N > 0 && Hs > 0 && Ws > 0 && (Hs % 2) == 0 && (Ws % 2) == 0 && C > 0);
+    MNK_REQUIRE(ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= C && ld_dst >= C && ld_src >= mnk::round_up(C, 4));
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)N * (Hs / 2) * (Ws / 2) * (ld_dst / 4);
+    ProfScope prof(K_LAYOUT, s, (double)N * Hs * Ws * C * 5);
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, ld_src, dst, ld_dst, N, Hs, Ws, C);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_resize_nearest(const float* src, int ld_src, int Hs, int Ws, float* dst, int ld_dst, int dst_off, int Hd,
+                       int Wd, int N, int C, void* stream) {
+    MNK_REQUIRE(src && dst && N > 0 && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && ld_src >= C &&
+                dst_off >= 0 && dst_off + C <= ld_dst);
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)N * Hd * Wd * C;
+    ProfScope prof(K_LAYOUT, s, (double)total * 8);
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, ld_src, Hs, Ws, dst, ld_dst,
+                       dst_off, Hd, Wd, N, C);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                           int Hs, int Ws, int N, int C, void* stream) {
+    MNK_REQUIRE(ddst && dsrc && N > 0 && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && ld_src >= C &&
+                dst_off >= 0 && dst_off + C <= ld_dst);
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)N * Hs * Ws * C;
+    ProfScope prof(K_LAYOUT, s, (double)total * 8);
+    hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, ddst, ld_dst, dst_off, Hd, Wd,
+                       dsrc, ld_src, Hs, Ws, N, C);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+}

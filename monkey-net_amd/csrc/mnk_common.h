@@ -1,0 +1,85 @@
+// Shared host/device helpers for the gfx950 kernels of libmonkeynet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "monkeynet_hip.h"
+
+namespace mnk {
+
+void set_error(const char* fmt, ...);
+
+// kernel ids of the profiling recorder (mnk_prof_*)
+enum KernelId {
+    K_CONV_FWD = 0,   // conv3x3 implicit GEMM (forward and dgrad share the kernel)
+    K_CONV_WGRAD,
+    K_CONV_REDUCE,    // split-K reductions + weight packing
+    K_BN_STATS,
+    K_BN_APPLY,
+    K_BN_BWD,
+    K_LAYOUT,
+    K_KEYPOINT,
+    K_EMBED,
+    K_FIELD,
+    K_DEFORM,
+    K_CONV1X1,
+    K_NUM
+};
+
+// RAII scope: when profiling is on, brackets the launches issued inside it with two HIP events on `stream`.
+struct ProfScope {
+    ProfScope(int kid, hipStream_t stream, double work);
+    ~ProfScope();
+    int kid;
+    hipStream_t stream;
+    int slot;
+};
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace mnk
+
+#define MNK_REQUIRE(cond)                                                        \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            mnk::set_error("%s: invalid argument: %s", __func__, #cond);         \
+            return MNK_EINVAL;                                                   \
+        }                                                                        \
+    } while (0)
+
+#define MNK_LAUNCH_CHECK()                                                       \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            mnk::set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return MNK_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+// ---- device helpers -------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// sum over the 256 threads of a block; every thread gets the result.  `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}

@@ -1,0 +1,107 @@
+// Error reporting + per-kernel event timing for libmonkeynet_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "mnk_common.h"
+
+namespace mnk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static const char* kNames[K_NUM] = {"conv3x3_igemm", "conv3x3_wgrad", "conv3x3_reduce_pack", "bn_stats",
+                                    "bn_act_apply", "bn_act_bwd", "layout", "softmax_kp", "movement_embedding",
+                                    "motion_field", "deform", "conv1x1"};
+
+struct ProfRec {
+    int kid;
+    hipEvent_t a, b;
+    double work;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static uint64_t g_launches[K_NUM];
+static double g_ms[K_NUM], g_work[K_NUM];
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(int kid_, hipStream_t stream_, double work) : kid(kid_), stream(stream_), slot(-1) {
+    if (!g_prof_on) return;
+    ProfRec r{kid, get_event(), get_event(), work};
+    (void)hipEventRecord(r.a, stream);
+    g_recs.push_back(r);
+    slot = (int)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, stream);
+}
+
+static void drain() {
+    for (ProfRec& r : g_recs) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        g_launches[r.kid] += 1;
+        g_ms[r.kid] += ms;
+        g_work[r.kid] += r.work;
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+}
+
+}  // namespace mnk
+
+extern "C" {
+
+int mnk_version(void) { return 100; }
+const char* mnk_last_error(void) { return mnk::g_err; }
+int mnk_is_device_build(void) {
+#ifdef HIPEMU
+    return 0;
+#else
+    return 1;
+#endif
+}
+int mnk_prof_enable(int on) {
+    mnk::g_prof_on = on != 0;
+    return MNK_OK;
+}
+int mnk_prof_reset(void) {
+    mnk::drain();
+    for (int i = 0; i < mnk::K_NUM; ++i) {
+        mnk::g_launches[i] = 0;
+        mnk::g_ms[i] = 0;
+        mnk::g_work[i] = 0;
+    }
+    return MNK_OK;
+}
+int mnk_prof_num_kernels(void) { return mnk::K_NUM; }
+const char* mnk_prof_kernel_name(int k) { return (k >= 0 && k < mnk::K_NUM) ? mnk::kNames[k] : ""; }
+int mnk_prof_query(int k, uint64_t* launches, double* total_ms, double* total_work) {
+    MNK_REQUIRE(k >= 0 && k < mnk::K_NUM);
+    mnk::drain();
+    if (launches) *launches = mnk::g_launches[k];
+    if (total_ms) *total_ms = mnk::g_ms[k];
+    if (total_work) *total_work = mnk::g_work[k];
+    return MNK_OK;
+}
+}

@@ -1,0 +1,95 @@
+"""ctypes binding of libmonkeynet_hip.so (the C-ABI declared in include/monkeynet_hip.h).
+
+The prototypes are parsed from the header itself, so the Python side can never drift from the C-ABI.
+There is NO fallback: if the shared library is missing or fails to load, importing any op raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+HEADER = os.path.join(os.path.dirname(_PKG), "include", "monkeynet_hip.h")
+DEFAULT_LIB = os.path.join(_PKG, "libmonkeynet_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "size_t": ctypes.c_size_t, "double": ctypes.c_double,
+    "float": ctypes.c_float, "void": None, "uint64_t": ctypes.c_uint64,
+}
+
+
+def parse_header(path=HEADER):
+    """Return {name: (restype, [argtypes], [argnames])} for every function declared in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#.*", "", text)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int|size_t)\s+(mnk_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if "char" in ret else _CTYPES[ret]
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                nm = re.search(r"(\w+)$", a).group(1)
+                ty = a[: a.rfind(nm)].strip()
+                if "*" in ty:
+                    base = ty.replace("const", "").replace("*", "").strip()
+                    if base in ("uint64_t", "double") and name.startswith("mnk_prof"):
+                        argtypes.append(ctypes.POINTER(_CTYPES[base]))
+                    else:
+                        argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPES[ty.replace("const", "").strip()])
+                argnames.append(nm)
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+class MnkError(RuntimeError):
+    pass
+
+
+class Library:
+    def __init__(self, path, strict=True):
+        if not os.path.exists(path):
+            raise MnkError(
+                "libmonkeynet_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or monkey-net_amd/csrc/build.sh).  There is no CPU fallback." % path)
+        self.path = path
+        self.cdll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        for name, (restype, argtypes, _) in self.protos.items():
+            if not strict and not hasattr(self.cdll, name):
+                continue
+            fn = getattr(self.cdll, name)      # AttributeError if a declared symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+        self.is_device_build = bool(self.cdll.mnk_is_device_build())
+
+    def call(self, name, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise MnkError("%s failed (%d): %s" % (name, rc, self.cdll.mnk_last_error().decode()))
+
+    def query(self, name, *args):
+        return getattr(self.cdll, name)(*args)
+
+
+_LIB = None
+
+
+def lib():
+    """The process-wide library handle (loaded on first use)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Library(os.environ.get("MNK_LIBRARY", DEFAULT_LIB))
+    return _LIB
+
+
+def _set_library_for_tests(path, strict=True):
+    """tests/ only: bind the C-ABI of another build of the same sources (the CPU emulator build used by the
+    `-m "not gpu"` kernel tests).  Never called by the product."""
+    global _LIB
+    _LIB = Library(path, strict=strict) if path is not None else None
+    return _LIB

@@ -1,0 +1,28 @@
+"""Helpers shared by the kernel tests."""
+import torch
+
+
+def ceil4(c):
+    return (c + 3) // 4 * 4
+
+
+def to_nhwc(x4, ld=None, pad_value=0.0):
+    """(N,C,H,W) -> (N,H,W,ld) with pad channels = pad_value."""
+    n, c, h, w = x4.shape
+    ld = ld or ceil4(c)
+    out = torch.full((n, h, w, ld), pad_value, dtype=x4.dtype)
+    out[..., :c] = x4.permute(0, 2, 3, 1)
+    return out
+
+
+def from_nhwc(x, c):
+    return x[..., :c].permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def maxerr(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())

@@ -1,0 +1,83 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "monkey-net_amd")
+for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+_EMU = {}
+
+
+def emu_library_path():
+    """Build (once per session) the CPU emulation of the kernels -- tests/hipemu, test infrastructure only."""
+    if "path" not in _EMU:
+        out = subprocess.run([os.path.join(ROOT, "tests", "hipemu", "build.sh")], capture_output=True, text=True)
+        if out.returncode != 0:
+            raise RuntimeError("hipemu build failed:\n" + out.stdout + out.stderr)
+        _EMU["path"] = out.stdout.strip().splitlines()[-1]
+    return _EMU["path"]
+
+
+class Backend:
+    """Where a kernel test runs: 'emu' = kernel sources compiled for the CPU emulator (CPU tensors),
+    'hip' = the real gfx950 library on cuda:0."""
+
+    def __init__(self, kind):
+        import torch
+        from mnk import _lib
+        self.kind = kind
+        if kind == "emu":
+            self.lib = _lib._set_library_for_tests(emu_library_path(), strict=False)
+            self.device = torch.device("cpu")
+        else:
+            if not torch.cuda.is_available():
+                pytest.skip("no GPU")
+            self.lib = _lib._set_library_for_tests(None) or _lib.lib()
+            assert self.lib.is_device_build
+            self.device = torch.device("cuda:0")
+
+    def t(self, x):
+        return x.to(self.device).contiguous()
+
+    def zeros(self, *shape):
+        import torch
+        return torch.zeros(*shape, device=self.device)
+
+    def empty(self, *shape):
+        import torch
+        return torch.full(shape, float("nan"), device=self.device)
+
+    def stream(self):
+        import torch
+        return torch.cuda.current_stream().cuda_stream if self.kind == "hip" else 0
+
+    def call(self, name, *args):
+        import torch
+        conv = [a.data_ptr() if torch.is_tensor(a) else a for a in args]
+        self.lib.call(name, *conv, self.stream())
+
+    def query(self, name, *args):
+        return self.lib.query(name, *args)
+
+    def sync(self):
+        import torch
+        if self.kind == "hip":
+            torch.cuda.synchronize()
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    b = Backend(request.param)
+    yield b
+    from mnk import _lib
+    _lib._set_library_for_tests(None)

@@ -1,0 +1,166 @@
+// hipemu: a tiny single-threaded, fiber-based stand-in for <hip/hip_runtime.h>.  TEST INFRASTRUCTURE ONLY.
+//
+// The authoring container has no GPU, and GPU minutes are scarce, so the *unmodified* kernel sources under
+// monkey-net_amd/csrc are also compiled with g++ against this header (tests/hipemu/build.sh puts
+// tests/hipemu/include in front of the include path) into tests/hipemu/build/libmnk_emu.so.  The CPU-side
+// unit tests (-m "not gpu") drive that library through the same C-ABI to check indexing, tiling, MFMA
+// fragment layouts, LDS staging and barrier placement before a kernel ever reaches an MI355X.
+//
+// Execution model: the blocks of a launch run one after another; the threads of a block are ucontext fibers
+// scheduled round-robin on one OS thread.  __syncthreads() and every wave-level primitive (__shfl*, MFMA)
+// are rendez-vous points between fibers; MFMA results follow the documented gfx950 fragment layouts
+// (cdna_hip_programming.md section 3).  Nothing in the product (monkey-net_amd/) loads the emulator library:
+// the shipped path links the real HIP runtime only and fails loudly without it.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+#define ext_vector_type(n) vector_size(4 * (n))
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef struct hipemu_event* hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorLaunchFailure = 719 };
+
+namespace hipemu {
+extern dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+void sync_wave();
+unsigned lane_id();
+// exchange one 32-bit value per lane inside the calling wave; returns pointer to the 64 published values
+const uint32_t* wave_publish(uint32_t v, int slot);
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_threadIdx)
+#define blockIdx (hipemu::g_blockIdx)
+#define blockDim (hipemu::g_blockDim)
+#define gridDim (hipemu::g_gridDim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+
+static inline void __syncthreads() { hipemu::sync_block(); }
+
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) == 4, "hipemu shuffles are 32-bit");
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    unsigned l = hipemu::lane_id();
+    const uint32_t* all = hipemu::wave_publish(u, 0);
+    unsigned base = l & ~(unsigned)(width - 1);
+    uint32_t r = all[base + ((unsigned)src & (unsigned)(width - 1))];
+    T out;
+    memcpy(&out, &r, 4);
+    return out;
+}
+template <typename T>
+static inline T __shfl_xor(T v, int mask, int width = 64) {
+    return __shfl(v, (int)((hipemu::lane_id() & (unsigned)(width - 1)) ^ (unsigned)mask), width);
+}
+template <typename T>
+static inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    unsigned l = hipemu::lane_id() & (unsigned)(width - 1);
+    unsigned s = l + delta;
+    return __shfl(v, (int)(s < (unsigned)width ? s : l), width);
+}
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+
+#define __expf(x) expf(x)
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float __frcp_rn(float a) { return 1.0f / a; }
+static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
+static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline int __float2int_rd(float a) { return (int)floorf(a); }
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_barrier() { hipemu::sync_block(); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
+
+typedef float hipemu_f32x16 __attribute__((vector_size(64)));
+typedef float hipemu_f32x4 __attribute__((vector_size(16)));
+
+// v_mfma_f32_32x32x2_f32: A[i][k] from lane i+32k, B[k][j] from lane j+32k,
+// D[row][col]: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); k-ordered fmaf chain.
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+    uint32_t ua, ub;
+    memcpy(&ua, &a, 4);
+    memcpy(&ub, &b, 4);
+    unsigned l = hipemu::lane_id();
+    const uint32_t* pa = hipemu::wave_publish(ua, 1);
+    const uint32_t* pb = hipemu::wave_publish(ub, 2);
+    const float* fa = reinterpret_cast<const float*>(pa);
+    const float* fb = reinterpret_cast<const float*>(pb);
+    // wave_publish for slot 2 synchronised the wave after both values were written
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (int)(l >> 5);
+        int col = (int)(l & 31);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = fmaf(fa[row + 32 * k], fb[col + 32 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+// v_mfma_f32_16x16x4_f32: A[i][k] from lane i+16k, B[k][j] from lane j+16k,
+// D: col = lane&15, row = 4*(lane>>4) + reg.
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {
+    uint32_t ua, ub;
+    memcpy(&ua, &a, 4);
+    memcpy(&ub, &b, 4);
+    unsigned l = hipemu::lane_id();
+    const uint32_t* pa = hipemu::wave_publish(ua, 1);
+    const uint32_t* pb = hipemu::wave_publish(ub, 2);
+    const float* fa = reinterpret_cast<const float*>(pa);
+    const float* fb = reinterpret_cast<const float*>(pb);
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (int)(l >> 4) + r;
+        int col = (int)(l & 15);
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(fa[row + 16 * k], fb[col + 16 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}

@@ -1,0 +1,128 @@
+"""conv3x3 implicit-GEMM kernels (forward, dgrad via packed weights, wgrad) against torch CPU conv2d.
+The same bodies run on the CPU emulator build (-m "not gpu") and on the MI355X (-m gpu)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import to_nhwc, from_nhwc, ceil4, relerr, maxerr
+
+CASES = [
+    # N, H, W, C0, C1, Cout, ups, bias, residual
+    (2, 8, 8, 3, 0, 20, 0, True, False),
+    (1, 6, 10, 20, 13, 45, 0, True, True),      # two sources, odd channel counts, residual
+    (2, 8, 8, 16, 10, 70, 1, True, False),      # nearest x2 up-sampling on both sources, 128-wide tile
+    (3, 4, 4, 40, 0, 136, 0, False, False),     # split-K path (few tiles), two N tiles
+    (1, 2, 2, 32, 0, 10, 1, True, False),
+    (2, 1, 1, 17, 0, 33, 0, True, False),       # 1x1 spatial (moving-gif bottleneck at 64x64 input)
+]
+
+
+def _inputs(case, seed=0):
+    n, h, w, c0, c1, cout, ups, bias, res = case
+    g = torch.Generator().manual_seed(seed)
+    hs, ws = (h // 2, w // 2) if ups else (h, w)
+    x0 = torch.randn(n, c0, hs, ws, generator=g)
+    x1 = torch.randn(n, c1, hs, ws, generator=g) if c1 else None
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) if bias else None
+    r = torch.randn(n, cout, h, w, generator=g) if res else None
+    return x0, x1, wt, b, r
+
+
+def _ref_fwd(case, x0, x1, wt, b, r):
+    ups = case[6]
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    y = F.conv2d(x.double(), wt.double(), None if b is None else b.double(), padding=1)
+    if r is not None:
+        y = y + r.double()
+    return y
+
+
+def _run_fwd(be, case, x0, x1, wt, b, r):
+    n, h, w, c0, c1, cout, ups, _, _ = case
+    wp = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
+    be.call("mnk_conv3x3_pack_fwd", be.t(wt), wp, cout, c0, c1)
+    X0 = be.t(to_nhwc(x0, pad_value=float("nan")))     # pad channels must be ignored by the kernel
+    X1 = be.t(to_nhwc(x1, pad_value=float("nan"))) if x1 is not None else None
+    R = be.t(to_nhwc(r)) if r is not None else None
+    ldy = ceil4(cout)
+    Y = be.empty(n, h, w, ldy)
+    nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
+    ws = be.empty(max(nws, 1))
+    be.call("mnk_conv3x3_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if x1 is not None else 0, c1, ups, wp,
+            be.t(b) if b is not None else None, R, R.shape[-1] if r is not None else 0, Y, ldy, n, h, w, cout,
+            ws, nws)
+    be.sync()
+    return Y.cpu()
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3x3_forward(be, case):
+    x0, x1, wt, b, r = _inputs(case)
+    Y = _run_fwd(be, case, x0, x1, wt, b, r)
+    ref = _ref_fwd(case, x0, x1, wt, b, r)
+    cout = case[5]
+    assert relerr(from_nhwc(Y, cout), ref) < 2e-6
+    assert torch.all(Y[..., cout:] == 0), "pad channels of the output must be written as zero"
+
+
+@pytest.mark.parametrize("case", CASES[:4])
+def test_conv3x3_dgrad(be, case):
+    """dx = conv(dy, flipped/transposed weights): the forward kernel with mnk_conv3x3_pack_dgrad weights."""
+    n, h, w, c0, c1, cout, ups, _, _ = case
+    if ups:
+        pytest.skip("dgrad of an up-sampled input = dgrad at full resolution + mnk_sumpool2x2 (tested below)")
+    x0, x1, wt, b, r = _inputs(case)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    x = (x0 if x1 is None else torch.cat([x0, x1], 1)).double().requires_grad_(True)
+    F.conv2d(x, wt.double(), None, padding=1).backward(dy.double())
+    DY = be.t(to_nhwc(dy))
+    for c_start, c_cnt in ((0, c0),) + (((c0, c1),) if c1 else ()):
+        wp = be.empty(be.query("mnk_conv3x3_packed_floats", c_cnt, cout, 0))
+        be.call("mnk_conv3x3_pack_dgrad", be.t(wt), wp, cout, c0 + c1, c_start, c_cnt)
+        ld = ceil4(c_cnt)
+        DX = be.empty(n, h, w, ld)
+        nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, cout, 0, c_cnt)
+        ws = be.empty(max(nws, 1))
+        be.call("mnk_conv3x3_fwd", DY, DY.shape[-1], cout, None, 0, 0, 0, wp, None, None, 0, DX, ld, n, h, w, c_cnt,
+                ws, nws)
+        be.sync()
+        assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv3x3_wgrad(be, case):
+    n, h, w, c0, c1, cout, ups, _, _ = case
+    x0, x1, wt, b, r = _inputs(case)
+    g = torch.Generator().manual_seed(6)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    wd = wt.double().requires_grad_(True)
+    x = x0 if x1 is None else torch.cat([x0, x1], 1)
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    F.conv2d(x.double(), wd, None, padding=1).backward(dy.double())
+    DY = be.t(to_nhwc(dy))
+    DW = be.empty(cout, c0 + c1, 3, 3)
+    for src, c_start, c_cnt in ((x0, 0, c0),) + (((x1, c0, c1),) if c1 else ()):
+        X = be.t(to_nhwc(src, pad_value=float("nan")))
+        nws = be.query("mnk_conv3x3_wgrad_workspace_floats", n, h, w, c_cnt, cout)
+        ws = be.empty(nws)
+        be.call("mnk_conv3x3_wgrad", X, X.shape[-1], c_cnt, ups, DY, DY.shape[-1], cout, DW, c0 + c1, c_start, n, h, w,
+                ws, nws)
+    be.sync()
+    assert relerr(DW.cpu(), wd.grad) < 2e-6
+
+
+def test_sumpool2x2(be):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 5, 6, 8, generator=g)
+    X = be.t(to_nhwc(x))
+    Y = be.empty(2, 3, 4, 8)
+    be.call("mnk_sumpool2x2", X, 8, Y, 8, 2, 6, 8, 5)
+    be.sync()
+    ref = F.avg_pool2d(x, 2) * 4
+    assert maxerr(from_nhwc(Y.cpu(), 5), ref) < 1e-5
+    assert torch.all(Y.cpu()[..., 5:] == 0)
