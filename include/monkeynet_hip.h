@@ -126,11 +126,11 @@ int mnk_conv1x1_sigmoid_bwd(const float* x, int ld_x, int Cin, const float* w, c
                             float* ws, size_t ws_floats, void* stream);
 
 /* ---- heat-map -> key-point (modules/keypoint_detector.py:43-78,103-107) ---------------------------------
- * softmax over H*W of heat*inv_temperature, +1e-7, mean (x,y) and centred 2x2 covariance.
+ * softmax over H*W of heat/temperature, +1e-7, mean (x,y) and centred 2x2 covariance (K <= 16).
  * mean [N][K][2], var [N][K][4], stat [N][K][2] = (row max of the scaled logits, softmax denominator). */
-int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, float inv_temperature, float* mean,
+int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, float temperature, float* mean,
                        float* var, float* stat, void* stream);
-int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, float inv_temperature,
+int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, float temperature,
                        const float* mean, const float* stat, const float* dmean, const float* dvar, float* dheat,
                        int ld_d, void* stream);
 
@@ -147,8 +147,10 @@ int mnk_movement_embedding_fwd(const float* img, int ld_img, int Cimg, const flo
                                int K, int add_bg, int use_heatmap, int use_difference, int use_deformed,
                                int heatmap_diff, float norm_const, const float* norm_d, const float* norm_s,
                                float* out, int ld_out, void* stream);
-/* gradients w.r.t. the key-points: dmean_d/dvar_d [Nb*d][K][2|4], dmean_s/dvar_s [Nb][K][2|4] (accumulated over
- * the d frames of a batch entry).  All four outputs are overwritten. */
+/* gradients w.r.t. the key-points, one row per frame: dmean_d/dvar_d/dmean_s/dvar_s [Nb*d][K][2|4] (the caller sums
+ * the source gradients over the d frames of a batch entry).  Overwritten.  dvar_* may both be NULL (constant
+ * variance).  The gradient w.r.t. the source image is not produced: no caller of the reference consumes it
+ * (SURVEY.md section 8b "Gradients"). */
 int mnk_movement_embedding_bwd(const float* img, int ld_img, int Cimg, const float* mean_d, const float* var_d,
                                const float* mean_s, const float* var_s, float const_var, int Nb, int d, int h, int w,
                                int K, int add_bg, int use_heatmap, int use_difference, int use_deformed,

@@ -1,0 +1,565 @@
+// Heat-map <-> key-point kernels.
+//   mnk_softmax_kp_*        : KPDetector head, modules/keypoint_detector.py:43-78,103-107
+//   mnk_gaussian_sums       : 'sum' normaliser of MovementEmbeddingModule.normalize_heatmap (movement_embedding.py:33-38)
+//   mnk_movement_embedding_*: MovementEmbeddingModule.forward (movement_embedding.py:42-92) incl. kp2gaussian
+//                             (keypoint_detector.py:7-40) and the translation grid_sample (:76-87)
+// All HBM/L2-bound; spatial reductions use wavefront shuffles + one LDS hop across the 4 waves of a block.
+#include "mnk_common.h"
+
+using namespace mnk;
+
+namespace {
+
+constexpr int MAXK = 16;   // key-points per block-row handled in registers
+
+// align_corners=True grid of modules/util.py:26-42:  x_j = 2*(j/(w-1)) - 1
+__device__ __forceinline__ float grid_coord(int j, int n) { return 2.f * ((float)j / (float)(n - 1)) - 1.f; }
+
+// Block-wide sums of small per-thread register arrays.  Loops are fully unrolled with compile-time indices so
+// the arrays stay in VGPRs (runtime-indexed arrays would be demoted to scratch).
+struct BlockRed {
+    float* red;  // [4][NMAX]
+    template <int NMAX>
+    __device__ __forceinline__ void reduce(float (&v)[NMAX], int n) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+            if (k < n) {
+                float s = wave_sum(v[k]);
+                if (lane == 0) red[wave * NMAX + k] = s;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+            if (k < n) v[k] = red[k] + red[NMAX + k] + red[2 * NMAX + k] + red[3 * NMAX + k];
+    }
+    template <int NMAX>
+    __device__ __forceinline__ void reduce_max(float (&v)[NMAX], int n) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+            if (k < n) {
+                float s = wave_max(v[k]);
+                if (lane == 0) red[wave * NMAX + k] = s;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k)
+            if (k < n) v[k] = fmaxf(fmaxf(red[k], red[NMAX + k]), fmaxf(red[2 * NMAX + k], red[3 * NMAX + k]));
+    }
+};
+
+// one block per frame; all K channels of a pixel are contiguous (NHWC), so a pixel is one 16..64 B read
+__global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __restrict__ heat, int ld, int H, int W,
+                                                             int K, float temperature, float* __restrict__ mean,
+                                                             float* __restrict__ var, float* __restrict__ stat) {
+    __shared__ float red_mem[4 * MAXK];
+    BlockRed br{red_mem};
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int P = H * W;
+    const float* hp = heat + (long)n * P * ld;
+    float mx[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) mx[k] = -INFINITY;
+    for (int p = t; p < P; p += 256) {
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) mx[k] = fmaxf(mx[k], hp[(long)p * ld + k] / temperature);
+    }
+    br.reduce_max(mx, K);
+    // pass 2: S = sum e, Sx = sum e*gx, Sy = sum e*gy  (+ G = sum of grid coords for the +1e-7 term)
+    float S[MAXK], Sx[MAXK], Sy[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) S[k] = Sx[k] = Sy[k] = 0.f;
+    float gsum[2] = {0.f, 0.f};
+    for (int p = t; p < P; p += 256) {
+        const float gx = grid_coord(p % W, W), gy = grid_coord(p / W, H);
+        gsum[0] += gx;
+        gsum[1] += gy;
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) {
+                const float e = expf(hp[(long)p * ld + k] / temperature - mx[k]);
+                S[k] += e;
+                Sx[k] += e * gx;
+                Sy[k] += e * gy;
+            }
+    }
+    br.reduce(S, K);
+    br.reduce(Sx, K);
+    br.reduce(Sy, K);
+    br.reduce(gsum, 2);
+    float mux[MAXK], muy[MAXK], invS[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            invS[k] = 1.f / S[k];
+            mux[k] = Sx[k] * invS[k] + 1e-7f * gsum[0];
+            muy[k] = Sy[k] * invS[k] + 1e-7f * gsum[1];
+        }
+    // pass 3: centred second moments with weight p + 1e-7 (keypoint_detector.py:49,57-60)
+    float vxx[MAXK], vxy[MAXK], vyy[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) vxx[k] = vxy[k] = vyy[k] = 0.f;
+    for (int p = t; p < P; p += 256) {
+        const float gx = grid_coord(p % W, W), gy = grid_coord(p / W, H);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) {
+                const float wgt = expf(hp[(long)p * ld + k] / temperature - mx[k]) * invS[k] + 1e-7f;
+                const float dx = gx - mux[k], dy = gy - muy[k];
+                vxx[k] += wgt * dx * dx;
+                vxy[k] += wgt * dx * dy;
+                vyy[k] += wgt * dy * dy;
+            }
+    }
+    br.reduce(vxx, K);
+    br.reduce(vxy, K);
+    br.reduce(vyy, K);
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k) {
+            if (k >= K) continue;
+            const long o = (long)n * K + k;
+            mean[o * 2 + 0] = mux[k];
+            mean[o * 2 + 1] = muy[k];
+            var[o * 4 + 0] = vxx[k];
+            var[o * 4 + 1] = vxy[k];
+            var[o * 4 + 2] = vxy[k];
+            var[o * 4 + 3] = vyy[k];
+            stat[o * 2 + 0] = mx[k];
+            stat[o * 2 + 1] = S[k];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __restrict__ heat, int ld, int H, int W,
+                                                             int K, float temperature, const float* __restrict__ mean,
+                                                             const float* __restrict__ stat,
+                                                             const float* __restrict__ dmean,
+                                                             const float* __restrict__ dvar, float* __restrict__ dheat,
+                                                             int ld_d) {
+    __shared__ float red_mem[4 * MAXK];
+    BlockRed br{red_mem};
+    const int n = blockIdx.x, t = threadIdx.x;
+    const int P = H * W;
+    const float* hp = heat + (long)n * P * ld;
+    float mux[MAXK], muy[MAXK], mx[MAXK], invS[MAXK], gmx[MAXK], gmy[MAXK], v00[MAXK], v01[MAXK], v11[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            const long o = (long)n * K + k;
+            mux[k] = mean[o * 2];
+            muy[k] = mean[o * 2 + 1];
+            mx[k] = stat[o * 2];
+            invS[k] = 1.f / stat[o * 2 + 1];
+            const float d00 = dvar[o * 4], d01 = dvar[o * 4 + 1], d10 = dvar[o * 4 + 2], d11 = dvar[o * 4 + 3];
+            // c = sum_i w_i (g_i - mu) = -mu * P * 1e-7 (weights sum to 1 + P*1e-7); the centring of var feeds
+            // back into mean:  dmu_total = dmean - (dvar + dvar^T) c
+            const float cx = -mux[k] * (float)P * 1e-7f, cy = -muy[k] * (float)P * 1e-7f;
+            gmx[k] = dmean[o * 2] - (2.f * d00 * cx + (d01 + d10) * cy);
+            gmy[k] = dmean[o * 2 + 1] - ((d01 + d10) * cx + 2.f * d11 * cy);
+            v00[k] = d00;
+            v01[k] = d01 + d10;
+            v11[k] = d11;
+        }
+    float A[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) A[k] = 0.f;
+    for (int p = t; p < P; p += 256) {
+        const float gx = grid_coord(p % W, W), gy = grid_coord(p / W, H);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) {
+                const float s = expf(hp[(long)p * ld + k] / temperature - mx[k]) * invS[k];
+                const float dx = gx - mux[k], dy = gy - muy[k];
+                const float ai = gmx[k] * gx + gmy[k] * gy + v00[k] * dx * dx + v01[k] * dx * dy + v11[k] * dy * dy;
+                A[k] += s * ai;
+            }
+    }
+    br.reduce(A, K);
+    float* dp = dheat + (long)n * P * ld_d;
+    for (int p = t; p < P; p += 256) {
+        const float gx = grid_coord(p % W, W), gy = grid_coord(p / W, H);
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) {
+                const float s = expf(hp[(long)p * ld + k] / temperature - mx[k]) * invS[k];
+                const float dx = gx - mux[k], dy = gy - muy[k];
+                const float ai = gmx[k] * gx + gmy[k] * gy + v00[k] * dx * dx + v01[k] * dx * dy + v11[k] * dy * dy;
+                dp[(long)p * ld_d + k] = s * (ai - A[k]) / temperature;
+            }
+        for (int k = K; k < ld_d; ++k) dp[(long)p * ld_d + k] = 0.f;
+    }
+}
+
+// ---- gaussians ---------------------------------------------------------------------------------------------
+struct Gauss {
+    float mx, my, a00, a01, a10, a11;  // mean and inverse covariance
+    __device__ __forceinline__ void load(const float* mean, const float* var, float const_var, long idx) {
+        mx = mean[idx * 2];
+        my = mean[idx * 2 + 1];
+        if (var) {
+            const float a = var[idx * 4], b = var[idx * 4 + 1], c = var[idx * 4 + 2], d = var[idx * 4 + 3];
+            const float det = a * d - b * c;
+            a00 = d / det;
+            a01 = -b / det;
+            a10 = -c / det;
+            a11 = a / det;
+        } else {
+            a00 = a11 = 1.f / const_var;
+            a01 = a10 = 0.f;
+        }
+    }
+    // exp(-0.5 * d^T A d), evaluated as ((d^T A) d) like the reference's two matmuls (keypoint_detector.py:32)
+    __device__ __forceinline__ float eval(float gx, float gy, float& dx, float& dy) const {
+        dx = gx - mx;
+        dy = gy - my;
+        const float r0 = dx * a00 + dy * a10, r1 = dx * a01 + dy * a11;
+        return expf(-0.5f * (r0 * dx + r1 * dy));
+    }
+};
+
+__global__ void __launch_bounds__(256) gaussian_sums_kernel(const float* __restrict__ mean,
+                                                            const float* __restrict__ var, float const_var, int h,
+                                                            int w, float* __restrict__ sums) {
+    __shared__ float red[4];
+    Gauss g;
+    g.load(mean, var, const_var, blockIdx.x);
+    float acc = 0.f;
+    for (int p = threadIdx.x; p < h * w; p += 256) {
+        float dx, dy;
+        acc += g.eval(grid_coord(p % w, w), grid_coord(p / w, h), dx, dy);
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) sums[blockIdx.x] = acc;
+}
+
+// bilinear sample of one NHWC pixel vector at normalised (x,y): zeros padding, align_corners=True
+// (ATen grid_sampler_2d: ix = ((x+1)/2)*(W-1); weights nw,ne,sw,se)
+struct Bilin {
+    int x0, y0;
+    float wnw, wne, wsw, wse;
+    float tx, ty;   // ix - x0, iy - y0  (for the gradient)
+    __device__ __forceinline__ void setup(float x, float y, int W, int H) {
+        const float ix = ((x + 1.f) / 2.f) * (float)(W - 1), iy = ((y + 1.f) / 2.f) * (float)(H - 1);
+        const float fx = floorf(ix), fy = floorf(iy);
+        x0 = (int)fx;
+        y0 = (int)fy;
+        const float ex = fx + 1.f, ey = fy + 1.f;
+        wnw = (ex - ix) * (ey - iy);
+        wne = (ix - fx) * (ey - iy);
+        wsw = (ex - ix) * (iy - fy);
+        wse = (ix - fx) * (iy - fy);
+        tx = ix - fx;
+        ty = iy - fy;
+    }
+};
+
+struct EmbedArgs {
+    const float* img;
+    int ld_img, Cimg;
+    const float *mean_d, *var_d, *mean_s, *var_s;
+    float const_var;
+    int Nb, d, h, w, K, add_bg, use_heatmap, use_difference, use_deformed, heatmap_diff;
+    float norm_const;
+    const float *norm_d, *norm_s;
+    int slots, per;
+};
+
+__global__ void __launch_bounds__(256) movement_embedding_fwd_kernel(EmbedArgs a, float* __restrict__ out, int ld_out) {
+    const long P = (long)a.h * a.w;
+    const long total = (long)a.Nb * a.d * P * a.slots;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(i % a.slots);
+        const long fp = i / a.slots;
+        const int p = (int)(fp % P);
+        const int f = (int)(fp / P);
+        const int b = f / a.d;
+        const int k = s - a.add_bg;
+        const int px = p % a.w, py = p / a.w;
+        const float gx = grid_coord(px, a.w), gy = grid_coord(py, a.h);
+        float* o = out + fp * ld_out + s * a.per;
+        int j = 0;
+        float ddx = 0.f, ddy = 0.f;
+        if (k >= 0) {
+            ddx = a.mean_s[((long)b * a.K + k) * 2] - a.mean_d[((long)f * a.K + k) * 2];
+            ddy = a.mean_s[((long)b * a.K + k) * 2 + 1] - a.mean_d[((long)f * a.K + k) * 2 + 1];
+        }
+        if (a.use_heatmap) {
+            float hv = 0.f;
+            if (k >= 0) {
+                Gauss g;
+                float dx, dy;
+                g.load(a.mean_d, a.var_d, a.const_var, (long)f * a.K + k);
+                const float nd = a.norm_const > 0.f ? a.norm_const : a.norm_d[(long)f * a.K + k];
+                hv = g.eval(gx, gy, dx, dy) / nd;
+                if (a.heatmap_diff) {
+                    g.load(a.mean_s, a.var_s, a.const_var, (long)b * a.K + k);
+                    const float ns = a.norm_const > 0.f ? a.norm_const : a.norm_s[(long)b * a.K + k];
+                    hv -= g.eval(gx, gy, dx, dy) / ns;
+                }
+            }
+            o[j++] = hv;
+        }
+        if (a.use_difference) {
+            o[j++] = ddx;
+            o[j++] = ddy;
+        }
+        if (a.use_deformed) {
+            Bilin bl;
+            bl.setup(gx + ddx, gy + ddy, a.w, a.h);
+            const float* ib = a.img + (long)b * P * a.ld_img;
+            const bool x0ok = bl.x0 >= 0 && bl.x0 < a.w, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 < a.w;
+            const bool y0ok = bl.y0 >= 0 && bl.y0 < a.h, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 < a.h;
+            for (int c = 0; c < a.Cimg; ++c) {
+                float v = 0.f;
+                if (y0ok && x0ok) v += ib[((long)bl.y0 * a.w + bl.x0) * a.ld_img + c] * bl.wnw;
+                if (y0ok && x1ok) v += ib[((long)bl.y0 * a.w + bl.x0 + 1) * a.ld_img + c] * bl.wne;
+                if (y1ok && x0ok) v += ib[((long)(bl.y0 + 1) * a.w + bl.x0) * a.ld_img + c] * bl.wsw;
+                if (y1ok && x1ok) v += ib[((long)(bl.y0 + 1) * a.w + bl.x0 + 1) * a.ld_img + c] * bl.wse;
+                o[j++] = v;
+            }
+        }
+        if (s == 0)
+            for (int c = a.slots * a.per; c < ld_out; ++c) out[fp * ld_out + c] = 0.f;
+    }
+}
+
+// one block per (frame, key-point): reduces the pixel gradients to d mean / d var of the driving and the
+// source key-point (per frame; the caller sums the source gradients over the d frames of a batch entry)
+__global__ void __launch_bounds__(256) movement_embedding_bwd_kernel(EmbedArgs a, const float* __restrict__ dout,
+                                                                     int ld_out, float* __restrict__ dmean_d,
+                                                                     float* __restrict__ dvar_d,
+                                                                     float* __restrict__ dmean_s,
+                                                                     float* __restrict__ dvar_s) {
+    __shared__ float red_mem[4 * 14];
+    BlockRed br{red_mem};
+    const int f = blockIdx.x / a.K, k = blockIdx.x % a.K;
+    const int b = f / a.d;
+    const int s = k + a.add_bg;
+    const int P = a.h * a.w;
+    const float* gp = dout + (long)f * P * ld_out + s * a.per;
+    Gauss gd, gs;
+    gd.load(a.mean_d, a.var_d, a.const_var, (long)f * a.K + k);
+    gs.load(a.mean_s, a.var_s, a.const_var, (long)b * a.K + k);
+    const bool sum_norm = a.use_heatmap && !(a.norm_const > 0.f);
+    const float nd = sum_norm ? a.norm_d[(long)f * a.K + k] : a.norm_const;
+    const float ns = sum_norm ? (a.heatmap_diff ? a.norm_s[(long)b * a.K + k] : 1.f) : a.norm_const;
+    const float ddx = a.mean_s[((long)b * a.K + k) * 2] - a.mean_d[((long)f * a.K + k) * 2];
+    const float ddy = a.mean_s[((long)b * a.K + k) * 2 + 1] - a.mean_d[((long)f * a.K + k) * 2 + 1];
+    // 'sum' normalisation: h = e/S  =>  dL/de_p = g_p/S - (sum_r g_r e_r)/S^2
+    float T[2] = {0.f, 0.f};
+    if (sum_norm) {
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const float gx = grid_coord(p % a.w, a.w), gy = grid_coord(p / a.w, a.h);
+            float dx, dy;
+            const float g = gp[(long)p * ld_out];
+            T[0] += g * gd.eval(gx, gy, dx, dy);
+            if (a.heatmap_diff) T[1] += g * gs.eval(gx, gy, dx, dy);
+        }
+        br.reduce(T, 2);
+    }
+    // acc: 0-1 dmu_d, 2-5 GA_d, 6-7 dmu_s, 8-11 GA_s, 12-13 d(delta)
+    float acc[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) acc[i] = 0.f;
+    const int off_diff = a.use_heatmap;
+    const int off_img = a.use_heatmap + 2 * a.use_difference;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const int px = p % a.w, py = p / a.w;
+        const float gx = grid_coord(px, a.w), gy = grid_coord(py, a.h);
+        const float* g = gp + (long)p * ld_out;
+        if (a.use_heatmap) {
+            float dx, dy;
+            float e = gd.eval(gx, gy, dx, dy);
+            float ge = sum_norm ? g[0] / nd - T[0] / (nd * nd) : g[0] / nd;   // dL/de
+            float c = -0.5f * e * ge;                                          // dL/dq
+            acc[0] += -c * ((gd.a00 + gd.a00) * dx + (gd.a01 + gd.a10) * dy);
+            acc[1] += -c * ((gd.a10 + gd.a01) * dx + (gd.a11 + gd.a11) * dy);
+            acc[2] += c * dx * dx;
+            acc[3] += c * dx * dy;
+            acc[4] += c * dy * dx;
+            acc[5] += c * dy * dy;
+            if (a.heatmap_diff) {
+                e = gs.eval(gx, gy, dx, dy);
+                ge = -(sum_norm ? g[0] / ns - T[1] / (ns * ns) : g[0] / ns);
+                c = -0.5f * e * ge;
+                acc[6] += -c * ((gs.a00 + gs.a00) * dx + (gs.a01 + gs.a10) * dy);
+                acc[7] += -c * ((gs.a10 + gs.a01) * dx + (gs.a11 + gs.a11) * dy);
+                acc[8] += c * dx * dx;
+                acc[9] += c * dx * dy;
+                acc[10] += c * dy * dx;
+                acc[11] += c * dy * dy;
+            }
+        }
+        if (a.use_difference) {
+            acc[12] += g[off_diff];
+            acc[13] += g[off_diff + 1];
+        }
+        if (a.use_deformed) {
+            Bilin bl;
+            bl.setup(gx + ddx, gy + ddy, a.w, a.h);
+            const float* ib = a.img + (long)b * P * a.ld_img;
+            const bool x0ok = bl.x0 >= 0 && bl.x0 < a.w, x1ok = bl.x0 + 1 >= 0 && bl.x0 + 1 < a.w;
+            const bool y0ok = bl.y0 >= 0 && bl.y0 < a.h, y1ok = bl.y0 + 1 >= 0 && bl.y0 + 1 < a.h;
+            float gix = 0.f, giy = 0.f;
+            for (int c = 0; c < a.Cimg; ++c) {
+                const float go = g[off_img + c];
+                const float nw = (y0ok && x0ok) ? ib[((long)bl.y0 * a.w + bl.x0) * a.ld_img + c] : 0.f;
+                const float ne = (y0ok && x1ok) ? ib[((long)bl.y0 * a.w + bl.x0 + 1) * a.ld_img + c] : 0.f;
+                const float sw = (y1ok && x0ok) ? ib[((long)(bl.y0 + 1) * a.w + bl.x0) * a.ld_img + c] : 0.f;
+                const float se = (y1ok && x1ok) ? ib[((long)(bl.y0 + 1) * a.w + bl.x0 + 1) * a.ld_img + c] : 0.f;
+                gix += go * ((ne - nw) * (1.f - bl.ty) + (se - sw) * bl.ty);
+                giy += go * ((sw - nw) * (1.f - bl.tx) + (se - ne) * bl.tx);
+            }
+            acc[12] += gix * (float)(a.w - 1) * 0.5f;
+            acc[13] += giy * (float)(a.h - 1) * 0.5f;
+        }
+    }
+    br.reduce(acc, 14);
+    if (threadIdx.x == 0) {
+        const long od = (long)f * a.K + k;
+        // delta = mean_s - mean_d
+        dmean_d[od * 2] = acc[0] - acc[12];
+        dmean_d[od * 2 + 1] = acc[1] - acc[13];
+        dmean_s[od * 2] = acc[6] + acc[12];
+        dmean_s[od * 2 + 1] = acc[7] + acc[13];
+        // dSigma = -A^T G A^T
+        if (dvar_d) {
+            const Gauss* gg[2] = {&gd, &gs};
+            float* outp[2] = {dvar_d + od * 4, dvar_s + od * 4};
+            for (int w = 0; w < 2; ++w) {
+                const float* G = acc + (w == 0 ? 2 : 8);
+                const float t00 = gg[w]->a00, t01 = gg[w]->a10, t10 = gg[w]->a01, t11 = gg[w]->a11;  // A^T
+                // M = A^T G
+                const float m00 = t00 * G[0] + t01 * G[2], m01 = t00 * G[1] + t01 * G[3];
+                const float m10 = t10 * G[0] + t11 * G[2], m11 = t10 * G[1] + t11 * G[3];
+                outp[w][0] = -(m00 * t00 + m01 * t10);
+                outp[w][1] = -(m00 * t01 + m01 * t11);
+                outp[w][2] = -(m10 * t00 + m11 * t10);
+                outp[w][3] = -(m10 * t01 + m11 * t11);
+            }
+        }
+    }
+}
+
+static inline int grid_for(long total, int cap = 4096) {
+    long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < cap ? b : cap);
+}
+
+static int fill_embed_args(EmbedArgs& a, const float* img, int ld_img, int Cimg, const float* mean_d,
+                           const float* var_d, const float* mean_s, const float* var_s, float const_var, int Nb, int d,
+                           int h, int w, int K, int add_bg, int use_heatmap, int use_difference, int use_deformed,
+                           int heatmap_diff, float norm_const, const float* norm_d, const float* norm_s) {
+    a.img = img;
+    a.ld_img = ld_img;
+    a.Cimg = Cimg;
+    a.mean_d = mean_d;
+    a.var_d = var_d;
+    a.mean_s = mean_s;
+    a.var_s = var_s;
+    a.const_var = const_var;
+    a.Nb = Nb;
+    a.d = d;
+    a.h = h;
+    a.w = w;
+    a.K = K;
+    a.add_bg = add_bg ? 1 : 0;
+    a.use_heatmap = use_heatmap ? 1 : 0;
+    a.use_difference = use_difference ? 1 : 0;
+    a.use_deformed = use_deformed ? 1 : 0;
+    a.heatmap_diff = heatmap_diff ? 1 : 0;
+    a.norm_const = norm_const;
+    a.norm_d = norm_d;
+    a.norm_s = norm_s;
+    a.slots = K + a.add_bg;
+    a.per = a.use_heatmap + 2 * a.use_difference + (a.use_deformed ? Cimg : 0);
+    return a.per;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, float temperature, float* mean,
+                       float* var, float* stat, void* stream) {
+    MNK_REQUIRE(heat && mean && var && stat && N > 0 && H > 1 && W > 1 && K > 0 && K <= MAXK && ld >= K);
+    MNK_REQUIRE(temperature > 0.f);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4 * 3);
+    hipLaunchKernelGGL(softmax_kp_fwd_kernel, dim3(N), dim3(256), 0, s, heat, ld, H, W, K, temperature, mean, var, stat);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, float temperature, const float* mean,
+                       const float* stat, const float* dmean, const float* dvar, float* dheat, int ld_d, void* stream) {
+    MNK_REQUIRE(heat && mean && stat && dmean && dvar && dheat && N > 0 && H > 1 && W > 1 && K > 0 && K <= MAXK);
+    MNK_REQUIRE(ld >= K && ld_d >= K && temperature > 0.f);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4 * 3);
+    hipLaunchKernelGGL(softmax_kp_bwd_kernel, dim3(N), dim3(256), 0, s, heat, ld, H, W, K, temperature, mean, stat,
+                       dmean, dvar, dheat, ld_d);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_gaussian_sums(const float* mean, const float* var, float const_var, int Nkp, int h, int w, float* sums,
+                      void* stream) {
+    MNK_REQUIRE(mean && sums && Nkp > 0 && h > 1 && w > 1 && (var || const_var > 0.f));
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_EMBED, s, (double)Nkp * 4);
+    hipLaunchKernelGGL(gaussian_sums_kernel, dim3(Nkp), dim3(256), 0, s, mean, var, const_var, h, w, sums);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_movement_embedding_fwd(const float* img, int ld_img, int Cimg, const float* mean_d, const float* var_d,
+                               const float* mean_s, const float* var_s, float const_var, int Nb, int d, int h, int w,
+                               int K, int add_bg, int use_heatmap, int use_difference, int use_deformed,
+                               int heatmap_diff, float norm_const, const float* norm_d, const float* norm_s,
+                               float* out, int ld_out, void* stream) {
+    MNK_REQUIRE(mean_d && mean_s && out && Nb > 0 && d > 0 && h > 1 && w > 1 && K > 0);
+    MNK_REQUIRE(!use_deformed || (img && ld_img >= Cimg && Cimg > 0));
+    MNK_REQUIRE(!use_heatmap || ((var_d && var_s) || const_var > 0.f));
+    MNK_REQUIRE(!use_heatmap || norm_const > 0.f || (norm_d && (!heatmap_diff || norm_s)));
+    EmbedArgs a;
+    int per = fill_embed_args(a, img, ld_img, Cimg, mean_d, var_d, mean_s, var_s, const_var, Nb, d, h, w, K, add_bg,
+                              use_heatmap, use_difference, use_deformed, heatmap_diff, norm_const, norm_d, norm_s);
+    MNK_REQUIRE(per > 0 && ld_out >= a.slots * per);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)Nb * d * h * w * a.slots;
+    ProfScope prof(K_EMBED, s, (double)total * per * 4);
+    hipLaunchKernelGGL(movement_embedding_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, a, out, ld_out);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_movement_embedding_bwd(const float* img, int ld_img, int Cimg, const float* mean_d, const float* var_d,
+                               const float* mean_s, const float* var_s, float const_var, int Nb, int d, int h, int w,
+                               int K, int add_bg, int use_heatmap, int use_difference, int use_deformed,
+                               int heatmap_diff, float norm_const, const float* norm_d, const float* norm_s,
+                               const float* dout, int ld_out, float* dmean_d, float* dvar_d, float* dmean_s,
+                               float* dvar_s, void* stream) {
+    MNK_REQUIRE(mean_d && mean_s && dout && dmean_d && dmean_s && Nb > 0 && d > 0 && h > 1 && w > 1 && K > 0);
+    MNK_REQUIRE(!use_deformed || (img && ld_img >= Cimg && Cimg > 0));
+    MNK_REQUIRE((dvar_d == nullptr) == (dvar_s == nullptr));
+    MNK_REQUIRE(!use_heatmap || ((var_d && var_s) || const_var > 0.f));
+    MNK_REQUIRE(!use_heatmap || norm_const > 0.f || (norm_d && (!heatmap_diff || norm_s)));
+    EmbedArgs a;
+    int per = fill_embed_args(a, img, ld_img, Cimg, mean_d, var_d, mean_s, var_s, const_var, Nb, d, h, w, K, add_bg,
+                              use_heatmap, use_difference, use_deformed, heatmap_diff, norm_const, norm_d, norm_s);
+    MNK_REQUIRE(per > 0 && ld_out >= a.slots * per);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_EMBED, s, (double)Nb * d * h * w * K * per * 4);
+    hipLaunchKernelGGL(movement_embedding_bwd_kernel, dim3(Nb * d * K), dim3(256), 0, s, a, dout, ld_out, dmean_d, dvar_d,
+                       dmean_s, dvar_s);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+}

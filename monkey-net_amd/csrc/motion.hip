@@ -1,0 +1,717 @@
+// Dense-motion head, bilinear warps and the small 1x1 convolutions of the generator.
+//   mnk_gconv1x1_*          : SameBlock3D grouped 1x1 conv (modules/util.py:118; dense_motion_module.py:24-28)
+//   mnk_conv1x1_sigmoid_*   : refinement 'conv-last' + torch.sigmoid (modules/generator.py:48,79-80)
+//   mnk_motion_field_*      : mask softmax, sum_k m_k*delta_k + correction + identity grid (dense_motion_module.py:52-76)
+//   mnk_deform_*            : MotionTransferGenerator.deform_input (generator.py:51-58): field resize + grid_sample
+// All HBM-bound element-wise / small-reduction kernels.
+#include "mnk_common.h"
+
+using namespace mnk;
+
+namespace {
+
+constexpr int MAXG = 8;    // channels per group of the grouped 1x1 conv
+constexpr int MAXS = 17;   // mask slots (num_kp + 1)
+constexpr int MAXCO = 4;   // output channels of the 1x1 + sigmoid conv
+
+__device__ __forceinline__ float grid_coord(int j, int n) { return 2.f * ((float)j / (float)(n - 1)) - 1.f; }
+
+static inline int grid_for(long total, int cap = 4096) {
+    long b = (total + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < cap ? b : cap);
+}
+
+// ---- grouped 1x1 ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gconv1x1_fwd_kernel(const float* __restrict__ x, int ld_x,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ y, int ld_y, long rows, int G, int S,
+                                                           int transpose) {
+    const long total = rows * G;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % G);
+        const long r = i / G;
+        float xin[MAXG];
+#pragma unroll
+        for (int k = 0; k < MAXG; ++k) xin[k] = k < S ? x[r * ld_x + g * S + k] : 0.f;
+#pragma unroll
+        for (int o = 0; o < MAXG; ++o) {
+            if (o >= S) continue;
+            float acc = bias ? bias[g * S + o] : 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXG; ++k)
+                if (k < S) acc += xin[k] * (transpose ? w[(g * S + k) * S + o] : w[(g * S + o) * S + k]);
+            y[r * ld_y + g * S + o] = acc;
+        }
+        if (g == 0)
+            for (int c = G * S; c < ld_y; ++c) y[r * ld_y + c] = 0.f;
+    }
+}
+
+// partial[rb][g][S*S + S]: dw then dbias of one group, reduced over the block's row range
+__global__ void __launch_bounds__(256) gconv1x1_wgrad_partial_kernel(const float* __restrict__ x, int ld_x,
+                                                                     const float* __restrict__ dy, int ld_dy, long rows,
+                                                                     int G, int S, long rows_per_block,
+                                                                     float* __restrict__ partial) {
+    __shared__ float red[4 * (MAXG * MAXG + MAXG)];
+    constexpr int NV = MAXG * MAXG + MAXG;
+    const int g = blockIdx.y;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+    for (long r = r0 + threadIdx.x; r < r1; r += 256) {
+        float xi[MAXG], go[MAXG];
+#pragma unroll
+        for (int k = 0; k < MAXG; ++k) {
+            xi[k] = k < S ? x[r * ld_x + g * S + k] : 0.f;
+            go[k] = k < S ? dy[r * ld_dy + g * S + k] : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < MAXG; ++o) {
+#pragma unroll
+            for (int k = 0; k < MAXG; ++k) acc[o * MAXG + k] += go[o] * xi[k];
+            acc[MAXG * MAXG + o] += go[o];
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float s = wave_sum(acc[k]);
+        if (lane == 0) red[wave * NV + k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int k = threadIdx.x;
+        partial[((long)blockIdx.x * G + g) * NV + k] = red[k] + red[NV + k] + red[2 * NV + k] + red[3 * NV + k];
+    }
+}
+
+__global__ void __launch_bounds__(256) gconv1x1_wgrad_final_kernel(const float* __restrict__ partial, int row_blocks,
+                                                                   int G, int S, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias) {
+    constexpr int NV = MAXG * MAXG + MAXG;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_w = G * S * S, n_b = G * S;
+    if (i >= n_w + n_b) return;
+    int g, slot;
+    if (i < n_w) {
+        g = i / (S * S);
+        const int rem = i - g * S * S;
+        slot = (rem / S) * MAXG + rem % S;
+    } else {
+        const int j = i - n_w;
+        g = j / S;
+        slot = MAXG * MAXG + j % S;
+    }
+    float acc = 0.f;
+    for (int rb = 0; rb < row_blocks; ++rb) acc += partial[((long)rb * G + g) * NV + slot];
+    if (i < n_w)
+        dw[i] = acc;
+    else if (dbias)
+        dbias[i - n_w] = acc;
+}
+
+// ---- 1x1 + sigmoid ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv1x1_sigmoid_fwd_kernel(const float* __restrict__ x, int ld_x, int Cin,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ bias,
+                                                                  float* __restrict__ out, int B, int D, int H, int W,
+                                                                  int Cout) {
+    const long HW = (long)H * W;
+    const long rows = (long)B * D * HW;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        float acc[MAXCO];
+#pragma unroll
+        for (int c = 0; c < MAXCO; ++c) acc[c] = (bias && c < Cout) ? bias[c] : 0.f;
+        const float* xr = x + r * ld_x;
+        for (int k = 0; k < Cin; ++k) {
+            const float v = xr[k];
+#pragma unroll
+            for (int c = 0; c < MAXCO; ++c)
+                if (c < Cout) acc[c] = fmaf(v, w[c * Cin + k], acc[c]);
+        }
+        const long hw = r % HW;
+        const long f = r / HW;
+        const int d = (int)(f % D);
+        const long b = f / D;
+#pragma unroll
+        for (int c = 0; c < MAXCO; ++c)
+            if (c < Cout) out[((b * Cout + c) * D + d) * HW + hw] = 1.f / (1.f + expf(-acc[c]));
+    }
+}
+
+// dpre = dout * o * (1 - o); dx[r][k] = sum_c w[c][k] dpre_c
+__global__ void __launch_bounds__(256) conv1x1_sigmoid_bwd_dx_kernel(const float* __restrict__ w,
+                                                                     const float* __restrict__ out,
+                                                                     const float* __restrict__ dout,
+                                                                     float* __restrict__ dx, int ld_dx, int Cin, int B,
+                                                                     int D, int H, int W, int Cout) {
+    const long HW = (long)H * W;
+    const long rows = (long)B * D * HW;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        const long hw = r % HW;
+        const long f = r / HW;
+        const int d = (int)(f % D);
+        const long b = f / D;
+        float dp[MAXCO];
+#pragma unroll
+        for (int c = 0; c < MAXCO; ++c) {
+            dp[c] = 0.f;
+            if (c < Cout) {
+                const long o = ((b * Cout + c) * D + d) * HW + hw;
+                const float s = out[o];
+                dp[c] = dout[o] * s * (1.f - s);
+            }
+        }
+        float* xr = dx + r * ld_dx;
+        for (int k = 0; k < ld_dx; ++k) {
+            float v = 0.f;
+            if (k < Cin) {
+#pragma unroll
+                for (int c = 0; c < MAXCO; ++c)
+                    if (c < Cout) v = fmaf(dp[c], w[c * Cin + k], v);
+            }
+            xr[k] = v;
+        }
+    }
+}
+
+// partial[rb][c][Cin + 1]: dw row c then dbias, threads (tx = input channel (+1 bias column), ty = row lane)
+__global__ void __launch_bounds__(256) conv1x1_sigmoid_wgrad_partial_kernel(const float* __restrict__ x, int ld_x,
+                                                                            int Cin, const float* __restrict__ out,
+                                                                            const float* __restrict__ dout, int B, int D,
+                                                                            int H, int W, int Cout, long rows_per_block,
+                                                                            float* __restrict__ partial) {
+    __shared__ float red[MAXCO][256];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 4 row lanes
+    const long HW = (long)H * W;
+    const long rows = (long)B * D * HW;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int k0 = 0; k0 <= Cin; k0 += 64) {
+        const int k = k0 + tx;
+        float acc[MAXCO];
+#pragma unroll
+        for (int c = 0; c < MAXCO; ++c) acc[c] = 0.f;
+        if (k <= Cin) {
+            for (long r = r0 + ty; r < r1; r += 4) {
+                const float xv = k < Cin ? x[r * ld_x + k] : 1.f;
+                const long hw = r % HW;
+                const long f = r / HW;
+                const int d = (int)(f % D);
+                const long b = f / D;
+#pragma unroll
+                for (int c = 0; c < MAXCO; ++c)
+                    if (c < Cout) {
+                        const long o = ((b * Cout + c) * D + d) * HW + hw;
+                        const float s = out[o];
+                        acc[c] = fmaf(dout[o] * s * (1.f - s), xv, acc[c]);
+                    }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < MAXCO; ++c) red[c][threadIdx.x] = acc[c];
+        __syncthreads();
+        if (ty == 0 && k <= Cin) {
+#pragma unroll
+            for (int c = 0; c < MAXCO; ++c)
+                if (c < Cout)
+                    partial[((long)blockIdx.x * Cout + c) * (Cin + 1) + k] =
+                        red[c][tx] + red[c][tx + 64] + red[c][tx + 128] + red[c][tx + 192];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) conv1x1_sigmoid_wgrad_final_kernel(const float* __restrict__ partial,
+                                                                          int row_blocks, int Cin, int Cout,
+                                                                          float* __restrict__ dw,
+                                                                          float* __restrict__ dbias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * (Cin + 1)) return;
+    const int c = i / (Cin + 1), k = i - c * (Cin + 1);
+    float acc = 0.f;
+    for (int rb = 0; rb < row_blocks; ++rb) acc += partial[((long)rb * Cout + c) * (Cin + 1) + k];
+    if (k < Cin)
+        dw[c * Cin + k] = acc;
+    else if (dbias)
+        dbias[c] = acc;
+}
+
+// ---- motion field ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) motion_field_fwd_kernel(const float* __restrict__ pred, int ld,
+                                                               const float* __restrict__ delta, int N, int h, int w,
+                                                               int K, int use_mask, int use_corr,
+                                                               float* __restrict__ field) {
+    const long P = (long)h * w;
+    const long total = (long)N * P;
+    const int S = K + 1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const long n = i / P;
+        const float* pr = pred + i * ld;
+        float fx = 0.f, fy = 0.f;
+        if (use_mask) {
+            float mx = -INFINITY;
+            for (int k = 0; k < S; ++k) mx = fmaxf(mx, pr[k]);
+            float den = 0.f;
+            for (int k = 0; k < S; ++k) den += expf(pr[k] - mx);
+            for (int k = 0; k < S; ++k) {
+                const float m = expf(pr[k] - mx) / den;
+                fx += delta[(n * S + k) * 2] * m;
+                fy += delta[(n * S + k) * 2 + 1] * m;
+            }
+        }
+        if (use_corr) {
+            const int o = use_mask ? S : 0;
+            fx += pr[o];
+            fy += pr[o + 1];
+        }
+        field[i * 2] = fx + grid_coord(p % w, w);
+        field[i * 2 + 1] = fy + grid_coord(p / w, h);
+    }
+}
+
+// one block per frame: writes dpred for its pixels and reduces ddelta[n][k][2] = sum_p m_k(p) * dfield(p)
+__global__ void __launch_bounds__(256) motion_field_bwd_kernel(const float* __restrict__ pred, int ld,
+                                                               const float* __restrict__ delta,
+                                                               const float* __restrict__ dfield, int h, int w, int K,
+                                                               int use_mask, int use_corr, float* __restrict__ dpred,
+                                                               int ld_d, float* __restrict__ ddelta) {
+    __shared__ float red[4 * 2 * MAXS];
+    const int n = blockIdx.x;
+    const int P = h * w, S = K + 1;
+    float dd[2 * MAXS];
+#pragma unroll
+    for (int k = 0; k < 2 * MAXS; ++k) dd[k] = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const long i = (long)n * P + p;
+        const float* pr = pred + i * ld;
+        float* dp = dpred + i * ld_d;
+        const float gx = dfield[i * 2], gy = dfield[i * 2 + 1];
+        int o = 0;
+        if (use_mask) {
+            float mx = -INFINITY;
+            for (int k = 0; k < S; ++k) mx = fmaxf(mx, pr[k]);
+            float den = 0.f;
+            for (int k = 0; k < S; ++k) den += expf(pr[k] - mx);
+            float dot = 0.f;
+            for (int k = 0; k < S; ++k) {
+                const float m = expf(pr[k] - mx) / den;
+                dot += m * (delta[((long)n * S + k) * 2] * gx + delta[((long)n * S + k) * 2 + 1] * gy);
+            }
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k)
+                if (k < S) {
+                    const float m = expf(pr[k] - mx) / den;
+                    const float dm = delta[((long)n * S + k) * 2] * gx + delta[((long)n * S + k) * 2 + 1] * gy;
+                    dp[k] = m * (dm - dot);
+                    dd[2 * k] += m * gx;
+                    dd[2 * k + 1] += m * gy;
+                }
+            o = S;
+        }
+        if (use_corr) {
+            dp[o] = gx;
+            dp[o + 1] = gy;
+            o += 2;
+        }
+        for (int c = o; c < ld_d; ++c) dp[c] = 0.f;
+    }
+    if (use_mask) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 2 * MAXS; ++k)
+            if (k < 2 * S) {
+                float s = wave_sum(dd[k]);
+                if (lane == 0) red[wave * 2 * MAXS + k] = s;
+            }
+        __syncthreads();
+        if (threadIdx.x < 2 * S) {
+            const int k = threadIdx.x;
+            ddelta[(long)n * S * 2 + k] = red[k] + red[2 * MAXS + k] + red[4 * MAXS + k] + red[6 * MAXS + k];
+        }
+    } else if (threadIdx.x < 2 * S) {
+        ddelta[(long)n * S * 2 + threadIdx.x] = 0.f;
+    }
+}
+
+// ---- deform (field resize + bilinear grid_sample) ------------------------------------------------------------------
+__device__ __forceinline__ int nearest_src(int dst, int in_size, int out_size) {
+    float scale = (float)in_size / (float)out_size;
+    int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
+// ATen area_pixel_compute_source_index, align_corners=False: max(0, scale*(dst+0.5)-0.5)
+struct Lin1D {
+    int i0, i1;
+    float l0, l1;
+    __device__ __forceinline__ void setup(int dst, int in_size, int out_size) {
+        const float scale = (float)in_size / (float)out_size;
+        float src = scale * ((float)dst + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+        i0 = (int)src;
+        if (i0 > in_size - 1) i0 = in_size - 1;
+        i1 = i0 < in_size - 1 ? i0 + 1 : i0;
+        l1 = src - (float)i0;
+        l0 = 1.f - l1;
+    }
+};
+
+struct FieldAt {
+    float x, y;
+    // contributions of the resized field value to the original field texels (for the backward)
+    int idx[4];
+    float wgt[4];
+    int n;
+    __device__ __forceinline__ void eval(const float* __restrict__ field, long nimg, int hf, int wf, int py, int px,
+                                         int h, int w, int mode) {
+        const float* fb = field + nimg * hf * wf * 2;
+        if (mode == 0) {
+            const int ys = nearest_src(py, hf, h), xs = nearest_src(px, wf, w);
+            idx[0] = ys * wf + xs;
+            wgt[0] = 1.f;
+            n = 1;
+            x = fb[idx[0] * 2];
+            y = fb[idx[0] * 2 + 1];
+        } else {
+            Lin1D ly, lx;
+            ly.setup(py, hf, h);
+            lx.setup(px, wf, w);
+            idx[0] = ly.i0 * wf + lx.i0;
+            wgt[0] = ly.l0 * lx.l0;
+            idx[1] = ly.i0 * wf + lx.i1;
+            wgt[1] = ly.l0 * lx.l1;
+            idx[2] = ly.i1 * wf + lx.i0;
+            wgt[2] = ly.l1 * lx.l0;
+            idx[3] = ly.i1 * wf + lx.i1;
+            wgt[3] = ly.l1 * lx.l1;
+            n = 4;
+            // ATen upsample_bilinear2d: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
+            x = ly.l0 * (lx.l0 * fb[idx[0] * 2] + lx.l1 * fb[idx[1] * 2]) +
+                ly.l1 * (lx.l0 * fb[idx[2] * 2] + lx.l1 * fb[idx[3] * 2]);
+            y = ly.l0 * (lx.l0 * fb[idx[0] * 2 + 1] + lx.l1 * fb[idx[1] * 2 + 1]) +
+                ly.l1 * (lx.l0 * fb[idx[2] * 2 + 1] + lx.l1 * fb[idx[3] * 2 + 1]);
+        }
+    }
+};
+
+struct Bilin {
+    int x0, y0;
+    float wnw, wne, wsw, wse, tx, ty;
+    bool x0ok, x1ok, y0ok, y1ok;
+    __device__ __forceinline__ void setup(float x, float y, int W, int H) {
+        const float ix = ((x + 1.f) / 2.f) * (float)(W - 1), iy = ((y + 1.f) / 2.f) * (float)(H - 1);
+        const float fx = floorf(ix), fy = floorf(iy);
+        // clamp before the int conversion so that far-away / non-finite coordinates stay out of range
+        x0 = (fx >= -2.f && fx <= (float)W) ? (int)fx : -2;
+        y0 = (fy >= -2.f && fy <= (float)H) ? (int)fy : -2;
+        const float ex = fx + 1.f, ey = fy + 1.f;
+        wnw = (ex - ix) * (ey - iy);
+        wne = (ix - fx) * (ey - iy);
+        wsw = (ex - ix) * (iy - fy);
+        wse = (ix - fx) * (iy - fy);
+        tx = ix - fx;
+        ty = iy - fy;
+        x0ok = x0 >= 0 && x0 < W;
+        x1ok = x0 + 1 >= 0 && x0 + 1 < W;
+        y0ok = y0 >= 0 && y0 < H;
+        y1ok = y0 + 1 >= 0 && y0 + 1 < H;
+    }
+};
+
+__global__ void __launch_bounds__(256) deform_fwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                         const float* __restrict__ field, int hf, int wf, int mode,
+                                                         float* __restrict__ out, int ld_out, int out_off, int N) {
+    const int nq = (C + 3) / 4;
+    const long P = (long)h * w;
+    const long total = (long)N * P * nq;
+    const bool vec_store = ((out_off & 3) == 0) && ((ld_out & 3) == 0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % nq);
+        const long np = i / nq;
+        const int p = (int)(np % P);
+        const long n = np / P;
+        const int py = p / w, px = p % w;
+        FieldAt fa;
+        fa.eval(field, n, hf, wf, py, px, h, w, mode);
+        Bilin bl;
+        bl.setup(fa.x, fa.y, w, h);
+        const float* ib = inp + n * P * ld_in + q * 4;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bl.y0ok && bl.x0ok) {
+            const float4 v = *reinterpret_cast<const float4*>(ib + ((long)bl.y0 * w + bl.x0) * ld_in);
+            o.x += v.x * bl.wnw; o.y += v.y * bl.wnw; o.z += v.z * bl.wnw; o.w += v.w * bl.wnw;
+        }
+        if (bl.y0ok && bl.x1ok) {
+            const float4 v = *reinterpret_cast<const float4*>(ib + ((long)bl.y0 * w + bl.x0 + 1) * ld_in);
+            o.x += v.x * bl.wne; o.y += v.y * bl.wne; o.z += v.z * bl.wne; o.w += v.w * bl.wne;
+        }
+        if (bl.y1ok && bl.x0ok) {
+            const float4 v = *reinterpret_cast<const float4*>(ib + ((long)(bl.y0 + 1) * w + bl.x0) * ld_in);
+            o.x += v.x * bl.wsw; o.y += v.y * bl.wsw; o.z += v.z * bl.wsw; o.w += v.w * bl.wsw;
+        }
+        if (bl.y1ok && bl.x1ok) {
+            const float4 v = *reinterpret_cast<const float4*>(ib + ((long)(bl.y0 + 1) * w + bl.x0 + 1) * ld_in);
+            o.x += v.x * bl.wse; o.y += v.y * bl.wse; o.z += v.z * bl.wse; o.w += v.w * bl.wse;
+        }
+        float* op = out + np * ld_out + out_off + q * 4;
+        const int rem = C - q * 4;
+        if (vec_store && rem >= 4) {
+            *reinterpret_cast<float4*>(op) = o;
+        } else {
+            if (rem > 0) op[0] = o.x;
+            if (rem > 1) op[1] = o.y;
+            if (rem > 2) op[2] = o.z;
+            if (rem > 3) op[3] = o.w;
+        }
+    }
+}
+
+// CL lanes (power of two <= 64) cooperate on one pixel: each walks channel quads q = cl, cl+CL, ...; the
+// per-pixel sums over channels (d out / d grid) are finished with wavefront shuffles.
+__global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                         const float* __restrict__ field, int hf, int wf, int mode,
+                                                         const float* __restrict__ dout, int ld_out, int out_off,
+                                                         float* __restrict__ dinp, float* __restrict__ dfield, int N,
+                                                         int CL) {
+    const int nq = (C + 3) / 4;
+    const long P = (long)h * w;
+    const long npix = (long)N * P;
+    const int ppb = 256 / CL;   // pixels per block iteration
+    const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+    const long iters = (npix + ppb - 1) / ppb;
+    for (long it = blockIdx.x; it < iters; it += gridDim.x) {
+        const long np = it * ppb + pl;
+        const bool live = np < npix;
+        float gix = 0.f, giy = 0.f;
+        FieldAt fa;
+        fa.n = 0;
+        long n = 0;
+        if (live) {
+            const int p = (int)(np % P);
+            n = np / P;
+            fa.eval(field, n, hf, wf, p / w, p % w, h, w, mode);
+            Bilin bl;
+            bl.setup(fa.x, fa.y, w, h);
+            const float* ib = inp + n * P * ld_in;
+            float* db = dinp ? dinp + n * P * ld_in : nullptr;
+            for (int q = cl; q < nq; q += CL) {
+                const float* gp = dout + np * ld_out + out_off + q * 4;
+                const int rem = C - q * 4;
+                float go[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) go[j] = j < rem ? gp[j] : 0.f;
+                float4 nw = make_float4(0.f, 0.f, 0.f, 0.f), ne = nw, sw = nw, se = nw;
+                const long o_nw = ((long)bl.y0 * w + bl.x0) * ld_in + q * 4, o_ne = o_nw + ld_in;
+                const long o_sw = o_nw + (long)w * ld_in, o_se = o_sw + ld_in;
+                if (bl.y0ok && bl.x0ok) nw = *reinterpret_cast<const float4*>(ib + o_nw);
+                if (bl.y0ok && bl.x1ok) ne = *reinterpret_cast<const float4*>(ib + o_ne);
+                if (bl.y1ok && bl.x0ok) sw = *reinterpret_cast<const float4*>(ib + o_sw);
+                if (bl.y1ok && bl.x1ok) se = *reinterpret_cast<const float4*>(ib + o_se);
+                const float vnw[4] = {nw.x, nw.y, nw.z, nw.w}, vne[4] = {ne.x, ne.y, ne.z, ne.w};
+                const float vsw[4] = {sw.x, sw.y, sw.z, sw.w}, vse[4] = {se.x, se.y, se.z, se.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gix += go[j] * ((vne[j] - vnw[j]) * (1.f - bl.ty) + (vse[j] - vsw[j]) * bl.ty);
+                    giy += go[j] * ((vsw[j] - vnw[j]) * (1.f - bl.tx) + (vse[j] - vne[j]) * bl.tx);
+                    if (db && j < rem) {
+                        if (bl.y0ok && bl.x0ok) atomicAdd(db + o_nw + j, go[j] * bl.wnw);
+                        if (bl.y0ok && bl.x1ok) atomicAdd(db + o_ne + j, go[j] * bl.wne);
+                        if (bl.y1ok && bl.x0ok) atomicAdd(db + o_sw + j, go[j] * bl.wsw);
+                        if (bl.y1ok && bl.x1ok) atomicAdd(db + o_se + j, go[j] * bl.wse);
+                    }
+                }
+            }
+        }
+        for (int o = CL >> 1; o > 0; o >>= 1) {
+            gix += __shfl_xor(gix, o);
+            giy += __shfl_xor(giy, o);
+        }
+        if (live && cl == 0 && dfield) {
+            gix *= (float)(w - 1) * 0.5f;
+            giy *= (float)(h - 1) * 0.5f;
+            float* fb = dfield + n * hf * wf * 2;
+            for (int j = 0; j < fa.n; ++j) {
+                atomicAdd(fb + fa.idx[j] * 2, gix * fa.wgt[j]);
+                atomicAdd(fb + fa.idx[j] * 2 + 1, giy * fa.wgt[j]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mnk_gconv1x1_fwd(const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, long rows,
+                     int groups, int gsize, void* stream) {
+    MNK_REQUIRE(x && w && y && rows > 0 && groups > 0 && gsize > 0 && gsize <= MAXG);
+    MNK_REQUIRE(ld_x >= groups * gsize && ld_y >= groups * gsize);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CONV1X1, s, (double)rows * groups * gsize * 8);
+    hipLaunchKernelGGL(gconv1x1_fwd_kernel, dim3(grid_for(rows * groups)), dim3(256), 0, s, x, ld_x, w, bias, y, ld_y,
+                       rows, groups, gsize, 0);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_gconv1x1_bwd_data(const float* dy, int ld_dy, const float* w, float* dx, int ld_dx, long rows, int groups,
+                          int gsize, void* stream) {
+    MNK_REQUIRE(dy && w && dx && rows > 0 && groups > 0 && gsize > 0 && gsize <= MAXG);
+    MNK_REQUIRE(ld_dy >= groups * gsize && ld_dx >= groups * gsize);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CONV1X1, s, (double)rows * groups * gsize * 8);
+    hipLaunchKernelGGL(gconv1x1_fwd_kernel, dim3(grid_for(rows * groups)), dim3(256), 0, s, dy, ld_dy, w,
+                       (const float*)nullptr, dx, ld_dx, rows, groups, gsize, 1);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+static long gconv_rows_per_block(long rows) {
+    long rb = (rows + 2047) / 2048;
+    if (rb > 256) rb = 256;
+    if (rb < 1) rb = 1;
+    return (rows + rb - 1) / rb;
+}
+
+size_t mnk_gconv1x1_workspace_floats(long rows, int groups, int gsize) {
+    if (rows <= 0 || groups <= 0) return 0;
+    long rpb = gconv_rows_per_block(rows);
+    long rb = (rows + rpb - 1) / rpb;
+    return (size_t)rb * groups * (MAXG * MAXG + MAXG);
+}
+
+int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy, float* dw, float* dbias, long rows,
+                            int groups, int gsize, float* ws, size_t ws_floats, void* stream) {
+    MNK_REQUIRE(x && dy && dw && ws && rows > 0 && groups > 0 && gsize > 0 && gsize <= MAXG);
+    MNK_REQUIRE(ld_x >= groups * gsize && ld_dy >= groups * gsize);
+    long rpb = gconv_rows_per_block(rows);
+    int rb = (int)((rows + rpb - 1) / rpb);
+    if (ws_floats < (size_t)rb * groups * (MAXG * MAXG + MAXG)) {
+        set_error("mnk_gconv1x1_bwd_weight: workspace too small");
+        return MNK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CONV1X1, s, (double)rows * groups * gsize * 8);
+    hipLaunchKernelGGL(gconv1x1_wgrad_partial_kernel, dim3(rb, groups), dim3(256), 0, s, x, ld_x, dy, ld_dy, rows, groups,
+                       gsize, rpb, ws);
+    hipLaunchKernelGGL(gconv1x1_wgrad_final_kernel, dim3(ceil_div(groups * gsize * (gsize + 1), 256)), dim3(256), 0, s, ws,
+                       rb, groups, gsize, dw, dbias);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_conv1x1_sigmoid_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B,
+                            int D, int H, int W, int Cout, void* stream) {
+    MNK_REQUIRE(x && w && out && B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout <= MAXCO && ld_x >= Cin);
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)B * D * H * W;
+    ProfScope prof(K_CONV1X1, s, (double)rows * (Cin + Cout) * 4);
+    hipLaunchKernelGGL(conv1x1_sigmoid_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, s, x, ld_x, Cin, w, bias, out, B, D,
+                       H, W, Cout);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+static long c11_rows_per_block(long rows) {
+    long rb = (rows + 1023) / 1024;
+    if (rb > 512) rb = 512;
+    if (rb < 1) rb = 1;
+    return (rows + rb - 1) / rb;
+}
+
+size_t mnk_conv1x1_workspace_floats(long rows, int Cin, int Cout) {
+    if (rows <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    long rpb = c11_rows_per_block(rows);
+    long rb = (rows + rpb - 1) / rpb;
+    return (size_t)rb * Cout * (Cin + 1);
+}
+
+int mnk_conv1x1_sigmoid_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout,
+                            float* dx, int ld_dx, float* dw, float* dbias, int B, int D, int H, int W, int Cout,
+                            float* ws, size_t ws_floats, void* stream) {
+    MNK_REQUIRE(x && w && out && dout && dx && dw && ws && B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+    MNK_REQUIRE(Cout <= MAXCO && ld_x >= Cin && ld_dx >= Cin);
+    const long rows = (long)B * D * H * W;
+    long rpb = c11_rows_per_block(rows);
+    int rb = (int)((rows + rpb - 1) / rpb);
+    if (ws_floats < (size_t)rb * Cout * (Cin + 1)) {
+        set_error("mnk_conv1x1_sigmoid_bwd: workspace too small");
+        return MNK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CONV1X1, s, (double)rows * (2 * Cin + 2 * Cout) * 4);
+    hipLaunchKernelGGL(conv1x1_sigmoid_bwd_dx_kernel, dim3(grid_for(rows)), dim3(256), 0, s, w, out, dout, dx, ld_dx, Cin,
+                       B, D, H, W, Cout);
+    hipLaunchKernelGGL(conv1x1_sigmoid_wgrad_partial_kernel, dim3(rb), dim3(256), 0, s, x, ld_x, Cin, out, dout, B, D, H,
+                       W, Cout, rpb, ws);
+    hipLaunchKernelGGL(conv1x1_sigmoid_wgrad_final_kernel, dim3(ceil_div(Cout * (Cin + 1), 256)), dim3(256), 0, s, ws, rb,
+                       Cin, Cout, dw, dbias);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_motion_field_fwd(const float* pred, int ld, const float* delta, int N, int h, int w, int K, int use_mask,
+                         int use_correction, float* field, void* stream) {
+    MNK_REQUIRE(pred && field && N > 0 && h > 1 && w > 1 && K >= 0 && K + 1 <= MAXS);
+    MNK_REQUIRE(!use_mask || delta);
+    MNK_REQUIRE(ld >= (K + 1) * (use_mask ? 1 : 0) + 2 * (use_correction ? 1 : 0));
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * h * w;
+    ProfScope prof(K_FIELD, s, (double)total * (ld + 2) * 4);
+    hipLaunchKernelGGL(motion_field_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, pred, ld, delta, N, h, w, K,
+                       use_mask, use_correction, field);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_motion_field_bwd(const float* pred, int ld, const float* delta, const float* dfield, int N, int h, int w,
+                         int K, int use_mask, int use_correction, float* dpred, int ld_d, float* ddelta,
+                         void* stream) {
+    MNK_REQUIRE(pred && dfield && dpred && ddelta && N > 0 && h > 1 && w > 1 && K >= 0 && K + 1 <= MAXS);
+    MNK_REQUIRE(!use_mask || delta);
+    MNK_REQUIRE(ld >= (K + 1) * (use_mask ? 1 : 0) + 2 * (use_correction ? 1 : 0) && ld_d >= ld - 3);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_FIELD, s, (double)N * h * w * (ld + ld_d + 2) * 4);
+    hipLaunchKernelGGL(motion_field_bwd_kernel, dim3(N), dim3(256), 0, s, pred, ld, delta, dfield, h, w, K, use_mask,
+                       use_correction, dpred, ld_d, ddelta);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_deform_fwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
+                   float* out, int ld_out, int out_off, int N, void* stream) {
+    MNK_REQUIRE(inp && field && out && N > 0 && C > 0 && h > 0 && w > 0 && hf > 0 && wf > 0 && (mode == 0 || mode == 1));
+    MNK_REQUIRE(ld_in % 4 == 0 && ld_in >= round_up(C, 4) && out_off >= 0 && out_off + C <= ld_out);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * h * w * ((C + 3) / 4);
+    ProfScope prof(K_DEFORM, s, (double)N * h * w * C * 8);
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, inp, ld_in, C, h, w, field, hf, wf, mode,
+                       out, ld_out, out_off, N);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
+                   const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, void* stream) {
+    MNK_REQUIRE(inp && field && dout && N > 0 && C > 0 && h > 0 && w > 0 && hf > 0 && wf > 0 && (mode == 0 || mode == 1));
+    MNK_REQUIRE(ld_in % 4 == 0 && ld_in >= round_up(C, 4) && out_off >= 0 && out_off + C <= ld_out);
+    MNK_REQUIRE(dinp || dfield);
+    hipStream_t s = (hipStream_t)stream;
+    const int nq = (C + 3) / 4;
+    int CL = 1;
+    while (CL < nq && CL < 64) CL <<= 1;
+    const long iters = ((long)N * h * w + (256 / CL) - 1) / (256 / CL);
+    ProfScope prof(K_DEFORM, s, (double)N * h * w * C * 12);
+    hipLaunchKernelGGL(deform_bwd_kernel, dim3((int)(iters < 4096 ? iters : 4096)), dim3(256), 0, s, inp, ld_in, C, h, w,
+                       field, hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+}

@@ -1,0 +1,133 @@
+"""BatchNorm statistics / apply / backward kernels and the layout kernels against torch CPU ops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import to_nhwc, from_nhwc, ceil4, relerr, maxerr
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 4), (3, 45, 4, 6), (2, 300, 2, 2), (1, 64, 16, 16)])
+@pytest.mark.parametrize("pool", [0, 1])
+def test_bn_train_forward_backward(be, shape, pool):
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.3
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    # reference (fp64)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    z = F.relu(F.batch_norm(xd, rm, rv, gd, bd, True, 0.1, 1e-5))
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    dz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(dz)
+
+    ld = ceil4(c)
+    X = be.t(to_nhwc(x))
+    rows = n * h * w
+    nws = be.query("mnk_bn_workspace_floats", rows, ld)
+    ws = be.empty(nws)
+    sums = be.empty(2 * c)
+    be.call("mnk_bn_stats", X, ld, rows, c, sums, ws, nws)
+    mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+    RM, RV, G, Bt = be.t(rm0.clone()), be.t(rv0.clone()), be.t(gamma), be.t(beta)
+    be.call("mnk_bn_finalize", sums, float(rows), G, RM, RV, 0.1, 1e-5, c, 1, mean, invstd, scale)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    ldz = ld + 8
+    Z = be.zeros(n, ho, wo, ldz)
+    be.call("mnk_bn_act_fwd", X, ld, mean, scale, Bt, Z, ldz, 4, n, h, w, c, 1, pool)
+    be.sync()
+    assert maxerr(Z.cpu()[..., 4:4 + c].permute(0, 3, 1, 2), z) < 2e-5
+    assert torch.all(Z.cpu()[..., :4] == 0) and torch.all(Z.cpu()[..., 4 + c:] == 0)
+    assert maxerr(RM.cpu(), rm) < 1e-5 and maxerr(RV.cpu(), rv) < 1e-4
+    # backward
+    DZ = be.zeros(n, ho, wo, ldz)
+    DZ[..., 4:4 + c] = be.t(dz.float().permute(0, 2, 3, 1))
+    bs = be.empty(2 * c)
+    be.call("mnk_bn_act_bwd_stats", X, ld, DZ, ldz, 4, mean, invstd, scale, Bt, n, h, w, c, 1, pool, bs, ws, nws)
+    DY = be.empty(n, h, w, ld)
+    be.call("mnk_bn_act_bwd_apply", X, ld, DZ, ldz, 4, mean, invstd, scale, Bt, bs, float(rows), 1, DY, ld, n, h, w, c,
+            1, pool)
+    be.sync()
+    assert relerr(bs.cpu()[:c], bd.grad) < 1e-4
+    assert relerr(bs.cpu()[c:], gd.grad) < 1e-4
+    assert relerr(from_nhwc(DY.cpu(), c), xd.grad) < 1e-4
+    assert torch.all(DY.cpu()[..., c:] == 0)
+
+
+def test_bn_eval(be):
+    n, c, h, w = 2, 13, 4, 4
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, c, h, w, generator=g)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.2
+    ref = F.relu(F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    ld = ceil4(c)
+    X = be.t(to_nhwc(x))
+    mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+    be.call("mnk_bn_eval_coeffs", be.t(gamma), be.t(rm), be.t(rv), 1e-5, c, mean, invstd, scale)
+    Z = be.zeros(n, h, w, ld)
+    be.call("mnk_bn_act_fwd", X, ld, mean, scale, be.t(beta), Z, ld, 0, n, h, w, c, 1, 0)
+    # eval-mode backward is a per-channel scale
+    dz = torch.randn(n, c, h, w, generator=g)
+    DZ = be.t(to_nhwc(dz))
+    DY = be.empty(n, h, w, ld)
+    be.call("mnk_bn_act_bwd_apply", X, ld, DZ, ld, 0, mean, invstd, scale, be.t(beta), None, 1.0, 0, DY, ld, n, h, w, c,
+            1, 0)
+    be.sync()
+    assert maxerr(from_nhwc(Z.cpu(), c), ref) < 1e-5
+    xr = x.clone().requires_grad_(True)
+    F.relu(F.batch_norm(xr, rm, rv, gamma, beta, False, 0.1, 1e-5)).backward(dz)
+    assert maxerr(from_nhwc(DY.cpu(), c), xr.grad) < 1e-5
+
+
+def test_layout_roundtrip_and_scale(be):
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(2, 3, 2, 8, 12, generator=g)
+    for step in (1, 2, 4):
+        ho, wo = 8 // step, 12 // step
+        out = be.empty(4, ho, wo, 4)
+        be.call("mnk_ncdhw_to_nhwc", be.t(x), out, 2, 3, 2, 8, 12, step, 4)
+        be.sync()
+        ref = x[:, :, :, ::step, ::step].permute(0, 2, 3, 4, 1).reshape(4, ho, wo, 3)
+        assert torch.equal(out.cpu()[..., :3], ref) and torch.all(out.cpu()[..., 3] == 0)
+        if step > 1:
+            sf = 1.0 / step
+            ref2 = F.interpolate(x, scale_factor=(1, sf, sf))
+            assert torch.equal(ref2, x[:, :, :, ::step, ::step])
+    nh = be.empty(4, 8, 12, 4)
+    be.call("mnk_ncdhw_to_nhwc", be.t(x), nh, 2, 3, 2, 8, 12, 1, 4)
+    back = be.empty(2, 3, 2, 8, 12)
+    be.call("mnk_nhwc_to_ncdhw", nh, 4, back, 2, 3, 2, 8, 12)
+    be.sync()
+    assert torch.equal(back.cpu(), x)
+
+
+def test_copy_channels_and_resize(be):
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(2, 7, 4, 4, generator=g)
+    A = be.t(to_nhwc(a))
+    D = be.zeros(2, 4, 4, 16)
+    be.call("mnk_copy_channels", A, 8, 2, D, 16, 5, 4, 2 * 4 * 4, 0)
+    be.call("mnk_copy_channels", A, 8, 2, D, 16, 5, 4, 2 * 4 * 4, 1)
+    be.sync()
+    assert torch.allclose(D.cpu()[..., 5:9], 2 * to_nhwc(a)[..., 2:6])
+    for (hs, ws, hd, wd) in ((8, 8, 4, 4), (4, 4, 8, 8), (8, 8, 1, 1), (6, 6, 6, 6), (8, 8, 2, 2)):
+        s = torch.randn(2, 3, hs, ws, generator=g)
+        S = be.t(to_nhwc(s))
+        O = be.zeros(2, hd, wd, 8)
+        be.call("mnk_resize_nearest", S, 4, hs, ws, O, 8, 2, hd, wd, 2, 3)
+        ref = F.interpolate(s, size=(hd, wd), mode="nearest")
+        dd = torch.randn(2, 3, hd, wd, generator=g)
+        DD = be.zeros(2, hd, wd, 8)
+        DD[..., 2:5] = be.t(dd.permute(0, 2, 3, 1))
+        DS = be.empty(2, hs, ws, 4)
+        be.call("mnk_resize_nearest_bwd", DD, 8, 2, hd, wd, DS, 4, hs, ws, 2, 3)
+        be.sync()
+        assert torch.equal(O.cpu()[..., 2:5].permute(0, 3, 1, 2), ref)
+        sr = s.clone().requires_grad_(True)
+        F.interpolate(sr, size=(hd, wd), mode="nearest").backward(dd)
+        assert maxerr(DS.cpu()[..., :3].permute(0, 3, 1, 2), sr.grad) < 1e-6

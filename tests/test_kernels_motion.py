@@ -1,0 +1,146 @@
+"""Grouped 1x1 conv, 1x1+sigmoid, motion-field head and the bilinear warp kernels against torch/oracle (fp64)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import to_nhwc, from_nhwc, ceil4, relerr, maxerr
+from oracle import restate
+
+
+@pytest.mark.parametrize("G,S", [(11, 4), (5, 6), (3, 1)])
+def test_gconv1x1(be, G, S):
+    g = torch.Generator().manual_seed(0)
+    n, h, w = 2, 5, 7
+    c = G * S
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, S, 1, 1, generator=g)
+    b = torch.randn(c, generator=g)
+    xd, wd, bd = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, bd, groups=G)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    ld = ceil4(c)
+    rows = n * h * w
+    X = be.t(to_nhwc(x))
+    Y = be.empty(n, h, w, ld)
+    be.call("mnk_gconv1x1_fwd", X, ld, be.t(wt), be.t(b), Y, ld, rows, G, S)
+    DY = be.t(to_nhwc(dy.float()))
+    DX = be.empty(n, h, w, ld)
+    be.call("mnk_gconv1x1_bwd_data", DY, ld, be.t(wt), DX, ld, rows, G, S)
+    nws = be.query("mnk_gconv1x1_workspace_floats", rows, G, S)
+    ws, DW, DB = be.empty(nws), be.empty(c, S), be.empty(c)
+    be.call("mnk_gconv1x1_bwd_weight", X, ld, DY, ld, DW, DB, rows, G, S, ws, nws)
+    be.sync()
+    assert relerr(from_nhwc(Y.cpu(), c), ref) < 1e-6 and torch.all(Y.cpu()[..., c:] == 0)
+    assert relerr(from_nhwc(DX.cpu(), c), xd.grad) < 1e-6 and torch.all(DX.cpu()[..., c:] == 0)
+    assert relerr(DW.cpu().view(c, S, 1, 1), wd.grad) < 1e-5
+    assert relerr(DB.cpu(), bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,D", [(45, 3, 1), (13, 1, 2), (70, 4, 1)])
+def test_conv1x1_sigmoid(be, cin, cout, D):
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 6, 5
+    x = torch.randn(B * D, cin, H, W, generator=g)
+    wt = torch.randn(cout, cin, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    xd, wd, bd = x.double().requires_grad_(True), wt.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref4 = torch.sigmoid(F.conv2d(xd, wd.view(cout, cin, 1, 1), bd))
+    ref = restate.unfold(ref4, B)                        # (B,cout,D,H,W)
+    dout = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dout)
+    ld = ceil4(cin)
+    X = be.t(to_nhwc(x))
+    OUT = be.empty(B, cout, D, H, W)
+    be.call("mnk_conv1x1_sigmoid_fwd", X, ld, cin, be.t(wt), be.t(b), OUT, B, D, H, W, cout)
+    rows = B * D * H * W
+    nws = be.query("mnk_conv1x1_workspace_floats", rows, cin, cout)
+    ws, DX, DW, DB = be.empty(nws), be.empty(B * D, H, W, ld), be.empty(cout, cin), be.empty(cout)
+    be.call("mnk_conv1x1_sigmoid_bwd", X, ld, cin, be.t(wt), OUT, be.t(dout.float()), DX, ld, DW, DB, B, D, H, W, cout,
+            ws, nws)
+    be.sync()
+    assert maxerr(OUT.cpu(), ref) < 1e-6
+    assert relerr(from_nhwc(DX.cpu(), cin), xd.grad) < 1e-5 and torch.all(DX.cpu()[..., cin:] == 0)
+    assert relerr(DW.cpu(), wd.grad) < 1e-5 and relerr(DB.cpu(), bd.grad) < 1e-5
+
+
+@pytest.mark.parametrize("use_mask,use_corr", [(1, 1), (1, 0), (0, 1)])
+def test_motion_field(be, use_mask, use_corr):
+    g = torch.Generator().manual_seed(2)
+    n, h, w, K = 3, 6, 9, 4
+    cpred = (K + 1) * use_mask + 2 * use_corr
+    pred = torch.randn(n, cpred, h, w, generator=g) * 2
+    delta = torch.randn(n, K + 1, 2, generator=g) * 0.3
+    delta[:, 0] = 0
+    pd, dd = pred.double().requires_grad_(True), delta.double().requires_grad_(True)
+    rel = 0
+    if use_mask:
+        mask = F.softmax(pd[:, :K + 1], dim=1)
+        rel = (dd.view(n, K + 1, 2, 1, 1) * mask.unsqueeze(2)).sum(1)
+    if use_corr:
+        rel = rel + pd[:, -2:]
+    ref = rel.permute(0, 2, 3, 1) + restate.make_coordinate_grid(h, w, torch.float64).view(1, h, w, 2)
+    df = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(df)
+    ld = ceil4(cpred)
+    PR = be.t(to_nhwc(pred, pad_value=float("nan")))
+    FLD = be.empty(n, h, w, 2)
+    be.call("mnk_motion_field_fwd", PR, ld, be.t(delta), n, h, w, K, use_mask, use_corr, FLD)
+    DP, DD = be.empty(n, h, w, ld), be.empty(n, K + 1, 2)
+    be.call("mnk_motion_field_bwd", PR, ld, be.t(delta), be.t(df.float()), n, h, w, K, use_mask, use_corr, DP, ld, DD)
+    be.sync()
+    assert maxerr(FLD.cpu(), ref) < 2e-6
+    assert relerr(from_nhwc(DP.cpu(), cpred), pd.grad) < 1e-5 and torch.all(DP.cpu()[..., cpred:] == 0)
+    if use_mask:
+        assert relerr(DD.cpu(), dd.grad) < 1e-5
+
+
+DEFORM_CASES = [("same", (2, 5, 16, 16), 0), ("down", (2, 6, 4, 4), 0), ("up", (2, 3, 32, 32), 0),
+                ("one", (2, 7, 1, 1), 0), ("tri_down", (2, 6, 8, 8), 1), ("tri_up", (2, 3, 32, 32), 1),
+                ("wide", (2, 300, 4, 4), 0)]
+
+
+@pytest.mark.parametrize("tag,shape,mode", DEFORM_CASES)
+def test_deform(be, tag, shape, mode):
+    g = torch.Generator().manual_seed(3)
+    n, c, h, w = shape
+    hf = wf = 16
+    inp = torch.rand(n, c, 1, h, w, generator=g)
+    field = torch.cat([restate.make_coordinate_grid(hf, wf).view(1, 1, hf, wf, 2).repeat(n, 1, 1, 1, 1) +
+                       0.4 * torch.randn(n, 1, hf, wf, 2, generator=g), torch.zeros(n, 1, hf, wf, 1)], -1)
+    i64, f64 = inp.double().requires_grad_(True), field.double().requires_grad_(True)
+    ref = restate.deform_input(i64, f64, "nearest" if mode == 0 else "trilinear")       # (n,c,1,h,w)
+    dout = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dout)
+    ld = ceil4(c)
+    X = be.t(to_nhwc(inp[:, :, 0]))
+    FL = be.t(field[:, 0, :, :, :2])
+    ldo, off = ld + 8, 3
+    OUT = be.zeros(n, h, w, ldo)
+    be.call("mnk_deform_fwd", X, ld, c, h, w, FL, hf, wf, mode, OUT, ldo, off, n)
+    DO = be.zeros(n, h, w, ldo)
+    DO[..., off:off + c] = be.t(dout[:, :, 0].float().permute(0, 2, 3, 1))
+    DI, DF = be.zeros(n, h, w, ld), be.zeros(n, hf, wf, 2)
+    be.call("mnk_deform_bwd", X, ld, c, h, w, FL, hf, wf, mode, DO, ldo, off, DI, DF, n)
+    be.sync()
+    # white-noise image x (w-1)/2 coordinate scaling amplifies fp32 coordinate rounding to a few 1e-6
+    assert maxerr(OUT.cpu()[..., off:off + c].permute(0, 3, 1, 2), ref[:, :, 0]) < 1e-5
+    assert torch.all(OUT.cpu()[..., :off] == 0) and torch.all(OUT.cpu()[..., off + c:] == 0)
+    assert relerr(from_nhwc(DI.cpu(), c), i64.grad[:, :, 0]) < 1e-5
+    assert relerr(DF.cpu(), f64.grad[:, 0, :, :, :2]) < 1e-5
+
+
+def test_deform_matches_reference_golden(be):
+    gold = torch.load(os.path.join(os.path.dirname(__file__), "golden", "functions.pt"), weights_only=False)
+    field = gold["deform_field"]
+    for tag, mode in (("same", 0), ("down", 0), ("up", 0), ("one", 0), ("tri_down", 1), ("tri_up", 1)):
+        inp, ref = gold["deform_%s_in" % tag], gold["deform_%s_out" % tag]
+        n, c, _, h, w = inp.shape
+        ld = ceil4(c)
+        OUT = be.zeros(n, h, w, ld)
+        be.call("mnk_deform_fwd", be.t(to_nhwc(inp[:, :, 0])), ld, c, h, w, be.t(field[:, 0, :, :, :2]), 16, 16, mode,
+                OUT, ld, 0, n)
+        be.sync()
+        assert maxerr(from_nhwc(OUT.cpu(), c), ref[:, :, 0]) < 1e-5, tag
