@@ -1,0 +1,545 @@
+"""torch.autograd wrappers around the C-ABI kernels of libmonkeynet_hip.so.
+
+Internal activation format ("act"): a contiguous fp32 tensor of shape (N, H, W, ld) -- NHWC with the reference's
+time axis D folded into N (frame = b*D + d) and the channel stride `ld` rounded up to a multiple of 4 (pad channels
+are zero).  The logical channel count travels next to the tensor.  PyTorch is used for memory, streams and the
+autograd tape only; every arithmetic step is a kernel launch through `mnk._lib` (no CPU / eager fallback).
+"""
+import torch
+
+from . import _lib
+from . import dist as mdist
+
+
+def ceil4(c):
+    return (c + 3) // 4 * 4
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def _check_device(t):
+    if not t.is_cuda and _lib.lib().is_device_build:
+        raise _lib.MnkError("the MI355X hot path needs CUDA/HIP tensors; got a %s tensor (there is no CPU fallback)"
+                            % t.device)
+
+
+class _Scratch:
+    """Grow-only scratch buffers, one per (purpose, device).  All launches of this process go to one stream per
+    device, so reusing them between consecutive kernels is ordered by the stream."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, key, nfloats, like):
+        nfloats = max(int(nfloats), 1)
+        k = (key, like.device)
+        buf = self.bufs.get(k)
+        if buf is None or buf.numel() < nfloats:
+            buf = torch.empty(int(nfloats * 1.25) + 1024, dtype=torch.float32, device=like.device)
+            self.bufs[k] = buf
+        return buf
+
+
+SCRATCH = _Scratch()
+
+
+def _call(name, ref, *args):
+    _lib.lib().call(name, *args, _stream(ref))
+
+
+def _query(name, *args):
+    return _lib.lib().query(name, *args)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# layout
+# ----------------------------------------------------------------------------------------------------------------
+class ToActFn(torch.autograd.Function):
+    """(B,C,D,H,W) -> act, with the nearest down-scaling by an integer `step` (keypoint_detector.py:98-99)."""
+
+    @staticmethod
+    def forward(ctx, x5, step):
+        _check_device(x5)
+        x5 = x5.contiguous().float()
+        b, c, d, h, w = x5.shape
+        out = torch.empty(b * d, h // step, w // step, ceil4(c), dtype=torch.float32, device=x5.device)
+        _call("mnk_ncdhw_to_nhwc", x5, _p(x5), _p(out), b, c, d, h, w, step, ceil4(c))
+        ctx.meta = (b, c, d, h, w, step)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, c, d, h, w, step = ctx.meta
+        if step != 1:
+            raise NotImplementedError("gradient w.r.t. a down-scaled input image is never consumed by the reference")
+        g = g.contiguous()
+        out = torch.empty(b, c, d, h, w, dtype=torch.float32, device=g.device)
+        _call("mnk_nhwc_to_ncdhw", g, _p(g), g.shape[-1], _p(out), b, c, d, h, w)
+        return out, None
+
+
+class FromActFn(torch.autograd.Function):
+    """act -> (B,C,D,H,W)."""
+
+    @staticmethod
+    def forward(ctx, a, c, b):
+        n, h, w, ld = a.shape
+        d = n // b
+        out = torch.empty(b, c, d, h, w, dtype=torch.float32, device=a.device)
+        _call("mnk_nhwc_to_ncdhw", a, _p(a), ld, _p(out), b, c, d, h, w)
+        ctx.meta = (b, c, d, h, w, ld)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, c, d, h, w, ld = ctx.meta
+        g = g.contiguous()
+        out = torch.empty(b * d, h, w, ld, dtype=torch.float32, device=g.device)
+        _call("mnk_ncdhw_to_nhwc", g, _p(g), _p(out), b, c, d, h, w, 1, ld)
+        return out, None, None
+
+
+class Concat2Fn(torch.autograd.Function):
+    """torch.cat([a, b], dim=channel) on acts (modules/util.py:185 for the last decoder stage)."""
+
+    @staticmethod
+    def forward(ctx, a, ca, b, cb):
+        n, h, w, _ = a.shape
+        out = torch.zeros(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)
+        rows = n * h * w
+        _call("mnk_copy_channels", a, _p(a), a.shape[-1], 0, _p(out), out.shape[-1], 0, ca, rows, 0)
+        _call("mnk_copy_channels", a, _p(b), b.shape[-1], 0, _p(out), out.shape[-1], ca, cb, rows, 0)
+        ctx.meta = (ca, cb, a.shape[-1], b.shape[-1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb, lda, ldb = ctx.meta
+        g = g.contiguous()
+        n, h, w, ld = g.shape
+        rows = n * h * w
+        ga = torch.zeros(n, h, w, lda, dtype=torch.float32, device=g.device)
+        gb = torch.zeros(n, h, w, ldb, dtype=torch.float32, device=g.device)
+        _call("mnk_copy_channels", g, _p(g), ld, 0, _p(ga), lda, 0, ca, rows, 0)
+        _call("mnk_copy_channels", g, _p(g), ld, ca, _p(gb), ldb, 0, cb, rows, 0)
+        return ga, None, gb, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# 3x3 convolution
+# ----------------------------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+
+
+def _packed_fwd_weight(weight, cout, c0, c1):
+    """Packed [Cout][tap][C0p+C1p] copy of a conv weight, cached per parameter version (inference loops reuse it;
+    training re-packs once per optimiser step)."""
+    key = (id(weight), weight.device)
+    ver = weight._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[1] == (cout, c0, c1) and hit[3] is weight:
+        return hit[2]
+    n = _query("mnk_conv3x3_packed_floats", cout, c0, c1)
+    wp = torch.empty(n, dtype=torch.float32, device=weight.device)
+    _call("mnk_conv3x3_pack_fwd", weight, _p(weight), _p(wp), cout, c0, c1)
+    _PACK_CACHE[key] = (ver, (cout, c0, c1), wp, weight)
+    return wp
+
+
+def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout):
+    y = torch.empty(n, h, w, ceil4(cout), dtype=torch.float32, device=x0.device)
+    nws = _query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
+    ws = SCRATCH.get("ws", nws, x0) if nws else None
+    _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
+          int(ups), _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
+          y.shape[-1], n, h, w, cout, _p(ws), nws)
+    return y
+
+
+def channel_sums(a, c):
+    """[sum over pixels of a[..., :c], sum of squares] -> tensor (2c,)."""
+    rows = a.numel() // a.shape[-1]
+    ld = a.shape[-1]
+    nws = _query("mnk_bn_workspace_floats", rows, ld)
+    ws = SCRATCH.get("ws", nws, a)
+    sums = torch.empty(2 * c, dtype=torch.float32, device=a.device)
+    _call("mnk_bn_stats", a, _p(a), ld, rows, c, _p(sums), _p(ws), nws)
+    return sums
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """nn.Conv3d((1,3,3), padding (0,1,1)) over the channel concatenation [x0 | x1], optionally read through the
+    nearest x2 up-sampling (UpBlock3D, modules/util.py:83-85), plus bias and residual add (ResBlock3D :66-67)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, residual, c0, c1, ups):
+        _check_device(x0)
+        cout = weight.shape[0]
+        assert weight.shape[1] == c0 + c1 and weight.is_contiguous()
+        n, hs, ws_, _ = x0.shape
+        h, w = (hs * 2, ws_ * 2) if ups else (hs, ws_)
+        wp = _packed_fwd_weight(weight, cout, c0, c1)
+        y = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout)
+        ctx.save_for_backward(x0, x1, weight)
+        ctx.meta = (c0, c1, ups, cout, n, h, w, bias is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight = ctx.saved_tensors
+        c0, c1, ups, cout, n, h, w, has_bias, has_res = ctx.meta
+        dy = dy.contiguous()
+        ld_dy = dy.shape[-1]
+        cin = c0 + c1
+        grads = [None, None]
+        for i, (src, cs, cc) in enumerate(((x0, 0, c0), (x1, c0, c1))):
+            if src is None or not ctx.needs_input_grad[i]:
+                continue
+            npk = _query("mnk_conv3x3_packed_floats", cc, cout, 0)
+            wp = SCRATCH.get("pack", npk, dy)
+            _call("mnk_conv3x3_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, cs, cc)
+            dx = _conv_launch(dy, cout, None, 0, 0, wp, None, None, n, h, w, cc)
+            if ups:
+                dxs = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
+                _call("mnk_sumpool2x2", dy, _p(dx), dx.shape[-1], _p(dxs), dxs.shape[-1], n, h, w, cc)
+                dx = dxs
+            grads[i] = dx
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(weight)
+            for src, cs, cc in ((x0, 0, c0), (x1, c0, c1)):
+                if src is None:
+                    continue
+                nws = _query("mnk_conv3x3_wgrad_workspace_floats", n, h, w, cc, cout)
+                ws = SCRATCH.get("ws", nws, dy)
+                _call("mnk_conv3x3_wgrad", dy, _p(src), src.shape[-1], cc, int(ups), _p(dy), ld_dy, cout, _p(dw), cin, cs,
+                      n, h, w, _p(ws), nws)
+        db = channel_sums(dy, cout)[:cout].clone() if has_bias and ctx.needs_input_grad[3] else None
+        dres = dy if has_res and ctx.needs_input_grad[4] else None
+        return grads[0], grads[1], dw, db, dres, None, None, None
+
+
+def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None):
+    return Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# BatchNorm (+ReLU, +2x2 average pool)
+# ----------------------------------------------------------------------------------------------------------------
+class BNActFn(torch.autograd.Function):
+    """SynchronizedBatchNorm3d (sync_batchnorm/batchnorm.py:48-78) fused with the ReLU and the AvgPool3d((1,2,2))
+    that follow it in DownBlock3D / UpBlock3D / SameBlock3D / ResBlock3D (modules/util.py).  In training mode under
+    torch.distributed the sufficient statistics are all-reduced over the ranks (SyncBN over RCCL)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, c, training, relu, pool, momentum, eps):
+        _check_device(y)
+        n, h, w, ld = y.shape
+        rows = n * h * w
+        dev = y.device
+        mean = torch.empty(c, dtype=torch.float32, device=dev)
+        invstd = torch.empty_like(mean)
+        scale = torch.empty_like(mean)
+        count = float(rows)
+        if training:
+            if rows * mdist.world_size() <= 1:
+                raise ValueError("BatchNorm needs more than one value per channel in training mode "
+                                 "(sync_batchnorm/batchnorm.py:116)")
+            sums = channel_sums(y, c)
+            if mdist.active():
+                mdist.all_reduce_sum_(sums)
+                count *= mdist.world_size()
+            _call("mnk_bn_finalize", y, _p(sums), count, _p(gamma), _p(running_mean), _p(running_var), float(momentum),
+                  float(eps), c, 1, _p(mean), _p(invstd), _p(scale))
+        else:
+            _call("mnk_bn_eval_coeffs", y, _p(gamma), _p(running_mean), _p(running_var), float(eps), c, _p(mean),
+                  _p(invstd), _p(scale))
+        ho, wo = (h // 2, w // 2) if pool else (h, w)
+        z = torch.zeros(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
+        _call("mnk_bn_act_fwd", y, _p(y), ld, _p(mean), _p(scale), _p(beta), _p(z), z.shape[-1], 0, n, h, w, c, int(relu),
+              int(pool))
+        ctx.save_for_backward(y, mean, invstd, scale, beta)
+        ctx.meta = (c, training, relu, pool, count)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, mean, invstd, scale, beta = ctx.saved_tensors
+        c, training, relu, pool, count = ctx.meta
+        dz = dz.contiguous()
+        n, h, w, ld = y.shape
+        rows = n * h * w
+        nws = _query("mnk_bn_workspace_floats", rows, ceil4(c))
+        ws = SCRATCH.get("ws", nws, y)
+        sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
+        _call("mnk_bn_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta), n, h,
+              w, c, int(relu), int(pool), _p(sums), _p(ws), nws)
+        dbeta, dgamma = sums[:c].clone(), sums[c:].clone()       # local contributions (averaged later with the grads)
+        if training and mdist.active():
+            mdist.all_reduce_sum_(sums)
+        dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
+        _call("mnk_bn_act_bwd_apply", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta),
+              _p(sums), count, int(training), _p(dy), ld, n, h, w, c, int(relu), int(pool))
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def bn_act(y, c, norm, relu=True, pool=False):
+    """`norm` is a sync_batchnorm.SynchronizedBatchNorm3d parameter holder."""
+    return BNActFn.apply(y, norm.weight, norm.bias, norm.running_mean, norm.running_var, c, norm.training, relu, pool,
+                         norm.momentum, norm.eps)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# grouped 1x1 conv, 1x1 conv + sigmoid
+# ----------------------------------------------------------------------------------------------------------------
+class GConv1x1Fn(torch.autograd.Function):
+    """nn.Conv3d(kernel (1,1,1), groups=num_kp+1) of SameBlock3D (dense_motion_module.py:24-28)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups):
+        _check_device(x)
+        c = weight.shape[0]
+        s = weight.shape[1]
+        assert c == groups * s
+        n, h, w, ld = x.shape
+        y = torch.empty(n, h, w, ceil4(c), dtype=torch.float32, device=x.device)
+        _call("mnk_gconv1x1_fwd", x, _p(x), ld, _p(weight), _p(bias), _p(y), y.shape[-1], n * h * w, groups, s)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (groups, s, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        groups, s, has_bias = ctx.meta
+        dy = dy.contiguous()
+        n, h, w, ld = x.shape
+        rows = n * h * w
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _call("mnk_gconv1x1_bwd_data", dy, _p(dy), dy.shape[-1], _p(weight), _p(dx), ld, rows, groups, s)
+        dw = torch.empty_like(weight)
+        db = torch.empty(groups * s, dtype=torch.float32, device=x.device)
+        nws = _query("mnk_gconv1x1_workspace_floats", rows, groups, s)
+        ws = SCRATCH.get("ws", nws, x)
+        _call("mnk_gconv1x1_bwd_weight", x, _p(x), ld, _p(dy), dy.shape[-1], _p(dw), _p(db), rows, groups, s, _p(ws), nws)
+        return dx, dw, db if has_bias else None, None
+
+
+class Conv1x1SigmoidFn(torch.autograd.Function):
+    """refinement_module['conv-last'] + torch.sigmoid, writing (B,C,D,H,W) directly (generator.py:48,79-80)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cin, b):
+        _check_device(x)
+        n, h, w, ld = x.shape
+        d = n // b
+        cout = weight.shape[0]
+        out = torch.empty(b, cout, d, h, w, dtype=torch.float32, device=x.device)
+        _call("mnk_conv1x1_sigmoid_fwd", x, _p(x), ld, cin, _p(weight), _p(bias), _p(out), b, d, h, w, cout)
+        ctx.save_for_backward(x, weight, out)
+        ctx.meta = (cin, b, d, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        cin, b, d, has_bias = ctx.meta
+        dout = dout.contiguous()
+        n, h, w, ld = x.shape
+        cout = weight.shape[0]
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(weight)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device)
+        nws = _query("mnk_conv1x1_workspace_floats", n * h * w, cin, cout)
+        ws = SCRATCH.get("ws", nws, x)
+        _call("mnk_conv1x1_sigmoid_bwd", x, _p(x), ld, cin, _p(weight), _p(out), _p(dout), _p(dx), ld, _p(dw), _p(db), b, d,
+              h, w, cout, _p(ws), nws)
+        return dx, dw, db if has_bias else None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# key-points
+# ----------------------------------------------------------------------------------------------------------------
+class SoftmaxKPFn(torch.autograd.Function):
+    """F.softmax(heatmap / T over H*W) + gaussian2kp 'matrix' (keypoint_detector.py:43-60,103-107)."""
+
+    @staticmethod
+    def forward(ctx, heat, k, temperature):
+        _check_device(heat)
+        n, h, w, ld = heat.shape
+        dev = heat.device
+        mean = torch.empty(n, k, 2, dtype=torch.float32, device=dev)
+        var = torch.empty(n, k, 2, 2, dtype=torch.float32, device=dev)
+        stat = torch.empty(n, k, 2, dtype=torch.float32, device=dev)
+        _call("mnk_softmax_kp_fwd", heat, _p(heat), ld, n, h, w, k, float(temperature), _p(mean), _p(var), _p(stat))
+        ctx.save_for_backward(heat, mean, stat)
+        ctx.meta = (k, float(temperature))
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, dmean, dvar):
+        heat, mean, stat = ctx.saved_tensors
+        k, temperature = ctx.meta
+        n, h, w, ld = heat.shape
+        dmean = dmean.contiguous() if dmean is not None else torch.zeros_like(mean)
+        dvar = dvar.contiguous() if dvar is not None else torch.zeros(n, k, 2, 2, dtype=torch.float32, device=heat.device)
+        dheat = torch.empty_like(heat)
+        _call("mnk_softmax_kp_bwd", heat, _p(heat), ld, n, h, w, k, temperature, _p(mean), _p(stat), _p(dmean), _p(dvar),
+              _p(dheat), ld)
+        return dheat, None, None
+
+
+class MovementEmbeddingFn(torch.autograd.Function):
+    """MovementEmbeddingModule.forward (movement_embedding.py:42-92) -> act with kp-major channel order."""
+
+    @staticmethod
+    def forward(ctx, img, mean_d, var_d, mean_s, var_s, cfg):
+        (b, d, h, w, k, cimg, add_bg, use_heatmap, use_difference, use_deformed, heatmap_diff, norm_const,
+         const_var) = cfg
+        ref = mean_d
+        _check_device(ref)
+        dev = ref.device
+        mean_d = mean_d.contiguous().float()
+        mean_s = mean_s.contiguous().float()
+        var_d = var_d.contiguous().float() if var_d is not None else None
+        var_s = var_s.contiguous().float() if var_s is not None else None
+        slots = k + int(add_bg)
+        per = int(use_heatmap) + 2 * int(use_difference) + (cimg if use_deformed else 0)
+        ld_out = ceil4(slots * per)
+        norm_d = norm_s = None
+        norm_c = float(norm_const) if norm_const != "sum" else 0.0
+        if norm_const == "sum" and use_heatmap:
+            norm_d = torch.empty(b * d * k, dtype=torch.float32, device=dev)
+            norm_s = torch.empty(b * k, dtype=torch.float32, device=dev)
+            _call("mnk_gaussian_sums", ref, _p(mean_d), _p(var_d), const_var, b * d * k, h, w, _p(norm_d))
+            _call("mnk_gaussian_sums", ref, _p(mean_s), _p(var_s), const_var, b * k, h, w, _p(norm_s))
+        out = torch.empty(b * d, h, w, ld_out, dtype=torch.float32, device=dev)
+        args = (_p(img), img.shape[-1] if img is not None else 0, cimg, _p(mean_d), _p(var_d), _p(mean_s), _p(var_s),
+                float(const_var), b, d, h, w, k, int(add_bg), int(use_heatmap), int(use_difference), int(use_deformed),
+                int(heatmap_diff), norm_c, _p(norm_d), _p(norm_s))
+        _call("mnk_movement_embedding_fwd", ref, *args, _p(out), ld_out)
+        ctx.save_for_backward(img, mean_d, var_d, mean_s, var_s, norm_d, norm_s)
+        ctx.cfg = cfg
+        ctx.norm_c = norm_c
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, mean_d, var_d, mean_s, var_s, norm_d, norm_s = ctx.saved_tensors
+        (b, d, h, w, k, cimg, add_bg, use_heatmap, use_difference, use_deformed, heatmap_diff, norm_const,
+         const_var) = ctx.cfg
+        dout = dout.contiguous()
+        dev = dout.device
+        gmd = torch.empty(b * d, k, 2, dtype=torch.float32, device=dev)
+        gms = torch.empty(b * d, k, 2, dtype=torch.float32, device=dev)
+        gvd = gvs = None
+        if var_d is not None:
+            gvd = torch.empty(b * d, k, 4, dtype=torch.float32, device=dev)
+            gvs = torch.empty(b * d, k, 4, dtype=torch.float32, device=dev)
+        args = (_p(img), img.shape[-1] if img is not None else 0, cimg, _p(mean_d), _p(var_d), _p(mean_s), _p(var_s),
+                float(const_var), b, d, h, w, k, int(add_bg), int(use_heatmap), int(use_difference), int(use_deformed),
+                int(heatmap_diff), ctx.norm_c, _p(norm_d), _p(norm_s))
+        _call("mnk_movement_embedding_bwd", dout, *args, _p(dout), dout.shape[-1], _p(gmd), _p(gvd), _p(gms), _p(gvs))
+        g_mean_d = gmd.view(b, d, k, 2)
+        g_mean_s = gms.view(b, d, k, 2).sum(dim=1, keepdim=True) if d > 1 else gms.view(b, 1, k, 2)
+        g_var_d = g_var_s = None
+        if gvd is not None:
+            g_var_d = gvd.view(b, d, k, 2, 2)
+            g_var_s = gvs.view(b, d, k, 2, 2).sum(dim=1, keepdim=True) if d > 1 else gvs.view(b, 1, k, 2, 2)
+            if not use_heatmap:
+                g_var_d = g_var_s = None
+        return None, g_mean_d, g_var_d, g_mean_s, g_var_s, None
+
+
+class MotionFieldFn(torch.autograd.Function):
+    """mask softmax, sum_k m_k * delta_k + correction + identity grid (dense_motion_module.py:52-73) -> (N,h,w,2)."""
+
+    @staticmethod
+    def forward(ctx, pred, delta, k, use_mask, use_corr):
+        _check_device(pred)
+        n, h, w, ld = pred.shape
+        delta = delta.contiguous().float() if delta is not None else None
+        field = torch.empty(n, h, w, 2, dtype=torch.float32, device=pred.device)
+        _call("mnk_motion_field_fwd", pred, _p(pred), ld, _p(delta), n, h, w, k, int(use_mask), int(use_corr), _p(field))
+        ctx.save_for_backward(pred, delta)
+        ctx.meta = (k, use_mask, use_corr)
+        return field
+
+    @staticmethod
+    def backward(ctx, dfield):
+        pred, delta = ctx.saved_tensors
+        k, use_mask, use_corr = ctx.meta
+        n, h, w, ld = pred.shape
+        dfield = dfield.contiguous()
+        dpred = torch.empty_like(pred)
+        ddelta = torch.empty(n, k + 1, 2, dtype=torch.float32, device=pred.device)
+        _call("mnk_motion_field_bwd", pred, _p(pred), ld, _p(delta), _p(dfield), n, h, w, k, int(use_mask), int(use_corr),
+              _p(dpred), ld, _p(ddelta))
+        return dpred, (ddelta if delta is not None else None), None, None, None
+
+
+class WarpSkipFn(torch.autograd.Function):
+    """deform_input (generator.py:51-58) of one skip tensor, with the nearest-resized key-point embedding written
+    behind it in the same buffer (generator.py:72-73): out = [warp(inp, field) | resize(emb)]."""
+
+    @staticmethod
+    def forward(ctx, inp, field, emb, c, ke, mode):
+        _check_device(inp)
+        n, h, w, ld_in = inp.shape
+        _, hf, wf, _ = field.shape
+        out = torch.zeros(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
+        _call("mnk_deform_fwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(out), out.shape[-1], 0, n)
+        if emb is not None:
+            if mode != 0:
+                raise NotImplementedError("interpolation_mode='trilinear' for the key-point embedding resize "
+                                          "(vox configs) is not built yet")
+            _call("mnk_resize_nearest", inp, _p(emb), emb.shape[-1], emb.shape[1], emb.shape[2], _p(out), out.shape[-1], c,
+                  h, w, n, ke)
+        ctx.save_for_backward(inp, field, emb)
+        ctx.meta = (c, ke, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inp, field, emb = ctx.saved_tensors
+        c, ke, mode = ctx.meta
+        dout = dout.contiguous()
+        n, h, w, ld_in = inp.shape
+        _, hf, wf, _ = field.shape
+        dinp = torch.zeros_like(inp) if ctx.needs_input_grad[0] else None
+        dfield = torch.zeros_like(field) if ctx.needs_input_grad[1] else None
+        if dinp is not None or dfield is not None:
+            _call("mnk_deform_bwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(dout), dout.shape[-1], 0,
+                  _p(dinp), _p(dfield), n)
+        demb = None
+        if emb is not None and ctx.needs_input_grad[2]:
+            demb = torch.zeros_like(emb)
+            _call("mnk_resize_nearest_bwd", inp, _p(dout), dout.shape[-1], c, h, w, _p(demb), emb.shape[-1], emb.shape[1],
+                  emb.shape[2], n, ke)
+        return dinp, dfield, demb, None, None, None
+
+
+# convenience wrappers ---------------------------------------------------------------------------------------------
+def to_act(x5, step=1):
+    return ToActFn.apply(x5, int(step))
+
+
+def from_act(a, c, b):
+    return FromActFn.apply(a, c, b)
+
+
+def step_from_scale(scale_factor):
+    if scale_factor == 1:
+        return 1
+    step = int(round(1.0 / scale_factor))
+    if abs(step * scale_factor - 1.0) > 1e-6:
+        raise NotImplementedError("only scale factors 1/integer are used by the reference configs; got %r" % scale_factor)
+    return step
