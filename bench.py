@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Benchmark of the Monkey-Net frame-generation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+A "step" is one full training iteration of train.py:110-136 on one synthetic batch: KPDetector (source + driving
+frame) -> generator -> discriminator x2 -> losses -> backward -> Adam (generator, kp detector), then the
+discriminator update.  KPDetector / DenseMotionModule / generator forward+backward run on the hand-written gfx950
+kernels (libmonkeynet_hip.so); the discriminator, the losses and Adam are stock PyTorch-ROCm ops (SURVEY.md
+section 8f, "next" rows).  Data: synthetic U[0,1) frame pairs (BASELINE.md section 2 protocol), random-init
+weights of the named configuration; inputs are resident in HBM before the timed region.
+
+One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one generated driving frame = one
+(source, driving) pair), whole-job aggregate over all ranks (weak scaling: fixed per-GPU batch), plus
+  roofline      -- the conv3x3 implicit-GEMM kernel (forward + dgrad launches): algorithmic FLOPs (2*MAC of the
+                   true, un-padded convolution) / HIP-event time measured on the launch stream in a separate
+                   profiled step, against the 157.3 TFLOP/s fp32-MFMA peak of MI355X_MICROARCH.md;
+  cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
+                   host's cores on a bounded sample of the same workload (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "monkey-net_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="moving-gif", help="moving-gif (BASELINE configs[1]) | taichi | shapes")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def build_models(cfg, device):
+    from modules.generator import MotionTransferGenerator
+    from modules.discriminator import Discriminator
+    from modules.keypoint_detector import KPDetector
+    mp = cfg["model_params"]
+    torch.manual_seed(0)
+    gen = MotionTransferGenerator(**mp["generator_params"], **mp["common_params"])
+    disc = Discriminator(**mp["discriminator_params"], **mp["common_params"])
+    kpd = KPDetector(**mp["kp_detector_params"], **mp["common_params"])
+    return gen.to(device), disc.to(device), kpd.to(device)
+
+
+def cpu_baseline(cfg, batch, size, steps):
+    """The oracle restatement (torch CPU, fp32) doing the same training iteration: forward through
+    restate.generator_full_forward / discriminator_full_forward, backward, 3x Adam."""
+    from oracle import restate, cases
+    from modules.generator import MotionTransferGenerator
+    from modules.discriminator import Discriminator
+    from modules.keypoint_detector import KPDetector
+    mp, tp = cfg["model_params"], cfg["train_params"]
+    torch.manual_seed(0)
+    mods = {"generator": MotionTransferGenerator(**mp["generator_params"], **mp["common_params"]),
+            "discriminator": Discriminator(**mp["discriminator_params"], **mp["common_params"]),
+            "kp_detector": KPDetector(**mp["kp_detector_params"], **mp["common_params"])}
+    # only the parameter containers are used here -- the arithmetic below is the oracle's
+    sds = {k: {n: t.detach().clone().requires_grad_(t.is_floating_point() and "running" not in n)
+               for n, t in m.state_dict().items()} for k, m in mods.items()}
+    params = {k: [t for t in sd.values() if t.requires_grad] for k, sd in sds.items()}
+    opts = {k: torch.optim.Adam(p, lr=tp["lr"], betas=(0.5, 0.999)) for k, p in params.items()}
+    src, drv = cases.synthetic_pair(batch, size, size)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one():
+        losses, generated, kp_joined, ctx_g, ctx_k = restate.generator_full_forward(sds, cfg, src, drv)
+        sum(v.mean() for v in losses).backward()
+        opts["generator"].step(), opts["generator"].zero_grad(), opts["discriminator"].zero_grad()
+        opts["kp_detector"].step(), opts["kp_detector"].zero_grad()
+        with torch.no_grad():
+            for ctx, key in ((ctx_g, "generator"), (ctx_k, "kp_detector")):
+                for n, v in ctx.new_stats.items():
+                    sds[key][n].copy_(v)
+        dl = restate.discriminator_full_forward(sds, cfg, drv, {k: v.detach() for k, v in kp_joined.items()},
+                                                {k: v.detach() for k, v in generated.items()})
+        sum(v.mean() for v in dl).backward()
+        opts["discriminator"].step(), opts["discriminator"].zero_grad()
+
+    one()   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d training iterations of the same config at batch %d (oracle/restate.py, torch CPU fp32, "
+                      "%d threads), %.2f s/iteration" % (steps, batch, cores, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py measures the MI355X path; no GPU visible"
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    from mnk import configs, engine, _lib
+    from oracle import cases, restate
+    cfg = configs.get(args.config)
+    lib = _lib.lib()
+    assert lib.is_device_build, "bench.py must run on the real HIP library"
+    gen, disc, kpd = build_models(cfg, device)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"])
+    src, drv = cases.synthetic_pair(args.batch, args.size, args.size, seed=1234 + rank)
+    x = {"source": src.to(device), "video": drv.to(device)}
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step.step(x)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.step(x)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    global_batch = args.batch * world
+    value = global_batch * args.steps / elapsed
+
+    # ---- per-kernel HIP-event timing of one extra (un-timed) step: roofline of the dominant kernel --------------
+    roofline = None
+    kernels = {}
+    if not args.no_profile and rank == 0:
+        import ctypes
+        lib.cdll.mnk_prof_reset()
+        lib.cdll.mnk_prof_enable(1)
+        prof_steps = 2
+        for _ in range(prof_steps):
+            step.step(x)
+        torch.cuda.synchronize(device)
+        lib.cdll.mnk_prof_enable(0)
+        for k in range(lib.cdll.mnk_prof_num_kernels()):
+            n, ms, work = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+            lib.cdll.mnk_prof_query(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work))
+            if n.value:
+                kernels[lib.cdll.mnk_prof_kernel_name(k).decode()] = {
+                    "launches_per_step": n.value / prof_steps, "ms_per_step": ms.value / prof_steps,
+                    "avg_us": ms.value / n.value * 1e3, "work_per_step": work.value / prof_steps}
+        lib.cdll.mnk_prof_reset()
+        conv = kernels.get("conv3x3_igemm")
+        if conv:
+            achieved = conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12
+            roofline = {"kernel": "conv3x3_igemm_kernel (forward + dgrad launches)", "bound": "mfma",
+                        "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2),
+                        "flop_per_launch": conv["work_per_step"] / conv["launches_per_step"]}
+    elif world > 1:
+        pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args.cpu_batch, args.size, args.cpu_steps)
+
+    if rank == 0:
+        flops = restate.conv_flops_hot_path(cfg, args.size, args.size)
+        out = {
+            "metric": "train frames/sec (Bx3x%dx%d, %d kp)" % (args.size, args.size,
+                                                               cfg["model_params"]["common_params"]["num_kp"]),
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s model params @ %dx%d, batch %d/GPU, full train.py:110-136 iteration "
+                                   "(G step + D step, 3x Adam)" % (args.config, args.size, args.size, args.batch),
+                       "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "hot_path_conv_gflop_fwd_per_pair": round(flops["total"] / 1e9, 3)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

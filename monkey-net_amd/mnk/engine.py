@@ -1,0 +1,103 @@
+"""Host-side mirror of the reference's training iteration (train.py:24-75,110-136) for one rank: the two "full
+model" wrappers and the alternating generator / discriminator update with three Adam optimisers.  The reference's
+own train.py can equally be used on top of the drop-in `modules` / `sync_batchnorm` packages; this file exists so
+that bench.py, the smoke test and the parity tests have a self-contained step that does not import the reference."""
+import torch
+
+from modules.losses import generator_loss, discriminator_loss
+from . import dist as mdist
+
+
+def split_kp(kp_joined, detach=False):
+    """Frame 0 of the joined key-points is the source, the rest is the driving video (train.py:14-21)."""
+    f = (lambda t: t.detach()) if detach else (lambda t: t)
+    return {'kp_driving': {k: f(v[:, 1:]) for k, v in kp_joined.items()},
+            'kp_source': {k: f(v[:, :1]) for k, v in kp_joined.items()}}
+
+
+class GeneratorFullModel(torch.nn.Module):
+    """train.py:24-53."""
+
+    def __init__(self, kp_extractor, generator, discriminator, train_params):
+        super(GeneratorFullModel, self).__init__()
+        self.kp_extractor = kp_extractor
+        self.generator = generator
+        self.discriminator = discriminator
+        self.train_params = train_params
+
+    def forward(self, x):
+        kp_joined = self.kp_extractor(torch.cat([x['source'], x['video']], dim=2))
+        generated = self.generator(x['source'], **split_kp(kp_joined, self.train_params['detach_kp_generator']))
+        kp_dict = split_kp(kp_joined, False)
+        maps_generated = self.discriminator(generated['video_prediction'], **kp_dict)
+        maps_real = self.discriminator(x['video'], **kp_dict)
+        generated.update(kp_dict)
+        losses = generator_loss(discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
+                                video_deformed=generated['video_deformed'],
+                                loss_weights=self.train_params['loss_weights'])
+        return tuple(losses) + (generated, kp_joined)
+
+
+class DiscriminatorFullModel(torch.nn.Module):
+    """train.py:56-75."""
+
+    def __init__(self, kp_extractor, generator, discriminator, train_params):
+        super(DiscriminatorFullModel, self).__init__()
+        self.kp_extractor = kp_extractor
+        self.generator = generator
+        self.discriminator = discriminator
+        self.train_params = train_params
+
+    def forward(self, x, kp_joined, generated):
+        kp_dict = split_kp(kp_joined, self.train_params['detach_kp_discriminator'])
+        maps_generated = self.discriminator(generated['video_prediction'].detach(), **kp_dict)
+        maps_real = self.discriminator(x['video'], **kp_dict)
+        return discriminator_loss(discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
+                                  loss_weights=self.train_params['loss_weights'])
+
+
+class TrainStep:
+    """One iteration of train.py:110-136 on this rank's shard, with gradients averaged over ranks (RCCL) before
+    every optimiser step."""
+
+    def __init__(self, generator, discriminator, kp_detector, train_params, fused_adam=None):
+        self.generator, self.discriminator, self.kp_detector = generator, discriminator, kp_detector
+        self.tp = train_params
+        lr = train_params['lr']
+        kw = {}
+        if fused_adam is None:
+            fused_adam = next(generator.parameters()).is_cuda
+        if fused_adam:
+            kw['fused'] = True
+        self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
+        self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
+        self.opt_k = torch.optim.Adam(kp_detector.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
+        self.gfull = GeneratorFullModel(kp_detector, generator, discriminator, train_params)
+        self.dfull = DiscriminatorFullModel(kp_detector, generator, discriminator, train_params)
+        self.avg_gk = mdist.GradAverager(list(generator.parameters()) + list(kp_detector.parameters()))
+        self.avg_d = mdist.GradAverager(list(discriminator.parameters()))
+        self.avg_k = mdist.GradAverager(list(kp_detector.parameters()))
+
+    def step(self, x):
+        tp = self.tp
+        out = self.gfull(x)
+        loss_values = [v.mean() for v in out[:-2]]
+        generated, kp_joined = out[-2], out[-1]
+        sum(loss_values).backward(retain_graph=not tp['detach_kp_discriminator'])
+        self.avg_gk.average()
+        self.opt_g.step()
+        self.opt_g.zero_grad()
+        self.opt_d.zero_grad()
+        if tp['detach_kp_discriminator']:
+            self.opt_k.step()
+            self.opt_k.zero_grad()
+        d_values = [v.mean() for v in self.dfull(x, kp_joined, generated)]
+        sum(d_values).backward()
+        self.avg_d.average()
+        self.opt_d.step()
+        self.opt_d.zero_grad()
+        if not tp['detach_kp_discriminator']:
+            self.avg_k.average()
+            self.opt_k.step()
+            self.opt_k.zero_grad()
+        return [v.detach() for v in loss_values], [v.detach() for v in d_values], generated

@@ -1,0 +1,56 @@
+"""The C-ABI shared library loads without a GPU and exports every symbol include/monkeynet_hip.h declares;
+argument validation returns MNK_EINVAL before anything is launched."""
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def real_lib():
+    import __graft_entry__ as ge
+    from mnk import _lib
+    if not os.path.exists(_lib.DEFAULT_LIB):
+        ge.build()
+    return _lib.Library(_lib.DEFAULT_LIB, strict=True)
+
+
+def test_every_declared_symbol_is_exported(real_lib):
+    from mnk import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    for name in protos:
+        assert hasattr(real_lib.cdll, name), name
+    assert real_lib.cdll.mnk_version() >= 100
+    assert real_lib.is_device_build
+
+
+def test_invalid_arguments_are_rejected_before_launch(real_lib):
+    from mnk import _lib
+    rc = real_lib.cdll.mnk_bn_stats(None, 4, 10, 3, None, None, 0, None)
+    assert rc == -1
+    assert b"invalid argument" in real_lib.cdll.mnk_last_error()
+    with pytest.raises(_lib.MnkError):
+        real_lib.call("mnk_conv3x3_fwd", None, 4, 3, None, 0, 0, 0, None, None, None, 0, None, 4, 1, 8, 8, 4, None, 0,
+                      None)
+    assert real_lib.query("mnk_conv3x3_packed_floats", 64, 3, 0) == 64 * 9 * 16
+    assert real_lib.query("mnk_conv3x3_workspace_floats", 32, 64, 64, 64, 0, 64) == 0      # no split-K needed
+    assert real_lib.query("mnk_conv3x3_workspace_floats", 32, 4, 4, 1024, 0, 1024) > 0     # deep level: split-K
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from mnk import _lib
+    with pytest.raises(_lib.MnkError):
+        _lib.Library(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may touch oracle/."""
+    pkg = os.path.join(ROOT, "monkey-net_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
+                assert "hipemu" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,109 @@
+"""Multi-rank path on CPU: world_size 2 over gloo (127.0.0.1).  The *host* code under test is the product's
+(mnk.dist all-reduces inside BNActFn, GradAverager, shard_batch, TrainStep); the kernels run on the CPU emulator
+build so no GPU is needed.  Property: 2 ranks x B/2 samples (SyncBN + gradient averaging) == 1 rank x B samples."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "monkey-net_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _worker(rank, world, port, emu_path, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from mnk import _lib, dist as mdist, engine
+    from oracle import cases
+    from test_modules import build
+    _lib._set_library_for_tests(emu_path, strict=False)
+    cfg = cases.TINY2
+    gen, disc, kpd = build(cfg)
+    for i, m in enumerate((gen, disc, kpd)):
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 7 + i)
+        m.load_state_dict(sd)
+    src, drv = cases.smooth_pair(4, 32, 32)
+    x = {"source": mdist.shard_batch(src).contiguous(), "video": mdist.shard_batch(drv).contiguous()}
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=False)
+    g_losses, d_losses, _ = step.step(x)
+    # the losses are per-shard means: average them over ranks like the reference's gather + mean (train.py:114)
+    lv = torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64)
+    dist.all_reduce(lv)
+    lv /= world
+    torch.save({"losses": lv, "gen": {k: v.clone() for k, v in gen.state_dict().items()},
+                "kp": {k: v.clone() for k, v in kpd.state_dict().items()},
+                "disc": {k: v.clone() for k, v in disc.state_dict().items()}},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    # plain collectives of mnk.dist
+    t = torch.full((3,), float(rank + 1))
+    mdist.all_reduce_sum_(t)
+    assert torch.equal(t, torch.full((3,), 3.0))
+    sums, count = mdist.combine_bn_stats(torch.tensor([1.0 * (rank + 1), 2.0]), 10)
+    assert count == 20 and torch.equal(sums, torch.tensor([3.0, 4.0]))
+    dist.destroy_process_group()
+
+
+def _single(emu_path):
+    _setup_paths()
+    from mnk import _lib, engine
+    from oracle import cases
+    from test_modules import build
+    _lib._set_library_for_tests(emu_path, strict=False)
+    cfg = cases.TINY2
+    gen, disc, kpd = build(cfg)
+    for i, m in enumerate((gen, disc, kpd)):
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 7 + i)
+        m.load_state_dict(sd)
+    src, drv = cases.smooth_pair(4, 32, 32)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=False)
+    g_losses, d_losses, _ = step.step({"source": src, "video": drv})
+    out = {"losses": torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64),
+           "gen": gen.state_dict(), "kp": kpd.state_dict(), "disc": disc.state_dict()}
+    _lib._set_library_for_tests(None)
+    return out
+
+
+def test_two_ranks_equal_one_rank_big_batch():
+    from conftest import emu_library_path
+    emu = emu_library_path()
+    ref = _single(emu)
+    with tempfile.TemporaryDirectory() as tmp:
+        port = 29500 + (os.getpid() % 2000)
+        mp.spawn(_worker, args=(2, port, emu, tmp), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(tmp, "rank0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(tmp, "rank1.pt"), weights_only=False)
+    # ranks stay bit-identical replicas after the step (same averaged gradients, same all-reduced BN statistics)
+    for key in ("gen", "kp", "disc"):
+        for k in r0[key]:
+            assert torch.equal(r0[key][k], r1[key][k]), (key, k)
+    # and the 2 x B/2 job matches the 1 x B job: losses, running statistics (SyncBN) and updated parameters
+    assert float((r0["losses"] - ref["losses"]).abs().max()) < 5e-5 * float(ref["losses"].abs().max() + 1)
+    for key in ("gen", "kp"):
+        for k, v in ref[key].items():
+            if "running" in k:
+                assert float((r0[key][k] - v).abs().max()) < 1e-5 * (1 + float(v.abs().max())), (key, k)
+
+
+def test_grad_averager_and_shard_batch_single_process():
+    _setup_paths()
+    from mnk import dist as mdist
+    p = torch.nn.Parameter(torch.ones(5))
+    p.grad = torch.full((5,), 2.0)
+    assert mdist.GradAverager([p]).average() == 0          # not initialised: no-op
+    assert mdist.world_size() == 1 and mdist.rank() == 0 and not mdist.active()
+    x = torch.arange(8)
+    assert mdist.shard_batch(x) is x
