@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1: replay the iteration as one captured hipGraph, 0: eager launches, -1: graph on 1 GPU")
     return ap.parse_args()
 
 
@@ -79,7 +81,9 @@ def cpu_baseline(cfg, batch, size, steps):
     params = {k: [t for t in sd.values() if t.requires_grad] for k, sd in sds.items()}
     opts = {k: torch.optim.Adam(p, lr=tp["lr"], betas=(0.5, 0.999)) for k, p in params.items()}
     src, drv = cases.synthetic_pair(batch, size, size)
-    cores = os.cpu_count() or 1
+    # threads actually used: the host's cores, capped -- the small 64x64 ops of this net stop scaling (and start
+    # thrashing in OpenMP barriers) long before a 100+ core host is filled
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
 
     def one():
@@ -96,11 +100,16 @@ def cpu_baseline(cfg, batch, size, steps):
         sum(v.mean() for v in dl).backward()
         opts["discriminator"].step(), opts["discriminator"].zero_grad()
 
-    one()   # warm-up
     t0 = time.perf_counter()
-    for _ in range(steps):
+    one()   # warm-up (also bounds the sample: if one iteration is already slow, it is the measurement)
+    first = time.perf_counter() - t0
+    done = 0
+    t0 = time.perf_counter()
+    while done < steps and (time.perf_counter() - t0) < 20.0 and first < 30.0:
         one()
-    dt = (time.perf_counter() - t0) / steps
+        done += 1
+    dt = (time.perf_counter() - t0) / done if done else first
+    steps = max(done, 1)
     return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d training iterations of the same config at batch %d (oracle/restate.py, torch CPU fp32, "
                       "%d threads), %.2f s/iteration" % (steps, batch, cores, dt)}
@@ -125,9 +134,21 @@ def main():
     lib = _lib.lib()
     assert lib.is_device_build, "bench.py must run on the real HIP library"
     gen, disc, kpd = build_models(cfg, device)
-    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"])
+    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
     src, drv = cases.synthetic_pair(args.batch, args.size, args.size, seed=1234 + rank)
     x = {"source": src.to(device), "video": drv.to(device)}
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
+    if use_graph:
+        try:
+            step.step(x)
+            torch.cuda.synchronize(device)
+        except Exception as e:   # capture is an optimisation, never a requirement
+            sys.stderr.write("hipGraph capture failed (%s: %s); running eager launches\n" % (type(e).__name__, e))
+            use_graph = False
+            torch.cuda.synchronize(device)
+            gen, disc, kpd = build_models(cfg, device)
+            step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+    eager = step if not use_graph else engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
 
     def sync():
         torch.cuda.synchronize(device)
@@ -160,7 +181,7 @@ def main():
         lib.cdll.mnk_prof_enable(1)
         prof_steps = 2
         for _ in range(prof_steps):
-            step.step(x)
+            eager.step(x)      # event timing needs real launches (a graph replay bypasses the recorder)
         torch.cuda.synchronize(device)
         lib.cdll.mnk_prof_enable(0)
         for k in range(lib.cdll.mnk_prof_num_kernels()):
@@ -197,6 +218,7 @@ def main():
             "config": {"workload": "%s model params @ %dx%d, batch %d/GPU, full train.py:110-136 iteration "
                                    "(G step + D step, 3x Adam)" % (args.config, args.size, args.size, args.batch),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
+                       "launch": "hipGraph replay" if use_graph else "eager",
                        "hot_path_conv_gflop_fwd_per_pair": round(flops["total"] / 1e9, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }

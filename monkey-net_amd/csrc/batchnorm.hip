@@ -20,9 +20,9 @@ static Map2D make_map(long rows, int ld) {
     m.tx = tx;
     m.ty = 256 / tx;
     m.col_tiles = (nv + tx - 1) / tx;
-    long want = 2048 / m.col_tiles;
+    long want = 1024 / m.col_tiles;   // ~4 blocks per CU in total
     if (want < 1) want = 1;
-    long min_rows = (long)m.ty * 4;  // at least 4 rows per thread before splitting further
+    long min_rows = (long)m.ty * 8;  // at least 8 rows per thread before splitting further
     long rb = (rows + min_rows - 1) / min_rows;
     if (rb > want) rb = want;
     if (rb < 1) rb = 1;
@@ -83,14 +83,31 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
     }
 }
 
+// one wavefront per output column: lanes stride over the row-block partials (fp64 accumulation), the 64 lane sums are
+// combined through LDS.  (A serial loop per column was 44 % of the step time in the first MI355X profile.)
 __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restrict__ partial, int row_blocks, int ld,
                                                             int C, float* __restrict__ sums) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * C) return;
-    int which = i / C, c = i - which * C;
+    __shared__ double sm[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
     double acc = 0.0;
-    for (int rb = 0; rb < row_blocks; ++rb) acc += (double)partial[((long)rb * 2 + which) * ld + c];
-    sums[i] = (float)acc;
+    if (i < 2 * C) {
+        const int which = i / C, c = i - which * C;
+        for (int rb = lane; rb < row_blocks; rb += 64) acc += (double)partial[((long)rb * 2 + which) * ld + c];
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane < 8) {
+        double t = 0.0;
+        for (int j = 0; j < 8; ++j) t += sm[wave * 64 + lane * 8 + j];
+        sm[wave * 64 + lane * 8] = t;
+    }
+    __syncthreads();
+    if (lane == 0 && i < 2 * C) {
+        double t = 0.0;
+        for (int j = 0; j < 8; ++j) t += sm[wave * 64 + j * 8];
+        sums[i] = (float)t;
+    }
 }
 
 struct StatsLoader {
@@ -186,6 +203,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
     const long total = (long)N * Ho * Wo * nv;
     const bool vec_store = ((z_off & 3) == 0) && ((ld_z & 3) == 0);
+    const bool owns_pads = z_off == 0 && ld_z == nv * 4;   // z is a plain act: its pad channels are written (as zero) here
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int q = (int)(i % nv);
         long p = i / nv;
@@ -237,7 +255,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
         }
         float* zp = z + p * ld_z + z_off + q * 4;
         const int rem = C - q * 4;
-        if (vec_store && rem >= 4) {
+        if (vec_store && (rem >= 4 || owns_pads)) {   // guarded parameter loads make the pad lanes of `o` zero
             *reinterpret_cast<float4*>(zp) = o;
         } else {
             if (rem > 0) zp[0] = o.x;
@@ -317,7 +335,7 @@ int mnk_bn_stats(const float* x, int ld, long rows, int C, float* sums, float* w
     StatsLoader L{x, ld};
     hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, rows,
                        ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
-    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, s, ws, m.row_blocks, ld, C, sums);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ld, C, sums);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -380,7 +398,7 @@ int mnk_bn_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz, i
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, relu, pool};
     hipLaunchKernelGGL(colsum2_partial_kernel<BwdLoader>, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, rows,
                        ldc / 4, ldc, m.tx, m.ty, m.rows_per_block, ws);
-    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 256)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, sums);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, sums);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

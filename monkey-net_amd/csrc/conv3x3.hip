@@ -258,26 +258,35 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------
+// GEMM  dW[co][n] = sum_p dY[p][co] * X[p + off(tap)][ci]  with n = ci*9 + tap, i.e. exactly the memory order of
+// the (Cout, Cin, 1, 3, 3) parameter: a block's result tile is written straight into the gradient (or into a
+// split-K partial of the same shape), coalesced along n.  K = pixels, split over blockIdx.z.
 struct WgradArgs {
     const float* x;
-    int ld_x, C, Cp, ups;
+    int ld_x, C, ups;
     const float* dy;
     int ld_dy, Cout;
     int N, H, W;
     long M;              // pixels
     long pix_per_split;  // multiple of 16
-    int NT;              // 9 * Cp
-    float* ws;           // [splits][Cout][NT]
+    int NT;              // 9 * C
+    float* out;          // splits == 1: dw + c_start*9 (row stride ld_out); else partials [splits][Cout][NT]
+    long ld_out;
+    int splits;
 };
 
-constexpr int WG_LD = 132;   // LDS row stride (floats) for the k-major 16 x 128 tiles
-
+template <int BM>
 __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
-    constexpr int BM = 128, BN = 128;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][WG_LD];   // dy tile   [pixel][co]
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][WG_LD];   // x-shifted [pixel][(tap,ci)]
+    constexpr int BN = 128;
+    constexpr int WM = BM / 64, WN = 4 / WM;       // waves along co / along n
+    constexpr int TN = BN / WN / 32;               // 32-wide MFMA tiles per wave along n (wave tile = 64 x 32*TN)
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A4 = BM / 4;                     // float4 columns of the dy tile
+    constexpr int RA = 16 / (256 / A4);            // dy rows per thread per step
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];   // dy tile   [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];   // x-shifted [pixel][n]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int co0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int split = blockIdx.z;
@@ -286,67 +295,76 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
     if (p_end > a.M) p_end = a.M;
     const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
 
-    // loader: thread covers pixel rows kr = t/32 + 8*j (j = 0,1), float4 column c4 = t%32
-    const int kr = t >> 5, c4 = t & 31;
-    // B column -> (tap, ci): fixed per thread
-    const int nb = n0 + c4 * 4;
-    const bool nb_ok = nb < a.NT;
-    const int tapb = nb_ok ? nb / a.Cp : 0;
-    const int cib = nb - tapb * a.Cp;
-    const int dyb = tapb / 3 - 1, dxb = tapb % 3 - 1;
-    const int coa = co0 + c4 * 4;
+    // dy loader: float4 along co
+    const int akr = t / A4, ac4 = t % A4;
+    const int coa = co0 + ac4 * 4;
+    // x loader: one fixed column n (-> ci, tap) per thread, 8 pixel rows (bk2, bk2+2, ...)
+    const int bn = t & 127, bk2 = t >> 7;
+    const int ncol = n0 + bn;
+    const bool n_ok = ncol < a.NT;
+    const int ci = n_ok ? ncol / 9 : 0;
+    const int tap = ncol - ci * 9;
+    const int dyb = tap / 3 - 1, dxb = tap % 3 - 1;
 
-    float4 ra[2], rb[2];
+    float4 ra[RA];
+    float rb[8];
     auto load_step = [&](long p0) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const long p = p0 + kr + 8 * j;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (p < p_end) {
-                if (coa < a.Cout) {   // ld_dy is a multiple of 4 and pad channels of dy are zero
-                    va = *reinterpret_cast<const float4*>(a.dy + p * a.ld_dy + coa);
-                    const int rem = a.Cout - coa;
-                    if (rem < 4) {
-                        if (rem < 2) va.y = 0.f;
-                        if (rem < 3) va.z = 0.f;
-                        va.w = 0.f;
-                    }
-                }
-                if (nb_ok && cib < a.C) {
-                    const int w = (int)(p % a.W);
-                    const long tt = p / a.W;
-                    const int h = (int)(tt % a.H);
-                    const long n = tt / a.H;
-                    const int hh = h + dyb, ww = w + dxb;
-                    if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
-                        const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
-                        vb = *reinterpret_cast<const float4*>(a.x + ((n * Hs + hs) * Ws + wsrc) * a.ld_x + cib);
-                        const int rem = a.C - cib;
-                        if (rem < 4) {
-                            if (rem < 2) vb.y = 0.f;
-                            if (rem < 3) vb.z = 0.f;
-                            vb.w = 0.f;
-                        }
-                    }
+        for (int j = 0; j < RA; ++j) {
+            const long p = p0 + akr + (256 / A4) * j;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < p_end && coa < a.Cout) {
+                va = *reinterpret_cast<const float4*>(a.dy + p * a.ld_dy + coa);
+                const int rem = a.Cout - coa;
+                if (rem < 4) {
+                    if (rem < 2) va.y = 0.f;
+                    if (rem < 3) va.z = 0.f;
+                    va.w = 0.f;
                 }
             }
             ra[j] = va;
-            rb[j] = vb;
+        }
+        // (n_img, h, w) of the first row, then incremental updates (rows advance by 2 pixels)
+        long p = p0 + bk2;
+        int w = (int)(p % a.W);
+        long tt = p / a.W;
+        int h = (int)(tt % a.H);
+        long nimg = tt / a.H;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = 0.f;
+            if (n_ok && p < p_end) {
+                const int hh = h + dyb, ww = w + dxb;
+                if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
+                    const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
+                    v = a.x[((nimg * Hs + hs) * Ws + wsrc) * a.ld_x + ci];
+                }
+            }
+            rb[j] = v;
+            p += 2;
+            w += 2;
+            while (w >= a.W) {
+                w -= a.W;
+                if (++h >= a.H) {
+                    h = 0;
+                    ++nimg;
+                }
+            }
         }
     };
     auto store_step = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<float4*>(&As[buf][kr + 8 * j][c4 * 4]) = ra[j];
-            *reinterpret_cast<float4*>(&Bs[buf][kr + 8 * j][c4 * 4]) = rb[j];
-        }
+        for (int j = 0; j < RA; ++j)
+            *reinterpret_cast<float4*>(&As[buf][akr + (256 / A4) * j][ac4 * 4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[buf][bk2 + 2 * j][bn] = rb[j];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -362,48 +380,46 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
         if (p0 + BK < p_end) load_step(p0 + BK);
 #pragma unroll
         for (int e = 0; e < BK / 2; ++e) {
-            float fa[2], fb[2];
+            float fa[2], fb[TN];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = As[buf][2 * e + fk][wm * 64 + 32 * i + fi];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = Bs[buf][2 * e + fk][wn * 64 + 32 * j + fi];
+            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][2 * e + fk][wn * (32 * TN) + 32 * j + fi];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (p0 + BK < p_end) store_step(buf ^ 1);
         __syncthreads();
     }
-    // rows = co, cols = (tap,ci)
+    // rows = co, cols = n (contiguous in the parameter layout): 32 lanes write 128 consecutive bytes
+    float* outp = a.splits > 1 ? a.out + (long)split * a.Cout * a.NT : a.out;
+    const long ldo = a.splits > 1 ? (long)a.NT : a.ld_out;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + 32 * j + fi;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (32 * TN) + 32 * j + fi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (co < a.Cout && n < a.NT) a.ws[((long)split * a.Cout + co) * a.NT + n] = acc[i][j][r];
+                if (co < a.Cout && n < a.NT) outp[(long)co * ldo + n] = acc[i][j][r];
             }
         }
 }
 
-// dw[co][c_start+ci][tap] = sum_splits ws[s][co][tap*Cp+ci]
+// dw[co][c_start*9 + n] = sum_splits partial[s][co][n]
 __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout,
-                                                                   int C, int Cp, float* __restrict__ dw,
-                                                                   int Cin_total, int c_start) {
-    const int NT = 9 * Cp;
+                                                                   int NT, float* __restrict__ dw, long ld_out) {
     const long total = (long)Cout * NT;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int n = (int)(i % NT);
-        int co = (int)(i / NT);
-        int tap = n / Cp, ci = n - tap * Cp;
-        if (ci >= C) continue;
+        const int n = (int)(i % NT);
+        const int co = (int)(i / NT);
         float v = 0.f;
         for (int s = 0; s < splits; ++s) v += ws[(long)s * total + i];
-        dw[((long)co * Cin_total + c_start + ci) * 9 + tap] = v;
+        dw[(long)co * ld_out + n] = v;
     }
 }
 
@@ -433,14 +449,15 @@ static Plan make_plan(long M, int Cout, int chunks) {
 }
 
 struct WPlan {
-    int gm, gn, splits;
+    int bm, gm, gn, splits;
     long pix_per_split;
 };
 
-static WPlan make_wplan(long M, int Cout, int Cp) {
+static WPlan make_wplan(long M, int Cout, int C) {
     WPlan p;
-    p.gm = ceil_div(Cout, 128);
-    p.gn = ceil_div(9 * Cp, 128);
+    p.bm = Cout > 64 ? 128 : 64;
+    p.gm = ceil_div(Cout, p.bm);
+    p.gn = ceil_div(9 * C, 128);
     long tiles = (long)p.gm * p.gn;
     long steps = (M + BK - 1) / BK;
     long splits = 1;
@@ -563,21 +580,19 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
 
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return 0;
-    const int Cp = round_up(C, 16);
-    WPlan p = make_wplan((long)N * H * W, Cout, Cp);
-    return (size_t)p.splits * Cout * 9 * Cp;
+    WPlan p = make_wplan((long)N * H * W, Cout, C);
+    return p.splits > 1 ? (size_t)p.splits * Cout * 9 * C : 0;
 }
 
 int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
                       int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream) {
-    MNK_REQUIRE(x && dy && dw && ws && N > 0 && H > 0 && W > 0 && C > 0 && Cout > 0);
-    MNK_REQUIRE(ld_x % 4 == 0 && ld_x >= C && ld_dy % 4 == 0 && ld_dy >= Cout);
+    MNK_REQUIRE(x && dy && dw && N > 0 && H > 0 && W > 0 && C > 0 && Cout > 0);
+    MNK_REQUIRE(ld_x >= C && ld_dy % 4 == 0 && ld_dy >= Cout);
     MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (H % 2 == 0 && W % 2 == 0)));
     WgradArgs a;
     a.x = x;
     a.ld_x = ld_x;
     a.C = C;
-    a.Cp = round_up(C, 16);
     a.ups = ups;
     a.dy = dy;
     a.ld_dy = ld_dy;
@@ -586,23 +601,35 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
     a.H = H;
     a.W = W;
     a.M = (long)N * H * W;
-    a.NT = 9 * a.Cp;
-    WPlan p = make_wplan(a.M, Cout, a.Cp);
+    a.NT = 9 * C;
+    WPlan p = make_wplan(a.M, Cout, C);
     a.pix_per_split = p.pix_per_split;
-    a.ws = ws;
-    if (ws_floats < (size_t)p.splits * Cout * a.NT) {
-        set_error("mnk_conv3x3_wgrad: workspace too small");
-        return MNK_EWORKSPACE;
+    a.splits = p.splits;
+    float* dst = dw + (long)c_start * 9;
+    const long ld_out = (long)Cin_total * 9;
+    if (p.splits > 1) {
+        if (!ws || ws_floats < (size_t)p.splits * Cout * a.NT) {
+            set_error("mnk_conv3x3_wgrad: workspace too small");
+            return MNK_EWORKSPACE;
+        }
+        a.out = ws;
+        a.ld_out = a.NT;
+    } else {
+        a.out = dst;
+        a.ld_out = ld_out;
     }
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope prof(K_CONV_WGRAD, s, 2.0 * (double)a.M * Cout * 9.0 * C);
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
+        if (p.bm == 128)
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<128>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<64>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
     }
-    {
+    if (p.splits > 1) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);
         hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * a.NT)), dim3(256), 0, s, ws, p.splits,
-                           Cout, C, a.Cp, dw, Cin_total, c_start);
+                           Cout, a.NT, dst, ld_out);
     }
     MNK_LAUNCH_CHECK();
     return MNK_OK;

@@ -60,7 +60,7 @@ class TrainStep:
     """One iteration of train.py:110-136 on this rank's shard, with gradients averaged over ranks (RCCL) before
     every optimiser step."""
 
-    def __init__(self, generator, discriminator, kp_detector, train_params, fused_adam=None):
+    def __init__(self, generator, discriminator, kp_detector, train_params, fused_adam=None, use_graph=False):
         self.generator, self.discriminator, self.kp_detector = generator, discriminator, kp_detector
         self.tp = train_params
         lr = train_params['lr']
@@ -69,6 +69,12 @@ class TrainStep:
             fused_adam = next(generator.parameters()).is_cuda
         if fused_adam:
             kw['fused'] = True
+        self.use_graph = bool(use_graph)
+        if self.use_graph:
+            kw['capturable'] = True          # step counters live on the device so the update can be captured
+        self._graph = None
+        self._static_x = None
+        self._static_out = None
         self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
         self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
         self.opt_k = torch.optim.Adam(kp_detector.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
@@ -79,6 +85,33 @@ class TrainStep:
         self.avg_k = mdist.GradAverager(list(kp_detector.parameters()))
 
     def step(self, x):
+        """Eager iteration, or -- with use_graph -- a replay of the whole iteration captured once as a hipGraph
+        (several hundred small launches per iteration make the eager path launch/host bound)."""
+        if not self.use_graph:
+            return self._eager_step(x)
+        if self._graph is None:
+            self._capture(x)
+        for k in self._static_x:
+            self._static_x[k].copy_(x[k], non_blocking=True)
+        self._graph.replay()
+        return self._static_out
+
+    def _capture(self, x, warmup=3):
+        assert not mdist.active(), "graph capture is used on the single-GPU path only"
+        self._static_x = {k: v.clone() for k, v in x.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # sizes the scratch buffers, warms MIOpen, creates Adam state
+                self._eager_step(self._static_x, set_to_none=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_out = self._eager_step(self._static_x, set_to_none=True)
+        self._graph = graph
+
+    def _eager_step(self, x, set_to_none=True):
         tp = self.tp
         out = self.gfull(x)
         loss_values = [v.mean() for v in out[:-2]]

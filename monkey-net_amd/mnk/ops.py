@@ -220,7 +220,7 @@ class Conv3x3Fn(torch.autograd.Function):
                 ws = SCRATCH.get("ws", nws, dy)
                 _call("mnk_conv3x3_wgrad", dy, _p(src), src.shape[-1], cc, int(ups), _p(dy), ld_dy, cout, _p(dw), cin, cs,
                       n, h, w, _p(ws), nws)
-        db = channel_sums(dy, cout)[:cout].clone() if has_bias and ctx.needs_input_grad[3] else None
+        db = channel_sums(dy, cout)[:cout] if has_bias and ctx.needs_input_grad[3] else None
         dres = dy if has_res and ctx.needs_input_grad[4] else None
         return grads[0], grads[1], dw, db, dres, None, None, None
 
@@ -261,7 +261,7 @@ class BNActFn(torch.autograd.Function):
             _call("mnk_bn_eval_coeffs", y, _p(gamma), _p(running_mean), _p(running_var), float(eps), c, _p(mean),
                   _p(invstd), _p(scale))
         ho, wo = (h // 2, w // 2) if pool else (h, w)
-        z = torch.zeros(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
+        z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)     # the kernel zeroes the pad channels
         _call("mnk_bn_act_fwd", y, _p(y), ld, _p(mean), _p(scale), _p(beta), _p(z), z.shape[-1], 0, n, h, w, c, int(relu),
               int(pool))
         ctx.save_for_backward(y, mean, invstd, scale, beta)
@@ -280,9 +280,9 @@ class BNActFn(torch.autograd.Function):
         sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
         _call("mnk_bn_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta), n, h,
               w, c, int(relu), int(pool), _p(sums), _p(ws), nws)
-        dbeta, dgamma = sums[:c].clone(), sums[c:].clone()       # local contributions (averaged later with the grads)
+        dbeta, dgamma = sums[:c], sums[c:]       # local contributions (averaged later together with all gradients)
         if training and mdist.active():
-            mdist.all_reduce_sum_(sums)
+            sums = mdist.all_reduce_sum_(sums.clone())
         dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
         _call("mnk_bn_act_bwd_apply", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta),
               _p(sums), count, int(training), _p(dy), ld, n, h, w, c, int(relu), int(pool))

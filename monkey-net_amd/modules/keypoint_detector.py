@@ -46,7 +46,7 @@ def _finish_kp(mean, var, kp_variance, clip_variance):
     if kp_variance == 'matrix':
         if clip_variance:
             # var * max(clip, sigma_min) / sigma_min (keypoint_detector.py:62-65): a handful of tiny element-wise ops
-            min_norm = torch.tensor(clip_variance, dtype=var.dtype, device=var.device)
+            min_norm = torch.full((), clip_variance, dtype=var.dtype, device=var.device)   # no H2D copy (graph-safe)
             sg = smallest_singular(var).unsqueeze(-1)
             var = torch.max(min_norm, sg) * var / sg
         kp['var'] = var
