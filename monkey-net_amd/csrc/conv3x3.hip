@@ -4,12 +4,16 @@
 // Replaces nn.Conv3d(kernel (1,3,3), padding (0,1,1)) of the reference (modules/util.py:52-55,79,98,176) in
 // forward, data-gradient (same kernel, flipped/transposed packed weights) and weight-gradient form.
 //
-//   forward / dgrad GEMM:  Y[m][co] = sum_{tap,ci} X[pix(m)+off(tap)][ci] * Wp[co][tap][ci]
-//       M = N*H*W pixels (rows, NHWC so ci is contiguous), N = Cout, K = 9 * (C0p + C1p)
-//       both operands are K-contiguous, so each lane fetches its MFMA fragment as one ds_read_b128:
+//   forward / dgrad GEMM:  Y[m][r] = sum_{chunk,tap,k} X[pix(m)+off(tap)][16*chunk+k] * W(r, 16*chunk+k, tap)
+//       M = N*H*W pixels (rows, NHWC so channels are contiguous), N = output channels, K = 9 * (C0p + C1p).
+//       K is walked chunk-major / tap-minor: the nine taps of one 16-channel chunk touch the same (halo of) pixel
+//       rows and the same 36-byte (row, k) weight groups back to back, so both operands are re-read from L1.
+//       The weights are read IN PLACE from the (Cout, Cin, 1, 3, 3) parameter (no packed copy): forward uses
+//       W(co, ci, tap), the data gradient the transposed / flipped view W(ci, co, 8 - tap).
+//       In LDS both operands are K-contiguous, so each lane fetches its MFMA fragment as one ds_read_b128:
 //       lane (i = l&31, kk = l>>5) holds k = 8*kh + 4*kk + e (e = 0..3) of row i -- a permutation of K inside the
 //       16-wide K step that is applied identically to A and B, hence harmless.
-//   weight-gradient GEMM:  dW[co][(tap,ci)] = sum_p dY[p][co] * X[p+off(tap)][ci]   (K = pixels, split over blocks)
+//   weight-gradient GEMM:  dW[co][ci*9+tap] = sum_p dY[p][co] * X[p+off(tap)][ci]   (K = pixels, split over blocks)
 //
 // Tiling: 256 threads = 4 waves; block tile BM x BN (128x128 default) staged through LDS in 16-deep K steps,
 // double buffered with register prefetch (one barrier per step); wave tile = (BM/WM) x (BN/WN) as 32x32 MFMA
@@ -33,7 +37,9 @@ struct ConvArgs {
     const float* x1;
     int ld0, ld1, C0, C1, C0p, C1p;
     int ups;
-    const float* wp;  // [Cout][9][C0p + C1p]
+    const float* w;   // parameter tensor, addressed as w[row*w_rs + k*w_ks + tap'] (see w_flip)
+    long w_rs, w_ks;
+    int w_flip;       // 0: tap' = tap (forward), 1: tap' = 8 - tap (data gradient)
     const float* bias;
     const float* residual;
     int ld_res;
@@ -42,7 +48,7 @@ struct ConvArgs {
     int N, H, W, Cout;
     long M;
     int chunks;        // (C0p + C1p) / 16
-    int ksteps;        // 9 * chunks
+    int ksteps;        // 9 * chunks, step s = chunk * 9 + tap
     int ksteps_per_split;
     int splits;
     float* ws;         // [splits][M][ldw] partial sums when splits > 1
@@ -50,9 +56,8 @@ struct ConvArgs {
 };
 
 template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) conv3x3_igemm_kernel(ConvArgs a) {
+__global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   // 3 waves/SIMD = 3 blocks per CU
     constexpr int RA = BM / 64;               // A rows per thread per K step
-    constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4, "4 waves per block");
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
@@ -83,26 +88,34 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(ConvArgs a) {
         pn[j] = (int)(tt / a.H);
     }
     const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
-    const int KT = 9 * (a.C0p + a.C1p);
+    // weight tile: BN rows x 16 k, TPR threads per row, KPT consecutive k per thread (scalar loads, 36 B apart for
+    // the forward; the 9 taps of a (row,k) pair are adjacent in memory and are served by L1 after the first tap)
+    constexpr int TPR = 256 / BN, KPT = BK / TPR;
+    const int brow = t / TPR, bk0 = (t % TPR) * KPT;
+    const bool brow_ok = n0 + brow < a.Cout;
+    const float* const wrow = a.w + (long)(n0 + brow) * a.w_rs;
 
-    float4 ra[RA], rb[RB];
+    float4 ra[RA];
+    float rb[KPT];
 
     auto load_step = [&](int s) {
-        const int tap = s / a.chunks;
-        const int chunk = s - tap * a.chunks;
+        const int chunk = s / 9;
+        const int tap = s - chunk * 9;
         const int dy = tap / 3 - 1, dx = tap % 3 - 1;
         int cbase = chunk * BK;
         const float* src;
-        int ld, C;
+        int ld, C, kglob;
         if (cbase < a.C0p) {
             src = a.x0;
             ld = a.ld0;
             C = a.C0;
+            kglob = cbase;
         } else {
             cbase -= a.C0p;
             src = a.x1;
             ld = a.ld1;
             C = a.C1;
+            kglob = a.C0 + cbase;
         }
         const int ch = cbase + lq * 4;
 #pragma unroll
@@ -121,22 +134,23 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(ConvArgs a) {
             }
             ra[j] = v;
         }
+        const int tapw = a.w_flip ? 8 - tap : tap;
+        const float* wp = wrow + (long)(kglob + bk0) * a.w_ks + tapw;
+        const int krem = C - (cbase + bk0);
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int r = lrow + 64 * j;
-            const int co = n0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < BN && co < a.Cout)
-                v = *reinterpret_cast<const float4*>(a.wp + (long)co * KT + (long)s * BK + lq * 4);
-            rb[j] = v;
-        }
+        for (int e = 0; e < KPT; ++e) rb[e] = (brow_ok && e < krem) ? wp[(long)e * a.w_ks] : 0.f;
     };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = ra[j];
+        if (KPT == 2) {
+            *reinterpret_cast<float2*>(&Bs[buf][brow][bk0]) = make_float2(rb[0], rb[1]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < RB; ++j)
-            if (lrow + 64 * j < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64 * j][lq * 4]) = rb[j];
+            for (int e = 0; e < KPT; e += 4)
+                *reinterpret_cast<float4*>(&Bs[buf][brow][bk0 + e]) =
+                    make_float4(rb[e], rb[e + 1 < KPT ? e + 1 : e], rb[e + 2 < KPT ? e + 2 : e], rb[e + 3 < KPT ? e + 3 : e]);
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -182,27 +196,38 @@ __global__ void __launch_bounds__(256) conv3x3_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: D[row][col], col = lane&31 (-> co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> pixel) ------
+    // bias is fetched once per column, residual values are fetched as a batch before the stores (no per-element
+    // load -> wait -> store chains), stores are predicated.
+    const bool split_out = a.splits > 1;
+    const long ldo = split_out ? (long)a.ldw : (long)a.ld_y;
+    float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
+    const int co_lim = split_out ? a.ldw : a.ld_y;
+    int cov[TN];
+    float bv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        cov[j] = n0 + wn * (BN / WN) + 32 * j + fi;
+        bv[j] = (!split_out && a.bias && cov[j] < a.Cout) ? a.bias[cov[j]] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn * (BN / WN) + 32 * j + fi;
+            const int co = cov[j];
+            const bool c_real = co < a.Cout, c_store = co < co_lim;
+            const long mbase = m0 + wm * (BM / WM) + 32 * i + 4 * fk;
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long m = m0 + wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (m >= a.M) continue;
+                const long m = mbase + (r & 3) + 8 * (r >> 2);
+                rv[r] = (!split_out && a.residual && c_real && m < a.M) ? a.residual[m * a.ld_res + co] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = mbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r];
-                if (a.splits > 1) {
-                    if (co < a.ldw) a.ws[((long)split * a.M + m) * a.ldw + co] = v;
-                } else if (co < a.ld_y) {
-                    if (co < a.Cout) {
-                        if (a.bias) v += a.bias[co];
-                        if (a.residual) v += a.residual[m * a.ld_res + co];
-                    } else {
-                        v = 0.f;
-                    }
-                    a.y[m * a.ld_y + co] = v;
-                }
+                if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
+                if (c_store && m < a.M) obase[m * ldo + co] = v;
             }
         }
 }
@@ -222,38 +247,6 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float*
             if (residual) v += residual[m * ld_res + co];
         }
         y[i] = v;
-    }
-}
-
-// ---- weight packing ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                                                       int C0, int C1, int C0p, int C1p) {
-    const int Kc = C0p + C1p, Cin = C0 + C1;
-    const long total = (long)Cout * 9 * Kc;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int k = (int)(i % Kc);
-        long t = i / Kc;
-        int tap = (int)(t % 9);
-        int co = (int)(t / 9);
-        int ci = -1;
-        if (k < C0p) {
-            if (k < C0) ci = k;
-        } else if (k - C0p < C1) {
-            ci = C0 + k - C0p;
-        }
-        wp[i] = ci >= 0 ? w[((long)co * Cin + ci) * 9 + tap] : 0.f;
-    }
-}
-
-__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                                                         int Cin_total, int c_start, int c_count, int Coutp) {
-    const long total = (long)c_count * 9 * Coutp;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int co = (int)(i % Coutp);
-        long t = i / Coutp;
-        int tap = (int)(t % 9);
-        int ci = (int)(t / 9);
-        wp[i] = co < Cout ? w[((long)co * Cin_total + c_start + ci) * 9 + (8 - tap)] : 0.f;
     }
 }
 
@@ -278,11 +271,13 @@ struct WgradArgs {
 template <int BM>
 __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
     constexpr int BN = 128;
-    constexpr int WM = BM / 64, WN = 4 / WM;       // waves along co / along n
-    constexpr int TN = BN / WN / 32;               // 32-wide MFMA tiles per wave along n (wave tile = 64 x 32*TN)
+    constexpr int TMW = BM >= 64 ? 2 : 1;          // 32-row MFMA tiles per wave along co
+    constexpr int WM = BM / (32 * TMW), WN = 4 / WM;   // waves along co / along n
+    constexpr int TN = BN / WN / 32;               // 32-wide MFMA tiles per wave along n
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int A4 = BM / 4;                     // float4 columns of the dy tile
-    constexpr int RA = 16 / (256 / A4);            // dy rows per thread per step
+    constexpr int APASS = 256 / A4;                // dy rows covered by one pass of the block
+    constexpr int RA = (BK + APASS - 1) / APASS;   // dy rows per thread per step
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];   // dy tile   [pixel][co]
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];   // x-shifted [pixel][n]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -311,9 +306,9 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
     auto load_step = [&](long p0) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const long p = p0 + akr + (256 / A4) * j;
+            const long p = p0 + akr + APASS * j;
             float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p < p_end && coa < a.Cout) {
+            if (akr + APASS * j < BK && p < p_end && coa < a.Cout) {
                 va = *reinterpret_cast<const float4*>(a.dy + p * a.ld_dy + coa);
                 const int rem = a.Cout - coa;
                 if (rem < 4) {
@@ -355,14 +350,14 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < RA; ++j)
-            *reinterpret_cast<float4*>(&As[buf][akr + (256 / A4) * j][ac4 * 4]) = ra[j];
+            if (akr + APASS * j < BK) *reinterpret_cast<float4*>(&As[buf][akr + APASS * j][ac4 * 4]) = ra[j];
 #pragma unroll
         for (int j = 0; j < 8; ++j) Bs[buf][bk2 + 2 * j][bn] = rb[j];
     };
 
-    f32x16 acc[2][TN];
+    f32x16 acc[TMW][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -380,13 +375,13 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
         if (p0 + BK < p_end) load_step(p0 + BK);
 #pragma unroll
         for (int e = 0; e < BK / 2; ++e) {
-            float fa[2], fb[TN];
+            float fa[TMW], fb[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = As[buf][2 * e + fk][wm * 64 + 32 * i + fi];
+            for (int i = 0; i < TMW; ++i) fa[i] = As[buf][2 * e + fk][wm * (32 * TMW) + 32 * i + fi];
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][2 * e + fk][wn * (32 * TN) + 32 * j + fi];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
@@ -398,13 +393,13 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
     float* outp = a.splits > 1 ? a.out + (long)split * a.Cout * a.NT : a.out;
     const long ldo = a.splits > 1 ? (long)a.NT : a.ld_out;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (32 * TN) + 32 * j + fi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const int co = co0 + wm * (32 * TMW) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (co < a.Cout && n < a.NT) outp[(long)co * ldo + n] = acc[i][j][r];
             }
         }
@@ -455,7 +450,7 @@ struct WPlan {
 
 static WPlan make_wplan(long M, int Cout, int C) {
     WPlan p;
-    p.bm = Cout > 64 ? 128 : 64;
+    p.bm = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     p.gm = ceil_div(Cout, p.bm);
     p.gn = ceil_div(9 * C, 128);
     long tiles = (long)p.gm * p.gn;
@@ -483,34 +478,6 @@ static inline int grid_for(long total, int cap = 4096) {
 
 extern "C" {
 
-size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1) {
-    if (Cout <= 0 || C0 <= 0 || C1 < 0) return 0;
-    return (size_t)Cout * 9 * (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0));
-}
-
-int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream) {
-    MNK_REQUIRE(w && wp && Cout > 0 && C0 > 0 && C1 >= 0);
-    hipStream_t s = (hipStream_t)stream;
-    const int C0p = round_up(C0, 16), C1p = C1 > 0 ? round_up(C1, 16) : 0;
-    const long total = (long)Cout * 9 * (C0p + C1p);
-    ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
-    hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, C0, C1, C0p, C1p);
-    MNK_LAUNCH_CHECK();
-    return MNK_OK;
-}
-
-int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream) {
-    MNK_REQUIRE(w && wp && Cout > 0 && Cin_total > 0 && c_start >= 0 && c_count > 0 && c_start + c_count <= Cin_total);
-    hipStream_t s = (hipStream_t)stream;
-    const int Coutp = round_up(Cout, 16);
-    const long total = (long)c_count * 9 * Coutp;
-    ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
-    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, Cin_total, c_start,
-                       c_count, Coutp);
-    MNK_LAUNCH_CHECK();
-    return MNK_OK;
-}
-
 size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
     const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
@@ -518,14 +485,17 @@ size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cou
     return p.splits > 1 ? (size_t)p.splits * N * H * W * p.ldw : 0;
 }
 
-int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
-                    const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
-                    int Cout, float* ws, size_t ws_floats, void* stream) {
-    MNK_REQUIRE(x0 && wp && y && N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
+int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* w,
+                    int w_mode, int w_cin_total, int w_c_start, const float* bias, const float* residual, int ld_res,
+                    float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, void* stream) {
+    MNK_REQUIRE(x0 && w && y && N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
     MNK_REQUIRE(ld0 % 4 == 0 && ld0 >= C0 && ld_y % 4 == 0 && ld_y >= Cout && ld_y <= round_up(Cout, 32));
     MNK_REQUIRE(C1 == 0 || (x1 && ld1 % 4 == 0 && ld1 >= C1));
     MNK_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0));
     MNK_REQUIRE(!residual || (ld_res >= Cout));
+    MNK_REQUIRE(w_mode == 0 || w_mode == 1);
+    MNK_REQUIRE(w_mode == 1 || (w_cin_total == C0 + C1 && w_c_start == 0));
+    MNK_REQUIRE(w_mode == 0 || (C1 == 0 && w_c_start >= 0 && w_c_start + Cout <= w_cin_total));
     ConvArgs a;
     a.x0 = x0;
     a.x1 = x1;
@@ -536,7 +506,17 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     a.C0p = round_up(C0, 16);
     a.C1p = C1 > 0 ? round_up(C1, 16) : 0;
     a.ups = ups;
-    a.wp = wp;
+    if (w_mode == 0) {          // W(co, ci, tap) = w[(co*Cin + ci)*9 + tap]
+        a.w = w;
+        a.w_rs = (long)w_cin_total * 9;
+        a.w_ks = 9;
+        a.w_flip = 0;
+    } else {                    // rows = input channels c_start + r, K = output channels of the layer, flipped taps
+        a.w = w + (long)w_c_start * 9;
+        a.w_rs = 9;
+        a.w_ks = (long)w_cin_total * 9;
+        a.w_flip = 1;
+    }
     a.bias = bias;
     a.residual = residual;
     a.ld_res = ld_res;
@@ -623,8 +603,10 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
         ProfScope prof(K_CONV_WGRAD, s, 2.0 * (double)a.M * Cout * 9.0 * C);
         if (p.bm == 128)
             hipLaunchKernelGGL((conv3x3_wgrad_kernel<128>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
-        else
+        else if (p.bm == 64)
             hipLaunchKernelGGL((conv3x3_wgrad_kernel<64>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<32>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
     }
     if (p.splits > 1) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);

@@ -18,7 +18,10 @@ def test_three_training_steps_match_reference_history(be):
     disc.load_state_dict(gold["state"]["discriminator"])
     kpd.load_state_dict(gold["state"]["kp_detector"])
     gen.to(be.device), disc.to(be.device), kpd.to(be.device)
-    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"])
+    # non-fused Adam: same update formula as the optimiser the golden history was recorded with; the fused ROCm
+    # kernel separates 10x faster from the fp64 trajectory (tools/step_diag.py on the MI355X: 7e-2 vs 6e-3 at
+    # iteration 1, independent of MIOpen being on or off)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=False)
     src, drv = cases.smooth_pair(gold["batch"], gold["size"], gold["size"])
     x = {"source": be.t(src), "video": be.t(drv)}
     report = []
@@ -34,10 +37,6 @@ def test_three_training_steps_match_reference_history(be):
         spread = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(r32, r64))
         err = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(mine, r64))
         report.append((it, err, spread))
-        # On the MI355X the discriminator / Adam are stock PyTorch-ROCm ops (MIOpen Winograd + implicit-GEMM
-        # convolutions, fused Adam) whose rounding differs from MKL-DNN's by more than the HIP kernels' does, so the
-        # sign-flip driven separation after the first Adam update is larger there: iteration 0 (forward + losses,
-        # before any update) is held to the strict bound, later iterations to a coarse "same dynamics" band.
-        bound = 8.0 * spread + 2e-5 if (be.kind == "emu" or it == 0) else max(8.0 * spread, 0.15)
+        bound = 8.0 * spread + 2e-5
         assert err <= bound, "iteration %d: |hip - ref64| = %.3e vs reference fp32 noise %.3e" % (it, err, spread)
     print("step parity (iteration, |hip-ref64|, |ref32-ref64|):", report)
