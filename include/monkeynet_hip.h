@@ -93,17 +93,18 @@ int mnk_bn_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz, i
 /* ---- 3x3 convolution, pad 1, stride 1 (nn.Conv3d (1,3,3): modules/util.py:52-55,79,98,176) -------------
  * implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).  The input is the channel concatenation of up to two
  * NHWC sources (torch.cat of modules/util.py:185 never materialised); `ups` = 1 reads both sources through the
- * nearest x2 up-sampling of modules/util.py:84.  The weights are read in place from the (Cout_layer, Cin_layer,
- * 1, 3, 3) parameter `w` (no packed copy):
- *   w_mode 0  forward:        y[.., co] = bias[co] + residual + sum x[.., ci] * w[co][ci][tap];
- *                             w_cin_total = C0 + C1, w_c_start = 0, Cout = Cout_layer
- *   w_mode 1  data gradient:  x0 = dy with C0 = Cout_layer channels (C1 = 0); the result is the gradient w.r.t. the
- *                             layer's input channels [w_c_start, w_c_start + Cout) of w_cin_total (flipped taps).
- * Outputs with few tiles are split along K over blockIdx.z; the partials live in `ws`. */
+ * nearest x2 up-sampling of modules/util.py:84.  Weights are first re-packed to [Cout][chunk][tap][16]: the
+ * K axis is walked in 16-channel chunks (CXp = C rounded up to 16, zero filled, source 0 then source 1) with the
+ * nine taps of a chunk adjacent, so the taps re-read the same pixel rows from L1.  (Reading the (Cout,Cin,3,3)
+ * parameter in place was measured 20 % slower on the MI355X: 36-byte strided rows thrash the 32 KB L1.) */
+size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1);
+int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream);
+/* dgrad weights for input channels [c_start, c_start+c_count): wp[ci][chunk][tap][16] = w[16*chunk+k][c_start+ci][8-tap] */
+int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream);
 size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
-int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* w,
-                    int w_mode, int w_cin_total, int w_c_start, const float* bias, const float* residual, int ld_res,
-                    float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, void* stream);
+int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
+                    const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
+                    int Cout, float* ws, size_t ws_floats, void* stream);
 /* dw[co][c_start+ci][ky][kx] = sum_pixels dy[p][co] * x[p+tap][ci]; x is one source (C channels) */
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout);
 int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,

@@ -134,15 +134,31 @@ class Concat2Fn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------
 # 3x3 convolution
 # ----------------------------------------------------------------------------------------------------------------
-def _conv_launch(x0, c0, x1, c1, ups, weight, w_mode, w_cin_total, w_c_start, bias, residual, n, h, w, cout):
-    """One mnk_conv3x3_fwd launch (forward: w_mode 0; data gradient: w_mode 1).  The (Cout,Cin,1,3,3) parameter is
-    read in place by the kernel -- there is no packed weight copy to build or cache."""
+_PACK_CACHE = {}
+
+
+def _packed_fwd_weight(weight, cout, c0, c1):
+    """Packed [Cout][chunk][tap][16] copy of a conv weight, cached per parameter version (inference loops reuse it;
+    training re-packs once per optimiser step)."""
+    key = (id(weight), weight.device)
+    ver = weight._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[1] == (cout, c0, c1) and hit[3] is weight:
+        return hit[2]
+    n = _query("mnk_conv3x3_packed_floats", cout, c0, c1)
+    wp = torch.empty(n, dtype=torch.float32, device=weight.device)
+    _call("mnk_conv3x3_pack_fwd", weight, _p(weight), _p(wp), cout, c0, c1)
+    _PACK_CACHE[key] = (ver, (cout, c0, c1), wp, weight)
+    return wp
+
+
+def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout):
     y = torch.empty(n, h, w, ceil4(cout), dtype=torch.float32, device=x0.device)
     nws = _query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
     ws = SCRATCH.get("ws", nws, x0) if nws else None
     _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
-          int(ups), _p(weight), w_mode, w_cin_total, w_c_start, _p(bias), _p(residual),
-          residual.shape[-1] if residual is not None else 0, _p(y), y.shape[-1], n, h, w, cout, _p(ws), nws)
+          int(ups), _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
+          y.shape[-1], n, h, w, cout, _p(ws), nws)
     return y
 
 
@@ -168,7 +184,8 @@ class Conv3x3Fn(torch.autograd.Function):
         assert weight.shape[1] == c0 + c1 and weight.is_contiguous()
         n, hs, ws_, _ = x0.shape
         h, w = (hs * 2, ws_ * 2) if ups else (hs, ws_)
-        y = _conv_launch(x0, c0, x1, c1, ups, weight, 0, c0 + c1, 0, bias, residual, n, h, w, cout)
+        wp = _packed_fwd_weight(weight, cout, c0, c1)
+        y = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout)
         ctx.save_for_backward(x0, x1, weight)
         ctx.meta = (c0, c1, ups, cout, n, h, w, bias is not None, residual is not None)
         return y
@@ -184,7 +201,10 @@ class Conv3x3Fn(torch.autograd.Function):
         for i, (src, cs, cc) in enumerate(((x0, 0, c0), (x1, c0, c1))):
             if src is None or not ctx.needs_input_grad[i]:
                 continue
-            dx = _conv_launch(dy, cout, None, 0, 0, weight, 1, cin, cs, None, None, n, h, w, cc)
+            npk = _query("mnk_conv3x3_packed_floats", cc, cout, 0)
+            wp = SCRATCH.get("pack", npk, dy)
+            _call("mnk_conv3x3_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, cs, cc)
+            dx = _conv_launch(dy, cout, None, 0, 0, wp, None, None, n, h, w, cc)
             if ups:
                 dxs = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
                 _call("mnk_sumpool2x2", dy, _p(dx), dx.shape[-1], _p(dxs), dxs.shape[-1], n, h, w, cc)

@@ -19,7 +19,7 @@ def real_lib():
 def test_every_declared_symbol_is_exported(real_lib):
     from mnk import _lib
     protos = _lib.parse_header()
-    assert len(protos) >= 38
+    assert len(protos) >= 40
     for name in protos:
         assert hasattr(real_lib.cdll, name), name
     assert real_lib.cdll.mnk_version() >= 100
@@ -32,8 +32,9 @@ def test_invalid_arguments_are_rejected_before_launch(real_lib):
     assert rc == -1
     assert b"invalid argument" in real_lib.cdll.mnk_last_error()
     with pytest.raises(_lib.MnkError):
-        real_lib.call("mnk_conv3x3_fwd", None, 4, 3, None, 0, 0, 0, None, 0, 3, 0, None, None, 0, None, 4, 1, 8, 8, 4,
-                      None, 0, None)
+        real_lib.call("mnk_conv3x3_fwd", None, 4, 3, None, 0, 0, 0, None, None, None, 0, None, 4, 1, 8, 8, 4, None, 0,
+                      None)
+    assert real_lib.query("mnk_conv3x3_packed_floats", 64, 3, 0) == 64 * 9 * 16
     assert real_lib.query("mnk_conv3x3_workspace_floats", 32, 64, 64, 64, 0, 64) == 0      # no split-K needed
     assert real_lib.query("mnk_conv3x3_workspace_floats", 32, 4, 4, 1024, 0, 1024) > 0     # deep level: split-K
 

@@ -42,6 +42,8 @@ def _ref_fwd(case, x0, x1, wt, b, r):
 
 def _run_fwd(be, case, x0, x1, wt, b, r):
     n, h, w, c0, c1, cout, ups, _, _ = case
+    wp = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
+    be.call("mnk_conv3x3_pack_fwd", be.t(wt), wp, cout, c0, c1)
     X0 = be.t(to_nhwc(x0, pad_value=float("nan")))     # pad channels must be ignored by the kernel
     X1 = be.t(to_nhwc(x1, pad_value=float("nan"))) if x1 is not None else None
     R = be.t(to_nhwc(r)) if r is not None else None
@@ -49,9 +51,9 @@ def _run_fwd(be, case, x0, x1, wt, b, r):
     Y = be.empty(n, h, w, ldy)
     nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
     ws = be.empty(max(nws, 1))
-    be.call("mnk_conv3x3_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if x1 is not None else 0, c1, ups, be.t(wt),
-            0, c0 + c1, 0, be.t(b) if b is not None else None, R, R.shape[-1] if r is not None else 0, Y, ldy, n, h, w,
-            cout, ws, nws)
+    be.call("mnk_conv3x3_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if x1 is not None else 0, c1, ups, wp,
+            be.t(b) if b is not None else None, R, R.shape[-1] if r is not None else 0, Y, ldy, n, h, w, cout,
+            ws, nws)
     be.sync()
     return Y.cpu()
 
@@ -68,7 +70,7 @@ def test_conv3x3_forward(be, case):
 
 @pytest.mark.parametrize("case", CASES[:4])
 def test_conv3x3_dgrad(be, case):
-    """dx = conv(dy, flipped/transposed weights): the forward kernel reading the parameter in w_mode 1."""
+    """dx = conv(dy, flipped/transposed weights): the forward kernel with mnk_conv3x3_pack_dgrad weights."""
     n, h, w, c0, c1, cout, ups, _, _ = case
     if ups:
         pytest.skip("dgrad of an up-sampled input = dgrad at full resolution + mnk_sumpool2x2 (tested below)")
@@ -79,12 +81,14 @@ def test_conv3x3_dgrad(be, case):
     F.conv2d(x, wt.double(), None, padding=1).backward(dy.double())
     DY = be.t(to_nhwc(dy))
     for c_start, c_cnt in ((0, c0),) + (((c0, c1),) if c1 else ()):
+        wp = be.empty(be.query("mnk_conv3x3_packed_floats", c_cnt, cout, 0))
+        be.call("mnk_conv3x3_pack_dgrad", be.t(wt), wp, cout, c0 + c1, c_start, c_cnt)
         ld = ceil4(c_cnt)
         DX = be.empty(n, h, w, ld)
         nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, cout, 0, c_cnt)
         ws = be.empty(max(nws, 1))
-        be.call("mnk_conv3x3_fwd", DY, DY.shape[-1], cout, None, 0, 0, 0, be.t(wt), 1, c0 + c1, c_start, None, None, 0,
-                DX, ld, n, h, w, c_cnt, ws, nws)
+        be.call("mnk_conv3x3_fwd", DY, DY.shape[-1], cout, None, 0, 0, 0, wp, None, None, 0, DX, ld, n, h, w, c_cnt,
+                ws, nws)
         be.sync()
         assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
 

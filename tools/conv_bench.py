@@ -53,10 +53,12 @@ def main():
             bias = torch.randn(cout, device=dev)
             dy = torch.randn(frames, h, w, ops.ceil4(cout), device=dev)
             fl = 2.0 * 9 * cin * cout * h * w * frames
-            t_f = timeit(lambda: ops._conv_launch(x, cin, None, 0, ups, wt, 0, cin, 0, bias, None, frames, h, w, cout),
-                         args.iters)
-            t_d = timeit(lambda: ops._conv_launch(dy, cout, None, 0, 0, wt, 1, cin, 0, None, None, frames, h, w, cin),
-                         args.iters)
+            wp = ops._packed_fwd_weight(wt, cout, cin, 0)
+            t_f = timeit(lambda: ops._conv_launch(x, cin, None, 0, ups, wp, bias, None, frames, h, w, cout), args.iters)
+            npk = ops._query("mnk_conv3x3_packed_floats", cin, cout, 0)
+            wpd = torch.empty(npk, device=dev)
+            ops._call("mnk_conv3x3_pack_dgrad", dy, wt.data_ptr(), wpd.data_ptr(), cout, cin, 0, cin)
+            t_d = timeit(lambda: ops._conv_launch(dy, cout, None, 0, 0, wpd, None, None, frames, h, w, cin), args.iters)
             dw = torch.empty_like(wt)
             nws = ops._query("mnk_conv3x3_wgrad_workspace_floats", frames, h, w, cin, cout)
             ws = torch.empty(max(nws, 1), device=dev)
