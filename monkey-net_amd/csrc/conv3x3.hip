@@ -22,6 +22,8 @@
 // 16-lane groups of a ds_read_b128 hit 16 distinct 16-B slots (no bank conflicts).
 // Small problems (deep hourglass levels: 4x4 / 2x2 maps with 1024 channels) are split along K across blockIdx.z
 // with a deterministic second-pass reduction (no atomics), which also applies bias and the residual add.
+#include <stdlib.h>
+
 #include "mnk_common.h"
 
 using namespace mnk;
@@ -223,21 +225,38 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
         }
 }
 
+// Split-K reductions: 64 outputs x 4 split-groups per block -- each thread sums every 4th partial (4x the loads in
+// flight of a one-thread-per-output loop), the groups are combined through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float* __restrict__ ws, int splits, long M,
                                                                     int ldw, const float* __restrict__ bias,
                                                                     const float* __restrict__ residual, int ld_res,
                                                                     float* __restrict__ y, int ld_y, int Cout) {
+    __shared__ float sm[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long total = M * ld_y;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long m = i / ld_y;
-        int co = (int)(i - m * ld_y);
+    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+        const long i = base + o;
+        long m = 0;
+        int co = 0;
         float v = 0.f;
-        if (co < Cout) {
-            for (int s = 0; s < splits; ++s) v += ws[((long)s * M + m) * ldw + co];
-            if (bias) v += bias[co];
-            if (residual) v += residual[m * ld_res + co];
+        if (i < total) {
+            m = i / ld_y;
+            co = (int)(i - m * ld_y);
+            if (co < Cout)
+                for (int s = g; s < splits; s += 4) v += ws[((long)s * M + m) * ldw + co];
         }
-        y[i] = v;
+        sm[g][o] = v;
+        __syncthreads();
+        if (g == 0 && i < total) {
+            float r = 0.f;
+            if (co < Cout) {
+                r = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+                if (bias) r += bias[co];
+                if (residual) r += residual[m * ld_res + co];
+            }
+            y[i] = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -437,19 +456,38 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
 // dw[co][c_start*9 + n] = sum_splits partial[s][co][n]
 __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout,
                                                                    int NT, float* __restrict__ dw, long ld_out) {
+    __shared__ float sm[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long total = (long)Cout * NT;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(i % NT);
-        const int co = (int)(i / NT);
+    for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+        const long i = base + o;
         float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += ws[(long)s * total + i];
-        dw[(long)co * ld_out + n] = v;
+        if (i < total)
+            for (int s = g; s < splits; s += 4) v += ws[(long)s * total + i];
+        sm[g][o] = v;
+        __syncthreads();
+        if (g == 0 && i < total) {
+            const int n = (int)(i % NT);
+            const int co = (int)(i / NT);
+            dw[(long)co * ld_out + n] = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
+        }
+        __syncthreads();
     }
 }
 
 struct Plan {
     int bm, bn, gm, gn, splits, ksteps, ksteps_per_split, ldw;
 };
+
+// split-K knobs (defaults from the MI355X sweep in profiles/README.md; env overrides are for tuning runs only)
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+static int g_split_tiles = env_int("MNK_SPLIT_TILES", 192), g_split_target = env_int("MNK_SPLIT_TARGET", 512),
+           g_split_minsteps = env_int("MNK_SPLIT_MINSTEPS", 6);
+static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = env_int("MNK_WSPLIT_TARGET", 1024),
+           g_wsplit_minsteps = env_int("MNK_WSPLIT_MINSTEPS", 8);
 
 static Plan make_plan(long M, int Cout, int chunks) {
     Plan p;
@@ -460,9 +498,9 @@ static Plan make_plan(long M, int Cout, int chunks) {
     p.ksteps = 9 * chunks;
     long tiles = (long)p.gm * p.gn;
     int splits = 1;
-    if (tiles < 128) {
-        splits = (int)((320 + tiles - 1) / tiles);
-        int max_splits = p.ksteps / 6;      // keep >= 6 K steps (96 deep) per split
+    if (tiles < g_split_tiles) {
+        splits = (int)((g_split_target + tiles - 1) / tiles);
+        int max_splits = p.ksteps / g_split_minsteps;      // keep >= 6 K steps (96 deep) per split
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
@@ -485,9 +523,9 @@ static WPlan make_wplan(long M, int Cout, int C) {
     long tiles = (long)p.gm * p.gn;
     long steps = (M + BK - 1) / BK;
     long splits = 1;
-    if (tiles < 256) {
-        splits = (512 + tiles - 1) / tiles;
-        long max_splits = steps / 16;       // >= 256 pixels per split
+    if (tiles < g_wsplit_tiles) {
+        splits = (g_wsplit_target + tiles - 1) / tiles;
+        long max_splits = steps / g_wsplit_minsteps;       // >= 128 pixels per split
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
@@ -595,7 +633,7 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     }
     if (p.splits > 1) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
-        hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * ld_y)), dim3(256), 0, s, ws, p.splits, a.M,
+        hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * ld_y * 4, 8192)), dim3(256), 0, s, ws, p.splits, a.M,
                            p.ldw, bias, residual, ld_res, y, ld_y, Cout);
     }
     MNK_LAUNCH_CHECK();
@@ -654,7 +692,7 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
     }
     if (p.splits > 1) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * a.NT)), dim3(256), 0, s, ws, p.splits,
+        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * a.NT * 4, 8192)), dim3(256), 0, s, ws, p.splits,
                            Cout, a.NT, dst, ld_out);
     }
     MNK_LAUNCH_CHECK();
