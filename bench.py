@@ -120,7 +120,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dist = os.environ.get("MNK_DIST_FORCE", "") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -134,7 +135,7 @@ def main():
     lib = _lib.lib()
     assert lib.is_device_build, "bench.py must run on the real HIP library"
     gen, disc, kpd = build_models(cfg, device)
-    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    use_graph = (world == 1 and not force_dist) if args.graph < 0 else bool(args.graph)
     src, drv = cases.synthetic_pair(args.batch, args.size, args.size, seed=1234 + rank)
     x = {"source": src.to(device), "video": drv.to(device)}
     step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
@@ -152,7 +153,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -164,7 +165,7 @@ def main():
         step.step(x)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -223,7 +224,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

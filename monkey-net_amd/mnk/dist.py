@@ -9,6 +9,8 @@ CPU tests).  Replaces the reference's single-process DataParallel + SyncMaster t
 * Gradients are averaged with a bucketed flat all-reduce after backward (`GradAverager`), replacing the implicit
   reduce-add of DataParallel's backward and its per-forward parameter broadcast.
 """
+import os
+
 import torch
 import torch.distributed as tdist
 
@@ -33,9 +35,12 @@ def rank():
     return tdist.get_rank() if initialized() else 0
 
 
+_FORCE = os.environ.get("MNK_DIST_FORCE", "") == "1"   # exercise the collectives even with a single rank (tests)
+
+
 def active():
     """True when BatchNorm statistics must be exchanged."""
-    return _SYNC_BN and initialized() and tdist.get_world_size() > 1
+    return _SYNC_BN and initialized() and (tdist.get_world_size() > 1 or _FORCE)
 
 
 def all_reduce_sum_(t):
@@ -64,7 +69,7 @@ class GradAverager:
         self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
 
     def average(self):
-        if not initialized() or world_size() == 1:
+        if not initialized() or (world_size() == 1 and not _FORCE):
             return 0
         ws = float(world_size())
         pending = []
