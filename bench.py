@@ -194,11 +194,25 @@ def main():
                     "avg_us": ms.value / n.value * 1e3, "work_per_step": work.value / prof_steps}
         lib.cdll.mnk_prof_reset()
         conv = kernels.get("conv3x3_igemm")
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_b%d.json" % (args.config, args.batch))
+        if os.path.exists(pmc_file) and args.size == 64:
+            # HBM-side bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc passes
+            # (FETCH_SIZE, WRITE_SIZE; tools/gpu_pmc.sh + tools/pmc_summarize.py), gfx950 correction: 2 x FETCH_SIZE
+            pm = json.load(open(pmc_file))
+            n = f = w = 0.0
+            for k, v in pm.items():
+                if "conv3x3_igemm" in k:
+                    n += v["launches"]
+                    f += v["fetch_bytes_per_launch_raw"] * v["launches"]
+                    w += v["write_bytes_per_launch"] * v["launches"]
+            if n:
+                traffic = round((2 * f + w) / n)
         if conv:
             achieved = conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12
             roofline = {"kernel": "conv3x3_igemm_kernel (forward + dgrad launches)", "bound": "mfma",
                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2),
                         "flop_per_launch": conv["work_per_step"] / conv["launches_per_step"]}
     elif world > 1:

@@ -68,6 +68,8 @@ int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, i
  * `sums` across ranks (RCCL) before mnk_bn_finalize -- that is the SyncBN exchange. */
 size_t mnk_bn_workspace_floats(long rows, int ld);
 int mnk_bn_stats(const float* x, int ld, long rows, int C, float* sums, float* ws, size_t ws_floats, void* stream);
+/* second stage only: sums[which*C + c] = sum_rb partial[(rb*2 + which)*ld + c]  (partials from a conv epilogue) */
+int mnk_bn_stats_finish(const float* partial, int row_blocks, int ld, int C, float* sums, void* stream);
 /* mean = sum/count, var = sumsq/count - mean^2, invstd = (var+eps)^-1/2, scale = gamma*invstd;
  * running_mean/var updated with momentum and the unbiased variance (batchnorm.py:119-123) */
 int mnk_bn_finalize(const float* sums, double count, const float* gamma, float* running_mean, float* running_var,
@@ -102,9 +104,13 @@ int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, vo
 /* dgrad weights for input channels [c_start, c_start+c_count): wp[ci][chunk][tap][16] = w[16*chunk+k][c_start+ci][8-tap] */
 int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream);
 size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
+/* `stats_partial` (optional, mnk_conv3x3_stats_floats floats; only when that query is > 0, i.e. no split-K): the kernel
+ * epilogue also emits per-block column sums / sums of squares of y -- the BatchNorm statistics of the following
+ * norm layer -- to be finished by mnk_bn_stats_finish(stats_partial, stats_floats / (2*ld_y), ld_y, Cout, sums). */
+size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout);
 int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
                     const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
-                    int Cout, float* ws, size_t ws_floats, void* stream);
+                    int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream);
 /* dw[co][c_start+ci][ky][kx] = sum_pixels dy[p][co] * x[p+tap][ci]; x is one source (C channels) */
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout);
 int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,

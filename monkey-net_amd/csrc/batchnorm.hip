@@ -340,6 +340,15 @@ int mnk_bn_stats(const float* x, int ld, long rows, int C, float* sums, float* w
     return MNK_OK;
 }
 
+int mnk_bn_stats_finish(const float* partial, int row_blocks, int ld, int C, float* sums, void* stream) {
+    MNK_REQUIRE(partial && sums && row_blocks > 0 && C > 0 && ld >= C);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_STATS, s, (double)row_blocks * 2 * C * 4);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, sums);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
 int mnk_bn_finalize(const float* sums, double count, const float* gamma, float* running_mean, float* running_var,
                     float momentum, float eps, int C, int update_running, float* mean, float* invstd, float* scale,
                     void* stream) {

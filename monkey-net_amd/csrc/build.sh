@@ -6,7 +6,7 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$HERE/build"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-unused-variable ${MNK_EXTRA_FLAGS}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-unused-variable ${MNK_EXTRA_FLAGS}"
 OBJS=""
 pids=""
 for f in "$HERE"/*.hip; do

@@ -54,6 +54,7 @@ struct ConvArgs {
     int splits;
     float* ws;         // [splits][M][ldw] partial sums when splits > 1
     int ldw;
+    float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
 };
 
 template <int BM, int BN, int WM, int WN>
@@ -196,11 +197,12 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
     float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
     const int co_lim = split_out ? a.ldw : a.ld_y;
     int cov[TN];
-    float bv[TN];
+    float bv[TN], s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         cov[j] = n0 + wn * (BN / WN) + 32 * j + fi;
         bv[j] = (!split_out && a.bias && cov[j] < a.Cout) ? a.bias[cov[j]] : 0.f;
+        s1[j] = s2[j] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -220,9 +222,40 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
                 const long m = mbase + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r];
                 if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
-                if (c_store && m < a.M) obase[m * ldo + co] = v;
+                if (c_store && m < a.M) {
+                    obase[m * ldo + co] = v;
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
+                }
             }
         }
+    // ---- fused BatchNorm statistics of the tensor just written (sync_batchnorm/batchnorm.py:60-62): per-block
+    // column sums -> stats[blockIdx.x][2][ld_y]; the tiny final reduction over blocks is mnk_bn_stats_finish.
+    if (a.stats && !split_out) {
+        float* red = &As[0][0][0];          // the main loop ended with a barrier: LDS is free
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+            if (fk == 0) {
+                const int col = wn * (BN / WN) + 32 * j + fi;
+                red[(wm * 2 + 0) * BN + col] = s1[j];
+                red[(wm * 2 + 1) * BN + col] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < a.ld_y) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                t1 += red[(w * 2 + 0) * BN + t];
+                t2 += red[(w * 2 + 1) * BN + t];
+            }
+            float* sp = a.stats + (long)blockIdx.x * 2 * a.ld_y;
+            sp[n0 + t] = t1;
+            sp[a.ld_y + n0 + t] = t2;
+        }
+    }
 }
 
 // Split-K reductions: 64 outputs x 4 split-groups per block -- each thread sums every 4th partial (4x the loads in
@@ -311,9 +344,10 @@ struct WgradArgs {
     long M;              // pixels
     long pix_per_split;  // multiple of 16
     int NT;              // 9 * C
-    float* out;          // splits == 1: dw + c_start*9 (row stride ld_out); else partials [splits][Cout][NT]
+    float* out;          // direct / atomic: dw + c_start*9 (row stride ld_out); else partials [splits][Cout][NT]
     long ld_out;
     int splits;
+    int atomic;          // splits > 1: accumulate into the zeroed gradient with fp32 atomics (no partial buffer)
 };
 
 template <int BM>
@@ -438,8 +472,10 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
         __syncthreads();
     }
     // rows = co, cols = n (contiguous in the parameter layout): 32 lanes write 128 consecutive bytes
-    float* outp = a.splits > 1 ? a.out + (long)split * a.Cout * a.NT : a.out;
-    const long ldo = a.splits > 1 ? (long)a.NT : a.ld_out;
+    const bool partial = a.splits > 1 && !a.atomic;
+    float* outp = partial ? a.out + (long)split * a.Cout * a.NT : a.out;
+    const long ldo = partial ? (long)a.NT : a.ld_out;
+    const bool use_atomic = a.splits > 1 && a.atomic;
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -448,7 +484,12 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * (32 * TMW) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (co < a.Cout && n < a.NT) outp[(long)co * ldo + n] = acc[i][j][r];
+                if (co < a.Cout && n < a.NT) {
+                    if (use_atomic)
+                        atomicAdd(outp + (long)co * ldo + n, acc[i][j][r]);
+                    else
+                        outp[(long)co * ldo + n] = acc[i][j][r];
+                }
             }
         }
 }
@@ -486,6 +527,9 @@ static int env_int(const char* name, int dflt) {
 }
 static int g_split_tiles = env_int("MNK_SPLIT_TILES", 192), g_split_target = env_int("MNK_SPLIT_TARGET", 512),
            g_split_minsteps = env_int("MNK_SPLIT_MINSTEPS", 6);
+// 1: split-K partial tiles of the weight gradient are accumulated with fp32 atomics into the (zeroed) gradient --
+// halves the HBM traffic of the shallow layers and drops the reduce launch; 0: deterministic partials + reduce
+static int g_wgrad_atomic = env_int("MNK_WGRAD_ATOMIC", 1);
 static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = env_int("MNK_WSPLIT_TARGET", 1024),
            g_wsplit_minsteps = env_int("MNK_WSPLIT_MINSTEPS", 8);
 
@@ -580,9 +624,16 @@ size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cou
     return p.splits > 1 ? (size_t)p.splits * N * H * W * p.ldw : 0;
 }
 
+size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
+    Plan p = make_plan((long)N * H * W, Cout, chunks);
+    return p.splits > 1 ? 0 : (size_t)p.gm * 2 * round_up(Cout, 4);
+}
+
 int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
                     const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
-                    int Cout, float* ws, size_t ws_floats, void* stream) {
+                    int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream) {
     MNK_REQUIRE(x0 && wp && y && N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
     MNK_REQUIRE(ld0 % 4 == 0 && ld0 >= C0 && ld_y % 4 == 0 && ld_y >= Cout && ld_y <= round_up(Cout, 32));
     MNK_REQUIRE(C1 == 0 || (x1 && ld1 % 4 == 0 && ld1 >= C1));
@@ -616,6 +667,8 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     a.splits = p.splits;
     a.ws = ws;
     a.ldw = p.ldw;
+    a.stats = stats_partial;
+    MNK_REQUIRE(!stats_partial || (p.splits == 1 && ld_y == round_up(Cout, 4)));
     if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * a.M * p.ldw)) {
         set_error("mnk_conv3x3_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * a.M * p.ldw);
         return MNK_EWORKSPACE;
@@ -643,7 +696,7 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return 0;
     WPlan p = make_wplan((long)N * H * W, Cout, C);
-    return p.splits > 1 ? (size_t)p.splits * Cout * 9 * C : 0;
+    return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)p.splits * Cout * 9 * C : 0;
 }
 
 int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
@@ -669,7 +722,9 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
     a.splits = p.splits;
     float* dst = dw + (long)c_start * 9;
     const long ld_out = (long)Cin_total * 9;
-    if (p.splits > 1) {
+    hipStream_t s = (hipStream_t)stream;
+    a.atomic = g_wgrad_atomic;
+    if (p.splits > 1 && !a.atomic) {
         if (!ws || ws_floats < (size_t)p.splits * Cout * a.NT) {
             set_error("mnk_conv3x3_wgrad: workspace too small");
             return MNK_EWORKSPACE;
@@ -679,8 +734,12 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
     } else {
         a.out = dst;
         a.ld_out = ld_out;
+        if (p.splits > 1 &&
+            hipMemset2DAsync(dst, (size_t)ld_out * 4, 0, (size_t)a.NT * 4, (size_t)Cout, s) != hipSuccess) {
+            set_error("mnk_conv3x3_wgrad: hipMemset2DAsync failed");
+            return MNK_ELAUNCH;
+        }
     }
-    hipStream_t s = (hipStream_t)stream;
     {
         ProfScope prof(K_CONV_WGRAD, s, 2.0 * (double)a.M * Cout * 9.0 * C);
         if (p.bm == 128)
@@ -690,7 +749,7 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
         else
             hipLaunchKernelGGL((conv3x3_wgrad_kernel<32>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
     }
-    if (p.splits > 1) {
+    if (p.splits > 1 && !a.atomic) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);
         hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * a.NT * 4, 8192)), dim3(256), 0, s, ws, p.splits,
                            Cout, a.NT, dst, ld_out);

@@ -152,14 +152,25 @@ def _packed_fwd_weight(weight, cout, c0, c1):
     return wp
 
 
-def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout):
+def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats=False):
+    """One conv launch.  With want_stats the BatchNorm sums of the output come out of the conv epilogue (finished by a
+    tiny second-stage kernel) instead of a separate pass over y; returns (y, sums or None)."""
     y = torch.empty(n, h, w, ceil4(cout), dtype=torch.float32, device=x0.device)
     nws = _query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
     ws = SCRATCH.get("ws", nws, x0) if nws else None
+    nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats else 0
+    st = SCRATCH.get("stats", nst, x0) if nst else None
     _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
           int(ups), _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
-          y.shape[-1], n, h, w, cout, _p(ws), nws)
-    return y
+          y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
+    sums = None
+    if want_stats:
+        if nst:
+            sums = torch.empty(2 * cout, dtype=torch.float32, device=x0.device)
+            _call("mnk_bn_stats_finish", x0, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, _p(sums))
+        else:
+            sums = channel_sums(y, cout)       # split-K layers: statistics by a pass over y
+    return y, sums
 
 
 def channel_sums(a, c):
@@ -178,20 +189,23 @@ class Conv3x3Fn(torch.autograd.Function):
     nearest x2 up-sampling (UpBlock3D, modules/util.py:83-85), plus bias and residual add (ResBlock3D :66-67)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, residual, c0, c1, ups):
+    def forward(ctx, x0, x1, weight, bias, residual, c0, c1, ups, want_stats):
         _check_device(x0)
         cout = weight.shape[0]
         assert weight.shape[1] == c0 + c1 and weight.is_contiguous()
         n, hs, ws_, _ = x0.shape
         h, w = (hs * 2, ws_ * 2) if ups else (hs, ws_)
         wp = _packed_fwd_weight(weight, cout, c0, c1)
-        y = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout)
+        y, sums = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats)
         ctx.save_for_backward(x0, x1, weight)
         ctx.meta = (c0, c1, ups, cout, n, h, w, bias is not None, residual is not None)
-        return y
+        if sums is None:
+            sums = y.new_empty(0)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dsums):
         x0, x1, weight = ctx.saved_tensors
         c0, c1, ups, cout, n, h, w, has_bias, has_res = ctx.meta
         dy = dy.contiguous()
@@ -204,7 +218,7 @@ class Conv3x3Fn(torch.autograd.Function):
             npk = _query("mnk_conv3x3_packed_floats", cc, cout, 0)
             wp = SCRATCH.get("pack", npk, dy)
             _call("mnk_conv3x3_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, cs, cc)
-            dx = _conv_launch(dy, cout, None, 0, 0, wp, None, None, n, h, w, cc)
+            dx, _ = _conv_launch(dy, cout, None, 0, 0, wp, None, None, n, h, w, cc)
             if ups:
                 dxs = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
                 _call("mnk_sumpool2x2", dy, _p(dx), dx.shape[-1], _p(dxs), dxs.shape[-1], n, h, w, cc)
@@ -222,11 +236,13 @@ class Conv3x3Fn(torch.autograd.Function):
                       n, h, w, _p(ws), nws)
         db = channel_sums(dy, cout)[:cout] if has_bias and ctx.needs_input_grad[3] else None
         dres = dy if has_res and ctx.needs_input_grad[4] else None
-        return grads[0], grads[1], dw, db, dres, None, None, None
+        return grads[0], grads[1], dw, db, dres, None, None, None, None
 
 
-def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None):
-    return Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups))
+def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False):
+    """-> (y, sums): sums = fused BatchNorm statistics [sum, sum of squares] of y when want_stats, else None."""
+    y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats))
+    return y, (sums if want_stats else None)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -238,7 +254,7 @@ class BNActFn(torch.autograd.Function):
     torch.distributed the sufficient statistics are all-reduced over the ranks (SyncBN over RCCL)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, c, training, relu, pool, momentum, eps):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, pre_sums, c, training, relu, pool, momentum, eps):
         _check_device(y)
         n, h, w, ld = y.shape
         rows = n * h * w
@@ -251,9 +267,9 @@ class BNActFn(torch.autograd.Function):
             if rows * mdist.world_size() <= 1:
                 raise ValueError("BatchNorm needs more than one value per channel in training mode "
                                  "(sync_batchnorm/batchnorm.py:116)")
-            sums = channel_sums(y, c)
+            sums = pre_sums if pre_sums is not None else channel_sums(y, c)
             if mdist.active():
-                mdist.all_reduce_sum_(sums)
+                sums = mdist.all_reduce_sum_(sums.clone() if pre_sums is not None else sums)
                 count *= mdist.world_size()
             _call("mnk_bn_finalize", y, _p(sums), count, _p(gamma), _p(running_mean), _p(running_var), float(momentum),
                   float(eps), c, 1, _p(mean), _p(invstd), _p(scale))
@@ -286,13 +302,14 @@ class BNActFn(torch.autograd.Function):
         dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
         _call("mnk_bn_act_bwd_apply", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta),
               _p(sums), count, int(training), _p(dy), ld, n, h, w, c, int(relu), int(pool))
-        return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def bn_act(y, c, norm, relu=True, pool=False):
-    """`norm` is a sync_batchnorm.SynchronizedBatchNorm3d parameter holder."""
-    return BNActFn.apply(y, norm.weight, norm.bias, norm.running_mean, norm.running_var, c, norm.training, relu, pool,
-                         norm.momentum, norm.eps)
+def bn_act(y, c, norm, relu=True, pool=False, sums=None):
+    """`norm` is a sync_batchnorm.SynchronizedBatchNorm3d parameter holder; `sums` = statistics of y that a conv
+    epilogue already produced (training mode)."""
+    return BNActFn.apply(y, norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                         sums if norm.training else None, c, norm.training, relu, pool, norm.momentum, norm.eps)
 
 
 # ----------------------------------------------------------------------------------------------------------------

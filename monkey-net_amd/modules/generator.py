@@ -77,11 +77,15 @@ class MotionTransferGenerator(nn.Module):
         deformed_img = ops.WarpSkipFn.apply(src_act, field, None, self.num_channels, 0, mode)
         video_deformed = ops.from_act(deformed_img, self.num_channels, b)
         out, c = self.video_decoder.forward_act(warped)
-        last = None
-        for name, block in self.refinement_module.named_children():
+        last, sums = None, None
+        blocks = list(self.refinement_module.named_children())
+        for idx, (name, block) in enumerate(blocks):
             if name == 'conv-last':
                 last = block
-            else:
-                out, c = block.forward_act(out, c)
+            else:     # hand the output statistics of each block to the next block's norm1 (fused in the conv epilogue)
+                more = idx + 1 < len(blocks) and blocks[idx + 1][0] != 'conv-last' and block.training
+                res = block.forward_act(out, c, x_sums=sums, want_stats=more)
+                out, c = res[0], res[1]
+                sums = res[2] if more else None
         video_prediction = ops.Conv1x1SigmoidFn.apply(out, last.weight, last.bias, c, b)
         return {"video_prediction": video_prediction, "video_deformed": video_deformed}

@@ -95,12 +95,14 @@ class ResBlock3D(nn.Module):
         self.norm2 = BatchNorm3d(in_features, affine=True)
         self.in_features = in_features
 
-    def forward_act(self, x, c):
-        out = ops.bn_act(x, c, self.norm1, relu=True)
-        out = ops.conv3x3(out, c, self.conv1.weight, self.conv1.bias)
-        out = ops.bn_act(out, c, self.norm2, relu=True)
-        out = ops.conv3x3(out, c, self.conv2.weight, self.conv2.bias, residual=x)
-        return out, c
+    def forward_act(self, x, c, x_sums=None, want_stats=False):
+        """x_sums: BatchNorm statistics of x from the producing conv epilogue; want_stats: also return those of the
+        output (the next block's norm1 consumes them).  Returns (out, c[, out_sums])."""
+        out = ops.bn_act(x, c, self.norm1, relu=True, sums=x_sums)
+        out, s = ops.conv3x3(out, c, self.conv1.weight, self.conv1.bias, want_stats=self.norm2.training)
+        out = ops.bn_act(out, c, self.norm2, relu=True, sums=s)
+        out, s = ops.conv3x3(out, c, self.conv2.weight, self.conv2.bias, residual=x, want_stats=want_stats)
+        return (out, c, s) if want_stats else (out, c)
 
     def forward(self, x):
         return _public(self, x, self.in_features, self.forward_act)
@@ -118,8 +120,9 @@ class UpBlock3D(nn.Module):
         _require_plain_3x3(self.conv.kernel_size, self.conv.padding)
 
     def forward_act(self, x0, c0, x1=None, c1=0):
-        out = ops.conv3x3(x0, c0, self.conv.weight, self.conv.bias, x1=x1, c1=c1, ups=True)
-        return ops.bn_act(out, self.out_features, self.norm, relu=True), self.out_features
+        out, s = ops.conv3x3(x0, c0, self.conv.weight, self.conv.bias, x1=x1, c1=c1, ups=True,
+                             want_stats=self.norm.training)
+        return ops.bn_act(out, self.out_features, self.norm, relu=True, sums=s), self.out_features
 
     def forward(self, x):
         return _public(self, x, self.in_features, self.forward_act)
@@ -138,8 +141,8 @@ class DownBlock3D(nn.Module):
         _require_plain_3x3(self.conv.kernel_size, self.conv.padding)
 
     def forward_act(self, x, c):
-        out = ops.conv3x3(x, c, self.conv.weight, self.conv.bias)
-        return ops.bn_act(out, self.out_features, self.norm, relu=True, pool=True), self.out_features
+        out, s = ops.conv3x3(x, c, self.conv.weight, self.conv.bias, want_stats=self.norm.training)
+        return ops.bn_act(out, self.out_features, self.norm, relu=True, pool=True, sums=s), self.out_features
 
     def forward(self, x):
         return _public(self, x, self.in_features, self.forward_act)
@@ -222,7 +225,7 @@ class Decoder(nn.Module):
             x0, c0 = up_block.forward_act(x0, c0, x1, c1)
             x1, c1 = skips.pop()
         if self.conv is not None:
-            out = ops.conv3x3(x0, c0, self.conv.weight, self.conv.bias, x1=x1, c1=c1)
+            out, _ = ops.conv3x3(x0, c0, self.conv.weight, self.conv.bias, x1=x1, c1=c1)
             return out, self.conv.out_channels
         return ops.Concat2Fn.apply(x0, c0, x1, c1), c0 + c1
 

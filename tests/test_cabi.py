@@ -33,7 +33,7 @@ def test_invalid_arguments_are_rejected_before_launch(real_lib):
     assert b"invalid argument" in real_lib.cdll.mnk_last_error()
     with pytest.raises(_lib.MnkError):
         real_lib.call("mnk_conv3x3_fwd", None, 4, 3, None, 0, 0, 0, None, None, None, 0, None, 4, 1, 8, 8, 4, None, 0,
-                      None)
+                      None, None)
     assert real_lib.query("mnk_conv3x3_packed_floats", 64, 3, 0) == 64 * 9 * 16
     assert real_lib.query("mnk_conv3x3_workspace_floats", 32, 64, 64, 64, 0, 64) == 0      # no split-K needed
     assert real_lib.query("mnk_conv3x3_workspace_floats", 32, 4, 4, 1024, 0, 1024) > 0     # deep level: split-K

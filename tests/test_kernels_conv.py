@@ -53,7 +53,7 @@ def _run_fwd(be, case, x0, x1, wt, b, r):
     ws = be.empty(max(nws, 1))
     be.call("mnk_conv3x3_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if x1 is not None else 0, c1, ups, wp,
             be.t(b) if b is not None else None, R, R.shape[-1] if r is not None else 0, Y, ldy, n, h, w, cout,
-            ws, nws)
+            ws, nws, None)
     be.sync()
     return Y.cpu()
 
@@ -88,7 +88,7 @@ def test_conv3x3_dgrad(be, case):
         nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, cout, 0, c_cnt)
         ws = be.empty(max(nws, 1))
         be.call("mnk_conv3x3_fwd", DY, DY.shape[-1], cout, None, 0, 0, 0, wp, None, None, 0, DX, ld, n, h, w, c_cnt,
-                ws, nws)
+                ws, nws, None)
         be.sync()
         assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
 
@@ -126,3 +126,33 @@ def test_sumpool2x2(be):
     ref = F.avg_pool2d(x, 2) * 4
     assert maxerr(from_nhwc(Y.cpu(), 5), ref) < 1e-5
     assert torch.all(Y.cpu()[..., 5:] == 0)
+
+
+# large enough (>= 192 output tiles) that the forward is not split along K -- only then are the statistics fused
+STAT_CASES = [(6, 64, 64, 5, 0, 20, 0, True, False), (6, 64, 64, 4, 3, 40, 1, True, True)]
+
+
+@pytest.mark.parametrize("case", STAT_CASES)
+def test_conv3x3_fused_bn_statistics(be, case):
+    """The conv epilogue's per-block column sums + mnk_bn_stats_finish == sums over the written output."""
+    n, h, w, c0, c1, cout, ups, _, _ = case
+    x0, x1, wt, b, r = _inputs(case, seed=3)
+    wp = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
+    be.call("mnk_conv3x3_pack_fwd", be.t(wt), wp, cout, c0, c1)
+    X0 = be.t(to_nhwc(x0))
+    X1 = be.t(to_nhwc(x1)) if x1 is not None else None
+    R = be.t(to_nhwc(r)) if r is not None else None
+    ldy = ceil4(cout)
+    Y = be.empty(n, h, w, ldy)
+    nst = be.query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout)
+    assert nst > 0 and nst % (2 * ldy) == 0
+    st = be.empty(nst)
+    be.call("mnk_conv3x3_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if x1 is not None else 0, c1, ups, wp,
+            be.t(b) if b is not None else None, R, R.shape[-1] if r is not None else 0, Y, ldy, n, h, w, cout,
+            None, 0, st)
+    sums = be.empty(2 * cout)
+    be.call("mnk_bn_stats_finish", st, nst // (2 * ldy), ldy, cout, sums)
+    be.sync()
+    y = from_nhwc(Y.cpu(), cout).double()
+    ref = torch.cat([y.sum(dim=(0, 2, 3)), (y * y).sum(dim=(0, 2, 3))])
+    assert relerr(sums.cpu(), ref) < 1e-5

@@ -139,3 +139,33 @@ def test_reference_configs_on_gpu(name):
     with torch.no_grad():
         out, _, _, _ = run_case(be, gold, train=False, backward=False)
     check_outputs(out, gold, "eval", factor=8.0, floor=5e-6)
+
+
+def test_down_block_with_fused_statistics(be):
+    """A block large enough that the conv is not split along K, so the BatchNorm statistics come out of the conv
+    epilogue (mnk_conv3x3_stats_floats > 0); forward, running stats and all gradients against the oracle in fp64."""
+    from modules.util import DownBlock3D
+    from oracle import restate
+    torch.manual_seed(3)
+    blk = DownBlock3D(5, 12, kernel_size=(1, 3, 3), padding=(0, 1, 1))
+    with torch.no_grad():
+        blk.norm.weight.add_(0.3 * torch.randn(12))
+        blk.norm.bias.add_(0.3 * torch.randn(12))
+    sd = {("blk." + k): v.detach().clone().double() for k, v in blk.state_dict().items()}
+    x = torch.rand(6, 5, 1, 64, 64)
+    for t in sd.values():
+        if t.is_floating_point():
+            t.requires_grad_(True)
+    ctx = restate.Ctx(sd, True)
+    ref = restate.down_block(ctx, restate.fold(x.double()), "blk")
+    g = torch.randn(ref.shape, dtype=torch.float64)
+    (ref * g).sum().backward()
+    blk.to(be.device).train()
+    out = blk(be.t(x))
+    (out * be.t(restate.unfold(g.float(), 6))).sum().backward()
+    be.sync()
+    assert float((out.detach().cpu()[:, :, 0].double() - ref).abs().max()) < 2e-5
+    for k in ("conv.weight", "norm.weight", "norm.bias"):
+        a, b = dict(blk.named_parameters())[k].grad.cpu().double(), sd["blk." + k].grad
+        assert float((a - b).norm() / b.norm()) < 1e-4, k
+    assert float((blk.norm.running_var.cpu().double() - ctx.new_stats["blk.norm.running_var"]).abs().max()) < 1e-5

@@ -27,6 +27,9 @@ def timeit(fn, iters):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+STATS = bool(int(os.environ.get('CB_STATS', '0')))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="taichi")
@@ -54,7 +57,7 @@ def main():
             dy = torch.randn(frames, h, w, ops.ceil4(cout), device=dev)
             fl = 2.0 * 9 * cin * cout * h * w * frames
             wp = ops._packed_fwd_weight(wt, cout, cin, 0)
-            t_f = timeit(lambda: ops._conv_launch(x, cin, None, 0, ups, wp, bias, None, frames, h, w, cout), args.iters)
+            t_f = timeit(lambda: ops._conv_launch(x, cin, None, 0, ups, wp, bias, None, frames, h, w, cout, STATS), args.iters)
             npk = ops._query("mnk_conv3x3_packed_floats", cin, cout, 0)
             wpd = torch.empty(npk, device=dev)
             ops._call("mnk_conv3x3_pack_dgrad", dy, wt.data_ptr(), wpd.data_ptr(), cout, cin, 0, cin)
