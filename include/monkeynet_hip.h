@@ -62,6 +62,12 @@ int mnk_resize_nearest(const float* src, int ld_src, int Hs, int Ws, float* dst,
                        int Wd, int N, int C, void* stream);
 int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
                            int Hs, int Ws, int N, int C, void* stream);
+/* the same with bilinear, align_corners=False weights (interpolation_mode='trilinear' with unchanged depth, vox configs);
+ * the adjoint ACCUMULATES into dsrc (zero it first) */
+int mnk_resize_bilinear(const float* src, int ld_src, int Hs, int Ws, float* dst, int ld_dst, int dst_off, int Hd,
+                        int Wd, int N, int C, void* stream);
+int mnk_resize_bilinear_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                            int Hs, int Ws, int N, int C, void* stream);
 
 /* ---- BatchNorm (sync_batchnorm/batchnorm.py:48-78,113-125; F.batch_norm semantics: (var+eps)^-1/2) -------
  * statistics: sums[0..C) = sum x, sums[C..2C) = sum x^2 over `rows` pixels.  The caller may all-reduce

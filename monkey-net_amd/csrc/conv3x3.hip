@@ -527,18 +527,24 @@ static int env_int(const char* name, int dflt) {
 }
 static int g_split_tiles = env_int("MNK_SPLIT_TILES", 192), g_split_target = env_int("MNK_SPLIT_TARGET", 512),
            g_split_minsteps = env_int("MNK_SPLIT_MINSTEPS", 6);
-// 1: split-K partial tiles of the weight gradient are accumulated with fp32 atomics into the (zeroed) gradient --
-// halves the HBM traffic of the shallow layers and drops the reduce launch; 0: deterministic partials + reduce
-static int g_wgrad_atomic = env_int("MNK_WGRAD_ATOMIC", 1);
+// 0 (default): deterministic split-K partials + reduce kernel; 1: accumulate the partial tiles with fp32 atomics into
+// the zeroed gradient (no partial buffer / reduce launch).  Measured equal on the MI355X (21.74 ms per training
+// iteration either way: the atomics cost the wgrad kernel what the reduce kernel saves), so determinism wins.
+static int g_wgrad_atomic = env_int("MNK_WGRAD_ATOMIC", 0);
 static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = env_int("MNK_WSPLIT_TARGET", 1024),
            g_wsplit_minsteps = env_int("MNK_WSPLIT_MINSTEPS", 8);
 
+// mid-size layers (fewer than ~2 blocks per CU with 128-row tiles) use 64-row tiles: twice the blocks, so every SIMD
+// has a second wave to overlap loads with MFMA, and less (or no) split-K
+static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
+
 static Plan make_plan(long M, int Cout, int chunks) {
     Plan p;
-    p.bm = 128;
     p.bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-    p.gm = ceil_div(M, p.bm);
     p.gn = ceil_div(Cout, p.bn);
+    p.bm = 128;
+    if (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn < g_bm64_tiles) p.bm = 64;
+    p.gm = ceil_div(M, p.bm);
     p.ksteps = 9 * chunks;
     long tiles = (long)p.gm * p.gn;
     int splits = 1;
@@ -677,10 +683,14 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     dim3 grid(p.gm, p.gn, p.splits);
     {
         ProfScope prof(K_CONV_FWD, s, 2.0 * (double)a.M * Cout * 9.0 * (C0 + C1));
-        if (p.bn == 128)
+        if (p.bn == 128 && p.bm == 128)
             hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
-        else if (p.bn == 64)
+        else if (p.bn == 128)
+            hipLaunchKernelGGL((conv3x3_igemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, a);
+        else if (p.bn == 64 && p.bm == 128)
             hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, a);
+        else if (p.bn == 64)
+            hipLaunchKernelGGL((conv3x3_igemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a);
         else
             hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
     }

@@ -139,6 +139,70 @@ __global__ void __launch_bounds__(256) resize_nearest_bwd_kernel(const float* __
     }
 }
 
+// bilinear resize with align_corners=False (ATen upsample_bilinear2d / 'trilinear' with unchanged depth):
+// source index = max(0, scale*(dst+0.5)-0.5), used for the key-point embedding when interpolation_mode='trilinear'
+// (generator.py:72, vox configs)
+struct Lin1D {
+    int i0, i1;
+    float l0, l1;
+    __device__ __forceinline__ void setup(int dst, int in_size, int out_size) {
+        const float scale = (float)in_size / (float)out_size;
+        float src = scale * ((float)dst + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+        i0 = (int)src;
+        if (i0 > in_size - 1) i0 = in_size - 1;
+        i1 = i0 < in_size - 1 ? i0 + 1 : i0;
+        l1 = src - (float)i0;
+        l0 = 1.f - l1;
+    }
+};
+
+__global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __restrict__ src, int ld_src, int Hs, int Ws,
+                                                              float* __restrict__ dst, int ld_dst, int dst_off, int Hd,
+                                                              int Wd, int N, int C) {
+    const long total = (long)N * Hd * Wd * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int w = (int)(p % Wd);
+        long t = p / Wd;
+        int h = (int)(t % Hd);
+        int n = (int)(t / Hd);
+        Lin1D ly, lx;
+        ly.setup(h, Hs, Hd);
+        lx.setup(w, Ws, Wd);
+        const float* sb = src + (long)n * Hs * Ws * ld_src + c;
+        const float v00 = sb[((long)ly.i0 * Ws + lx.i0) * ld_src], v01 = sb[((long)ly.i0 * Ws + lx.i1) * ld_src];
+        const float v10 = sb[((long)ly.i1 * Ws + lx.i0) * ld_src], v11 = sb[((long)ly.i1 * Ws + lx.i1) * ld_src];
+        dst[p * ld_dst + dst_off + c] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    }
+}
+
+// adjoint: scatter with fp32 atomics into the zero-initialised source gradient
+__global__ void __launch_bounds__(256) resize_bilinear_bwd_kernel(const float* __restrict__ ddst, int ld_dst,
+                                                                  int dst_off, int Hd, int Wd,
+                                                                  float* __restrict__ dsrc, int ld_src, int Hs, int Ws,
+                                                                  int N, int C) {
+    const long total = (long)N * Hd * Wd * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int w = (int)(p % Wd);
+        long t = p / Wd;
+        int h = (int)(t % Hd);
+        int n = (int)(t / Hd);
+        Lin1D ly, lx;
+        ly.setup(h, Hs, Hd);
+        lx.setup(w, Ws, Wd);
+        const float g = ddst[p * ld_dst + dst_off + c];
+        float* sb = dsrc + (long)n * Hs * Ws * ld_src + c;
+        atomicAdd(sb + ((long)ly.i0 * Ws + lx.i0) * ld_src, g * ly.l0 * lx.l0);
+        atomicAdd(sb + ((long)ly.i0 * Ws + lx.i1) * ld_src, g * ly.l0 * lx.l1);
+        atomicAdd(sb + ((long)ly.i1 * Ws + lx.i0) * ld_src, g * ly.l1 * lx.l0);
+        atomicAdd(sb + ((long)ly.i1 * Ws + lx.i1) * ld_src, g * ly.l1 * lx.l1);
+    }
+}
+
 static inline int grid_for(long total, int cap = 2048) {
     long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -214,6 +278,32 @@ int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, i
     ProfScope prof(K_LAYOUT, s, (double)total * 8);
     hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, ddst, ld_dst, dst_off, Hd, Wd,
                        dsrc, ld_src, Hs, Ws, N, C);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_resize_bilinear(const float* src, int ld_src, int Hs, int Ws, float* dst, int ld_dst, int dst_off, int Hd,
+                        int Wd, int N, int C, void* stream) {
+    MNK_REQUIRE(src && dst && N > 0 && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && ld_src >= C &&
+                dst_off >= 0 && dst_off + C <= ld_dst);
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)N * Hd * Wd * C;
+    ProfScope prof(K_LAYOUT, s, (double)total * 8);
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, s, src, ld_src, Hs, Ws, dst, ld_dst,
+                       dst_off, Hd, Wd, N, C);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_resize_bilinear_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                            int Hs, int Ws, int N, int C, void* stream) {
+    MNK_REQUIRE(ddst && dsrc && N > 0 && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && ld_src >= C &&
+                dst_off >= 0 && dst_off + C <= ld_dst);
+    hipStream_t s = (hipStream_t)stream;
+    long total = (long)N * Hd * Wd * C;
+    ProfScope prof(K_LAYOUT, s, (double)total * 8);
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, ddst, ld_dst, dst_off, Hd,
+                       Wd, dsrc, ld_src, Hs, Ws, N, C);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

@@ -6,7 +6,7 @@ import copy
 
 def _cfg(num_kp, be, mx, nb_kp, nb_gen, nb_dm, *, kp_scale=1, dm_scale=1, emb_scale=None, clip=0.001, norm=100,
          use_difference=False, group_blocks=2, refinement=4, disc_be=32, disc_mx=256, interpolation='nearest',
-         rec_weights=(10, 10, 10, 10, 1), lr=2.0e-4):
+         rec_weights=(10, 10, 10, 10, 1), rec_def=0, lr=2.0e-4):
     mask = {"use_heatmap": True, "use_deformed_source_image": True, "heatmap_type": "difference", "norm_const": norm}
     if use_difference:
         mask["use_difference"] = True
@@ -33,7 +33,7 @@ def _cfg(num_kp, be, mx, nb_kp, nb_gen, nb_dm, *, kp_scale=1, dm_scale=1, emb_sc
             "discriminator_params": {"kp_embedding_params": {"norm_const": norm}, "block_expansion": disc_be,
                                      "max_features": disc_mx, "num_blocks": 4}},
         "train_params": {"detach_kp_generator": False, "detach_kp_discriminator": True, "lr": lr,
-                         "loss_weights": {"reconstruction": list(rec_weights), "reconstruction_deformed": 0,
+                         "loss_weights": {"reconstruction": list(rec_weights), "reconstruction_deformed": rec_def,
                                           "generator_gan": 1, "discriminator_gan": 1}},
     }
 
@@ -45,6 +45,11 @@ CONFIGS = {
     "moving-gif": _cfg(10, 32, 1024, 5, 6, 5, kp_scale=0.5, dm_scale=0.5, emb_scale=0.5, use_difference=True),
     # config/shapes.yaml: 4 kp, narrow nets, no variance clipping, no group blocks
     "shapes": _cfg(4, 16, 128, 5, 5, 5, clip=None, norm=10, group_blocks=0, rec_weights=(10, 10, 10, 10, 1)),
+    # config/bair.yaml (= nemo.yaml up to the normaliser): 512 features, 'sum'-normalised heat-maps, warped-frame loss
+    "bair": _cfg(10, 32, 512, 5, 5, 5, norm="sum", rec_def=10),
+    "nemo": _cfg(10, 32, 512, 5, 5, 5),
+    # config/vox.yaml: 256x256, 7-level generator, sub-networks at quarter resolution, 'trilinear' field / embedding resize
+    "vox": _cfg(10, 32, 1024, 5, 7, 5, kp_scale=0.25, dm_scale=0.25, emb_scale=0.25, interpolation="trilinear"),
 }
 
 

@@ -134,3 +134,46 @@ class TrainStep:
             self.opt_k.step()
             self.opt_k.zero_grad()
         return [v.detach() for v in loss_values], [v.detach() for v in d_values], generated
+
+
+class Reconstructor:
+    """Batched eval-mode frame generation -- what reconstruction.py:12-25,57-61 / transfer.py:65-79 do frame by frame:
+    key-points of the source and of every driving frame, then one generator call per (source, driving) pair.  In eval
+    mode BatchNorm uses running statistics, so frames are independent and (video, frame) folds into the batch.  With
+    use_graph the whole forward (kp detector x2 + generator, ~250 launches) is captured once as a hipGraph and
+    replayed per batch (BASELINE config 5: "hipGraph-captured generator forward")."""
+
+    def __init__(self, kp_detector, generator, use_graph=False):
+        self.kp_detector, self.generator = kp_detector.eval(), generator.eval()
+        self.use_graph = bool(use_graph)
+        self._graph = None
+        self._static_in = None
+        self._static_out = None
+
+    @torch.no_grad()
+    def _forward(self, source, driving):
+        kp_source = self.kp_detector(source)
+        kp_driving = self.kp_detector(driving)
+        out = self.generator(source, kp_driving=kp_driving, kp_source=kp_source)
+        return {"video_prediction": out["video_prediction"], "video_deformed": out["video_deformed"],
+                "kp_driving_mean": kp_driving["mean"], "kp_source_mean": kp_source["mean"]}
+
+    def __call__(self, source, driving):
+        if not self.use_graph:
+            return self._forward(source, driving)
+        if self._graph is None or self._static_in[0].shape != source.shape:
+            self._static_in = (source.clone(), driving.clone())
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._forward(*self._static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static_out = self._forward(*self._static_in)
+        self._static_in[0].copy_(source, non_blocking=True)
+        self._static_in[1].copy_(driving, non_blocking=True)
+        self._graph.replay()
+        return self._static_out

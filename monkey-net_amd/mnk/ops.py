@@ -515,10 +515,7 @@ class WarpSkipFn(torch.autograd.Function):
         out = torch.zeros(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
         _call("mnk_deform_fwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(out), out.shape[-1], 0, n)
         if emb is not None:
-            if mode != 0:
-                raise NotImplementedError("interpolation_mode='trilinear' for the key-point embedding resize "
-                                          "(vox configs) is not built yet")
-            _call("mnk_resize_nearest", inp, _p(emb), emb.shape[-1], emb.shape[1], emb.shape[2], _p(out), out.shape[-1], c,
+            _call("mnk_resize_nearest" if mode == 0 else "mnk_resize_bilinear", inp, _p(emb), emb.shape[-1], emb.shape[1], emb.shape[2], _p(out), out.shape[-1], c,
                   h, w, n, ke)
         ctx.save_for_backward(inp, field, emb)
         ctx.meta = (c, ke, mode)
@@ -539,7 +536,7 @@ class WarpSkipFn(torch.autograd.Function):
         demb = None
         if emb is not None and ctx.needs_input_grad[2]:
             demb = torch.zeros_like(emb)
-            _call("mnk_resize_nearest_bwd", inp, _p(dout), dout.shape[-1], c, h, w, _p(demb), emb.shape[-1], emb.shape[1],
+            _call("mnk_resize_nearest_bwd" if mode == 0 else "mnk_resize_bilinear_bwd", inp, _p(dout), dout.shape[-1], c, h, w, _p(demb), emb.shape[-1], emb.shape[1],
                   emb.shape[2], n, ke)
         return dinp, dfield, demb, None, None, None
 

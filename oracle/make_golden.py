@@ -187,7 +187,7 @@ def relerr(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-6))
 
 
-def module_case(ref, name, cfg, batch, size, store_weights, smooth=True, grad_keys=None):
+def module_case(ref, name, cfg, batch, size, store_weights, smooth=True, grad_keys=None, compact=False):
     """Goldens = the reference run in fp32 (what a user of the reference gets) AND in fp64 (the arbiter).
     The restatement is pinned against the reference in fp64, where implementation noise vanishes."""
     gen, disc, kpd, init_sums = build_reference(ref, cfg)
@@ -225,8 +225,13 @@ def module_case(ref, name, cfg, batch, size, store_weights, smooth=True, grad_ke
             check("%s.%s.%s restate64-vs-ref64" % (name, mode, k), o64[k], m64[k], 1e-7)
             REPORT.append(("%s.%s.%s ref32-vs-ref64 (info)" % (name, mode, k), maxdiff(o32[k], o64[k]), float("inf")))
             REPORT.append(("%s.%s.%s restate32-vs-ref64 (info)" % (name, mode, k), maxdiff(m32[k], o64[k]), float("inf")))
-        out[mode] = o32
-        out[mode + "64"] = o64
+        if compact:   # large frames: keep the fp64 run (rounded to fp32) + the fp32-vs-fp64 spreads only
+            out[mode + "64"] = {k: v.float() for k, v in o64.items()}
+            out[mode + "_spread"] = {k: maxdiff(o32[k], o64[k]) for k in ("kp_mean", "kp_var", "video_prediction",
+                                                                            "video_deformed")}
+        else:
+            out[mode] = o32
+            out[mode + "64"] = o64
         if train:
             worst = 0.0
             for m in ("generator", "kp_detector"):
@@ -317,6 +322,8 @@ def main():
     module_case(ref, "shapes", load_cfg("shapes"), batch=2, size=64, store_weights=False, grad_keys=keys)
     module_case(ref, "taichi", load_cfg("taichi"), batch=2, size=64, store_weights=False, grad_keys=keys[:1])
     module_case(ref, "moving-gif", load_cfg("moving-gif"), batch=2, size=64, store_weights=False, grad_keys=keys[:1])
+    module_case(ref, "bair", load_cfg("bair"), batch=2, size=64, store_weights=False, grad_keys=keys[:1], compact=True)
+    module_case(ref, "vox", load_cfg("vox"), batch=2, size=128, store_weights=False, grad_keys=keys[:1], compact=True)
     step_case(ref, "step_tiny", cases.TINY, batch=2, size=32)
     width = max(len(r[0]) for r in REPORT)
     with open(os.path.join(GOLD, "RESTATEMENT_REPORT.txt"), "w") as f:

@@ -131,3 +131,25 @@ def test_copy_channels_and_resize(be):
         sr = s.clone().requires_grad_(True)
         F.interpolate(sr, size=(hd, wd), mode="nearest").backward(dd)
         assert maxerr(DS.cpu()[..., :3].permute(0, 3, 1, 2), sr.grad) < 1e-6
+
+
+def test_resize_bilinear(be):
+    """interpolation_mode='trilinear' resize of the key-point embedding (generator.py:72) == F.interpolate bilinear,
+    align_corners=False, forward and adjoint."""
+    g = torch.Generator().manual_seed(5)
+    for (hs, ws, hd, wd) in ((16, 16, 4, 4), (8, 8, 32, 32), (16, 16, 1, 1), (6, 6, 6, 6)):
+        s = torch.randn(2, 3, hs, ws, generator=g)
+        S = be.t(to_nhwc(s))
+        O = be.zeros(2, hd, wd, 8)
+        be.call("mnk_resize_bilinear", S, 4, hs, ws, O, 8, 2, hd, wd, 2, 3)
+        sr = s.double().requires_grad_(True)
+        ref = F.interpolate(sr, size=(hd, wd), mode="bilinear", align_corners=False)
+        dd = torch.randn(2, 3, hd, wd, generator=g)
+        ref.backward(dd.double())
+        DD = be.zeros(2, hd, wd, 8)
+        DD[..., 2:5] = be.t(dd.permute(0, 2, 3, 1))
+        DS = be.zeros(2, hs, ws, 4)
+        be.call("mnk_resize_bilinear_bwd", DD, 8, 2, hd, wd, DS, 4, hs, ws, 2, 3)
+        be.sync()
+        assert maxerr(O.cpu()[..., 2:5].permute(0, 3, 1, 2), ref) < 2e-6
+        assert maxerr(DS.cpu()[..., :3].permute(0, 3, 1, 2), sr.grad) < 1e-5

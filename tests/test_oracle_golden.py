@@ -75,7 +75,7 @@ def test_flop_model_matches_survey():
     sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "monkey-net_amd"))
     from mnk import configs
     for name, size, total in (("taichi", 64, 9.470), ("moving-gif", 64, 5.116), ("moving-gif", 128, 20.465),
-                              ("shapes", 64, 1.892)):
+                              ("shapes", 64, 1.892), ("bair", 64, 8.867), ("vox", 256, 64.404)):
         f = restate.conv_flops_hot_path(configs.get(name), size, size)
         assert abs(f["total"] / 1e9 - total) < 2e-3, (name, f["total"])
 

@@ -11,6 +11,7 @@ fi
 timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 300 > "$OUT/pytest_gpu.log" 2>&1; echo "pytest rc=$?" | tee -a "$OUT/summary.txt"
 tail -3 "$OUT/pytest_gpu.log" | tee -a "$OUT/summary.txt"; grep -E "^E  |FAILED" "$OUT/pytest_gpu.log" | head -10 | tee -a "$OUT/summary.txt"
 timeout 600 python bench.py --steps 20 --warmup 5 ${BENCH_ARGS} > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?" | tee -a "$OUT/summary.txt"
+timeout 300 python tools/infer_bench.py > "$OUT/infer_bench.json" 2> "$OUT/infer_bench.err"; cat "$OUT/infer_bench.json" | tee -a "$OUT/summary.txt"; tail -2 "$OUT/infer_bench.err" | cut -c1-200 | tee -a "$OUT/summary.txt"
 timeout 400 python bench.py --config taichi --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_taichi.json" 2> "$OUT/bench_taichi.err"
 python - "$OUT" <<'PY' | tee -a "$OUT/summary.txt"
 import json, sys
