@@ -58,43 +58,80 @@ def combine_bn_stats(sums, count):
 
 
 class GradAverager:
-    """Bucketed gradient averaging over ranks.
+    """Bucketed gradient averaging over ranks, overlapped with backward.
 
-    Gradients are copied into flat fp32 buckets of ~`bucket_mb` MB (fewer, larger collectives: xGMI rings are
-    per-link bound), each bucket is all-reduced asynchronously as soon as it is filled, and the averaged values are
-    copied back.  Parameters without a gradient are skipped (e.g. the discriminator in an inference-only step)."""
+    Parameters are assigned (in reverse registration order ~ the order backward produces them) to flat fp32 buckets of
+    ~`bucket_mb` MB -- fewer, larger collectives: xGMI rings are per-link bound.  `arm()` before backward; a
+    post-accumulate-grad hook launches a bucket's asynchronous all-reduce as soon as its last gradient has been
+    written, so the exchange of early buckets runs under the rest of backward; `average()` after backward launches
+    whatever is left (parameters that received no gradient are skipped), waits, divides by the world size and copies
+    the averaged values back.  Launch order is a pure function of the autograd graph, hence identical on all ranks.
+    Replaces DataParallel's implicit reduce-add + per-forward parameter broadcast (train.py:104-105)."""
 
-    def __init__(self, params, bucket_mb=64.0):
+    def __init__(self, params, bucket_mb=64.0, overlap=None):
         self.params = [p for p in params if p.requires_grad]
-        self.bucket_elems = int(bucket_mb * 1024 * 1024 / 4)
+        limit = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel()
+            if size >= limit:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._pending = [0] * len(self.buckets)
+        self._launched = [None] * len(self.buckets)
+        self._armed = False
+        if overlap is None:
+            overlap = os.environ.get("MNK_GRAD_OVERLAP", "1") == "1"
+        self.overlap = overlap
+        self._hooks = []
+        if overlap:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _enabled(self):
+        return initialized() and (world_size() > 1 or _FORCE)
+
+    def arm(self):
+        """Call right before backward()."""
+        self._armed = self._enabled() and self.overlap
+        self._pending = [len(b) for b in self.buckets]
+        self._launched = [None] * len(self.buckets)
+
+    def _launch(self, i):
+        ps = [p for p in self.buckets[i] if p.grad is not None]
+        if not ps:
+            self._launched[i] = ()
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        work = tdist.all_reduce(flat, op=tdist.ReduceOp.SUM, async_op=True)
+        self._launched[i] = (work, flat, ps)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0 and self._launched[i] is None:
+            self._launch(i)
 
     def average(self):
-        if not initialized() or (world_size() == 1 and not _FORCE):
+        """Call after backward(), before optimizer.step().  Returns the number of averaged parameters."""
+        self._armed = False
+        if not self._enabled():
             return 0
         ws = float(world_size())
-        pending = []
-        bucket, size = [], 0
-
-        def flush():
-            nonlocal bucket, size
-            if not bucket:
-                return
-            flat = torch.cat([p.grad.reshape(-1) for p in bucket])
-            work = tdist.all_reduce(flat, op=tdist.ReduceOp.SUM, async_op=True)
-            pending.append((work, flat, bucket))
-            bucket, size = [], 0
-
         n = 0
-        for p in reversed(self.params):          # roughly the order in which backward produced them
-            if p.grad is None:
+        for i in range(len(self.buckets)):
+            if self._launched[i] is None:
+                self._launch(i)
+        for item in self._launched:
+            if not item:
                 continue
-            bucket.append(p)
-            size += p.grad.numel()
-            n += 1
-            if size >= self.bucket_elems:
-                flush()
-        flush()
-        for work, flat, ps in pending:
+            work, flat, ps = item
             work.wait()
             flat.div_(ws)
             off = 0
@@ -102,6 +139,8 @@ class GradAverager:
                 k = p.grad.numel()
                 p.grad.copy_(flat[off:off + k].view_as(p.grad))
                 off += k
+            n += len(ps)
+        self._launched = [None] * len(self.buckets)
         return n
 
 

@@ -113,10 +113,20 @@ class TrainStep:
 
     def _eager_step(self, x, set_to_none=True):
         tp = self.tp
-        out = self.gfull(x)
-        loss_values = [v.mean() for v in out[:-2]]
-        generated, kp_joined = out[-2], out[-1]
-        sum(loss_values).backward(retain_graph=not tp['detach_kp_discriminator'])
+        # The generator pass back-propagates THROUGH the discriminator but the reference throws the discriminator's own
+        # weight gradients of this pass away (optimizer_discriminator.zero_grad(), train.py:120): do not compute them.
+        d_params = list(self.discriminator.parameters())
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            out = self.gfull(x)
+            loss_values = [v.mean() for v in out[:-2]]
+            generated, kp_joined = out[-2], out[-1]
+            self.avg_gk.arm()
+            sum(loss_values).backward(retain_graph=not tp['detach_kp_discriminator'])
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
         self.avg_gk.average()
         self.opt_g.step()
         self.opt_g.zero_grad()
@@ -125,6 +135,9 @@ class TrainStep:
             self.opt_k.step()
             self.opt_k.zero_grad()
         d_values = [v.mean() for v in self.dfull(x, kp_joined, generated)]
+        self.avg_d.arm()
+        if not tp['detach_kp_discriminator']:
+            self.avg_k.arm()
         sum(d_values).backward()
         self.avg_d.average()
         self.opt_d.step()

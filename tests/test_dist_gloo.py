@@ -107,3 +107,37 @@ def test_grad_averager_and_shard_batch_single_process():
     assert mdist.world_size() == 1 and mdist.rank() == 0 and not mdist.active()
     x = torch.arange(8)
     assert mdist.shard_batch(x) is x
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mnk import dist as mdist
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    unused = torch.nn.Parameter(torch.ones(4))                        # never receives a gradient
+    params = list(lin.parameters()) + [unused]
+    for overlap in (True, False):
+        avg = mdist.GradAverager(params, bucket_mb=1e-4, overlap=overlap)    # ~26 floats per bucket: several buckets
+        assert len(avg.buckets) >= 3
+        for p in params:
+            p.grad = None
+        x = torch.full((4, 7), float(rank + 1))
+        avg.arm()
+        lin(x).sum().backward()
+        local = [p.grad.clone() for p in lin.parameters()]
+        n = avg.average()
+        assert n == 6 and unused.grad is None
+        # reference: plain all-reduce of the local gradients
+        for p, g in zip(lin.parameters(), local):
+            dist.all_reduce(g)
+            assert torch.allclose(p.grad, g / world, atol=1e-6)
+        for h in avg._hooks:
+            h.remove()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_gradient_averaging():
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_bucket_worker, args=(2, port, None), nprocs=2, join=True)
