@@ -119,7 +119,7 @@ def _bucket_worker(rank, world, port, out_dir):
     unused = torch.nn.Parameter(torch.ones(4))                        # never receives a gradient
     params = list(lin.parameters()) + [unused]
     for overlap in (True, False):
-        avg = mdist.GradAverager(params, bucket_mb=1e-4, overlap=overlap)    # ~26 floats per bucket: several buckets
+        avg = mdist.GradAverager(params, bucket_mb=4e-5, overlap=overlap)    # ~10 floats per bucket: several buckets
         assert len(avg.buckets) >= 3
         for p in params:
             p.grad = None
