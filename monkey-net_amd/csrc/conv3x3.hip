@@ -494,6 +494,129 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
         }
 }
 
+// ---- weight gradient, LDS-halo form (layers with W >= 16) -------------------------------------------------------
+// One block owns a 64 (co) x 64 (ci) x 9 (taps) slab of dW and walks a range of 64-pixel tiles (TR rows x TC columns of
+// one frame, TC = min(W,64)).  Per tile it stages in LDS (a) the dy tile [64 px][64 co] and (b) the x halo
+// [(TR+2) x (TC+2) px][64 ci] with a ZERO border (image edges and the padding of the convolution), then runs all nine
+// taps out of LDS: B(k = pixel, n = ci) for tap (dy,dx) is the halo row shifted by dy*(TC+2)+dx -- no per-tap global
+// gathers, no masks.  Each wave owns one 32x32 (co, ci) quadrant for all 9 taps = 9 accumulators; per pixel pair it
+// issues 1 + 9 ds_read_b32 and 9 MFMAs.  Loads are ~7 % of a tile's MFMA time, two blocks per CU overlap them.
+struct WgradHaloArgs {
+    const float* x;
+    int ld_x, C, ups;
+    const float* dy;
+    int ld_dy, Cout;
+    int N, H, W;
+    int TR, TC, tiles_w, tiles_per_img;
+    long total_tiles, tiles_per_split;
+    int NT;
+    float* out;
+    long ld_out;
+    int splits;
+};
+
+constexpr int WH_HP = 198;   // max halo pixels: (1+2) x (64+2)
+
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[64][68];        // dy tile  [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Xs[WH_HP][64];     // x halo   [halo pixel][ci]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int cot = wave >> 1, cit = wave & 1;
+    const int fi = lane & 31, fk = lane >> 5;
+    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const int split = blockIdx.z;
+    const long tile_begin = (long)split * a.tiles_per_split;
+    long tile_end = tile_begin + a.tiles_per_split;
+    if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+    const int TC = a.TC, TR = a.TR, HW2 = TC + 2, HP = (TR + 2) * HW2;
+    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+
+    int tapoff[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) tapoff[tp] = (tp / 3 - 1) * HW2 + (tp % 3 - 1);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+    for (long tile = tile_begin; tile < tile_end; ++tile) {
+        const int n = (int)(tile / a.tiles_per_img);
+        const int ti = (int)(tile - (long)n * a.tiles_per_img);
+        const int r0 = (ti / a.tiles_w) * TR, c0 = (ti % a.tiles_w) * TC;
+        __syncthreads();   // previous tile's LDS reads are done
+        // ---- dy tile: pixel q = (q / TC, q % TC), 16 float4 of co per pixel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = (t >> 4) + 16 * j, c4 = t & 15;
+            const int r = q / TC, c = q - r * TC;
+            const int h = r0 + r, w = c0 + c, co = co0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h < a.H && w < a.W && co < a.Cout) {
+                v = *reinterpret_cast<const float4*>(a.dy + (((long)n * a.H + h) * a.W + w) * a.ld_dy + co);
+                const int rem = a.Cout - co;
+                if (rem < 4) {
+                    if (rem < 2) v.y = 0.f;
+                    if (rem < 3) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            *reinterpret_cast<float4*>(&As[q][c4 * 4]) = v;
+        }
+        // ---- x halo with zero border
+        for (int idx = t; idx < HP * 16; idx += 256) {
+            const int hp = idx >> 4, c4 = idx & 15;
+            const int hr = hp / HW2, hc = hp - hr * HW2;
+            const int h = r0 + hr - 1, w = c0 + hc - 1, ci = ci0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h >= 0 && h < a.H && w >= 0 && w < a.W && ci < a.C) {
+                const int hs = a.ups ? h >> 1 : h, wsrc = a.ups ? w >> 1 : w;
+                const float* px = a.x + (((long)n * Hs + hs) * Ws + wsrc) * a.ld_x + ci;
+                const int rem = a.C - ci;
+                if (rem >= 4) {
+                    v = *reinterpret_cast<const float4*>(px);
+                } else {   // ld_x is only guaranteed >= C: read the tail element-wise
+                    v.x = px[0];
+                    if (rem > 1) v.y = px[1];
+                    if (rem > 2) v.z = px[2];
+                }
+            }
+            *reinterpret_cast<float4*>(&Xs[hp][c4 * 4]) = v;
+        }
+        __syncthreads();
+        // ---- 32 pixel pairs x 9 taps
+        int r = 0, c = fk;               // pixel q = 2e + fk  ->  (r, c); TC is even
+        while (c >= TC) {
+            c -= TC;
+            ++r;
+        }
+        for (int e = 0; e < 32; ++e) {
+            const float av = As[2 * e + fk][cot * 32 + fi];
+            const float* xb = &Xs[(r + 1) * HW2 + (c + 1)][cit * 32 + fi];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp)
+                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[tapoff[tp] * 64], acc[tp], 0, 0, 0);
+            c += 2;
+            if (c >= TC) {
+                c -= TC;
+                ++r;
+            }
+        }
+    }
+    const bool partial = a.splits > 1;
+    float* outp = partial ? a.out + (long)split * a.Cout * a.NT : a.out;
+    const long ldo = partial ? (long)a.NT : a.ld_out;
+    const int ci = ci0 + cit * 32 + fi;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int co = co0 + cot * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * fk;
+            if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + tp] = acc[tp][rr];
+        }
+}
+
 // dw[co][c_start*9 + n] = sum_splits partial[s][co][n]
 __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout,
                                                                    int NT, float* __restrict__ dw, long ld_out) {
@@ -564,6 +687,38 @@ struct WPlan {
     int bm, gm, gn, splits;
     long pix_per_split;
 };
+
+// LDS-halo wgrad plan
+struct HPlan {
+    bool use;
+    int TR, TC, tiles_w, tiles_per_img, gm, gn, splits;
+    long total_tiles, tiles_per_split;
+};
+static int g_wgrad_halo = env_int("MNK_WGRAD_HALO", 1), g_whalo_target = env_int("MNK_WHALO_TARGET", 512);
+
+static HPlan make_hplan(int N, int H, int W, int Cout, int C) {
+    HPlan p;
+    p.use = g_wgrad_halo && W >= 16 && (W % 2) == 0 && H >= 2;
+    if (!p.use) return p;
+    p.TC = W < 64 ? W : 64;
+    if (64 % p.TC != 0) {        // widths that do not divide the 64-pixel tile: keep the gather kernel
+        p.use = false;
+        return p;
+    }
+    p.TR = 64 / p.TC;
+    p.tiles_w = ceil_div(W, p.TC);
+    p.tiles_per_img = ceil_div(H, p.TR) * p.tiles_w;
+    p.total_tiles = (long)N * p.tiles_per_img;
+    p.gm = ceil_div(Cout, 64);
+    p.gn = ceil_div(C, 64);
+    long base = (long)p.gm * p.gn;
+    long splits = (g_whalo_target + base - 1) / base;
+    if (splits > p.total_tiles / 4) splits = p.total_tiles / 4;     // >= 4 tiles (256 pixels) per block
+    if (splits < 1) splits = 1;
+    p.tiles_per_split = (p.total_tiles + splits - 1) / splits;
+    p.splits = (int)((p.total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
+    return p;
+}
 
 static WPlan make_wplan(long M, int Cout, int C) {
     WPlan p;
@@ -705,6 +860,8 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
 
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return 0;
+    HPlan hp = make_hplan(N, H, W, Cout, C);
+    if (hp.use) return hp.splits > 1 ? (size_t)hp.splits * Cout * 9 * C : 0;
     WPlan p = make_wplan((long)N * H * W, Cout, C);
     return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)p.splits * Cout * 9 * C : 0;
 }
@@ -714,6 +871,53 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
     MNK_REQUIRE(x && dy && dw && N > 0 && H > 0 && W > 0 && C > 0 && Cout > 0);
     MNK_REQUIRE(ld_x >= C && ld_dy % 4 == 0 && ld_dy >= Cout);
     MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (H % 2 == 0 && W % 2 == 0)));
+    HPlan hp = make_hplan(N, H, W, Cout, C);
+    if (hp.use) {
+        WgradHaloArgs h;
+        h.x = x;
+        h.ld_x = ld_x;
+        h.C = C;
+        h.ups = ups;
+        h.dy = dy;
+        h.ld_dy = ld_dy;
+        h.Cout = Cout;
+        h.N = N;
+        h.H = H;
+        h.W = W;
+        h.TR = hp.TR;
+        h.TC = hp.TC;
+        h.tiles_w = hp.tiles_w;
+        h.tiles_per_img = hp.tiles_per_img;
+        h.total_tiles = hp.total_tiles;
+        h.tiles_per_split = hp.tiles_per_split;
+        h.NT = 9 * C;
+        h.splits = hp.splits;
+        float* dsth = dw + (long)c_start * 9;
+        const long ldh = (long)Cin_total * 9;
+        if (hp.splits > 1) {
+            if (!ws || ws_floats < (size_t)hp.splits * Cout * h.NT) {
+                set_error("mnk_conv3x3_wgrad: workspace too small");
+                return MNK_EWORKSPACE;
+            }
+            h.out = ws;
+            h.ld_out = h.NT;
+        } else {
+            h.out = dsth;
+            h.ld_out = ldh;
+        }
+        hipStream_t sh = (hipStream_t)stream;
+        {
+            ProfScope prof(K_CONV_WGRAD, sh, 2.0 * (double)N * H * W * Cout * 9.0 * C);
+            hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3(hp.gm, hp.gn, hp.splits), dim3(256), 0, sh, h);
+        }
+        if (hp.splits > 1) {
+            ProfScope prof(K_CONV_REDUCE, sh, (double)hp.splits * Cout * h.NT * 4);
+            hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * h.NT * 4, 8192)), dim3(256), 0, sh, ws,
+                               hp.splits, Cout, h.NT, dsth, ldh);
+        }
+        MNK_LAUNCH_CHECK();
+        return MNK_OK;
+    }
     WgradArgs a;
     a.x = x;
     a.ld_x = ld_x;

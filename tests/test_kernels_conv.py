@@ -93,7 +93,16 @@ def test_conv3x3_dgrad(be, case):
         assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
 
 
-@pytest.mark.parametrize("case", CASES)
+# W >= 16: the LDS-halo weight-gradient kernel (64-pixel tiles, zero-bordered halo, 9 taps from LDS)
+HALO_CASES = [
+    (1, 16, 16, 20, 0, 45, 0, False, False),
+    (1, 32, 32, 8, 5, 70, 1, False, False),      # up-sampled sources, two sources, TC = 32
+    (2, 16, 32, 70, 0, 130, 0, False, False),    # 2 ci tiles x 3 co tiles, several splits
+    (1, 6, 64, 3, 0, 10, 0, False, False),       # TC = 64 (one row per tile), H not a multiple of anything
+]
+
+
+@pytest.mark.parametrize("case", CASES + HALO_CASES)
 def test_conv3x3_wgrad(be, case):
     n, h, w, c0, c1, cout, ups, _, _ = case
     x0, x1, wt, b, r = _inputs(case)
