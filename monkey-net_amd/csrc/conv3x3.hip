@@ -258,6 +258,183 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
     }
 }
 
+// ---- narrow-output variant on v_mfma_f32_16x16x4_f32 -----------------------------------------------------------
+// For Cout <= 48 (the 45-channel refinement stack, the 10 / 13-channel heads, dgrad into 45 channels) a 32-wide MFMA
+// tile wastes up to 3/4 of the matrix pipe.  Here the block tile is 128 pixels x BN (16 / 48) channels built from
+// 16x16 tiles: 4 waves x 32 rows, each wave covers all BN columns (2 x BN/16 accumulator tiles of 4 VGPRs).
+// Fragment layout of the 16x16x4 form: lane l holds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; with K-contiguous
+// LDS rows a lane reads the float4 at k = 4*(l>>4) .. +3 and feeds element e to MFMA e (K permuted identically for A
+// and B); D: col = l&15, row = 4*(l>>4) + reg.  Loader, K order, split-K and epilogue semantics are those of the
+// 32x32 kernel above.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BN>
+__global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
+    constexpr int BM = 128, RA = 2, TM = 2, TN = BN / 16;
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_K];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * a.ksteps_per_split;
+    int s_end = s_begin + a.ksteps_per_split;
+    if (s_end > a.ksteps) s_end = a.ksteps;
+    const int lrow = t >> 2, lq = t & 3;
+    int pn[RA], ph[RA], pw[RA];
+    bool pvalid[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        long m = m0 + lrow + 64 * j;
+        pvalid[j] = m < a.M;
+        long mm = pvalid[j] ? m : 0;
+        pw[j] = (int)(mm % a.W);
+        long tt = mm / a.W;
+        ph[j] = (int)(tt % a.H);
+        pn[j] = (int)(tt / a.H);
+    }
+    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+    const long KT = (long)a.ksteps * BK;
+    float4 ra[RA], rb;
+    auto load_step = [&](int s) {
+        const int chunk = s / 9;
+        const int tap = s - chunk * 9;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int cbase = chunk * BK;
+        const float* src;
+        int ld, C;
+        if (cbase < a.C0p) {
+            src = a.x0;
+            ld = a.ld0;
+            C = a.C0;
+        } else {
+            cbase -= a.C0p;
+            src = a.x1;
+            ld = a.ld1;
+            C = a.C1;
+        }
+        const int ch = cbase + lq * 4;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int hh = ph[j] + dy, ww = pw[j] + dx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pvalid[j] && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W && ch < C) {
+                const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
+                v = *reinterpret_cast<const float4*>(src + (((long)pn[j] * Hs + hs) * Ws + wsrc) * ld + ch);
+                const int rem = C - ch;
+                if (rem < 4) {
+                    if (rem < 2) v.y = 0.f;
+                    if (rem < 3) v.z = 0.f;
+                    v.w = 0.f;
+                }
+            }
+            ra[j] = v;
+        }
+        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lrow < BN && n0 + lrow < a.Cout)
+            rb = *reinterpret_cast<const float4*>(a.wp + (long)(n0 + lrow) * KT + (long)s * BK + lq * 4);
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = ra[j];
+        if (lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = rb;
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const int fi = lane & 15, fk = lane >> 4;     // row/col inside a 16-tile, k group 0..3
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+    }
+    __syncthreads();
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) load_step(s + 1);
+        float4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            fa[i] = *reinterpret_cast<const float4*>(&As[buf][wave * 32 + 16 * i + fi][fk * 4]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][16 * j + fi][fk * 4]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+            }
+        if (s + 1 < s_end) store_step(buf ^ 1);
+        __syncthreads();
+    }
+    const bool split_out = a.splits > 1;
+    const long ldo = split_out ? (long)a.ldw : (long)a.ld_y;
+    float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
+    const int co_lim = split_out ? a.ldw : a.ld_y;
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        s1[j] = s2[j] = 0.f;
+        const int co = n0 + 16 * j + fi;
+        const bool c_real = co < a.Cout, c_store = co < co_lim;
+        const float bv = (!split_out && a.bias && c_real) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const long mbase = m0 + wave * 32 + 16 * i + 4 * fk;
+            float rv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rv[r] = (!split_out && a.residual && c_real && mbase + r < a.M) ? a.residual[(mbase + r) * a.ld_res + co]
+                                                                             : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = mbase + r;
+                float v = acc[i][j][r];
+                if (!split_out) v = c_real ? (v + bv) + rv[r] : 0.f;
+                if (c_store && m < a.M) {
+                    obase[m * ldo + co] = v;
+                    s1[j] += v;
+                    s2[j] = fmaf(v, v, s2[j]);
+                }
+            }
+        }
+    }
+    if (a.stats && !split_out) {
+        float* red = &As[0][0][0];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            s1[j] += __shfl_xor(s1[j], 16);
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 16);
+            s2[j] += __shfl_xor(s2[j], 32);
+            if (fk == 0) {
+                red[(wave * 2 + 0) * BN + 16 * j + fi] = s1[j];
+                red[(wave * 2 + 1) * BN + 16 * j + fi] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < a.ld_y) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                t1 += red[(w * 2 + 0) * BN + t];
+                t2 += red[(w * 2 + 1) * BN + t];
+            }
+            float* sp = a.stats + (long)blockIdx.x * 2 * a.ld_y;
+            sp[n0 + t] = t1;
+            sp[a.ld_y + n0 + t] = t2;
+        }
+    }
+}
+
 // Split-K reductions: 64 outputs x 4 split-groups per block -- each thread sums every 4th partial (4x the loads in
 // flight of a one-thread-per-output loop), the groups are combined through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float* __restrict__ ws, int splits, long M,
@@ -495,19 +672,20 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
 }
 
 // ---- weight gradient, LDS-halo form (layers with W >= 16) -------------------------------------------------------
-// One block owns a 64 (co) x 64 (ci) x 9 (taps) slab of dW and walks a range of 64-pixel tiles (TR rows x TC columns of
-// one frame, TC = min(W,64)).  Per tile it stages in LDS (a) the dy tile [64 px][64 co] and (b) the x halo
-// [(TR+2) x (TC+2) px][64 ci] with a ZERO border (image edges and the padding of the convolution), then runs all nine
-// taps out of LDS: B(k = pixel, n = ci) for tap (dy,dx) is the halo row shifted by dy*(TC+2)+dx -- no per-tap global
-// gathers, no masks.  Each wave owns one 32x32 (co, ci) quadrant for all 9 taps = 9 accumulators; per pixel pair it
-// issues 1 + 9 ds_read_b32 and 9 MFMAs.  Loads are ~7 % of a tile's MFMA time, two blocks per CU overlap them.
+// One block owns a 64 (co) x 64 (ci) x 3 (one tap ROW: ky fixed, kx = 0..2) slab of dW and walks a range of 64-pixel
+// tiles (TR rows x TC columns of one frame, TC = min(W,64)).  Per tile it stages in LDS (a) the dy tile [64 px][64 co]
+// and (b) the x rows shifted by ky-1 with one ZERO-bordered column on each side [(TR) x (TC+2) px][64 ci]; the three
+// kx taps are then served from LDS: B(k = pixel, n = ci) for kx is the staged row shifted by kx-1 -- no per-tap global
+// gathers, no masks.  Each wave owns one 32x32 (co, ci) quadrant = 3 accumulators; per pixel pair it issues 1 + 3
+// ds_read_b32 and 3 MFMAs.  Splitting the taps over blockIdx.y triples the block count at the same split-K partial
+// volume (different tap rows write different dW elements), which is what keeps the partial traffic small.
 struct WgradHaloArgs {
     const float* x;
     int ld_x, C, ups;
     const float* dy;
     int ld_dy, Cout;
     int N, H, W;
-    int TR, TC, tiles_w, tiles_per_img;
+    int TR, TC, tiles_w, tiles_per_img, gn;
     long total_tiles, tiles_per_split;
     int NT;
     float* out;
@@ -515,29 +693,27 @@ struct WgradHaloArgs {
     int splits;
 };
 
-constexpr int WH_HP = 198;   // max halo pixels: (1+2) x (64+2)
+constexpr int WH_HP = 72;   // max staged x pixels: TR x (TC+2) = 1x66, 2x34, 4x18
 
-__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
+__global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a) {
     __shared__ __attribute__((aligned(16))) float As[64][68];        // dy tile  [pixel][co]
-    __shared__ __attribute__((aligned(16))) float Xs[WH_HP][64];     // x halo   [halo pixel][ci]
+    __shared__ __attribute__((aligned(16))) float Xs[WH_HP][64];     // x rows   [staged pixel][ci]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int cot = wave >> 1, cit = wave & 1;
     const int fi = lane & 31, fk = lane >> 5;
-    const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+    const int co0 = blockIdx.x * 64;
+    const int ci0 = (blockIdx.y % a.gn) * 64;
+    const int ky = blockIdx.y / a.gn;            // tap row 0..2  (dy = ky - 1)
     const int split = blockIdx.z;
     const long tile_begin = (long)split * a.tiles_per_split;
     long tile_end = tile_begin + a.tiles_per_split;
     if (tile_end > a.total_tiles) tile_end = a.total_tiles;
-    const int TC = a.TC, TR = a.TR, HW2 = TC + 2, HP = (TR + 2) * HW2;
+    const int TC = a.TC, TR = a.TR, HW2 = TC + 2, HP = TR * HW2;
     const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
 
-    int tapoff[9];
+    f32x16 acc[3];
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp) tapoff[tp] = (tp / 3 - 1) * HW2 + (tp % 3 - 1);
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
 
@@ -564,11 +740,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_halo_kernel(WgradHaloArg
             }
             *reinterpret_cast<float4*>(&As[q][c4 * 4]) = v;
         }
-        // ---- x halo with zero border
+        // ---- x rows (shifted by ky-1) with zero border columns / rows outside the frame
         for (int idx = t; idx < HP * 16; idx += 256) {
             const int hp = idx >> 4, c4 = idx & 15;
             const int hr = hp / HW2, hc = hp - hr * HW2;
-            const int h = r0 + hr - 1, w = c0 + hc - 1, ci = ci0 + c4 * 4;
+            const int h = r0 + hr + ky - 1, w = c0 + hc - 1, ci = ci0 + c4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (h >= 0 && h < a.H && w >= 0 && w < a.W && ci < a.C) {
                 const int hs = a.ups ? h >> 1 : h, wsrc = a.ups ? w >> 1 : w;
@@ -585,18 +761,19 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_halo_kernel(WgradHaloArg
             *reinterpret_cast<float4*>(&Xs[hp][c4 * 4]) = v;
         }
         __syncthreads();
-        // ---- 32 pixel pairs x 9 taps
+        // ---- 32 pixel pairs x 3 taps
         int r = 0, c = fk;               // pixel q = 2e + fk  ->  (r, c); TC is even
         while (c >= TC) {
             c -= TC;
             ++r;
         }
+#pragma unroll 4
         for (int e = 0; e < 32; ++e) {
             const float av = As[2 * e + fk][cot * 32 + fi];
-            const float* xb = &Xs[(r + 1) * HW2 + (c + 1)][cit * 32 + fi];
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp)
-                acc[tp] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[tapoff[tp] * 64], acc[tp], 0, 0, 0);
+            const float* xb = &Xs[r * HW2 + c][cit * 32 + fi];      // kx = 0 reads column c-1 (+1 border) = index c
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[64], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, xb[128], acc[2], 0, 0, 0);
             c += 2;
             if (c >= TC) {
                 c -= TC;
@@ -609,11 +786,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_halo_kernel(WgradHaloArg
     const long ldo = partial ? (long)a.NT : a.ld_out;
     const int ci = ci0 + cit * 32 + fi;
 #pragma unroll
-    for (int tp = 0; tp < 9; ++tp)
+    for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
             const int co = co0 + cot * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * fk;
-            if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + tp] = acc[tp][rr];
+            if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + ky * 3 + tp] = acc[tp][rr];
         }
 }
 
@@ -660,10 +837,15 @@ static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = 
 // mid-size layers (fewer than ~2 blocks per CU with 128-row tiles) use 64-row tiles: twice the blocks, so every SIMD
 // has a second wave to overlap loads with MFMA, and less (or no) split-K
 static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
+static int g_mfma16 = env_int("MNK_MFMA16", 1);
 
 static Plan make_plan(long M, int Cout, int chunks) {
     Plan p;
     p.bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    if (g_mfma16) {              // narrow outputs: 16x16x4 MFMA tiles (BN = 16 / 48), see conv3x3_igemm16_kernel
+        if (Cout <= 16) p.bn = 16;
+        else if (Cout > 32 && Cout <= 48) p.bn = 48;
+    }
     p.gn = ceil_div(Cout, p.bn);
     p.bm = 128;
     if (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn < g_bm64_tiles) p.bm = 64;
@@ -694,11 +876,15 @@ struct HPlan {
     int TR, TC, tiles_w, tiles_per_img, gm, gn, splits;
     long total_tiles, tiles_per_split;
 };
-static int g_wgrad_halo = env_int("MNK_WGRAD_HALO", 1), g_whalo_target = env_int("MNK_WHALO_TARGET", 512);
+static int g_wgrad_halo = env_int("MNK_WGRAD_HALO", 1), g_whalo_target = env_int("MNK_WHALO_TARGET", 768),
+           g_whalo_mintiles = env_int("MNK_WHALO_MINTILES", 8);
 
 static HPlan make_hplan(int N, int H, int W, int Cout, int C) {
     HPlan p;
-    p.use = g_wgrad_halo && W >= 16 && (W % 2) == 0 && H >= 2;
+    // measured on the MI355X (profiles/README.md): the halo kernel wins when its 64x64 (co, ci) slab is reasonably
+    // full; narrow layers (3 input channels, 10/13/32 output channels with ragged ci) stay on the gather kernel
+    const double fill = ((double)C / round_up(C, 64)) * ((double)Cout / round_up(Cout, 64));
+    p.use = g_wgrad_halo && W >= 16 && (W % 2) == 0 && H >= 2 && fill >= 0.45;
     if (!p.use) return p;
     p.TC = W < 64 ? W : 64;
     if (64 % p.TC != 0) {        // widths that do not divide the 64-pixel tile: keep the gather kernel
@@ -711,9 +897,9 @@ static HPlan make_hplan(int N, int H, int W, int Cout, int C) {
     p.total_tiles = (long)N * p.tiles_per_img;
     p.gm = ceil_div(Cout, 64);
     p.gn = ceil_div(C, 64);
-    long base = (long)p.gm * p.gn;
+    long base = (long)p.gm * p.gn * 3;                             // x3: one block per tap row
     long splits = (g_whalo_target + base - 1) / base;
-    if (splits > p.total_tiles / 4) splits = p.total_tiles / 4;     // >= 4 tiles (256 pixels) per block
+    if (splits > p.total_tiles / g_whalo_mintiles) splits = p.total_tiles / g_whalo_mintiles;   // tiles per block
     if (splits < 1) splits = 1;
     p.tiles_per_split = (p.total_tiles + splits - 1) / splits;
     p.splits = (int)((p.total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
@@ -796,7 +982,7 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
                     const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
                     int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream) {
     MNK_REQUIRE(x0 && wp && y && N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
-    MNK_REQUIRE(ld0 % 4 == 0 && ld0 >= C0 && ld_y % 4 == 0 && ld_y >= Cout && ld_y <= round_up(Cout, 32));
+    MNK_REQUIRE(ld0 % 4 == 0 && ld0 >= C0 && ld_y % 4 == 0 && ld_y >= Cout && ld_y <= round_up(Cout, 16));
     MNK_REQUIRE(C1 == 0 || (x1 && ld1 % 4 == 0 && ld1 >= C1));
     MNK_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0));
     MNK_REQUIRE(!residual || (ld_res >= Cout));
@@ -838,7 +1024,11 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     dim3 grid(p.gm, p.gn, p.splits);
     {
         ProfScope prof(K_CONV_FWD, s, 2.0 * (double)a.M * Cout * 9.0 * (C0 + C1));
-        if (p.bn == 128 && p.bm == 128)
+        if (p.bn == 16)
+            hipLaunchKernelGGL((conv3x3_igemm16_kernel<16>), grid, dim3(256), 0, s, a);
+        else if (p.bn == 48)
+            hipLaunchKernelGGL((conv3x3_igemm16_kernel<48>), grid, dim3(256), 0, s, a);
+        else if (p.bn == 128 && p.bm == 128)
             hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
         else if (p.bn == 128)
             hipLaunchKernelGGL((conv3x3_igemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, a);
@@ -888,6 +1078,7 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
         h.TC = hp.TC;
         h.tiles_w = hp.tiles_w;
         h.tiles_per_img = hp.tiles_per_img;
+        h.gn = hp.gn;
         h.total_tiles = hp.total_tiles;
         h.tiles_per_split = hp.tiles_per_split;
         h.NT = 9 * C;
@@ -908,7 +1099,7 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
         hipStream_t sh = (hipStream_t)stream;
         {
             ProfScope prof(K_CONV_WGRAD, sh, 2.0 * (double)N * H * W * Cout * 9.0 * C);
-            hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3(hp.gm, hp.gn, hp.splits), dim3(256), 0, sh, h);
+            hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3(hp.gm, hp.gn * 3, hp.splits), dim3(256), 0, sh, h);
         }
         if (hp.splits > 1) {
             ProfScope prof(K_CONV_REDUCE, sh, (double)hp.splits * Cout * h.NT * 4);

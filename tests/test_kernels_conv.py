@@ -95,10 +95,11 @@ def test_conv3x3_dgrad(be, case):
 
 # W >= 16: the LDS-halo weight-gradient kernel (64-pixel tiles, zero-bordered halo, 9 taps from LDS)
 HALO_CASES = [
-    (1, 16, 16, 20, 0, 45, 0, False, False),
-    (1, 32, 32, 8, 5, 70, 1, False, False),      # up-sampled sources, two sources, TC = 32
-    (2, 16, 32, 70, 0, 130, 0, False, False),    # 2 ci tiles x 3 co tiles, several splits
-    (1, 6, 64, 3, 0, 10, 0, False, False),       # TC = 64 (one row per tile), H not a multiple of anything
+    (1, 16, 16, 40, 0, 60, 0, False, False),
+    (1, 32, 32, 60, 50, 64, 1, False, False),    # up-sampled sources, two sources, TC = 32
+    (2, 16, 32, 120, 0, 130, 0, False, False),   # 2 ci tiles x 3 co tiles, several splits
+    (1, 6, 64, 64, 0, 40, 0, False, False),      # TC = 64 (one row per tile), ragged H
+    (1, 16, 16, 20, 0, 45, 0, False, False),     # poorly filled slab -> stays on the gather kernel
 ]
 
 
