@@ -122,6 +122,26 @@ size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout);
 int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
                       int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream);
 
+/* ---- general K x K form of the same kernels (stride 1).  Used for the discriminator's nn.Conv3d((1,4,4)) without
+ * padding (modules/discriminator.py:17-18; SURVEY.md section 8f row 1, the first "next" component): forward
+ * kh = kw = 4, pad = 0; its data gradient is the same kernel on dy with pad = 3 and the flipped pack.
+ * Ho = Hi + 2*pad - kh + 1 (same for W); `ups` views the input through the nearest x2 up-sampling (Hi, Wi are the
+ * up-sampled sizes).  Packed weights: [Cout][chunk][tap][16], tap = ky*kw + kx. */
+size_t mnk_conv2d_packed_floats(int Cout, int C0, int C1, int ntaps);
+int mnk_conv2d_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, int ntaps, void* stream);
+int mnk_conv2d_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, int ntaps,
+                          void* stream);
+size_t mnk_conv2d_workspace_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps);
+size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps);
+int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, int Hi, int Wi, int kh,
+                   int kw, int pad, const float* wp, const float* bias, const float* residual, int ld_res, float* y,
+                   int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats, float* stats_partial,
+                   void* stream);
+size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad);
+int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
+                     int ld_dy, int Cout, float* dw, int Cin_total, int c_start, int N, int Ho, int Wo, float* ws,
+                     size_t ws_floats, void* stream);
+
 /* ---- grouped 1x1 convolution (SameBlock3D, modules/util.py:118, dense_motion_module.py:24-28) ----------- */
 int mnk_gconv1x1_fwd(const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, long rows,
                      int groups, int gsize, void* stream);

@@ -46,10 +46,12 @@ struct ConvArgs {
     int ld_res;
     float* y;
     int ld_y;
-    int N, H, W, Cout;
+    int N, H, W, Cout;   // output frames / height / width / channels
+    int Hi, Wi;          // input height / width (before the optional x2 up-sampling view): H,W for 3x3 pad 1
+    int ntaps, kw, pad;  // kernel taps (kh*kw), kernel width, zero padding (3x3: 9, 3, 1; discriminator 4x4: 16, 4, 0)
     long M;
     int chunks;        // (C0p + C1p) / 16
-    int ksteps;        // 9 * chunks, step s = chunk * 9 + tap
+    int ksteps;        // ntaps * chunks, step s = chunk * ntaps + tap
     int ksteps_per_split;
     int splits;
     float* ws;         // [splits][M][ldw] partial sums when splits > 1
@@ -89,16 +91,16 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
         ph[j] = (int)(tt % a.H);
         pn[j] = (int)(tt / a.H);
     }
-    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
     constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
     const long KT = (long)a.ksteps * BK;     // packed row length
 
     float4 ra[RA], rb[RB];
 
     auto load_step = [&](int s) {
-        const int chunk = s / 9;
-        const int tap = s - chunk * 9;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int chunk = s / a.ntaps;
+        const int tap = s - chunk * a.ntaps;
+        const int dy = tap / a.kw - a.pad, dx = tap % a.kw - a.pad;
         int cbase = chunk * BK;
         const float* src;
         int ld, C;
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
         for (int j = 0; j < RA; ++j) {
             const int hh = ph[j] + dy, ww = pw[j] + dx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pvalid[j] && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W && ch < C) {
+            if (pvalid[j] && hh >= 0 && hh < a.Hi && ww >= 0 && ww < a.Wi && ch < C) {
                 const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
                 v = *reinterpret_cast<const float4*>(src + (((long)pn[j] * Hs + hs) * Ws + wsrc) * ld + ch);
                 const int rem = C - ch;   // pad channels of the producer may hold anything: mask them
@@ -293,13 +295,13 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
         ph[j] = (int)(tt % a.H);
         pn[j] = (int)(tt / a.H);
     }
-    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
     const long KT = (long)a.ksteps * BK;
     float4 ra[RA], rb;
     auto load_step = [&](int s) {
-        const int chunk = s / 9;
-        const int tap = s - chunk * 9;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int chunk = s / a.ntaps;
+        const int tap = s - chunk * a.ntaps;
+        const int dy = tap / a.kw - a.pad, dx = tap % a.kw - a.pad;
         int cbase = chunk * BK;
         const float* src;
         int ld, C;
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
         for (int j = 0; j < RA; ++j) {
             const int hh = ph[j] + dy, ww = pw[j] + dx;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pvalid[j] && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W && ch < C) {
+            if (pvalid[j] && hh >= 0 && hh < a.Hi && ww >= 0 && ww < a.Wi && ch < C) {
                 const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
                 v = *reinterpret_cast<const float4*>(src + (((long)pn[j] * Hs + hs) * Ws + wsrc) * ld + ch);
                 const int rem = C - ch;
@@ -472,14 +474,14 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float*
 
 // ---- weight packing: Wp[row][chunk][tap][16] --------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                                                       int C0, int C1, int C0p, int C1p) {
+                                                       int C0, int C1, int C0p, int C1p, int ntaps) {
     const int Cin = C0 + C1, chunks = (C0p + C1p) / 16;
-    const long total = (long)Cout * chunks * 144;
+    const long total = (long)Cout * chunks * ntaps * 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k16 = (int)(i & 15);
         long t = i >> 4;
-        const int tap = (int)(t % 9);
-        t /= 9;
+        const int tap = (int)(t % ntaps);
+        t /= ntaps;
         const int chunk = (int)(t % chunks);
         const int co = (int)(t / chunks);
         const int k = chunk * 16 + k16;
@@ -489,22 +491,23 @@ __global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__
         } else if (k - C0p < C1) {
             ci = C0 + k - C0p;
         }
-        wp[i] = ci >= 0 ? w[((long)co * Cin + ci) * 9 + tap] : 0.f;
+        wp[i] = ci >= 0 ? w[((long)co * Cin + ci) * ntaps + tap] : 0.f;
     }
 }
 
 __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
-                                                         int Cin_total, int c_start, int c_count, int chunks) {
-    const long total = (long)c_count * chunks * 144;
+                                                         int Cin_total, int c_start, int c_count, int chunks,
+                                                         int ntaps) {
+    const long total = (long)c_count * chunks * ntaps * 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k16 = (int)(i & 15);
         long t = i >> 4;
-        const int tap = (int)(t % 9);
-        t /= 9;
+        const int tap = (int)(t % ntaps);
+        t /= ntaps;
         const int chunk = (int)(t % chunks);
         const int ci = (int)(t / chunks);
         const int co = chunk * 16 + k16;
-        wp[i] = co < Cout ? w[((long)co * Cin_total + c_start + ci) * 9 + (8 - tap)] : 0.f;
+        wp[i] = co < Cout ? w[((long)co * Cin_total + c_start + ci) * ntaps + (ntaps - 1 - tap)] : 0.f;
     }
 }
 
@@ -517,10 +520,11 @@ struct WgradArgs {
     int ld_x, C, ups;
     const float* dy;
     int ld_dy, Cout;
-    int N, H, W;
+    int N, H, W;         // output (dy) geometry
+    int Hi, Wi, ntaps, kw, pad;
     long M;              // pixels
     long pix_per_split;  // multiple of 16
-    int NT;              // 9 * C
+    int NT;              // ntaps * C
     float* out;          // direct / atomic: dw + c_start*9 (row stride ld_out); else partials [splits][Cout][NT]
     long ld_out;
     int splits;
@@ -547,7 +551,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
     const long p_begin = (long)split * a.pix_per_split;
     long p_end = p_begin + a.pix_per_split;
     if (p_end > a.M) p_end = a.M;
-    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
 
     // dy loader: float4 along co
     const int akr = t / A4, ac4 = t % A4;
@@ -556,9 +560,9 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
     const int bn = t & 127, bk2 = t >> 7;
     const int ncol = n0 + bn;
     const bool n_ok = ncol < a.NT;
-    const int ci = n_ok ? ncol / 9 : 0;
-    const int tap = ncol - ci * 9;
-    const int dyb = tap / 3 - 1, dxb = tap % 3 - 1;
+    const int ci = n_ok ? ncol / a.ntaps : 0;
+    const int tap = ncol - ci * a.ntaps;
+    const int dyb = tap / a.kw - a.pad, dxb = tap % a.kw - a.pad;
 
     float4 ra[RA];
     float rb[8];
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
             float v = 0.f;
             if (n_ok && p < p_end) {
                 const int hh = h + dyb, ww = w + dxb;
-                if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) {
+                if (hh >= 0 && hh < a.Hi && ww >= 0 && ww < a.Wi) {
                     const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
                     v = a.x[((nimg * Hs + hs) * Ws + wsrc) * a.ld_x + ci];
                 }
@@ -839,7 +843,7 @@ static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = 
 static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
 static int g_mfma16 = env_int("MNK_MFMA16", 1);
 
-static Plan make_plan(long M, int Cout, int chunks) {
+static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9) {
     Plan p;
     p.bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     if (g_mfma16) {              // narrow outputs: 16x16x4 MFMA tiles (BN = 16 / 48), see conv3x3_igemm16_kernel
@@ -850,7 +854,7 @@ static Plan make_plan(long M, int Cout, int chunks) {
     p.bm = 128;
     if (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn < g_bm64_tiles) p.bm = 64;
     p.gm = ceil_div(M, p.bm);
-    p.ksteps = 9 * chunks;
+    p.ksteps = ntaps * chunks;
     long tiles = (long)p.gm * p.gn;
     int splits = 1;
     if (tiles < g_split_tiles) {
@@ -906,11 +910,11 @@ static HPlan make_hplan(int N, int H, int W, int Cout, int C) {
     return p;
 }
 
-static WPlan make_wplan(long M, int Cout, int C) {
+static WPlan make_wplan(long M, int Cout, int C, int ntaps = 9) {
     WPlan p;
     p.bm = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     p.gm = ceil_div(Cout, p.bm);
-    p.gn = ceil_div(9 * C, 128);
+    p.gn = ceil_div(ntaps * C, 128);
     long tiles = (long)p.gm * p.gn;
     long steps = (M + BK - 1) / BK;
     long splits = 1;
@@ -936,56 +940,63 @@ static inline int grid_for(long total, int cap = 4096) {
 
 extern "C" {
 
-size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1) {
-    if (Cout <= 0 || C0 <= 0 || C1 < 0) return 0;
-    return (size_t)Cout * 9 * (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0));
+// ---- general K x K entry points (3x3 pad 1 of the hot path; 4x4 pad 0 of the discriminator, its data gradient = 4x4 pad 3)
+size_t mnk_conv2d_packed_floats(int Cout, int C0, int C1, int ntaps) {
+    if (Cout <= 0 || C0 <= 0 || C1 < 0 || ntaps <= 0) return 0;
+    return (size_t)Cout * ntaps * (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0));
 }
 
-int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream) {
-    MNK_REQUIRE(w && wp && Cout > 0 && C0 > 0 && C1 >= 0);
+int mnk_conv2d_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, int ntaps, void* stream) {
+    MNK_REQUIRE(w && wp && Cout > 0 && C0 > 0 && C1 >= 0 && ntaps > 0);
     hipStream_t s = (hipStream_t)stream;
     const int C0p = round_up(C0, 16), C1p = C1 > 0 ? round_up(C1, 16) : 0;
-    const long total = (long)Cout * 9 * (C0p + C1p);
+    const long total = (long)Cout * ntaps * (C0p + C1p);
     ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
-    hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, C0, C1, C0p, C1p);
+    hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, C0, C1, C0p, C1p, ntaps);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
 
-int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream) {
+int mnk_conv2d_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, int ntaps,
+                          void* stream) {
     MNK_REQUIRE(w && wp && Cout > 0 && Cin_total > 0 && c_start >= 0 && c_count > 0 && c_start + c_count <= Cin_total);
+    MNK_REQUIRE(ntaps > 0);
     hipStream_t s = (hipStream_t)stream;
     const int chunks = round_up(Cout, 16) / 16;
-    const long total = (long)c_count * chunks * 144;
+    const long total = (long)c_count * chunks * ntaps * 16;
     ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
     hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, Cin_total, c_start,
-                       c_count, chunks);
+                       c_count, chunks, ntaps);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
 
-size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout) {
-    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+size_t mnk_conv2d_workspace_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps) {
+    if (N <= 0 || Ho <= 0 || Wo <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || ntaps <= 0) return 0;
     const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
-    Plan p = make_plan((long)N * H * W, Cout, chunks);
-    return p.splits > 1 ? (size_t)p.splits * N * H * W * p.ldw : 0;
+    Plan p = make_plan((long)N * Ho * Wo, Cout, chunks, ntaps);
+    return p.splits > 1 ? (size_t)p.splits * N * Ho * Wo * p.ldw : 0;
 }
 
-size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout) {
-    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps) {
+    if (N <= 0 || Ho <= 0 || Wo <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || ntaps <= 0) return 0;
     const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
-    Plan p = make_plan((long)N * H * W, Cout, chunks);
+    Plan p = make_plan((long)N * Ho * Wo, Cout, chunks, ntaps);
     return p.splits > 1 ? 0 : (size_t)p.gm * 2 * round_up(Cout, 4);
 }
 
-int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
-                    const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
-                    int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream) {
-    MNK_REQUIRE(x0 && wp && y && N > 0 && H > 0 && W > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
+int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, int Hi, int Wi, int kh,
+                   int kw, int pad, const float* wp, const float* bias, const float* residual, int ld_res, float* y,
+                   int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats, float* stats_partial,
+                   void* stream) {
+    MNK_REQUIRE(x0 && wp && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
+    MNK_REQUIRE(kh > 0 && kw > 0 && pad >= 0 && Hi > 0 && Wi > 0);
+    MNK_REQUIRE(Ho == Hi + 2 * pad - kh + 1 && Wo == Wi + 2 * pad - kw + 1);
     MNK_REQUIRE(ld0 % 4 == 0 && ld0 >= C0 && ld_y % 4 == 0 && ld_y >= Cout && ld_y <= round_up(Cout, 16));
     MNK_REQUIRE(C1 == 0 || (x1 && ld1 % 4 == 0 && ld1 >= C1));
-    MNK_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0));
+    MNK_REQUIRE(!ups || (Hi % 2 == 0 && Wi % 2 == 0));
     MNK_REQUIRE(!residual || (ld_res >= Cout));
+    const int ntaps = kh * kw;
     ConvArgs a;
     a.x0 = x0;
     a.x1 = x1;
@@ -1003,12 +1014,17 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     a.y = y;
     a.ld_y = ld_y;
     a.N = N;
-    a.H = H;
-    a.W = W;
+    a.H = Ho;
+    a.W = Wo;
+    a.Hi = Hi;
+    a.Wi = Wi;
+    a.ntaps = ntaps;
+    a.kw = kw;
+    a.pad = pad;
     a.Cout = Cout;
-    a.M = (long)N * H * W;
+    a.M = (long)N * Ho * Wo;
     a.chunks = (a.C0p + a.C1p) / 16;
-    Plan p = make_plan(a.M, Cout, a.chunks);
+    Plan p = make_plan(a.M, Cout, a.chunks, ntaps);
     a.ksteps = p.ksteps;
     a.ksteps_per_split = p.ksteps_per_split;
     a.splits = p.splits;
@@ -1017,13 +1033,13 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     a.stats = stats_partial;
     MNK_REQUIRE(!stats_partial || (p.splits == 1 && ld_y == round_up(Cout, 4)));
     if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * a.M * p.ldw)) {
-        set_error("mnk_conv3x3_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * a.M * p.ldw);
+        set_error("mnk_conv2d_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * a.M * p.ldw);
         return MNK_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p.gm, p.gn, p.splits);
     {
-        ProfScope prof(K_CONV_FWD, s, 2.0 * (double)a.M * Cout * 9.0 * (C0 + C1));
+        ProfScope prof(K_CONV_FWD, s, 2.0 * (double)a.M * Cout * (double)ntaps * (C0 + C1));
         if (p.bn == 16)
             hipLaunchKernelGGL((conv3x3_igemm16_kernel<16>), grid, dim3(256), 0, s, a);
         else if (p.bn == 48)
@@ -1048,20 +1064,29 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     return MNK_OK;
 }
 
-size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
-    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return 0;
-    HPlan hp = make_hplan(N, H, W, Cout, C);
-    if (hp.use) return hp.splits > 1 ? (size_t)hp.splits * Cout * 9 * C : 0;
-    WPlan p = make_wplan((long)N * H * W, Cout, C);
-    return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)p.splits * Cout * 9 * C : 0;
+size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad) {
+    if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return 0;
+    const int ntaps = kh * kw;
+    if (kh == 3 && kw == 3 && pad == 1) {
+        HPlan hp = make_hplan(N, Ho, Wo, Cout, C);
+        if (hp.use) return hp.splits > 1 ? (size_t)hp.splits * Cout * 9 * C : 0;
+    }
+    WPlan p = make_wplan((long)N * Ho * Wo, Cout, C, ntaps);
+    return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)p.splits * Cout * ntaps * C : 0;
 }
 
-int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
-                      int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream) {
-    MNK_REQUIRE(x && dy && dw && N > 0 && H > 0 && W > 0 && C > 0 && Cout > 0);
+int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
+                     int ld_dy, int Cout, float* dw, int Cin_total, int c_start, int N, int Ho, int Wo, float* ws,
+                     size_t ws_floats, void* stream) {
+    MNK_REQUIRE(x && dy && dw && N > 0 && Ho > 0 && Wo > 0 && C > 0 && Cout > 0 && kh > 0 && kw > 0 && pad >= 0);
+    MNK_REQUIRE(Ho == Hi + 2 * pad - kh + 1 && Wo == Wi + 2 * pad - kw + 1);
     MNK_REQUIRE(ld_x >= C && ld_dy % 4 == 0 && ld_dy >= Cout);
-    MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (H % 2 == 0 && W % 2 == 0)));
-    HPlan hp = make_hplan(N, H, W, Cout, C);
+    MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (Hi % 2 == 0 && Wi % 2 == 0)));
+    const int ntaps = kh * kw;
+    const int H = Ho, W = Wo;
+    HPlan hp;
+    hp.use = false;
+    if (kh == 3 && kw == 3 && pad == 1) hp = make_hplan(N, H, W, Cout, C);
     if (hp.use) {
         WgradHaloArgs h;
         h.x = x;
@@ -1087,7 +1112,7 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
         const long ldh = (long)Cin_total * 9;
         if (hp.splits > 1) {
             if (!ws || ws_floats < (size_t)hp.splits * Cout * h.NT) {
-                set_error("mnk_conv3x3_wgrad: workspace too small");
+                set_error("mnk_conv2d_wgrad: workspace too small");
                 return MNK_EWORKSPACE;
             }
             h.out = ws;
@@ -1120,18 +1145,23 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
     a.N = N;
     a.H = H;
     a.W = W;
+    a.Hi = Hi;
+    a.Wi = Wi;
+    a.ntaps = ntaps;
+    a.kw = kw;
+    a.pad = pad;
     a.M = (long)N * H * W;
-    a.NT = 9 * C;
-    WPlan p = make_wplan(a.M, Cout, C);
+    a.NT = ntaps * C;
+    WPlan p = make_wplan(a.M, Cout, C, ntaps);
     a.pix_per_split = p.pix_per_split;
     a.splits = p.splits;
-    float* dst = dw + (long)c_start * 9;
-    const long ld_out = (long)Cin_total * 9;
+    float* dst = dw + (long)c_start * ntaps;
+    const long ld_out = (long)Cin_total * ntaps;
     hipStream_t s = (hipStream_t)stream;
     a.atomic = g_wgrad_atomic;
     if (p.splits > 1 && !a.atomic) {
         if (!ws || ws_floats < (size_t)p.splits * Cout * a.NT) {
-            set_error("mnk_conv3x3_wgrad: workspace too small");
+            set_error("mnk_conv2d_wgrad: workspace too small");
             return MNK_EWORKSPACE;
         }
         a.out = ws;
@@ -1141,12 +1171,12 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
         a.ld_out = ld_out;
         if (p.splits > 1 &&
             hipMemset2DAsync(dst, (size_t)ld_out * 4, 0, (size_t)a.NT * 4, (size_t)Cout, s) != hipSuccess) {
-            set_error("mnk_conv3x3_wgrad: hipMemset2DAsync failed");
+            set_error("mnk_conv2d_wgrad: hipMemset2DAsync failed");
             return MNK_ELAUNCH;
         }
     }
     {
-        ProfScope prof(K_CONV_WGRAD, s, 2.0 * (double)a.M * Cout * 9.0 * C);
+        ProfScope prof(K_CONV_WGRAD, s, 2.0 * (double)a.M * Cout * (double)ntaps * C);
         if (p.bm == 128)
             hipLaunchKernelGGL((conv3x3_wgrad_kernel<128>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
         else if (p.bm == 64)
@@ -1161,5 +1191,34 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
     }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+// ---- 3x3 / pad 1 forms (the hot path's nn.Conv3d (1,3,3)) ------------------------------------------------------------
+size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1) { return mnk_conv2d_packed_floats(Cout, C0, C1, 9); }
+int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream) {
+    return mnk_conv2d_pack_fwd(w, wp, Cout, C0, C1, 9, stream);
+}
+int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream) {
+    return mnk_conv2d_pack_dgrad(w, wp, Cout, Cin_total, c_start, c_count, 9, stream);
+}
+size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout) {
+    return mnk_conv2d_workspace_floats(N, H, W, C0, C1, Cout, 9);
+}
+size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout) {
+    return mnk_conv2d_stats_floats(N, H, W, C0, C1, Cout, 9);
+}
+int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
+                    const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
+                    int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream) {
+    return mnk_conv2d_fwd(x0, ld0, C0, x1, ld1, C1, ups, H, W, 3, 3, 1, wp, bias, residual, ld_res, y, ld_y, N, H, W, Cout,
+                          ws, ws_floats, stats_partial, stream);
+}
+size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
+    return mnk_conv2d_wgrad_workspace_floats(N, H, W, C, Cout, 3, 3, 1);
+}
+int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
+                      int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream) {
+    return mnk_conv2d_wgrad(x, ld_x, C, ups, H, W, 3, 3, 1, dy, ld_dy, Cout, dw, Cin_total, c_start, N, H, W, ws, ws_floats,
+                            stream);
 }
 }

@@ -166,3 +166,49 @@ def test_conv3x3_fused_bn_statistics(be, case):
     y = from_nhwc(Y.cpu(), cout).double()
     ref = torch.cat([y.sum(dim=(0, 2, 3)), (y * y).sum(dim=(0, 2, 3))])
     assert relerr(sums.cpu(), ref) < 1e-5
+
+
+# ---- general K x K form: the discriminator's (1,4,4) convolutions without padding (modules/discriminator.py:17-18)
+K4_CASES = [(2, 16, 16, 13, 32), (1, 13, 13, 32, 64), (3, 6, 6, 64, 20), (2, 5, 4, 7, 1)]
+
+
+@pytest.mark.parametrize("case", K4_CASES)
+def test_conv4x4_nopad_forward_dgrad_wgrad(be, case):
+    n, hi, wi, cin, cout = case
+    kh = kw = 4
+    ho, wo = hi - 3, wi - 3
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, cin, hi, wi, generator=g)
+    wt = torch.randn(cout, cin, kh, kw, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd, b.double())
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    X, W, ldx, ldy = be.t(to_nhwc(x)), be.t(wt), ceil4(cin), ceil4(cout)
+    # forward
+    wp = be.empty(be.query("mnk_conv2d_packed_floats", cout, cin, 0, 16))
+    be.call("mnk_conv2d_pack_fwd", W, wp, cout, cin, 0, 16)
+    Y = be.empty(n, ho, wo, ldy)
+    nws = be.query("mnk_conv2d_workspace_floats", n, ho, wo, cin, 0, cout, 16)
+    ws = be.empty(max(nws, 1))
+    be.call("mnk_conv2d_fwd", X, ldx, cin, None, 0, 0, 0, hi, wi, kh, kw, 0, wp, be.t(b), None, 0, Y, ldy, n, ho, wo, cout,
+            ws, nws, None)
+    # data gradient: the same kernel on dy, pad = k-1, flipped/transposed pack
+    DY = be.t(to_nhwc(dy.float()))
+    wpd = be.empty(be.query("mnk_conv2d_packed_floats", cin, cout, 0, 16))
+    be.call("mnk_conv2d_pack_dgrad", W, wpd, cout, cin, 0, cin, 16)
+    DX = be.empty(n, hi, wi, ldx)
+    nws2 = be.query("mnk_conv2d_workspace_floats", n, hi, wi, cout, 0, cin, 16)
+    ws2 = be.empty(max(nws2, 1))
+    be.call("mnk_conv2d_fwd", DY, ldy, cout, None, 0, 0, 0, ho, wo, kh, kw, 3, wpd, None, None, 0, DX, ldx, n, hi, wi, cin,
+            ws2, nws2, None)
+    # weight gradient
+    DW = be.empty(cout, cin, kh, kw)
+    nws3 = be.query("mnk_conv2d_wgrad_workspace_floats", n, ho, wo, cin, cout, kh, kw, 0)
+    ws3 = be.empty(max(nws3, 1))
+    be.call("mnk_conv2d_wgrad", X, ldx, cin, 0, hi, wi, kh, kw, 0, DY, ldy, cout, DW, cin, 0, n, ho, wo, ws3, nws3)
+    be.sync()
+    assert relerr(from_nhwc(Y.cpu(), cout), ref) < 2e-6
+    assert relerr(from_nhwc(DX.cpu(), cin), xd.grad) < 2e-6
+    assert relerr(DW.cpu(), wd.grad) < 2e-6
