@@ -98,6 +98,27 @@ int mnk_bn_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz, i
                          int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu, int pool,
                          void* stream);
 
+/* ---- general normalisation forms: `frames` / per_frame = statistics per frame (nn.InstanceNorm3d of the discriminator,
+ * modules/discriminator.py:19-22,29-30: sums [2][frames*C], mean/invstd/scale [frames*C], beta [C]); `slope` selects
+ * the fused activation: < 0 none, 0 ReLU, > 0 LeakyReLU(slope) (discriminator.py:31).  With odd H / W the average pool
+ * drops the last row / column like F.avg_pool3d (discriminator.py:32).  mnk_bn_* above are the frames = 1 forms. */
+size_t mnk_norm_workspace_floats(long rows_per_frame, int frames, int ld);
+int mnk_norm_stats(const float* x, int ld, long rows_per_frame, int frames, int C, float* sums, float* ws,
+                   size_t ws_floats, void* stream);
+int mnk_norm_finalize(const float* sums, double count, const float* gamma, float* running_mean, float* running_var,
+                      float momentum, float eps, int C, int frames, int update_running, float* mean, float* invstd,
+                      float* scale, void* stream);
+int mnk_norm_act_fwd(const float* y, int ld_y, const float* mean, const float* scale, const float* beta, int per_frame,
+                     float* z, int ld_z, int z_off, int N, int H, int W, int C, float slope, int pool, void* stream);
+int mnk_norm_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                           const float* invstd, const float* scale, const float* beta, int per_frame, int N, int H,
+                           int W, int C, float slope, int pool, float* sums, float* ws, size_t ws_floats,
+                           void* stream);
+int mnk_norm_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                           const float* invstd, const float* scale, const float* beta, int per_frame, const float* sums,
+                           double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, float slope,
+                           int pool, void* stream);
+
 /* ---- 3x3 convolution, pad 1, stride 1 (nn.Conv3d (1,3,3): modules/util.py:52-55,79,98,176) -------------
  * implicit GEMM on fp32 MFMA (v_mfma_f32_32x32x2_f32).  The input is the channel concatenation of up to two
  * NHWC sources (torch.cat of modules/util.py:185 never materialised); `ups` = 1 reads both sources through the
@@ -155,6 +176,12 @@ int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy
 int mnk_conv1x1_sigmoid_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B,
                             int D, int H, int W, int Cout, void* stream);
 size_t mnk_conv1x1_workspace_floats(long rows, int Cin, int Cout);
+/* general form: act = 1 sigmoid, 0 linear (the discriminator's score head nn.Conv3d(C, 1, 1), discriminator.py:59,77) */
+int mnk_conv1x1_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B, int D, int H,
+                    int W, int Cout, int act, void* stream);
+int mnk_conv1x1_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout, float* dx,
+                    int ld_dx, float* dw, float* dbias, int B, int D, int H, int W, int Cout, int act, float* ws,
+                    size_t ws_floats, void* stream);
 int mnk_conv1x1_sigmoid_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout,
                             float* dx, int ld_dx, float* dw, float* dbias, int B, int D, int H, int W, int Cout,
                             float* ws, size_t ws_floats, void* stream);

@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) conv1x1_sigmoid_fwd_kernel(const float* _
                                                                   const float* __restrict__ w,
                                                                   const float* __restrict__ bias,
                                                                   float* __restrict__ out, int B, int D, int H, int W,
-                                                                  int Cout) {
+                                                                  int Cout, int act) {
     const long HW = (long)H * W;
     const long rows = (long)B * D * HW;
     for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) conv1x1_sigmoid_fwd_kernel(const float* _
         const long b = f / D;
 #pragma unroll
         for (int c = 0; c < MAXCO; ++c)
-            if (c < Cout) out[((b * Cout + c) * D + d) * HW + hw] = 1.f / (1.f + expf(-acc[c]));
+            if (c < Cout) out[((b * Cout + c) * D + d) * HW + hw] = act ? 1.f / (1.f + expf(-acc[c])) : acc[c];
     }
 }
 
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) conv1x1_sigmoid_bwd_dx_kernel(const float
                                                                      const float* __restrict__ out,
                                                                      const float* __restrict__ dout,
                                                                      float* __restrict__ dx, int ld_dx, int Cin, int B,
-                                                                     int D, int H, int W, int Cout) {
+                                                                     int D, int H, int W, int Cout, int act) {
     const long HW = (long)H * W;
     const long rows = (long)B * D * HW;
     for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) conv1x1_sigmoid_bwd_dx_kernel(const float
             if (c < Cout) {
                 const long o = ((b * Cout + c) * D + d) * HW + hw;
                 const float s = out[o];
-                dp[c] = dout[o] * s * (1.f - s);
+                dp[c] = act ? dout[o] * s * (1.f - s) : dout[o];
             }
         }
         float* xr = dx + r * ld_dx;
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) conv1x1_sigmoid_wgrad_partial_kernel(cons
                                                                             int Cin, const float* __restrict__ out,
                                                                             const float* __restrict__ dout, int B, int D,
                                                                             int H, int W, int Cout, long rows_per_block,
-                                                                            float* __restrict__ partial) {
+                                                                            float* __restrict__ partial, int act) {
     __shared__ float red[MAXCO][256];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 4 row lanes
     const long HW = (long)H * W;
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) conv1x1_sigmoid_wgrad_partial_kernel(cons
                     if (c < Cout) {
                         const long o = ((b * Cout + c) * D + d) * HW + hw;
                         const float s = out[o];
-                        acc[c] = fmaf(dout[o] * s * (1.f - s), xv, acc[c]);
+                        acc[c] = fmaf(act ? dout[o] * s * (1.f - s) : dout[o], xv, acc[c]);
                     }
             }
         }
@@ -607,16 +607,21 @@ int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy
     return MNK_OK;
 }
 
-int mnk_conv1x1_sigmoid_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B,
-                            int D, int H, int W, int Cout, void* stream) {
+int mnk_conv1x1_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B, int D, int H,
+                    int W, int Cout, int act, void* stream) {
     MNK_REQUIRE(x && w && out && B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout <= MAXCO && ld_x >= Cin);
     hipStream_t s = (hipStream_t)stream;
     const long rows = (long)B * D * H * W;
     ProfScope prof(K_CONV1X1, s, (double)rows * (Cin + Cout) * 4);
     hipLaunchKernelGGL(conv1x1_sigmoid_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, s, x, ld_x, Cin, w, bias, out, B, D,
-                       H, W, Cout);
+                       H, W, Cout, act);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_conv1x1_sigmoid_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B,
+                            int D, int H, int W, int Cout, void* stream) {
+    return mnk_conv1x1_fwd(x, ld_x, Cin, w, bias, out, B, D, H, W, Cout, 1, stream);
 }
 
 static long c11_rows_per_block(long rows) {
@@ -633,28 +638,34 @@ size_t mnk_conv1x1_workspace_floats(long rows, int Cin, int Cout) {
     return (size_t)rb * Cout * (Cin + 1);
 }
 
-int mnk_conv1x1_sigmoid_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout,
-                            float* dx, int ld_dx, float* dw, float* dbias, int B, int D, int H, int W, int Cout,
-                            float* ws, size_t ws_floats, void* stream) {
+int mnk_conv1x1_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout, float* dx,
+                    int ld_dx, float* dw, float* dbias, int B, int D, int H, int W, int Cout, int act, float* ws,
+                    size_t ws_floats, void* stream) {
     MNK_REQUIRE(x && w && out && dout && dx && dw && ws && B > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     MNK_REQUIRE(Cout <= MAXCO && ld_x >= Cin && ld_dx >= Cin);
     const long rows = (long)B * D * H * W;
     long rpb = c11_rows_per_block(rows);
     int rb = (int)((rows + rpb - 1) / rpb);
     if (ws_floats < (size_t)rb * Cout * (Cin + 1)) {
-        set_error("mnk_conv1x1_sigmoid_bwd: workspace too small");
+        set_error("mnk_conv1x1_bwd: workspace too small");
         return MNK_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_CONV1X1, s, (double)rows * (2 * Cin + 2 * Cout) * 4);
     hipLaunchKernelGGL(conv1x1_sigmoid_bwd_dx_kernel, dim3(grid_for(rows)), dim3(256), 0, s, w, out, dout, dx, ld_dx, Cin,
-                       B, D, H, W, Cout);
+                       B, D, H, W, Cout, act);
     hipLaunchKernelGGL(conv1x1_sigmoid_wgrad_partial_kernel, dim3(rb), dim3(256), 0, s, x, ld_x, Cin, out, dout, B, D, H,
-                       W, Cout, rpb, ws);
+                       W, Cout, rpb, ws, act);
     hipLaunchKernelGGL(conv1x1_sigmoid_wgrad_final_kernel, dim3(ceil_div(Cout * (Cin + 1), 256)), dim3(256), 0, s, ws, rb,
                        Cin, Cout, dw, dbias);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_conv1x1_sigmoid_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout,
+                            float* dx, int ld_dx, float* dw, float* dbias, int B, int D, int H, int W, int Cout,
+                            float* ws, size_t ws_floats, void* stream) {
+    return mnk_conv1x1_bwd(x, ld_x, Cin, w, out, dout, dx, ld_dx, dw, dbias, B, D, H, W, Cout, 1, ws, ws_floats, stream);
 }
 
 int mnk_motion_field_fwd(const float* pred, int ld, const float* delta, int N, int h, int w, int K, int use_mask,

@@ -315,6 +315,109 @@ def bn_act(y, c, norm, relu=True, pool=False, sums=None):
 # ----------------------------------------------------------------------------------------------------------------
 # grouped 1x1 conv, 1x1 conv + sigmoid
 # ----------------------------------------------------------------------------------------------------------------
+class ConvKxKFn(torch.autograd.Function):
+    """nn.Conv3d((1,k,k)), stride 1, zero padding `pad`, single source -- the discriminator's 4x4 convolutions without
+    padding (modules/discriminator.py:17-18,28) on the same implicit-GEMM kernels; the data gradient is the same
+    kernel on dy with pad k-1-pad and the flipped / transposed pack."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cin, kh, kw, pad):
+        _check_device(x)
+        cout = weight.shape[0]
+        n, hi, wi, ld = x.shape
+        ho, wo = hi + 2 * pad - kh + 1, wi + 2 * pad - kw + 1
+        nt = kh * kw
+        wp = SCRATCH.get("pack", _query("mnk_conv2d_packed_floats", cout, cin, 0, nt), x)
+        _call("mnk_conv2d_pack_fwd", x, _p(weight), _p(wp), cout, cin, 0, nt)
+        y = torch.empty(n, ho, wo, ceil4(cout), dtype=torch.float32, device=x.device)
+        nws = _query("mnk_conv2d_workspace_floats", n, ho, wo, cin, 0, cout, nt)
+        ws = SCRATCH.get("ws", nws, x) if nws else None
+        _call("mnk_conv2d_fwd", x, _p(x), ld, cin, None, 0, 0, 0, hi, wi, kh, kw, pad, _p(wp), _p(bias), None, 0, _p(y),
+              y.shape[-1], n, ho, wo, cout, _p(ws), nws, None)
+        ctx.save_for_backward(x, weight)
+        ctx.meta = (cin, cout, kh, kw, pad, n, hi, wi, ho, wo, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        cin, cout, kh, kw, pad, n, hi, wi, ho, wo, has_bias = ctx.meta
+        dy = dy.contiguous()
+        nt = kh * kw
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = SCRATCH.get("pack", _query("mnk_conv2d_packed_floats", cin, cout, 0, nt), dy)
+            _call("mnk_conv2d_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, 0, cin, nt)
+            dx = torch.empty(n, hi, wi, ceil4(cin), dtype=torch.float32, device=dy.device)
+            nws = _query("mnk_conv2d_workspace_floats", n, hi, wi, cout, 0, cin, nt)
+            ws = SCRATCH.get("ws", nws, dy) if nws else None
+            _call("mnk_conv2d_fwd", dy, _p(dy), dy.shape[-1], cout, None, 0, 0, 0, ho, wo, kh, kw, kh - 1 - pad, _p(wp), None,
+                  None, 0, _p(dx), dx.shape[-1], n, hi, wi, cin, _p(ws), nws, None)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            nws = _query("mnk_conv2d_wgrad_workspace_floats", n, ho, wo, cin, cout, kh, kw, pad)
+            ws = SCRATCH.get("ws", nws, dy) if nws else None
+            _call("mnk_conv2d_wgrad", dy, _p(x), x.shape[-1], cin, 0, hi, wi, kh, kw, pad, _p(dy), dy.shape[-1], cout, _p(dw),
+                  cin, 0, n, ho, wo, _p(ws), nws)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = channel_sums(dy, cout)[:cout]
+        return dx, dw, db, None, None, None, None
+
+
+class InstNormActFn(torch.autograd.Function):
+    """[InstanceNorm3d (affine)] -> LeakyReLU(slope) -> avg_pool (1,2,2) of the discriminator's DownBlock3D
+    (modules/discriminator.py:26-33): per-frame statistics (the time axis is 1 on every call path), one fused pass."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, c, slope, pool, eps):
+        _check_device(y)
+        n, h, w, ld = y.shape
+        dev = y.device
+        has_norm = gamma is not None
+        if has_norm:
+            nws = _query("mnk_norm_workspace_floats", h * w, n, ld)
+            ws = SCRATCH.get("ws", nws, y)
+            sums = torch.empty(2 * n * c, dtype=torch.float32, device=dev)
+            _call("mnk_norm_stats", y, _p(y), ld, h * w, n, c, _p(sums), _p(ws), nws)
+            mean = torch.empty(n * c, dtype=torch.float32, device=dev)
+            invstd, scale = torch.empty_like(mean), torch.empty_like(mean)
+            _call("mnk_norm_finalize", y, _p(sums), float(h * w), _p(gamma), None, None, 0.0, float(eps), c, n, 0, _p(mean),
+                  _p(invstd), _p(scale))
+            bt = beta
+        else:   # first block: no normalisation -> identity affine
+            mean = torch.zeros(c, dtype=torch.float32, device=dev)
+            invstd = torch.ones(c, dtype=torch.float32, device=dev)
+            scale, bt = invstd, mean
+        ho, wo = (h // 2, w // 2) if pool else (h, w)
+        z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
+        _call("mnk_norm_act_fwd", y, _p(y), ld, _p(mean), _p(scale), _p(bt), int(has_norm), _p(z), z.shape[-1], 0, n, h, w, c,
+              float(slope), int(pool))
+        ctx.save_for_backward(y, mean, invstd, scale, bt)
+        ctx.meta = (c, float(slope), pool, has_norm)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, mean, invstd, scale, bt = ctx.saved_tensors
+        c, slope, pool, has_norm = ctx.meta
+        dz = dz.contiguous()
+        n, h, w, ld = y.shape
+        dy = torch.empty_like(y)
+        dgamma = dbeta = None
+        sums = None
+        if has_norm:
+            nws = _query("mnk_norm_workspace_floats", h * w, n, ceil4(c))
+            ws = SCRATCH.get("ws", nws, y)
+            sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
+            _call("mnk_norm_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(bt), 1,
+                  n, h, w, c, slope, int(pool), _p(sums), _p(ws), nws)
+            per = sums.view(2, n, c).sum(dim=1)
+            dbeta, dgamma = per[0], per[1]
+        _call("mnk_norm_act_bwd_apply", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(bt),
+              int(has_norm), _p(sums), float(h * w), int(has_norm), _p(dy), ld, n, h, w, c, slope, int(pool))
+        return dy, dgamma, dbeta, None, None, None, None
+
+
 class GConv1x1Fn(torch.autograd.Function):
     """nn.Conv3d(kernel (1,1,1), groups=num_kp+1) of SameBlock3D (dense_motion_module.py:24-28)."""
 
@@ -351,24 +454,25 @@ class GConv1x1Fn(torch.autograd.Function):
 
 
 class Conv1x1SigmoidFn(torch.autograd.Function):
-    """refinement_module['conv-last'] + torch.sigmoid, writing (B,C,D,H,W) directly (generator.py:48,79-80)."""
+    """1x1 conv writing (B,C,D,H,W) directly: refinement_module['conv-last'] + torch.sigmoid (generator.py:48,79-80;
+    act=1) or the discriminator's linear score head (discriminator.py:59,77; act=0)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cin, b):
+    def forward(ctx, x, weight, bias, cin, b, act=1):
         _check_device(x)
         n, h, w, ld = x.shape
         d = n // b
         cout = weight.shape[0]
         out = torch.empty(b, cout, d, h, w, dtype=torch.float32, device=x.device)
-        _call("mnk_conv1x1_sigmoid_fwd", x, _p(x), ld, cin, _p(weight), _p(bias), _p(out), b, d, h, w, cout)
+        _call("mnk_conv1x1_fwd", x, _p(x), ld, cin, _p(weight), _p(bias), _p(out), b, d, h, w, cout, int(act))
         ctx.save_for_backward(x, weight, out)
-        ctx.meta = (cin, b, d, bias is not None)
+        ctx.meta = (cin, b, d, bias is not None, int(act))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, weight, out = ctx.saved_tensors
-        cin, b, d, has_bias = ctx.meta
+        cin, b, d, has_bias, act = ctx.meta
         dout = dout.contiguous()
         n, h, w, ld = x.shape
         cout = weight.shape[0]
@@ -377,9 +481,9 @@ class Conv1x1SigmoidFn(torch.autograd.Function):
         db = torch.empty(cout, dtype=torch.float32, device=x.device)
         nws = _query("mnk_conv1x1_workspace_floats", n * h * w, cin, cout)
         ws = SCRATCH.get("ws", nws, x)
-        _call("mnk_conv1x1_sigmoid_bwd", x, _p(x), ld, cin, _p(weight), _p(out), _p(dout), _p(dx), ld, _p(dw), _p(db), b, d,
-              h, w, cout, _p(ws), nws)
-        return dx, dw, db if has_bias else None, None, None
+        _call("mnk_conv1x1_bwd", x, _p(x), ld, cin, _p(weight), _p(out), _p(dout), _p(dx), ld, _p(dw), _p(db), b, d,
+              h, w, cout, act, _p(ws), nws)
+        return dx, dw, db if has_bias else None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -153,3 +153,44 @@ def test_resize_bilinear(be):
         be.sync()
         assert maxerr(O.cpu()[..., 2:5].permute(0, 3, 1, 2), ref) < 2e-6
         assert maxerr(DS.cpu()[..., :3].permute(0, 3, 1, 2), sr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 12, 13, 13), (2, 70, 6, 5)])
+@pytest.mark.parametrize("pool", [0, 1])
+def test_instance_norm_leaky_pool(be, shape, pool):
+    """Per-frame statistics + LeakyReLU(0.2) + avg-pool with odd sizes (the discriminator's DownBlock3D,
+    modules/discriminator.py:26-33) through the mnk_norm_* entry points."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    z = F.leaky_relu(F.instance_norm(xd, weight=gd, bias=bd, eps=1e-5), 0.2)
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    dz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(dz)
+    ld = ceil4(c)
+    X = be.t(to_nhwc(x))
+    nws = be.query("mnk_norm_workspace_floats", h * w, n, ld)
+    ws, sums = be.empty(nws), be.empty(2 * n * c)
+    be.call("mnk_norm_stats", X, ld, h * w, n, c, sums, ws, nws)
+    mean, invstd, scale = be.empty(n * c), be.empty(n * c), be.empty(n * c)
+    G, Bt = be.t(gamma), be.t(beta)
+    be.call("mnk_norm_finalize", sums, float(h * w), G, None, None, 0.0, 1e-5, c, n, 0, mean, invstd, scale)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    Z = be.empty(n, ho, wo, ld)
+    be.call("mnk_norm_act_fwd", X, ld, mean, scale, Bt, 1, Z, ld, 0, n, h, w, c, 0.2, pool)
+    DZ = be.t(to_nhwc(dz.float()))
+    bs = be.empty(2 * n * c)
+    be.call("mnk_norm_act_bwd_stats", X, ld, DZ, ld, 0, mean, invstd, scale, Bt, 1, n, h, w, c, 0.2, pool, bs, ws, nws)
+    DY = be.empty(n, h, w, ld)
+    be.call("mnk_norm_act_bwd_apply", X, ld, DZ, ld, 0, mean, invstd, scale, Bt, 1, bs, float(h * w), 1, DY, ld, n, h, w, c,
+            0.2, pool)
+    be.sync()
+    assert maxerr(from_nhwc(Z.cpu(), c), z) < 2e-5
+    assert relerr(from_nhwc(DY.cpu(), c), xd.grad) < 1e-4
+    # affine gradients = per-frame sums added over the frames
+    assert relerr(bs.cpu()[:n * c].view(n, c).sum(0), bd.grad) < 1e-4
+    assert relerr(bs.cpu()[n * c:].view(n, c).sum(0), gd.grad) < 1e-4

@@ -172,3 +172,54 @@ def test_down_block_with_fused_statistics(be):
         a, b = dict(blk.named_parameters())[k].grad.cpu().double(), sd["blk." + k].grad
         assert float((a - b).norm() / b.norm()) < 1e-4, k
     assert float((blk.norm.running_var.cpu().double() - ctx.new_stats["blk.norm.running_var"]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("cfg_name,size", [("tiny", 32), pytest.param("taichi", 64, marks=pytest.mark.gpu)])
+def test_discriminator_matches_oracle(be, cfg_name, size):
+    """modules.discriminator.Discriminator (4x4 no-pad convs, InstanceNorm, LeakyReLU, avg-pool, 1x1 head on the HIP
+    kernels) against oracle/restate.py::discriminator_forward in fp64: every returned feature map and all gradients
+    (parameters, input frame, key-points)."""
+    from modules.discriminator import Discriminator
+    from oracle import restate
+    if be.kind == "emu" and cfg_name != "tiny":
+        pytest.skip("too slow on the emulator")
+    cfg = load(cfg_name)["cfg"]
+    mp = cfg["model_params"]
+    common = mp["common_params"]
+    torch.manual_seed(5)
+    disc = Discriminator(**mp["discriminator_params"], **common)
+    sd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+    cases.perturb_state_dict(sd, 11)
+    disc.load_state_dict(sd)
+    b = 2
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(b, 3, 1, size, size, generator=g)
+    kd, ks = cases.random_kp(b, 1, common["num_kp"], seed=1), cases.random_kp(b, 1, common["num_kp"], seed=2)
+    # oracle, fp64
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    x64 = x.double().requires_grad_(True)
+    kd64 = {k: v.double().requires_grad_(True) for k, v in kd.items()}
+    ks64 = {k: v.double() for k, v in ks.items()}
+    maps64 = restate.discriminator_forward(sd64, mp["discriminator_params"], common, x64, kd64, ks64)
+    ws = [torch.randn(m.shape, generator=g, dtype=torch.float64) for m in maps64]
+    sum((m * w).sum() for m, w in zip(maps64[1:], ws[1:])).backward()
+    # HIP
+    disc.to(be.device)
+    xh = be.t(x).requires_grad_(True)
+    kdh = {k: be.t(v).requires_grad_(True) for k, v in kd.items()}
+    ksh = {k: be.t(v) for k, v in ks.items()}
+    maps = disc(xh, kdh, ksh)
+    sum((m * be.t(w.float())).sum() for m, w in zip(maps[1:], ws[1:])).backward()
+    be.sync()
+    assert len(maps) == len(maps64)
+    for i, (a, r) in enumerate(zip(maps, maps64)):
+        assert a.shape == r.shape
+        assert float((a.detach().cpu().double() - r.detach()).abs().max()) < 2e-5 * (1 + float(r.abs().max())), i
+    for k, p in disc.named_parameters():
+        ref = sd64[k].grad
+        if k.endswith("conv.bias") and "down_blocks.0" not in k and k != "conv.bias":
+            continue      # bias in front of an InstanceNorm: analytically zero gradient (noise in the reference too)
+        err = float((p.grad.cpu().double() - ref).norm() / (ref.norm() + 1e-9))
+        assert err < 2e-3, (k, err)   # InstanceNorm over 2x2..5x5 maps amplifies fp32 rounding
+    assert float((xh.grad.cpu().double() - x64.grad).norm() / x64.grad.norm()) < 2e-3
+    assert float((kdh["mean"].grad.cpu().double() - kd64["mean"].grad).norm() / kd64["mean"].grad.norm()) < 2e-3
