@@ -1,0 +1,84 @@
+"""Patch discriminator of the training step (modules/discriminator.py), first "next" row of SURVEY.md section 8f, on the
+same gfx950 kernels as the hot path (parity-tested, NOT the default yet).
+
+Measured on the MI355X (profiles/README.md, run r01l): with this class the moving-gif training iteration takes 22.95 ms
+against 20.93 ms with the stock-op `modules.discriminator.Discriminator` (MIOpen Winograd / implicit-GEMM kernels):
+the discriminator's layers are tiny (61x61x13 -> ... -> 2x2x256 at batch 32, four passes per iteration), where the
+128-row implicit-GEMM tiles, split-K reductions and the NHWC<->NCDHW conversions of the returned feature maps cost
+more than they save.  It stays here, tested against the oracle, as the starting point for that row; `modules/
+discriminator.py` keeps the stock-op implementation that the benchmark uses.
+
+Kernels: the (1,4,4) convolutions without padding run on the implicit-GEMM conv kernels
+(K x K form), InstanceNorm + LeakyReLU(0.2) + avg-pool is one fused pass (per-frame statistics), the score head is
+the linear 1x1 kernel.  Constructor, state_dict keys (5-D conv weights, InstanceNorm3d affine parameters) and the
+forward signature / returned list of feature maps are the reference's."""
+from torch import nn
+
+from modules.movement_embedding import MovementEmbeddingModule
+from mnk import ops
+
+
+class DownBlock3D(nn.Module):
+    """conv(1,k,k) without padding -> InstanceNorm (optional) -> LeakyReLU(0.2) -> avg-pool (1,2,2)
+    (modules/discriminator.py:7-33)."""
+
+    def __init__(self, in_features, out_features, norm=False, kernel_size=4):
+        super(DownBlock3D, self).__init__()
+        self.conv = nn.Conv3d(in_channels=in_features, out_channels=out_features,
+                              kernel_size=(1, kernel_size, kernel_size))
+        self.norm = nn.InstanceNorm3d(out_features, affine=True) if norm else None
+        self.in_features, self.out_features, self.kernel_size = in_features, out_features, kernel_size
+
+    def forward_act(self, x, c):
+        k = self.kernel_size
+        out = ops.ConvKxKFn.apply(x, self.conv.weight, self.conv.bias, c, k, k, 0)
+        if self.norm is not None:
+            out = ops.InstNormActFn.apply(out, self.norm.weight, self.norm.bias, self.out_features, 0.2, True,
+                                          self.norm.eps)
+        else:
+            out = ops.InstNormActFn.apply(out, None, None, self.out_features, 0.2, True, 0.0)
+        return out, self.out_features
+
+    def forward(self, x):
+        out, c = self.forward_act(ops.to_act(x), self.in_features)
+        return ops.from_act(out, c, x.shape[0])
+
+
+class Discriminator(nn.Module):
+    """Pix2Pix-like discriminator on [frame | key-point heat-maps]; returns every intermediate feature map
+    (modules/discriminator.py:36-79)."""
+
+    def __init__(self, num_channels=3, num_kp=10, kp_variance=0.01, scale_factor=1,
+                 block_expansion=64, num_blocks=4, max_features=512, kp_embedding_params=None):
+        super(Discriminator, self).__init__()
+        if kp_embedding_params is not None:
+            self.kp_embedding = MovementEmbeddingModule(num_kp=num_kp, kp_variance=kp_variance,
+                                                        num_channels=num_channels, **kp_embedding_params)
+            embedding_channels = self.kp_embedding.out_channels
+        else:
+            self.kp_embedding = None
+            embedding_channels = 0
+        widths = [num_channels + embedding_channels] + [min(max_features, block_expansion * (2 ** (i + 1)))
+                                                        for i in range(num_blocks)]
+        self.down_blocks = nn.ModuleList([DownBlock3D(widths[i], widths[i + 1], norm=(i != 0), kernel_size=4)
+                                          for i in range(num_blocks)])
+        self.conv = nn.Conv3d(self.down_blocks[-1].conv.out_channels, out_channels=1, kernel_size=1)
+        self.scale_factor = scale_factor
+        self.num_channels = num_channels
+
+    def forward(self, x, kp_driving, kp_source):
+        b, _, d = x.shape[:3]
+        if d != 1:
+            raise NotImplementedError("InstanceNorm3d statistics span the time axis; every caller of the reference "
+                                      "passes one frame (train.py:43-44,69-70)")
+        out_maps = [x]
+        step = ops.step_from_scale(self.scale_factor)
+        out, c = ops.to_act(x, step), self.num_channels
+        if self.kp_embedding:
+            emb, ce = self.kp_embedding.forward_act(x, kp_driving, kp_source, pre_step=step)
+            out, c = ops.Concat2Fn.apply(out, c, emb, ce), c + ce
+        for down_block in self.down_blocks:
+            out, c = down_block.forward_act(out, c)
+            out_maps.append(ops.from_act(out, c, b))
+        out_maps.append(ops.Conv1x1SigmoidFn.apply(out, self.conv.weight, self.conv.bias, c, b, 0))
+        return out_maps

@@ -1,12 +1,12 @@
-"""Patch discriminator of the training step (modules/discriminator.py), first "next" row of SURVEY.md section 8f, on the
-same gfx950 kernels as the hot path: the (1,4,4) convolutions without padding run on the implicit-GEMM conv kernels
-(K x K form), InstanceNorm + LeakyReLU(0.2) + avg-pool is one fused pass (per-frame statistics), the score head is
-the linear 1x1 kernel.  Constructor, state_dict keys (5-D conv weights, InstanceNorm3d affine parameters) and the
-forward signature / returned list of feature maps are the reference's."""
+"""Patch discriminator used by the training step (modules/discriminator.py).  NOT part of the MI355X hot path
+(SURVEY.md section 8f-1 "next"): it runs on stock PyTorch-ROCm ops, with the reference's constructor, state_dict keys
+(5-D conv weights) and forward signature so that checkpoints and train.py interoperate.  The (1,4,4) convolutions are
+evaluated as 2-D convolutions on the folded frames.  Its key-point heat-maps come from the HIP embedding kernel."""
+import torch
 from torch import nn
+import torch.nn.functional as F
 
 from modules.movement_embedding import MovementEmbeddingModule
-from mnk import ops
 
 
 class DownBlock3D(nn.Module):
@@ -18,21 +18,14 @@ class DownBlock3D(nn.Module):
         self.conv = nn.Conv3d(in_channels=in_features, out_channels=out_features,
                               kernel_size=(1, kernel_size, kernel_size))
         self.norm = nn.InstanceNorm3d(out_features, affine=True) if norm else None
-        self.in_features, self.out_features, self.kernel_size = in_features, out_features, kernel_size
-
-    def forward_act(self, x, c):
-        k = self.kernel_size
-        out = ops.ConvKxKFn.apply(x, self.conv.weight, self.conv.bias, c, k, k, 0)
-        if self.norm is not None:
-            out = ops.InstNormActFn.apply(out, self.norm.weight, self.norm.bias, self.out_features, 0.2, True,
-                                          self.norm.eps)
-        else:
-            out = ops.InstNormActFn.apply(out, None, None, self.out_features, 0.2, True, 0.0)
-        return out, self.out_features
 
     def forward(self, x):
-        out, c = self.forward_act(ops.to_act(x), self.in_features)
-        return ops.from_act(out, c, x.shape[0])
+        b, c, d, h, w = x.shape
+        y = F.conv2d(x.transpose(1, 2).reshape(b * d, c, h, w), self.conv.weight[:, :, 0], self.conv.bias)
+        if self.norm is not None:
+            y = F.instance_norm(y, weight=self.norm.weight, bias=self.norm.bias, eps=self.norm.eps)
+        y = F.avg_pool2d(F.leaky_relu(y, 0.2), 2)
+        return y.reshape(b, d, y.shape[1], y.shape[2], y.shape[3]).transpose(1, 2)
 
 
 class Discriminator(nn.Module):
@@ -55,21 +48,18 @@ class Discriminator(nn.Module):
                                           for i in range(num_blocks)])
         self.conv = nn.Conv3d(self.down_blocks[-1].conv.out_channels, out_channels=1, kernel_size=1)
         self.scale_factor = scale_factor
-        self.num_channels = num_channels
 
     def forward(self, x, kp_driving, kp_source):
-        b, _, d = x.shape[:3]
-        if d != 1:
-            raise NotImplementedError("InstanceNorm3d statistics span the time axis; every caller of the reference "
-                                      "passes one frame (train.py:43-44,69-70)")
         out_maps = [x]
-        step = ops.step_from_scale(self.scale_factor)
-        out, c = ops.to_act(x, step), self.num_channels
+        if self.scale_factor != 1:
+            x = F.interpolate(x, scale_factor=(1, self.scale_factor, self.scale_factor))
+        out = x
         if self.kp_embedding:
-            emb, ce = self.kp_embedding.forward_act(x, kp_driving, kp_source, pre_step=step)
-            out, c = ops.Concat2Fn.apply(out, c, emb, ce), c + ce
+            out = torch.cat([x, self.kp_embedding(x, kp_driving, kp_source)], dim=1)
         for down_block in self.down_blocks:
-            out, c = down_block.forward_act(out, c)
-            out_maps.append(ops.from_act(out, c, b))
-        out_maps.append(ops.Conv1x1SigmoidFn.apply(out, self.conv.weight, self.conv.bias, c, b, 0))
+            out = down_block(out)
+            out_maps.append(out)
+        b, c, d, h, w = out.shape
+        score = F.conv2d(out.transpose(1, 2).reshape(b * d, c, h, w), self.conv.weight[:, :, 0], self.conv.bias)
+        out_maps.append(score.reshape(b, d, 1, h, w).transpose(1, 2))
         return out_maps

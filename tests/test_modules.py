@@ -176,10 +176,10 @@ def test_down_block_with_fused_statistics(be):
 
 @pytest.mark.parametrize("cfg_name,size", [("tiny", 32), pytest.param("taichi", 64, marks=pytest.mark.gpu)])
 def test_discriminator_matches_oracle(be, cfg_name, size):
-    """modules.discriminator.Discriminator (4x4 no-pad convs, InstanceNorm, LeakyReLU, avg-pool, 1x1 head on the HIP
-    kernels) against oracle/restate.py::discriminator_forward in fp64: every returned feature map and all gradients
+    """mnk.discriminator_hip.Discriminator (4x4 no-pad convs, InstanceNorm, LeakyReLU, avg-pool, 1x1 head on the HIP
+    kernels; not the default discriminator yet, see its docstring) against oracle/restate.py::discriminator_forward in fp64: every returned feature map and all gradients
     (parameters, input frame, key-points)."""
-    from modules.discriminator import Discriminator
+    from mnk.discriminator_hip import Discriminator
     from oracle import restate
     if be.kind == "emu" and cfg_name != "tiny":
         pytest.skip("too slow on the emulator")
