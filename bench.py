@@ -176,7 +176,7 @@ def main():
     # ---- per-kernel HIP-event timing of one extra (un-timed) step: roofline of the dominant kernel --------------
     roofline = None
     kernels = {}
-    if not args.no_profile and rank == 0:
+    if not args.no_profile:      # every rank runs the profiled steps (they contain the SyncBN / gradient collectives)
         import ctypes
         lib.cdll.mnk_prof_reset()
         lib.cdll.mnk_prof_enable(1)
@@ -215,8 +215,8 @@ def main():
                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2),
                         "flop_per_launch": conv["work_per_step"] / conv["launches_per_step"]}
-    elif world > 1:
-        pass
+    if world > 1 or force_dist:
+        dist.barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -625,8 +625,8 @@ int mnk_conv1x1_sigmoid_fwd(const float* x, int ld_x, int Cin, const float* w, c
 }
 
 static long c11_rows_per_block(long rows) {
-    long rb = (rows + 1023) / 1024;
-    if (rb > 512) rb = 512;
+    long rb = (rows + 127) / 128;      // ~128 rows per block: 1024 blocks at 64x64 x 32 frames (was 128 blocks: 190 us)
+    if (rb > 2048) rb = 2048;
     if (rb < 1) rb = 1;
     return (rows + rb - 1) / rb;
 }
