@@ -3,7 +3,9 @@
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-OUT="$HERE/build"
+# MNK_BUILD_TAG=_x MNK_EXTRA_FLAGS=-D... builds an experiment variant next to the product library
+TAG="${MNK_BUILD_TAG:-}"
+OUT="$HERE/build$TAG"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-unused-variable ${MNK_EXTRA_FLAGS}"
@@ -18,5 +20,5 @@ for f in "$HERE"/*.hip; do
   OBJS="$OBJS $o"
 done
 for p in $pids; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/../libmonkeynet_hip.so" $OBJS
-echo "$HERE/../libmonkeynet_hip.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/../libmonkeynet_hip$TAG.so" $OBJS
+echo "$HERE/../libmonkeynet_hip$TAG.so"

@@ -78,75 +78,92 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
     if (s_end > a.ksteps) s_end = a.ksteps;
 
     // ---- per-thread global->LDS assignment --------------------------------------------------------------
+    // Everything a K step needs per row is precomputed (frame base, row/column, per-row validity bit masks of the
+    // kernel rows / columns); the per-step gather is branch-free: a tap outside the image reads the clamped pixel
+    // and is zeroed on its way to LDS, rows beyond M / Cout are clamped to the last real row (never stored).
     const int lrow = t >> 2, lq = t & 3;      // row inside a 64-row slab, float4 column (4 channels)
-    int pn[RA], ph[RA], pw[RA];
-    bool pvalid[RA];
+    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
+    const int khh = a.ntaps / a.kw;
+    int prow[RA], ph[RA], pw[RA];
+    unsigned pmask[RA];                       // bits 0..7: kernel rows inside the image, bits 8..15: kernel columns
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         long m = m0 + lrow + 64 * j;
-        pvalid[j] = m < a.M;
-        long mm = pvalid[j] ? m : 0;
-        pw[j] = (int)(mm % a.W);
-        long tt = mm / a.W;
+        if (m > a.M - 1) m = a.M - 1;
+        pw[j] = (int)(m % a.W);
+        const long tt = m / a.W;
         ph[j] = (int)(tt % a.H);
-        pn[j] = (int)(tt / a.H);
+        prow[j] = (int)(tt / a.H) * Hs * Ws;
+        unsigned mk = 0;
+        for (int ky = 0; ky < khh; ++ky) {
+            const int hh = ph[j] + ky - a.pad;
+            if (hh >= 0 && hh < a.Hi) mk |= 1u << ky;
+        }
+        for (int kx = 0; kx < a.kw; ++kx) {
+            const int ww = pw[j] + kx - a.pad;
+            if (ww >= 0 && ww < a.Wi) mk |= 256u << kx;
+        }
+        pmask[j] = mk;
     }
-    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
     constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
     const long KT = (long)a.ksteps * BK;     // packed row length
+    static_assert(RB <= 2, "at most two weight rows per thread");
+    const int wco0 = n0 + lrow, wco1 = n0 + lrow + 64;
+    const unsigned woff0 = (unsigned)((wco0 < a.Cout ? wco0 : a.Cout - 1) * KT) + lq * 4;
+    const unsigned woff1 = (unsigned)((wco1 < a.Cout ? wco1 : a.Cout - 1) * KT) + lq * 4;
 
-    float4 ra[RA], rb[RB];
+    float4 ra[RA], rb0, rb1;
+    int ra_tail[RA];                          // real channels in ra[j] (<= 0: tap outside the image / chunk beyond C);
+                                              // the other components are zeroed on the way to LDS, one step later
+    // K-step cursor of the loader (step = chunk * ntaps + ky * kw + kx), advanced without divisions or branches
+    int l_chunk = s_begin / a.ntaps;
+    int l_ky = (s_begin - l_chunk * a.ntaps) / a.kw;
+    int l_kx = (s_begin - l_chunk * a.ntaps) - l_ky * a.kw;
+    const int hmax = a.Hi - 1, wmax = a.Wi - 1;
 
-    auto load_step = [&](int s) {
-        const int chunk = s / a.ntaps;
-        const int tap = s - chunk * a.ntaps;
-        const int dy = tap / a.kw - a.pad, dx = tap % a.kw - a.pad;
-        int cbase = chunk * BK;
-        const float* src;
-        int ld, C;
-        if (cbase < a.C0p) {
-            src = a.x0;
-            ld = a.ld0;
-            C = a.C0;
-        } else {
-            cbase -= a.C0p;
-            src = a.x1;
-            ld = a.ld1;
-            C = a.C1;
-        }
+    auto load_step = [&](int s) __attribute__((always_inline)) {
+        const int c0 = l_chunk * BK;
+        const bool second = c0 >= a.C0p;
+        const int cbase = second ? c0 - a.C0p : c0;
+        const float* src = second ? a.x1 : a.x0;
+        const int ld = second ? a.ld1 : a.ld0, C = second ? a.C1 : a.C0;
         const int ch = cbase + lq * 4;
+        const int tail = C - ch;
+        const int che = tail > 0 ? ch : 0;
+        const int dy = l_ky - a.pad, dx = l_kx - a.pad;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const int hh = ph[j] + dy, ww = pw[j] + dx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pvalid[j] && hh >= 0 && hh < a.Hi && ww >= 0 && ww < a.Wi && ch < C) {
-                const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
-                v = *reinterpret_cast<const float4*>(src + (((long)pn[j] * Hs + hs) * Ws + wsrc) * ld + ch);
-                const int rem = C - ch;   // pad channels of the producer may hold anything: mask them
-                if (rem < 4) {
-                    if (rem < 2) v.y = 0.f;
-                    if (rem < 3) v.z = 0.f;
-                    v.w = 0.f;
-                }
-            }
-            ra[j] = v;
+            const bool ok = (pmask[j] >> l_ky) & (pmask[j] >> (8 + l_kx)) & 1u;
+            int hh = ph[j] + dy, ww = pw[j] + dx;     // clamped into the image: the load is unconditional
+            hh = hh < 0 ? 0 : (hh > hmax ? hmax : hh);
+            ww = ww < 0 ? 0 : (ww > wmax ? wmax : ww);
+            const unsigned off = (unsigned)(prow[j] + (hh >> a.ups) * Ws + (ww >> a.ups)) * (unsigned)ld + (unsigned)che;
+            ra[j] = *reinterpret_cast<const float4*>(src + off);
+            ra_tail[j] = ok ? tail : 0;
         }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int r = lrow + 64 * j;
-            const int co = n0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < BN && co < a.Cout)
-                v = *reinterpret_cast<const float4*>(a.wp + (long)co * KT + (long)s * BK + lq * 4);
-            rb[j] = v;
-        }
+        const float* wsrc_ptr = a.wp + (long)s * BK;
+        rb0 = *reinterpret_cast<const float4*>(wsrc_ptr + woff0);
+        if constexpr (RB > 1) rb1 = *reinterpret_cast<const float4*>(wsrc_ptr + woff1);
+        const int kx1 = l_kx + 1;
+        const bool wx = kx1 == a.kw;
+        l_kx = wx ? 0 : kx1;
+        const int ky1 = l_ky + (wx ? 1 : 0);
+        const bool wy = ky1 == khh;
+        l_ky = wy ? 0 : ky1;
+        l_chunk += wy ? 1 : 0;
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < RB; ++j)
-            if (lrow + 64 * j < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64 * j][lq * 4]) = rb[j];
+        for (int j = 0; j < RA; ++j) {
+            float4 v = ra[j];
+            v.x = ra_tail[j] < 1 ? 0.f : v.x;
+            v.y = ra_tail[j] < 2 ? 0.f : v.y;
+            v.z = ra_tail[j] < 3 ? 0.f : v.z;
+            v.w = ra_tail[j] < 4 ? 0.f : v.w;
+            *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = v;
+        }
+        if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = rb0;
+        if constexpr (RB > 1) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64][lq * 4]) = rb1;
     };
 
     f32x16 acc[TM][TN];
@@ -160,14 +177,7 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
     const int fi = lane & 31, fk = lane >> 5;
     const int a_row0 = wm * (BM / WM) + fi, b_row0 = wn * (BN / WN) + fi;
 
-    if (s_begin < s_end) {
-        load_step(s_begin);
-        store_step(0);
-    }
-    __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if (s + 1 < s_end) load_step(s + 1);
+    auto mfma_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             float4 fa[TM], fb[TN];
@@ -187,9 +197,35 @@ __global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   /
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (s + 1 < s_end) store_step(buf ^ 1);
+    };
+
+    // Pipeline: the registers always hold the step after the one in LDS.  In step s the wave first parks step s+1
+    // in the other LDS buffer (loaded a whole step ago: no wait), issues the global loads of step s+2 and then runs
+    // the MFMAs of step s, so loads, address arithmetic and LDS writes sit in the MFMA shadow; one barrier per step.
+    // The steady-state loop body is branch-free (one basic block); the last two steps are peeled.
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+        if (s_begin + 1 < s_end) load_step(s_begin + 1);
+    }
+    __syncthreads();
+    int s = s_begin;
+    for (; s + 2 < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        store_step(buf ^ 1);
+        load_step(s + 2);
+        mfma_step(buf);
         __syncthreads();
     }
+    if (s + 1 < s_end) {
+        const int buf = (s - s_begin) & 1;
+        store_step(buf ^ 1);
+        mfma_step(buf);
+        __syncthreads();
+        ++s;
+    }
+    if (s < s_end) mfma_step((s - s_begin) & 1);
+    __syncthreads();                          // the epilogue reuses As for the column sums
 
     // ---- epilogue: D[row][col], col = lane&31 (-> co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> pixel) ------
     // bias is fetched once per column, residual values are fetched as a batch before the stores (no per-element

@@ -5,6 +5,13 @@
 
 #include "monkeynet_hip.h"
 
+// keep a wave-uniform pointer in scalar registers across a loop (opaque to rematerialisation); no-op on the emulator
+#ifdef HIPEMU
+#define MNK_KEEP_SGPR(p) ((void)0)
+#else
+#define MNK_KEEP_SGPR(p) asm volatile("" : "+s"(p))
+#endif
+
 namespace mnk {
 
 void set_error(const char* fmt, ...);

@@ -227,19 +227,24 @@ __global__ void __launch_bounds__(256) conv1x1_sigmoid_wgrad_partial_kernel(cons
     }
 }
 
+// one wavefront per output element: lanes stride over the row blocks, fixed-order wave reduction (deterministic)
 __global__ void __launch_bounds__(256) conv1x1_sigmoid_wgrad_final_kernel(const float* __restrict__ partial,
                                                                           int row_blocks, int Cin, int Cout,
                                                                           float* __restrict__ dw,
                                                                           float* __restrict__ dbias) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= Cout * (Cin + 1)) return;
     const int c = i / (Cin + 1), k = i - c * (Cin + 1);
     float acc = 0.f;
-    for (int rb = 0; rb < row_blocks; ++rb) acc += partial[((long)rb * Cout + c) * (Cin + 1) + k];
-    if (k < Cin)
-        dw[c * Cin + k] = acc;
-    else if (dbias)
-        dbias[c] = acc;
+    for (int rb = lane; rb < row_blocks; rb += 64) acc += partial[((long)rb * Cout + c) * (Cin + 1) + k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (k < Cin)
+            dw[c * Cin + k] = acc;
+        else if (dbias)
+            dbias[c] = acc;
+    }
 }
 
 // ---- motion field ------------------------------------------------------------------------------------------------
@@ -656,7 +661,7 @@ int mnk_conv1x1_bwd(const float* x, int ld_x, int Cin, const float* w, const flo
                        B, D, H, W, Cout, act);
     hipLaunchKernelGGL(conv1x1_sigmoid_wgrad_partial_kernel, dim3(rb), dim3(256), 0, s, x, ld_x, Cin, out, dout, B, D, H,
                        W, Cout, rpb, ws, act);
-    hipLaunchKernelGGL(conv1x1_sigmoid_wgrad_final_kernel, dim3(ceil_div(Cout * (Cin + 1), 256)), dim3(256), 0, s, ws, rb,
+    hipLaunchKernelGGL(conv1x1_sigmoid_wgrad_final_kernel, dim3(ceil_div(Cout * (Cin + 1), 4)), dim3(256), 0, s, ws, rb,
                        Cin, Cout, dw, dbias);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
