@@ -59,8 +59,12 @@ struct ConvArgs {
     float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
 };
 
+#ifndef MNK_IGEMM_OCC
+#define MNK_IGEMM_OCC 3                       // waves per SIMD = blocks per CU the register budget is held to
+#endif
+
 template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256, 3) conv3x3_igemm_kernel(ConvArgs a) {   // 3 waves/SIMD = 3 blocks per CU
+__global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvArgs a) {
     constexpr int RA = BM / 64;               // A rows per thread per K step
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(WM * WN == 4, "4 waves per block");
@@ -834,6 +838,202 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
         }
 }
 
+// ---- weight gradient, tap-major form (the default for C >= 16) ---------------------------------------------------
+// The same pipeline as the forward kernel with K = pixels: one block owns a BM (co) x BN (ci) tile of ONE tap and a
+// range of pixels.  Per 16-pixel K step both operands are plain coalesced float4 reads along channels -- dy rows
+// [pixel][co] and x rows of the tap-shifted pixels [pixel + off(tap)][ci] (clamped into the image, zeroed on the way
+// to LDS when the tap falls outside) -- so there are no scalar gathers and no branches in the steady-state loop;
+// registers hold step s+1, loads of step s+2 are issued before the MFMAs of step s.  The tile is written to a
+// tap-major partial [split][tap][co][ci] (coalesced along ci); conv3x3_wgrad_tap_reduce_kernel sums the splits and
+// transposes (tap, ci) -> the parameter order ci*ntaps + tap through LDS.
+struct WgradTapArgs {
+    const float* x;
+    int ld_x, C, ups;
+    const float* dy;
+    int ld_dy, Cout;
+    int H, W;            // dy geometry
+    int Hi, Wi, ntaps, kw, pad;
+    long M, pix_per_split;
+    int gn;              // ci tiles per tap
+    float* part;         // [splits][ntaps][Cout][C]
+    unsigned mulW, shW, mulH, shH;   // division by W / H of a pixel index < 2^31 (mul == 0: shift only)
+};
+
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned sh) {
+    return mul ? __umulhi(n, mul) >> sh : n >> sh;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs a) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A4 = BM / 4, B4 = BN / 4;              // float4 columns of a tile row
+    constexpr int APASS = 256 / A4, BPASS = 256 / B4;     // pixel rows covered by one pass of the block
+    constexpr int RA = (BK + APASS - 1) / APASS, RB = (BK + BPASS - 1) / BPASS;
+    static_assert(RA <= 2 && RB <= 2, "at most two rows per thread and operand");
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];   // dy tile   [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];   // x-shifted [pixel][ci]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int co0 = blockIdx.x * BM;
+    const int tap = blockIdx.y / a.gn;
+    const int ci0 = (blockIdx.y - tap * a.gn) * BN;
+    const int split = blockIdx.z;
+    const long p_begin = (long)split * a.pix_per_split;
+    long p_end = p_begin + a.pix_per_split;
+    if (p_end > a.M) p_end = a.M;
+    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
+    const int dyt = tap / a.kw - a.pad, dxt = tap % a.kw - a.pad;
+    const int hmax = a.Hi - 1, wmax = a.Wi - 1;
+    const unsigned plast = (unsigned)(a.M - 1), pend = (unsigned)p_end;
+
+    const int ar = t / A4, ac4 = t % A4, br = t / B4, bc4 = t % B4;
+    const int coa = co0 + ac4 * 4, cib = ci0 + bc4 * 4;
+    const int tail_a = a.Cout - coa, tail_b = a.C - cib;
+    const unsigned coa_e = tail_a > 0 ? coa : 0, cib_e = tail_b > 0 ? cib : 0;
+
+    float4 ra0, ra1, rb0, rb1;
+    int ta0 = 0, ta1 = 0, tb0 = 0, tb1 = 0;       // valid channels of the float4s (<= 0: zero the whole vector)
+
+    auto load_a = [&](unsigned p, float4& v, int& tl) __attribute__((always_inline)) {
+        tl = p < pend ? tail_a : 0;
+        const unsigned pe = p < plast ? p : plast;
+        v = *reinterpret_cast<const float4*>(a.dy + (unsigned long)pe * (unsigned)a.ld_dy + coa_e);
+    };
+    auto load_b = [&](unsigned p, float4& v, int& tl) __attribute__((always_inline)) {
+        const unsigned pe = p < plast ? p : plast;
+        const unsigned q = fast_div(pe, a.mulW, a.shW);
+        const int w = (int)(pe - q * (unsigned)a.W);
+        const unsigned n = fast_div(q, a.mulH, a.shH);
+        const int h = (int)(q - n * (unsigned)a.H);
+        int hh = h + dyt, ww = w + dxt;
+        const bool ok = hh >= 0 && hh <= hmax && ww >= 0 && ww <= wmax;
+        hh = hh < 0 ? 0 : (hh > hmax ? hmax : hh);
+        ww = ww < 0 ? 0 : (ww > wmax ? wmax : ww);
+        tl = ok ? tail_b : 0;
+        const unsigned pix = (n * (unsigned)Hs + (unsigned)(hh >> a.ups)) * (unsigned)Ws + (unsigned)(ww >> a.ups);
+        v = *reinterpret_cast<const float4*>(a.x + (unsigned long)pix * (unsigned)a.ld_x + cib_e);
+    };
+    auto load_step = [&](long p0) __attribute__((always_inline)) {
+        const unsigned pa = (unsigned)p0 + ar, pb = (unsigned)p0 + br;
+        load_a(pa, ra0, ta0);
+        if constexpr (RA > 1) load_a(pa + APASS, ra1, ta1);
+        load_b(pb, rb0, tb0);
+        if constexpr (RB > 1) load_b(pb + BPASS, rb1, tb1);
+    };
+    auto masked = [&](float4 v, int tl) __attribute__((always_inline)) {
+        v.x = tl < 1 ? 0.f : v.x;
+        v.y = tl < 2 ? 0.f : v.y;
+        v.z = tl < 3 ? 0.f : v.z;
+        v.w = tl < 4 ? 0.f : v.w;
+        return v;
+    };
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
+        if (APASS >= BK ? ar < BK : true) *reinterpret_cast<float4*>(&As[buf][ar][ac4 * 4]) = masked(ra0, ta0);
+        if constexpr (RA > 1) *reinterpret_cast<float4*>(&As[buf][ar + APASS][ac4 * 4]) = masked(ra1, ta1);
+        if (BPASS >= BK ? br < BK : true) *reinterpret_cast<float4*>(&Bs[buf][br][bc4 * 4]) = masked(rb0, tb0);
+        if constexpr (RB > 1) *reinterpret_cast<float4*>(&Bs[buf][br + BPASS][bc4 * 4]) = masked(rb1, tb1);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fi = lane & 31, fk = lane >> 5;
+    auto mfma_step = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < BK / 2; ++e) {
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = As[buf][2 * e + fk][wm * (32 * TM) + 32 * i + fi];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][2 * e + fk][wn * (32 * TN) + 32 * j + fi];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (p_begin < p_end) {
+        load_step(p_begin);
+        store_step(0);
+        if (p_begin + BK < p_end) load_step(p_begin + BK);
+    }
+    __syncthreads();
+    long p0 = p_begin;
+    int it = 0;
+    for (; p0 + 2 * BK < p_end; p0 += BK, ++it) {
+        const int buf = it & 1;
+        store_step(buf ^ 1);
+        load_step(p0 + 2 * BK);
+        mfma_step(buf);
+        __syncthreads();
+    }
+    if (p0 + BK < p_end) {
+        const int buf = it & 1;
+        store_step(buf ^ 1);
+        mfma_step(buf);
+        __syncthreads();
+        p0 += BK;
+        ++it;
+    }
+    if (p0 < p_end) mfma_step(it & 1);
+
+    // rows = co, cols = ci: 32 lanes write 128 consecutive bytes of the tap-major partial
+    float* outp = a.part + ((long)split * a.ntaps + tap) * a.Cout * a.C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci0 + wn * (32 * TN) + 32 * j + fi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (co < a.Cout && ci < a.C) outp[(long)co * a.C + ci] = acc[i][j][r];
+            }
+        }
+}
+
+// dw[co][(c_start + ci) * ntaps + tap] = sum_s part[s][tap][co][ci]: one block per (64-channel ci tile, co); reads
+// are coalesced along ci, the (tap, ci) -> (ci, tap) transposition goes through LDS, writes are contiguous runs of
+// 64 * ntaps floats.  Fixed summation order (deterministic).
+__global__ void __launch_bounds__(256) conv3x3_wgrad_tap_reduce_kernel(const float* __restrict__ part, int splits,
+                                                                       int ntaps, int Cout, int C,
+                                                                       float* __restrict__ dw, long ld_out) {
+    __shared__ float tile[16][65];
+    const int t = threadIdx.x;
+    const int ci0 = blockIdx.x * 64, co = blockIdx.y;
+    const long plane = (long)Cout * C, sstride = (long)ntaps * plane;
+    for (int idx = t; idx < ntaps * 64; idx += 256) {
+        const int tp = idx >> 6, c = idx & 63;
+        float v0 = 0.f, v1 = 0.f;
+        if (ci0 + c < C) {
+            const float* src = part + (long)tp * plane + (long)co * C + ci0 + c;
+            int s = 0;
+            for (; s + 1 < splits; s += 2) {
+                v0 += src[(long)s * sstride];
+                v1 += src[(long)(s + 1) * sstride];
+            }
+            if (s < splits) v0 += src[(long)s * sstride];
+        }
+        tile[tp][c] = v0 + v1;
+    }
+    __syncthreads();
+    float* dst = dw + (long)co * ld_out + (long)ci0 * ntaps;
+    const int lim = (C - ci0 < 64 ? C - ci0 : 64) * ntaps;
+    for (int idx = t; idx < lim; idx += 256) {
+        const int c = idx / ntaps, tp = idx - c * ntaps;
+        dst[idx] = tile[tp][c];
+    }
+}
+
 // dw[co][c_start*9 + n] = sum_splits partial[s][co][n]
 __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int Cout,
                                                                    int NT, float* __restrict__ dw, long ld_out) {
@@ -964,6 +1164,53 @@ static WPlan make_wplan(long M, int Cout, int C, int ntaps = 9) {
     p.pix_per_split = steps_per * BK;
     p.splits = (int)((steps + steps_per - 1) / steps_per);
     return p;
+}
+
+// tap-major wgrad plan
+struct TPlan {
+    bool use;
+    int bm, bn, gm, gn, splits;
+    long pix_per_split;
+};
+static int g_wgrad_tap = env_int("MNK_WGRAD_TAP", 1), g_wtap_target = env_int("MNK_WTAP_TARGET", 768),
+           g_wtap_minsteps = env_int("MNK_WTAP_MINSTEPS", 8), g_wtap_minc = env_int("MNK_WTAP_MINC", 16);
+
+static TPlan make_tplan(long M, int Cout, int C, int ntaps, int ld_x) {
+    TPlan p;
+    // measured on the MI355X (profiles/README.md): the tap-major form wins (+10..35 %) once one of the channel counts
+    // exceeds a 64-wide tile; narrow high-resolution layers (45 -> 45, 35 -> 10, 44 -> 64) keep the halo / gather
+    // kernels, whose tiles span several taps of the same channels (higher arithmetic intensity per staged byte)
+    p.use = g_wgrad_tap && C >= g_wtap_minc && (g_wgrad_tap > 1 || C > 64 || Cout > 64) && ntaps <= 16 &&
+            ld_x % 4 == 0 && ld_x >= round_up(C, 4) && M < (1L << 31);
+    if (!p.use) return p;
+    p.bm = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    p.bn = (C > 64 || p.bm <= 64) ? 128 : 64;   // tiles in use: 128x128, 128x64, 64x128, 32x128
+    p.gm = ceil_div(Cout, p.bm);
+    p.gn = ceil_div(C, p.bn);
+    const long tiles = (long)p.gm * p.gn * ntaps;
+    const long steps = (M + BK - 1) / BK;
+    long splits = (g_wtap_target + tiles - 1) / tiles;
+    const long max_splits = steps / g_wtap_minsteps;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const long steps_per = (steps + splits - 1) / splits;
+    p.pix_per_split = steps_per * BK;
+    p.splits = (int)((steps + steps_per - 1) / steps_per);
+    return p;
+}
+
+// n / d for n < 2^31 as (mulhi(n, mul) >> sh), or (n >> sh) when mul == 0 (d a power of two)
+static void fast_div_consts(unsigned d, unsigned* mul, unsigned* sh) {
+    unsigned s = 0;
+    while ((1u << s) < d) ++s;
+    if ((1u << s) == d) {
+        *mul = 0;
+        *sh = s;
+        return;
+    }
+    const unsigned long long num = 1ull << (31 + s);
+    *mul = (unsigned)((num + d - 1) / d);
+    *sh = s - 1;
 }
 
 static inline int grid_for(long total, int cap = 4096) {
@@ -1103,6 +1350,10 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
 size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return 0;
     const int ntaps = kh * kw;
+    {   // the caller's ld_x is not known here: size for the tap-major form whenever the shape allows it
+        TPlan tp = make_tplan((long)N * Ho * Wo, Cout, C, ntaps, round_up(C, 4));
+        if (tp.use) return (size_t)tp.splits * ntaps * Cout * C;
+    }
     if (kh == 3 && kw == 3 && pad == 1) {
         HPlan hp = make_hplan(N, Ho, Wo, Cout, C);
         if (hp.use) return hp.splits > 1 ? (size_t)hp.splits * Cout * 9 * C : 0;
@@ -1120,6 +1371,56 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
     MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (Hi % 2 == 0 && Wi % 2 == 0)));
     const int ntaps = kh * kw;
     const int H = Ho, W = Wo;
+    TPlan tp = make_tplan((long)N * H * W, Cout, C, ntaps, ld_x);
+    if (tp.use && ((size_t)x % 16 != 0 || (size_t)dy % 16 != 0)) tp.use = false;
+    if (tp.use) {
+        const size_t need = (size_t)tp.splits * ntaps * Cout * C;
+        if (!ws || ws_floats < need) {
+            set_error("mnk_conv2d_wgrad: workspace too small (%zu < %zu floats)", ws_floats, need);
+            return MNK_EWORKSPACE;
+        }
+        WgradTapArgs g;
+        g.x = x;
+        g.ld_x = ld_x;
+        g.C = C;
+        g.ups = ups;
+        g.dy = dy;
+        g.ld_dy = ld_dy;
+        g.Cout = Cout;
+        g.H = H;
+        g.W = W;
+        g.Hi = Hi;
+        g.Wi = Wi;
+        g.ntaps = ntaps;
+        g.kw = kw;
+        g.pad = pad;
+        g.M = (long)N * H * W;
+        g.pix_per_split = tp.pix_per_split;
+        g.gn = tp.gn;
+        g.part = ws;
+        fast_div_consts((unsigned)W, &g.mulW, &g.shW);
+        fast_div_consts((unsigned)H, &g.mulH, &g.shH);
+        hipStream_t st = (hipStream_t)stream;
+        dim3 grid(tp.gm, tp.gn * ntaps, tp.splits);
+        {
+            ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)g.M * Cout * (double)ntaps * C);
+            if (tp.bm == 128 && tp.bn == 128)
+                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
+            else if (tp.bm == 128)
+                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, g);
+            else if (tp.bm == 64)
+                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<64, 128, 1, 4>), grid, dim3(256), 0, st, g);
+            else
+                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, g);
+        }
+        {
+            ProfScope prof(K_CONV_REDUCE, st, (double)(tp.splits + 1) * ntaps * Cout * C * 4);
+            hipLaunchKernelGGL(conv3x3_wgrad_tap_reduce_kernel, dim3(ceil_div(C, 64), Cout), dim3(256), 0, st, ws, tp.splits,
+                               ntaps, Cout, C, dw + (long)c_start * ntaps, (long)Cin_total * ntaps);
+        }
+        MNK_LAUNCH_CHECK();
+        return MNK_OK;
+    }
     HPlan hp;
     hp.use = false;
     if (kh == 3 && kw == 3 && pad == 1) hp = make_hplan(N, H, W, Cout, C);

@@ -116,6 +116,7 @@ static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline int __float2int_rd(float a) { return (int)floorf(a); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_barrier() { hipemu::sync_block(); }

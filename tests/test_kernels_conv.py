@@ -100,6 +100,9 @@ HALO_CASES = [
     (2, 16, 32, 120, 0, 130, 0, False, False),   # 2 ci tiles x 3 co tiles, several splits
     (1, 6, 64, 64, 0, 40, 0, False, False),      # TC = 64 (one row per tile), ragged H
     (1, 16, 16, 20, 0, 45, 0, False, False),     # poorly filled slab -> stays on the gather kernel
+    (1, 8, 8, 72, 0, 48, 0, False, False),       # tap-major form, 64 x 128 tile
+    (2, 5, 7, 33, 0, 129, 0, False, False),      # tap-major form, odd H / W (magic-number division), ragged tiles
+    (1, 8, 8, 80, 0, 24, 1, False, False),       # tap-major form, 32 x 128 tile, up-sampled source
 ]
 
 
