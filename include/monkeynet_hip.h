@@ -130,6 +130,11 @@ size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1);
 int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream);
 /* dgrad weights for input channels [c_start, c_start+c_count): wp[ci][chunk][tap][16] = w[16*chunk+k][c_start+ci][8-tap] */
 int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream);
+/* One launch for a training forward: the forward pack and the dgrad packs of source 0 (channels [0, C0), size
+ * mnk_conv3x3_packed_floats(C0, Cout, 0)) and of source 1 ([C0, C0+C1), size ..(C1, Cout, 0)); wp_d0 / wp_d1 may be
+ * NULL.  The parameter changes every optimiser step (train.py:118,132), so nothing packed can be kept across steps. */
+int mnk_conv3x3_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d1, int Cout, int C0, int C1,
+                         void* stream);
 size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
 /* `stats_partial` (optional, mnk_conv3x3_stats_floats floats; only when that query is > 0, i.e. no split-K): the kernel
  * epilogue also emits per-block column sums / sums of squares of y -- the BatchNorm statistics of the following
@@ -150,6 +155,8 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy,
  * up-sampled sizes).  Packed weights: [Cout][chunk][tap][16], tap = ky*kw + kx. */
 size_t mnk_conv2d_packed_floats(int Cout, int C0, int C1, int ntaps);
 int mnk_conv2d_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, int ntaps, void* stream);
+int mnk_conv2d_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d1, int Cout, int C0, int C1, int ntaps,
+                        void* stream);
 int mnk_conv2d_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, int ntaps,
                           void* stream);
 size_t mnk_conv2d_workspace_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps);

@@ -551,6 +551,52 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
     }
 }
 
+// forward layout and the data-gradient layouts of both sources in one launch: [0, nf) forward, [nf, nf + nd0) source 0,
+// [nf + nd0, nf + nd0 + nd1) source 1 (what a training forward needs; the pack kernels above stay for single uses)
+__global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                       float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0,
+                                                       int C1, int C0p, int C1p, int ntaps) {
+    const int Cin = C0 + C1, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
+    const long nf = (long)Cout * chunks * ntaps * 16;
+    const long nd0 = wd0 ? (long)C0 * dchunks * ntaps * 16 : 0, nd1 = wd1 ? (long)C1 * dchunks * ntaps * 16 : 0;
+    const long total = nf + nd0 + nd1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < nf) {
+            const int k16 = (int)(i & 15);
+            long t = i >> 4;
+            const int tap = (int)(t % ntaps);
+            t /= ntaps;
+            const int chunk = (int)(t % chunks);
+            const int co = (int)(t / chunks);
+            const int k = chunk * 16 + k16;
+            int ci = -1;
+            if (k < C0p) {
+                if (k < C0) ci = k;
+            } else if (k - C0p < C1) {
+                ci = C0 + k - C0p;
+            }
+            wf[i] = ci >= 0 ? w[((long)co * Cin + ci) * ntaps + tap] : 0.f;
+        } else {
+            long j = i - nf;
+            float* dst = wd0;
+            int c_start = 0;
+            if (j >= nd0) {
+                j -= nd0;
+                dst = wd1;
+                c_start = C0;
+            }
+            const int k16 = (int)(j & 15);
+            long t = j >> 4;
+            const int tap = (int)(t % ntaps);
+            t /= ntaps;
+            const int chunk = (int)(t % dchunks);
+            const int ci = (int)(t / dchunks);
+            const int co = chunk * 16 + k16;
+            dst[j] = co < Cout ? w[((long)co * Cin + c_start + ci) * ntaps + (ntaps - 1 - tap)] : 0.f;
+        }
+    }
+}
+
 // ---- weight gradient ----------------------------------------------------------------------------------------
 // GEMM  dW[co][n] = sum_p dY[p][co] * X[p + off(tap)][ci]  with n = ci*9 + tap, i.e. exactly the memory order of
 // the (Cout, Cin, 1, 3, 3) parameter: a block's result tile is written straight into the gradient (or into a
@@ -1254,6 +1300,20 @@ int mnk_conv2d_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, in
     return MNK_OK;
 }
 
+int mnk_conv2d_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d1, int Cout, int C0, int C1, int ntaps,
+                        void* stream) {
+    MNK_REQUIRE(w && wp_fwd && Cout > 0 && C0 > 0 && C1 >= 0 && ntaps > 0 && (!wp_d1 || C1 > 0));
+    hipStream_t s = (hipStream_t)stream;
+    const int C0p = round_up(C0, 16), C1p = C1 > 0 ? round_up(C1, 16) : 0;
+    const long dper = (long)round_up(Cout, 16) * ntaps;
+    const long total = (long)Cout * ntaps * (C0p + C1p) + (wp_d0 ? C0 * dper : 0) + (wp_d1 ? C1 * dper : 0);
+    ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0, C1, C0p,
+                       C1p, ntaps);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
 size_t mnk_conv2d_workspace_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || ntaps <= 0) return 0;
     const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
@@ -1534,6 +1594,10 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
 size_t mnk_conv3x3_packed_floats(int Cout, int C0, int C1) { return mnk_conv2d_packed_floats(Cout, C0, C1, 9); }
 int mnk_conv3x3_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream) {
     return mnk_conv2d_pack_fwd(w, wp, Cout, C0, C1, 9, stream);
+}
+int mnk_conv3x3_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d1, int Cout, int C0, int C1,
+                         void* stream) {
+    return mnk_conv2d_pack_all(w, wp_fwd, wp_d0, wp_d1, Cout, C0, C1, 9, stream);
 }
 int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream) {
     return mnk_conv2d_pack_dgrad(w, wp, Cout, Cin_total, c_start, c_count, 9, stream);

@@ -6,6 +6,7 @@ import torch
 
 from modules.losses import generator_loss, discriminator_loss
 from . import dist as mdist
+from . import ops as mops
 
 
 def split_kp(kp_joined, detach=False):
@@ -94,6 +95,7 @@ class TrainStep:
         for k in self._static_x:
             self._static_x[k].copy_(x[k], non_blocking=True)
         self._graph.replay()
+        mops.invalidate_packed_weights()      # the captured optimiser steps changed the parameters
         return self._static_out
 
     def _capture(self, x, warmup=3):
@@ -162,6 +164,7 @@ class Reconstructor:
         self._graph = None
         self._static_in = None
         self._static_out = None
+        self._epoch = -1
 
     @torch.no_grad()
     def _forward(self, source, driving):
@@ -174,7 +177,9 @@ class Reconstructor:
     def __call__(self, source, driving):
         if not self.use_graph:
             return self._forward(source, driving)
-        if self._graph is None or self._static_in[0].shape != source.shape:
+        if (self._graph is None or self._static_in[0].shape != source.shape
+                or self._epoch != mops._PACK_EPOCH[0]):    # parameters were updated: the captured packs are stale
+            self._epoch = mops._PACK_EPOCH[0]
             self._static_in = (source.clone(), driving.clone())
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -135,13 +135,29 @@ class Concat2Fn(torch.autograd.Function):
 # 3x3 convolution
 # ----------------------------------------------------------------------------------------------------------------
 _PACK_CACHE = {}
+_PACK_EPOCH = [0]
+
+
+def invalidate_packed_weights():
+    """Drop the inference-side packed-weight cache.  Fused optimisers update parameters without bumping
+    `Tensor._version`, so the version check alone cannot see an optimiser step: every optimiser step in the process
+    (hook below) and every replay of a captured training iteration (mnk.engine.TrainStep) calls this."""
+    _PACK_EPOCH[0] += 1
+
+
+try:  # any torch optimiser step anywhere invalidates the cache
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+    _reg_hook(lambda opt, args, kwargs: invalidate_packed_weights())
+except Exception:  # pragma: no cover - older torch: TrainStep still invalidates explicitly
+    pass
 
 
 def _packed_fwd_weight(weight, cout, c0, c1):
-    """Packed [Cout][chunk][tap][16] copy of a conv weight, cached per parameter version (inference loops reuse it;
-    training re-packs once per optimiser step)."""
+    """Packed [Cout][chunk][tap][16] copy of a conv weight for NO-GRAD forwards (inference loops), cached per
+    parameter version and optimiser epoch.  Training forwards never use the cache (Conv3x3Fn.forward packs the
+    forward and data-gradient layouts afresh in one launch)."""
     key = (id(weight), weight.device)
-    ver = weight._version
+    ver = (weight._version, _PACK_EPOCH[0])
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[1] == (cout, c0, c1) and hit[3] is weight:
         return hit[2]
@@ -189,13 +205,25 @@ class Conv3x3Fn(torch.autograd.Function):
     nearest x2 up-sampling (UpBlock3D, modules/util.py:83-85), plus bias and residual add (ResBlock3D :66-67)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, residual, c0, c1, ups, want_stats):
+    def forward(ctx, x0, x1, weight, bias, residual, c0, c1, ups, want_stats, track):
         _check_device(x0)
         cout = weight.shape[0]
         assert weight.shape[1] == c0 + c1 and weight.is_contiguous()
         n, hs, ws_, _ = x0.shape
         h, w = (hs * 2, ws_ * 2) if ups else (hs, ws_)
-        wp = _packed_fwd_weight(weight, cout, c0, c1)
+        if track:
+            # a backward will follow: the parameter changes every step -> pack now, forward + the data-gradient
+            # layouts the backward will need, in one launch
+            wp = torch.empty(_query("mnk_conv3x3_packed_floats", cout, c0, c1), dtype=torch.float32, device=x0.device)
+            wd = [None, None]
+            for i, cc in enumerate((c0, c1)):
+                if cc and ctx.needs_input_grad[i]:
+                    wd[i] = torch.empty(_query("mnk_conv3x3_packed_floats", cc, cout, 0), dtype=torch.float32,
+                                        device=x0.device)
+            _call("mnk_conv3x3_pack_all", weight, _p(weight), _p(wp), _p(wd[0]), _p(wd[1]), cout, c0, c1)
+            ctx.wd = wd
+        else:
+            wp = _packed_fwd_weight(weight, cout, c0, c1)
         y, sums = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats)
         ctx.save_for_backward(x0, x1, weight)
         ctx.meta = (c0, c1, ups, cout, n, h, w, bias is not None, residual is not None)
@@ -215,9 +243,7 @@ class Conv3x3Fn(torch.autograd.Function):
         for i, (src, cs, cc) in enumerate(((x0, 0, c0), (x1, c0, c1))):
             if src is None or not ctx.needs_input_grad[i]:
                 continue
-            npk = _query("mnk_conv3x3_packed_floats", cc, cout, 0)
-            wp = SCRATCH.get("pack", npk, dy)
-            _call("mnk_conv3x3_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, cs, cc)
+            wp = ctx.wd[i]                       # packed in the forward (mnk_conv3x3_pack_all)
             dx, _ = _conv_launch(dy, cout, None, 0, 0, wp, None, None, n, h, w, cc)
             if ups:
                 dxs = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
@@ -236,12 +262,14 @@ class Conv3x3Fn(torch.autograd.Function):
                       n, h, w, _p(ws), nws)
         db = channel_sums(dy, cout)[:cout] if has_bias and ctx.needs_input_grad[3] else None
         dres = dy if has_res and ctx.needs_input_grad[4] else None
-        return grads[0], grads[1], dw, db, dres, None, None, None, None
+        return grads[0], grads[1], dw, db, dres, None, None, None, None, None
 
 
 def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False):
     """-> (y, sums): sums = fused BatchNorm statistics [sum, sum of squares] of y when want_stats, else None."""
-    y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats))
+    track = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (x0, x1, weight, bias, residual))
+    y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
     return y, (sums if want_stats else None)
 
 

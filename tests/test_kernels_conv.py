@@ -129,6 +129,27 @@ def test_conv3x3_wgrad(be, case):
     assert relerr(DW.cpu(), wd.grad) < 2e-6
 
 
+def test_pack_all_equals_separate_packs(be):
+    """mnk_conv3x3_pack_all (one launch per training forward) == pack_fwd + pack_dgrad of both sources."""
+    cout, c0, c1 = 21, 18, 7
+    g = torch.Generator().manual_seed(11)
+    wt = be.t(torch.randn(cout, c0 + c1, 1, 3, 3, generator=g))
+    nf = be.query("mnk_conv3x3_packed_floats", cout, c0, c1)
+    n0, n1 = be.query("mnk_conv3x3_packed_floats", c0, cout, 0), be.query("mnk_conv3x3_packed_floats", c1, cout, 0)
+    ref_f, ref_0, ref_1 = be.empty(nf), be.empty(n0), be.empty(n1)
+    be.call("mnk_conv3x3_pack_fwd", wt, ref_f, cout, c0, c1)
+    be.call("mnk_conv3x3_pack_dgrad", wt, ref_0, cout, c0 + c1, 0, c0)
+    be.call("mnk_conv3x3_pack_dgrad", wt, ref_1, cout, c0 + c1, c0, c1)
+    a_f, a_0, a_1 = be.empty(nf), be.empty(n0), be.empty(n1)
+    be.call("mnk_conv3x3_pack_all", wt, a_f, a_0, a_1, cout, c0, c1)
+    be.sync()
+    assert torch.equal(a_f.cpu(), ref_f.cpu()) and torch.equal(a_0.cpu(), ref_0.cpu()) and torch.equal(a_1.cpu(), ref_1.cpu())
+    b_f = be.empty(nf)
+    be.call("mnk_conv3x3_pack_all", wt, b_f, None, None, cout, c0, c1)
+    be.sync()
+    assert torch.equal(b_f.cpu(), ref_f.cpu())
+
+
 def test_sumpool2x2(be):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(2, 5, 6, 8, generator=g)

@@ -144,6 +144,40 @@ def test_reference_configs_on_gpu(name):
     check_outputs(out, gold, "eval", factor=8.0, floor=5e-6)
 
 
+def test_weights_updated_without_version_bump_are_seen(be):
+    """Fused optimisers (torch.optim.Adam(fused=True), the default of mnk.engine.TrainStep on the GPU) write the
+    parameters without bumping Tensor._version.  Neither the training forward (packs per call) nor the no-grad
+    forward (cache keyed by version AND optimiser epoch) may keep using the old packed weights."""
+    from mnk import ops
+    torch.manual_seed(5)
+    import torch.nn.functional as F
+    w = torch.nn.Parameter(be.t(torch.randn(9, 6, 1, 3, 3) * 0.2))
+    x = torch.rand(2, 6, 1, 8, 8)
+    xa = ops.to_act(be.t(x))
+
+    def run(grad):
+        with torch.enable_grad() if grad else torch.no_grad():
+            y, _ = ops.conv3x3(xa, 6, w)
+        return ops.from_act(y.detach(), 9, 2).cpu()
+
+    def ref():
+        return F.conv2d(x[:, :, 0].double(), w.detach().cpu()[:, :, 0].double(), padding=1).float().unsqueeze(2)
+
+    for grad in (True, False):
+        assert float((run(grad) - ref()).abs().max()) < 1e-5
+        ver = w._version
+        w.data.mul_(-1.5)                      # what a fused optimiser step looks like to the version counter
+        assert w._version == ver
+        ops.invalidate_packed_weights()        # what the optimiser-step hook / TrainStep replay do
+        assert float((run(grad) - ref()).abs().max()) < 1e-5, "stale packed weights (grad=%s)" % grad
+    # and the hook itself: any optimiser step invalidates
+    e0 = ops._PACK_EPOCH[0]
+    opt = torch.optim.SGD([w], lr=0.1)
+    w.grad = torch.zeros_like(w)
+    opt.step()
+    assert ops._PACK_EPOCH[0] > e0
+
+
 def test_down_block_with_fused_statistics(be):
     """A block large enough that the conv is not split along K, so the BatchNorm statistics come out of the conv
     epilogue (mnk_conv3x3_stats_floats > 0); forward, running stats and all gradients against the oracle in fp64."""
