@@ -59,6 +59,90 @@ struct ConvArgs {
     float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
 };
 
+// ---- the activation-side loader of the implicit GEMM (shared by the 32x32 and 16x16 tile kernels) -------------------
+// Everything a K step needs per row is precomputed (frame base, row / column, validity bit masks of the kernel rows
+// and columns); the per-step gather is branch-free: a tap outside the image reads the clamped pixel and is zeroed on
+// its way to LDS, rows beyond M are clamped to the last pixel (their results are never stored).  K-step cursor
+// (step = chunk * ntaps + ky * kw + kx) advances without divisions or branches.
+template <int RA>
+struct ActLoader {
+    int prow[RA], ph[RA], pw[RA];
+    unsigned pmask[RA];            // bits 0..7: kernel rows inside the image, bits 8..15: kernel columns
+    float4 ra[RA];
+    int tail[RA];                  // real channels in ra[j] (<= 0: tap outside the image / chunk beyond C)
+    int chunk, ky, kx, khh, Hs, Ws, hmax, wmax, lq;
+
+    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin) {
+        lq = lq_;
+        Hs = a.ups ? a.Hi >> 1 : a.Hi;
+        Ws = a.ups ? a.Wi >> 1 : a.Wi;
+        khh = a.ntaps / a.kw;
+        hmax = a.Hi - 1;
+        wmax = a.Wi - 1;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            long m = m0 + lrow + 64 * j;
+            if (m > a.M - 1) m = a.M - 1;
+            pw[j] = (int)(m % a.W);
+            const long tt = m / a.W;
+            ph[j] = (int)(tt % a.H);
+            prow[j] = (int)(tt / a.H) * Hs * Ws;
+            unsigned mk = 0;
+            for (int y = 0; y < khh; ++y) {
+                const int hh = ph[j] + y - a.pad;
+                if (hh >= 0 && hh < a.Hi) mk |= 1u << y;
+            }
+            for (int x = 0; x < a.kw; ++x) {
+                const int ww = pw[j] + x - a.pad;
+                if (ww >= 0 && ww < a.Wi) mk |= 256u << x;
+            }
+            pmask[j] = mk;
+            tail[j] = 0;
+        }
+        chunk = s_begin / a.ntaps;
+        ky = (s_begin - chunk * a.ntaps) / a.kw;
+        kx = (s_begin - chunk * a.ntaps) - ky * a.kw;
+    }
+    // issue the global loads of the cursor's K step, then advance the cursor
+    __device__ __forceinline__ void load(const ConvArgs& a) {
+        const int c0 = chunk * BK;
+        const bool second = c0 >= a.C0p;
+        const int cbase = second ? c0 - a.C0p : c0;
+        const float* src = second ? a.x1 : a.x0;
+        const int ld = second ? a.ld1 : a.ld0, C = second ? a.C1 : a.C0;
+        const int ch = cbase + lq * 4;
+        const int tl = C - ch;
+        const int che = tl > 0 ? ch : 0;
+        const int dy = ky - a.pad, dx = kx - a.pad;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const bool ok = (pmask[j] >> ky) & (pmask[j] >> (8 + kx)) & 1u;
+            int hh = ph[j] + dy, ww = pw[j] + dx;     // clamped into the image: the load is unconditional
+            hh = hh < 0 ? 0 : (hh > hmax ? hmax : hh);
+            ww = ww < 0 ? 0 : (ww > wmax ? wmax : ww);
+            const unsigned off = (unsigned)(prow[j] + (hh >> a.ups) * Ws + (ww >> a.ups)) * (unsigned)ld + (unsigned)che;
+            ra[j] = *reinterpret_cast<const float4*>(src + off);
+            tail[j] = ok ? tl : 0;
+        }
+        const int kx1 = kx + 1;
+        const bool wx = kx1 == a.kw;
+        kx = wx ? 0 : kx1;
+        const int ky1 = ky + (wx ? 1 : 0);
+        const bool wy = ky1 == khh;
+        ky = wy ? 0 : ky1;
+        chunk += wy ? 1 : 0;
+    }
+    // row j on its way to LDS: pad channels of the producer may hold anything, taps outside the image are zero
+    __device__ __forceinline__ float4 masked(int j) const {
+        float4 v = ra[j];
+        v.x = tail[j] < 1 ? 0.f : v.x;
+        v.y = tail[j] < 2 ? 0.f : v.y;
+        v.z = tail[j] < 3 ? 0.f : v.z;
+        v.w = tail[j] < 4 ? 0.f : v.w;
+        return v;
+    }
+};
+
 #ifndef MNK_IGEMM_OCC
 #define MNK_IGEMM_OCC 3                       // waves per SIMD = blocks per CU the register budget is held to
 #endif
@@ -81,91 +165,27 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     int s_end = s_begin + a.ksteps_per_split;
     if (s_end > a.ksteps) s_end = a.ksteps;
 
-    // ---- per-thread global->LDS assignment --------------------------------------------------------------
-    // Everything a K step needs per row is precomputed (frame base, row/column, per-row validity bit masks of the
-    // kernel rows / columns); the per-step gather is branch-free: a tap outside the image reads the clamped pixel
-    // and is zeroed on its way to LDS, rows beyond M / Cout are clamped to the last real row (never stored).
-    const int lrow = t >> 2, lq = t & 3;      // row inside a 64-row slab, float4 column (4 channels)
-    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
-    const int khh = a.ntaps / a.kw;
-    int prow[RA], ph[RA], pw[RA];
-    unsigned pmask[RA];                       // bits 0..7: kernel rows inside the image, bits 8..15: kernel columns
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        long m = m0 + lrow + 64 * j;
-        if (m > a.M - 1) m = a.M - 1;
-        pw[j] = (int)(m % a.W);
-        const long tt = m / a.W;
-        ph[j] = (int)(tt % a.H);
-        prow[j] = (int)(tt / a.H) * Hs * Ws;
-        unsigned mk = 0;
-        for (int ky = 0; ky < khh; ++ky) {
-            const int hh = ph[j] + ky - a.pad;
-            if (hh >= 0 && hh < a.Hi) mk |= 1u << ky;
-        }
-        for (int kx = 0; kx < a.kw; ++kx) {
-            const int ww = pw[j] + kx - a.pad;
-            if (ww >= 0 && ww < a.Wi) mk |= 256u << kx;
-        }
-        pmask[j] = mk;
-    }
+    // ---- per-thread global->LDS assignment: row inside a 64-row slab, float4 column (4 channels) --------------
+    const int lrow = t >> 2, lq = t & 3;
+    ActLoader<RA> L;
+    L.setup(a, m0, lrow, lq, s_begin);
     constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
     const long KT = (long)a.ksteps * BK;     // packed row length
     static_assert(RB <= 2, "at most two weight rows per thread");
-    const int wco0 = n0 + lrow, wco1 = n0 + lrow + 64;
+    const int wco0 = n0 + lrow, wco1 = n0 + lrow + 64;    // rows beyond Cout: clamped, never stored
     const unsigned woff0 = (unsigned)((wco0 < a.Cout ? wco0 : a.Cout - 1) * KT) + lq * 4;
     const unsigned woff1 = (unsigned)((wco1 < a.Cout ? wco1 : a.Cout - 1) * KT) + lq * 4;
-
-    float4 ra[RA], rb0, rb1;
-    int ra_tail[RA];                          // real channels in ra[j] (<= 0: tap outside the image / chunk beyond C);
-                                              // the other components are zeroed on the way to LDS, one step later
-    // K-step cursor of the loader (step = chunk * ntaps + ky * kw + kx), advanced without divisions or branches
-    int l_chunk = s_begin / a.ntaps;
-    int l_ky = (s_begin - l_chunk * a.ntaps) / a.kw;
-    int l_kx = (s_begin - l_chunk * a.ntaps) - l_ky * a.kw;
-    const int hmax = a.Hi - 1, wmax = a.Wi - 1;
+    float4 rb0, rb1;
 
     auto load_step = [&](int s) __attribute__((always_inline)) {
-        const int c0 = l_chunk * BK;
-        const bool second = c0 >= a.C0p;
-        const int cbase = second ? c0 - a.C0p : c0;
-        const float* src = second ? a.x1 : a.x0;
-        const int ld = second ? a.ld1 : a.ld0, C = second ? a.C1 : a.C0;
-        const int ch = cbase + lq * 4;
-        const int tail = C - ch;
-        const int che = tail > 0 ? ch : 0;
-        const int dy = l_ky - a.pad, dx = l_kx - a.pad;
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const bool ok = (pmask[j] >> l_ky) & (pmask[j] >> (8 + l_kx)) & 1u;
-            int hh = ph[j] + dy, ww = pw[j] + dx;     // clamped into the image: the load is unconditional
-            hh = hh < 0 ? 0 : (hh > hmax ? hmax : hh);
-            ww = ww < 0 ? 0 : (ww > wmax ? wmax : ww);
-            const unsigned off = (unsigned)(prow[j] + (hh >> a.ups) * Ws + (ww >> a.ups)) * (unsigned)ld + (unsigned)che;
-            ra[j] = *reinterpret_cast<const float4*>(src + off);
-            ra_tail[j] = ok ? tail : 0;
-        }
+        L.load(a);
         const float* wsrc_ptr = a.wp + (long)s * BK;
         rb0 = *reinterpret_cast<const float4*>(wsrc_ptr + woff0);
         if constexpr (RB > 1) rb1 = *reinterpret_cast<const float4*>(wsrc_ptr + woff1);
-        const int kx1 = l_kx + 1;
-        const bool wx = kx1 == a.kw;
-        l_kx = wx ? 0 : kx1;
-        const int ky1 = l_ky + (wx ? 1 : 0);
-        const bool wy = ky1 == khh;
-        l_ky = wy ? 0 : ky1;
-        l_chunk += wy ? 1 : 0;
     };
     auto store_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            float4 v = ra[j];
-            v.x = ra_tail[j] < 1 ? 0.f : v.x;
-            v.y = ra_tail[j] < 2 ? 0.f : v.y;
-            v.z = ra_tail[j] < 3 ? 0.f : v.z;
-            v.w = ra_tail[j] < 4 ? 0.f : v.w;
-            *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = v;
-        }
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = L.masked(j);
         if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = rb0;
         if constexpr (RB > 1) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64][lq * 4]) = rb1;
     };
@@ -323,62 +343,19 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     int s_end = s_begin + a.ksteps_per_split;
     if (s_end > a.ksteps) s_end = a.ksteps;
     const int lrow = t >> 2, lq = t & 3;
-    int pn[RA], ph[RA], pw[RA];
-    bool pvalid[RA];
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        long m = m0 + lrow + 64 * j;
-        pvalid[j] = m < a.M;
-        long mm = pvalid[j] ? m : 0;
-        pw[j] = (int)(mm % a.W);
-        long tt = mm / a.W;
-        ph[j] = (int)(tt % a.H);
-        pn[j] = (int)(tt / a.H);
-    }
-    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
+    ActLoader<RA> L;
+    L.setup(a, m0, lrow, lq, s_begin);
     const long KT = (long)a.ksteps * BK;
-    float4 ra[RA], rb;
-    auto load_step = [&](int s) {
-        const int chunk = s / a.ntaps;
-        const int tap = s - chunk * a.ntaps;
-        const int dy = tap / a.kw - a.pad, dx = tap % a.kw - a.pad;
-        int cbase = chunk * BK;
-        const float* src;
-        int ld, C;
-        if (cbase < a.C0p) {
-            src = a.x0;
-            ld = a.ld0;
-            C = a.C0;
-        } else {
-            cbase -= a.C0p;
-            src = a.x1;
-            ld = a.ld1;
-            C = a.C1;
-        }
-        const int ch = cbase + lq * 4;
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int hh = ph[j] + dy, ww = pw[j] + dx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pvalid[j] && hh >= 0 && hh < a.Hi && ww >= 0 && ww < a.Wi && ch < C) {
-                const int hs = a.ups ? hh >> 1 : hh, wsrc = a.ups ? ww >> 1 : ww;
-                v = *reinterpret_cast<const float4*>(src + (((long)pn[j] * Hs + hs) * Ws + wsrc) * ld + ch);
-                const int rem = C - ch;
-                if (rem < 4) {
-                    if (rem < 2) v.y = 0.f;
-                    if (rem < 3) v.z = 0.f;
-                    v.w = 0.f;
-                }
-            }
-            ra[j] = v;
-        }
-        rb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lrow < BN && n0 + lrow < a.Cout)
-            rb = *reinterpret_cast<const float4*>(a.wp + (long)(n0 + lrow) * KT + (long)s * BK + lq * 4);
+    const int wco = n0 + (lrow < BN ? lrow : 0);           // rows beyond BN / Cout: clamped, never stored
+    const unsigned woff = (unsigned)((wco < a.Cout ? wco : a.Cout - 1) * KT) + lq * 4;
+    float4 rb;
+    auto load_step = [&](int s) __attribute__((always_inline)) {
+        L.load(a);
+        rb = *reinterpret_cast<const float4*>(a.wp + (long)s * BK + woff);
     };
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = ra[j];
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = L.masked(j);
         if (lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = rb;
     };
 
@@ -391,14 +368,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     const int fi = lane & 15, fk = lane >> 4;     // row/col inside a 16-tile, k group 0..3
-    if (s_begin < s_end) {
-        load_step(s_begin);
-        store_step(0);
-    }
-    __syncthreads();
-    for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        if (s + 1 < s_end) load_step(s + 1);
+    auto mfma_step = [&](int buf) __attribute__((always_inline)) {
         float4 fa[TM], fb[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -414,9 +384,31 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
             }
-        if (s + 1 < s_end) store_step(buf ^ 1);
+    };
+    // same pipeline as conv3x3_igemm_kernel: registers hold step s+1, loads of step s+2 precede the MFMAs of step s
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+        if (s_begin + 1 < s_end) load_step(s_begin + 1);
+    }
+    __syncthreads();
+    int s = s_begin;
+    for (; s + 2 < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        store_step(buf ^ 1);
+        load_step(s + 2);
+        mfma_step(buf);
         __syncthreads();
     }
+    if (s + 1 < s_end) {
+        const int buf = (s - s_begin) & 1;
+        store_step(buf ^ 1);
+        mfma_step(buf);
+        __syncthreads();
+        ++s;
+    }
+    if (s < s_end) mfma_step((s - s_begin) & 1);
+    __syncthreads();                          // the epilogue reuses As for the column sums
     const bool split_out = a.splits > 1;
     const long ldo = split_out ? (long)a.ldw : (long)a.ld_y;
     float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
@@ -556,44 +548,51 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ w, float* __restrict__ wf,
                                                        float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0,
                                                        int C1, int C0p, int C1p, int ntaps) {
-    const int Cin = C0 + C1, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
-    const long nf = (long)Cout * chunks * ntaps * 16;
-    const long nd0 = wd0 ? (long)C0 * dchunks * ntaps * 16 : 0, nd1 = wd1 ? (long)C1 * dchunks * ntaps * 16 : 0;
-    const long total = nf + nd0 + nd1;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        if (i < nf) {
-            const int k16 = (int)(i & 15);
-            long t = i >> 4;
-            const int tap = (int)(t % ntaps);
-            t /= ntaps;
-            const int chunk = (int)(t % chunks);
-            const int co = (int)(t / chunks);
-            const int k = chunk * 16 + k16;
-            int ci = -1;
-            if (k < C0p) {
-                if (k < C0) ci = k;
-            } else if (k - C0p < C1) {
-                ci = C0 + k - C0p;
+    // one thread per 16-float group (index arithmetic once per group, four 16-byte stores)
+    const unsigned Cin = C0 + C1, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
+    const unsigned gf = (unsigned)Cout * chunks * ntaps;
+    const unsigned gd0 = wd0 ? (unsigned)C0 * dchunks * ntaps : 0, gd1 = wd1 ? (unsigned)C1 * dchunks * ntaps : 0;
+    const unsigned total = gf + gd0 + gd1;
+    for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        float v[16];
+        float* dst;
+        if (g < gf) {
+            const unsigned tap = g % ntaps, t = g / ntaps;
+            const unsigned chunk = t % chunks, co = t / chunks;
+            const float* src = w + ((size_t)co * Cin) * ntaps + tap;
+#pragma unroll
+            for (int k16 = 0; k16 < 16; ++k16) {
+                const int k = chunk * 16 + k16;
+                int ci = -1;
+                if (k < C0p) {
+                    if (k < C0) ci = k;
+                } else if (k - C0p < C1) {
+                    ci = C0 + k - C0p;
+                }
+                v[k16] = ci >= 0 ? src[(size_t)ci * ntaps] : 0.f;
             }
-            wf[i] = ci >= 0 ? w[((long)co * Cin + ci) * ntaps + tap] : 0.f;
+            dst = wf + (size_t)g * 16;
         } else {
-            long j = i - nf;
-            float* dst = wd0;
-            int c_start = 0;
-            if (j >= nd0) {
-                j -= nd0;
+            unsigned j = g - gf, c_start = 0;
+            dst = wd0;
+            if (j >= gd0) {
+                j -= gd0;
                 dst = wd1;
                 c_start = C0;
             }
-            const int k16 = (int)(j & 15);
-            long t = j >> 4;
-            const int tap = (int)(t % ntaps);
-            t /= ntaps;
-            const int chunk = (int)(t % dchunks);
-            const int ci = (int)(t / dchunks);
-            const int co = chunk * 16 + k16;
-            dst[j] = co < Cout ? w[((long)co * Cin + c_start + ci) * ntaps + (ntaps - 1 - tap)] : 0.f;
+            const unsigned tap = j % ntaps, t = j / ntaps;
+            const unsigned chunk = t % dchunks, ci = t / dchunks;
+            const float* src = w + ((size_t)c_start + ci) * ntaps + (ntaps - 1 - tap);
+#pragma unroll
+            for (int k16 = 0; k16 < 16; ++k16) {
+                const unsigned co = chunk * 16 + k16;
+                v[k16] = co < (unsigned)Cout ? src[(size_t)co * Cin * ntaps] : 0.f;
+            }
+            dst += (size_t)j * 16;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
 }
 
@@ -1047,9 +1046,10 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
         }
 }
 
-// dw[co][(c_start + ci) * ntaps + tap] = sum_s part[s][tap][co][ci]: one block per (64-channel ci tile, co); reads
-// are coalesced along ci, the (tap, ci) -> (ci, tap) transposition goes through LDS, writes are contiguous runs of
-// 64 * ntaps floats.  Fixed summation order (deterministic).
+// dw[co][(c_start + ci) * ntaps + tap] = sum_s part[s][tap][co][ci]: one block per (64-channel ci tile, co row);
+// reads are coalesced along ci with four independent split-sum chains per element (loads in flight), the
+// (tap, ci) -> (ci, tap) transposition goes through LDS, writes are contiguous runs of 64 * ntaps floats.
+// Fixed summation order (deterministic).
 __global__ void __launch_bounds__(256) conv3x3_wgrad_tap_reduce_kernel(const float* __restrict__ part, int splits,
                                                                        int ntaps, int Cout, int C,
                                                                        float* __restrict__ dw, long ld_out) {
@@ -1057,26 +1057,55 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_tap_reduce_kernel(const flo
     const int t = threadIdx.x;
     const int ci0 = blockIdx.x * 64, co = blockIdx.y;
     const long plane = (long)Cout * C, sstride = (long)ntaps * plane;
-    for (int idx = t; idx < ntaps * 64; idx += 256) {
-        const int tp = idx >> 6, c = idx & 63;
-        float v0 = 0.f, v1 = 0.f;
-        if (ci0 + c < C) {
-            const float* src = part + (long)tp * plane + (long)co * C + ci0 + c;
-            int s = 0;
-            for (; s + 1 < splits; s += 2) {
-                v0 += src[(long)s * sstride];
-                v1 += src[(long)(s + 1) * sstride];
-            }
-            if (s < splits) v0 += src[(long)s * sstride];
+    const int c = t & 63;
+    const bool c_ok = ci0 + c < C;
+    for (int tp = t >> 6; tp < ntaps; tp += 4) {
+        const float* src = c_ok ? part + (long)tp * plane + (long)co * C + ci0 + c : part;   // always loadable
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int sp = 0;
+        for (; sp + 3 < splits; sp += 4) {
+            const float x0 = src[(long)sp * sstride], x1 = src[(long)(sp + 1) * sstride];
+            const float x2 = src[(long)(sp + 2) * sstride], x3 = src[(long)(sp + 3) * sstride];
+            v0 += x0;
+            v1 += x1;
+            v2 += x2;
+            v3 += x3;
         }
-        tile[tp][c] = v0 + v1;
+        for (; sp < splits; ++sp) v0 += src[(long)sp * sstride];
+        tile[tp][c] = c_ok ? (v0 + v1) + (v2 + v3) : 0.f;
     }
     __syncthreads();
     float* dst = dw + (long)co * ld_out + (long)ci0 * ntaps;
     const int lim = (C - ci0 < 64 ? C - ci0 : 64) * ntaps;
     for (int idx = t; idx < lim; idx += 256) {
-        const int c = idx / ntaps, tp = idx - c * ntaps;
-        dst[idx] = tile[tp][c];
+        const int cc = idx / ntaps, tp = idx - cc * ntaps;
+        dst[idx] = tile[tp][cc];
+    }
+}
+
+// first stage for many-split layers (large pixel counts, small dW): out[z][i] = sum of the splits of group z, so the
+// summation runs over (elements x groups) threads instead of elements only; the transposing kernel above then sums
+// the groups.  Fixed order inside a group and over the groups (deterministic).
+__global__ void __launch_bounds__(256) conv3x3_wgrad_group_sum_kernel(const float* __restrict__ part, long n, int splits,
+                                                                      int per_group, float* __restrict__ out) {
+    const int z = blockIdx.y;
+    const int s0 = z * per_group;
+    int s1 = s0 + per_group;
+    if (s1 > splits) s1 = splits;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float* src = part + i;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int sp = s0;
+        for (; sp + 3 < s1; sp += 4) {
+            const float x0 = src[(long)sp * n], x1 = src[(long)(sp + 1) * n];
+            const float x2 = src[(long)(sp + 2) * n], x3 = src[(long)(sp + 3) * n];
+            v0 += x0;
+            v1 += x1;
+            v2 += x2;
+            v3 += x3;
+        }
+        for (; sp < s1; ++sp) v0 += src[(long)sp * n];
+        out[(long)z * n + i] = (v0 + v1) + (v2 + v3);
     }
 }
 
@@ -1216,6 +1245,7 @@ static WPlan make_wplan(long M, int Cout, int C, int ntaps = 9) {
 struct TPlan {
     bool use;
     int bm, bn, gm, gn, splits;
+    int groups, per_group;       // two-stage split reduction when splits > 12 (groups of ~8 splits), else groups = 0
     long pix_per_split;
 };
 static int g_wgrad_tap = env_int("MNK_WGRAD_TAP", 1), g_wtap_target = env_int("MNK_WTAP_TARGET", 768),
@@ -1242,6 +1272,8 @@ static TPlan make_tplan(long M, int Cout, int C, int ntaps, int ld_x) {
     const long steps_per = (steps + splits - 1) / splits;
     p.pix_per_split = steps_per * BK;
     p.splits = (int)((steps + steps_per - 1) / steps_per);
+    p.groups = p.splits > 12 ? ceil_div(p.splits, 8) : 0;     // == split_groups(splits)
+    p.per_group = 8;
     return p;
 }
 
@@ -1263,6 +1295,26 @@ static inline int grid_for(long total, int cap = 4096) {
     long b = (total + 255) / 256;
     if (b < 1) b = 1;
     return (int)(b < cap ? b : cap);
+}
+
+// groups of the two-stage split reduction (0: single stage)
+static inline int split_groups(int splits) { return splits > 12 ? ceil_div(splits, 8) : 0; }
+
+// sum `splits` partials of n floats each (at ws) into dst rows: optional first stage over groups of 8 splits
+static void launch_wgrad_reduce(float* ws, int splits, int Cout, int NT, float* dst, long ld_out, hipStream_t s) {
+    const long n = (long)Cout * NT;
+    const float* src = ws;
+    int nsum = splits;
+    const int groups = split_groups(splits);
+    if (groups) {
+        float* part2 = ws + (size_t)splits * n;
+        hipLaunchKernelGGL(conv3x3_wgrad_group_sum_kernel, dim3(grid_for(n, 1024), groups), dim3(256), 0, s, ws, n, splits, 8,
+                           part2);
+        src = part2;
+        nsum = groups;
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for(n * 4, 8192)), dim3(256), 0, s, src, nsum, Cout, NT, dst,
+                       ld_out);
 }
 
 }  // namespace
@@ -1307,9 +1359,10 @@ int mnk_conv2d_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d
     const int C0p = round_up(C0, 16), C1p = C1 > 0 ? round_up(C1, 16) : 0;
     const long dper = (long)round_up(Cout, 16) * ntaps;
     const long total = (long)Cout * ntaps * (C0p + C1p) + (wp_d0 ? C0 * dper : 0) + (wp_d1 ? C1 * dper : 0);
+    MNK_REQUIRE(total < (1L << 31) && ((size_t)wp_fwd % 16) == 0 && ((size_t)wp_d0 % 16) == 0 && ((size_t)wp_d1 % 16) == 0);
     ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
-    hipLaunchKernelGGL(pack_all_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0, C1, C0p,
-                       C1p, ntaps);
+    hipLaunchKernelGGL(pack_all_kernel, dim3(grid_for(total / 16, 8192)), dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0,
+                       C1, C0p, C1p, ntaps);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -1412,14 +1465,14 @@ size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout,
     const int ntaps = kh * kw;
     {   // the caller's ld_x is not known here: size for the tap-major form whenever the shape allows it
         TPlan tp = make_tplan((long)N * Ho * Wo, Cout, C, ntaps, round_up(C, 4));
-        if (tp.use) return (size_t)tp.splits * ntaps * Cout * C;
+        if (tp.use) return (size_t)(tp.splits + tp.groups) * ntaps * Cout * C;
     }
     if (kh == 3 && kw == 3 && pad == 1) {
         HPlan hp = make_hplan(N, Ho, Wo, Cout, C);
-        if (hp.use) return hp.splits > 1 ? (size_t)hp.splits * Cout * 9 * C : 0;
+        if (hp.use) return hp.splits > 1 ? (size_t)(hp.splits + split_groups(hp.splits)) * Cout * 9 * C : 0;
     }
     WPlan p = make_wplan((long)N * Ho * Wo, Cout, C, ntaps);
-    return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)p.splits * Cout * ntaps * C : 0;
+    return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
 }
 
 int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
@@ -1434,7 +1487,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
     TPlan tp = make_tplan((long)N * H * W, Cout, C, ntaps, ld_x);
     if (tp.use && ((size_t)x % 16 != 0 || (size_t)dy % 16 != 0)) tp.use = false;
     if (tp.use) {
-        const size_t need = (size_t)tp.splits * ntaps * Cout * C;
+        const size_t need = (size_t)(tp.splits + tp.groups) * ntaps * Cout * C;
         if (!ws || ws_floats < need) {
             set_error("mnk_conv2d_wgrad: workspace too small (%zu < %zu floats)", ws_floats, need);
             return MNK_EWORKSPACE;
@@ -1475,7 +1528,17 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
         }
         {
             ProfScope prof(K_CONV_REDUCE, st, (double)(tp.splits + 1) * ntaps * Cout * C * 4);
-            hipLaunchKernelGGL(conv3x3_wgrad_tap_reduce_kernel, dim3(ceil_div(C, 64), Cout), dim3(256), 0, st, ws, tp.splits,
+            const long n = (long)ntaps * Cout * C;
+            const float* src = ws;
+            int nsum = tp.splits;
+            if (tp.groups) {
+                float* part2 = ws + (size_t)tp.splits * n;
+                hipLaunchKernelGGL(conv3x3_wgrad_group_sum_kernel, dim3(grid_for(n, 1024), tp.groups), dim3(256), 0, st, ws, n,
+                                   tp.splits, tp.per_group, part2);
+                src = part2;
+                nsum = tp.groups;
+            }
+            hipLaunchKernelGGL(conv3x3_wgrad_tap_reduce_kernel, dim3(ceil_div(C, 64), Cout), dim3(256), 0, st, src, nsum,
                                ntaps, Cout, C, dw + (long)c_start * ntaps, (long)Cin_total * ntaps);
         }
         MNK_LAUNCH_CHECK();
@@ -1508,7 +1571,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
         float* dsth = dw + (long)c_start * 9;
         const long ldh = (long)Cin_total * 9;
         if (hp.splits > 1) {
-            if (!ws || ws_floats < (size_t)hp.splits * Cout * h.NT) {
+            if (!ws || ws_floats < (size_t)(hp.splits + split_groups(hp.splits)) * Cout * h.NT) {
                 set_error("mnk_conv2d_wgrad: workspace too small");
                 return MNK_EWORKSPACE;
             }
@@ -1525,8 +1588,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
         }
         if (hp.splits > 1) {
             ProfScope prof(K_CONV_REDUCE, sh, (double)hp.splits * Cout * h.NT * 4);
-            hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * h.NT * 4, 8192)), dim3(256), 0, sh, ws,
-                               hp.splits, Cout, h.NT, dsth, ldh);
+            launch_wgrad_reduce(ws, hp.splits, Cout, h.NT, dsth, ldh, sh);
         }
         MNK_LAUNCH_CHECK();
         return MNK_OK;
@@ -1557,7 +1619,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
     hipStream_t s = (hipStream_t)stream;
     a.atomic = g_wgrad_atomic;
     if (p.splits > 1 && !a.atomic) {
-        if (!ws || ws_floats < (size_t)p.splits * Cout * a.NT) {
+        if (!ws || ws_floats < (size_t)(p.splits + split_groups(p.splits)) * Cout * a.NT) {
             set_error("mnk_conv2d_wgrad: workspace too small");
             return MNK_EWORKSPACE;
         }
@@ -1583,8 +1645,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
     }
     if (p.splits > 1 && !a.atomic) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);
-        hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(grid_for((long)Cout * a.NT * 4, 8192)), dim3(256), 0, s, ws, p.splits,
-                           Cout, a.NT, dst, ld_out);
+        launch_wgrad_reduce(ws, p.splits, Cout, a.NT, dst, ld_out, s);
     }
     MNK_LAUNCH_CHECK();
     return MNK_OK;

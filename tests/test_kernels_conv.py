@@ -103,6 +103,9 @@ HALO_CASES = [
     (1, 8, 8, 72, 0, 48, 0, False, False),       # tap-major form, 64 x 128 tile
     (2, 5, 7, 33, 0, 129, 0, False, False),      # tap-major form, odd H / W (magic-number division), ragged tiles
     (1, 8, 8, 80, 0, 24, 1, False, False),       # tap-major form, 32 x 128 tile, up-sampled source
+    (2, 32, 32, 72, 0, 40, 0, False, False),     # tap-major form, 16 pixel splits -> two-stage split reduction
+    (6, 64, 64, 5, 0, 20, 0, False, False),      # gather kernel, 192 pixel splits -> two-stage split reduction
+    (2, 64, 64, 40, 0, 60, 0, False, False),     # halo kernel, 16 tile splits -> two-stage split reduction
 ]
 
 
