@@ -883,6 +883,153 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
         }
 }
 
+// ---- weight gradient, narrow layers (C, Cout <= 64 at high resolution: the 45-channel refinement stack) ------------
+// 16x16x4 MFMA tiles on a 48 (co) x 48 (ci) channel tile (45 channels fill 94 % of it; a 64-wide tile only 49 %) with
+// ALL nine taps in one block: per 8x8-pixel tile the dy tile [64 px][48 co] and the x tile with a one-pixel halo
+// [10 x 10 px][48 ci] are staged in LDS once, and every tap is a shifted LDS read -- 27 MFMAs per 12 ds_read_b32.
+// A block is 3 wavefronts, wavefront w owns kernel row ky = w: 3 (kx) x 3 (co tiles) x 3 (ci tiles) accumulators of
+// 4 registers.  The next pixel tile is prefetched into registers while the MFMAs of the current one run.
+// LDS rows are 48 floats (= 16 mod 32 banks): the four 16-lane groups of a fragment read hit disjoint banks.
+struct WgradN16Args {
+    const float* x;
+    int ld_x, C, ups;
+    const float* dy;
+    int ld_dy, Cout;
+    int H, W;
+    int tiles_w, tiles_per_img;
+    long total_tiles, tiles_per_split;
+    int NT;
+    float* out;
+    long ld_out;
+    int splits;
+};
+
+
+template <int NCT, int NCI>     // 16-wide co / ci tiles in use (1..3): narrower layers skip the padded tiles at compile time
+__global__ void __launch_bounds__(192) conv3x3_wgrad_n16_kernel(WgradN16Args a) {
+    constexpr int LD = 48, HW2 = 10, HP = 100;
+    __shared__ __attribute__((aligned(16))) float As[64][LD];       // dy tile [pixel][co]
+    __shared__ __attribute__((aligned(16))) float Xs[HP][LD];       // x tile with halo [staged pixel][ci]
+    const int t = threadIdx.x, lane = t & 63, ky = t >> 6;
+    const int co0 = blockIdx.x * 48, ci0 = blockIdx.y * 48, split = blockIdx.z;
+    const long tile_begin = (long)split * a.tiles_per_split;
+    long tile_end = tile_begin + a.tiles_per_split;
+    if (tile_end > a.total_tiles) tile_end = a.total_tiles;
+    const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
+
+    f32x4 acc[3][NCT][NCI];       // [kx][co tile][ci tile]
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int i = 0; i < NCT; ++i)
+#pragma unroll
+            for (int j = 0; j < NCI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[kx][i][j][r] = 0.f;
+
+    // loader assignment: dy 64 px x 12 float4 = 4 per thread; x 100 px x 12 float4 = 1200 -> 7 passes of 192
+    float4 rd[4], rx[7];
+    const int dq = t / 12, dc4 = t % 12;          // dy: pixel dq + 16*j, float4 column dc4
+    const int coa = co0 + dc4 * 4;
+    const int tail_a = a.Cout - coa;
+    const int coa_e = tail_a > 0 ? coa : 0;
+    const int tail_b0 = a.C - ci0;                // valid channels from the tile start
+
+    auto tile_origin = [&](long tile, int& n, int& r0, int& c0) __attribute__((always_inline)) {
+        n = (int)(tile / a.tiles_per_img);
+        const int ti = (int)(tile - (long)n * a.tiles_per_img);
+        r0 = (ti / a.tiles_w) * 8;
+        c0 = (ti % a.tiles_w) * 8;
+    };
+    auto zero_tail = [&](float4 v, int tl) __attribute__((always_inline)) {
+        v.x = tl < 1 ? 0.f : v.x;
+        v.y = tl < 2 ? 0.f : v.y;
+        v.z = tl < 3 ? 0.f : v.z;
+        v.w = tl < 4 ? 0.f : v.w;
+        return v;
+    };
+    auto load_tile = [&](long tile) __attribute__((always_inline)) {
+        int n, r0, c0;
+        tile_origin(tile, n, r0, c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = dq + 16 * j;
+            const int h = r0 + (q >> 3), w = c0 + (q & 7);
+            const float4 v = *reinterpret_cast<const float4*>(a.dy + (((long)n * a.H + h) * a.W + w) * a.ld_dy + coa_e);
+            rd[j] = zero_tail(v, tail_a);
+        }
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int idx = t + 192 * j;
+            const int hp = idx / 12 < HP ? idx / 12 : HP - 1, c4 = idx % 12;
+            const int hr = hp / HW2, hc = hp - hr * HW2;
+            int h = r0 + hr - 1, w = c0 + hc - 1;
+            const bool ok = h >= 0 && h < a.H && w >= 0 && w < a.W;
+            h = h < 0 ? 0 : (h >= a.H ? a.H - 1 : h);
+            w = w < 0 ? 0 : (w >= a.W ? a.W - 1 : w);
+            const int tl = ok ? tail_b0 - c4 * 4 : 0;
+            const int ce = tl > 0 ? ci0 + c4 * 4 : 0;
+            const float4 v = *reinterpret_cast<const float4*>(
+                a.x + (((long)n * Hs + (h >> a.ups)) * Ws + (w >> a.ups)) * a.ld_x + ce);
+            rx[j] = zero_tail(v, tl);
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[dq + 16 * j][dc4 * 4]) = rd[j];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int idx = t + 192 * j;
+            if (idx < HP * 12) *reinterpret_cast<float4*>(&Xs[idx / 12][(idx % 12) * 4]) = rx[j];
+        }
+    };
+
+    const int fi = lane & 15, fk = lane >> 4;     // row/col inside a 16-tile, pixel 0..3 of the K group
+    if (tile_begin < tile_end) load_tile(tile_begin);
+    for (long tile = tile_begin; tile < tile_end; ++tile) {
+        __syncthreads();                          // the previous tile's LDS reads are done
+        store_tile();
+        __syncthreads();
+        if (tile + 1 < tile_end) load_tile(tile + 1);     // in flight during the MFMAs below
+#pragma unroll 2
+        for (int g = 0; g < 16; ++g) {            // K group = pixels 4g..4g+3 = row g>>1, columns 4*(g&1)..+3
+            const int q = 4 * g + fk;
+            const int xr = ((g >> 1) + ky) * HW2 + (g & 1) * 4 + fk;     // staged pixel of tap (ky, kx = 0)
+            float fa[NCT], fb[3][NCI];
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) fa[i] = As[q][16 * i + fi];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < NCI; ++j) fb[kx][j] = Xs[xr + kx][16 * j + fi];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int i = 0; i < NCT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NCI; ++j)
+                        acc[kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[kx][j], acc[kx][i][j], 0, 0, 0);
+        }
+    }
+    // D: col = lane & 15 (-> ci), row = 4 * (lane >> 4) + r (-> co); parameter layout n = ci * 9 + tap
+    const bool partial = a.splits > 1;
+    float* outp = partial ? a.out + (long)split * a.Cout * a.NT : a.out;
+    const long ldo = partial ? (long)a.NT : a.ld_out;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int i = 0; i < NCT; ++i)
+#pragma unroll
+            for (int j = 0; j < NCI; ++j) {
+                const int ci = ci0 + 16 * j + fi;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + 16 * i + 4 * fk + r;
+                    if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + ky * 3 + kx] = acc[kx][i][j][r];
+                }
+            }
+}
+
 // ---- weight gradient, tap-major form (the default for C >= 16) ---------------------------------------------------
 // The same pipeline as the forward kernel with K = pixels: one block owns a BM (co) x BN (ci) tile of ONE tap and a
 // range of pixels.  Per 16-pixel K step both operands are plain coalesced float4 reads along channels -- dy rows
@@ -1241,6 +1388,34 @@ static WPlan make_wplan(long M, int Cout, int C, int ntaps = 9) {
     return p;
 }
 
+// narrow-layer (16x16 tiles, nine taps per block) wgrad plan
+struct NPlan {
+    bool use;
+    int gm, gn, tiles_w, tiles_per_img, splits;
+    long total_tiles, tiles_per_split;
+};
+static int g_wgrad_n16 = env_int("MNK_WGRAD_N16", 1), g_wn16_target = env_int("MNK_WN16_TARGET", 512),
+           g_wn16_mintiles = env_int("MNK_WN16_MINTILES", 2), g_wn16_minc = env_int("MNK_WN16_MINC", 1);
+
+static NPlan make_nplan(int N, int H, int W, int Cout, int C, int ld_x) {
+    NPlan p;
+    p.use = g_wgrad_n16 && C <= 64 && Cout <= 64 && C >= g_wn16_minc && H % 8 == 0 && W % 8 == 0 && ld_x % 4 == 0 &&
+            ld_x >= round_up(C, 4);
+    if (!p.use) return p;
+    p.gm = ceil_div(Cout, 48);
+    p.gn = ceil_div(C, 48);
+    p.tiles_w = W / 8;
+    p.tiles_per_img = (H / 8) * p.tiles_w;
+    p.total_tiles = (long)N * p.tiles_per_img;
+    const long base = (long)p.gm * p.gn;
+    long splits = (g_wn16_target + base - 1) / base;
+    if (splits > p.total_tiles / g_wn16_mintiles) splits = p.total_tiles / g_wn16_mintiles;
+    if (splits < 1) splits = 1;
+    p.tiles_per_split = (p.total_tiles + splits - 1) / splits;
+    p.splits = (int)((p.total_tiles + p.tiles_per_split - 1) / p.tiles_per_split);
+    return p;
+}
+
 // tap-major wgrad plan
 struct TPlan {
     bool use;
@@ -1468,8 +1643,19 @@ size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout,
         if (tp.use) return (size_t)(tp.splits + tp.groups) * ntaps * Cout * C;
     }
     if (kh == 3 && kw == 3 && pad == 1) {
+        NPlan np = make_nplan(N, Ho, Wo, Cout, C, round_up(C, 4));
         HPlan hp = make_hplan(N, Ho, Wo, Cout, C);
-        if (hp.use) return hp.splits > 1 ? (size_t)(hp.splits + split_groups(hp.splits)) * Cout * 9 * C : 0;
+        size_t need = 0;        // the caller's ld_x / alignment may still demote the n16 form: size for both
+        if (np.use && np.splits > 1) need = (size_t)(np.splits + split_groups(np.splits)) * Cout * 9 * C;
+        if (hp.use) {
+            const size_t nh = hp.splits > 1 ? (size_t)(hp.splits + split_groups(hp.splits)) * Cout * 9 * C : 0;
+            return nh > need ? nh : need;
+        }
+        if (np.use) {
+            WPlan p = make_wplan((long)N * Ho * Wo, Cout, C, ntaps);
+            const size_t ng = (p.splits > 1 && !g_wgrad_atomic) ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
+            return ng > need ? ng : need;
+        }
     }
     WPlan p = make_wplan((long)N * Ho * Wo, Cout, C, ntaps);
     return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
@@ -1543,6 +1729,60 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
         }
         MNK_LAUNCH_CHECK();
         return MNK_OK;
+    }
+    if (kh == 3 && kw == 3 && pad == 1) {
+        NPlan np = make_nplan(N, H, W, Cout, C, ld_x);
+        if (np.use && ((size_t)x % 16 != 0 || (size_t)dy % 16 != 0)) np.use = false;
+        if (np.use) {
+            WgradN16Args g;
+            g.x = x;
+            g.ld_x = ld_x;
+            g.C = C;
+            g.ups = ups;
+            g.dy = dy;
+            g.ld_dy = ld_dy;
+            g.Cout = Cout;
+            g.H = H;
+            g.W = W;
+            g.tiles_w = np.tiles_w;
+            g.tiles_per_img = np.tiles_per_img;
+            g.total_tiles = np.total_tiles;
+            g.tiles_per_split = np.tiles_per_split;
+            g.NT = 9 * C;
+            g.splits = np.splits;
+            float* dstn = dw + (long)c_start * 9;
+            const long ldn = (long)Cin_total * 9;
+            if (np.splits > 1) {
+                const size_t need = (size_t)(np.splits + split_groups(np.splits)) * Cout * g.NT;
+                if (!ws || ws_floats < need) {
+                    set_error("mnk_conv2d_wgrad: workspace too small (%zu < %zu floats)", ws_floats, need);
+                    return MNK_EWORKSPACE;
+                }
+                g.out = ws;
+                g.ld_out = g.NT;
+            } else {
+                g.out = dstn;
+                g.ld_out = ldn;
+            }
+            hipStream_t sn = (hipStream_t)stream;
+            {
+                ProfScope prof(K_CONV_WGRAD, sn, 2.0 * (double)N * H * W * Cout * 9.0 * C);
+                const int nct = Cout > 32 ? 3 : (Cout > 16 ? 2 : 1), nci = C > 32 ? 3 : (C > 16 ? 2 : 1);
+                const dim3 gridn(np.gm, np.gn, np.splits);
+#define MNK_N16(T, I)                                                                                      \
+    if (nct == T && nci == I) hipLaunchKernelGGL((conv3x3_wgrad_n16_kernel<T, I>), gridn, dim3(192), 0, sn, g)
+                MNK_N16(3, 3); MNK_N16(3, 2); MNK_N16(3, 1);
+                MNK_N16(2, 3); MNK_N16(2, 2); MNK_N16(2, 1);
+                MNK_N16(1, 3); MNK_N16(1, 2); MNK_N16(1, 1);
+#undef MNK_N16
+            }
+            if (np.splits > 1) {
+                ProfScope prof(K_CONV_REDUCE, sn, (double)np.splits * Cout * g.NT * 4);
+                launch_wgrad_reduce(ws, np.splits, Cout, g.NT, dstn, ldn, sn);
+            }
+            MNK_LAUNCH_CHECK();
+            return MNK_OK;
+        }
     }
     HPlan hp;
     hp.use = false;

@@ -105,7 +105,14 @@ HALO_CASES = [
     (1, 8, 8, 80, 0, 24, 1, False, False),       # tap-major form, 32 x 128 tile, up-sampled source
     (2, 32, 32, 72, 0, 40, 0, False, False),     # tap-major form, 16 pixel splits -> two-stage split reduction
     (6, 64, 64, 5, 0, 20, 0, False, False),      # gather kernel, 192 pixel splits -> two-stage split reduction
-    (2, 64, 64, 40, 0, 60, 0, False, False),     # halo kernel, 16 tile splits -> two-stage split reduction
+    (2, 64, 64, 40, 0, 60, 0, False, False),     # narrow-layer (n16) kernel, many tile splits -> two-stage reduction
+    (1, 8, 8, 35, 0, 10, 0, False, False),       # n16 kernel tile-count variants <co tiles, ci tiles>: <1,3>
+    (1, 8, 8, 12, 0, 12, 0, False, False),       # <1,1>
+    (1, 8, 16, 20, 0, 14, 1, False, False),      # <1,2>, up-sampled source
+    (2, 8, 8, 30, 0, 30, 0, False, False),       # <2,2>
+    (1, 16, 8, 40, 0, 20, 0, False, False),      # <2,3>
+    (1, 8, 8, 10, 0, 40, 0, False, False),       # <3,1>
+    (1, 8, 8, 50, 0, 56, 0, False, False),       # <3,3> with two tiles along co and ci (48-wide tiles)
 ]
 
 
