@@ -81,6 +81,14 @@ int mnk_bn_stats_finish(const float* partial, int row_blocks, int ld, int C, flo
 int mnk_bn_finalize(const float* sums, double count, const float* gamma, float* running_mean, float* running_var,
                     float momentum, float eps, int C, int update_running, float* mean, float* invstd, float* scale,
                     void* stream);
+/* Single-process form of (mnk_bn_stats | mnk_bn_stats_finish) + mnk_bn_finalize with the second stage and the
+ * finalisation in ONE launch: statistics either from `pre_partial` (pre_row_blocks conv-epilogue partials) or from a
+ * pass over x (workspace as for mnk_bn_stats).  `sums` (optional, 2C) receives what mnk_bn_stats would have written.
+ * Not for SyncBN over several ranks (the all-reduce sits between the two stages there). */
+int mnk_bn_stats_finalize(const float* x, int ld, long rows, int C, const float* pre_partial, int pre_row_blocks,
+                          double count, const float* gamma, float* running_mean, float* running_var, float momentum,
+                          float eps, int update_running, float* sums, float* mean, float* invstd, float* scale, float* ws,
+                          size_t ws_floats, void* stream);
 int mnk_bn_eval_coeffs(const float* gamma, const float* running_mean, const float* running_var, float eps, int C,
                        float* mean, float* invstd, float* scale, void* stream);
 /* z = [avgpool2x2] [relu] ((y-mean)*scale + beta)   (modules/util.py:56-57,62,81,87,100-101,106-107) */
@@ -97,6 +105,13 @@ int mnk_bn_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz, i
                          const float* invstd, const float* scale, const float* beta, const float* sums, double count,
                          int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu, int pool,
                          void* stream);
+/* the same pass, additionally dy_sums[0..C) = column sums of the written dy: the bias gradient of the convolution
+ * in front of the norm layer (util.py:54-56,80-81,99-100), which otherwise costs that convolution's backward a pass
+ * over dy.  Workspace: mnk_bn_workspace_floats(N*H*W, round_up(C,4)). */
+int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                                const float* invstd, const float* scale, const float* beta, const float* sums,
+                                double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu,
+                                int pool, float* dy_sums, float* ws, size_t ws_floats, void* stream);
 
 /* ---- general normalisation forms: `frames` / per_frame = statistics per frame (nn.InstanceNorm3d of the discriminator,
  * modules/discriminator.py:19-22,29-30: sums [2][frames*C], mean/invstd/scale [frames*C], beta [C]); `slope` selects

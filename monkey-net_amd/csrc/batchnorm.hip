@@ -14,7 +14,7 @@ struct Map2D {
     long rows_per_block;
 };
 
-static Map2D make_map(long rows, int ld) {
+static Map2D make_map(long rows, int ld, int rows_per_thread = 8, int want_blocks = 1024) {
     Map2D m;
     int nv = ld / 4;
     int tx = 1;
@@ -22,9 +22,9 @@ static Map2D make_map(long rows, int ld) {
     m.tx = tx;
     m.ty = 256 / tx;
     m.col_tiles = (nv + tx - 1) / tx;
-    long want = 1024 / m.col_tiles;   // ~4 blocks per CU in total
+    long want = want_blocks / m.col_tiles;   // default ~4 blocks per CU in total
     if (want < 1) want = 1;
-    long min_rows = (long)m.ty * 8;  // at least 8 rows per thread before splitting further
+    long min_rows = (long)m.ty * rows_per_thread;  // at least this many rows per thread before splitting further
     long rb = (rows + min_rows - 1) / min_rows;
     if (rb > want) rb = want;
     if (rb < 1) rb = 1;
@@ -63,9 +63,12 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
     if (r1 > fbase + rows) r1 = fbase + rows;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (q < nv) {
+        typename F::State st;         // per-thread channel constants (the column quad q is fixed per thread)
+        f.init(st);
+#pragma unroll 2
         for (long r = r0 + ty; r < r1; r += ty_n) {
             float4 va, vb;
-            f(r, q, va, vb);
+            f(r, q, st, va, vb);
             a = f4_add(a, va);
             b = f4_add(b, vb);
         }
@@ -90,14 +93,14 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
 // one wavefront per output column: lanes stride over the row-block partials (fp64 accumulation), the 64 lane sums are
 // combined through LDS.  (A serial loop per column was 44 % of the step time in the first MI355X profile.)
 __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restrict__ partial, int row_blocks, int ld,
-                                                            int C, int frames, float* __restrict__ sums) {
-    // sums[which][frame][c] = sum_rb partial[frame][rb][which][c]
+                                                            int C, int frames, float* __restrict__ sums, int nwhich) {
+    // sums[which][frame][c] = sum_rb partial[frame][rb][which][c], which < nwhich (1: first sum only)
     __shared__ double sm[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
     const int FC = frames * C;
     double acc = 0.0;
-    if (i < 2 * FC) {
+    if (i < nwhich * FC) {
         const int which = i / FC, rem = i - which * FC;
         const int f = rem / C, c = rem - f * C;
         const float* pb = partial + (long)f * row_blocks * 2 * ld;
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restr
         sm[wave * 64 + lane * 8] = t;
     }
     __syncthreads();
-    if (lane == 0 && i < 2 * FC) {
+    if (lane == 0 && i < nwhich * FC) {
         double t = 0.0;
         for (int j = 0; j < 8; ++j) t += sm[wave * 64 + j * 8];
         sums[i] = (float)t;
@@ -121,7 +124,9 @@ __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restr
 struct StatsLoader {
     const float* x;
     int ld;
-    __device__ __forceinline__ void operator()(long r, int q, float4& a, float4& b) const {
+    struct State {};
+    __device__ __forceinline__ void init(State&) const {}
+    __device__ __forceinline__ void operator()(long r, int q, State&, float4& a, float4& b) const {
         a = *reinterpret_cast<const float4*>(x + r * ld + q * 4);
         b = make_float4(a.x * a.x, a.y * a.y, a.z * a.z, a.w * a.w);
     }
@@ -133,41 +138,57 @@ struct BwdLoader {
     const float *y, *dz, *mean, *invstd, *scale, *beta;
     int ld_y, ld_dz, dz_off, H, W, C, pool, pstride;
     float slope;
-    __device__ __forceinline__ long poff(long r) const { return pstride ? (r / ((long)H * W)) * pstride : 0; }
-    __device__ __forceinline__ void load(long r, int q, float4& g, float4& xhat) const {
-        const float4 v = *reinterpret_cast<const float4*>(y + r * ld_y + q * 4);
+    // per-thread channel constants: loaded once for BatchNorm, once per frame for per-frame statistics
+    struct State {
+        long cur;
+        float4 m, is, sc, be;
+    };
+    __device__ __forceinline__ void init(State& st) const { st.cur = -1; }
+    __device__ __forceinline__ long poff(long r) const {
+        return pstride ? (long)((unsigned)r / (unsigned)(H * W)) * pstride : 0;     // rows < 2^31 (host check)
+    }
+    __device__ __forceinline__ void load(long r, int q, State& st, float4& g, float4& xhat) const {
         const long po = poff(r);
-        const float4 m = ld4_guard(mean + po, q, C);
-        const float4 is = ld4_guard(invstd + po, q, C);
+        if (po != st.cur) {
+            st.cur = po;
+            st.m = ld4_guard(mean + po, q, C);
+            st.is = ld4_guard(invstd + po, q, C);
+            st.sc = ld4_guard(scale + po, q, C);
+            st.be = ld4_guard(beta, q, C);
+        }
+        const float4 v = *reinterpret_cast<const float4*>(y + r * ld_y + q * 4);
         long rz = r;
         float k = 1.f;
         if (pool) {
-            int w = (int)(r % W);
-            long t = r / W;
-            int h = (int)(t % H);
-            long n = t / H;
-            rz = (n * (H / 2) + (h >> 1)) * (W / 2) + (w >> 1);
+            const unsigned ur = (unsigned)r, t = ur / (unsigned)W;
+            const int w = (int)(ur - t * (unsigned)W);
+            const unsigned n = t / (unsigned)H;
+            const int h = (int)(t - n * (unsigned)H);
+            rz = ((long)n * (H / 2) + (h >> 1)) * (W / 2) + (w >> 1);
             k = ((h >> 1) < H / 2 && (w >> 1) < W / 2) ? 0.25f : 0.f;   // odd H / W: the last row / column is not pooled
             if (k == 0.f) rz = 0;
         }
         const float* dp = dz + rz * ld_dz + dz_off + q * 4;
         const int rem = C - q * 4;
-        g = make_float4(rem > 0 ? dp[0] * k : 0.f, rem > 1 ? dp[1] * k : 0.f, rem > 2 ? dp[2] * k : 0.f,
-                        rem > 3 ? dp[3] * k : 0.f);
-        const float4 d = make_float4(v.x - m.x, v.y - m.y, v.z - m.z, v.w - m.w);
-        if (slope >= 0.f) {
-            const float4 sc = ld4_guard(scale + po, q, C);
-            const float4 be = ld4_guard(beta, q, C);
-            if (!(fmaf(d.x, sc.x, be.x) > 0.f)) g.x *= slope;
-            if (!(fmaf(d.y, sc.y, be.y) > 0.f)) g.y *= slope;
-            if (!(fmaf(d.z, sc.z, be.z) > 0.f)) g.z *= slope;
-            if (!(fmaf(d.w, sc.w, be.w) > 0.f)) g.w *= slope;
+        if (rem >= 4 && ((ld_dz | dz_off) & 3) == 0) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dp);
+            g = make_float4(d4.x * k, d4.y * k, d4.z * k, d4.w * k);
+        } else {
+            g = make_float4(rem > 0 ? dp[0] * k : 0.f, rem > 1 ? dp[1] * k : 0.f, rem > 2 ? dp[2] * k : 0.f,
+                            rem > 3 ? dp[3] * k : 0.f);
         }
-        xhat = make_float4(d.x * is.x, d.y * is.y, d.z * is.z, d.w * is.w);
+        const float4 d = make_float4(v.x - st.m.x, v.y - st.m.y, v.z - st.m.z, v.w - st.m.w);
+        if (slope >= 0.f) {
+            if (!(fmaf(d.x, st.sc.x, st.be.x) > 0.f)) g.x *= slope;
+            if (!(fmaf(d.y, st.sc.y, st.be.y) > 0.f)) g.y *= slope;
+            if (!(fmaf(d.z, st.sc.z, st.be.z) > 0.f)) g.z *= slope;
+            if (!(fmaf(d.w, st.sc.w, st.be.w) > 0.f)) g.w *= slope;
+        }
+        xhat = make_float4(d.x * st.is.x, d.y * st.is.y, d.z * st.is.z, d.w * st.is.w);
     }
-    __device__ __forceinline__ void operator()(long r, int q, float4& a, float4& b) const {
+    __device__ __forceinline__ void operator()(long r, int q, State& st, float4& a, float4& b) const {
         float4 g, xh;
-        load(r, q, g, xh);
+        load(r, q, st, g, xh);
         a = g;
         b = make_float4(g.x * xh.x, g.y * xh.y, g.z * xh.z, g.w * xh.w);
     }
@@ -196,6 +217,64 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     }
 }
 
+// colsum2_final + bn_finalize in one launch (single-process BatchNorm: nothing sits between the two): one wavefront
+// per channel sums both statistics over the row-block partials in fp64 and lane 0 derives mean / invstd / scale and
+// the running-statistics update.
+__global__ void __launch_bounds__(256) bn_final_finalize_kernel(const float* __restrict__ partial, int row_blocks, int ld,
+                                                                int C, double count, const float* __restrict__ gamma,
+                                                                float* running_mean, float* running_var, float momentum,
+                                                                float eps, int update_running, float* sums, float* mean,
+                                                                float* invstd, float* scale) {
+    __shared__ double sm[2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C)
+        for (int rb = lane; rb < row_blocks; rb += 64) {
+            a1 += (double)partial[((long)rb * 2 + 0) * ld + c];
+            a2 += (double)partial[((long)rb * 2 + 1) * ld + c];
+        }
+    sm[0][threadIdx.x] = a1;
+    sm[1][threadIdx.x] = a2;
+    __syncthreads();
+    if (lane < 8) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int j = 0; j < 8; ++j) {
+            t1 += sm[0][wave * 64 + lane * 8 + j];
+            t2 += sm[1][wave * 64 + lane * 8 + j];
+        }
+        sm[0][wave * 64 + lane * 8] = t1;
+        sm[1][wave * 64 + lane * 8] = t2;
+    }
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int j = 0; j < 8; ++j) {
+            t1 += sm[0][wave * 64 + j * 8];
+            t2 += sm[1][wave * 64 + j * 8];
+        }
+        // the same arithmetic as colsum2_final_kernel -> bn_finalize_kernel (sums round-trip through fp32)
+        const float s1 = (float)t1, s2 = (float)t2;
+        if (sums) {
+            sums[c] = s1;
+            sums[C + c] = s2;
+        }
+        const double m = (double)s1 / count;
+        double v = (double)s2 / count - m * m;
+        if (v < 0.0) v = 0.0;
+        const float mf = (float)m, vf = (float)v;
+        const float is = 1.0f / sqrtf(vf + eps);
+        mean[c] = mf;
+        invstd[c] = is;
+        scale[c] = gamma[c] * is;
+        if (update_running) {
+            const float unbiased = (float)(v * count / (count - 1.0));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* __restrict__ gamma,
                                                              const float* __restrict__ rm,
                                                              const float* __restrict__ rv, float eps, int C,
@@ -212,39 +291,52 @@ __device__ __forceinline__ float act_apply(float v, float slope) {   // slope < 
     return (slope >= 0.f && !(v > 0.f)) ? v * slope : v;
 }
 
+// thread (tx = channel quad, ty = output pixel lane): the per-channel constants stay in registers
 template <int POOL>
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ y, int ld_y,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ beta, int pstride,
                                                          float* __restrict__ z, int ld_z, int z_off, int N, int H,
-                                                         int W, int C, float slope) {
+                                                         int W, int C, float slope, int tx_n, int ty_n,
+                                                         long rows_per_block) {
     const int nv = (C + 3) / 4;
+    const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+    const int q = blockIdx.x * tx_n + tx;
+    if (q >= nv) return;
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
-    const long total = (long)N * Ho * Wo * nv;
-    const long HWo = (long)Ho * Wo;
+    const long rows = (long)N * Ho * Wo;              // output pixels, < 2^31 (host check)
+    const unsigned HWo = (unsigned)(Ho * Wo);
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
     const bool vec_store = ((z_off & 3) == 0) && ((ld_z & 3) == 0);
     const bool owns_pads = z_off == 0 && ld_z == nv * 4;   // z is a plain act: its pad channels are written (as zero) here
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int q = (int)(i % nv);
-        long p = i / nv;
-        const long po = pstride ? (p / HWo) * pstride : 0;     // per-frame statistics (InstanceNorm)
-        const float4 m = ld4_guard(mean + po, q, C);
-        const float4 sc = ld4_guard(scale + po, q, C);
-        const float4 be = ld4_guard(beta, q, C);
+    const int rem = C - q * 4;
+    long cur = -1;
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sc = m;
+    const float4 be = ld4_guard(beta, q, C);
+#pragma unroll 2
+    for (long p = r0 + ty; p < r1; p += ty_n) {
+        const long po = pstride ? (long)((unsigned)p / HWo) * pstride : 0;     // per-frame statistics (InstanceNorm)
+        if (po != cur) {
+            cur = po;
+            m = ld4_guard(mean + po, q, C);
+            sc = ld4_guard(scale + po, q, C);
+        }
         float4 o;
         if (POOL) {
-            int wo = (int)(p % Wo);
-            long t = p / Wo;
-            int ho = (int)(t % Ho);
-            long n = t / Ho;
+            const unsigned up = (unsigned)p, t = up / (unsigned)Wo;
+            const int wo = (int)(up - t * (unsigned)Wo);
+            const unsigned n = t / (unsigned)Ho;
+            const int ho = (int)(t - n * (unsigned)Ho);
             o = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* yb = y + (((long)n * H + 2 * ho) * W + 2 * wo) * ld_y + q * 4;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    const float4 v = *reinterpret_cast<const float4*>(
-                        y + ((n * H + 2 * ho + dy) * W + 2 * wo + dx) * ld_y + q * 4);
+                    const float4 v = *reinterpret_cast<const float4*>(yb + ((long)dy * W + dx) * ld_y);
                     o.x += act_apply(fmaf(v.x - m.x, sc.x, be.x), slope);
                     o.y += act_apply(fmaf(v.y - m.y, sc.y, be.y), slope);
                     o.z += act_apply(fmaf(v.z - m.z, sc.z, be.z), slope);
@@ -262,7 +354,6 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
             o.w = act_apply(fmaf(v.w - m.w, sc.w, be.w), slope);
         }
         float* zp = z + p * ld_z + z_off + q * 4;
-        const int rem = C - q * 4;
         if (vec_store && (rem >= 4 || owns_pads)) {   // guarded parameter loads make the pad lanes of `o` zero
             *reinterpret_cast<float4*>(zp) = o;
         } else {
@@ -278,16 +369,24 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, const float* __restrict__ sums,
                                                                double count, int training, int FC,
                                                                float* __restrict__ dy, int ld_dy, long rows, int C,
-                                                               int nv, int tx_n, int ty_n, long rows_per_block) {
+                                                               int nv, int tx_n, int ty_n, long rows_per_block,
+                                                               float* __restrict__ dy_partial) {
+    // dy_partial (optional): [gridDim.y][2][4 * nv] with the column sums of the written dy in slot 0 -- the bias
+    // gradient of the convolution in front of this norm layer (Conv3x3Fn.backward), saving its pass over dy
+    __shared__ float4 red[256];
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx;
-    if (q >= nv) return;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < nv) {
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     const float inv = training ? (float)(1.0 / count) : 0.f;
     long cur = -1;
     float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), k1 = sc, k2 = sc;
+    BwdLoader::State st;
+    L.init(st);
+#pragma unroll 2
     for (long r = r0 + ty; r < r1; r += ty_n) {
         const long po = L.poff(r);
         if (po != cur) {            // (re)load the per-channel constants: once for BatchNorm, once per frame otherwise
@@ -301,7 +400,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
             }
         }
         float4 g, xh;
-        L.load(r, q, g, xh);
+        L.load(r, q, st, g, xh);
         float4 o;
         o.x = sc.x * (g.x - k1.x - xh.x * k2.x);
         o.y = sc.y * (g.y - k1.y - xh.y * k2.y);
@@ -314,6 +413,18 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
             o.w = 0.f;
         }
         *reinterpret_cast<float4*>(dy + r * ld_dy + q * 4) = o;
+        csum = f4_add(csum, o);
+    }
+    }
+    if (dy_partial) {
+        red[threadIdx.x] = csum;
+        __syncthreads();
+        for (int s = ty_n >> 1; s > 0; s >>= 1) {
+            if (ty < s) red[threadIdx.x] = f4_add(red[threadIdx.x], red[threadIdx.x + s * tx_n]);
+            __syncthreads();
+        }
+        if (ty == 0 && q < nv)
+            *reinterpret_cast<float4*>(dy_partial + (long)blockIdx.y * 2 * (4 * nv) + q * 4) = red[tx];
     }
 }
 
@@ -348,7 +459,7 @@ int mnk_norm_stats(const float* x, int ld, long rows_per_frame, int frames, int 
     hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L,
                        rows_per_frame, ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ld, C,
-                       frames, sums);
+                       frames, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -371,15 +482,18 @@ int mnk_norm_act_fwd(const float* y, int ld_y, const float* mean, const float* s
     MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && z_off >= 0 && z_off + C <= ld_z);
     MNK_REQUIRE(!pool || (H >= 2 && W >= 2));
     hipStream_t s = (hipStream_t)stream;
-    long total = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * ((C + 3) / 4);
+    const long rows = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    MNK_REQUIRE((long)N * H * W < (1L << 31));
     ProfScope prof(K_BN_APPLY, s, (double)N * H * W * C * 4 * (pool ? 1.25 : 2.0));
     const int pstride = per_frame ? C : 0;
+    Map2D m = make_map(rows, round_up(C, 4), 2, 2048);     // no reduction here: small layers want blocks, not rows per thread
+    const dim3 grid(m.col_tiles, m.row_blocks);
     if (pool)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(grid_for(total, 4096)), dim3(256), 0, s, y, ld_y, mean, scale, beta,
-                           pstride, z, ld_z, z_off, N, H, W, C, slope);
+        hipLaunchKernelGGL(bn_act_fwd_kernel<1>, grid, dim3(256), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
+                           N, H, W, C, slope, m.tx, m.ty, m.rows_per_block);
     else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(grid_for(total, 4096)), dim3(256), 0, s, y, ld_y, mean, scale, beta,
-                           pstride, z, ld_z, z_off, N, H, W, C, slope);
+        hipLaunchKernelGGL(bn_act_fwd_kernel<0>, grid, dim3(256), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
+                           N, H, W, C, slope, m.tx, m.ty, m.rows_per_block);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -390,7 +504,7 @@ int mnk_norm_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz,
                            void* stream) {
     MNK_REQUIRE(y && dz && mean && invstd && scale && beta && sums && ws && N > 0 && H > 0 && W > 0 && C > 0);
     MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && dz_off >= 0 && dz_off + C <= ld_dz);
-    MNK_REQUIRE(!pool || (H >= 2 && W >= 2));
+    MNK_REQUIRE((!pool || (H >= 2 && W >= 2)) && (long)N * H * W < (1L << 31));
     const int frames = per_frame ? N : 1;
     const long rows = per_frame ? (long)H * W : (long)N * H * W;
     const int ldc = round_up(C, 4);
@@ -405,7 +519,7 @@ int mnk_norm_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz,
     hipLaunchKernelGGL(colsum2_partial_kernel<BwdLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L, rows,
                        ldc / 4, ldc, m.tx, m.ty, m.rows_per_block, ws);
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C,
-                       frames, sums);
+                       frames, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -418,6 +532,7 @@ int mnk_norm_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz,
     MNK_REQUIRE(!training || (sums && count > 0));
     MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && ld_dy % 4 == 0 && ld_dy >= round_up(C, 4));
     MNK_REQUIRE(dz_off >= 0 && dz_off + C <= ld_dz && (!pool || (H >= 2 && W >= 2)));
+    MNK_REQUIRE((long)N * H * W < (1L << 31));
     const long rows = (long)N * H * W;
     const int ldc = round_up(C, 4);
     Map2D m = make_map(rows, ldc);
@@ -425,7 +540,62 @@ int mnk_norm_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz,
     ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, per_frame ? C : 0, slope};
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
-                       (per_frame ? N : 1) * C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block);
+                       (per_frame ? N : 1) * C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, (float*)nullptr);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                                const float* invstd, const float* scale, const float* beta, const float* sums,
+                                double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu,
+                                int pool, float* dy_sums, float* ws, size_t ws_floats, void* stream) {
+    MNK_REQUIRE(y && dz && mean && invstd && scale && beta && dy && dy_sums && ws && N > 0 && H > 0 && W > 0 && C > 0);
+    MNK_REQUIRE(!training || (sums && count > 0));
+    MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && ld_dy % 4 == 0 && ld_dy >= round_up(C, 4));
+    MNK_REQUIRE(dz_off >= 0 && dz_off + C <= ld_dz && (!pool || (H >= 2 && W >= 2)));
+    MNK_REQUIRE((long)N * H * W < (1L << 31));
+    const long rows = (long)N * H * W;
+    const int ldc = round_up(C, 4);
+    Map2D m = make_map(rows, ldc);
+    if (ws_floats < (size_t)m.row_blocks * 2 * ldc) {
+        set_error("mnk_bn_act_bwd_apply_colsum: workspace too small");
+        return MNK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
+    BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, 0, relu ? 0.f : -1.f};
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
+                       C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, ws);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, 1, dy_sums, 1);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_bn_stats_finalize(const float* x, int ld, long rows, int C, const float* pre_partial, int pre_row_blocks,
+                          double count, const float* gamma, float* running_mean, float* running_var, float momentum,
+                          float eps, int update_running, float* sums, float* mean, float* invstd, float* scale, float* ws,
+                          size_t ws_floats, void* stream) {
+    MNK_REQUIRE(gamma && mean && invstd && scale && C > 0 && count > 0 && ld % 4 == 0 && ld >= C);
+    MNK_REQUIRE(!update_running || (running_mean && running_var && count > 1));
+    MNK_REQUIRE(pre_partial ? pre_row_blocks > 0 : (x && rows > 0 && ws));
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_STATS, s, pre_partial ? (double)pre_row_blocks * 2 * C * 4 : (double)rows * C * 4);
+    const float* partial = pre_partial;
+    int row_blocks = pre_row_blocks;
+    if (!pre_partial) {
+        Map2D m = make_map(rows, ld);
+        if (ws_floats < (size_t)m.row_blocks * 2 * ld) {
+            set_error("mnk_bn_stats_finalize: workspace too small");
+            return MNK_EWORKSPACE;
+        }
+        StatsLoader L{x, ld};
+        hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, 1), dim3(256), 0, s, L, rows,
+                           ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
+        partial = ws;
+        row_blocks = m.row_blocks;
+    }
+    hipLaunchKernelGGL(bn_final_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, count, gamma,
+                       running_mean, running_var, momentum, eps, update_running, sums, mean, invstd, scale);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -441,7 +611,7 @@ int mnk_bn_stats_finish(const float* partial, int row_blocks, int ld, int C, flo
     MNK_REQUIRE(partial && sums && row_blocks > 0 && C > 0 && ld >= C);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_STATS, s, (double)row_blocks * 2 * C * 4);
-    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, 1, sums);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, 1, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

@@ -175,17 +175,21 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
     nws = _query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
     ws = SCRATCH.get("ws", nws, x0) if nws else None
     nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats else 0
-    st = SCRATCH.get("stats", nst, x0) if nst else None
+    st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None   # lives until the norm layer reads it
     _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
           int(ups), _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
           y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
     sums = None
     if want_stats:
-        if nst:
+        if nst and not mdist.active():
+            sums = st                          # per-block partials: finished together with the finalisation (bn_act)
+        elif nst:
             sums = torch.empty(2 * cout, dtype=torch.float32, device=x0.device)
             _call("mnk_bn_stats_finish", x0, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, _p(sums))
-        else:
+        elif mdist.active():
             sums = channel_sums(y, cout)       # split-K layers: statistics by a pass over y
+        else:
+            sums = y.new_empty(0)              # split-K layers, single process: bn_act makes its own pass over y
     return y, sums
 
 
@@ -198,6 +202,10 @@ def channel_sums(a, c):
     sums = torch.empty(2 * c, dtype=torch.float32, device=a.device)
     _call("mnk_bn_stats", a, _p(a), ld, rows, c, _p(sums), _p(ws), nws)
     return sums
+
+
+# (dy tensor, its column sums) handed from BNActFn.backward to the Conv3x3Fn.backward that receives this very tensor
+_DY_SUMS = [None]
 
 
 class Conv3x3Fn(torch.autograd.Function):
@@ -236,6 +244,7 @@ class Conv3x3Fn(torch.autograd.Function):
     def backward(ctx, dy, _dsums):
         x0, x1, weight = ctx.saved_tensors
         c0, c1, ups, cout, n, h, w, has_bias, has_res = ctx.meta
+        dy_in = dy
         dy = dy.contiguous()
         ld_dy = dy.shape[-1]
         cin = c0 + c1
@@ -260,7 +269,13 @@ class Conv3x3Fn(torch.autograd.Function):
                 ws = SCRATCH.get("ws", nws, dy) if nws else None
                 _call("mnk_conv3x3_wgrad", dy, _p(src), src.shape[-1], cc, int(ups), _p(dy), ld_dy, cout, _p(dw), cin, cs,
                       n, h, w, _p(ws), nws)
-        db = channel_sums(dy, cout)[:cout] if has_bias and ctx.needs_input_grad[3] else None
+        db = None
+        if has_bias and ctx.needs_input_grad[3]:
+            slot, _DY_SUMS[0] = _DY_SUMS[0], None
+            if slot is not None and slot[0] is dy_in and slot[1].numel() == cout:
+                db = slot[1]                   # column sums of dy came out of the norm layer's backward pass
+            else:
+                db = channel_sums(dy, cout)[:cout]
         dres = dy if has_res and ctx.needs_input_grad[4] else None
         return grads[0], grads[1], dw, db, dres, None, None, None, None, None
 
@@ -295,12 +310,25 @@ class BNActFn(torch.autograd.Function):
             if rows * mdist.world_size() <= 1:
                 raise ValueError("BatchNorm needs more than one value per channel in training mode "
                                  "(sync_batchnorm/batchnorm.py:116)")
-            sums = pre_sums if pre_sums is not None else channel_sums(y, c)
             if mdist.active():
-                sums = mdist.all_reduce_sum_(sums.clone() if pre_sums is not None else sums)
+                sums = pre_sums if pre_sums is not None and pre_sums.numel() == 2 * c else channel_sums(y, c)
+                sums = mdist.all_reduce_sum_(sums.clone() if sums is pre_sums else sums)
                 count *= mdist.world_size()
-            _call("mnk_bn_finalize", y, _p(sums), count, _p(gamma), _p(running_mean), _p(running_var), float(momentum),
-                  float(eps), c, 1, _p(mean), _p(invstd), _p(scale))
+                _call("mnk_bn_finalize", y, _p(sums), count, _p(gamma), _p(running_mean), _p(running_var),
+                      float(momentum), float(eps), c, 1, _p(mean), _p(invstd), _p(scale))
+            else:
+                # one launch for second stage + finalisation; partials from the conv epilogue when it produced them
+                part = pre_sums if pre_sums is not None and pre_sums.numel() > 2 * c else None
+                if pre_sums is not None and part is None and pre_sums.numel() == 2 * c:
+                    _call("mnk_bn_finalize", y, _p(pre_sums), count, _p(gamma), _p(running_mean), _p(running_var),
+                          float(momentum), float(eps), c, 1, _p(mean), _p(invstd), _p(scale))
+                else:
+                    nws = 0 if part is not None else _query("mnk_bn_workspace_floats", rows, ld)
+                    ws = SCRATCH.get("ws", nws, y) if nws else None
+                    _call("mnk_bn_stats_finalize", y, _p(y), ld, rows, c, _p(part),
+                          part.numel() // (2 * ld) if part is not None else 0, count, _p(gamma), _p(running_mean),
+                          _p(running_var), float(momentum), float(eps), 1, None, _p(mean), _p(invstd), _p(scale),
+                          _p(ws), nws)
         else:
             _call("mnk_bn_eval_coeffs", y, _p(gamma), _p(running_mean), _p(running_var), float(eps), c, _p(mean),
                   _p(invstd), _p(scale))
@@ -328,8 +356,11 @@ class BNActFn(torch.autograd.Function):
         if training and mdist.active():
             sums = mdist.all_reduce_sum_(sums.clone())
         dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
-        _call("mnk_bn_act_bwd_apply", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta),
-              _p(sums), count, int(training), _p(dy), ld, n, h, w, c, int(relu), int(pool))
+        dy_sums = torch.empty(c, dtype=torch.float32, device=y.device)
+        _call("mnk_bn_act_bwd_apply_colsum", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale),
+              _p(beta), _p(sums), count, int(training), _p(dy), ld, n, h, w, c, int(relu), int(pool), _p(dy_sums), _p(ws),
+              nws)
+        _DY_SUMS[0] = (dy, dy_sums)          # picked up by Conv3x3Fn.backward when it receives this very tensor
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

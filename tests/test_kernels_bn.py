@@ -56,6 +56,19 @@ def test_bn_train_forward_backward(be, shape, pool):
     assert relerr(bs.cpu()[c:], gd.grad) < 1e-4
     assert relerr(from_nhwc(DY.cpu(), c), xd.grad) < 1e-4
     assert torch.all(DY.cpu()[..., c:] == 0)
+    # fused forms: second stage + finalisation in one launch; dy pass that also returns the column sums of dy
+    m2, i2, s2, sums2 = be.empty(c), be.empty(c), be.empty(c), be.empty(2 * c)
+    RM2, RV2 = be.t(rm0.clone()), be.t(rv0.clone())
+    be.call("mnk_bn_stats_finalize", X, ld, rows, c, None, 0, float(rows), G, RM2, RV2, 0.1, 1e-5, 1, sums2, m2, i2, s2,
+            ws, nws)
+    DY2, dys = be.empty(n, h, w, ld), be.empty(c)
+    be.call("mnk_bn_act_bwd_apply_colsum", X, ld, DZ, ldz, 4, mean, invstd, scale, Bt, bs, float(rows), 1, DY2, ld, n, h,
+            w, c, 1, pool, dys, ws, nws)
+    be.sync()
+    for a, b in ((m2, mean), (i2, invstd), (s2, scale), (sums2, sums), (RM2, RM), (RV2, RV), (DY2, DY)):
+        assert torch.equal(a.cpu(), b.cpu())
+    ref_sum = DY.cpu().double().reshape(-1, ld).sum(0)[:c]
+    assert maxerr(dys.cpu(), ref_sum) <= 1e-5 * float(DY.cpu().abs().double().reshape(-1, ld).sum(0).max()) + 1e-6
 
 
 def test_bn_eval(be):
