@@ -886,9 +886,11 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_halo_kernel(WgradHaloArgs a
 // ---- weight gradient, narrow layers (C, Cout <= 64 at high resolution: the 45-channel refinement stack) ------------
 // 16x16x4 MFMA tiles on a 48 (co) x 48 (ci) channel tile (45 channels fill 94 % of it; a 64-wide tile only 49 %) with
 // ALL nine taps in one block: per 8x8-pixel tile the dy tile [64 px][48 co] and the x tile with a one-pixel halo
-// [10 x 10 px][48 ci] are staged in LDS once, and every tap is a shifted LDS read -- 27 MFMAs per 12 ds_read_b32.
-// A block is 3 wavefronts, wavefront w owns kernel row ky = w: 3 (kx) x 3 (co tiles) x 3 (ci tiles) accumulators of
-// 4 registers.  The next pixel tile is prefetched into registers while the MFMAs of the current one run.
+// [10 x 10 px][48 ci] are staged in LDS once, and every tap is a shifted LDS read.
+// Work split over the 4 wavefronts (81 = 9 taps x 3 co tiles x 3 ci tiles accumulators of 4 registers): wavefront w
+// owns taps 2w and 2w+1 completely (18 tiles, sharing the three dy fragments) plus co tile w of tap 8 (3 tiles;
+// wavefront 3 repeats one as a dummy) -- 21 MFMAs per 13 ds_read_b32 and K group, 96 % balanced.
+// The next pixel tile is prefetched into registers while the MFMAs of the current one run.
 // LDS rows are 48 floats (= 16 mod 32 banks): the four 16-lane groups of a fragment read hit disjoint banks.
 struct WgradN16Args {
     const float* x;
@@ -904,43 +906,42 @@ struct WgradN16Args {
     int splits;
 };
 
-
 template <int NCT, int NCI>     // 16-wide co / ci tiles in use (1..3): narrower layers skip the padded tiles at compile time
-__global__ void __launch_bounds__(192) conv3x3_wgrad_n16_kernel(WgradN16Args a) {
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args a) {
     constexpr int LD = 48, HW2 = 10, HP = 100;
+    constexpr int XP = (HP * 12 + 255) / 256;                       // x loader passes (5)
     __shared__ __attribute__((aligned(16))) float As[64][LD];       // dy tile [pixel][co]
     __shared__ __attribute__((aligned(16))) float Xs[HP][LD];       // x tile with halo [staged pixel][ci]
-    const int t = threadIdx.x, lane = t & 63, ky = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int co0 = blockIdx.x * 48, ci0 = blockIdx.y * 48, split = blockIdx.z;
     const long tile_begin = (long)split * a.tiles_per_split;
     long tile_end = tile_begin + a.tiles_per_split;
     if (tile_end > a.total_tiles) tile_end = a.total_tiles;
     const int Hs = a.ups ? a.H >> 1 : a.H, Ws = a.ups ? a.W >> 1 : a.W;
 
-    f32x4 acc[3][NCT][NCI];       // [kx][co tile][ci tile]
+    f32x4 acc[2][NCT][NCI];       // taps 2*wave + {0, 1}: [tap][co tile][ci tile]
+    f32x4 accx[NCI];              // tap 8, co tile xc: [ci tile]
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
         for (int i = 0; i < NCT; ++i)
 #pragma unroll
             for (int j = 0; j < NCI; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[kx][i][j][r] = 0.f;
+                for (int r = 0; r < 4; ++r) acc[tp][i][j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accx[j][r] = 0.f;
+    // staged-pixel offsets of this wavefront's taps (kernel row * 10 + kernel column) and its co tile of tap 8
+    const int tap0 = 2 * wave, tap1 = 2 * wave + 1;
+    const int toff0 = (tap0 / 3) * HW2 + tap0 % 3, toff1 = (tap1 / 3) * HW2 + tap1 % 3, toffx = 2 * HW2 + 2;
+    const int xc = wave < NCT ? wave : 0;
 
-    // loader assignment: dy 64 px x 12 float4 = 4 per thread; x 100 px x 12 float4 = 1200 -> 7 passes of 192
-    float4 rd[4], rx[7];
-    const int dq = t / 12, dc4 = t % 12;          // dy: pixel dq + 16*j, float4 column dc4
-    const int coa = co0 + dc4 * 4;
-    const int tail_a = a.Cout - coa;
-    const int coa_e = tail_a > 0 ? coa : 0;
+    // loader assignment: dy 64 px x 12 float4 = 3 per thread; x 100 px x 12 float4 = 1200 -> 5 passes of 256
+    float4 rd[3], rx[XP];
     const int tail_b0 = a.C - ci0;                // valid channels from the tile start
 
-    auto tile_origin = [&](long tile, int& n, int& r0, int& c0) __attribute__((always_inline)) {
-        n = (int)(tile / a.tiles_per_img);
-        const int ti = (int)(tile - (long)n * a.tiles_per_img);
-        r0 = (ti / a.tiles_w) * 8;
-        c0 = (ti % a.tiles_w) * 8;
-    };
     auto zero_tail = [&](float4 v, int tl) __attribute__((always_inline)) {
         v.x = tl < 1 ? 0.f : v.x;
         v.y = tl < 2 ? 0.f : v.y;
@@ -949,18 +950,22 @@ __global__ void __launch_bounds__(192) conv3x3_wgrad_n16_kernel(WgradN16Args a) 
         return v;
     };
     auto load_tile = [&](long tile) __attribute__((always_inline)) {
-        int n, r0, c0;
-        tile_origin(tile, n, r0, c0);
+        const int n = (int)(tile / a.tiles_per_img);
+        const int ti = (int)(tile - (long)n * a.tiles_per_img);
+        const int r0 = (ti / a.tiles_w) * 8, c0 = (ti % a.tiles_w) * 8;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = dq + 16 * j;
+        for (int j = 0; j < 3; ++j) {
+            const int idx = t + 256 * j;
+            const int q = idx / 12, c4 = idx % 12;       // 256 * 3 = 64 px * 12 float4 exactly
             const int h = r0 + (q >> 3), w = c0 + (q & 7);
-            const float4 v = *reinterpret_cast<const float4*>(a.dy + (((long)n * a.H + h) * a.W + w) * a.ld_dy + coa_e);
-            rd[j] = zero_tail(v, tail_a);
+            const int tl = a.Cout - (co0 + c4 * 4);
+            const int ce = tl > 0 ? co0 + c4 * 4 : 0;
+            const float4 v = *reinterpret_cast<const float4*>(a.dy + (((long)n * a.H + h) * a.W + w) * a.ld_dy + ce);
+            rd[j] = zero_tail(v, tl);
         }
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int idx = t + 192 * j;
+        for (int j = 0; j < XP; ++j) {
+            const int idx = t + 256 * j;
             const int hp = idx / 12 < HP ? idx / 12 : HP - 1, c4 = idx % 12;
             const int hr = hp / HW2, hc = hp - hr * HW2;
             int h = r0 + hr - 1, w = c0 + hc - 1;
@@ -976,10 +981,13 @@ __global__ void __launch_bounds__(192) conv3x3_wgrad_n16_kernel(WgradN16Args a) 
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(&As[dq + 16 * j][dc4 * 4]) = rd[j];
+        for (int j = 0; j < 3; ++j) {             // 256 * 3 = 768 = 64 px * 12 exactly; the float4 column is idx % 12
+            const int idx = t + 256 * j;
+            *reinterpret_cast<float4*>(&As[idx / 12][(idx % 12) * 4]) = rd[j];
+        }
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int idx = t + 192 * j;
+        for (int j = 0; j < XP; ++j) {
+            const int idx = t + 256 * j;
             if (idx < HP * 12) *reinterpret_cast<float4*>(&Xs[idx / 12][(idx % 12) * 4]) = rx[j];
         }
     };
@@ -994,40 +1002,60 @@ __global__ void __launch_bounds__(192) conv3x3_wgrad_n16_kernel(WgradN16Args a) 
 #pragma unroll 2
         for (int g = 0; g < 16; ++g) {            // K group = pixels 4g..4g+3 = row g>>1, columns 4*(g&1)..+3
             const int q = 4 * g + fk;
-            const int xr = ((g >> 1) + ky) * HW2 + (g & 1) * 4 + fk;     // staged pixel of tap (ky, kx = 0)
-            float fa[NCT], fb[3][NCI];
+            const int xr = (g >> 1) * HW2 + (g & 1) * 4 + fk;        // staged pixel of tap (0, 0)
+            float fa[NCT], fb0[NCI], fb1[NCI], fbx[NCI];
 #pragma unroll
             for (int i = 0; i < NCT; ++i) fa[i] = As[q][16 * i + fi];
+            const float fax = As[q][16 * xc + fi];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int j = 0; j < NCI; ++j) {
+                fb0[j] = Xs[xr + toff0][16 * j + fi];
+                fb1[j] = Xs[xr + toff1][16 * j + fi];
+                fbx[j] = Xs[xr + toffx][16 * j + fi];
+            }
 #pragma unroll
-                for (int j = 0; j < NCI; ++j) fb[kx][j] = Xs[xr + kx][16 * j + fi];
+            for (int i = 0; i < NCT; ++i)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+                for (int j = 0; j < NCI; ++j) {
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb0[j], acc[0][i][j], 0, 0, 0);
+                    acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb1[j], acc[1][i][j], 0, 0, 0);
+                }
 #pragma unroll
-                for (int i = 0; i < NCT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NCI; ++j)
-                        acc[kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[kx][j], acc[kx][i][j], 0, 0, 0);
+            for (int j = 0; j < NCI; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fax, fbx[j], accx[j], 0, 0, 0);
         }
     }
     // D: col = lane & 15 (-> ci), row = 4 * (lane >> 4) + r (-> co); parameter layout n = ci * 9 + tap
     const bool partial = a.splits > 1;
     float* outp = partial ? a.out + (long)split * a.Cout * a.NT : a.out;
     const long ldo = partial ? (long)a.NT : a.ld_out;
+    if (wave < 4) {
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+        for (int tp = 0; tp < 2; ++tp) {
+            const int tap = 2 * wave + tp;
+            if (tap < 8)
 #pragma unroll
-        for (int i = 0; i < NCT; ++i)
+                for (int i = 0; i < NCT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NCI; ++j) {
+                        const int ci = ci0 + 16 * j + fi;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int co = co0 + 16 * i + 4 * fk + r;
+                            if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + tap] = acc[tp][i][j][r];
+                        }
+                    }
+        }
+        if (wave < NCT)
 #pragma unroll
             for (int j = 0; j < NCI; ++j) {
                 const int ci = ci0 + 16 * j + fi;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + 16 * i + 4 * fk + r;
-                    if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + ky * 3 + kx] = acc[kx][i][j][r];
+                    const int co = co0 + 16 * xc + 4 * fk + r;
+                    if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + 8] = accx[j][r];
                 }
             }
+    }
 }
 
 // ---- weight gradient, tap-major form (the default for C >= 16) ---------------------------------------------------
@@ -1770,7 +1798,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
                 const int nct = Cout > 32 ? 3 : (Cout > 16 ? 2 : 1), nci = C > 32 ? 3 : (C > 16 ? 2 : 1);
                 const dim3 gridn(np.gm, np.gn, np.splits);
 #define MNK_N16(T, I)                                                                                      \
-    if (nct == T && nci == I) hipLaunchKernelGGL((conv3x3_wgrad_n16_kernel<T, I>), gridn, dim3(192), 0, sn, g)
+    if (nct == T && nci == I) hipLaunchKernelGGL((conv3x3_wgrad_n16_kernel<T, I>), gridn, dim3(256), 0, sn, g)
                 MNK_N16(3, 3); MNK_N16(3, 2); MNK_N16(3, 1);
                 MNK_N16(2, 3); MNK_N16(2, 2); MNK_N16(2, 1);
                 MNK_N16(1, 3); MNK_N16(1, 2); MNK_N16(1, 1);
