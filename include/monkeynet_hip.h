@@ -216,6 +216,10 @@ int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, fl
 int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, float temperature,
                        const float* mean, const float* stat, const float* dmean, const float* dvar, float* dheat,
                        int ld_d, void* stream);
+/* clip_variance (keypoint_detector.py:62-65): out = var * max(clip, sigma_min(var)) / sigma_min(var) over M 2x2
+ * matrices, sigma_min by the closed form of modules/util.py:244-255; backward through both factors. */
+int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, void* stream);
+int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* dout, float* dvar, void* stream);
 
 /* ---- key-point -> movement embedding (modules/movement_embedding.py:42-92, keypoint_detector.py:7-40) ----
  * one kernel renders, per slot (background first when add_bg): [heat-map (driving - source when

@@ -482,6 +482,53 @@ static int fill_embed_args(EmbedArgs& a, const float* img, int ld_img, int Cimg,
     return a.per;
 }
 
+// ---- clip_variance (keypoint_detector.py:62-65): var * max(clip, sigma_min(var)) / sigma_min(var), with the closed
+// form of the smallest singular value of a 2x2 matrix (modules/util.py:244-255), operation order of the reference.
+__device__ __forceinline__ void sigma_min_2x2(float a, float b, float c, float d, float& s2, float& sg) {
+    const float s1 = a * a + b * b + c * c + d * d;
+    const float t = a * a + b * b - c * c - d * d;
+    const float u = a * c + b * d;
+    s2 = sqrtf(t * t + 4.f * (u * u));
+    sg = sqrtf((s1 - s2) / 2.f);
+}
+
+__global__ void __launch_bounds__(256) kp_clip_var_fwd_kernel(const float* __restrict__ var, float clip, long M,
+                                                              float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float4 v = *reinterpret_cast<const float4*>(var + i * 4);
+    float s2, sg;
+    sigma_min_2x2(v.x, v.y, v.z, v.w, s2, sg);
+    const float mx = fmaxf(clip, sg);
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4((mx * v.x) / sg, (mx * v.y) / sg, (mx * v.z) / sg, (mx * v.w) / sg);
+}
+
+// dvar = dout * mx / sg + g_sg * d sigma_min / d var,  g_sg = sum_ij dout_ij v_ij ([sg > clip] / sg - mx / sg^2)
+__global__ void __launch_bounds__(256) kp_clip_var_bwd_kernel(const float* __restrict__ var, float clip, long M,
+                                                              const float* __restrict__ dout, float* __restrict__ dvar) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const float4 v = *reinterpret_cast<const float4*>(var + i * 4);
+    const float4 g = *reinterpret_cast<const float4*>(dout + i * 4);
+    const float a = v.x, b = v.y, c = v.z, d = v.w;
+    float s2, sg;
+    sigma_min_2x2(a, b, c, d, s2, sg);
+    const float mx = fmaxf(clip, sg);
+    const float dmx = sg > clip ? 1.f : (sg == clip ? 0.5f : 0.f);      // torch.max splits the gradient on ties
+    const float gv = g.x * a + g.y * b + g.z * c + g.w * d;
+    const float g_sg = gv * (dmx / sg - mx / (sg * sg));
+    // sigma = sqrt((s1 - s2) / 2):  d sigma = (d s1 - d s2) / (4 sigma),  d s2 = (t dt + 4 u du) / s2
+    const float t = a * a + b * b - c * c - d * d, u = a * c + b * d;
+    const float k = g_sg / (4.f * sg);
+    const float da = 2.f * a - (t * 2.f * a + 4.f * u * c) / s2;
+    const float db = 2.f * b - (t * 2.f * b + 4.f * u * d) / s2;
+    const float dc = 2.f * c - (-t * 2.f * c + 4.f * u * a) / s2;
+    const float dd = 2.f * d - (-t * 2.f * d + 4.f * u * b) / s2;
+    const float f = mx / sg;
+    *reinterpret_cast<float4*>(dvar + i * 4) =
+        make_float4(fmaf(g.x, f, k * da), fmaf(g.y, f, k * db), fmaf(g.z, f, k * dc), fmaf(g.w, f, k * dd));
+}
+
 }  // namespace
 
 extern "C" {
@@ -559,6 +606,24 @@ int mnk_movement_embedding_bwd(const float* img, int ld_img, int Cimg, const flo
     ProfScope prof(K_EMBED, s, (double)Nb * d * h * w * K * per * 4);
     hipLaunchKernelGGL(movement_embedding_bwd_kernel, dim3(Nb * d * K), dim3(256), 0, s, a, dout, ld_out, dmean_d, dvar_d,
                        dmean_s, dvar_s);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, void* stream) {
+    MNK_REQUIRE(var && out && M > 0 && clip > 0.f && ((size_t)var % 16) == 0 && ((size_t)out % 16) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_KEYPOINT, s, (double)M * 32);
+    hipLaunchKernelGGL(kp_clip_var_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, clip, M, out);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* dout, float* dvar, void* stream) {
+    MNK_REQUIRE(var && dout && dvar && M > 0 && clip > 0.f);
+    MNK_REQUIRE(((size_t)var % 16) == 0 && ((size_t)dout % 16) == 0 && ((size_t)dvar % 16) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_KEYPOINT, s, (double)M * 48);
+    hipLaunchKernelGGL(kp_clip_var_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, clip, M, dout, dvar);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

@@ -577,6 +577,29 @@ class SoftmaxKPFn(torch.autograd.Function):
         return dheat, None, None
 
 
+class ClipVarianceFn(torch.autograd.Function):
+    """var * max(clip, sigma_min(var)) / sigma_min(var) on (..., 2, 2) covariances (keypoint_detector.py:62-65,
+    modules/util.py:244-255) in one kernel instead of ~25 element-wise launches (+ ~60 in the backward)."""
+
+    @staticmethod
+    def forward(ctx, var, clip):
+        _check_device(var)
+        var = var.contiguous().float()
+        out = torch.empty_like(var)
+        _call("mnk_kp_clip_variance_fwd", var, _p(var), float(clip), var.numel() // 4, _p(out))
+        ctx.save_for_backward(var)
+        ctx.clip = float(clip)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        var, = ctx.saved_tensors
+        dout = dout.contiguous()
+        dvar = torch.empty_like(var)
+        _call("mnk_kp_clip_variance_bwd", var, _p(var), ctx.clip, var.numel() // 4, _p(dout), _p(dvar))
+        return dvar, None
+
+
 class MovementEmbeddingFn(torch.autograd.Function):
     """MovementEmbeddingModule.forward (movement_embedding.py:42-92) -> act with kp-major channel order."""
 

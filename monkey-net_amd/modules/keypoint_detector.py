@@ -45,10 +45,7 @@ def _finish_kp(mean, var, kp_variance, clip_variance):
     kp = {'mean': mean}
     if kp_variance == 'matrix':
         if clip_variance:
-            # var * max(clip, sigma_min) / sigma_min (keypoint_detector.py:62-65): a handful of tiny element-wise ops
-            min_norm = torch.full((), clip_variance, dtype=var.dtype, device=var.device)   # no H2D copy (graph-safe)
-            sg = smallest_singular(var).unsqueeze(-1)
-            var = torch.max(min_norm, sg) * var / sg
+            var = ops.ClipVarianceFn.apply(var, clip_variance)    # var * max(clip, sigma_min) / sigma_min (:62-65)
         kp['var'] = var
     elif kp_variance == 'single':
         kp['var'] = ((var[..., 0, 0] + var[..., 1, 1]) / 2).unsqueeze(-1).unsqueeze(-1)

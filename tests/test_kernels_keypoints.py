@@ -136,3 +136,32 @@ def test_embedding_matches_reference_golden(be):
         b, c, d, h, w = ref.shape
         assert c == cemb
         assert maxerr(out[..., :c], ref.permute(0, 2, 3, 4, 1).reshape(b * d, h, w, c)) < 3e-6, tag
+
+
+def test_clip_variance(be):
+    """mnk_kp_clip_variance_fwd/bwd == var * max(clip, sigma_min) / sigma_min with the reference's closed-form sigma_min
+    (keypoint_detector.py:62-65, modules/util.py:244-255), forward and gradient, clipped and unclipped matrices."""
+    g = torch.Generator().manual_seed(4)
+    m = 37
+    a = torch.randn(m, 2, 2, generator=g) * 0.1
+    var = a @ a.transpose(1, 2) + 0.002 * torch.eye(2)          # SPD, sigma_min around the clip value
+    clip = 0.004
+    vd = var.double().requires_grad_(True)
+    sg = restate.smallest_singular(vd).unsqueeze(-1)
+    ref = torch.max(torch.full((), clip, dtype=torch.float64), sg) * vd / sg
+    dout = torch.randn(m, 2, 2, generator=g, dtype=torch.float64)
+    ref.backward(dout)
+    clipped = (sg.detach().flatten() < clip)
+    assert 3 < int(clipped.sum()) < m - 3                        # both branches are exercised
+    # the closed form cancels (s1 - s2) in fp32: the yard-stick is the same formula evaluated by torch in fp32
+    v32 = var.clone().requires_grad_(True)
+    sg32 = restate.smallest_singular(v32).unsqueeze(-1)
+    ref32 = torch.max(torch.full((), clip), sg32) * v32 / sg32
+    ref32.backward(dout.float())
+    spread_f, spread_b = relerr(ref32.detach(), ref.detach()), relerr(v32.grad, vd.grad)
+    V, O, DV = be.t(var), be.empty(m, 2, 2), be.empty(m, 2, 2)
+    be.call("mnk_kp_clip_variance_fwd", V, clip, m, O)
+    be.call("mnk_kp_clip_variance_bwd", V, clip, m, be.t(dout.float()), DV)
+    be.sync()
+    assert relerr(O.cpu(), ref.detach()) < 4 * spread_f + 1e-6
+    assert relerr(DV.cpu(), vd.grad) < 4 * spread_b + 1e-5
