@@ -133,13 +133,13 @@ def main():
     torch.cuda.set_device(device)
 
     from mnk import configs, engine, _lib
-    from oracle import cases, restate
+    from mnk import workload
     cfg = configs.get(args.config)
     lib = _lib.lib()
     assert lib.is_device_build, "bench.py must run on the real HIP library"
     gen, disc, kpd = build_models(cfg, device)
     use_graph = (world == 1 and not force_dist) if args.graph < 0 else bool(args.graph)
-    src, drv = cases.synthetic_pair(args.batch, args.size, args.size, seed=1234 + rank)
+    src, drv = workload.synthetic_pair(args.batch, args.size, args.size, seed=1234 + rank)
     x = {"source": src.to(device), "video": drv.to(device)}
     step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
     if use_graph:
@@ -226,7 +226,7 @@ def main():
         cpu = cpu_baseline(cfg, args.cpu_batch, args.size, args.cpu_steps)
 
     if rank == 0:
-        flops = restate.conv_flops_hot_path(cfg, args.size, args.size)
+        flops = workload.conv_flops_hot_path(cfg, args.size, args.size)
         out = {
             "metric": "train frames/sec (Bx3x%dx%d, %d kp)" % (args.size, args.size,
                                                                cfg["model_params"]["common_params"]["num_kp"]),

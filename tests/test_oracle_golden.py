@@ -78,6 +78,8 @@ def test_flop_model_matches_survey():
                               ("shapes", 64, 1.892), ("bair", 64, 8.867), ("vox", 256, 64.404)):
         f = restate.conv_flops_hot_path(configs.get(name), size, size)
         assert abs(f["total"] / 1e9 - total) < 2e-3, (name, f["total"])
+        from mnk import workload          # the product-side accounting bench.py quotes is the same count
+        assert workload.conv_flops_hot_path(configs.get(name), size, size)["layers"] == f["layers"]
 
 
 @pytest.mark.skipif(not ref_shim.available(), reason="reference tree only exists in the authoring container")

@@ -10,8 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "monkey-net_amd"))
 import torch  # noqa: E402
 
-from mnk import configs, ops, _lib  # noqa: E402
-from oracle import restate  # noqa: E402
+from mnk import configs, ops, _lib, workload  # noqa: E402
 
 
 def timeit(fn, iters):
@@ -38,7 +37,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     args = ap.parse_args()
     cfg = configs.get(args.config)
-    layers = restate.conv_flops_hot_path(cfg, args.size, args.size)["layers"]
+    layers = workload.conv_flops_hot_path(cfg, args.size, args.size)["layers"]
     dev = torch.device("cuda:0")
     tot = {"fwd": [0.0, 0.0], "dgrad": [0.0, 0.0], "wgrad": [0.0, 0.0]}
     print("%-16s %5s %5s %4s %7s | %8s %8s %8s  (TFLOP/s, ms)" % ("layer", "cin", "cout", "hw", "frames", "fwd", "dgrad", "wgrad"))
