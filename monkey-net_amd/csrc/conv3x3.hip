@@ -57,7 +57,25 @@ struct ConvArgs {
     float* ws;         // [splits][M][ldw] partial sums when splits > 1
     int ldw;
     float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
+    int xcd;           // re-chunk the launch order per XCD (xcd_tile)
 };
+
+// Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), and every XCD has its own L2: with the
+// plain mapping each XCD touches every weight tile and every pixel tile of a layer, so both operands cross the fabric
+// up to 8 times.  Re-chunking the launch order -- XCD class c = L % 8 works on the contiguous range
+// [start(c), start(c) + count(c)) of the logical (x fastest, then y) tile order -- gives each XCD a few complete rows
+// of the tile grid: one operand is fetched once per chip, the other once per XCD that needs it.  (Placement is not
+// guaranteed by the hardware; this is a locality heuristic only -- any mapping is correct.)
+__device__ __forceinline__ void xcd_tile(int enable, int& bx, int& by) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    const unsigned gx = gridDim.x, per_z = gx * gridDim.y;
+    if (!enable || per_z < 16) return;
+    const unsigned L = blockIdx.x + gx * blockIdx.y, c = L & 7u, base = per_z >> 3, rem = per_z & 7u;
+    const unsigned logical = c * base + (c < rem ? c : rem) + (L >> 3);
+    by = (int)(logical / gx);
+    bx = (int)(logical - (unsigned)by * gx);
+}
 
 // ---- the activation-side loader of the implicit GEMM (shared by the 32x32 and 16x16 tile kernels) -------------------
 // Everything a K step needs per row is precomputed (frame base, row / column, validity bit masks of the kernel rows
@@ -158,8 +176,10 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int bx, by;
+    xcd_tile(a.xcd, bx, by);
+    const long m0 = (long)bx * BM;
+    const int n0 = by * BN;
     const int split = blockIdx.z;
     const int s_begin = split * a.ksteps_per_split;
     int s_end = s_begin + a.ksteps_per_split;
@@ -313,7 +333,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
                 t1 += red[(w * 2 + 0) * BN + t];
                 t2 += red[(w * 2 + 1) * BN + t];
             }
-            float* sp = a.stats + (long)blockIdx.x * 2 * a.ld_y;
+            float* sp = a.stats + (long)bx * 2 * a.ld_y;
             sp[n0 + t] = t1;
             sp[a.ld_y + n0 + t] = t2;
         }
@@ -336,8 +356,10 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_K];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int bx, by;
+    xcd_tile(a.xcd, bx, by);
+    const long m0 = (long)bx * BM;
+    const int n0 = by * BN;
     const int split = blockIdx.z;
     const int s_begin = split * a.ksteps_per_split;
     int s_end = s_begin + a.ksteps_per_split;
@@ -462,7 +484,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
                 t1 += red[(w * 2 + 0) * BN + t];
                 t2 += red[(w * 2 + 1) * BN + t];
             }
-            float* sp = a.stats + (long)blockIdx.x * 2 * a.ld_y;
+            float* sp = a.stats + (long)bx * 2 * a.ld_y;
             sp[n0 + t] = t1;
             sp[a.ld_y + n0 + t] = t2;
         }
@@ -543,57 +565,47 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
     }
 }
 
-// forward layout and the data-gradient layouts of both sources in one launch: [0, nf) forward, [nf, nf + nd0) source 0,
-// [nf + nd0, nf + nd0 + nd1) source 1 (what a training forward needs; the pack kernels above stay for single uses)
+// forward layout and the data-gradient layouts of both sources in one launch (what a training forward needs; the pack
+// kernels above stay for single uses).  One block per (16 output channels, source, 16 input channels) tile of the
+// parameter: the 16 x (16 * ntaps) floats are read as 16 contiguous runs, transposed through LDS and written as
+// 16 + 16 contiguous 16 * ntaps-float groups -- forward wf[co][chunk][tap][ci] and, for the same tile,
+// data-gradient wd[ci][chunk][ntaps-1-tap][co] -- so the parameter crosses HBM once and every access is coalesced.
 __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ w, float* __restrict__ wf,
                                                        float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0,
                                                        int C1, int C0p, int C1p, int ntaps) {
-    // one thread per 16-float group (index arithmetic once per group, four 16-byte stores)
-    const unsigned Cin = C0 + C1, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
-    const unsigned gf = (unsigned)Cout * chunks * ntaps;
-    const unsigned gd0 = wd0 ? (unsigned)C0 * dchunks * ntaps : 0, gd1 = wd1 ? (unsigned)C1 * dchunks * ntaps : 0;
-    const unsigned total = gf + gd0 + gd1;
-    for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
-        float v[16];
-        float* dst;
-        if (g < gf) {
-            const unsigned tap = g % ntaps, t = g / ntaps;
-            const unsigned chunk = t % chunks, co = t / chunks;
-            const float* src = w + ((size_t)co * Cin) * ntaps + tap;
-#pragma unroll
-            for (int k16 = 0; k16 < 16; ++k16) {
-                const int k = chunk * 16 + k16;
-                int ci = -1;
-                if (k < C0p) {
-                    if (k < C0) ci = k;
-                } else if (k - C0p < C1) {
-                    ci = C0 + k - C0p;
-                }
-                v[k16] = ci >= 0 ? src[(size_t)ci * ntaps] : 0.f;
-            }
-            dst = wf + (size_t)g * 16;
-        } else {
-            unsigned j = g - gf, c_start = 0;
-            dst = wd0;
-            if (j >= gd0) {
-                j -= gd0;
-                dst = wd1;
-                c_start = C0;
-            }
-            const unsigned tap = j % ntaps, t = j / ntaps;
-            const unsigned chunk = t % dchunks, ci = t / dchunks;
-            const float* src = w + ((size_t)c_start + ci) * ntaps + (ntaps - 1 - tap);
-#pragma unroll
-            for (int k16 = 0; k16 < 16; ++k16) {
-                const unsigned co = chunk * 16 + k16;
-                v[k16] = co < (unsigned)Cout ? src[(size_t)co * Cin * ntaps] : 0.f;
-            }
-            dst += (size_t)j * 16;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    __shared__ float T[16 * (16 * 17 + 1)];         // [16 co][16 ci][ntaps <= 16], padded strides (odd: no bank conflicts)
+    const int ntp = ntaps | 1, cos = 16 * ntp + 1;
+    const int chunks0 = C0p / 16, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
+    const int cc = blockIdx.x;                      // forward chunk (source 0 chunks, then source 1 chunks)
+    const int cot = blockIdx.y;                     // co tile (16 rows)
+    const bool second = cc >= chunks0;
+    const int Cs = second ? C1 : C0, cstart = second ? C0 : 0, lc = second ? cc - chunks0 : cc;
+    const int ci0 = lc * 16, co0 = cot * 16, Cin = C0 + C1;
+    const int run = 16 * ntaps;                     // floats per row of the tile
+    const int t = threadIdx.x;
+    for (int i = t; i < 16 * run; i += 256) {
+        const int r = i / run, o = i - r * run;     // row (co), offset inside the row = ci * ntaps + tap
+        const int ci = o / ntaps, tap = o - ci * ntaps;
+        const int co = co0 + r;
+        float v = 0.f;
+        if (co < Cout && ci0 + ci < Cs) v = w[((size_t)co * Cin + cstart + ci0) * ntaps + o];
+        T[r * cos + ci * ntp + tap] = v;
     }
+    __syncthreads();
+    for (int i = t; i < 16 * run; i += 256) {       // forward: 16 rows (co) of [tap][16 ci]
+        const int r = i / run, o = i - r * run;
+        const int tap = o >> 4, k16 = o & 15;
+        const int co = co0 + r;
+        if (co < Cout) wf[(((size_t)co * chunks + cc) * ntaps) * 16 + o] = T[r * cos + k16 * ntp + tap];
+    }
+    float* wd = second ? wd1 : wd0;
+    if (wd)
+        for (int i = t; i < 16 * run; i += 256) {   // data gradient: 16 rows (ci) of [flipped tap][16 co]
+            const int r = i / run, o = i - r * run;
+            const int tap = o >> 4, k16 = o & 15;
+            const int ci = ci0 + r;
+            if (ci < Cs) wd[(((size_t)ci * dchunks + cot) * ntaps) * 16 + o] = T[k16 * cos + r * ntp + (ntaps - 1 - tap)];
+        }
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------
@@ -1024,10 +1036,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args 
             for (int j = 0; j < NCI; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fax, fbx[j], accx[j], 0, 0, 0);
         }
     }
-    // D: col = lane & 15 (-> ci), row = 4 * (lane >> 4) + r (-> co); parameter layout n = ci * 9 + tap
+    // D: col = lane & 15 (-> ci), row = 4 * (lane >> 4) + r (-> co).  A single split writes the parameter layout
+    // (n = ci * 9 + tap) directly; split partials are tap-major [split][tap][co][ci] -- 64-byte runs along ci instead
+    // of 36-byte-strided words (measured: 82 MB of HBM writes per launch for 37 MB of partials) -- and are summed and
+    // transposed by conv3x3_wgrad_tap_reduce_kernel.
     const bool partial = a.splits > 1;
     float* outp = partial ? a.out + (long)split * a.Cout * a.NT : a.out;
-    const long ldo = partial ? (long)a.NT : a.ld_out;
+    const long ldo = partial ? (long)a.C : a.ld_out;                 // row stride (co)
+    const long tstride = partial ? (long)a.Cout * a.C : 1;             // tap stride
+    const int cstride = partial ? 1 : 9;                               // ci stride
     if (wave < 4) {
 #pragma unroll
         for (int tp = 0; tp < 2; ++tp) {
@@ -1041,7 +1058,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int co = co0 + 16 * i + 4 * fk + r;
-                            if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + tap] = acc[tp][i][j][r];
+                            if (co < a.Cout && ci < a.C)
+                                outp[tap * tstride + (long)co * ldo + ci * cstride] = acc[tp][i][j][r];
                         }
                     }
         }
@@ -1052,7 +1070,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + 16 * xc + 4 * fk + r;
-                    if (co < a.Cout && ci < a.C) outp[(long)co * ldo + ci * 9 + 8] = accx[j][r];
+                    if (co < a.Cout && ci < a.C) outp[8 * tstride + (long)co * ldo + ci * cstride] = accx[j][r];
                 }
             }
     }
@@ -1077,6 +1095,7 @@ struct WgradTapArgs {
     int gn;              // ci tiles per tap
     float* part;         // [splits][ntaps][Cout][C]
     unsigned mulW, shW, mulH, shH;   // division by W / H of a pixel index < 2^31 (mul == 0: shift only)
+    int xcd;             // re-chunk the launch order per XCD (xcd_tile)
 };
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned sh) {
@@ -1096,9 +1115,11 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];   // x-shifted [pixel][ci]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int co0 = blockIdx.x * BM;
-    const int tap = blockIdx.y / a.gn;
-    const int ci0 = (blockIdx.y - tap * a.gn) * BN;
+    int bx, by;
+    xcd_tile(a.xcd, bx, by);
+    const int co0 = bx * BM;
+    const int tap = by / a.gn;
+    const int ci0 = (by - tap * a.gn) * BN;
     const int split = blockIdx.z;
     const long p_begin = (long)split * a.pix_per_split;
     long p_end = p_begin + a.pix_per_split;
@@ -1327,6 +1348,7 @@ static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = 
 // mid-size layers (fewer than ~2 blocks per CU with 128-row tiles) use 64-row tiles: twice the blocks, so every SIMD
 // has a second wave to overlap loads with MFMA, and less (or no) split-K
 static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
+static int g_xcd_remap = env_int("MNK_XCD_REMAP", 1);
 static int g_mfma16 = env_int("MNK_MFMA16", 1);
 
 static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9) {
@@ -1564,8 +1586,9 @@ int mnk_conv2d_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d
     const long total = (long)Cout * ntaps * (C0p + C1p) + (wp_d0 ? C0 * dper : 0) + (wp_d1 ? C1 * dper : 0);
     MNK_REQUIRE(total < (1L << 31) && ((size_t)wp_fwd % 16) == 0 && ((size_t)wp_d0 % 16) == 0 && ((size_t)wp_d1 % 16) == 0);
     ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
-    hipLaunchKernelGGL(pack_all_kernel, dim3(grid_for(total / 16, 8192)), dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0,
-                       C1, C0p, C1p, ntaps);
+    MNK_REQUIRE(ntaps <= 16);
+    hipLaunchKernelGGL(pack_all_kernel, dim3((C0p + C1p) / 16, ceil_div(Cout, 16)), dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1,
+                       Cout, C0, C1, C0p, C1p, ntaps);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -1630,6 +1653,7 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     a.ws = ws;
     a.ldw = p.ldw;
     a.stats = stats_partial;
+    a.xcd = g_xcd_remap;
     MNK_REQUIRE(!stats_partial || (p.splits == 1 && ld_y == round_up(Cout, 4)));
     if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * a.M * p.ldw)) {
         set_error("mnk_conv2d_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * a.M * p.ldw);
@@ -1725,6 +1749,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
         g.pix_per_split = tp.pix_per_split;
         g.gn = tp.gn;
         g.part = ws;
+        g.xcd = g_xcd_remap;
         fast_div_consts((unsigned)W, &g.mulW, &g.shW);
         fast_div_consts((unsigned)H, &g.mulH, &g.shH);
         hipStream_t st = (hipStream_t)stream;
@@ -1806,7 +1831,19 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
             }
             if (np.splits > 1) {
                 ProfScope prof(K_CONV_REDUCE, sn, (double)np.splits * Cout * g.NT * 4);
-                launch_wgrad_reduce(ws, np.splits, Cout, g.NT, dstn, ldn, sn);
+                const long n = (long)Cout * g.NT;
+                const float* src = ws;
+                int nsum = np.splits;
+                const int groups = split_groups(np.splits);
+                if (groups) {
+                    float* part2 = ws + (size_t)np.splits * n;
+                    hipLaunchKernelGGL(conv3x3_wgrad_group_sum_kernel, dim3(grid_for(n, 1024), groups), dim3(256), 0, sn, ws,
+                                       n, np.splits, 8, part2);
+                    src = part2;
+                    nsum = groups;
+                }
+                hipLaunchKernelGGL(conv3x3_wgrad_tap_reduce_kernel, dim3(ceil_div(C, 64), Cout), dim3(256), 0, sn, src, nsum, 9,
+                                   Cout, C, dstn, ldn);
             }
             MNK_LAUNCH_CHECK();
             return MNK_OK;

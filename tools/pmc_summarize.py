@@ -3,7 +3,7 @@
 usage: pmc_summarize.py <dir with FETCH pass> <dir with WRITE pass> <out.json>
 FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section); on gfx950 FETCH_SIZE reads 1/2 of the bytes of
 a wide coalesced stream, so the corrected figure doubles it."""
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, re, sys, collections
 
 
 def load(d, counter):
@@ -19,11 +19,9 @@ def load(d, counter):
 
 
 def short(n):
-    for key in ("conv3x3_igemm_kernel<128, 128", "conv3x3_igemm_kernel<128, 64", "conv3x3_igemm_kernel<128, 32",
-                "conv3x3_wgrad_kernel<128>", "conv3x3_wgrad_kernel<64>", "conv3x3_wgrad_kernel<32>"):
-        if key in n:
-            return key
-    return n.split("(")[0][-60:]
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)[:72]
 
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
