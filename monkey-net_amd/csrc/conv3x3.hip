@@ -570,10 +570,12 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
 // parameter: the 16 x (16 * ntaps) floats are read as 16 contiguous runs, transposed through LDS and written as
 // 16 + 16 contiguous 16 * ntaps-float groups -- forward wf[co][chunk][tap][ci] and, for the same tile,
 // data-gradient wd[ci][chunk][ntaps-1-tap][co] -- so the parameter crosses HBM once and every access is coalesced.
+template <int NT>                                 // NT = ntaps when known at compile time (9: constant divisions), else 0
 __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ w, float* __restrict__ wf,
                                                        float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0,
-                                                       int C1, int C0p, int C1p, int ntaps) {
+                                                       int C1, int C0p, int C1p, int ntaps_rt) {
     __shared__ float T[16 * (16 * 17 + 1)];         // [16 co][16 ci][ntaps <= 16], padded strides (odd: no bank conflicts)
+    const int ntaps = NT ? NT : ntaps_rt;
     const int ntp = ntaps | 1, cos = 16 * ntp + 1;
     const int chunks0 = C0p / 16, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
     const int cc = blockIdx.x;                      // forward chunk (source 0 chunks, then source 1 chunks)
@@ -1587,8 +1589,11 @@ int mnk_conv2d_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d
     MNK_REQUIRE(total < (1L << 31) && ((size_t)wp_fwd % 16) == 0 && ((size_t)wp_d0 % 16) == 0 && ((size_t)wp_d1 % 16) == 0);
     ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
     MNK_REQUIRE(ntaps <= 16);
-    hipLaunchKernelGGL(pack_all_kernel, dim3((C0p + C1p) / 16, ceil_div(Cout, 16)), dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1,
-                       Cout, C0, C1, C0p, C1p, ntaps);
+    const dim3 grid((C0p + C1p) / 16, ceil_div(Cout, 16));
+    if (ntaps == 9)
+        hipLaunchKernelGGL(pack_all_kernel<9>, grid, dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0, C1, C0p, C1p, ntaps);
+    else
+        hipLaunchKernelGGL(pack_all_kernel<0>, grid, dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0, C1, C0p, C1p, ntaps);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
