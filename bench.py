@@ -43,8 +43,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU sample (default: the workload's)")
+    ap.add_argument("--cpu-steps", type=int, default=6, help="CPU sample: at most this many iterations / ~20 s")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the iteration as one captured hipGraph, 0: eager launches, -1: graph on 1 GPU")
@@ -138,7 +138,9 @@ def main():
     lib = _lib.lib()
     assert lib.is_device_build, "bench.py must run on the real HIP library"
     gen, disc, kpd = build_models(cfg, device)
-    use_graph = (world == 1 and not force_dist) if args.graph < 0 else bool(args.graph)
+    # default: the whole iteration (with its RCCL collectives when there are several ranks) replays as one hipGraph
+    use_graph = (os.environ.get("MNK_DIST_GRAPH", "1") == "1" or (world == 1 and not force_dist)) \
+        if args.graph < 0 else bool(args.graph)
     src, drv = workload.synthetic_pair(args.batch, args.size, args.size, seed=1234 + rank)
     x = {"source": src.to(device), "video": drv.to(device)}
     step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
