@@ -54,3 +54,31 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, f)
                 assert "hipemu" not in text, os.path.join(dirpath, f)
+
+
+def test_integration_stub_runs(be):
+    """The ctypes binding printed in INTEGRATION.md section 2 is executed as written (library path, device and stream
+    substituted for the backend under test) and reproduces DownBlock3D.forward of the reference."""
+    import re
+    import torch
+    import torch.nn.functional as F
+    from torch import nn
+    from _util import to_nhwc
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch\n.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libmonkeynet_hip.so")', "ctypes.CDLL(LIB_PATH)")
+    if be.kind == "emu":
+        code = code.replace("torch.cuda.current_stream().cuda_stream", "None")
+    ns = {"LIB_PATH": be.lib.path}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    torch.manual_seed(2)
+    n, h, w, cin, cout = 3, 8, 8, 5, 14
+    conv = nn.Conv3d(cin, cout, (1, 3, 3), padding=(0, 1, 1)).to(be.device)
+    norm = nn.BatchNorm3d(cout).to(be.device)
+    x = torch.rand(n, cin, h, w)
+    z = ns["down_block"](be.t(to_nhwc(x)), conv, norm, n, h, w, cin, cout)
+    be.sync()
+    ref = F.avg_pool2d(F.relu(F.batch_norm(F.conv2d(x.double(), conv.weight.detach().cpu()[:, :, 0].double(),
+                                                    conv.bias.detach().cpu().double(), padding=1),
+                                           None, None, torch.ones(cout).double(), torch.zeros(cout).double(), True)), 2)
+    assert float((z.cpu()[..., :cout].permute(0, 3, 1, 2).double() - ref).abs().max()) < 2e-5
