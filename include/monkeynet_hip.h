@@ -155,7 +155,13 @@ size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cou
  * epilogue also emits per-block column sums / sums of squares of y -- the BatchNorm statistics of the following
  * norm layer -- to be finished by mnk_bn_stats_finish(stats_partial, stats_floats / (2*ld_y), ld_y, Cout, sums). */
 size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout);
-int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
+/* `flags`: MNK_CONV_UPSAMPLED (= 1, the former `ups` argument: both sources are read through the nearest x2 up-sampling)
+ * | MNK_CONV_CLEAN_PADS (= 2): the caller vouches that the pad channels [C, ld) of the sources hold zeros (every
+ * activation this library writes does).  Without it the gather masks them (a source with garbage / NaN pads is fine,
+ * ~10 % slower); with it the 3x3 kernels use raw buffer loads whose out-of-range lanes read zero. */
+#define MNK_CONV_UPSAMPLED 1
+#define MNK_CONV_CLEAN_PADS 2
+int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp,
                     const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
                     int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream);
 /* dw[co][c_start+ci][ky][kx] = sum_pixels dy[p][co] * x[p+tap][ci]; x is one source (C channels) */
@@ -176,7 +182,7 @@ int mnk_conv2d_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, in
                           void* stream);
 size_t mnk_conv2d_workspace_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps);
 size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, int ntaps);
-int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, int Hi, int Wi, int kh,
+int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, int Hi, int Wi, int kh,
                    int kw, int pad, const float* wp, const float* bias, const float* residual, int ld_res, float* y,
                    int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats, float* stats_partial,
                    void* stream);

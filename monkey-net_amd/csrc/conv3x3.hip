@@ -58,6 +58,7 @@ struct ConvArgs {
     int ldw;
     float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
     int xcd;           // re-chunk the launch order per XCD (xcd_tile)
+    int clean;         // the sources' pad channels [C, ld) hold zeros (finite values): the 3x3 fast loader may be used
 };
 
 // Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), and every XCD has its own L2: with the
@@ -153,6 +154,9 @@ struct ActLoader {
     // row j on its way to LDS: pad channels of the producer may hold anything, taps outside the image are zero
     __device__ __forceinline__ float4 masked(int j) const {
         float4 v = ra[j];
+#ifdef MNK_EXPERIMENT_NOMASK
+        return v;
+#endif
         v.x = tail[j] < 1 ? 0.f : v.x;
         v.y = tail[j] < 2 ? 0.f : v.y;
         v.z = tail[j] < 3 ? 0.f : v.z;
@@ -161,11 +165,113 @@ struct ActLoader {
     }
 };
 
+// ---- the same loader for the hot case (3x3, pad 1, sources with clean pad channels) with the fewest instructions per
+// K step -- every vector instruction between two MFMAs costs matrix-pipe time on this hardware (profiles/README.md:
+// dropping only the data masks of the generic loader was worth +9 %).  Raw buffer loads relative to a per-block base
+// (offsets stay far below 2^30; num_records = 2^30): an out-of-image tap or a chunk beyond the channel count gets bit
+// 30 added to its offset and the hardware returns zeros -- no clamping, no data masks, no branches.  Per row and step:
+// one add, one bit-field extract, one and-or (+ five for the parity shifts of the nearest x2 up-sampling view).
+template <int RA, bool UPS>
+struct ActLoader3 {
+    unsigned b0[RA], b1[RA];       // byte offset of the row's centre pixel in source 0 / 1 (relative to the block base)
+    unsigned inv[RA];              // bit t: tap t lies outside the image
+    unsigned par[RA];              // up-sampling: bit 0 h even, 1 h odd, 2 w even, 3 w odd (bit 4 stays 0)
+    float4 ra[RA];
+    __amdgpu_buffer_rsrc_t r0, r1;
+    int chunk, ky, kx, Ws, lq4;
+
+    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin) {
+        lq4 = lq_ * 16;
+        const int Hs = UPS ? a.Hi >> 1 : a.Hi;
+        Ws = UPS ? a.Wi >> 1 : a.Wi;
+        long mb = m0 < a.M ? m0 : a.M - 1;
+        const long tb = mb / a.W;
+        const long rowidx0 = (tb / a.H) * Hs + ((int)(tb % a.H) >> (UPS ? 1 : 0));
+        long pbase = rowidx0 * Ws - Ws - 1;
+        if (pbase < 0) pbase = 0;
+        r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x0 + pbase * a.ld0), 0, 0x40000000, 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc((void*)((a.x1 ? a.x1 : a.x0) + pbase * (a.x1 ? a.ld1 : a.ld0)), 0, 0x40000000,
+                                               0x00020000);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            long m = m0 + lrow + 64 * j;
+            if (m > a.M - 1) m = a.M - 1;
+            const int w = (int)(m % a.W);
+            const long tt = m / a.W;
+            const int h = (int)(tt % a.H);
+            const long rel = ((tt / a.H) * Hs + (h >> (UPS ? 1 : 0))) * Ws + (w >> (UPS ? 1 : 0)) - pbase;
+            b0[j] = (unsigned)(rel * a.ld0 * 4);
+            b1[j] = (unsigned)(rel * a.ld1 * 4);
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+                if (hh < 0 || hh >= a.Hi || ww < 0 || ww >= a.Wi) mk |= 1u << t;
+            }
+            inv[j] = mk;
+            par[j] = ((h & 1) ? 2u : 1u) | ((w & 1) ? 8u : 4u);
+        }
+        chunk = s_begin / 9;
+        ky = (s_begin - chunk * 9) / 3;
+        kx = (s_begin - chunk * 9) - ky * 3;
+    }
+    __device__ __forceinline__ void load(const ConvArgs& a) {
+        const int c0 = chunk * BK;
+        const bool second = c0 >= a.C0p;
+        const int cbase = second ? c0 - a.C0p : c0;
+        const int ldb = (second ? a.ld1 : a.ld0) * 4, C = second ? a.C1 : a.C0;
+        const __amdgpu_buffer_rsrc_t rs = second ? r1 : r0;
+        const int tap = ky * 3 + kx;
+        // per thread: channel offset, + bit 30 when the whole float4 lies beyond the channel count
+        unsigned st = (unsigned)(cbase * 4 + lq4);
+        st += (cbase * 4 + lq4 >= C * 4) ? 0x40000000u : 0u;
+        int s_dr = 0, s_dc = 0, rbit = 4, cbit = 4;
+        if (UPS) {
+            s_dr = ky == 0 ? -Ws * ldb : (ky == 2 ? Ws * ldb : 0);
+            s_dc = kx == 0 ? -ldb : (kx == 2 ? ldb : 0);
+            rbit = ky == 0 ? 0 : (ky == 2 ? 1 : 4);
+            cbit = kx == 0 ? 2 : (kx == 2 ? 3 : 4);
+        } else {
+            st += (unsigned)(((ky - 1) * Ws + (kx - 1)) * ldb);
+        }
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            unsigned off = (second ? b1[j] : b0[j]) + st;
+            if (UPS) {
+                const int nr = __builtin_amdgcn_sbfe(par[j], rbit, 1), nc = __builtin_amdgcn_sbfe(par[j], cbit, 1);
+                off += (unsigned)(nr & s_dr) + (unsigned)(nc & s_dc);
+            }
+            const int bad = __builtin_amdgcn_sbfe(inv[j], tap, 1);            // 0 or -1
+            off = ((unsigned)bad & 0x40000000u) | off;
+            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+        const int kx1 = kx + 1;
+        const bool wx = kx1 == 3;
+        kx = wx ? 0 : kx1;
+        const int ky1 = ky + (wx ? 1 : 0);
+        const bool wy = ky1 == 3;
+        ky = wy ? 0 : ky1;
+        chunk += wy ? 1 : 0;
+    }
+    __device__ __forceinline__ float4 masked(int j) const { return ra[j]; }
+};
+
+template <int RA, int MODE> struct LoaderSel { typedef ActLoader<RA> type; };
+template <int RA> struct LoaderSel<RA, 1> { typedef ActLoader3<RA, false> type; };
+template <int RA> struct LoaderSel<RA, 2> { typedef ActLoader3<RA, true> type; };
+
+// timing experiment only (wrong results): -DMNK_EXPERIMENT_NOSYNC drops the per-step barrier of the igemm main loop
+#ifdef MNK_EXPERIMENT_NOSYNC
+#define MNK_LOOP_SYNC() ((void)0)
+#else
+#define MNK_LOOP_SYNC() __syncthreads()
+#endif
+
 #ifndef MNK_IGEMM_OCC
 #define MNK_IGEMM_OCC 3                       // waves per SIMD = blocks per CU the register budget is held to
 #endif
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MODE>     // MODE: 0 generic loader, 1 / 2 the 3x3 fast loader (plain / x2 up-sampled)
 __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvArgs a) {
     constexpr int RA = BM / 64;               // A rows per thread per K step
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -187,7 +293,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
 
     // ---- per-thread global->LDS assignment: row inside a 64-row slab, float4 column (4 channels) --------------
     const int lrow = t >> 2, lq = t & 3;
-    ActLoader<RA> L;
+    typename LoaderSel<RA, MODE>::type L;
     L.setup(a, m0, lrow, lq, s_begin);
     constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
     const long KT = (long)a.ksteps * BK;     // packed row length
@@ -221,16 +327,30 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     const int fi = lane & 31, fk = lane >> 5;
     const int a_row0 = wm * (BM / WM) + fi, b_row0 = wn * (BN / WN) + fi;
 
+#ifdef MNK_EXPERIMENT_NOLDSREAD
+    float4 xfa[2][TM], xfb[2][TN];
+    for (int kh = 0; kh < 2; ++kh) {
+        for (int i = 0; i < TM; ++i) xfa[kh][i] = *reinterpret_cast<const float4*>(&As[0][a_row0 + 32 * i][kh * 8 + fk * 4]);
+        for (int j = 0; j < TN; ++j) xfb[kh][j] = *reinterpret_cast<const float4*>(&Bs[0][b_row0 + 32 * j][kh * 8 + fk * 4]);
+    }
+#endif
     auto mfma_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             float4 fa[TM], fb[TN];
+#ifdef MNK_EXPERIMENT_NOLDSREAD
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = xfa[kh][i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = xfb[kh][j];
+#else
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 fa[i] = *reinterpret_cast<const float4*>(&As[buf][a_row0 + 32 * i][kh * 8 + fk * 4]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_row0 + 32 * j][kh * 8 + fk * 4]);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -256,10 +376,16 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     int s = s_begin;
     for (; s + 2 < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
+#ifndef MNK_EXPERIMENT_NOSTORE
         store_step(buf ^ 1);
+#endif
+#ifndef MNK_EXPERIMENT_NOLOAD
         load_step(s + 2);
+#endif
+#ifndef MNK_EXPERIMENT_NOMFMA
         mfma_step(buf);
-        __syncthreads();
+#endif
+        MNK_LOOP_SYNC();
     }
     if (s + 1 < s_end) {
         const int buf = (s - s_begin) & 1;
@@ -350,7 +476,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
 // 32x32 kernel above.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BN>
+template <int BN, int MODE>
 __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     constexpr int BM = 128, RA = 2, TM = 2, TN = BN / 16;
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
@@ -365,7 +491,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     int s_end = s_begin + a.ksteps_per_split;
     if (s_end > a.ksteps) s_end = a.ksteps;
     const int lrow = t >> 2, lq = t & 3;
-    ActLoader<RA> L;
+    typename LoaderSel<RA, MODE>::type L;
     L.setup(a, m0, lrow, lq, s_begin);
     const long KT = (long)a.ksteps * BK;
     const int wco = n0 + (lrow < BN ? lrow : 0);           // rows beyond BN / Cout: clamped, never stored
@@ -1351,6 +1477,7 @@ static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = 
 // has a second wave to overlap loads with MFMA, and less (or no) split-K
 static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
 static int g_xcd_remap = env_int("MNK_XCD_REMAP", 1);
+static int g_fast_loader = env_int("MNK_FAST_LOADER", 1);
 static int g_mfma16 = env_int("MNK_MFMA16", 1);
 
 static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9) {
@@ -1612,10 +1739,12 @@ size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, 
     return p.splits > 1 ? 0 : (size_t)p.gm * 2 * round_up(Cout, 4);
 }
 
-int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, int Hi, int Wi, int kh,
+int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, int Hi, int Wi, int kh,
                    int kw, int pad, const float* wp, const float* bias, const float* residual, int ld_res, float* y,
                    int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats, float* stats_partial,
                    void* stream) {
+    MNK_REQUIRE(flags >= 0 && flags <= 3);
+    const int ups = flags & MNK_CONV_UPSAMPLED, clean = (flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
     MNK_REQUIRE(x0 && wp && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
     MNK_REQUIRE(kh > 0 && kw > 0 && pad >= 0 && Hi > 0 && Wi > 0);
     MNK_REQUIRE(Ho == Hi + 2 * pad - kh + 1 && Wo == Wi + 2 * pad - kw + 1);
@@ -1634,6 +1763,7 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     a.C0p = round_up(C0, 16);
     a.C1p = C1 > 0 ? round_up(C1, 16) : 0;
     a.ups = ups;
+    a.clean = clean;
     a.wp = wp;
     a.bias = bias;
     a.residual = residual;
@@ -1668,20 +1798,32 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     dim3 grid(p.gm, p.gn, p.splits);
     {
         ProfScope prof(K_CONV_FWD, s, 2.0 * (double)a.M * Cout * (double)ntaps * (C0 + C1));
+        // loader: the 3x3 / pad 1 fast form when the caller vouches for clean pad channels and a block's pixel span
+        // fits the 2^30-byte buffer window (always, short of ~2 M-float pixel rows)
+        const long span = ((long)BK * 8 + 3L * (ups ? Wi / 2 : Wi) + 8) * (ld0 > ld1 ? ld0 : ld1) * 4;
+        const int mode = (g_fast_loader && a.clean && kh == 3 && kw == 3 && pad == 1 && span < (1L << 29) &&
+                          (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0)) ? (ups ? 2 : 1) : 0;
+#define MNK_IGEMM(KERNEL, ...)                                                                          \
+    do {                                                                                                \
+        if (mode == 1) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 1>), grid, dim3(256), 0, s, a);        \
+        else if (mode == 2) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 2>), grid, dim3(256), 0, s, a);   \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 0>), grid, dim3(256), 0, s, a);                  \
+    } while (0)
         if (p.bn == 16)
-            hipLaunchKernelGGL((conv3x3_igemm16_kernel<16>), grid, dim3(256), 0, s, a);
+            MNK_IGEMM(conv3x3_igemm16_kernel, 16);
         else if (p.bn == 48)
-            hipLaunchKernelGGL((conv3x3_igemm16_kernel<48>), grid, dim3(256), 0, s, a);
+            MNK_IGEMM(conv3x3_igemm16_kernel, 48);
         else if (p.bn == 128 && p.bm == 128)
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+            MNK_IGEMM(conv3x3_igemm_kernel, 128, 128, 2, 2);
         else if (p.bn == 128)
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<64, 128, 1, 4>), grid, dim3(256), 0, s, a);
+            MNK_IGEMM(conv3x3_igemm_kernel, 64, 128, 1, 4);
         else if (p.bn == 64 && p.bm == 128)
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 64, 2, 2>), grid, dim3(256), 0, s, a);
+            MNK_IGEMM(conv3x3_igemm_kernel, 128, 64, 2, 2);
         else if (p.bn == 64)
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, a);
+            MNK_IGEMM(conv3x3_igemm_kernel, 64, 64, 2, 2);
         else
-            hipLaunchKernelGGL((conv3x3_igemm_kernel<128, 32, 4, 1>), grid, dim3(256), 0, s, a);
+            MNK_IGEMM(conv3x3_igemm_kernel, 128, 32, 4, 1);
+#undef MNK_IGEMM
     }
     if (p.splits > 1) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
@@ -1979,10 +2121,10 @@ size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cou
 size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout) {
     return mnk_conv2d_stats_floats(N, H, W, C0, C1, Cout, 9);
 }
-int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int ups, const float* wp,
+int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp,
                     const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
                     int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream) {
-    return mnk_conv2d_fwd(x0, ld0, C0, x1, ld1, C1, ups, H, W, 3, 3, 1, wp, bias, residual, ld_res, y, ld_y, N, H, W, Cout,
+    return mnk_conv2d_fwd(x0, ld0, C0, x1, ld1, C1, flags, H, W, 3, 3, 1, wp, bias, residual, ld_res, y, ld_y, N, H, W, Cout,
                           ws, ws_floats, stats_partial, stream);
 }
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {

@@ -176,8 +176,10 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
     ws = SCRATCH.get("ws", nws, x0) if nws else None
     nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats else 0
     st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None   # lives until the norm layer reads it
+    # flags: bit 0 = nearest x2 up-sampled view, bit 1 = MNK_CONV_CLEAN_PADS -- every act this module produces has zero
+    # pad channels (tests/test_modules.py::test_pad_channels_are_written pins that), so the fast 3x3 loader applies
     _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
-          int(ups), _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
+          int(ups) | 2, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
           y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
     sums = None
     if want_stats:

@@ -116,11 +116,34 @@ static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 static inline int __float2int_rd(float a) { return (int)floorf(a); }
+static inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) {   // signed bit-field extract
+    off &= 31u;
+    if (width == 0) return 0;
+    if (off + width > 32) width = 32 - off;
+    return (int)((unsigned)v << (32 - off - width)) >> (32 - width);
+}
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_barrier() { hipemu::sync_block(); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return __shfl(v, 0); }
+
+// raw buffer loads: resource = (base, num_records in bytes); an access that does not lie inside [0, num_records) reads 0
+struct __amdgpu_buffer_rsrc_t {
+    const char* base;
+    unsigned num_records;
+};
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_records, int) {
+    return __amdgpu_buffer_rsrc_t{(const char*)p, (unsigned)num_records};
+}
+typedef int hipemu_i32x4 __attribute__((vector_size(16)));
+static inline hipemu_i32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voffset, unsigned soffset,
+                                                                 int) {
+    hipemu_i32x4 v = {0, 0, 0, 0};
+    const unsigned long long off = (unsigned long long)voffset + soffset;
+    if (off + 16 <= r.num_records) memcpy(&v, r.base + off, 16);
+    return v;
+}
 
 typedef float hipemu_f32x16 __attribute__((vector_size(64)));
 typedef float hipemu_f32x4 __attribute__((vector_size(16)));

@@ -40,12 +40,16 @@ def _ref_fwd(case, x0, x1, wt, b, r):
     return y
 
 
-def _run_fwd(be, case, x0, x1, wt, b, r):
+def _run_fwd(be, case, x0, x1, wt, b, r, clean=False):
+    """clean = False: generic loader, pad channels of the sources hold NaN and must be ignored by the kernel;
+    clean = True: MNK_CONV_CLEAN_PADS (zero pads vouched for) -> the raw-buffer-load 3x3 loader."""
     n, h, w, c0, c1, cout, ups, _, _ = case
     wp = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
     be.call("mnk_conv3x3_pack_fwd", be.t(wt), wp, cout, c0, c1)
-    X0 = be.t(to_nhwc(x0, pad_value=float("nan")))     # pad channels must be ignored by the kernel
-    X1 = be.t(to_nhwc(x1, pad_value=float("nan"))) if x1 is not None else None
+    padv = 0.0 if clean else float("nan")
+    ups = int(ups) | (2 if clean else 0)
+    X0 = be.t(to_nhwc(x0, pad_value=padv))
+    X1 = be.t(to_nhwc(x1, pad_value=padv)) if x1 is not None else None
     R = be.t(to_nhwc(r)) if r is not None else None
     ldy = ceil4(cout)
     Y = be.empty(n, h, w, ldy)
@@ -58,10 +62,21 @@ def _run_fwd(be, case, x0, x1, wt, b, r):
     return Y.cpu()
 
 
-@pytest.mark.parametrize("case", CASES)
-def test_conv3x3_forward(be, case):
+# more shapes for the fast loader: all five igemm tiles + both 16x16 tiles, up-sampled, ragged M, odd sizes, frame borders
+FAST_CASES = [
+    (3, 6, 10, 33, 0, 129, 0, True, False),      # 128x128 tile (Cout > 128 -> 2 N tiles), odd H / W
+    (2, 16, 16, 24, 17, 40, 1, True, True),      # 16x16x4 kernel BN = 48, two up-sampled sources, residual
+    (5, 4, 6, 20, 0, 9, 0, False, False),        # BN = 16
+    (2, 8, 8, 72, 0, 30, 1, True, False),        # 128x32 tile, up-sampled
+    (6, 64, 64, 5, 0, 20, 0, True, False),       # 192 M tiles, no split-K, XCD re-chunked order
+]
+
+
+@pytest.mark.parametrize("clean", [False, True])
+@pytest.mark.parametrize("case", CASES + FAST_CASES)
+def test_conv3x3_forward(be, case, clean):
     x0, x1, wt, b, r = _inputs(case)
-    Y = _run_fwd(be, case, x0, x1, wt, b, r)
+    Y = _run_fwd(be, case, x0, x1, wt, b, r, clean)
     ref = _ref_fwd(case, x0, x1, wt, b, r)
     cout = case[5]
     assert relerr(from_nhwc(Y, cout), ref) < 2e-6
@@ -87,10 +102,11 @@ def test_conv3x3_dgrad(be, case):
         DX = be.empty(n, h, w, ld)
         nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, cout, 0, c_cnt)
         ws = be.empty(max(nws, 1))
-        be.call("mnk_conv3x3_fwd", DY, DY.shape[-1], cout, None, 0, 0, 0, wp, None, None, 0, DX, ld, n, h, w, c_cnt,
-                ws, nws, None)
-        be.sync()
-        assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
+        for flags in (0, 2):     # generic / fast loader (to_nhwc pads with zeros)
+            be.call("mnk_conv3x3_fwd", DY, DY.shape[-1], cout, None, 0, 0, flags, wp, None, None, 0, DX, ld, n, h, w,
+                    c_cnt, ws, nws, None)
+            be.sync()
+            assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
 
 
 # W >= 16: the LDS-halo weight-gradient kernel (64-pixel tiles, zero-bordered halo, 9 taps from LDS)

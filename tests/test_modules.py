@@ -178,6 +178,41 @@ def test_weights_updated_without_version_bump_are_seen(be):
     assert ops._PACK_EPOCH[0] > e0
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny2"])
+def test_pad_channels_are_written(be, name, monkeypatch):
+    """The 3x3 fast loader (MNK_CONV_CLEAN_PADS) relies on every activation this package produces having ZERO pad
+    channels.  Here every torch.empty / empty_like of mnk.ops is pre-filled with NaN: a producer that leaves its pad
+    channels (or anything else a consumer reads) unwritten turns the losses / gradients into NaN."""
+    from mnk import ops
+
+    def nan_empty(*a, **k):
+        t = torch.zeros(*a, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+
+    def nan_empty_like(x, **k):
+        t = torch.zeros_like(x, **k)
+        return t.fill_(float("nan")) if t.is_floating_point() else t
+
+    class TorchProxy:
+        def __getattr__(self, item):
+            if item == "empty":
+                return nan_empty
+            if item == "empty_like":
+                return nan_empty_like
+            return getattr(torch, item)
+
+    monkeypatch.setattr(ops, "torch", TorchProxy())
+    ops.SCRATCH.bufs.clear()
+    gold = load(name)
+    out, grads, _, _ = run_case(be, gold, train=True, backward=True)
+    ops.SCRATCH.bufs.clear()
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), "non-finite output %s" % k
+    for grp, d in grads.items():
+        for k, v in d.items():
+            assert torch.isfinite(v).all(), "non-finite gradient %s.%s" % (grp, k)
+
+
 def test_down_block_with_fused_statistics(be):
     """A block large enough that the conv is not split along K, so the BatchNorm statistics come out of the conv
     epilogue (mnk_conv3x3_stats_floats > 0); forward, running stats and all gradients against the oracle in fp64."""
