@@ -166,7 +166,7 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
                     int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream);
 /* dw[co][c_start+ci][ky][kx] = sum_pixels dy[p][co] * x[p+tap][ci]; x is one source (C channels) */
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout);
-int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
+int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int flags, const float* dy, int ld_dy, int Cout, float* dw,
                       int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream);
 
 /* ---- general K x K form of the same kernels (stride 1).  Used for the discriminator's nn.Conv3d((1,4,4)) without
@@ -187,7 +187,7 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
                    int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats, float* stats_partial,
                    void* stream);
 size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad);
-int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
+int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
                      int ld_dy, int Cout, float* dw, int Cin_total, int c_start, int N, int Ho, int Wo, float* ws,
                      size_t ws_floats, void* stream);
 

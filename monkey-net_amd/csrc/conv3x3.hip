@@ -1224,13 +1224,20 @@ struct WgradTapArgs {
     float* part;         // [splits][ntaps][Cout][C]
     unsigned mulW, shW, mulH, shH;   // division by W / H of a pixel index < 2^31 (mul == 0: shift only)
     int xcd;             // re-chunk the launch order per XCD (xcd_tile)
+    int clean;           // pad channels of x and dy hold zeros: the buffer-load fast path may be used
+    int sw, sh, sn;      // fast path: one 16-pixel K step = sw columns + sh rows + sn frames
 };
 
 __device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned sh) {
     return mul ? __umulhi(n, mul) >> sh : n >> sh;
 }
 
-template <int BM, int BN, int WM, int WN>
+// MODE 0: generic loader (any K x K, masks, clamps, magic-number division per row and step).  MODE 1 / 2: 3x3 pad 1 with
+// clean pad channels, W >= 16 (plain / x2 up-sampled source): raw buffer loads whose out-of-range lanes read zero --
+// dy rows beyond the split's pixel range fall off the end of the buffer, taps outside the image and float4s beyond
+// the channel count get bit 30 added to their offset -- and the (h, w) of a row is advanced incrementally (16 pixels
+// per step wrap at most once), so a row costs ~10 vector instructions per step instead of ~35.
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs a) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -1284,14 +1291,77 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
         const unsigned pix = (n * (unsigned)Hs + (unsigned)(hh >> a.ups)) * (unsigned)Ws + (unsigned)(ww >> a.ups);
         v = *reinterpret_cast<const float4*>(a.x + (unsigned long)pix * (unsigned)a.ld_x + cib_e);
     };
+    // ---- fast loader state (MODE != 0) -----------------------------------------------------------------------
+    constexpr bool FUPS = MODE == 2;
+    __amdgpu_buffer_rsrc_t rsa, rsb;
+    unsigned aoff0 = 0, aoff1 = 0, boff0 = 0, boff1 = 0;     // running byte offsets (non-ups B: linear in the pixel)
+    int bw0 = 0, bh0 = 0, bn0 = 0, bw1 = 0, bh1 = 0, bn1 = 0;  // (w, h, frame relative to the first) of the B rows
+    const int ldy4 = a.ld_dy * 4, ldx4 = a.ld_x * 4;
+    const int hbad = dyt < 0 ? 0 : (dyt > 0 ? a.H - 1 : -1), wbad = dxt < 0 ? 0 : (dxt > 0 ? a.W - 1 : -1);
+    if constexpr (MODE != 0) {
+        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + p_begin * a.ld_dy), 0, (int)((p_end - p_begin) * ldy4),
+                                                0x00020000);
+        const unsigned tail_flag_a = tail_a > 0 ? 0u : 0x40000000u, tail_flag_b = tail_b > 0 ? 0u : 0x40000000u;
+        aoff0 = (unsigned)(ar * ldy4 + (int)coa_e * 4) + tail_flag_a;
+        aoff1 = aoff0 + (unsigned)(APASS * ldy4);
+        const long frame_px = (long)a.H * a.W;
+        const long nb = p_begin / frame_px;                       // first frame of the split
+        long pb0 = FUPS ? nb * Hs * Ws : p_begin + dyt * a.W + dxt;   // pixel the B resource starts at
+        if (pb0 < 0) pb0 = 0;
+        const long total_src = FUPS ? (a.M / frame_px) * Hs * Ws : a.M;
+        long nrec = (total_src - pb0) * ldx4;
+        if (nrec > 0x40000000L) nrec = 0x40000000L;
+        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + pb0 * a.ld_x), 0, (int)nrec, 0x00020000);
+        auto init_b = [&](long p, int& w, int& h, int& n, unsigned& off) __attribute__((always_inline)) {
+            const long q = p / a.W;
+            w = (int)(p - q * a.W);
+            const long fr = q / a.H;
+            h = (int)(q - fr * a.H);
+            n = (int)(fr - nb);
+            off = (FUPS ? (unsigned)((int)cib_e * 4) : (unsigned)((int)(p + dyt * a.W + dxt - pb0) * ldx4 + (int)cib_e * 4)) +
+                  tail_flag_b;
+        };
+        init_b(p_begin + br, bw0, bh0, bn0, boff0);
+        init_b(p_begin + br + BPASS, bw1, bh1, bn1, boff1);
+    }
+    auto fast_b = [&](int& w, int& h, int& n, unsigned& off, float4& v) __attribute__((always_inline)) {
+        const bool bad = (h == hbad) | (w == wbad);
+        unsigned o = off;
+        if constexpr (FUPS)
+            o += (unsigned)(((n * Hs + ((h + dyt) >> 1)) * Ws + ((w + dxt) >> 1)) * ldx4);
+        o |= bad ? 0x40000000u : 0u;
+        v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsb, o, 0, 0));
+        if constexpr (!FUPS) off += (unsigned)(BK * ldx4);
+        // 16 pixels ahead as (sw, sh, sn) columns / rows / frames (host: W >= 16 -> (16,0,0); W | 16 -> rows or whole
+        // frames), each with at most one wrap
+        w += a.sw;
+        const bool ww = w >= a.W;
+        w -= ww ? a.W : 0;
+        h += a.sh + (ww ? 1 : 0);
+        const bool hw = h >= a.H;
+        h -= hw ? a.H : 0;
+        if constexpr (FUPS) n += a.sn + (hw ? 1 : 0);
+    };
     auto load_step = [&](long p0) __attribute__((always_inline)) {
-        const unsigned pa = (unsigned)p0 + ar, pb = (unsigned)p0 + br;
-        load_a(pa, ra0, ta0);
-        if constexpr (RA > 1) load_a(pa + APASS, ra1, ta1);
-        load_b(pb, rb0, tb0);
-        if constexpr (RB > 1) load_b(pb + BPASS, rb1, tb1);
+        if constexpr (MODE != 0) {
+            ra0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff0, 0, 0));
+            aoff0 += (unsigned)(BK * ldy4);
+            if constexpr (RA > 1) {
+                ra1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff1, 0, 0));
+                aoff1 += (unsigned)(BK * ldy4);
+            }
+            fast_b(bw0, bh0, bn0, boff0, rb0);
+            if constexpr (RB > 1) fast_b(bw1, bh1, bn1, boff1, rb1);
+        } else {
+            const unsigned pa = (unsigned)p0 + ar, pb = (unsigned)p0 + br;
+            load_a(pa, ra0, ta0);
+            if constexpr (RA > 1) load_a(pa + APASS, ra1, ta1);
+            load_b(pb, rb0, tb0);
+            if constexpr (RB > 1) load_b(pb + BPASS, rb1, tb1);
+        }
     };
     auto masked = [&](float4 v, int tl) __attribute__((always_inline)) {
+        if constexpr (MODE != 0) return v;
         v.x = tl < 1 ? 0.f : v.x;
         v.y = tl < 2 ? 0.f : v.y;
         v.z = tl < 3 ? 0.f : v.z;
@@ -1860,9 +1930,11 @@ size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout,
     return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
 }
 
-int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
+int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
                      int ld_dy, int Cout, float* dw, int Cin_total, int c_start, int N, int Ho, int Wo, float* ws,
                      size_t ws_floats, void* stream) {
+    MNK_REQUIRE(flags >= 0 && flags <= 3);
+    const int ups = flags & MNK_CONV_UPSAMPLED, clean = (flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
     MNK_REQUIRE(x && dy && dw && N > 0 && Ho > 0 && Wo > 0 && C > 0 && Cout > 0 && kh > 0 && kw > 0 && pad >= 0);
     MNK_REQUIRE(Ho == Hi + 2 * pad - kh + 1 && Wo == Wi + 2 * pad - kw + 1);
     MNK_REQUIRE(ld_x >= C && ld_dy % 4 == 0 && ld_dy >= Cout);
@@ -1897,20 +1969,48 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int ups, int Hi, int Wi, i
         g.gn = tp.gn;
         g.part = ws;
         g.xcd = g_xcd_remap;
+        g.clean = clean;
         fast_div_consts((unsigned)W, &g.mulW, &g.shW);
         fast_div_consts((unsigned)H, &g.mulH, &g.shH);
         hipStream_t st = (hipStream_t)stream;
         dim3 grid(tp.gm, tp.gn * ntaps, tp.splits);
         {
             ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)g.M * Cout * (double)ntaps * C);
+            // fast loader: 3x3 pad 1, clean pads, rows of >= 16 pixels, split ranges inside the 2^30-byte buffer window
+            const long span_a = tp.pix_per_split * (long)ld_dy * 4, span_b = (tp.pix_per_split + 2L * W + 2 * BK) * ld_x * 4;
+            bool walk = true;          // can a 16-pixel step be walked as columns / rows / frames with single wraps?
+            g.sw = BK;
+            g.sh = g.sn = 0;
+            if (W < BK) {
+                g.sw = 0;
+                const int r = BK / W;
+                if (BK % W != 0)
+                    walk = false;
+                else if (r < H)
+                    g.sh = r;
+                else if (r % H == 0)
+                    g.sn = r / H;
+                else
+                    walk = false;
+            }
+            const int mode = (g_fast_loader && clean && kh == 3 && kw == 3 && pad == 1 && walk && span_a < (1L << 29) &&
+                              span_b < (1L << 29) && (!ups || (long)N * (Hi / 2) * (Wi / 2) * ld_x * 4 < (1L << 29)))
+                                 ? (ups ? 2 : 1) : 0;
+#define MNK_WTAP(...)                                                                                            \
+    do {                                                                                                         \
+        if (mode == 1) hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<__VA_ARGS__, 1>), grid, dim3(256), 0, st, g);      \
+        else if (mode == 2) hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<__VA_ARGS__, 2>), grid, dim3(256), 0, st, g); \
+        else hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<__VA_ARGS__, 0>), grid, dim3(256), 0, st, g);                \
+    } while (0)
             if (tp.bm == 128 && tp.bn == 128)
-                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
+                MNK_WTAP(128, 128, 2, 2);
             else if (tp.bm == 128)
-                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, g);
+                MNK_WTAP(128, 64, 2, 2);
             else if (tp.bm == 64)
-                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<64, 128, 1, 4>), grid, dim3(256), 0, st, g);
+                MNK_WTAP(64, 128, 1, 4);
             else
-                hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<32, 128, 1, 4>), grid, dim3(256), 0, st, g);
+                MNK_WTAP(32, 128, 1, 4);
+#undef MNK_WTAP
         }
         {
             ProfScope prof(K_CONV_REDUCE, st, (double)(tp.splits + 1) * ntaps * Cout * C * 4);
@@ -2130,9 +2230,9 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
     return mnk_conv2d_wgrad_workspace_floats(N, H, W, C, Cout, 3, 3, 1);
 }
-int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int ups, const float* dy, int ld_dy, int Cout, float* dw,
+int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int flags, const float* dy, int ld_dy, int Cout, float* dw,
                       int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream) {
-    return mnk_conv2d_wgrad(x, ld_x, C, ups, H, W, 3, 3, 1, dy, ld_dy, Cout, dw, Cin_total, c_start, N, H, W, ws, ws_floats,
+    return mnk_conv2d_wgrad(x, ld_x, C, flags, H, W, 3, 3, 1, dy, ld_dy, Cout, dw, Cin_total, c_start, N, H, W, ws, ws_floats,
                             stream);
 }
 }

@@ -269,8 +269,8 @@ class Conv3x3Fn(torch.autograd.Function):
                     continue
                 nws = _query("mnk_conv3x3_wgrad_workspace_floats", n, h, w, cc, cout)
                 ws = SCRATCH.get("ws", nws, dy) if nws else None
-                _call("mnk_conv3x3_wgrad", dy, _p(src), src.shape[-1], cc, int(ups), _p(dy), ld_dy, cout, _p(dw), cin, cs,
-                      n, h, w, _p(ws), nws)
+                _call("mnk_conv3x3_wgrad", dy, _p(src), src.shape[-1], cc, int(ups) | 2, _p(dy), ld_dy, cout, _p(dw), cin,
+                      cs, n, h, w, _p(ws), nws)      # | 2: MNK_CONV_CLEAN_PADS (x and dy are acts of this module)
         db = None
         if has_bias and ctx.needs_input_grad[3]:
             slot, _DY_SUMS[0] = _DY_SUMS[0], None

@@ -132,8 +132,21 @@ HALO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CASES + HALO_CASES)
-def test_conv3x3_wgrad(be, case):
+# tap-major kernel through the fast loader (rows of >= 16 pixels): tiles 128x128 / 128x64 / 64x128 / 32x128, up-sampled
+# sources, several frames per split and splits that end inside a row / inside a frame
+WFAST_CASES = [
+    (3, 16, 16, 130, 0, 140, 0, False, False),
+    (2, 32, 16, 20, 0, 136, 1, False, False),
+    (2, 16, 48, 80, 0, 40, 1, False, False),
+    (3, 6, 20, 72, 0, 24, 0, False, False),
+]
+
+
+@pytest.mark.parametrize("clean", [False, True])
+@pytest.mark.parametrize("case", CASES + HALO_CASES + WFAST_CASES)
+def test_conv3x3_wgrad(be, case, clean):
+    """clean = False: NaN pad channels in x must be ignored (generic loaders); clean = True: MNK_CONV_CLEAN_PADS, zero
+    pads -> the buffer-load loader of the tap-major kernel where the shape allows it (W >= 16)."""
     n, h, w, c0, c1, cout, ups, _, _ = case
     x0, x1, wt, b, r = _inputs(case)
     g = torch.Generator().manual_seed(6)
@@ -146,11 +159,11 @@ def test_conv3x3_wgrad(be, case):
     DY = be.t(to_nhwc(dy))
     DW = be.empty(cout, c0 + c1, 3, 3)
     for src, c_start, c_cnt in ((x0, 0, c0),) + (((x1, c0, c1),) if c1 else ()):
-        X = be.t(to_nhwc(src, pad_value=float("nan")))
+        X = be.t(to_nhwc(src, pad_value=0.0 if clean else float("nan")))
         nws = be.query("mnk_conv3x3_wgrad_workspace_floats", n, h, w, c_cnt, cout)
         ws = be.empty(max(nws, 1))
-        be.call("mnk_conv3x3_wgrad", X, X.shape[-1], c_cnt, ups, DY, DY.shape[-1], cout, DW, c0 + c1, c_start, n, h, w,
-                ws, nws)
+        be.call("mnk_conv3x3_wgrad", X, X.shape[-1], c_cnt, int(ups) | (2 if clean else 0), DY, DY.shape[-1], cout, DW,
+                c0 + c1, c_start, n, h, w, ws, nws)
     be.sync()
     assert relerr(DW.cpu(), wd.grad) < 2e-6
 

@@ -66,7 +66,7 @@ def main():
             ws = torch.empty(max(nws, 1), device=dev)
 
             def wg():
-                ops._call("mnk_conv3x3_wgrad", dy, x.data_ptr(), x.shape[-1], cin, int(ups), dy.data_ptr(), dy.shape[-1], cout,
+                ops._call("mnk_conv3x3_wgrad", dy, x.data_ptr(), x.shape[-1], cin, int(ups) | 2, dy.data_ptr(), dy.shape[-1], cout,
                           dw.data_ptr(), cin, 0, frames, h, w, ws.data_ptr(), nws)
             t_w = timeit(wg, args.iters)
             seen[key] = (fl, t_f, t_d, t_w)
