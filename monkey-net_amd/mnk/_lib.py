@@ -57,6 +57,13 @@ class Library:
                 "libmonkeynet_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or monkey-net_amd/csrc/build.sh).  There is no CPU fallback." % path)
         self.path = path
+        # PyTorch-ROCm ships its own libamdhip64: load it first so that this library binds to the same HIP runtime as
+        # the tensors it is handed (loading the system runtime first leaves two runtimes in the process, and launches
+        # from the second one fail with "no ROCm-capable device is detected")
+        try:
+            import torch  # noqa: F401
+        except ImportError:  # pragma: no cover - the C-ABI itself does not need torch
+            pass
         self.cdll = ctypes.CDLL(path)
         self.protos = parse_header()
         for name, (restype, argtypes, _) in self.protos.items():
