@@ -59,7 +59,16 @@ struct ConvArgs {
     float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
     int xcd;           // re-chunk the launch order per XCD (xcd_tile)
     int clean;         // the sources' pad channels [C, ld) hold zeros (finite values): the 3x3 fast loader may be used
+    unsigned mulW, shW, mulH, shH;   // division of an output pixel index (< 2^31) by W and H (fast_div)
 };
+
+struct TrueTag { static constexpr bool value = true; };
+struct FalseTag { static constexpr bool value = false; };
+
+// n / d for n < 2^31 with host-made constants (fast_div_consts): mulhi + shift, or a shift alone when mul == 0
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned sh) {
+    return mul ? __umulhi(n, mul) >> sh : n >> sh;
+}
 
 // Workgroups are handed to the 8 XCDs round-robin in launch order (x fastest), and every XCD has its own L2: with the
 // plain mapping each XCD touches every weight tile and every pixel tile of a layer, so both operands cross the fabric
@@ -100,12 +109,12 @@ struct ActLoader {
         wmax = a.Wi - 1;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            long m = m0 + lrow + 64 * j;
-            if (m > a.M - 1) m = a.M - 1;
-            pw[j] = (int)(m % a.W);
-            const long tt = m / a.W;
-            ph[j] = (int)(tt % a.H);
-            prow[j] = (int)(tt / a.H) * Hs * Ws;
+            long ml = m0 + lrow + 64 * j;
+            if (ml > a.M - 1) ml = a.M - 1;
+            const unsigned m = (unsigned)ml, tt = fast_div(m, a.mulW, a.shW), fr = fast_div(tt, a.mulH, a.shH);
+            pw[j] = (int)(m - tt * (unsigned)a.W);
+            ph[j] = (int)(tt - fr * (unsigned)a.H);
+            prow[j] = (int)fr * Hs * Ws;
             unsigned mk = 0;
             for (int y = 0; y < khh; ++y) {
                 const int hh = ph[j] + y - a.pad;
@@ -184,9 +193,9 @@ struct ActLoader3 {
         lq4 = lq_ * 16;
         const int Hs = UPS ? a.Hi >> 1 : a.Hi;
         Ws = UPS ? a.Wi >> 1 : a.Wi;
-        long mb = m0 < a.M ? m0 : a.M - 1;
-        const long tb = mb / a.W;
-        const long rowidx0 = (tb / a.H) * Hs + ((int)(tb % a.H) >> (UPS ? 1 : 0));
+        const unsigned mb = (unsigned)(m0 < a.M ? m0 : a.M - 1), tb = fast_div(mb, a.mulW, a.shW),
+                       fb = fast_div(tb, a.mulH, a.shH);
+        const long rowidx0 = (long)fb * Hs + ((int)(tb - fb * (unsigned)a.H) >> (UPS ? 1 : 0));
         long pbase = rowidx0 * Ws - Ws - 1;
         if (pbase < 0) pbase = 0;
         r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x0 + pbase * a.ld0), 0, 0x40000000, 0x00020000);
@@ -194,12 +203,11 @@ struct ActLoader3 {
                                                0x00020000);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            long m = m0 + lrow + 64 * j;
-            if (m > a.M - 1) m = a.M - 1;
-            const int w = (int)(m % a.W);
-            const long tt = m / a.W;
-            const int h = (int)(tt % a.H);
-            const long rel = ((tt / a.H) * Hs + (h >> (UPS ? 1 : 0))) * Ws + (w >> (UPS ? 1 : 0)) - pbase;
+            long ml = m0 + lrow + 64 * j;
+            if (ml > a.M - 1) ml = a.M - 1;
+            const unsigned m = (unsigned)ml, tt = fast_div(m, a.mulW, a.shW), fr = fast_div(tt, a.mulH, a.shH);
+            const int w = (int)(m - tt * (unsigned)a.W), h = (int)(tt - fr * (unsigned)a.H);
+            const long rel = ((long)fr * Hs + (h >> (UPS ? 1 : 0))) * Ws + (w >> (UPS ? 1 : 0)) - pbase;
             b0[j] = (unsigned)(rel * a.ld0 * 4);
             b1[j] = (unsigned)(rel * a.ld1 * 4);
             unsigned mk = 0;
@@ -401,9 +409,12 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     // bias is fetched once per column, residual values are fetched as a batch before the stores (no per-element
     // load -> wait -> store chains), stores are predicated.
     const bool split_out = a.splits > 1;
-    const long ldo = split_out ? (long)a.ldw : (long)a.ld_y;
+    const unsigned ldo = split_out ? (unsigned)a.ldw : (unsigned)a.ld_y;          // 32-bit element offsets (host check)
     float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
     const int co_lim = split_out ? a.ldw : a.ld_y;
+    const bool use_res = !split_out && a.residual;
+    const bool full = m0 + BM <= a.M;             // every row of the tile is a real pixel: no per-row guards
+    const unsigned mrow0 = (unsigned)m0 + wm * (BM / WM) + 4 * fk, Mu = (unsigned)a.M;
     int cov[TN];
     float bv[TN], s1[TN], s2[TN];
 #pragma unroll
@@ -412,31 +423,45 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
         bv[j] = (!split_out && a.bias && cov[j] < a.Cout) ? a.bias[cov[j]] : 0.f;
         s1[j] = s2[j] = 0.f;
     }
+    auto emit = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = cov[j];
-            const bool c_real = co < a.Cout, c_store = co < co_lim;
-            const long mbase = m0 + wm * (BM / WM) + 32 * i + 4 * fk;
-            float rv[16];
+            for (int j = 0; j < TN; ++j) {
+                const int co = cov[j];
+                const bool c_real = co < a.Cout, c_store = co < co_lim;
+                const unsigned mb = mrow0 + 32 * i;
+                const unsigned off0 = mb * ldo + (unsigned)co, roff0 = mb * (unsigned)a.ld_res + (unsigned)co;
+                if (c_store) {
+                    float rv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = mbase + (r & 3) + 8 * (r >> 2);
-                rv[r] = (!split_out && a.residual && c_real && m < a.M) ? a.residual[m * a.ld_res + co] : 0.f;
-            }
+                    for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+                    if (use_res && c_real) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = mbase + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r];
-                if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
-                if (c_store && m < a.M) {
-                    obase[m * ldo + co] = v;
-                    s1[j] += v;
-                    s2[j] = fmaf(v, v, s2[j]);
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned ro = (r & 3) + 8 * (r >> 2);
+                            if (FULL || mb + ro < Mu) rv[r] = a.residual[roff0 + ro * (unsigned)a.ld_res];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned ro = (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r];
+                        if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
+                        if (FULL || mb + ro < Mu) {
+                            obase[off0 + ro * ldo] = v;
+                            s1[j] += v;
+                            s2[j] = fmaf(v, v, s2[j]);
+                        }
+                    }
                 }
             }
-        }
+    };
+    if (full)
+        emit(TrueTag{});
+    else
+        emit(FalseTag{});
     // ---- fused BatchNorm statistics of the tensor just written (sync_batchnorm/batchnorm.py:60-62): per-block
     // column sums -> stats[blockIdx.x][2][ld_y]; the tiny final reduction over blocks is mnk_bn_stats_finish.
     if (a.stats && !split_out) {
@@ -558,37 +583,51 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     if (s < s_end) mfma_step((s - s_begin) & 1);
     __syncthreads();                          // the epilogue reuses As for the column sums
     const bool split_out = a.splits > 1;
-    const long ldo = split_out ? (long)a.ldw : (long)a.ld_y;
+    const unsigned ldo = split_out ? (unsigned)a.ldw : (unsigned)a.ld_y;          // 32-bit element offsets (host check)
     float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
     const int co_lim = split_out ? a.ldw : a.ld_y;
+    const bool use_res = !split_out && a.residual;
+    const bool full = m0 + BM <= a.M;
+    const unsigned mrow0 = (unsigned)m0 + wave * 32 + 4 * fk, Mu = (unsigned)a.M;
     float s1[TN], s2[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        s1[j] = s2[j] = 0.f;
-        const int co = n0 + 16 * j + fi;
-        const bool c_real = co < a.Cout, c_store = co < co_lim;
-        const float bv = (!split_out && a.bias && c_real) ? a.bias[co] : 0.f;
+    for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    auto emit = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long mbase = m0 + wave * 32 + 16 * i + 4 * fk;
-            float rv[4];
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + 16 * j + fi;
+            const bool c_real = co < a.Cout, c_store = co < co_lim;
+            const float bv = (!split_out && a.bias && c_real) ? a.bias[co] : 0.f;
+            if (c_store) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                rv[r] = (!split_out && a.residual && c_real && mbase + r < a.M) ? a.residual[(mbase + r) * a.ld_res + co]
-                                                                             : 0.f;
+                for (int i = 0; i < TM; ++i) {
+                    const unsigned mb = mrow0 + 16 * i;
+                    const unsigned off0 = mb * ldo + (unsigned)co, roff0 = mb * (unsigned)a.ld_res + (unsigned)co;
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (use_res && c_real) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = mbase + r;
-                float v = acc[i][j][r];
-                if (!split_out) v = c_real ? (v + bv) + rv[r] : 0.f;
-                if (c_store && m < a.M) {
-                    obase[m * ldo + co] = v;
-                    s1[j] += v;
-                    s2[j] = fmaf(v, v, s2[j]);
+                        for (int r = 0; r < 4; ++r)
+                            if (FULL || mb + r < Mu) rv[r] = a.residual[roff0 + r * (unsigned)a.ld_res];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r];
+                        if (!split_out) v = c_real ? (v + bv) + rv[r] : 0.f;
+                        if (FULL || mb + r < Mu) {
+                            obase[off0 + r * ldo] = v;
+                            s1[j] += v;
+                            s2[j] = fmaf(v, v, s2[j]);
+                        }
+                    }
                 }
             }
         }
-    }
+    };
+    if (full)
+        emit(TrueTag{});
+    else
+        emit(FalseTag{});
     if (a.stats && !split_out) {
         float* red = &As[0][0][0];
 #pragma unroll
@@ -1090,9 +1129,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args 
         return v;
     };
     auto load_tile = [&](long tile) __attribute__((always_inline)) {
-        const int n = (int)(tile / a.tiles_per_img);
-        const int ti = (int)(tile - (long)n * a.tiles_per_img);
-        const int r0 = (ti / a.tiles_w) * 8, c0 = (ti % a.tiles_w) * 8;
+        const unsigned ut = (unsigned)tile;                        // total_tiles < 2^31 (host check)
+        const int n = (int)(ut / (unsigned)a.tiles_per_img);
+        const unsigned ti = ut - (unsigned)n * (unsigned)a.tiles_per_img, tr = ti / (unsigned)a.tiles_w;
+        const int r0 = (int)tr * 8, c0 = (int)(ti - tr * (unsigned)a.tiles_w) * 8;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int idx = t + 256 * j;
@@ -1228,10 +1268,6 @@ struct WgradTapArgs {
     int sw, sh, sn;      // fast path: one 16-pixel K step = sw columns + sh rows + sn frames
 };
 
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned mul, unsigned sh) {
-    return mul ? __umulhi(n, mul) >> sh : n >> sh;
-}
-
 // MODE 0: generic loader (any K x K, masks, clamps, magic-number division per row and step).  MODE 1 / 2: 3x3 pad 1 with
 // clean pad channels, W >= 16 (plain / x2 up-sampled source): raw buffer loads whose out-of-range lanes read zero --
 // dy rows beyond the split's pixel range fall off the end of the buffer, taps outside the image and float4s beyond
@@ -1313,11 +1349,10 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
         if (nrec > 0x40000000L) nrec = 0x40000000L;
         rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + pb0 * a.ld_x), 0, (int)nrec, 0x00020000);
         auto init_b = [&](long p, int& w, int& h, int& n, unsigned& off) __attribute__((always_inline)) {
-            const long q = p / a.W;
-            w = (int)(p - q * a.W);
-            const long fr = q / a.H;
-            h = (int)(q - fr * a.H);
-            n = (int)(fr - nb);
+            const unsigned up = (unsigned)p, q = fast_div(up, a.mulW, a.shW), fr = fast_div(q, a.mulH, a.shH);
+            w = (int)(up - q * (unsigned)a.W);
+            h = (int)(q - fr * (unsigned)a.H);
+            n = (int)((long)fr - nb);
             off = (FUPS ? (unsigned)((int)cib_e * 4) : (unsigned)((int)(p + dyt * a.W + dxt - pb0) * ldx4 + (int)cib_e * 4)) +
                   tail_flag_b;
         };
@@ -1649,7 +1684,7 @@ static int g_wgrad_n16 = env_int("MNK_WGRAD_N16", 1), g_wn16_target = env_int("M
 static NPlan make_nplan(int N, int H, int W, int Cout, int C, int ld_x) {
     NPlan p;
     p.use = g_wgrad_n16 && C <= 64 && Cout <= 64 && C >= g_wn16_minc && H % 8 == 0 && W % 8 == 0 && ld_x % 4 == 0 &&
-            ld_x >= round_up(C, 4);
+            ld_x >= round_up(C, 4) && (long)N * H * W < (1L << 31);
     if (!p.use) return p;
     p.gm = ceil_div(Cout, 48);
     p.gn = ceil_div(C, 48);
@@ -1850,6 +1885,9 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     a.pad = pad;
     a.Cout = Cout;
     a.M = (long)N * Ho * Wo;
+    MNK_REQUIRE(a.M < (1L << 31) && a.M * round_up(Cout, 16) < (1L << 32) && (!residual || a.M * ld_res < (1L << 32)));
+    fast_div_consts((unsigned)Wo, &a.mulW, &a.shW);
+    fast_div_consts((unsigned)Ho, &a.mulH, &a.shH);
     a.chunks = (a.C0p + a.C1p) / 16;
     Plan p = make_plan(a.M, Cout, a.chunks, ntaps);
     a.ksteps = p.ksteps;
