@@ -1460,19 +1460,31 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
     }
     if (p0 < p_end) mfma_step(it & 1);
 
-    // rows = co, cols = ci: 32 lanes write 128 consecutive bytes of the tap-major partial
+    // rows = co, cols = ci: 32 lanes write 128 consecutive bytes of the tap-major partial (32-bit offsets inside the
+    // tap plane, no per-row guards when the whole co tile exists)
     float* outp = a.part + ((long)split * a.ntaps + tap) * a.Cout * a.C;
+    const unsigned Cu = (unsigned)a.C, corow0 = (unsigned)co0 + wm * (32 * TM) + 4 * fk;
+    auto emit = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ci = ci0 + wn * (32 * TN) + 32 * j + fi;
+            for (int j = 0; j < TN; ++j) {
+                const unsigned ci = (unsigned)ci0 + wn * (32 * TN) + 32 * j + fi;
+                const unsigned cb = corow0 + 32 * i, off0 = cb * Cu + ci;
+                if (ci < Cu) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * (32 * TM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (co < a.Cout && ci < a.C) outp[(long)co * a.C + ci] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned ro = (r & 3) + 8 * (r >> 2);
+                        if (FULL || cb + ro < (unsigned)a.Cout) outp[off0 + ro * Cu] = acc[i][j][r];
+                    }
+                }
             }
-        }
+    };
+    if (co0 + BM <= a.Cout)
+        emit(TrueTag{});
+    else
+        emit(FalseTag{});
 }
 
 // dw[co][(c_start + ci) * ntaps + tap] = sum_s part[s][tap][co][ci]: one block per (64-channel ci tile, co row);
