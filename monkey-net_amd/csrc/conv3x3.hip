@@ -62,6 +62,16 @@ struct ConvArgs {
     unsigned mulW, shW, mulH, shH;   // division of an output pixel index (< 2^31) by W and H (fast_div)
 };
 
+// buffer resource from values the compiler cannot prove wave-uniform (e.g. derived from a 64-bit division): pin the
+// pointer into scalar registers, otherwise every buffer load becomes a readfirstlane "waterfall" loop
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, unsigned num_records) {
+    unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    const unsigned nr = __builtin_amdgcn_readfirstlane((int)num_records);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long)hi << 32) | lo), 0, (int)nr, 0x00020000);
+}
+
 struct TrueTag { static constexpr bool value = true; };
 struct FalseTag { static constexpr bool value = false; };
 
@@ -1335,8 +1345,7 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
     const int ldy4 = a.ld_dy * 4, ldx4 = a.ld_x * 4;
     const int hbad = dyt < 0 ? 0 : (dyt > 0 ? a.H - 1 : -1), wbad = dxt < 0 ? 0 : (dxt > 0 ? a.W - 1 : -1);
     if constexpr (MODE != 0) {
-        rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + p_begin * a.ld_dy), 0, (int)((p_end - p_begin) * ldy4),
-                                                0x00020000);
+        rsa = uniform_rsrc(a.dy + p_begin * a.ld_dy, (unsigned)((p_end - p_begin) * ldy4));
         const unsigned tail_flag_a = tail_a > 0 ? 0u : 0x40000000u, tail_flag_b = tail_b > 0 ? 0u : 0x40000000u;
         aoff0 = (unsigned)(ar * ldy4 + (int)coa_e * 4) + tail_flag_a;
         aoff1 = aoff0 + (unsigned)(APASS * ldy4);
@@ -1347,7 +1356,7 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
         const long total_src = FUPS ? (a.M / frame_px) * Hs * Ws : a.M;
         long nrec = (total_src - pb0) * ldx4;
         if (nrec > 0x40000000L) nrec = 0x40000000L;
-        rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + pb0 * a.ld_x), 0, (int)nrec, 0x00020000);
+        rsb = uniform_rsrc(a.x + pb0 * a.ld_x, (unsigned)nrec);
         auto init_b = [&](long p, int& w, int& h, int& n, unsigned& off) __attribute__((always_inline)) {
             const unsigned up = (unsigned)p, q = fast_div(up, a.mulW, a.shW), fr = fast_div(q, a.mulH, a.shH);
             w = (int)(up - q * (unsigned)a.W);
@@ -1420,18 +1429,27 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
 
     const int fi = lane & 31, fk = lane >> 5;
     auto mfma_step = [&](int buf) __attribute__((always_inline)) {
+        // fragments are read two pixel pairs ahead of the MFMAs that use them (sched_group_barrier pins the order the
+        // source states: without it the scheduler reads each pair right before its MFMAs and waits for the LDS every time)
+        float fa[BK / 2][TM], fb[BK / 2][TN];
+        auto rd = [&](int e) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[e][i] = As[buf][2 * e + fk][wm * (32 * TM) + 32 * i + fi];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[e][j] = Bs[buf][2 * e + fk][wn * (32 * TN) + 32 * j + fi];
+        };
+        rd(0);
+        rd(1);
 #pragma unroll
         for (int e = 0; e < BK / 2; ++e) {
-            float fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = As[buf][2 * e + fk][wm * (32 * TM) + 32 * i + fi];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = Bs[buf][2 * e + fk][wn * (32 * TN) + 32 * j + fi];
+            if (e + 2 < BK / 2) rd(e + 2);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e][i], fb[e][j], acc[i][j], 0, 0, 0);
+            MNK_SCHED_GROUP(0x100, TM + TN);      // DS reads of pair e + 2
+            MNK_SCHED_GROUP(0x008, TM * TN);      // MFMAs of pair e
         }
     };
 

@@ -12,6 +12,13 @@
 #define MNK_KEEP_SGPR(p) asm volatile("" : "+s"(p))
 #endif
 
+// instruction-scheduling hint (no-op on the emulator): the next `n` instructions of class `mask` form a group, in order
+#ifdef HIPEMU
+#define MNK_SCHED_GROUP(mask, n) ((void)0)
+#else
+#define MNK_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
+
 namespace mnk {
 
 void set_error(const char* fmt, ...);
