@@ -173,9 +173,6 @@ struct ActLoader {
     // row j on its way to LDS: pad channels of the producer may hold anything, taps outside the image are zero
     __device__ __forceinline__ float4 masked(int j) const {
         float4 v = ra[j];
-#ifdef MNK_EXPERIMENT_NOMASK
-        return v;
-#endif
         v.x = tail[j] < 1 ? 0.f : v.x;
         v.y = tail[j] < 2 ? 0.f : v.y;
         v.z = tail[j] < 3 ? 0.f : v.z;
@@ -278,13 +275,6 @@ template <int RA, int MODE> struct LoaderSel { typedef ActLoader<RA> type; };
 template <int RA> struct LoaderSel<RA, 1> { typedef ActLoader3<RA, false> type; };
 template <int RA> struct LoaderSel<RA, 2> { typedef ActLoader3<RA, true> type; };
 
-// timing experiment only (wrong results): -DMNK_EXPERIMENT_NOSYNC drops the per-step barrier of the igemm main loop
-#ifdef MNK_EXPERIMENT_NOSYNC
-#define MNK_LOOP_SYNC() ((void)0)
-#else
-#define MNK_LOOP_SYNC() __syncthreads()
-#endif
-
 #ifndef MNK_IGEMM_OCC
 #define MNK_IGEMM_OCC 3                       // waves per SIMD = blocks per CU the register budget is held to
 #endif
@@ -345,30 +335,16 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     const int fi = lane & 31, fk = lane >> 5;
     const int a_row0 = wm * (BM / WM) + fi, b_row0 = wn * (BN / WN) + fi;
 
-#ifdef MNK_EXPERIMENT_NOLDSREAD
-    float4 xfa[2][TM], xfb[2][TN];
-    for (int kh = 0; kh < 2; ++kh) {
-        for (int i = 0; i < TM; ++i) xfa[kh][i] = *reinterpret_cast<const float4*>(&As[0][a_row0 + 32 * i][kh * 8 + fk * 4]);
-        for (int j = 0; j < TN; ++j) xfb[kh][j] = *reinterpret_cast<const float4*>(&Bs[0][b_row0 + 32 * j][kh * 8 + fk * 4]);
-    }
-#endif
     auto mfma_step = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             float4 fa[TM], fb[TN];
-#ifdef MNK_EXPERIMENT_NOLDSREAD
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = xfa[kh][i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = xfb[kh][j];
-#else
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 fa[i] = *reinterpret_cast<const float4*>(&As[buf][a_row0 + 32 * i][kh * 8 + fk * 4]);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 fb[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_row0 + 32 * j][kh * 8 + fk * 4]);
-#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -392,18 +368,22 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     }
     __syncthreads();
     int s = s_begin;
+    for (; s + 3 < s_end; s += 2) {           // two steps per trip: the LDS buffer index is a compile-time constant
+        store_step(1);
+        load_step(s + 2);
+        mfma_step(0);
+        __syncthreads();
+        store_step(0);
+        load_step(s + 3);
+        mfma_step(1);
+        __syncthreads();
+    }
     for (; s + 2 < s_end; ++s) {
         const int buf = (s - s_begin) & 1;
-#ifndef MNK_EXPERIMENT_NOSTORE
         store_step(buf ^ 1);
-#endif
-#ifndef MNK_EXPERIMENT_NOLOAD
         load_step(s + 2);
-#endif
-#ifndef MNK_EXPERIMENT_NOMFMA
         mfma_step(buf);
-#endif
-        MNK_LOOP_SYNC();
+        __syncthreads();
     }
     if (s + 1 < s_end) {
         const int buf = (s - s_begin) & 1;
