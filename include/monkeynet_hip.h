@@ -150,6 +150,18 @@ int mnk_conv3x3_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, i
  * NULL.  The parameter changes every optimiser step (train.py:118,132), so nothing packed can be kept across steps. */
 int mnk_conv3x3_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d1, int Cout, int C0, int C1,
                          void* stream);
+/* The same for EVERY 3x3 layer of a model in one launch (a training iteration re-packs ~40 layers; one launch each is
+ * launch-bound): `descs_device` is a table of n descriptors in device memory, sorted by tile_begin, where layer i owns
+ * the blocks [tile_begin, tile_begin + tiles) with tiles = ((ceil16(C0) + ceil16(C1)) / 16) * ceil(Cout / 16);
+ * total_tiles = sum of tiles.  Pointers as for mnk_conv3x3_pack_all (wp_d0 / wp_d1 may be NULL). */
+typedef struct MnkPackDesc {
+    const float* w;
+    float* wp_fwd;
+    float* wp_d0;
+    float* wp_d1;
+    int Cout, C0, C1, tile_begin;
+} MnkPackDesc;
+int mnk_conv3x3_pack_multi(const MnkPackDesc* descs_device, int n, int total_tiles, void* stream);
 size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
 /* `stats_partial` (optional, mnk_conv3x3_stats_floats floats; only when that query is > 0, i.e. no split-K): the kernel
  * epilogue also emits per-block column sums / sums of squares of y -- the BatchNorm statistics of the following

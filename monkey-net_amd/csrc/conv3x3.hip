@@ -32,6 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+__device__ __forceinline__ int round_up16(int v) { return (v + 15) & ~15; }
+
 constexpr int BK = 16;        // K step (floats)
 constexpr int LDS_K = 20;     // padded LDS row (floats)
 
@@ -726,15 +728,14 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
 // 16 + 16 contiguous 16 * ntaps-float groups -- forward wf[co][chunk][tap][ci] and, for the same tile,
 // data-gradient wd[ci][chunk][ntaps-1-tap][co] -- so the parameter crosses HBM once and every access is coalesced.
 template <int NT>                                 // NT = ntaps when known at compile time (9: constant divisions), else 0
-__global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ w, float* __restrict__ wf,
-                                                       float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0,
-                                                       int C1, int C0p, int C1p, int ntaps_rt) {
-    __shared__ float T[16 * (16 * 17 + 1)];         // [16 co][16 ci][ntaps <= 16], padded strides (odd: no bank conflicts)
+__device__ __forceinline__ void pack_tile(float* T, const float* __restrict__ w, float* __restrict__ wf,
+                                          float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0, int C1,
+                                          int C0p, int C1p, int ntaps_rt, int cc, int cot) {
+    // T: LDS [16 co][16 ci][ntaps <= 16] with padded strides (odd: no bank conflicts); cc = forward chunk (source 0
+    // chunks, then source 1 chunks), cot = co tile (16 rows)
     const int ntaps = NT ? NT : ntaps_rt;
     const int ntp = ntaps | 1, cos = 16 * ntp + 1;
     const int chunks0 = C0p / 16, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
-    const int cc = blockIdx.x;                      // forward chunk (source 0 chunks, then source 1 chunks)
-    const int cot = blockIdx.y;                     // co tile (16 rows)
     const bool second = cc >= chunks0;
     const int Cs = second ? C1 : C0, cstart = second ? C0 : 0, lc = second ? cc - chunks0 : cc;
     const int ci0 = lc * 16, co0 = cot * 16, Cin = C0 + C1;
@@ -763,6 +764,34 @@ __global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__
             const int ci = ci0 + r;
             if (ci < Cs) wd[(((size_t)ci * dchunks + cot) * ntaps) * 16 + o] = T[k16 * cos + r * ntp + (ntaps - 1 - tap)];
         }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256) pack_all_kernel(const float* __restrict__ w, float* __restrict__ wf,
+                                                       float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0,
+                                                       int C1, int C0p, int C1p, int ntaps_rt) {
+    __shared__ float T[16 * (16 * 17 + 1)];
+    pack_tile<NT>(T, w, wf, wd0, wd1, Cout, C0, C1, C0p, C1p, ntaps_rt, blockIdx.x, blockIdx.y);
+}
+
+// every 3x3 layer of a model in ONE launch: block b works on tile (b - tile_begin) of the layer whose
+// [tile_begin, tile_begin + tiles) range contains it (binary search over the descriptor table in device memory)
+__global__ void __launch_bounds__(256) pack_multi_kernel(const MnkPackDesc* __restrict__ descs, int n) {
+    __shared__ float T[16 * (16 * 17 + 1)];
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile_begin <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const MnkPackDesc d = descs[lo];
+    const int local = b - d.tile_begin;
+    const int C0p = round_up16(d.C0), C1p = d.C1 > 0 ? round_up16(d.C1) : 0, tiles_x = (C0p + C1p) / 16;
+    const int cot = local / tiles_x, cc = local - cot * tiles_x;
+    pack_tile<9>(T, d.w, d.wp_fwd, d.wp_d0, d.wp_d1, d.Cout, d.C0, d.C1, C0p, C1p, 9, cc, cot);
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------
@@ -1836,6 +1865,15 @@ int mnk_conv2d_pack_all(const float* w, float* wp_fwd, float* wp_d0, float* wp_d
         hipLaunchKernelGGL(pack_all_kernel<9>, grid, dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0, C1, C0p, C1p, ntaps);
     else
         hipLaunchKernelGGL(pack_all_kernel<0>, grid, dim3(256), 0, s, w, wp_fwd, wp_d0, wp_d1, Cout, C0, C1, C0p, C1p, ntaps);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_conv3x3_pack_multi(const MnkPackDesc* descs_device, int n, int total_tiles, void* stream) {
+    MNK_REQUIRE(descs_device && n > 0 && total_tiles > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CONV_REDUCE, s, (double)total_tiles * 16 * 16 * 9 * 12);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(total_tiles), dim3(256), 0, s, descs_device, n);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

@@ -127,6 +127,7 @@ class TrainStep:
         d_params = list(self.discriminator.parameters())
         for p in d_params:
             p.requires_grad_(False)
+        mops.repack_registered()           # every conv parameter seen so far: packed for this iteration in one launch
         try:
             out = self.gfull(x)
             loss_values = [v.mean() for v in out[:-2]]

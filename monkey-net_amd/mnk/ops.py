@@ -5,6 +5,10 @@ time axis D folded into N (frame = b*D + d) and the channel stride `ld` rounded 
 are zero).  The logical channel count travels next to the tensor.  PyTorch is used for memory, streams and the
 autograd tape only; every arithmetic step is a kernel launch through `mnk._lib` (no CPU / eager fallback).
 """
+import os
+import weakref
+
+import numpy as np
 import torch
 
 from . import _lib
@@ -13,6 +17,10 @@ from . import dist as mdist
 
 def ceil4(c):
     return (c + 3) // 4 * 4
+
+
+def ceil16(c):
+    return (c + 15) // 16 * 16
 
 
 def _p(t):
@@ -168,6 +176,87 @@ def _packed_fwd_weight(weight, cout, c0, c1):
     return wp
 
 
+class _PackEntry:
+    """Persistent packed copies (forward + data-gradient layouts) of one conv parameter used by training forwards."""
+    __slots__ = ("wref", "wptr", "meta", "wp", "wd", "stamp", "__weakref__")
+
+    def fresh(self, weight, meta, need):
+        return (self.wref() is weight and self.wptr == weight.data_ptr() and self.meta == meta
+                and self.stamp == (weight._version, _PACK_EPOCH[0])
+                and all(self.wd[i] is not None for i in (0, 1) if need[i]))
+
+
+_PACK_REG = {}                     # id(parameter) -> _PackEntry
+_PACK_TABLE = {"dirty": True, "descs": None, "n": 0, "tiles": 0, "entries": (), "keep": []}
+
+
+def _pack_entry(weight, cout, c0, c1, need):
+    """The (packed, up to date) registry entry of `weight`: packs with one per-layer launch unless the entry is fresh
+    (repack_registered() ran since the last optimiser step)."""
+    meta = (cout, c0, c1)
+    e = _PACK_REG.get(id(weight))
+    if e is not None and e.fresh(weight, meta, need):
+        return e
+    if e is None or e.wref() is not weight or e.wptr != weight.data_ptr() or e.meta != meta:
+        e = _PackEntry()
+        e.wref, e.wptr, e.meta, e.wd, e.stamp = weakref.ref(weight), weight.data_ptr(), meta, [None, None], None
+        e.wp = torch.empty(_query("mnk_conv3x3_packed_floats", cout, c0, c1), dtype=torch.float32, device=weight.device)
+        key = id(weight)
+        _PACK_REG[key] = e
+        weakref.finalize(weight, _drop_pack_entry, key, weakref.ref(e))
+        _PACK_TABLE["dirty"] = True
+    for i, cc in enumerate((c0, c1)):
+        if need[i] and e.wd[i] is None:
+            e.wd[i] = torch.empty(_query("mnk_conv3x3_packed_floats", cc, cout, 0), dtype=torch.float32,
+                                  device=weight.device)
+            _PACK_TABLE["dirty"] = True
+    _call("mnk_conv3x3_pack_all", weight, _p(weight), _p(e.wp), _p(e.wd[0]), _p(e.wd[1]), cout, c0, c1)
+    e.stamp = None            # only repack_registered() vouches for freshness: a user-owned loop packs on every call
+    return e
+
+
+def _drop_pack_entry(key, eref):
+    if _PACK_REG.get(key) is eref():
+        _PACK_REG.pop(key, None)
+        _PACK_TABLE["dirty"] = True
+
+
+def repack_registered():
+    """Re-pack EVERY registered conv parameter in one launch (mnk_conv3x3_pack_multi) -- the start of a training
+    iteration (mnk.engine.TrainStep): ~40 per-layer pack launches become one.  Parameters first seen later in the
+    iteration (and everything, when called under stream capture before the table exists) fall back to per-layer packs."""
+    t = _PACK_TABLE
+    if os.environ.get("MNK_PACK_MULTI", "1") == "0":
+        return False
+    if t["dirty"]:
+        entries = [e for e in _PACK_REG.values() if e.wref() is not None and e.wptr == e.wref().data_ptr()]
+        if not entries:
+            return False
+        dev = entries[0].wp.device
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return False                     # building the table needs a host-to-device copy
+        entries = [e for e in entries if e.wp.device == dev]
+        rec = np.zeros(len(entries), dtype=np.dtype([("p", "<u8", 4), ("i", "<i4", 4)]))
+        tiles = 0
+        for k, e in enumerate(entries):
+            cout, c0, c1 = e.meta
+            rec["p"][k] = (e.wptr, e.wp.data_ptr(), e.wd[0].data_ptr() if e.wd[0] is not None else 0,
+                           e.wd[1].data_ptr() if e.wd[1] is not None else 0)
+            rec["i"][k] = (cout, c0, c1, tiles)
+            tiles += ((ceil16(c0) + (ceil16(c1) if c1 else 0)) // 16) * ((cout + 15) // 16)
+        descs = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev)
+        t["keep"].append(descs)              # captured graphs hold raw pointers to earlier tables: never free them
+        t.update(dirty=False, descs=descs, n=len(entries), tiles=tiles, entries=tuple(entries))
+    if not t["n"]:
+        return False
+    _call("mnk_conv3x3_pack_multi", t["descs"], _p(t["descs"]), t["n"], t["tiles"])
+    for e in t["entries"]:
+        w = e.wref()
+        if w is not None:
+            e.stamp = (w._version, _PACK_EPOCH[0])
+    return True
+
+
 def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats=False):
     """One conv launch.  With want_stats the BatchNorm sums of the output come out of the conv epilogue (finished by a
     tiny second-stage kernel) instead of a separate pass over y; returns (y, sums or None)."""
@@ -222,16 +311,11 @@ class Conv3x3Fn(torch.autograd.Function):
         n, hs, ws_, _ = x0.shape
         h, w = (hs * 2, ws_ * 2) if ups else (hs, ws_)
         if track:
-            # a backward will follow: the parameter changes every step -> pack now, forward + the data-gradient
-            # layouts the backward will need, in one launch
-            wp = torch.empty(_query("mnk_conv3x3_packed_floats", cout, c0, c1), dtype=torch.float32, device=x0.device)
-            wd = [None, None]
-            for i, cc in enumerate((c0, c1)):
-                if cc and ctx.needs_input_grad[i]:
-                    wd[i] = torch.empty(_query("mnk_conv3x3_packed_floats", cc, cout, 0), dtype=torch.float32,
-                                        device=x0.device)
-            _call("mnk_conv3x3_pack_all", weight, _p(weight), _p(wp), _p(wd[0]), _p(wd[1]), cout, c0, c1)
-            ctx.wd = wd
+            # a backward will follow: the parameter changes every step -> packed per iteration (forward + the
+            # data-gradient layouts the backward will need), by repack_registered() or one launch here
+            need = [bool(cc and ctx.needs_input_grad[i]) for i, cc in enumerate((c0, c1))]
+            e = _pack_entry(weight, cout, c0, c1, need)
+            wp, ctx.wd = e.wp, list(e.wd)
         else:
             wp = _packed_fwd_weight(weight, cout, c0, c1)
         y, sums = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats)

@@ -178,6 +178,73 @@ def test_weights_updated_without_version_bump_are_seen(be):
     assert ops._PACK_EPOCH[0] > e0
 
 
+def test_repack_registered_serves_training_forwards(be):
+    """mnk.ops.repack_registered() (start of a mnk.engine.TrainStep iteration) packs every conv parameter seen so far
+    in one launch; training forwards then use those buffers without a per-layer pack -- until the next optimiser step.
+    Forward AND both gradients must match torch on the re-packed weights."""
+    from mnk import ops
+    import torch.nn.functional as F
+    torch.manual_seed(6)
+    ws = [torch.nn.Parameter(be.t(torch.randn(co, ci, 1, 3, 3) * 0.2)) for co, ci in ((9, 6), (5, 9), (20, 5))]
+    x = torch.rand(2, 6, 1, 8, 8)
+
+    def run():
+        a = ops.to_act(be.t(x)).requires_grad_(True)
+        h, c = a, 6
+        for w in ws:
+            h, _ = ops.conv3x3(h, c, w)
+            c = w.shape[0]
+        (h * h).sum().backward()
+        out = (ops.from_act(h.detach(), c, 2).cpu(), a.grad.cpu().clone(), [w.grad.cpu().clone() for w in ws])
+        for w in ws:
+            w.grad = None
+        return out
+
+    def ref():
+        xr = x[:, :, 0].double().requires_grad_(True)
+        wr = [w.detach().cpu()[:, :, 0].double().requires_grad_(True) for w in ws]
+        h = xr
+        for w in wr:
+            h = F.conv2d(h, w, padding=1)
+        (h * h).sum().backward()
+        return h.detach(), xr.grad, [w.grad for w in wr]
+
+    def check(tag):
+        y, dx, dws = run()
+        ry, rdx, rdws = ref()
+        def rel(a, b):
+            return float((a - b).abs().max() / b.abs().max())
+        assert rel(y[:, :, 0], ry) < 1e-5, tag
+        assert rel(dx.permute(0, 3, 1, 2)[:, :6], rdx) < 1e-5, tag
+        for a, b in zip(dws, rdws):
+            assert rel(a[:, :, 0], b) < 1e-5, tag
+
+    launches = []
+    real = ops._call
+
+    def counting(name, *a, **k):
+        launches.append(name)
+        return real(name, *a, **k)
+
+    check("first use: per-layer packs register the parameters")
+    for w in ws:
+        w.data.mul_(-0.7)                      # a fused optimiser step: no version bump ...
+    ops.invalidate_packed_weights()            # ... but the step hook fires
+    ops._call = counting
+    try:
+        assert ops.repack_registered()
+        check("after repack_registered")
+        assert launches.count("mnk_conv3x3_pack_multi") == 1 and "mnk_conv3x3_pack_all" not in launches
+        del launches[:]
+        for w in ws:
+            w.data.add_(0.05)
+        ops.invalidate_packed_weights()        # stale again: without a repack every forward packs its own layer
+        check("stale entries fall back to per-layer packs")
+        assert launches.count("mnk_conv3x3_pack_all") == len(ws) and "mnk_conv3x3_pack_multi" not in launches
+    finally:
+        ops._call = real
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny2"])
 def test_pad_channels_are_written(be, name, monkeypatch):
     """The 3x3 fast loader (MNK_CONV_CLEAN_PADS) relies on every activation this package produces having ZERO pad
