@@ -118,6 +118,37 @@ def cpu_baseline(cfg, batch, size, steps):
                       "%d threads), %.2f s/iteration" % (steps, batch, cores, dt)}
 
 
+def graph_phase(args, rank, fallback, run, device):
+    """Multi-rank only: capture + time the hipGraph iteration under a deadline.  Returns the elapsed seconds of the K
+    timed replays, or None when any rank failed to capture.  If the phase does not finish within MNK_GRAPH_DEADLINE_S
+    (a collective stuck inside a replay cannot be recovered in-process), rank 0 prints the already measured eager line
+    and every rank leaves -- the bench never hangs on the optimisation."""
+    import threading
+
+    def expire():
+        sys.stderr.write("rank %d: hipGraph phase exceeded its deadline; reporting the eager measurement\n" % rank)
+        if rank == 0:
+            print(json.dumps(fallback))
+            sys.stdout.flush()
+        os._exit(0)
+
+    guard = threading.Timer(float(os.environ.get("MNK_GRAPH_DEADLINE_S", "150")), expire)
+    guard.daemon = True
+    guard.start()
+    dt, ok = None, 1
+    try:
+        dt = run()
+    except Exception as e:      # capture is an optimisation, never a requirement
+        sys.stderr.write("rank %d: hipGraph capture failed (%s: %s); keeping the eager measurement\n"
+                         % (rank, type(e).__name__, e))
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # the ranks must agree on which measurement is reported
+    all_ok = int(flag.item()) == 1
+    guard.cancel()
+    return dt if all_ok else None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,37 +174,52 @@ def main():
         if args.graph < 0 else bool(args.graph)
     src, drv = workload.synthetic_pair(args.batch, args.size, args.size, seed=1234 + rank)
     x = {"source": src.to(device), "video": drv.to(device)}
-    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
-    if use_graph:
-        try:
-            step.step(x)
-            torch.cuda.synchronize(device)
-        except Exception as e:   # capture is an optimisation, never a requirement
-            sys.stderr.write("hipGraph capture failed (%s: %s); running eager launches\n" % (type(e).__name__, e))
-            use_graph = False
-            torch.cuda.synchronize(device)
-            gen, disc, kpd = build_models(cfg, device)
-            step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
-    eager = step if not use_graph else engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+    dist_mode = world > 1 or force_dist
 
     def sync():
         torch.cuda.synchronize(device)
-        if world > 1 or force_dist:
+        if dist_mode:
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step.step(x)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step.step(x)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1 or force_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(st):
+        """W un-timed + exactly K timed iterations, barrier + synchronize on both sides, MAX over the ranks."""
+        for _ in range(args.warmup):
+            st.step(x)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            st.step(x)
+        sync()
+        dt = time.perf_counter() - t0
+        if dist_mode:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    if not dist_mode:
+        step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
+        if use_graph:
+            try:
+                step.step(x)
+                torch.cuda.synchronize(device)
+            except Exception as e:   # capture is an optimisation, never a requirement
+                sys.stderr.write("hipGraph capture failed (%s: %s); running eager launches\n" % (type(e).__name__, e))
+                use_graph = False
+                torch.cuda.synchronize(device)
+                gen, disc, kpd = build_models(cfg, device)
+                step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+        eager = step if not use_graph else engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+        elapsed = timed(step)
+        launch = "hipGraph replay" if use_graph else "eager"
+    else:
+        # several ranks: the eager iteration is measured FIRST (a complete, valid K-step measurement), then the iteration
+        # with its RCCL collectives is captured as a hipGraph and measured again under a deadline (below) -- a capture
+        # problem on some RCCL / driver combination costs the graph number, never the bench line
+        eager = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+        elapsed = timed(eager)
+        launch = "eager"
     ms_per_step = elapsed / args.steps * 1e3
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
@@ -238,12 +284,23 @@ def main():
             "config": {"workload": "%s model params @ %dx%d, batch %d/GPU, full train.py:110-136 iteration "
                                    "(G step + D step, 3x Adam)" % (args.config, args.size, args.size, args.batch),
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
-                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "launch": launch,
                        "hot_path_conv_gflop_fwd_per_pair": round(flops["total"] / 1e9, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
+    else:
+        out = None
+    if dist_mode and use_graph:
+        g_elapsed = graph_phase(args, rank, out, lambda: timed(
+            engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=True)), device)
+        if g_elapsed is not None and g_elapsed < elapsed and rank == 0:
+            out.update(value=round(global_batch * args.steps / g_elapsed, 2),
+                       ms_per_step=round(g_elapsed / args.steps * 1e3, 3))
+            out["config"]["launch"] = "hipGraph replay (RCCL collectives captured); eager: %.3f ms/step" % ms_per_step
+    if rank == 0:
         print(json.dumps(out))
-    if world > 1 or force_dist:
+        sys.stdout.flush()
+    if dist_mode:
         dist.destroy_process_group()
 
 
