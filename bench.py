@@ -118,6 +118,26 @@ def cpu_baseline(cfg, batch, size, steps):
                       "%d threads), %.2f s/iteration" % (steps, batch, cores, dt)}
 
 
+_JSON_FD = [None]
+
+
+def keep_stdout_for_json():
+    """RCCL prints a version banner on stdout when the communicator comes up; the contract is ONE JSON line there.
+    File descriptor 1 points at stderr until emit() writes the line to the real stdout."""
+    sys.stdout.flush()
+    _JSON_FD[0] = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _JSON_FD[0] is None:
+        os.write(1, line)
+    else:
+        os.write(_JSON_FD[0], line)
+
+
 def graph_phase(args, rank, fallback, run, device):
     """Multi-rank only: capture + time the hipGraph iteration under a deadline.  Returns the elapsed seconds of the K
     timed replays, or None when any rank failed to capture.  If the phase does not finish within MNK_GRAPH_DEADLINE_S
@@ -128,8 +148,7 @@ def graph_phase(args, rank, fallback, run, device):
     def expire():
         sys.stderr.write("rank %d: hipGraph phase exceeded its deadline; reporting the eager measurement\n" % rank)
         if rank == 0:
-            print(json.dumps(fallback))
-            sys.stdout.flush()
+            emit(fallback)
         os._exit(0)
 
     guard = threading.Timer(float(os.environ.get("MNK_GRAPH_DEADLINE_S", "150")), expire)
@@ -156,6 +175,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("MNK_DIST_FORCE", "") == "1" and "RANK" in os.environ
     if world > 1 or force_dist:
+        keep_stdout_for_json()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -298,8 +318,7 @@ def main():
                        ms_per_step=round(g_elapsed / args.steps * 1e3, 3))
             out["config"]["launch"] = "hipGraph replay (RCCL collectives captured); eager: %.3f ms/step" % ms_per_step
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out)
     if dist_mode:
         dist.destroy_process_group()
 
