@@ -53,10 +53,7 @@ def parse():
 
 def build_models(cfg, device):
     from modules.generator import MotionTransferGenerator
-    if os.environ.get("MNK_NATIVE_DISC", "0") == "1":     # experiment: the discriminator on the gfx950 kernels too
-        from mnk.discriminator_hip import Discriminator
-    else:
-        from modules.discriminator import Discriminator
+    from modules.discriminator import Discriminator     # the gfx950-kernel one (MNK_NATIVE_DISC=0: stock PyTorch ops)
     from modules.keypoint_detector import KPDetector
     mp = cfg["model_params"]
     torch.manual_seed(0)

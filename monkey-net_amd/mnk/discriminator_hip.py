@@ -1,12 +1,11 @@
 """Patch discriminator of the training step (modules/discriminator.py), first "next" row of SURVEY.md section 8f, on the
-same gfx950 kernels as the hot path (parity-tested, NOT the default yet).
+same gfx950 kernels as the hot path; `modules.discriminator.Discriminator` resolves to this class (MNK_NATIVE_DISC=0
+selects the stock-op twin).
 
-Measured on the MI355X (profiles/README.md, run r01l): with this class the moving-gif training iteration takes 22.95 ms
-against 20.93 ms with the stock-op `modules.discriminator.Discriminator` (MIOpen Winograd / implicit-GEMM kernels):
-the discriminator's layers are tiny (61x61x13 -> ... -> 2x2x256 at batch 32, four passes per iteration), where the
-128-row implicit-GEMM tiles, split-K reductions and the NHWC<->NCDHW conversions of the returned feature maps cost
-more than they save.  It stays here, tested against the oracle, as the starting point for that row; `modules/
-discriminator.py` keeps the stock-op implementation that the benchmark uses.
+Measured on the MI355X (profiles/README.md): its layers are tiny (61x61x13 -> ... -> 2x2x256 at batch 32), so with four
+separate passes per iteration it only matched the stock-op network (MIOpen Winograd / implicit-GEMM kernels): 16.48 vs
+16.47 ms per moving-gif iteration.  With the generated and the real frames of a pass batched into one call
+(mnk.engine.discriminate_pair -- every layer here is per sample) it wins: 15.41 vs 15.62 ms.
 
 Kernels: the (1,4,4) convolutions without padding run on the implicit-GEMM conv kernels
 (K x K form), InstanceNorm + LeakyReLU(0.2) + avg-pool is one fused pass (per-frame statistics), the score head is

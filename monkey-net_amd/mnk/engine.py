@@ -18,6 +18,19 @@ def split_kp(kp_joined, detach=False):
             'kp_source': {k: f(v[:, :1]) for k, v in kp_joined.items()}}
 
 
+def discriminate_pair(discriminator, fake, real, kp_dict):
+    """(D(fake, kp), D(real, kp)) -- train.py:43-45,66-68 call the discriminator twice with the same key-points.
+    Every layer of it works per sample (convolutions, InstanceNorm, LeakyReLU, pooling; no batch statistics), so the
+    two calls are ONE pass over the batch [fake; real]: half the launches on layers this small (64x64 and below at
+    batch 32 are launch / latency bound).  MNK_DISC_BATCHED=0 keeps the two separate calls."""
+    if os.environ.get("MNK_DISC_BATCHED", "1") == "0":
+        return discriminator(fake, **kp_dict), discriminator(real, **kp_dict)
+    b = fake.shape[0]
+    kp2 = {name: {k: torch.cat([v, v], dim=0) for k, v in kp.items()} for name, kp in kp_dict.items()}
+    maps = discriminator(torch.cat([fake, real], dim=0), **kp2)
+    return [m[:b] for m in maps], [m[b:] for m in maps]
+
+
 class GeneratorFullModel(torch.nn.Module):
     """train.py:24-53."""
 
@@ -32,8 +45,8 @@ class GeneratorFullModel(torch.nn.Module):
         kp_joined = self.kp_extractor(torch.cat([x['source'], x['video']], dim=2))
         generated = self.generator(x['source'], **split_kp(kp_joined, self.train_params['detach_kp_generator']))
         kp_dict = split_kp(kp_joined, False)
-        maps_generated = self.discriminator(generated['video_prediction'], **kp_dict)
-        maps_real = self.discriminator(x['video'], **kp_dict)
+        maps_generated, maps_real = discriminate_pair(self.discriminator, generated['video_prediction'], x['video'],
+                                                      kp_dict)
         generated.update(kp_dict)
         losses = generator_loss(discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
                                 video_deformed=generated['video_deformed'],
@@ -53,8 +66,8 @@ class DiscriminatorFullModel(torch.nn.Module):
 
     def forward(self, x, kp_joined, generated):
         kp_dict = split_kp(kp_joined, self.train_params['detach_kp_discriminator'])
-        maps_generated = self.discriminator(generated['video_prediction'].detach(), **kp_dict)
-        maps_real = self.discriminator(x['video'], **kp_dict)
+        maps_generated, maps_real = discriminate_pair(self.discriminator, generated['video_prediction'].detach(),
+                                                      x['video'], kp_dict)
         return discriminator_loss(discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
                                   loss_weights=self.train_params['loss_weights'])
 

@@ -1,7 +1,14 @@
-"""Patch discriminator used by the training step (modules/discriminator.py).  NOT part of the MI355X hot path
-(SURVEY.md section 8f-1 "next"): it runs on stock PyTorch-ROCm ops, with the reference's constructor, state_dict keys
-(5-D conv weights) and forward signature so that checkpoints and train.py interoperate.  The (1,4,4) convolutions are
-evaluated as 2-D convolutions on the folded frames.  Its key-point heat-maps come from the HIP embedding kernel."""
+"""Patch discriminator of the training step (modules/discriminator.py; SURVEY.md section 8f-1, the first "next" row).
+
+`Discriminator` / `DownBlock3D` are the gfx950-kernel classes of `mnk/discriminator_hip.py` (4x4 no-pad implicit-GEMM
+convolutions, fused InstanceNorm + LeakyReLU + avg-pool, 1x1 score head): with the two discriminator calls of a pass
+batched into one (mnk.engine.discriminate_pair) they are the faster choice on the MI355X (15.41 vs 15.62 ms per
+moving-gif iteration, profiles/README.md).  `StockDiscriminator` below is the same network on stock PyTorch-ROCm ops
+(MIOpen); MNK_NATIVE_DISC=0 selects it.  Both keep the reference's constructor, state_dict keys (5-D conv weights)
+and forward signature, so checkpoints and train.py interoperate; the (1,4,4) convolutions are evaluated as 2-D
+convolutions on the folded frames and the key-point heat-maps come from the HIP embedding kernel either way."""
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -9,12 +16,12 @@ import torch.nn.functional as F
 from modules.movement_embedding import MovementEmbeddingModule
 
 
-class DownBlock3D(nn.Module):
+class StockDownBlock3D(nn.Module):
     """conv(1,k,k) without padding -> InstanceNorm (optional) -> LeakyReLU(0.2) -> avg-pool (1,2,2)
     (modules/discriminator.py:7-33)."""
 
     def __init__(self, in_features, out_features, norm=False, kernel_size=4):
-        super(DownBlock3D, self).__init__()
+        super(StockDownBlock3D, self).__init__()
         self.conv = nn.Conv3d(in_channels=in_features, out_channels=out_features,
                               kernel_size=(1, kernel_size, kernel_size))
         self.norm = nn.InstanceNorm3d(out_features, affine=True) if norm else None
@@ -28,13 +35,13 @@ class DownBlock3D(nn.Module):
         return y.reshape(b, d, y.shape[1], y.shape[2], y.shape[3]).transpose(1, 2)
 
 
-class Discriminator(nn.Module):
+class StockDiscriminator(nn.Module):
     """Pix2Pix-like discriminator on [frame | key-point heat-maps]; returns every intermediate feature map
     (modules/discriminator.py:36-79)."""
 
     def __init__(self, num_channels=3, num_kp=10, kp_variance=0.01, scale_factor=1,
                  block_expansion=64, num_blocks=4, max_features=512, kp_embedding_params=None):
-        super(Discriminator, self).__init__()
+        super(StockDiscriminator, self).__init__()
         if kp_embedding_params is not None:
             self.kp_embedding = MovementEmbeddingModule(num_kp=num_kp, kp_variance=kp_variance,
                                                         num_channels=num_channels, **kp_embedding_params)
@@ -44,7 +51,7 @@ class Discriminator(nn.Module):
             embedding_channels = 0
         widths = [num_channels + embedding_channels] + [min(max_features, block_expansion * (2 ** (i + 1)))
                                                         for i in range(num_blocks)]
-        self.down_blocks = nn.ModuleList([DownBlock3D(widths[i], widths[i + 1], norm=(i != 0), kernel_size=4)
+        self.down_blocks = nn.ModuleList([StockDownBlock3D(widths[i], widths[i + 1], norm=(i != 0), kernel_size=4)
                                           for i in range(num_blocks)])
         self.conv = nn.Conv3d(self.down_blocks[-1].conv.out_channels, out_channels=1, kernel_size=1)
         self.scale_factor = scale_factor
@@ -63,3 +70,11 @@ class Discriminator(nn.Module):
         score = F.conv2d(out.transpose(1, 2).reshape(b * d, c, h, w), self.conv.weight[:, :, 0], self.conv.bias)
         out_maps.append(score.reshape(b, d, 1, h, w).transpose(1, 2))
         return out_maps
+
+
+from mnk.discriminator_hip import Discriminator as HipDiscriminator, DownBlock3D as HipDownBlock3D  # noqa: E402
+
+if os.environ.get("MNK_NATIVE_DISC", "1") != "0":
+    Discriminator, DownBlock3D = HipDiscriminator, HipDownBlock3D
+else:
+    Discriminator, DownBlock3D = StockDiscriminator, StockDownBlock3D

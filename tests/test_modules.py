@@ -310,12 +310,16 @@ def test_down_block_with_fused_statistics(be):
     assert float((blk.norm.running_var.cpu().double() - ctx.new_stats["blk.norm.running_var"]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("impl", ["hip", "stock"])
 @pytest.mark.parametrize("cfg_name,size", [("tiny", 32), pytest.param("taichi", 64, marks=pytest.mark.gpu)])
-def test_discriminator_matches_oracle(be, cfg_name, size):
-    """mnk.discriminator_hip.Discriminator (4x4 no-pad convs, InstanceNorm, LeakyReLU, avg-pool, 1x1 head on the HIP
-    kernels; not the default discriminator yet, see its docstring) against oracle/restate.py::discriminator_forward in fp64: every returned feature map and all gradients
-    (parameters, input frame, key-points)."""
-    from mnk.discriminator_hip import Discriminator
+def test_discriminator_matches_oracle(be, cfg_name, size, impl):
+    """modules.discriminator: the gfx950-kernel Discriminator (4x4 no-pad convs, InstanceNorm, LeakyReLU, avg-pool, 1x1
+    head; the default) and its stock-op twin (MNK_NATIVE_DISC=0) against oracle/restate.py::discriminator_forward in
+    fp64: every returned feature map and all gradients (parameters, input frame, key-points)."""
+    import modules.discriminator as md
+    Discriminator = md.HipDiscriminator if impl == "hip" else md.StockDiscriminator
+    if impl == "hip":
+        assert md.Discriminator is md.HipDiscriminator, "the drop-in name must resolve to the gfx950-kernel class"
     from oracle import restate
     if be.kind == "emu" and cfg_name != "tiny":
         pytest.skip("too slow on the emulator")
@@ -359,3 +363,50 @@ def test_discriminator_matches_oracle(be, cfg_name, size):
         assert err < 2e-3, (k, err)   # InstanceNorm over 2x2..5x5 maps amplifies fp32 rounding
     assert float((xh.grad.cpu().double() - x64.grad).norm() / x64.grad.norm()) < 2e-3
     assert float((kdh["mean"].grad.cpu().double() - kd64["mean"].grad).norm() / kd64["mean"].grad.norm()) < 2e-3
+
+
+@pytest.mark.parametrize("impl", ["hip", "stock"])
+def test_discriminate_pair_batched_equals_two_calls(be, impl, monkeypatch):
+    """mnk.engine.discriminate_pair: D(fake) and D(real) as one pass over [fake; real] (every layer of the
+    discriminator is per sample) == the reference's two calls (train.py:43-45): feature maps and every gradient."""
+    import modules.discriminator as md
+    from mnk import engine
+    cfg = load("tiny")["cfg"]
+    mp = cfg["model_params"]
+    common = mp["common_params"]
+    torch.manual_seed(8)
+    disc = (md.HipDiscriminator if impl == "hip" else md.StockDiscriminator)(**mp["discriminator_params"], **common)
+    sd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
+    cases.perturb_state_dict(sd, 13)
+    disc.load_state_dict(sd)
+    disc.to(be.device)
+    g = torch.Generator().manual_seed(9)
+    fake0, real0 = torch.rand(3, 3, 1, 32, 32, generator=g), torch.rand(3, 3, 1, 32, 32, generator=g)
+    kd, ks = cases.random_kp(3, 1, common["num_kp"], seed=3), cases.random_kp(3, 1, common["num_kp"], seed=4)
+    ws = None
+
+    def run(batched):
+        nonlocal ws
+        monkeypatch.setenv("MNK_DISC_BATCHED", "1" if batched else "0")
+        fake = be.t(fake0.clone()).requires_grad_(True)         # (be.t is the identity on the emulator backend)
+        kp = {"kp_driving": {k: be.t(v.clone()).requires_grad_(True) for k, v in kd.items()},
+              "kp_source": {k: be.t(v) for k, v in ks.items()}}
+        mf, mr = engine.discriminate_pair(disc, fake, be.t(real0), kp)
+        if ws is None:
+            ws = [torch.randn(m.shape, generator=g) for m in mf]
+        sum((a * be.t(w)).sum() + (b * be.t(w)).sum() * 0.5 for a, b, w in zip(mf, mr, ws)).backward()
+        be.sync()
+        out = ([m.detach().cpu() for m in mf + mr], fake.grad.cpu().clone(), kp["kp_driving"]["mean"].grad.cpu().clone(),
+               {k: p.grad.cpu().clone() for k, p in disc.named_parameters()})
+        disc.zero_grad()
+        return out
+
+    two, one = run(False), run(True)
+    for a, b in zip(one[0], two[0]):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-5 * (1 + float(b.abs().max()))
+    for a, b in ((one[1], two[1]), (one[2], two[2])):
+        assert float((a - b).norm() / b.norm()) < 1e-4
+    for k in two[3]:
+        if k.endswith("conv.bias") and "down_blocks.0" not in k and k != "conv.bias":
+            continue      # bias in front of an InstanceNorm: rounding noise around an analytically zero gradient
+        assert float((one[3][k] - two[3][k]).norm() / (two[3][k].norm() + 1e-12)) < 1e-3, k
