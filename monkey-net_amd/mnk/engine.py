@@ -134,6 +134,91 @@ class TrainStep:
         self._graph = graph
 
     def _eager_step(self, x, set_to_none=True):
+        if os.environ.get("MNK_DISC_SHARED", "1") != "0":
+            return self._eager_step_shared(x)
+        return self._eager_step_two_pass(x)
+
+    def _eager_step_shared(self, x):
+        """train.py:110-136 with ONE discriminator forward per iteration.  The reference runs the discriminator on
+        (generated, real) in the generator pass and again, on the same frames with the same (not yet updated)
+        discriminator weights, in the discriminator pass (train.py:43-45,66-68): the second forward recomputes the
+        first one's values.  Here the graph is cut at the discriminator's inputs (generated frames and key-points become
+        leaves), so that one forward serves both losses:
+          1. dL_G / d(generated, key-points) by a backward through the discriminator only (no weight gradients);
+          2. one backward through generator + key-point detector seeded with those gradients (and L_G's direct terms);
+          3. after the generator step, dL_D / d(discriminator weights) through the same retained graph (the generated
+             frames are a leaf there -- the reference's `.detach()`); key-point gradients of L_D continue into the
+             detector unless train_params['detach_kp_discriminator'].
+        Same losses and gradients as the two-pass form (tests/test_step.py), one discriminator forward less."""
+        tp = self.tp
+        mops.repack_registered()           # every conv parameter seen so far: packed for this iteration in one launch
+        g_params = list(self.generator.parameters())
+        k_params = list(self.kp_detector.parameters())
+        d_params = list(self.discriminator.parameters())
+        kp_joined = self.kp_detector(torch.cat([x['source'], x['video']], dim=2))
+        generated = self.generator(x['source'], **split_kp(kp_joined, tp['detach_kp_generator']))
+        fake = generated['video_prediction']
+        fake_leaf = fake.detach().requires_grad_(True)
+        kp_names = list(kp_joined.keys())
+        kp_leaf = {k: kp_joined[k].detach().requires_grad_(True) for k in kp_names}
+        maps_generated, maps_real = discriminate_pair(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False))
+        generated.update(split_kp(kp_joined, False))
+        loss_values = [v.mean() for v in generator_loss(
+            discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
+            video_deformed=generated['video_deformed'], loss_weights=tp['loss_weights'])]
+        d_values = [v.mean() for v in discriminator_loss(
+            discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
+            loss_weights=tp['loss_weights'])]
+        g_total = sum(loss_values)
+        # 1. through the discriminator only
+        leaves = [fake_leaf] + [kp_leaf[k] for k in kp_names]
+        with mops.no_param_grads():
+            seeds = torch.autograd.grad(g_total, leaves, retain_graph=True, allow_unused=True)
+        # 2. generator + key-point detector, one traversal
+        roots, root_grads = [], []
+        for t, g in zip([fake] + [kp_joined[k] for k in kp_names], seeds):
+            if g is not None and t.requires_grad:
+                roots.append(t)
+                root_grads.append(g)
+        if tp['loss_weights']['reconstruction_deformed'] != 0:      # the only term of L_G that does not pass the cut
+            roots.append(g_total)
+            root_grads.append(None)
+        self.avg_gk.arm()
+        torch.autograd.backward(roots, root_grads, inputs=g_params + k_params,
+                                retain_graph=not tp['detach_kp_discriminator'])
+        self.avg_gk.average()
+        self.opt_g.step()
+        self.opt_g.zero_grad()
+        self.opt_d.zero_grad()
+        if tp['detach_kp_discriminator']:
+            self.opt_k.step()
+            self.opt_k.zero_grad()
+        # 3. the discriminator loss through the retained discriminator graph
+        self.avg_d.arm()
+        d_total = sum(d_values)
+        if tp['detach_kp_discriminator']:
+            torch.autograd.backward(d_total, inputs=d_params)
+        else:
+            self.avg_k.arm()
+            kl = [kp_leaf[k] for k in kp_names]
+            for t in kl:
+                t.grad = None
+            torch.autograd.backward(d_total, inputs=d_params + kl)
+            back = [(kp_joined[k], kp_leaf[k].grad) for k in kp_names if kp_leaf[k].grad is not None]
+            if back:
+                torch.autograd.backward([t for t, _ in back], [g for _, g in back], inputs=k_params)
+        self.avg_d.average()
+        self.opt_d.step()
+        self.opt_d.zero_grad()
+        if not tp['detach_kp_discriminator']:
+            self.avg_k.average()
+            self.opt_k.step()
+            self.opt_k.zero_grad()
+        return [v.detach() for v in loss_values], [v.detach() for v in d_values], generated
+
+    def _eager_step_two_pass(self, x, set_to_none=True):
+        """The reference's structure: generator pass and discriminator pass each run the discriminator
+        (MNK_DISC_SHARED=0)."""
         tp = self.tp
         # The generator pass back-propagates THROUGH the discriminator but the reference throws the discriminator's own
         # weight gradients of this pass away (optimizer_discriminator.zero_grad(), train.py:120): do not compute them.

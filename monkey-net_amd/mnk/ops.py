@@ -460,6 +460,20 @@ def bn_act(y, c, norm, relu=True, pool=False, sums=None):
 # ----------------------------------------------------------------------------------------------------------------
 # grouped 1x1 conv, 1x1 conv + sigmoid
 # ----------------------------------------------------------------------------------------------------------------
+_SKIP_PARAM_GRADS = [False]
+
+
+class no_param_grads:
+    """Context: backward passes of the discriminator's convolutions skip their weight / bias gradients (the caller
+    asked torch.autograd.grad for input gradients only -- a custom Function cannot see that restriction)."""
+
+    def __enter__(self):
+        self.prev, _SKIP_PARAM_GRADS[0] = _SKIP_PARAM_GRADS[0], True
+
+    def __exit__(self, *exc):
+        _SKIP_PARAM_GRADS[0] = self.prev
+
+
 class ConvKxKFn(torch.autograd.Function):
     """nn.Conv3d((1,k,k)), stride 1, zero padding `pad`, single source -- the discriminator's 4x4 convolutions without
     padding (modules/discriminator.py:17-18,28) on the same implicit-GEMM kernels; the data gradient is the same
@@ -498,13 +512,13 @@ class ConvKxKFn(torch.autograd.Function):
             ws = SCRATCH.get("ws", nws, dy) if nws else None
             _call("mnk_conv2d_fwd", dy, _p(dy), dy.shape[-1], cout, None, 0, 0, 0, ho, wo, kh, kw, kh - 1 - pad, _p(wp), None,
                   None, 0, _p(dx), dx.shape[-1], n, hi, wi, cin, _p(ws), nws, None)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS[0]:
             dw = torch.empty_like(weight)
             nws = _query("mnk_conv2d_wgrad_workspace_floats", n, ho, wo, cin, cout, kh, kw, pad)
             ws = SCRATCH.get("ws", nws, dy) if nws else None
             _call("mnk_conv2d_wgrad", dy, _p(x), x.shape[-1], cin, 0, hi, wi, kh, kw, pad, _p(dy), dy.shape[-1], cout, _p(dw),
                   cin, 0, n, ho, wo, _p(ws), nws)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and not _SKIP_PARAM_GRADS[0]:
             db = channel_sums(dy, cout)[:cout]
         return dx, dw, db, None, None, None, None
 

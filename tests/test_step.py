@@ -42,3 +42,61 @@ def test_three_training_steps_match_reference_history(be):
         bound = 16.0 * spread + 2e-5
         assert err <= bound, "iteration %d: |hip - ref64| = %.3e vs reference fp32 noise %.3e" % (it, err, spread)
     print("step parity (iteration, |hip-ref64|, |ref32-ref64|):", report)
+
+
+import copy
+
+import pytest
+
+
+@pytest.mark.parametrize("rec_def,detach_d,detach_g", [(1, True, False), (0, True, False), (1, False, False),
+                                                        (0, False, True)])
+def test_shared_discriminator_forward_equals_two_pass_step(be, monkeypatch, rec_def, detach_d, detach_g):
+    """mnk.engine.TrainStep with ONE discriminator forward per iteration (graph cut at the discriminator's inputs,
+    the default) against the reference's two-pass structure (MNK_DISC_SHARED=0): the same losses and, at each of the
+    three optimiser steps, the same gradients on every parameter -- for the loss / detach variants the configs use
+    (reconstruction_deformed on / off, key-points of the discriminator pass detached or not)."""
+    from mnk import engine
+    gold = load("step_tiny")
+    cfg = copy.deepcopy(gold["cfg"])
+    tp = cfg["train_params"]
+    tp["loss_weights"]["reconstruction_deformed"] = rec_def
+    tp["detach_kp_discriminator"], tp["detach_kp_generator"] = detach_d, detach_g
+    src, drv = cases.smooth_pair(gold["batch"], gold["size"], gold["size"])
+    x = {"source": be.t(src), "video": be.t(drv)}
+
+    def run(shared):
+        monkeypatch.setenv("MNK_DISC_SHARED", "1" if shared else "0")
+        gen, disc, kpd = build(cfg)
+        gen.load_state_dict(gold["state"]["generator"])
+        disc.load_state_dict(gold["state"]["discriminator"])
+        kpd.load_state_dict(gold["state"]["kp_detector"])
+        gen.to(be.device), disc.to(be.device), kpd.to(be.device)
+        step = engine.TrainStep(gen, disc, kpd, tp, fused_adam=False)
+        seen = {}
+        for name, opt, mod in (("g", step.opt_g, gen), ("d", step.opt_d, disc), ("k", step.opt_k, kpd)):
+            def wrapped(real=opt.step, name=name, mod=mod):
+                seen[name] = {k: (p.grad.detach().cpu().clone() if p.grad is not None else None)
+                              for k, p in mod.named_parameters()}
+                return real()
+            opt.step = wrapped
+        g_l, d_l, _ = step._eager_step(x)
+        be.sync()
+        return [float(v) for v in g_l] + [float(v) for v in d_l], seen
+
+    l2, grads2 = run(False)
+    l1, grads1 = run(True)
+    assert max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(l1, l2)) < 1e-6, (l1, l2)
+    checked = 0
+    for name in ("g", "d", "k"):
+        for k, ref in grads2[name].items():
+            got = grads1[name][k]
+            assert (got is None) == (ref is None), (name, k)
+            if ref is None:
+                continue
+            scale = max(float(r.norm()) for r in grads2[name].values() if r is not None)
+            # tensors whose gradient is analytically zero (biases in front of a normalisation) hold rounding noise
+            err = float((got - ref).norm())
+            assert err <= 2e-4 * float(ref.norm()) + 1e-6 * scale, (name, k, err, float(ref.norm()))
+            checked += 1
+    assert checked > 50
