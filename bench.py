@@ -278,7 +278,9 @@ def main():
                 traffic = round((2 * f + w) / n)
         if conv:
             achieved = conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12
-            roofline = {"kernel": "conv3x3_igemm_kernel (forward + dgrad launches)", "bound": "mfma",
+            roofline = {"kernel": "conv3x3_igemm_kernel / conv3x3_igemm16_kernel: every forward + data-gradient launch "
+                                  "of the iteration (3x3 hot path and the discriminator's 4x4 convolutions)",
+                        "bound": "mfma",
                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2),

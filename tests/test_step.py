@@ -49,14 +49,16 @@ import copy
 import pytest
 
 
-@pytest.mark.parametrize("rec_def,detach_d,detach_g", [(1, True, False), (0, True, False), (1, False, False),
-                                                        (0, False, True)])
+@pytest.mark.parametrize("rec_def,detach_d,detach_g", [(1, True, False), (0, False, True), (0, True, False),
+                                                        (1, False, False)])
 def test_shared_discriminator_forward_equals_two_pass_step(be, monkeypatch, rec_def, detach_d, detach_g):
     """mnk.engine.TrainStep with ONE discriminator forward per iteration (graph cut at the discriminator's inputs,
     the default) against the reference's two-pass structure (MNK_DISC_SHARED=0): the same losses and, at each of the
     three optimiser steps, the same gradients on every parameter -- for the loss / detach variants the configs use
     (reconstruction_deformed on / off, key-points of the discriminator pass detached or not)."""
     from mnk import engine
+    if be.kind == "emu" and (rec_def, detach_d) in ((0, True), (1, False)):
+        pytest.skip("the CPU suite keeps the two extreme combinations; all four run on the MI355X")
     gold = load("step_tiny")
     cfg = copy.deepcopy(gold["cfg"])
     tp = cfg["train_params"]
