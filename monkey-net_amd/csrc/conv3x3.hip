@@ -1959,11 +1959,19 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
         const long span = ((long)BK * 8 + 3L * (ups ? Wi / 2 : Wi) + 8) * (ld0 > ld1 ? ld0 : ld1) * 4;
         const int mode = (g_fast_loader && a.clean && kh == 3 && kw == 3 && pad == 1 && span < (1L << 29) &&
                           (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0)) ? (ups ? 2 : 1) : 0;
-#define MNK_IGEMM(KERNEL, ...)                                                                          \
-    do {                                                                                                \
-        if (mode == 1) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 1>), grid, dim3(256), 0, s, a);        \
-        else if (mode == 2) hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 2>), grid, dim3(256), 0, s, a);   \
-        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, 0>), grid, dim3(256), 0, s, a);                  \
+        // the roofline kernel is timed by its own begin / end stamps (bench.py `roofline`, agrees with rocprofv3)
+        hipEvent_t ev0, ev1;
+        const bool timed = prof.kernel_events(&ev0, &ev1);
+#define MNK_IGEMM_MODE(KERNEL, MODE, ...)                                                                     \
+    do {                                                                                                      \
+        if (timed) hipExtLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), 0, s, ev0, ev1, 0, a); \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), 0, s, a);                       \
+    } while (0)
+#define MNK_IGEMM(KERNEL, ...)                                      \
+    do {                                                            \
+        if (mode == 1) MNK_IGEMM_MODE(KERNEL, 1, __VA_ARGS__);      \
+        else if (mode == 2) MNK_IGEMM_MODE(KERNEL, 2, __VA_ARGS__); \
+        else MNK_IGEMM_MODE(KERNEL, 0, __VA_ARGS__);                \
     } while (0)
         if (p.bn == 16)
             MNK_IGEMM(conv3x3_igemm16_kernel, 16);
@@ -1980,6 +1988,7 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
         else
             MNK_IGEMM(conv3x3_igemm_kernel, 128, 32, 4, 1);
 #undef MNK_IGEMM
+#undef MNK_IGEMM_MODE
     }
     if (p.splits > 1) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);

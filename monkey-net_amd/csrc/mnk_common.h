@@ -1,6 +1,7 @@
 // Shared host/device helpers for the gfx950 kernels of libmonkeynet_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "monkeynet_hip.h"
@@ -44,9 +45,14 @@ enum KernelId {
 struct ProfScope {
     ProfScope(int kid, hipStream_t stream, double work);
     ~ProfScope();
+    // For a scope that holds exactly ONE launch: the two events to hand to hipExtLaunchKernelGGL, which stamps them with
+    // the kernel's own begin / end (what rocprofv3 reports) instead of the stream positions around the launch, which
+    // also span the dispatch gap.  Returns false (and leaves the events null) when profiling is off.
+    bool kernel_events(hipEvent_t* start, hipEvent_t* stop);
     int kid;
     hipStream_t stream;
     int slot;
+    bool ext;
 };
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

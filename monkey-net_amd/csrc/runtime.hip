@@ -43,7 +43,7 @@ static hipEvent_t get_event() {
     return e;
 }
 
-ProfScope::ProfScope(int kid_, hipStream_t stream_, double work) : kid(kid_), stream(stream_), slot(-1) {
+ProfScope::ProfScope(int kid_, hipStream_t stream_, double work) : kid(kid_), stream(stream_), slot(-1), ext(false) {
     if (!g_prof_on) return;
     ProfRec r{kid, get_event(), get_event(), work};
     (void)hipEventRecord(r.a, stream);
@@ -51,7 +51,15 @@ ProfScope::ProfScope(int kid_, hipStream_t stream_, double work) : kid(kid_), st
     slot = (int)g_recs.size() - 1;
 }
 ProfScope::~ProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, stream);
+    if (slot >= 0 && !ext) (void)hipEventRecord(g_recs[slot].b, stream);
+}
+bool ProfScope::kernel_events(hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (slot < 0) return false;
+    ext = true;                       // the launch re-records `a` at the kernel's begin and `b` at its end
+    *start = g_recs[slot].a;
+    *stop = g_recs[slot].b;
+    return true;
 }
 
 static void drain() {

@@ -73,6 +73,9 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemset2DAsync(void* p, size_t pitch, int v, size_t w, size_t h, hipStream_t) { for (size_t r = 0; r < h; ++r) memset((char*)p + r * pitch, v, w); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 enum { hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+// hipExtLaunchKernelGGL (hip_ext.h): the launch with per-kernel start / stop events -- events are stubs here
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, start_ev, stop_ev, flags, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
