@@ -4,17 +4,19 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
 A "step" is one full training iteration of train.py:110-136 on one synthetic batch: KPDetector (source + driving
-frame) -> generator -> discriminator x2 -> losses -> backward -> Adam (generator, kp detector), then the
-discriminator update.  KPDetector / DenseMotionModule / generator forward+backward run on the hand-written gfx950
-kernels (libmonkeynet_hip.so); the discriminator, the losses and Adam are stock PyTorch-ROCm ops (SURVEY.md
-section 8f, "next" rows).  Data: synthetic U[0,1) frame pairs (BASELINE.md section 2 protocol), random-init
+frame) -> generator -> discriminator on (generated, real) -> losses -> backward -> Adam (generator, kp detector),
+then the discriminator update (mnk.engine.TrainStep: same losses and gradients as train.py's two passes, with one
+discriminator forward serving both).  KPDetector / DenseMotionModule / generator and the discriminator run forward
+and backward on the hand-written gfx950 kernels (libmonkeynet_hip.so); the losses and Adam are stock PyTorch-ROCm
+ops.  Data: synthetic U[0,1) frame pairs (BASELINE.md section 2 protocol), random-init
 weights of the named configuration; inputs are resident in HBM before the timed region.
 
 One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one generated driving frame = one
 (source, driving) pair), whole-job aggregate over all ranks (weak scaling: fixed per-GPU batch), plus
-  roofline      -- the conv3x3 implicit-GEMM kernel (forward + dgrad launches): algorithmic FLOPs (2*MAC of the
-                   true, un-padded convolution) / HIP-event time measured on the launch stream in a separate
-                   profiled step, against the 157.3 TFLOP/s fp32-MFMA peak of MI355X_MICROARCH.md;
+  roofline      -- the conv implicit-GEMM kernels (every forward + data-gradient launch): algorithmic FLOPs (2*MAC of
+                   the true, un-padded convolution) / kernel duration from HIP events stamped with each launch's own
+                   begin and end on the launch stream (hipExtLaunchKernelGGL) in two profiled eager iterations after
+                   the timed region, against the 157.3 TFLOP/s fp32-MFMA peak of MI355X_MICROARCH.md;
   cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
                    host's cores on a bounded sample of the same workload (rank 0, N == 1 only).
 """

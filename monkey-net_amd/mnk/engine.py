@@ -117,7 +117,7 @@ class TrainStep:
         # With several ranks the captured iteration contains the RCCL all-reduces (SyncBN sums, gradient buckets):
         # every rank replays the same sequence -- collectives inside hipGraphs, as the hipGraph-captured serving stacks
         # on this hardware use them.  Exercised on the MI355X with a forced single-rank process group
-        # (MNK_DIST_FORCE=1: 18.7 ms per iteration against 22.1 ms eager); MNK_DIST_GRAPH=0 opts out.
+        # (MNK_DIST_FORCE=1: 16.0 ms per iteration against 17.7 ms eager); MNK_DIST_GRAPH=0 opts out.
         assert not mdist.active() or os.environ.get("MNK_DIST_GRAPH", "1") == "1", \
             "graph capture with torch.distributed active was disabled (MNK_DIST_GRAPH=0)"
         self._static_x = {k: v.clone() for k, v in x.items()}

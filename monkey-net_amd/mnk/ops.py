@@ -162,8 +162,8 @@ except Exception:  # pragma: no cover - older torch: TrainStep still invalidates
 
 def _packed_fwd_weight(weight, cout, c0, c1):
     """Packed [Cout][chunk][tap][16] copy of a conv weight for NO-GRAD forwards (inference loops), cached per
-    parameter version and optimiser epoch.  Training forwards never use the cache (Conv3x3Fn.forward packs the
-    forward and data-gradient layouts afresh in one launch)."""
+    parameter version and optimiser epoch.  Training forwards never use this cache (they take the registry entry
+    of _pack_entry: re-packed once per iteration by repack_registered(), or per call in a user-owned loop)."""
     key = (id(weight), weight.device)
     ver = (weight._version, _PACK_EPOCH[0])
     hit = _PACK_CACHE.get(key)
