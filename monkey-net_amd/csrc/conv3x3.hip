@@ -273,7 +273,83 @@ struct ActLoader3 {
     __device__ __forceinline__ float4 masked(int j) const { return ra[j]; }
 };
 
+// ---- the same idea for any K x K kernel with stride 1 and padding `pad` (the discriminator's 4x4 / pad 0 forward and its
+// pad 3 data gradient), sources with clean pad channels, no up-sampled view: per-row base offset + one validity bit per
+// tap (K*K <= 32); an out-of-image tap or a channel chunk beyond C reads zeros through the buffer range check.
+template <int RA>
+struct ActLoaderK {
+    unsigned b0[RA], b1[RA];       // byte offset of input pixel (h, w) -- tap (pad, pad) -- relative to the block base;
+                                   // may lie outside the image (pad > 0): it is only a base for the tap arithmetic
+    unsigned inv[RA];              // bit ky * kw + kx: the tap lies outside the image
+    float4 ra[RA];
+    __amdgpu_buffer_rsrc_t r0, r1;
+    int chunk, ky, kx, khh, lq4;
+
+    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin) {
+        lq4 = lq_ * 16;
+        khh = a.ntaps / a.kw;
+        const unsigned mb = (unsigned)(m0 < a.M ? m0 : a.M - 1), tb = fast_div(mb, a.mulW, a.shW),
+                       fb = fast_div(tb, a.mulH, a.shH);
+        // lowest address a valid tap of this block can have: input pixel (h0 - pad, -pad) of the first row's frame
+        long pbase = ((long)fb * a.Hi + (int)(tb - fb * (unsigned)a.H) - a.pad) * a.Wi - a.pad;
+        if (pbase < 0) pbase = 0;
+        r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x0 + pbase * a.ld0), 0, 0x40000000, 0x00020000);
+        r1 = __builtin_amdgcn_make_buffer_rsrc((void*)((a.x1 ? a.x1 : a.x0) + pbase * (a.x1 ? a.ld1 : a.ld0)), 0, 0x40000000,
+                                               0x00020000);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            long ml = m0 + lrow + 64 * j;
+            if (ml > a.M - 1) ml = a.M - 1;
+            const unsigned m = (unsigned)ml, tt = fast_div(m, a.mulW, a.shW), fr = fast_div(tt, a.mulH, a.shH);
+            const int w = (int)(m - tt * (unsigned)a.W), h = (int)(tt - fr * (unsigned)a.H);
+            const long rel = ((long)fr * a.Hi + h) * a.Wi + w - pbase;
+            b0[j] = (unsigned)(rel * a.ld0 * 4);
+            b1[j] = (unsigned)(rel * a.ld1 * 4);
+            unsigned mk = 0, bit = 1;
+            for (int y = 0; y < khh; ++y) {
+                const int hh = h + y - a.pad;
+                const bool rowbad = hh < 0 || hh >= a.Hi;
+                for (int x = 0; x < a.kw; ++x, bit <<= 1) {
+                    const int ww = w + x - a.pad;
+                    if (rowbad || ww < 0 || ww >= a.Wi) mk |= bit;
+                }
+            }
+            inv[j] = mk;
+        }
+        chunk = s_begin / a.ntaps;
+        ky = (s_begin - chunk * a.ntaps) / a.kw;
+        kx = (s_begin - chunk * a.ntaps) - ky * a.kw;
+    }
+    __device__ __forceinline__ void load(const ConvArgs& a) {
+        const int c0 = chunk * BK;
+        const bool second = c0 >= a.C0p;
+        const int cbase = second ? c0 - a.C0p : c0;
+        const int ldb = (second ? a.ld1 : a.ld0) * 4, C = second ? a.C1 : a.C0;
+        const __amdgpu_buffer_rsrc_t rs = second ? r1 : r0;
+        const int tap = ky * a.kw + kx;
+        unsigned st = (unsigned)(cbase * 4 + lq4);
+        st += (cbase * 4 + lq4 >= C * 4) ? 0x40000000u : 0u;
+        st += (unsigned)(((ky - a.pad) * a.Wi + (kx - a.pad)) * ldb);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            unsigned off = (second ? b1[j] : b0[j]) + st;
+            const int bad = __builtin_amdgcn_sbfe(inv[j], tap, 1);            // 0 or -1
+            off = ((unsigned)bad & 0x40000000u) | off;
+            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+        const int kx1 = kx + 1;
+        const bool wx = kx1 == a.kw;
+        kx = wx ? 0 : kx1;
+        const int ky1 = ky + (wx ? 1 : 0);
+        const bool wy = ky1 == khh;
+        ky = wy ? 0 : ky1;
+        chunk += wy ? 1 : 0;
+    }
+    __device__ __forceinline__ float4 masked(int j) const { return ra[j]; }
+};
+
 template <int RA, int MODE> struct LoaderSel { typedef ActLoader<RA> type; };
+template <int RA> struct LoaderSel<RA, 3> { typedef ActLoaderK<RA> type; };
 template <int RA> struct LoaderSel<RA, 1> { typedef ActLoader3<RA, false> type; };
 template <int RA> struct LoaderSel<RA, 2> { typedef ActLoader3<RA, true> type; };
 
@@ -1622,6 +1698,7 @@ static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = 
 static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
 static int g_xcd_remap = env_int("MNK_XCD_REMAP", 1);
 static int g_fast_loader = env_int("MNK_FAST_LOADER", 1);
+static int g_kxk_fast = env_int("MNK_KXK_FAST", 1);     // buffer-load loader for K x K / any pad (MODE 3)
 static int g_mfma16 = env_int("MNK_MFMA16", 1);
 
 static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9) {
@@ -1957,8 +2034,15 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
         // loader: the 3x3 / pad 1 fast form when the caller vouches for clean pad channels and a block's pixel span
         // fits the 2^30-byte buffer window (always, short of ~2 M-float pixel rows)
         const long span = ((long)BK * 8 + 3L * (ups ? Wi / 2 : Wi) + 8) * (ld0 > ld1 ? ld0 : ld1) * 4;
-        const int mode = (g_fast_loader && a.clean && kh == 3 && kw == 3 && pad == 1 && span < (1L << 29) &&
-                          (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0)) ? (ups ? 2 : 1) : 0;
+        int mode = (g_fast_loader && a.clean && kh == 3 && kw == 3 && pad == 1 && span < (1L << 29) &&
+                    (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0)) ? (ups ? 2 : 1) : 0;
+        // any other K x K / pad (the discriminator's 4x4 convolutions and their pad-3 data gradients): ActLoaderK.  A
+        // block's 128 output pixels span at most 128 * kh + (kh + 3) * Wi input pixels (rows of a narrow output, a frame
+        // boundary in the middle)
+        const long span_k = (128L * kh + (long)(kh + 3) * Wi) * (ld0 > ld1 ? ld0 : ld1) * 4;
+        if (mode == 0 && g_fast_loader && g_kxk_fast && a.clean && !ups && ntaps <= 32 && pad >= 0 && pad < kh && pad < kw &&
+            span_k < (1L << 29) && (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0))
+            mode = 3;
         // the roofline kernel is timed by its own begin / end stamps (bench.py `roofline`, agrees with rocprofv3)
         hipEvent_t ev0, ev1;
         const bool timed = prof.kernel_events(&ev0, &ev1);
@@ -1971,6 +2055,7 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     do {                                                            \
         if (mode == 1) MNK_IGEMM_MODE(KERNEL, 1, __VA_ARGS__);      \
         else if (mode == 2) MNK_IGEMM_MODE(KERNEL, 2, __VA_ARGS__); \
+        else if (mode == 3) MNK_IGEMM_MODE(KERNEL, 3, __VA_ARGS__); \
         else MNK_IGEMM_MODE(KERNEL, 0, __VA_ARGS__);                \
     } while (0)
         if (p.bn == 16)

@@ -491,7 +491,8 @@ class ConvKxKFn(torch.autograd.Function):
         y = torch.empty(n, ho, wo, ceil4(cout), dtype=torch.float32, device=x.device)
         nws = _query("mnk_conv2d_workspace_floats", n, ho, wo, cin, 0, cout, nt)
         ws = SCRATCH.get("ws", nws, x) if nws else None
-        _call("mnk_conv2d_fwd", x, _p(x), ld, cin, None, 0, 0, 0, hi, wi, kh, kw, pad, _p(wp), _p(bias), None, 0, _p(y),
+        # flags = MNK_CONV_CLEAN_PADS: x is an act of this module (zero pad channels) -> the K x K buffer-load loader
+        _call("mnk_conv2d_fwd", x, _p(x), ld, cin, None, 0, 0, 2, hi, wi, kh, kw, pad, _p(wp), _p(bias), None, 0, _p(y),
               y.shape[-1], n, ho, wo, cout, _p(ws), nws, None)
         ctx.save_for_backward(x, weight)
         ctx.meta = (cin, cout, kh, kw, pad, n, hi, wi, ho, wo, bias is not None)
@@ -510,7 +511,7 @@ class ConvKxKFn(torch.autograd.Function):
             dx = torch.empty(n, hi, wi, ceil4(cin), dtype=torch.float32, device=dy.device)
             nws = _query("mnk_conv2d_workspace_floats", n, hi, wi, cout, 0, cin, nt)
             ws = SCRATCH.get("ws", nws, dy) if nws else None
-            _call("mnk_conv2d_fwd", dy, _p(dy), dy.shape[-1], cout, None, 0, 0, 0, ho, wo, kh, kw, kh - 1 - pad, _p(wp), None,
+            _call("mnk_conv2d_fwd", dy, _p(dy), dy.shape[-1], cout, None, 0, 0, 2, ho, wo, kh, kw, kh - 1 - pad, _p(wp), None,
                   None, 0, _p(dx), dx.shape[-1], n, hi, wi, cin, _p(ws), nws, None)
         if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS[0]:
             dw = torch.empty_like(weight)

@@ -168,6 +168,40 @@ def test_conv3x3_wgrad(be, case, clean):
     assert relerr(DW.cpu(), wd.grad) < 2e-6
 
 
+# (n, hi, wi, c0, c1, cout, kh, kw, pad): odd kernels / paddings through the K x K buffer-load loader (MNK_CONV_CLEAN_PADS
+# on anything that is not 3x3 pad 1), ragged channel counts, two sources, frames narrower than a 128-pixel tile
+KXK_CASES = [(2, 9, 11, 5, 0, 7, 3, 3, 0), (2, 9, 11, 5, 0, 7, 3, 3, 2), (1, 12, 10, 18, 0, 33, 5, 5, 2),
+             (3, 7, 6, 16, 3, 9, 4, 4, 1), (2, 6, 5, 3, 0, 70, 2, 2, 1), (5, 4, 4, 20, 0, 12, 4, 4, 3),
+             (2, 40, 24, 6, 0, 16, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("clean", [0, 2], ids=["generic-loader", "kxk-buffer-loader"])
+@pytest.mark.parametrize("case", KXK_CASES)
+def test_conv2d_any_kernel_and_padding(be, case, clean):
+    n, hi, wi, c0, c1, cout, kh, kw, pad = case
+    g = torch.Generator().manual_seed(17)
+    x0 = torch.randn(n, c0, hi, wi, generator=g)
+    x1 = torch.randn(n, c1, hi, wi, generator=g) if c1 else None
+    wt = torch.randn(cout, c0 + c1, kh, kw, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    ref = F.conv2d(xin.double(), wt.double(), b.double(), padding=pad)
+    ho, wo = ref.shape[2], ref.shape[3]
+    nt = kh * kw
+    wp = be.empty(be.query("mnk_conv2d_packed_floats", cout, c0, c1, nt))
+    be.call("mnk_conv2d_pack_fwd", be.t(wt), wp, cout, c0, c1, nt)
+    X0 = be.t(to_nhwc(x0))
+    X1 = be.t(to_nhwc(x1)) if c1 else None
+    Y = be.empty(n, ho, wo, ceil4(cout)).fill_(float("nan"))
+    nws = be.query("mnk_conv2d_workspace_floats", n, ho, wo, c0, c1, cout, nt)
+    ws = be.empty(max(nws, 1))
+    be.call("mnk_conv2d_fwd", X0, ceil4(c0), c0, X1, ceil4(c1) if c1 else 0, c1, clean, hi, wi, kh, kw, pad, wp, be.t(b),
+            None, 0, Y, ceil4(cout), n, ho, wo, cout, ws, nws, None)
+    be.sync()
+    assert relerr(from_nhwc(Y.cpu(), cout), ref) < 2e-6
+    assert torch.all(Y.cpu()[..., cout:] == 0)
+
+
 def test_pack_all_equals_separate_packs(be):
     """mnk_conv3x3_pack_all (one launch per training forward) == pack_fwd + pack_dgrad of both sources."""
     cout, c0, c1 = 21, 18, 7
@@ -269,8 +303,9 @@ def test_conv3x3_fused_bn_statistics(be, case):
 K4_CASES = [(2, 16, 16, 13, 32), (1, 13, 13, 32, 64), (3, 6, 6, 64, 20), (2, 5, 4, 7, 1)]
 
 
+@pytest.mark.parametrize("clean", [0, 2], ids=["generic-loader", "kxk-buffer-loader"])
 @pytest.mark.parametrize("case", K4_CASES)
-def test_conv4x4_nopad_forward_dgrad_wgrad(be, case):
+def test_conv4x4_nopad_forward_dgrad_wgrad(be, case, clean):
     n, hi, wi, cin, cout = case
     kh = kw = 4
     ho, wo = hi - 3, wi - 3
@@ -289,8 +324,8 @@ def test_conv4x4_nopad_forward_dgrad_wgrad(be, case):
     Y = be.empty(n, ho, wo, ldy)
     nws = be.query("mnk_conv2d_workspace_floats", n, ho, wo, cin, 0, cout, 16)
     ws = be.empty(max(nws, 1))
-    be.call("mnk_conv2d_fwd", X, ldx, cin, None, 0, 0, 0, hi, wi, kh, kw, 0, wp, be.t(b), None, 0, Y, ldy, n, ho, wo, cout,
-            ws, nws, None)
+    be.call("mnk_conv2d_fwd", X, ldx, cin, None, 0, 0, clean, hi, wi, kh, kw, 0, wp, be.t(b), None, 0, Y, ldy, n, ho, wo,
+            cout, ws, nws, None)
     # data gradient: the same kernel on dy, pad = k-1, flipped/transposed pack
     DY = be.t(to_nhwc(dy.float()))
     wpd = be.empty(be.query("mnk_conv2d_packed_floats", cin, cout, 0, 16))
@@ -298,8 +333,8 @@ def test_conv4x4_nopad_forward_dgrad_wgrad(be, case):
     DX = be.empty(n, hi, wi, ldx)
     nws2 = be.query("mnk_conv2d_workspace_floats", n, hi, wi, cout, 0, cin, 16)
     ws2 = be.empty(max(nws2, 1))
-    be.call("mnk_conv2d_fwd", DY, ldy, cout, None, 0, 0, 0, ho, wo, kh, kw, 3, wpd, None, None, 0, DX, ldx, n, hi, wi, cin,
-            ws2, nws2, None)
+    be.call("mnk_conv2d_fwd", DY, ldy, cout, None, 0, 0, clean, ho, wo, kh, kw, 3, wpd, None, None, 0, DX, ldx, n, hi, wi,
+            cin, ws2, nws2, None)
     # weight gradient
     DW = be.empty(cout, cin, kh, kw)
     nws3 = be.query("mnk_conv2d_wgrad_workspace_floats", n, ho, wo, cin, cout, kh, kw, 0)
