@@ -1,7 +1,12 @@
-// hipemu runtime: round-robin ucontext fibers, one per emulated GPU thread.  TEST INFRASTRUCTURE ONLY.
+// hipemu runtime: round-robin fibers, one per emulated GPU thread.  TEST INFRASTRUCTURE ONLY.
 // See tests/hipemu/include/hip/hip_runtime.h for the rationale.
+// Fiber switch: on x86-64 a dozen instructions (callee-saved registers + stack pointer); glibc's swapcontext makes a
+// sigprocmask system call per switch, which dominated kernels with a barrier per K step.  ucontext elsewhere.
 #include <hip/hip_runtime.h>
+#include <string.h>
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <vector>
 
@@ -14,8 +19,81 @@ constexpr size_t kStack = 96 * 1024;
 constexpr int kMaxWaves = 16;
 constexpr int kSlots = 3;
 
+#if defined(__x86_64__)
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch,.-hipemu_switch
+)");
+struct Context {
+    void* sp = nullptr;
+};
+void trampoline();
+// a fresh fiber: the first switch into it "returns" into trampoline() with a correctly aligned stack
+static void make_fiber(Context& c, char* stack, size_t size) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    uint64_t* sp = (uint64_t*)(top - 72);          // [csr][r15 r14 r13 r12 rbx rbp][return address][pad]
+    memset(sp, 0, 72);
+    uint32_t csr;
+    uint16_t cw;
+    asm volatile("stmxcsr %0" : "=m"(csr));
+    asm volatile("fnstcw %0" : "=m"(cw));
+    ((uint32_t*)sp)[0] = csr;
+    ((uint16_t*)sp)[2] = cw;
+    sp[7] = (uint64_t)(uintptr_t)&trampoline;
+    c.sp = sp;
+}
+static inline void switch_ctx(Context& from, Context& to) { hipemu_switch(&from.sp, to.sp); }
+[[noreturn]] static inline void jump_ctx(Context& to) {
+    void* dummy;
+    hipemu_switch(&dummy, to.sp);
+    abort();
+}
+#else
+struct Context {
+    ucontext_t uc;
+};
+void trampoline();
+static void make_fiber(Context& c, char* stack, size_t size) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack;
+    c.uc.uc_stack.ss_size = size;
+    c.uc.uc_link = nullptr;
+    makecontext(&c.uc, trampoline, 0);
+}
+static inline void switch_ctx(Context& from, Context& to) { swapcontext(&from.uc, &to.uc); }
+[[noreturn]] static inline void jump_ctx(Context& to) {
+    setcontext(&to.uc);
+    abort();
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Context ctx;
     bool done = false;
     unsigned lin = 0;
     dim3 tid;
@@ -32,7 +110,7 @@ struct BlockState {
     int wave_done[kMaxWaves];
     unsigned long wave_gen[kMaxWaves];
     uint32_t xchg[kMaxWaves][kSlots][2][64];
-    ucontext_t main_ctx;
+    Context main_ctx;
     const std::function<void()>* body = nullptr;
 };
 
@@ -43,7 +121,7 @@ void switch_to(int next) {
     int prev = B->cur;
     B->cur = next;
     g_threadIdx = B->fibers[next].tid;
-    swapcontext(&B->fibers[prev].ctx, &B->fibers[next].ctx);
+    switch_ctx(B->fibers[prev].ctx, B->fibers[next].ctx);
 }
 
 void yield() {
@@ -88,11 +166,11 @@ void trampoline() {
             int prev = B->cur;
             B->cur = j;
             g_threadIdx = B->fibers[j].tid;
-            swapcontext(&B->fibers[prev].ctx, &B->fibers[j].ctx);
+            switch_ctx(B->fibers[prev].ctx, B->fibers[j].ctx);
             abort();  // a finished fiber is never resumed
         }
     }
-    setcontext(&B->main_ctx);
+    jump_ctx(B->main_ctx);
 }
 }  // namespace
 
@@ -156,14 +234,10 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
                     f.lin = (unsigned)t;
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                     f.slot_ctr[0] = f.slot_ctr[1] = f.slot_ctr[2] = 0;
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = g_stacks.data() + (size_t)t * kStack;
-                    f.ctx.uc_stack.ss_size = kStack;
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, trampoline, 0);
+                    make_fiber(f.ctx, g_stacks.data() + (size_t)t * kStack, kStack);
                 }
                 g_threadIdx = st.fibers[0].tid;
-                swapcontext(&st.main_ctx, &st.fibers[0].ctx);
+                switch_ctx(st.main_ctx, st.fibers[0].ctx);
             }
     B = saved;
 }

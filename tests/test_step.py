@@ -57,8 +57,6 @@ def test_shared_discriminator_forward_equals_two_pass_step(be, monkeypatch, rec_
     three optimiser steps, the same gradients on every parameter -- for the loss / detach variants the configs use
     (reconstruction_deformed on / off, key-points of the discriminator pass detached or not)."""
     from mnk import engine
-    if be.kind == "emu" and (rec_def, detach_d) in ((0, True), (1, False)):
-        pytest.skip("the CPU suite keeps the two extreme combinations; all four run on the MI355X")
     gold = load("step_tiny")
     cfg = copy.deepcopy(gold["cfg"])
     tp = cfg["train_params"]
