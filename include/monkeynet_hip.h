@@ -284,6 +284,15 @@ int mnk_deform_fwd(const float* inp, int ld_in, int C, int h, int w, const float
 int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
                    const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, void* stream);
 
+/* ---- feature-matching L1 on the discriminator's activations (modules/losses.py:8-12 reconstruction_loss over
+ * discriminator maps; train.py:47-51) ---------------------------------------------------------------------------
+ * a: act of 2B frames [generated | real] ([2B][rows][ld], rows = H*W pixels per frame, C <= ld true channels).
+ * out[i] = weight * mean over pixels and channels c < C of |a[i] - a[B + i]|        (weight * mean_batch(|fake - real|))
+ * da[i]  = g[i] * weight * sign(a[i] - a[B + i]) / (rows * C), da[B + i] = -da[i]; pad channels of da are written 0. */
+int mnk_pair_l1_fwd(const float* a, int ld, long rows, int C, int B, float weight, float* out, void* stream);
+int mnk_pair_l1_bwd(const float* a, int ld, long rows, int C, int B, float weight, const float* g, float* da,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

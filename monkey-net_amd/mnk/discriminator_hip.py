@@ -65,6 +65,23 @@ class Discriminator(nn.Module):
         self.scale_factor = scale_factor
         self.num_channels = num_channels
 
+    def forward_acts(self, x, kp_driving, kp_source):
+        """The same pass with the block outputs left in the kernels' NHWC form: ([(act, channels), ...] per down block,
+        score (B,1,1,h,w)) -- for callers that reduce the feature maps on the device (mnk.engine, PairL1Fn)."""
+        b, _, d = x.shape[:3]
+        if d != 1:
+            raise NotImplementedError("one frame per sample (train.py:43-44,69-70)")
+        step = ops.step_from_scale(self.scale_factor)
+        out, c = ops.to_act(x, step), self.num_channels
+        if self.kp_embedding:
+            emb, ce = self.kp_embedding.forward_act(x, kp_driving, kp_source, pre_step=step)
+            out, c = ops.Concat2Fn.apply(out, c, emb, ce), c + ce
+        acts = []
+        for down_block in self.down_blocks:
+            out, c = down_block.forward_act(out, c)
+            acts.append((out, c))
+        return acts, ops.Conv1x1SigmoidFn.apply(out, self.conv.weight, self.conv.bias, c, b, 0)
+
     def forward(self, x, kp_driving, kp_source):
         b, _, d = x.shape[:3]
         if d != 1:

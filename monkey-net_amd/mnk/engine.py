@@ -31,6 +31,33 @@ def discriminate_pair(discriminator, fake, real, kp_dict):
     return [m[:b] for m in maps], [m[b:] for m in maps]
 
 
+def fused_pair_losses(discriminator, fake, real, kp_dict, video_deformed, loss_weights):
+    """generator_loss(...) and discriminator_loss(...) of modules/losses.py for one batched discriminator pass, with the
+    feature-matching terms of the down-block outputs reduced on the device from the NHWC activations (ops.PairL1Fn)
+    instead of from NCDHW copies of every feature map.  Needs a discriminator with forward_acts (the gfx950-kernel
+    one).  Returns (generator loss vectors in generator_loss's order, discriminator loss vectors)."""
+    from modules.losses import reconstruction_loss
+    b = fake.shape[0]
+    kp2 = {name: {k: torch.cat([v, v], dim=0) for k, v in kp.items()} for name, kp in kp_dict.items()}
+    acts, score = discriminator.forward_acts(torch.cat([fake, real], dim=0), **kp2)
+    score_fake, score_real = score[:b], score[b:]
+    w = loss_weights
+    g_values = []
+    if w['reconstruction_deformed'] != 0:
+        g_values.append(reconstruction_loss(real, video_deformed, w['reconstruction_deformed']))
+    if w['reconstruction'] != 0:
+        rec = w['reconstruction']
+        if rec[0] != 0:                               # map 0 is the frame itself
+            g_values.append(reconstruction_loss(fake, real, weight=rec[0]))
+        for i, (act, c) in enumerate(acts, start=1):
+            if i < len(rec) and rec[i] != 0:
+                g_values.append(mops.PairL1Fn.apply(act, c, b, float(rec[i])))
+    flat = lambda t: t.reshape(t.shape[0], -1).mean(-1)      # losses.mean_batch
+    g_values.append(w['generator_gan'] * flat((1 - score_fake) ** 2))
+    d_values = [w['discriminator_gan'] * flat((1 - score_real) ** 2 + score_fake ** 2)]
+    return g_values, d_values
+
+
 class GeneratorFullModel(torch.nn.Module):
     """train.py:24-53."""
 
@@ -161,14 +188,22 @@ class TrainStep:
         fake_leaf = fake.detach().requires_grad_(True)
         kp_names = list(kp_joined.keys())
         kp_leaf = {k: kp_joined[k].detach().requires_grad_(True) for k in kp_names}
-        maps_generated, maps_real = discriminate_pair(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False))
-        generated.update(split_kp(kp_joined, False))
-        loss_values = [v.mean() for v in generator_loss(
-            discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
-            video_deformed=generated['video_deformed'], loss_weights=tp['loss_weights'])]
-        d_values = [v.mean() for v in discriminator_loss(
-            discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
-            loss_weights=tp['loss_weights'])]
+        if os.environ.get("MNK_FUSED_FM_LOSS", "0") == "1" and hasattr(self.discriminator, "forward_acts"):
+            # opt-in until measured on the MI355X: feature-matching terms straight from the NHWC activations
+            g_vec, d_vec = fused_pair_losses(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False),
+                                             generated['video_deformed'], tp['loss_weights'])
+            generated.update(split_kp(kp_joined, False))
+            loss_values, d_values = [v.mean() for v in g_vec], [v.mean() for v in d_vec]
+        else:
+            maps_generated, maps_real = discriminate_pair(self.discriminator, fake_leaf, x['video'],
+                                                          split_kp(kp_leaf, False))
+            generated.update(split_kp(kp_joined, False))
+            loss_values = [v.mean() for v in generator_loss(
+                discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
+                video_deformed=generated['video_deformed'], loss_weights=tp['loss_weights'])]
+            d_values = [v.mean() for v in discriminator_loss(
+                discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
+                loss_weights=tp['loss_weights'])]
         g_total = sum(loss_values)
         # 1. through the discriminator only
         leaves = [fake_leaf] + [kp_leaf[k] for k in kp_names]

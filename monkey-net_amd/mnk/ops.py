@@ -578,6 +578,33 @@ class InstNormActFn(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None
 
 
+class PairL1Fn(torch.autograd.Function):
+    """weight * mean_batch(|generated - real|) (modules/losses.py:8-12) of one discriminator feature map, read from the
+    act of the batched pass [generated | real] (2B frames) -> tensor (B,).  One launch forward, one backward; the
+    feature maps never take their NCDHW form."""
+
+    @staticmethod
+    def forward(ctx, act, c, b, weight):
+        _check_device(act)
+        n, h, w, ld = act.shape
+        assert n == 2 * b and act.is_contiguous()
+        out = torch.empty(b, dtype=torch.float32, device=act.device)
+        _call("mnk_pair_l1_fwd", act, _p(act), ld, h * w, c, b, float(weight), _p(out))
+        ctx.save_for_backward(act)
+        ctx.meta = (c, b, float(weight))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        act, = ctx.saved_tensors
+        c, b, weight = ctx.meta
+        n, h, w, ld = act.shape
+        g = g.contiguous()
+        da = torch.empty_like(act)
+        _call("mnk_pair_l1_bwd", act, _p(act), ld, h * w, c, b, weight, _p(g), _p(da))
+        return da, None, None, None
+
+
 class GConv1x1Fn(torch.autograd.Function):
     """nn.Conv3d(kernel (1,1,1), groups=num_kp+1) of SameBlock3D (dense_motion_module.py:24-28)."""
 

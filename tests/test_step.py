@@ -53,9 +53,24 @@ import pytest
                                                         (1, False, False)])
 def test_shared_discriminator_forward_equals_two_pass_step(be, monkeypatch, rec_def, detach_d, detach_g):
     """mnk.engine.TrainStep with ONE discriminator forward per iteration (graph cut at the discriminator's inputs,
-    the default) against the reference's two-pass structure (MNK_DISC_SHARED=0): the same losses and, at each of the
-    three optimiser steps, the same gradients on every parameter -- for the loss / detach variants the configs use
-    (reconstruction_deformed on / off, key-points of the discriminator pass detached or not)."""
+    the default) against the reference's two-pass structure (MNK_DISC_SHARED=0) -- for the loss / detach variants the
+    configs use (reconstruction_deformed on / off, key-points of the discriminator pass detached or not)."""
+    _compare_step_forms(be, monkeypatch, rec_def, detach_d, detach_g,
+                        base={"MNK_DISC_SHARED": "0"}, other={"MNK_DISC_SHARED": "1"})
+
+
+@pytest.mark.parametrize("rec_def,detach_d", [(1, True), (0, False)])
+def test_fused_feature_matching_losses_equal_the_loss_module(be, monkeypatch, rec_def, detach_d):
+    """MNK_FUSED_FM_LOSS=1 (opt-in): the feature-matching terms reduced on the device from the discriminator's NHWC
+    activations (ops.PairL1Fn, mnk.engine.fused_pair_losses) give the losses and gradients of modules/losses.py on the
+    NCDHW feature maps."""
+    _compare_step_forms(be, monkeypatch, rec_def, detach_d, False,
+                        base={"MNK_FUSED_FM_LOSS": "0"}, other={"MNK_FUSED_FM_LOSS": "1"})
+
+
+def _compare_step_forms(be, monkeypatch, rec_def, detach_d, detach_g, base, other):
+    """One training iteration under two environment settings from identical weights and inputs: the same losses and, at
+    each of the three optimiser steps, the same gradients on every parameter."""
     from mnk import engine
     gold = load("step_tiny")
     cfg = copy.deepcopy(gold["cfg"])
@@ -65,8 +80,9 @@ def test_shared_discriminator_forward_equals_two_pass_step(be, monkeypatch, rec_
     src, drv = cases.smooth_pair(gold["batch"], gold["size"], gold["size"])
     x = {"source": be.t(src), "video": be.t(drv)}
 
-    def run(shared):
-        monkeypatch.setenv("MNK_DISC_SHARED", "1" if shared else "0")
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         gen, disc, kpd = build(cfg)
         gen.load_state_dict(gold["state"]["generator"])
         disc.load_state_dict(gold["state"]["discriminator"])
@@ -84,8 +100,8 @@ def test_shared_discriminator_forward_equals_two_pass_step(be, monkeypatch, rec_
         be.sync()
         return [float(v) for v in g_l] + [float(v) for v in d_l], seen
 
-    l2, grads2 = run(False)
-    l1, grads1 = run(True)
+    l2, grads2 = run(base)
+    l1, grads1 = run(other)
     assert max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(l1, l2)) < 1e-6, (l1, l2)
     checked = 0
     for name in ("g", "d", "k"):
