@@ -129,6 +129,19 @@ def test_tiny_forward_eval(be, name):
     check_outputs(out, gold, "eval", factor=8.0, floor=5e-6)
 
 
+def test_reference_config_shapes_on_the_emulator():
+    """config/shapes.yaml (BASELINE configs[0], the reference's own CPU-runnable case) at 64x64, batch 2, weights
+    rebuilt from the seed: training-mode outputs and every parameter gradient against the golden recorded from the real
+    reference -- on the CPU emulator build of the kernels (the other YAML configs take minutes there; they run on the
+    MI355X below)."""
+    from conftest import Backend
+    be = Backend("emu")
+    gold = load("shapes")
+    out, grads, _, _ = run_case(be, gold, train=True, backward=True)
+    check_outputs(out, gold, "train")
+    check_grads(grads, gold, factor=8.0, floor=1e-3)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["shapes", "taichi", "moving-gif", "bair", "vox"])
 def test_reference_configs_on_gpu(name):
