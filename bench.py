@@ -268,7 +268,7 @@ def main():
         pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_b%d.json" % (args.config, args.batch))
         if os.path.exists(pmc_file) and args.size == 64:
             # HBM-side bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc passes
-            # (FETCH_SIZE, WRITE_SIZE; tools/gpu_pmc.sh + tools/pmc_summarize.py), gfx950 correction: 2 x FETCH_SIZE
+            # (FETCH_SIZE, WRITE_SIZE; tools/gpu_prof_pmc.sh + tools/pmc_summarize.py), gfx950 correction: 2 x FETCH_SIZE
             pm = json.load(open(pmc_file))
             n = f = w = 0.0
             for k, v in pm.items():
