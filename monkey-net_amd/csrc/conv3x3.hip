@@ -2037,9 +2037,9 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
         int mode = (g_fast_loader && a.clean && kh == 3 && kw == 3 && pad == 1 && span < (1L << 29) &&
                     (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0)) ? (ups ? 2 : 1) : 0;
         // any other K x K / pad (the discriminator's 4x4 convolutions and their pad-3 data gradients): ActLoaderK.  A
-        // block's 128 output pixels span at most 128 * kh + (kh + 3) * Wi input pixels (rows of a narrow output, a frame
-        // boundary in the middle)
-        const long span_k = (128L * kh + (long)(kh + 3) * Wi) * (ld0 > ld1 ? ld0 : ld1) * 4;
+        // block's 128 output pixels span at most 128 * kh * kw + (kh + 3) * Wi input pixels (a 1x1 output per frame
+        // advances a whole kh x kw input frame per output pixel; plus the rows of the taps)
+        const long span_k = (128L * kh * kw + (long)(kh + 3) * Wi) * (ld0 > ld1 ? ld0 : ld1) * 4;
         if (mode == 0 && g_fast_loader && g_kxk_fast && a.clean && !ups && ntaps <= 32 && pad >= 0 && pad < kh && pad < kw &&
             span_k < (1L << 29) && (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0))
             mode = 3;

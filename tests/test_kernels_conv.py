@@ -172,7 +172,7 @@ def test_conv3x3_wgrad(be, case, clean):
 # on anything that is not 3x3 pad 1), ragged channel counts, two sources, frames narrower than a 128-pixel tile
 KXK_CASES = [(2, 9, 11, 5, 0, 7, 3, 3, 0), (2, 9, 11, 5, 0, 7, 3, 3, 2), (1, 12, 10, 18, 0, 33, 5, 5, 2),
              (3, 7, 6, 16, 3, 9, 4, 4, 1), (2, 6, 5, 3, 0, 70, 2, 2, 1), (5, 4, 4, 20, 0, 12, 4, 4, 3),
-             (2, 40, 24, 6, 0, 16, 1, 1, 0)]
+             (2, 40, 24, 6, 0, 16, 1, 1, 0), (150, 4, 4, 24, 0, 8, 4, 4, 0), (70, 5, 5, 8, 0, 20, 4, 4, 0)]
 
 
 @pytest.mark.parametrize("clean", [0, 2], ids=["generic-loader", "kxk-buffer-loader"])
