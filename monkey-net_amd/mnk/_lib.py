@@ -7,6 +7,8 @@ import ctypes
 import os
 import re
 
+from . import knobs
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
 HEADER = os.path.join(os.path.dirname(_PKG), "include", "monkeynet_hip.h")
@@ -90,7 +92,7 @@ def lib():
     """The process-wide library handle (loaded on first use)."""
     global _LIB
     if _LIB is None:
-        _LIB = Library(os.environ.get("MNK_LIBRARY", DEFAULT_LIB))
+        _LIB = Library(knobs.get("MNK_LIBRARY") or DEFAULT_LIB)
     return _LIB
 
 

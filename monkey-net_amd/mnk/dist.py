@@ -9,10 +9,11 @@ CPU tests).  Replaces the reference's single-process DataParallel + SyncMaster t
 * Gradients are averaged with a bucketed flat all-reduce after backward (`GradAverager`), replacing the implicit
   reduce-add of DataParallel's backward and its per-forward parameter broadcast.
 """
-import os
 
 import torch
 import torch.distributed as tdist
+
+from . import knobs
 
 _SYNC_BN = True
 
@@ -35,7 +36,7 @@ def rank():
     return tdist.get_rank() if initialized() else 0
 
 
-_FORCE = os.environ.get("MNK_DIST_FORCE", "") == "1"   # exercise the collectives even with a single rank (tests)
+_FORCE = knobs.on("MNK_DIST_FORCE")   # exercise the collectives even with a single rank (tests)
 
 
 def active():
@@ -85,7 +86,7 @@ class GradAverager:
         self._launched = [None] * len(self.buckets)
         self._armed = False
         if overlap is None:
-            overlap = os.environ.get("MNK_GRAD_OVERLAP", "1") == "1"
+            overlap = knobs.on("MNK_GRAD_OVERLAP")
         self.overlap = overlap
         self._hooks = []
         if overlap:

@@ -2,12 +2,11 @@
 model" wrappers and the alternating generator / discriminator update with three Adam optimisers.  The reference's
 own train.py can equally be used on top of the drop-in `modules` / `sync_batchnorm` packages; this file exists so
 that bench.py, the smoke test and the parity tests have a self-contained step that does not import the reference."""
-import os
-
 import torch
 
 from modules.losses import generator_loss, discriminator_loss
 from . import dist as mdist
+from . import knobs
 from . import ops as mops
 
 
@@ -23,7 +22,7 @@ def discriminate_pair(discriminator, fake, real, kp_dict):
     Every layer of it works per sample (convolutions, InstanceNorm, LeakyReLU, pooling; no batch statistics), so the
     two calls are ONE pass over the batch [fake; real]: half the launches on layers this small (64x64 and below at
     batch 32 are launch / latency bound).  MNK_DISC_BATCHED=0 keeps the two separate calls."""
-    if os.environ.get("MNK_DISC_BATCHED", "1") == "0":
+    if not knobs.on("MNK_DISC_BATCHED"):
         return discriminator(fake, **kp_dict), discriminator(real, **kp_dict)
     b = fake.shape[0]
     kp2 = {name: {k: torch.cat([v, v], dim=0) for k, v in kp.items()} for name, kp in kp_dict.items()}
@@ -145,7 +144,7 @@ class TrainStep:
         # every rank replays the same sequence -- collectives inside hipGraphs, as the hipGraph-captured serving stacks
         # on this hardware use them.  Exercised on the MI355X with a forced single-rank process group
         # (MNK_DIST_FORCE=1: 16.0 ms per iteration against 17.7 ms eager); MNK_DIST_GRAPH=0 opts out.
-        assert not mdist.active() or os.environ.get("MNK_DIST_GRAPH", "1") == "1", \
+        assert not mdist.active() or knobs.on("MNK_DIST_GRAPH"), \
             "graph capture with torch.distributed active was disabled (MNK_DIST_GRAPH=0)"
         self._static_x = {k: v.clone() for k, v in x.items()}
         side = torch.cuda.Stream()
@@ -161,7 +160,7 @@ class TrainStep:
         self._graph = graph
 
     def _eager_step(self, x, set_to_none=True):
-        if os.environ.get("MNK_DISC_SHARED", "1") != "0":
+        if knobs.on("MNK_DISC_SHARED"):
             return self._eager_step_shared(x)
         return self._eager_step_two_pass(x)
 
@@ -188,7 +187,7 @@ class TrainStep:
         fake_leaf = fake.detach().requires_grad_(True)
         kp_names = list(kp_joined.keys())
         kp_leaf = {k: kp_joined[k].detach().requires_grad_(True) for k in kp_names}
-        if os.environ.get("MNK_FUSED_FM_LOSS", "0") == "1" and hasattr(self.discriminator, "forward_acts"):
+        if knobs.on("MNK_FUSED_FM_LOSS") and hasattr(self.discriminator, "forward_acts"):
             # opt-in until measured on the MI355X: feature-matching terms straight from the NHWC activations
             g_vec, d_vec = fused_pair_losses(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False),
                                              generated['video_deformed'], tp['loss_weights'])

@@ -1,0 +1,34 @@
+"""Environment switches of the Python host side, in one place.  Every switch keeps a measured default; the other
+setting exists so that an A/B can be repeated (tools/gpu_knob_ab.sh) or the reference's own structure restored.
+Values are read from the environment at call time (tests flip them with monkeypatch.setenv).
+
+The kernel launch plans have their own tuning switches, read once when the library is loaded
+(monkey-net_amd/csrc/conv3x3.hip: MNK_SPLIT_*, MNK_WSPLIT_*, MNK_WTAP_*, MNK_WN16_*, MNK_WHALO_*, MNK_BM64_TILES,
+MNK_MFMA16, MNK_XCD_REMAP, MNK_FAST_LOADER, MNK_KXK_FAST, MNK_WGRAD_ATOMIC) -- defaults from sweeps on the MI355X,
+profiles/README.md."""
+import os
+
+KNOBS = {
+    # name: (default, meaning)
+    "MNK_LIBRARY": ("", "path of libmonkeynet_hip.so to load instead of the in-tree build (variant builds, A/B)"),
+    "MNK_NATIVE_DISC": ("1", "modules.discriminator.Discriminator = gfx950-kernel network (0: stock PyTorch-ROCm ops)"),
+    "MNK_DISC_BATCHED": ("1", "D(generated) and D(real) of a pass as one call on the batch [generated; real]"),
+    "MNK_DISC_SHARED": ("1", "one discriminator forward per training iteration (0: the reference's two passes)"),
+    "MNK_FUSED_FM_LOSS": ("0", "feature-matching L1 terms reduced on the device from NHWC activations (not measured yet)"),
+    "MNK_PACK_MULTI": ("1", "re-pack every conv weight of the model in one launch per iteration (0: one launch per layer)"),
+    "MNK_DIST_GRAPH": ("1", "with a process group: capture the iteration incl. its RCCL collectives as a hipGraph"),
+    "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),
+    "MNK_GRAD_OVERLAP": ("1", "launch a gradient bucket's all-reduce as soon as its last gradient is written"),
+}
+
+
+def get(name):
+    default, _ = KNOBS[name]
+    return os.environ.get(name, default)
+
+
+def on(name):
+    """True unless the switch is set to "0" (switches with default "1"), or only when set to "1" (default "0" / "")."""
+    default, _ = KNOBS[name]
+    v = os.environ.get(name, default)
+    return v != "0" if default == "1" else v == "1"

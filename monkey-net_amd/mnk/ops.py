@@ -5,13 +5,13 @@ time axis D folded into N (frame = b*D + d) and the channel stride `ld` rounded 
 are zero).  The logical channel count travels next to the tensor.  PyTorch is used for memory, streams and the
 autograd tape only; every arithmetic step is a kernel launch through `mnk._lib` (no CPU / eager fallback).
 """
-import os
 import weakref
 
 import numpy as np
 import torch
 
 from . import _lib
+from . import knobs
 from . import dist as mdist
 
 
@@ -226,7 +226,7 @@ def repack_registered():
     iteration (mnk.engine.TrainStep): ~40 per-layer pack launches become one.  Parameters first seen later in the
     iteration (and everything, when called under stream capture before the table exists) fall back to per-layer packs."""
     t = _PACK_TABLE
-    if os.environ.get("MNK_PACK_MULTI", "1") == "0":
+    if not knobs.on("MNK_PACK_MULTI"):
         return False
     if t["dirty"]:
         entries = [e for e in _PACK_REG.values() if e.wref() is not None and e.wptr == e.wref().data_ptr()]

@@ -7,13 +7,12 @@ moving-gif iteration, profiles/README.md).  `StockDiscriminator` below is the sa
 (MIOpen); MNK_NATIVE_DISC=0 selects it.  Both keep the reference's constructor, state_dict keys (5-D conv weights)
 and forward signature, so checkpoints and train.py interoperate; the (1,4,4) convolutions are evaluated as 2-D
 convolutions on the folded frames and the key-point heat-maps come from the HIP embedding kernel either way."""
-import os
-
 import torch
 from torch import nn
 import torch.nn.functional as F
 
 from modules.movement_embedding import MovementEmbeddingModule
+from mnk import knobs
 
 
 class StockDownBlock3D(nn.Module):
@@ -74,7 +73,7 @@ class StockDiscriminator(nn.Module):
 
 from mnk.discriminator_hip import Discriminator as HipDiscriminator, DownBlock3D as HipDownBlock3D  # noqa: E402
 
-if os.environ.get("MNK_NATIVE_DISC", "1") != "0":
+if knobs.on("MNK_NATIVE_DISC"):
     Discriminator, DownBlock3D = HipDiscriminator, HipDownBlock3D
 else:
     Discriminator, DownBlock3D = StockDiscriminator, StockDownBlock3D
