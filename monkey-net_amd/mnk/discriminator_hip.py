@@ -28,9 +28,9 @@ class DownBlock3D(nn.Module):
         self.norm = nn.InstanceNorm3d(out_features, affine=True) if norm else None
         self.in_features, self.out_features, self.kernel_size = in_features, out_features, kernel_size
 
-    def forward_act(self, x, c):
+    def forward_act(self, x, c, leaf_input=False):
         k = self.kernel_size
-        out = ops.ConvKxKFn.apply(x, self.conv.weight, self.conv.bias, c, k, k, 0)
+        out = ops.ConvKxKFn.apply(x, self.conv.weight, self.conv.bias, c, k, k, 0, leaf_input)
         if self.norm is not None:
             out = ops.InstNormActFn.apply(out, self.norm.weight, self.norm.bias, self.out_features, 0.2, True,
                                           self.norm.eps)
@@ -77,8 +77,8 @@ class Discriminator(nn.Module):
             emb, ce = self.kp_embedding.forward_act(x, kp_driving, kp_source, pre_step=step)
             out, c = ops.Concat2Fn.apply(out, c, emb, ce), c + ce
         acts = []
-        for down_block in self.down_blocks:
-            out, c = down_block.forward_act(out, c)
+        for i, down_block in enumerate(self.down_blocks):
+            out, c = down_block.forward_act(out, c, leaf_input=(i == 0))
             acts.append((out, c))
         return acts, ops.Conv1x1SigmoidFn.apply(out, self.conv.weight, self.conv.bias, c, b, 0)
 
@@ -93,8 +93,8 @@ class Discriminator(nn.Module):
         if self.kp_embedding:
             emb, ce = self.kp_embedding.forward_act(x, kp_driving, kp_source, pre_step=step)
             out, c = ops.Concat2Fn.apply(out, c, emb, ce), c + ce
-        for down_block in self.down_blocks:
-            out, c = down_block.forward_act(out, c)
+        for i, down_block in enumerate(self.down_blocks):
+            out, c = down_block.forward_act(out, c, leaf_input=(i == 0))
             out_maps.append(ops.from_act(out, c, b))
         out_maps.append(ops.Conv1x1SigmoidFn.apply(out, self.conv.weight, self.conv.bias, c, b, 0))
         return out_maps

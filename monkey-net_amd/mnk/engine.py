@@ -231,7 +231,8 @@ class TrainStep:
         self.avg_d.arm()
         d_total = sum(d_values)
         if tp['detach_kp_discriminator']:
-            torch.autograd.backward(d_total, inputs=d_params)
+            with mops.no_leaf_input_grads():     # nothing below the discriminator's first convolution is asked for
+                torch.autograd.backward(d_total, inputs=d_params)
         else:
             self.avg_k.arm()
             kl = [kp_leaf[k] for k in kp_names]

@@ -474,14 +474,30 @@ class no_param_grads:
         _SKIP_PARAM_GRADS[0] = self.prev
 
 
+_SKIP_LEAF_INPUT_GRADS = [False]
+
+
+class no_leaf_input_grads:
+    """Context: a ConvKxKFn marked `leaf_input` (the discriminator's first convolution) skips its data gradient -- the
+    caller's backward only asks for parameter gradients and nothing below that convolution will run (the custom
+    Function cannot see torch.autograd.backward(inputs=...))."""
+
+    def __enter__(self):
+        self.prev, _SKIP_LEAF_INPUT_GRADS[0] = _SKIP_LEAF_INPUT_GRADS[0], True
+
+    def __exit__(self, *exc):
+        _SKIP_LEAF_INPUT_GRADS[0] = self.prev
+
+
 class ConvKxKFn(torch.autograd.Function):
     """nn.Conv3d((1,k,k)), stride 1, zero padding `pad`, single source -- the discriminator's 4x4 convolutions without
     padding (modules/discriminator.py:17-18,28) on the same implicit-GEMM kernels; the data gradient is the same
     kernel on dy with pad k-1-pad and the flipped / transposed pack."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cin, kh, kw, pad):
+    def forward(ctx, x, weight, bias, cin, kh, kw, pad, leaf_input=False):
         _check_device(x)
+        ctx.leaf_input = bool(leaf_input)
         cout = weight.shape[0]
         n, hi, wi, ld = x.shape
         ho, wo = hi + 2 * pad - kh + 1, wi + 2 * pad - kw + 1
@@ -505,7 +521,7 @@ class ConvKxKFn(torch.autograd.Function):
         dy = dy.contiguous()
         nt = kh * kw
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not (ctx.leaf_input and _SKIP_LEAF_INPUT_GRADS[0]):
             wp = SCRATCH.get("pack", _query("mnk_conv2d_packed_floats", cin, cout, 0, nt), dy)
             _call("mnk_conv2d_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, 0, cin, nt)
             dx = torch.empty(n, hi, wi, ceil4(cin), dtype=torch.float32, device=dy.device)
@@ -521,7 +537,7 @@ class ConvKxKFn(torch.autograd.Function):
                   cin, 0, n, ho, wo, _p(ws), nws)
         if has_bias and ctx.needs_input_grad[2] and not _SKIP_PARAM_GRADS[0]:
             db = channel_sums(dy, cout)[:cout]
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class InstNormActFn(torch.autograd.Function):
