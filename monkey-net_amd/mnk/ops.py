@@ -587,8 +587,9 @@ class InstNormActFn(torch.autograd.Function):
             sums = torch.empty(2 * n * c, dtype=torch.float32, device=y.device)
             _call("mnk_norm_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(bt), 1,
                   n, h, w, c, slope, int(pool), _p(sums), _p(ws), nws)
-            per = sums.view(2, n, c).sum(dim=1)
-            dbeta, dgamma = per[0], per[1]
+            if not _SKIP_PARAM_GRADS[0]:
+                per = sums.view(2, n, c).sum(dim=1)
+                dbeta, dgamma = per[0], per[1]
         _call("mnk_norm_act_bwd_apply", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(bt),
               int(has_norm), _p(sums), float(h * w), int(has_norm), _p(dy), ld, n, h, w, c, slope, int(pool))
         return dy, dgamma, dbeta, None, None, None, None
