@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="batch of the CPU sample (default: the workload's)")
     ap.add_argument("--cpu-steps", type=int, default=6, help="CPU sample: at most this many iterations / ~20 s")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="additionally time K iterations whose inputs start in pinned host memory (PCIe-inclusive "
+                         "rate, reported as `pcie_inclusive`; never `value`)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the iteration as one captured hipGraph, 0: eager launches, -1: graph on 1 GPU")
     return ap.parse_args()
@@ -243,6 +246,23 @@ def main():
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
 
+    pcie = None
+    if args.host_inputs and not dist_mode:
+        # the reference's loop hands over DataLoader (host) batches; here: pinned host tensors, one asynchronous
+        # host-to-device copy per iteration on the launch stream, then the same step
+        host = {k: v.cpu().pin_memory() for k, v in x.items()}
+        for _ in range(args.warmup):
+            step.step({k: v.to(device, non_blocking=True) for k, v in host.items()})
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step.step({k: v.to(device, non_blocking=True) for k, v in host.items()})
+        sync()
+        dt = time.perf_counter() - t0
+        pcie = {"value": round(global_batch * args.steps / dt, 2), "unit": "frames/s",
+                "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "bytes_per_step": int(sum(v.numel() * 4 for v in host.values()))}
+
     # ---- per-kernel HIP-event timing of one extra (un-timed) step: roofline of the dominant kernel --------------
     roofline = None
     kernels = {}
@@ -309,6 +329,8 @@ def main():
                        "hot_path_conv_gflop_fwd_per_pair": round(flops["total"] / 1e9, 3)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
     else:
         out = None
     if dist_mode and use_graph:
