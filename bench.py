@@ -53,7 +53,59 @@ def parse():
                          "rate, reported as `pcie_inclusive`; never `value`)")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the iteration as one captured hipGraph, 0: eager launches, -1: graph on 1 GPU")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU check of the N-rank self-launch: every rank joins a gloo group, rank 0 prints one line")
+    ap.add_argument("--print-launch", action="store_true", help="print the N-rank launch command and exit")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: become the launcher -- one process per GPU under
+    torch.distributed.run on this node (RCCL world size N), exactly the command the driver would have typed.  The
+    reference's multi-GPU entry is likewise one command (run.py:28 `--device_ids`, train.py:104-105).  Returns only when
+    this process already is a rank (RANK set) or N == 1."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    if not args.launcher_selftest:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
+            sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    if args.print_launch:
+        print(" ".join(cmd))
+        sys.exit(0)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def launcher_selftest():
+    """What the ranks of `--gpus N --launcher-selftest` run (CPU, gloo): proves the self-launch produced N ranks that can
+    talk, and that rank 0 alone owns stdout."""
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    keep_stdout_for_json()
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    t = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        emit({"selftest": True, "n_gpus": world, "ranks_seen": int(t.item())})
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def build_models(cfg, device):
@@ -172,6 +224,9 @@ def graph_phase(args, rank, fallback, run, device):
 
 def main():
     args = parse()
+    self_launch(args)
+    if args.launcher_selftest:
+        return launcher_selftest()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -29,13 +29,8 @@ def available():
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "modules"))
 
 
-def install():
-    """Install the pins and put the reference on sys.path.  Idempotent."""
-    global _installed
-    if _installed:
-        return
-    if not available():
-        raise RuntimeError("reference tree not found at %s" % REFERENCE_ROOT)
+def install_torch_pins():
+    """torch.gesv and the align_corners default of F.grid_sample as torch 0.4.1 had them.  Idempotent."""
     if not hasattr(torch, "gesv"):
         torch.gesv = lambda B, A: (torch.linalg.solve(A, B), None)
     if not getattr(F.grid_sample, "_mnk_pinned", False):
@@ -46,17 +41,33 @@ def install():
 
         grid_sample._mnk_pinned = True
         F.grid_sample = grid_sample
+
+
+def install_stubs():
+    """Empty stand-ins for the third-party packages of the reference's callers that are not installed here."""
     for name in ("imageio", "skimage", "skimage.draw", "skimage.io", "skimage.transform", "skimage.color",
-                 "skimage.util", "matplotlib", "matplotlib.pyplot", "sklearn", "sklearn.model_selection"):
+                 "skimage.util", "matplotlib", "matplotlib.pyplot", "sklearn", "sklearn.model_selection", "torchvision",
+                 "PIL", "pandas", "tqdm"):
         if name not in sys.modules:
             try:
                 __import__(name)
             except Exception:
                 m = types.ModuleType(name)
                 m.__dict__.update(circle=None, imread=None, mimread=None, resize=None, rotate=None,
-                                  gray2rgb=None, img_as_ubyte=None, img_as_float32=None, pad=None,
-                                  train_test_split=None)
+                                  gray2rgb=None, img_as_ubyte=None, img_as_float32=None, img_as_float=None, pad=None,
+                                  train_test_split=None, io=None, use=lambda *a, **k: None)
                 sys.modules[name] = m
+
+
+def install():
+    """Install the pins and put the reference on sys.path.  Idempotent."""
+    global _installed
+    if _installed:
+        return
+    if not available():
+        raise RuntimeError("reference tree not found at %s" % REFERENCE_ROOT)
+    install_torch_pins()
+    install_stubs()
     # our drop-in packages are also called `modules` / `sync_batchnorm`: make sure the reference's win here
     for name in list(sys.modules):
         if name == "modules" or name.startswith("modules.") or name == "sync_batchnorm" or \

@@ -76,3 +76,27 @@ def test_graph_phase_deadline_prints_the_eager_line():
     lines = outs[0][0].splitlines()
     assert len(lines) == 1 and json.loads(lines[0]) == {"value": 1.0, "config": {"launch": "eager"}}, outs[0]
     assert outs[1][0] == "" and "deadline" in outs[0][1] and "deadline" in outs[1][1]
+
+
+def test_gpus_flag_self_launches_n_ranks():
+    """`python bench.py --gpus 2` without a rank environment must start 2 ranks by itself (round-1 verdict: the flag was
+    parsed and ignored).  --launcher-selftest swaps the GPU workload for a gloo all-reduce so this runs on CPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launcher-selftest"],
+                         env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    got = json.loads(lines[0])
+    assert got == {"selftest": True, "n_gpus": 2, "ranks_seen": 2}
+
+
+def test_print_launch_is_the_drivers_command():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--launcher-selftest",
+                          "--print-launch"], capture_output=True, text=True, timeout=120,
+                         env={k: v for k, v in os.environ.items() if k != "RANK"})
+    assert out.returncode == 0, out.stderr
+    cmd = out.stdout.strip()
+    assert "-m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1" in cmd
+    assert cmd.endswith("bench.py --gpus 4 --steps 3 --launcher-selftest --print-launch")

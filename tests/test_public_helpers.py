@@ -1,0 +1,99 @@
+"""The public helper functions the boundary promises next to the module classes (transfer.py:10 and
+modules/discriminator.py:4 import some of them directly): make_coordinate_grid, matrix_inverse, smallest_singular,
+kp2gaussian, gaussian2kp, IdentityDeformation -- each against the outputs the REAL reference produced
+(tests/golden/functions.pt, made by oracle/make_golden.py::functions) on the same inputs."""
+import pytest
+import torch
+
+from test_modules import load
+
+
+def _m(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def test_make_coordinate_grid_matches_reference():
+    """modules/util.py:26-42 (a1)."""
+    from modules.util import make_coordinate_grid
+    gold = load("functions")
+    grid = make_coordinate_grid((5, 7), torch.FloatTensor().type())
+    assert grid.shape == (5, 7, 2) and _m(grid, gold["grid_5x7"]) == 0.0
+    assert float(grid[0, 0, 0]) == -1.0 and float(grid[-1, -1, 1]) == 1.0 and float(grid[0, -1, 0]) == 1.0
+
+
+def test_matrix_helpers_match_reference():
+    """modules/util.py:206-255: matrix_inverse (the reference's eps == 0 branch is an LU solve) and smallest_singular."""
+    from modules.util import matrix_inverse, smallest_singular, matrix_det, matrix_trace
+    gold = load("functions")
+    mat = gold["mat"]
+    assert _m(matrix_inverse(mat), gold["matrix_inverse"]) < 2e-5 * float(gold["matrix_inverse"].abs().max())
+    assert _m(smallest_singular(mat), gold["smallest_singular"]) < 1e-6
+    sv = torch.linalg.svdvals(mat.double())[..., -1:]
+    assert _m(smallest_singular(mat), sv) < 1e-5
+    assert _m(matrix_det(mat), torch.linalg.det(mat.double()).unsqueeze(-1)) < 1e-5
+    assert _m(matrix_trace(mat), (mat[..., 0, 0] + mat[..., 1, 1]).unsqueeze(-1)) == 0.0
+    eps = 0.5                                              # the clamped-determinant branch (util.py:215-221)
+    det = (mat[..., 0, 0] * mat[..., 1, 1] - mat[..., 0, 1] * mat[..., 1, 0]).clamp(min=eps)
+    expect = torch.stack([mat[..., 1, 1], -mat[..., 0, 1], -mat[..., 1, 0], mat[..., 0, 0]], -1) / det.unsqueeze(-1)
+    assert _m(matrix_inverse(mat, eps=eps), expect.view(mat.shape)) < 1e-6
+
+
+@pytest.mark.parametrize("variance", ["matrix", 0.01])
+def test_kp2gaussian_matches_reference(be, variance):
+    """modules/keypoint_detector.py:7-40 (a9), the public wrapper: (B,d,K,.) key-points -> (B,d,K,h,w) heat-maps."""
+    from modules.keypoint_detector import kp2gaussian
+    gold = load("functions")
+    kp = {k: be.t(v) for k, v in gold["k2g_kp"].items()}
+    if variance != "matrix":
+        kp = {"mean": kp["mean"]}
+    out = kp2gaussian(kp, (9, 6), kp_variance=variance)
+    ref = gold["k2g_matrix" if variance == "matrix" else "k2g_const"]
+    assert out.shape == ref.shape
+    assert _m(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("variant", ["matrix", "clip", "single", "const"])
+def test_gaussian2kp_matches_reference(be, variant):
+    """modules/keypoint_detector.py:43-78 (a8), the public wrapper on an already normalised heat-map (B,K,D,H,W)."""
+    from modules.keypoint_detector import gaussian2kp
+    gold = load("functions")
+    logits = gold["g2k_logits"]
+    b, k, d, h, w = logits.shape
+    heat = torch.softmax(logits.view(b, k, d, -1) / 0.1, dim=3).view(logits.shape)   # keypoint_detector.py:103-105
+    args = {"matrix": ("matrix", None), "clip": ("matrix", 0.001), "single": ("single", None), "const": (0.01, None)}[variant]
+    kp = gaussian2kp(be.t(heat), kp_variance=args[0], clip_variance=args[1])
+    be.sync()
+    assert _m(kp["mean"], gold["g2k_%s_mean" % variant]) < 2e-6
+    if variant == "const":
+        assert "var" not in kp
+    else:
+        ref = gold["g2k_%s_var" % variant]
+        assert kp["var"].shape == ref.shape
+        assert _m(kp["var"], ref) < 2e-6 + 2e-5 * float(ref.abs().max())
+
+
+def test_identity_deformation(be):
+    """modules/dense_motion_module.py:79-87 (a12): the identity field, and a generator built without dense_motion_params
+    (generator.py:32-35) returns the source as `video_deformed`."""
+    from modules.dense_motion_module import IdentityDeformation
+    from modules.generator import MotionTransferGenerator
+    from modules.util import make_coordinate_grid
+    b, d, h, w = 2, 3, 6, 10
+    img = be.t(torch.rand(b, 3, 1, h, w))
+    kp = {"mean": be.t(torch.zeros(b, d, 4, 2))}
+    field = IdentityDeformation()(img, kp, {"mean": kp["mean"][:, :1]})
+    assert field.shape == (b, d, h, w, 3)
+    grid = make_coordinate_grid((h, w), torch.FloatTensor().type())
+    assert _m(field[..., :2], grid.view(1, 1, h, w, 2).expand(b, d, h, w, 2)) == 0.0
+    assert float(field[..., 2].abs().max()) == 0.0
+    torch.manual_seed(0)
+    gen = MotionTransferGenerator(num_channels=3, num_kp=4, kp_variance="matrix", block_expansion=8, max_features=16,
+                                  num_blocks=2, num_refinement_blocks=1, dense_motion_params=None,
+                                  kp_embedding_params=None).to(be.device)
+    assert isinstance(gen.dense_motion_module, IdentityDeformation)
+    src = be.t(torch.rand(2, 3, 1, 16, 16))
+    kpv = {"mean": be.t(torch.rand(2, 1, 4, 2) - 0.5), "var": be.t(torch.eye(2).expand(2, 1, 4, 2, 2) * 0.01)}
+    out = gen(src, kp_driving=kpv, kp_source=kpv)
+    be.sync()
+    assert out["video_prediction"].shape == (2, 3, 1, 16, 16)
+    assert _m(out["video_deformed"], src) < 1e-6            # identity grid, align_corners=True: exact resampling
