@@ -1,0 +1,185 @@
+"""Goldens at the BENCHMARKED sizes, from the REAL reference (imported unmodified through oracle/ref_shim.py):
+
+    python -m oracle.make_golden_full [fullstep] [allgrads] [vox256] [infer]        (default: all)
+
+* fullstep_moving-gif_b32.pt -- ONE full training iteration of train.py:110-136 at BASELINE configs[1] (moving-gif
+  parameters @ 64x64, batch 32, U[0,1) pairs of the bench protocol): the seven losses, generated frames, key-points and,
+  for EVERY parameter of the three networks, the fp64 gradient norm, a 64-element sample and the reference's own
+  fp32-vs-fp64 spread (full gradients would be 270 MB).
+* <config>_allgrads.pt -- the same per-parameter norm / sample / spread records for the batch-2 module cases of
+  oracle/make_golden.py (taichi, moving-gif, bair, vox@128), which keep one full gradient per sub-network.
+* vox256.pt -- config/vox.yaml at its native 256x256 (BASELINE configs[3]), batch 2, compact form + per-parameter records.
+* infer_bair_b512.pt -- bair.yaml eval forward at batch 512 (BASELINE configs[4]): reconstruction L1 (reconstruction.py:74),
+  key-points, every 16th frame.
+The restatement is re-pinned on the way (fp64, same tolerances as make_golden.py).  TEST INFRASTRUCTURE ONLY."""
+import copy
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_shim, restate, cases  # noqa: E402
+from oracle.make_golden import (build_reference, grads_of, load_cfg, save, maxdiff, relerr, _run_reference,  # noqa: E402
+                                _run_restate, REPORT)
+
+NS = 64
+
+
+def sample_index(n):
+    """64 positions spread over a flattened tensor of n elements (multiplicative hash, deterministic)."""
+    return (torch.arange(NS, dtype=torch.int64) * 2654435761) % n
+
+
+def records(g32, g64):
+    """per parameter: fp64 norm, fp64 sample, the reference's fp32-vs-fp64 relative error (full tensor and sample)."""
+    out = {}
+    for k, v64 in g64.items():
+        f64, f32 = v64.double().reshape(-1), g32[k].double().reshape(-1)
+        idx = sample_index(f64.numel())
+        out[k] = {"norm": float(f64.norm()), "sample": f64[idx].clone(), "numel": f64.numel(),
+                  "spread": float((f32 - f64).norm() / (f64.norm() + 1e-6)),
+                  "spread_sample": float((f32[idx] - f64[idx]).norm() / (f64[idx].norm() + 1e-30))}
+    return out
+
+
+def fullstep(ref, name="fullstep_moving-gif_b32", cfg_name="moving-gif", batch=32, size=64):
+    cfg = copy.deepcopy(cases.TINY) if cfg_name == "tiny" else load_cfg(cfg_name)
+    tp = cfg["train_params"]
+    src, drv = cases.synthetic_pair(batch, size, size)
+    res = {}
+    for dtype in (torch.float32, torch.float64):
+        t0 = time.time()
+        gen, disc, kpd, init_sums = build_reference(ref, cfg)
+        for m in (gen, disc, kpd):
+            m.to(dtype).train()
+        x = {"source": src.to(dtype), "video": drv.to(dtype)}
+        gfull = ref.GeneratorFullModel(kpd, gen, disc, tp)
+        dfull = ref.DiscriminatorFullModel(kpd, gen, disc, tp)
+        outs = gfull(x)
+        lv = [v.mean() for v in outs[:-2]]
+        generated, kp_joined = outs[-2], outs[-1]
+        sum(lv).backward(retain_graph=not tp["detach_kp_discriminator"])
+        gg, gk = grads_of(gen), grads_of(kpd)
+        disc.zero_grad()                                     # train.py:120
+        dl = [v.mean() for v in dfull(x, kp_joined, generated)]
+        sum(dl).backward()
+        gd = grads_of(disc)
+        res[dtype] = {"g_losses": [float(v) for v in lv], "d_losses": [float(v) for v in dl],
+                      "pred": generated["video_prediction"].detach(), "deformed": generated["video_deformed"].detach(),
+                      "kp_mean": kp_joined["mean"].detach(), "kp_var": kp_joined["var"].detach(),
+                      "grads": {"generator": gg, "kp_detector": gk, "discriminator": gd}, "init_sums": init_sums}
+        print("fullstep %s %s: %.1f s, losses %s" % (name, dtype, time.time() - t0, res[dtype]["g_losses"]), flush=True)
+    r32, r64 = res[torch.float32], res[torch.float64]
+    # re-pin the restatement at this size (fp64): losses and frames
+    gen, disc, kpd, _ = build_reference(ref, cfg)
+    sds = restate.to_dtype({"generator": gen.state_dict(), "discriminator": disc.state_dict(),
+                            "kp_detector": kpd.state_dict()}, torch.float64)
+    lm, gm, _, _, _ = restate.generator_full_forward(sds, cfg, src.double(), drv.double())
+    for i, (a, b) in enumerate(zip(r64["g_losses"], lm)):
+        d = abs(a - float(b.mean()))
+        REPORT.append(("%s.gen_loss%d restate64-vs-ref64" % (name, i), d, 1e-9))
+        assert d < 1e-9 * max(1.0, abs(a)), (i, a, float(b.mean()))
+    d = maxdiff(r64["pred"], gm["video_prediction"])
+    REPORT.append(("%s.video_prediction restate64-vs-ref64" % name, d, 1e-8))
+    assert d < 1e-8, d
+    out = {"cfg": cfg, "batch": batch, "size": size, "init_sums": r32["init_sums"],
+           "g_losses32": r32["g_losses"], "g_losses64": r64["g_losses"], "d_losses32": r32["d_losses"],
+           "d_losses64": r64["d_losses"],
+           "pred64": r64["pred"].float(), "kp_mean64": r64["kp_mean"].float(), "kp_var64": r64["kp_var"].float(),
+           "spread": {"pred": maxdiff(r32["pred"], r64["pred"]), "deformed": maxdiff(r32["deformed"], r64["deformed"]),
+                      "kp_mean": maxdiff(r32["kp_mean"], r64["kp_mean"]), "kp_var": maxdiff(r32["kp_var"], r64["kp_var"])},
+           "deformed_is_source_warp": maxdiff(r64["deformed"], r64["deformed"]) == 0.0,
+           "grads": {m: records(r32["grads"][m], r64["grads"][m]) for m in r64["grads"]}}
+    save(name, out)
+
+
+def allgrads(ref, name, batch=2, size=64):
+    """per-parameter records of the module case `name` of make_golden.py (same seeds, weights, inputs, loss)."""
+    cfg = load_cfg(name)
+    gen, disc, kpd, _ = build_reference(ref, cfg)
+    sds0 = {"generator": copy.deepcopy(gen.state_dict()), "kp_detector": copy.deepcopy(kpd.state_dict())}
+    src, drv = cases.smooth_pair(batch, size, size)
+    g = torch.Generator().manual_seed(99)
+    r1 = torch.randn(batch, 3, 1, size, size, generator=g)
+    r2 = torch.randn(batch, 3, 1, size, size, generator=g)
+    _, g32 = _run_reference(gen, kpd, src, drv, r1, r2, True, backward=True)
+    gen.load_state_dict(sds0["generator"]), kpd.load_state_dict(sds0["kp_detector"])
+    gen.double(), kpd.double()
+    o64, g64 = _run_reference(gen, kpd, src.double(), drv.double(), r1.double(), r2.double(), True, backward=True)
+    return {m: records(g32[m], g64[m]) for m in g64}, o64
+
+
+def vox256(ref):
+    from oracle.make_golden import module_case
+    cfg = load_cfg("vox")
+    t0 = time.time()
+    module_case(ref, "vox256", cfg, batch=2, size=256, store_weights=False,
+                grad_keys=("encoder.down_blocks.0.conv.weight",), compact=True)
+    rec, _ = allgrads(ref, "vox", batch=2, size=256)
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "vox256.pt"), weights_only=False)
+    gold["grad_records"] = rec
+    save("vox256", gold)
+    print("vox256: %.1f s" % (time.time() - t0), flush=True)
+
+
+def infer(ref, name="infer_bair_b512", batch=512, size=64, keep_every=16):
+    cfg = load_cfg("bair")
+    src, drv = cases.synthetic_pair(batch, size, size, seed=4321)
+    res = {}
+    for dtype in (torch.float32, torch.float64):
+        t0 = time.time()
+        gen, disc, kpd, _ = build_reference(ref, cfg)
+        gen.to(dtype).eval(), kpd.to(dtype).eval()
+        preds, kps = [], []
+        with torch.no_grad():
+            for i in range(0, batch, 64):                      # frames are independent in eval mode
+                s, d = src[i:i + 64].to(dtype), drv[i:i + 64].to(dtype)
+                kp_s, kp_d = kpd(s), kpd(d)                   # reconstruction.py:57-59: one frame per call
+                out = gen(s, kp_driving=kp_d, kp_source=kp_s)
+                preds.append(out["video_prediction"])
+                kps.append(kp_d["mean"])
+        res[dtype] = (torch.cat(preds), torch.cat(kps))
+        print("infer %s: %.1f s" % (dtype, time.time() - t0), flush=True)
+    p32, k32 = res[torch.float32]
+    p64, k64 = res[torch.float64]
+    l1 = lambda p: float((p.double() - drv.double()).abs().mean())     # reconstruction.py:74 with weight 1
+    out = {"cfg": cfg, "batch": batch, "size": size, "seed": 4321, "keep_every": keep_every,
+           "l1_32": l1(p32), "l1_64": l1(p64),
+           "l1_per_frame64": (p64 - drv.double()).abs().flatten(1).mean(1).float(),
+           "pred64_kept": p64[::keep_every].float(), "kp_mean64": k64.float(),
+           "spread": {"pred": maxdiff(p32, p64), "kp_mean": maxdiff(k32, k64)}}
+    save(name, out)
+    print("infer: L1 fp32 %.8f fp64 %.8f, spread %s" % (out["l1_32"], out["l1_64"], out["spread"]), flush=True)
+
+
+def main():
+    assert ref_shim.available(), "run this in the authoring container (needs /root/reference)"
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    what = set(sys.argv[1:]) or {"fullstep", "allgrads", "vox256", "infer"}
+    ref = ref_shim.load()
+    if "fullstep" in what:
+        fullstep(ref)
+    if "fullstep_tiny" in what or "fullstep" in what:     # the same record at a size the CPU emulator runs in seconds
+        fullstep(ref, "fullstep_tiny_b4", "tiny", batch=4, size=32)
+    if "allgrads" in what:
+        for name, size in (("taichi", 64), ("moving-gif", 64), ("bair", 64), ("vox", 128)):
+            t0 = time.time()
+            rec, _ = allgrads(ref, name, 2, size)
+            save(name + "_allgrads", {"records": rec, "batch": 2, "size": size})
+            print("allgrads %s: %.1f s, %d parameters" % (name, time.time() - t0, sum(len(v) for v in rec.values())),
+                  flush=True)
+    if "vox256" in what:
+        vox256(ref)
+    if "infer" in what:
+        infer(ref)
+    with open(os.path.join(ROOT, "tests", "golden", "RESTATEMENT_REPORT_FULL.txt"), "a") as f:
+        for n, d, t in REPORT:
+            f.write("%-70s %.3e (tol %.1e)\n" % (n, d, t))
+
+
+if __name__ == "__main__":
+    main()

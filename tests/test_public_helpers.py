@@ -69,7 +69,16 @@ def test_gaussian2kp_matches_reference(be, variant):
     else:
         ref = gold["g2k_%s_var" % variant]
         assert kp["var"].shape == ref.shape
-        assert _m(kp["var"], ref) < 2e-6 + 2e-5 * float(ref.abs().max())
+        if variant == "clip":
+            # var * max(clip, s_min) / s_min with s_min = sqrt((s1 - s2) / 2) (util.py:244-255) cancels catastrophically in
+            # fp32 for near-singular covariances (here s_min^2 / s1 ~ 5e-6): the reference's own fp32 result is ~1 % away
+            # from its fp64 evaluation.  Yard-stick: the fp64 restatement; bound: the reference's fp32 distance to it.
+            from oracle import restate
+            r64 = restate.gaussian2kp(heat.double(), "matrix", 0.001)["var"]
+            spread = _m(ref, r64)
+            assert _m(kp["var"], r64) <= 4 * spread + 2e-6, (_m(kp["var"], r64), spread)
+        else:
+            assert _m(kp["var"], ref) < 2e-6 + 2e-5 * float(ref.abs().max())
 
 
 def test_identity_deformation(be):
