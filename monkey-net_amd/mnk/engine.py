@@ -188,7 +188,7 @@ class TrainStep:
         kp_names = list(kp_joined.keys())
         kp_leaf = {k: kp_joined[k].detach().requires_grad_(True) for k in kp_names}
         if knobs.on("MNK_FUSED_FM_LOSS") and hasattr(self.discriminator, "forward_acts"):
-            # opt-in until measured on the MI355X: feature-matching terms straight from the NHWC activations
+            # feature-matching terms straight from the NHWC activations (profiles/README.md: 14.59 -> 14.26 ms per step)
             g_vec, d_vec = fused_pair_losses(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False),
                                              generated['video_deformed'], tp['loss_weights'])
             generated.update(split_kp(kp_joined, False))

