@@ -203,6 +203,56 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
                      int ld_dy, int Cout, float* dw, int Cin_total, int c_start, int N, int Ho, int Wo, float* ws,
                      size_t ws_floats, void* stream);
 
+/* ---- deferred split reductions (new; the reference has no counterpart: torch's conv backward reduces inside cuDNN).
+ * A backward pass launches ~60 weight-gradient GEMMs whose pixel-split partials each needed 1-2 small reduction launches
+ * (latency bound: ~100 launches of 5-10 us per iteration).  With MNK_WGRAD_DEFER (flags bit 2) mnk_conv2d_wgrad /
+ * mnk_conv3x3_wgrad only run the GEMM and leave its partials in `ws`; mnk_conv2d_wgrad_plan says in which layout and how
+ * many floats (`ws` must then be a buffer that lives until the reduction); mnk_wgrad_reduce_multi reduces the partials
+ * of ANY number of layers in one launch, each into its slice dw[co][c_start + ci][tap] of a (Cout, Cin_total, kh, kw)
+ * parameter gradient.  Descriptor table in device memory, sorted by block_begin; layer i owns blocks
+ * [block_begin, block_begin + Cout * ceil(C / 64)); total_blocks = their sum.  Deterministic summation order. */
+#define MNK_WGRAD_DEFER 4
+typedef struct MnkWgradPlan {
+    int layout;          /* 0: tap-major partials [split][tap][Cout][C]; 1: parameter-major [split][Cout][C * ntaps] */
+    int splits;          /* 0: the GEMM writes dw itself -- nothing to reduce */
+    size_t part_floats;  /* floats of `ws` the GEMM fills under MNK_WGRAD_DEFER */
+} MnkWgradPlan;
+int mnk_conv2d_wgrad_plan(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad, int ld_x, MnkWgradPlan* plan);
+typedef struct MnkWgradReduceDesc {
+    const float* part;
+    float* dw;           /* start of the (Cout, Cin_total, ntaps) gradient */
+    int layout, splits, ntaps, Cout, C, Cin_total, c_start;
+    int accumulate;      /* 1: add to dw (a second contribution to the same parameter) */
+    int block_begin;
+    int reserved;
+} MnkWgradReduceDesc;
+int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream);
+
+/* ---- optimiser: torch.optim.Adam(lr, betas=(0.5, 0.999)) of train.py:81-83,118-136 for EVERY
+ * tensor of a model in one launch.  Formula of torch/optim/adam.py::_single_tensor_adam (no amsgrad / weight decay) in
+ * fp32.  `hyper` = 10 floats in DEVICE memory [lr, beta1, beta2, eps, lr / (1 - beta1^t), sqrt(1 - beta2^t), grad_scale, t,
+ * 1 - beta1, 1 - beta2] (the last two rounded from the host's doubles, as torch does): a captured hipGraph sees a
+ * learning-rate change (MultiStepLR, train.py:91-96) without re-capture; mnk_adam_tick does t += 1 and refreshes slots
+ * 4 and 5 (call it once before the launches of an iteration); grad_scale multiplies g first (1 / world size after a sum
+ * all-reduce).  A descriptor is a plain range of n floats, or -- wp_fwd != NULL -- a
+ * (Cout, C0 + C1, 1, 3, 3) convolution weight whose packed forward / data-gradient layouts (mnk_conv3x3_pack_multi's)
+ * are written from the updated values in the same pass.  Table in device memory sorted by block_begin; a descriptor owns
+ * mnk_adam_blocks(...) blocks. */
+typedef struct MnkAdamDesc {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+    float* wp_fwd;
+    float* wp_d0;
+    float* wp_d1;
+    int Cout, C0, C1, block_begin;
+} MnkAdamDesc;
+int mnk_adam_blocks(long n, int Cout, int C0, int C1, int packed);
+int mnk_adam_tick(float* hyper, void* stream);
+int mnk_adam_multi(const MnkAdamDesc* descs_device, int n, int total_blocks, const float* hyper, void* stream);
+
 /* ---- grouped 1x1 convolution (SameBlock3D, modules/util.py:118, dense_motion_module.py:24-28) ----------- */
 int mnk_gconv1x1_fwd(const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, long rows,
                      int groups, int gsize, void* stream);

@@ -11,14 +11,15 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-unused-variable ${MNK_EXTRA_FLAGS}"
 OBJS=""
 pids=""
+NEWEST_H="$(ls -t "$HERE"/*.h "$ROOT/include/monkeynet_hip.h" | head -1)"
 for f in "$HERE"/*.hip; do
   o="$OUT/$(basename "$f").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/mnk_common.h" -nt "$o" ] || [ "$ROOT/include/monkeynet_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$NEWEST_H" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids="$pids $!"
   fi
   OBJS="$OBJS $o"
 done
 for p in $pids; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/../libmonkeynet_hip$TAG.so" $OBJS
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/../libmonkeynet_hip$TAG.so" $OBJS -ldl
 echo "$HERE/../libmonkeynet_hip$TAG.so"

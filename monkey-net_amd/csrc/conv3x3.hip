@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "mnk_common.h"
+#include "pack_tile.h"
 
 using namespace mnk;
 
@@ -796,50 +797,6 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
         const int co = chunk * 16 + k16;
         wp[i] = co < Cout ? w[((long)co * Cin_total + c_start + ci) * ntaps + (ntaps - 1 - tap)] : 0.f;
     }
-}
-
-// forward layout and the data-gradient layouts of both sources in one launch (what a training forward needs; the pack
-// kernels above stay for single uses).  One block per (16 output channels, source, 16 input channels) tile of the
-// parameter: the 16 x (16 * ntaps) floats are read as 16 contiguous runs, transposed through LDS and written as
-// 16 + 16 contiguous 16 * ntaps-float groups -- forward wf[co][chunk][tap][ci] and, for the same tile,
-// data-gradient wd[ci][chunk][ntaps-1-tap][co] -- so the parameter crosses HBM once and every access is coalesced.
-template <int NT>                                 // NT = ntaps when known at compile time (9: constant divisions), else 0
-__device__ __forceinline__ void pack_tile(float* T, const float* __restrict__ w, float* __restrict__ wf,
-                                          float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0, int C1,
-                                          int C0p, int C1p, int ntaps_rt, int cc, int cot) {
-    // T: LDS [16 co][16 ci][ntaps <= 16] with padded strides (odd: no bank conflicts); cc = forward chunk (source 0
-    // chunks, then source 1 chunks), cot = co tile (16 rows)
-    const int ntaps = NT ? NT : ntaps_rt;
-    const int ntp = ntaps | 1, cos = 16 * ntp + 1;
-    const int chunks0 = C0p / 16, chunks = (C0p + C1p) / 16, dchunks = (Cout + 15) / 16;
-    const bool second = cc >= chunks0;
-    const int Cs = second ? C1 : C0, cstart = second ? C0 : 0, lc = second ? cc - chunks0 : cc;
-    const int ci0 = lc * 16, co0 = cot * 16, Cin = C0 + C1;
-    const int run = 16 * ntaps;                     // floats per row of the tile
-    const int t = threadIdx.x;
-    for (int i = t; i < 16 * run; i += 256) {
-        const int r = i / run, o = i - r * run;     // row (co), offset inside the row = ci * ntaps + tap
-        const int ci = o / ntaps, tap = o - ci * ntaps;
-        const int co = co0 + r;
-        float v = 0.f;
-        if (co < Cout && ci0 + ci < Cs) v = w[((size_t)co * Cin + cstart + ci0) * ntaps + o];
-        T[r * cos + ci * ntp + tap] = v;
-    }
-    __syncthreads();
-    for (int i = t; i < 16 * run; i += 256) {       // forward: 16 rows (co) of [tap][16 ci]
-        const int r = i / run, o = i - r * run;
-        const int tap = o >> 4, k16 = o & 15;
-        const int co = co0 + r;
-        if (co < Cout) wf[(((size_t)co * chunks + cc) * ntaps) * 16 + o] = T[r * cos + k16 * ntp + tap];
-    }
-    float* wd = second ? wd1 : wd0;
-    if (wd)
-        for (int i = t; i < 16 * run; i += 256) {   // data gradient: 16 rows (ci) of [flipped tap][16 co]
-            const int r = i / run, o = i - r * run;
-            const int tap = o >> 4, k16 = o & 15;
-            const int ci = ci0 + r;
-            if (ci < Cs) wd[(((size_t)ci * dchunks + cot) * ntaps) * 16 + o] = T[k16 * cos + r * ntp + (ntaps - 1 - tap)];
-        }
 }
 
 template <int NT>
@@ -1675,6 +1632,72 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* 
     }
 }
 
+// ---- split reductions of MANY layers in one launch (deferred weight-gradient reductions of a whole backward pass) ----
+// Block b belongs to the layer whose [block_begin, block_begin + Cout * ceil(C / 64)) range contains it (binary search
+// over the descriptor table in device memory) and owns one output row co and one 64-channel ci tile, i.e. the
+// 64 * ntaps contiguous gradient floats dw[co][(c_start + ci0 .. +64) * ntaps + tap].  Threads = 4 split groups x 64
+// channels (tap-major partials) or 4 split groups x 64 consecutive words (parameter-major partials); group g sums the
+// splits g, g+4, ... with `ntaps` independent chains in flight, the groups are combined through LDS in a fixed order
+// (deterministic), and the (tap, ci) -> (ci, tap) transposition of the tap-major form happens on the way out.
+__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradReduceDesc* __restrict__ descs, int n) {
+    __shared__ float sm[4][16 * 64 + 16];
+    int lo = 0, hi = n - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_begin <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const MnkWgradReduceDesc d = descs[lo];
+    const int local = b - d.block_begin;
+    const int ctiles = (d.C + 63) / 64;
+    const int co = local / ctiles, ci0 = (local - co * ctiles) * 64;
+    const int t = threadIdx.x, g = t >> 6, c = t & 63;
+    const int ntaps = d.ntaps;
+    const int cw = d.C - ci0 < 64 ? d.C - ci0 : 64;          // channels of this tile
+    const int lim = cw * ntaps;                              // gradient floats of this tile
+    float* dst = d.dw + ((long)co * d.Cin_total + d.c_start + ci0) * ntaps;
+    if (d.layout == 0) {
+        // part[s][tap][co][ci]
+        const long plane = (long)d.Cout * d.C, sstride = (long)ntaps * plane;
+        const bool ok = c < cw;
+        const float* src = d.part + (long)co * d.C + ci0 + (ok ? c : 0);
+        float acc[16];
+#pragma unroll
+        for (int tp = 0; tp < 16; ++tp) acc[tp] = 0.f;
+        for (int sp = g; sp < d.splits; sp += 4) {
+            const float* ps = src + (long)sp * sstride;
+#pragma unroll
+            for (int tp = 0; tp < 16; ++tp)
+                if (tp < ntaps) acc[tp] += ps[(long)tp * plane];
+        }
+#pragma unroll
+        for (int tp = 0; tp < 16; ++tp)
+            if (tp < ntaps) sm[g][c * ntaps + tp] = ok ? acc[tp] : 0.f;      // already in (ci, tap) order
+    } else {
+        // part[s][co][ci * ntaps + tap]
+        const long NT = (long)d.C * ntaps, sstride = (long)d.Cout * NT;
+        const float* src = d.part + (long)co * NT + (long)ci0 * ntaps;
+        for (int idx = c; idx < lim; idx += 64) {
+            float v0 = 0.f, v1 = 0.f;
+            int sp = g;
+            for (; sp + 4 < d.splits; sp += 8) {
+                v0 += src[(long)sp * sstride + idx];
+                v1 += src[(long)(sp + 4) * sstride + idx];
+            }
+            if (sp < d.splits) v0 += src[(long)sp * sstride + idx];
+            sm[g][idx] = v0 + v1;
+        }
+    }
+    __syncthreads();
+    for (int idx = t; idx < lim; idx += 256) {
+        const float v = (sm[0][idx] + sm[1][idx]) + (sm[2][idx] + sm[3][idx]);
+        dst[idx] = d.accumulate ? dst[idx] + v : v;
+    }
+}
+
 struct Plan {
     int bm, bn, gm, gn, splits, ksteps, ksteps_per_split, ldw;
 };
@@ -2113,9 +2136,13 @@ size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout,
 int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
                      int ld_dy, int Cout, float* dw, int Cin_total, int c_start, int N, int Ho, int Wo, float* ws,
                      size_t ws_floats, void* stream) {
-    MNK_REQUIRE(flags >= 0 && flags <= 3);
+    MNK_REQUIRE(flags >= 0 && flags <= 7);
     const int ups = flags & MNK_CONV_UPSAMPLED, clean = (flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
+    // MNK_WGRAD_DEFER: leave the split partials in `ws` (layout / size: mnk_conv2d_wgrad_plan) and skip the reduction --
+    // the caller reduces the partials of many layers in one launch (mnk_wgrad_reduce_multi)
+    const bool defer = (flags & MNK_WGRAD_DEFER) != 0;
     MNK_REQUIRE(x && dy && dw && N > 0 && Ho > 0 && Wo > 0 && C > 0 && Cout > 0 && kh > 0 && kw > 0 && pad >= 0);
+    MNK_REQUIRE(!defer || ((size_t)x % 16 == 0 && (size_t)dy % 16 == 0));      // the plan query assumes aligned operands
     MNK_REQUIRE(Ho == Hi + 2 * pad - kh + 1 && Wo == Wi + 2 * pad - kw + 1);
     MNK_REQUIRE(ld_x >= C && ld_dy % 4 == 0 && ld_dy >= Cout);
     MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (Hi % 2 == 0 && Wi % 2 == 0)));
@@ -2124,7 +2151,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
     TPlan tp = make_tplan((long)N * H * W, Cout, C, ntaps, ld_x);
     if (tp.use && ((size_t)x % 16 != 0 || (size_t)dy % 16 != 0)) tp.use = false;
     if (tp.use) {
-        const size_t need = (size_t)(tp.splits + tp.groups) * ntaps * Cout * C;
+        const size_t need = (size_t)(tp.splits + (defer ? 0 : tp.groups)) * ntaps * Cout * C;
         if (!ws || ws_floats < need) {
             set_error("mnk_conv2d_wgrad: workspace too small (%zu < %zu floats)", ws_floats, need);
             return MNK_EWORKSPACE;
@@ -2192,7 +2219,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
                 MNK_WTAP(32, 128, 1, 4);
 #undef MNK_WTAP
         }
-        {
+        if (!defer) {
             ProfScope prof(K_CONV_REDUCE, st, (double)(tp.splits + 1) * ntaps * Cout * C * 4);
             const long n = (long)ntaps * Cout * C;
             const float* src = ws;
@@ -2233,7 +2260,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
             float* dstn = dw + (long)c_start * 9;
             const long ldn = (long)Cin_total * 9;
             if (np.splits > 1) {
-                const size_t need = (size_t)(np.splits + split_groups(np.splits)) * Cout * g.NT;
+                const size_t need = (size_t)(np.splits + (defer ? 0 : split_groups(np.splits))) * Cout * g.NT;
                 if (!ws || ws_floats < need) {
                     set_error("mnk_conv2d_wgrad: workspace too small (%zu < %zu floats)", ws_floats, need);
                     return MNK_EWORKSPACE;
@@ -2256,7 +2283,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
                 MNK_N16(1, 3); MNK_N16(1, 2); MNK_N16(1, 1);
 #undef MNK_N16
             }
-            if (np.splits > 1) {
+            if (np.splits > 1 && !defer) {
                 ProfScope prof(K_CONV_REDUCE, sn, (double)np.splits * Cout * g.NT * 4);
                 const long n = (long)Cout * g.NT;
                 const float* src = ws;
@@ -2303,7 +2330,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
         float* dsth = dw + (long)c_start * 9;
         const long ldh = (long)Cin_total * 9;
         if (hp.splits > 1) {
-            if (!ws || ws_floats < (size_t)(hp.splits + split_groups(hp.splits)) * Cout * h.NT) {
+            if (!ws || ws_floats < (size_t)(hp.splits + (defer ? 0 : split_groups(hp.splits))) * Cout * h.NT) {
                 set_error("mnk_conv2d_wgrad: workspace too small");
                 return MNK_EWORKSPACE;
             }
@@ -2318,7 +2345,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
             ProfScope prof(K_CONV_WGRAD, sh, 2.0 * (double)N * H * W * Cout * 9.0 * C);
             hipLaunchKernelGGL(conv3x3_wgrad_halo_kernel, dim3(hp.gm, hp.gn * 3, hp.splits), dim3(256), 0, sh, h);
         }
-        if (hp.splits > 1) {
+        if (hp.splits > 1 && !defer) {
             ProfScope prof(K_CONV_REDUCE, sh, (double)hp.splits * Cout * h.NT * 4);
             launch_wgrad_reduce(ws, hp.splits, Cout, h.NT, dsth, ldh, sh);
         }
@@ -2349,9 +2376,9 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
     float* dst = dw + (long)c_start * ntaps;
     const long ld_out = (long)Cin_total * ntaps;
     hipStream_t s = (hipStream_t)stream;
-    a.atomic = g_wgrad_atomic;
+    a.atomic = defer ? 0 : g_wgrad_atomic;
     if (p.splits > 1 && !a.atomic) {
-        if (!ws || ws_floats < (size_t)(p.splits + split_groups(p.splits)) * Cout * a.NT) {
+        if (!ws || ws_floats < (size_t)(p.splits + (defer ? 0 : split_groups(p.splits))) * Cout * a.NT) {
             set_error("mnk_conv2d_wgrad: workspace too small");
             return MNK_EWORKSPACE;
         }
@@ -2375,10 +2402,62 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
         else
             hipLaunchKernelGGL((conv3x3_wgrad_kernel<32>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
     }
-    if (p.splits > 1 && !a.atomic) {
+    if (p.splits > 1 && !a.atomic && !defer) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);
         launch_wgrad_reduce(ws, p.splits, Cout, a.NT, dst, ld_out, s);
     }
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+// which weight-gradient form mnk_conv2d_wgrad runs for a shape (16-byte aligned operands assumed) and what it leaves behind
+// under MNK_WGRAD_DEFER: layout 0 = tap-major partials [split][tap][Cout][C], 1 = parameter-major [split][Cout][C*ntaps];
+// splits == 0: the GEMM writes dw itself (nothing to reduce)
+int mnk_conv2d_wgrad_plan(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad, int ld_x, MnkWgradPlan* plan) {
+    MNK_REQUIRE(plan && N > 0 && Ho > 0 && Wo > 0 && C > 0 && Cout > 0 && kh > 0 && kw > 0 && pad >= 0 && ld_x >= C);
+    const int ntaps = kh * kw;
+    plan->layout = 0;
+    plan->splits = 0;
+    plan->part_floats = 0;
+    TPlan tp = make_tplan((long)N * Ho * Wo, Cout, C, ntaps, ld_x);
+    if (tp.use) {
+        plan->splits = tp.splits;
+        plan->part_floats = (size_t)tp.splits * ntaps * Cout * C;
+        return MNK_OK;
+    }
+    if (kh == 3 && kw == 3 && pad == 1) {
+        NPlan np = make_nplan(N, Ho, Wo, Cout, C, ld_x);
+        if (np.use) {
+            if (np.splits > 1) {
+                plan->splits = np.splits;
+                plan->part_floats = (size_t)np.splits * Cout * 9 * C;
+            }
+            return MNK_OK;
+        }
+        HPlan hp = make_hplan(N, Ho, Wo, Cout, C);
+        if (hp.use) {
+            if (hp.splits > 1) {
+                plan->layout = 1;
+                plan->splits = hp.splits;
+                plan->part_floats = (size_t)hp.splits * Cout * 9 * C;
+            }
+            return MNK_OK;
+        }
+    }
+    WPlan p = make_wplan((long)N * Ho * Wo, Cout, C, ntaps);
+    if (p.splits > 1) {
+        plan->layout = 1;
+        plan->splits = p.splits;
+        plan->part_floats = (size_t)p.splits * Cout * ntaps * C;
+    }
+    return MNK_OK;
+}
+
+int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream) {
+    MNK_REQUIRE(descs_device && n > 0 && total_blocks > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CONV_REDUCE, s, 0.0);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, s, descs_device, n);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

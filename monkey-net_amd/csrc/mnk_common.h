@@ -38,6 +38,8 @@ enum KernelId {
     K_FIELD,
     K_DEFORM,
     K_CONV1X1,
+    K_OPTIM,          // multi-tensor Adam (+ weight re-pack)
+    K_LOSS,           // loss reductions
     K_NUM
 };
 

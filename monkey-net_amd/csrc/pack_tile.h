@@ -1,0 +1,84 @@
+// Weight re-layout tile shared by the pack kernels (conv3x3.hip) and the optimiser kernel that emits the packed layouts
+// right after updating the parameter (optim.hip).
+#pragma once
+#include "mnk_common.h"
+
+namespace mnk {
+
+// forward layout and the data-gradient layouts of both sources in one launch (what a training forward needs; the pack
+// kernels of conv3x3.hip stay for single uses).  One block per (16 output channels, source, 16 input channels) tile of
+// the parameter: the 16 x (16 * ntaps) floats are read as 16 contiguous runs, transposed through LDS and written as
+// 16 + 16 contiguous 16 * ntaps-float groups -- forward wf[co][chunk][tap][ci] and, for the same tile,
+// data-gradient wd[ci][chunk][ntaps-1-tap][co] -- so the parameter crosses HBM once and every access is coalesced.
+// T: LDS [16 co][16 ci][ntaps <= 16] with padded strides (odd: no bank conflicts); cc = forward chunk (source 0
+// chunks, then source 1 chunks), cot = co tile (16 rows).
+struct PackTileGeom {
+    int ntaps, ntp, cos, chunks0, chunks, dchunks, Cs, cstart, ci0, co0, Cin, run;
+    bool second;
+};
+
+template <int NT>                                 // NT = ntaps when known at compile time (9: constant divisions), else 0
+__device__ __forceinline__ PackTileGeom pack_tile_geom(int Cout, int C0, int C1, int C0p, int C1p, int ntaps_rt, int cc,
+                                                       int cot) {
+    PackTileGeom g;
+    g.ntaps = NT ? NT : ntaps_rt;
+    g.ntp = g.ntaps | 1;
+    g.cos = 16 * g.ntp + 1;
+    g.chunks0 = C0p / 16;
+    g.chunks = (C0p + C1p) / 16;
+    g.dchunks = (Cout + 15) / 16;
+    g.second = cc >= g.chunks0;
+    g.Cs = g.second ? C1 : C0;
+    g.cstart = g.second ? C0 : 0;
+    const int lc = g.second ? cc - g.chunks0 : cc;
+    g.ci0 = lc * 16;
+    g.co0 = cot * 16;
+    g.Cin = C0 + C1;
+    g.run = 16 * g.ntaps;                         // floats per row of the tile
+    return g;
+}
+
+// T (LDS tile, already holding the parameter values of the tile; zeros outside the parameter) -> packed layouts
+template <int NT>
+__device__ __forceinline__ void pack_tile_emit(const float* T, const PackTileGeom& g, float* __restrict__ wf,
+                                               float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int cc, int cot) {
+    const int ntaps = NT ? NT : g.ntaps;
+    const int run = 16 * ntaps;
+    const int t = threadIdx.x;
+    for (int i = t; i < 16 * run; i += 256) {       // forward: 16 rows (co) of [tap][16 ci]
+        const int r = i / run, o = i - r * run;
+        const int tap = o >> 4, k16 = o & 15;
+        const int co = g.co0 + r;
+        if (co < Cout) wf[(((size_t)co * g.chunks + cc) * ntaps) * 16 + o] = T[r * g.cos + k16 * g.ntp + tap];
+    }
+    float* wd = g.second ? wd1 : wd0;
+    if (wd)
+        for (int i = t; i < 16 * run; i += 256) {   // data gradient: 16 rows (ci) of [flipped tap][16 co]
+            const int r = i / run, o = i - r * run;
+            const int tap = o >> 4, k16 = o & 15;
+            const int ci = g.ci0 + r;
+            if (ci < g.Cs) wd[(((size_t)ci * g.dchunks + cot) * ntaps) * 16 + o] = T[k16 * g.cos + r * g.ntp + (ntaps - 1 - tap)];
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void pack_tile(float* T, const float* __restrict__ w, float* __restrict__ wf,
+                                          float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0, int C1,
+                                          int C0p, int C1p, int ntaps_rt, int cc, int cot) {
+    const PackTileGeom g = pack_tile_geom<NT>(Cout, C0, C1, C0p, C1p, ntaps_rt, cc, cot);
+    const int ntaps = NT ? NT : g.ntaps;
+    const int run = 16 * ntaps;
+    const int t = threadIdx.x;
+    for (int i = t; i < 16 * run; i += 256) {
+        const int r = i / run, o = i - r * run;     // row (co), offset inside the row = ci * ntaps + tap
+        const int ci = o / ntaps, tap = o - ci * ntaps;
+        const int co = g.co0 + r;
+        float v = 0.f;
+        if (co < Cout && g.ci0 + ci < g.Cs) v = w[((size_t)co * g.Cin + g.cstart + g.ci0) * ntaps + o];
+        T[r * g.cos + ci * g.ntp + tap] = v;
+    }
+    __syncthreads();
+    pack_tile_emit<NT>(T, g, wf, wd0, wd1, Cout, cc, cot);
+}
+
+}  // namespace mnk

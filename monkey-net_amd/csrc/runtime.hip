@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 static const char* kNames[K_NUM] = {"conv3x3_igemm", "conv3x3_wgrad", "conv3x3_reduce_pack", "bn_stats",
                                     "bn_act_apply", "bn_act_bwd", "layout", "softmax_kp", "movement_embedding",
-                                    "motion_field", "deform", "conv1x1"};
+                                    "motion_field", "deform", "conv1x1", "adam_pack", "losses"};
 
 struct ProfRec {
     int kid;

@@ -7,13 +7,14 @@ SRC="$ROOT/monkey-net_amd/csrc"
 OUT="$HERE/build"
 mkdir -p "$OUT"
 OBJS=""
+NEWEST_H="$(ls -t "$SRC"/*.h "$ROOT/include/monkeynet_hip.h" "$HERE/include/hip/hip_runtime.h" | head -1)"
 for f in "$SRC"/*.hip "$HERE/hipemu.cpp"; do
   o="$OUT/$(basename "$f").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$SRC/mnk_common.h" -nt "$o" ] || [ "$ROOT/include/monkeynet_hip.h" -nt "$o" ] || [ "$HERE/include/hip/hip_runtime.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$NEWEST_H" -nt "$o" ]; then
     g++ -O2 -g -std=c++17 -fPIC -x c++ -I"$HERE/include" -I"$ROOT/include" -I"$SRC" -Wall -Wno-unknown-pragmas -Wno-unused-function -Wno-unused-variable -Wno-psabi -c "$f" -o "$o" &
   fi
   OBJS="$OBJS $o"
 done
 wait
-g++ -shared -o "$OUT/libmnk_emu.so" $OBJS
+g++ -shared -o "$OUT/libmnk_emu.so" $OBJS -ldl
 echo "$OUT/libmnk_emu.so"

@@ -1,0 +1,179 @@
+"""Deferred weight-gradient reductions (mnk_conv2d_wgrad under MNK_WGRAD_DEFER + mnk_wgrad_reduce_multi: the split
+partials of MANY layers reduced in one launch) and the one-launch Adam that also emits the packed convolution weights
+(mnk_adam_multi), against torch: conv2d's weight gradient in fp64, torch.optim.Adam's trajectory."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import to_nhwc, ceil4, relerr
+from test_kernels_conv import CASES, HALO_CASES, WFAST_CASES, K4_CASES, _inputs
+
+
+class Plan(ctypes.Structure):
+    _fields_ = [("layout", ctypes.c_int), ("splits", ctypes.c_int), ("part_floats", ctypes.c_size_t)]
+
+
+REDUCE_DESC = np.dtype([("part", "<u8"), ("dw", "<u8"), ("layout", "<i4"), ("splits", "<i4"), ("ntaps", "<i4"),
+                        ("Cout", "<i4"), ("C", "<i4"), ("Cin_total", "<i4"), ("c_start", "<i4"), ("accumulate", "<i4"),
+                        ("block_begin", "<i4"), ("reserved", "<i4")])
+ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("wp_fwd", "<u8"),
+                      ("wp_d0", "<u8"), ("wp_d1", "<u8"), ("Cout", "<i4"), ("C0", "<i4"), ("C1", "<i4"),
+                      ("block_begin", "<i4")])
+
+
+def test_descriptor_sizes_match_the_header():
+    assert REDUCE_DESC.itemsize == 56 and ADAM_DESC.itemsize == 80
+
+
+def _table(be, rec):
+    return be.t(torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()))
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_deferred_wgrad_of_many_layers_reduced_in_one_launch(be, accumulate):
+    """every weight-gradient form (tap-major, nine-tap 16x16, LDS-halo, gather; 3x3 and the discriminator's 4x4) leaves its
+    partials behind; ONE mnk_wgrad_reduce_multi launch produces all gradients (two-source layers: two descriptors into
+    one parameter gradient)."""
+    layers = []
+    for case in CASES + HALO_CASES + WFAST_CASES:
+        n, h, w, c0, c1, cout, ups, _, _ = case
+        x0, x1, wt, b, r = _inputs(case)
+        layers.append((n, h, w, h, w, c0, c1, cout, ups, 3, 3, 1, x0, x1, wt))
+    g = torch.Generator().manual_seed(9)
+    for n, hi, wi, cin, cout in K4_CASES:
+        layers.append((n, hi - 3, wi - 3, hi, wi, cin, 0, cout, 0, 4, 4, 0, torch.randn(n, cin, hi, wi, generator=g), None,
+                       torch.randn(cout, cin, 4, 4, generator=g) * 0.2))
+    rows, keep, blocks, direct = [], [], 0, 0
+    for li, (n, ho, wo, hi, wi, c0, c1, cout, ups, kh, kw, pad, x0, x1, wt) in enumerate(layers):
+        gd = torch.Generator().manual_seed(100 + li)
+        dy = torch.randn(n, cout, ho, wo, generator=gd)
+        wd = wt.double().requires_grad_(True)
+        x = x0 if x1 is None else torch.cat([x0, x1], 1)
+        if ups:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        F.conv2d(x.double(), wd, None, padding=pad).backward(dy.double())
+        DY = be.t(to_nhwc(dy))
+        base = torch.randn(cout, c0 + c1, kh, kw, generator=gd) if accumulate else None
+        DW = be.t(base.clone()) if accumulate else be.empty(cout, c0 + c1, kh, kw)
+        for src, c_start, c_cnt in ((x0, 0, c0),) + (((x1, c0, c1),) if c1 else ()):
+            X = be.t(to_nhwc(src))
+            plan = Plan()
+            his, wis = (hi // 2, wi // 2) if ups else (hi, wi)
+            assert be.query("mnk_conv2d_wgrad_plan", n, ho, wo, c_cnt, cout, kh, kw, pad, X.shape[-1], ctypes.byref(plan)) == 0
+            part = be.empty(max(plan.part_floats, 1))
+            tgt = DW if not (plan.splits == 0 and accumulate) else be.empty(cout, c0 + c1, kh, kw)
+            be.call("mnk_conv2d_wgrad", X, X.shape[-1], c_cnt, int(ups) | 2 | 4, hi, wi, kh, kw, pad, DY, DY.shape[-1], cout,
+                    tgt, c0 + c1, c_start, n, ho, wo, part, plan.part_floats)
+            if plan.splits > 0:
+                rows.append((part.data_ptr(), DW.data_ptr(), plan.layout, plan.splits, kh * kw, cout, c_cnt, c0 + c1,
+                             c_start, accumulate, blocks, 0))
+                blocks += cout * ((c_cnt + 63) // 64)
+            else:
+                direct += 1
+                if accumulate:      # the direct form overwrites: the caller adds (rare path, not the kernel's business)
+                    be.sync()
+                    DW[:, c_start:c_start + c_cnt] = be.t(base)[:, c_start:c_start + c_cnt] + tgt[:, c_start:c_start + c_cnt]
+            keep.append((X, part, tgt))
+        keep.append((DY, DW, wd.grad, base))
+    rec = np.array(rows, dtype=REDUCE_DESC)
+    layouts = set(int(r["layout"]) for r in rec)
+    assert layouts == {0, 1} and direct > 0 and len(rec) > 12, (layouts, direct, len(rec))
+    descs = _table(be, rec)
+    be.call("mnk_wgrad_reduce_multi", descs, len(rec), blocks)
+    be.sync()
+    for item in keep:
+        if len(item) == 4:
+            DY, DW, ref, base = item
+            want = ref if base is None else ref + base.double()
+            assert relerr(DW.cpu(), want) < 2e-6
+
+
+def _adam_reference(params, grads_seq, lr):
+    ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = torch.optim.Adam(ps, lr=lr, betas=(0.5, 0.999))
+    for grads in grads_seq:
+        for p, g in zip(ps, grads):
+            p.grad = g.clone()
+        opt.step()
+    return [p.detach() for p in ps], opt
+
+
+@pytest.mark.parametrize("lr_drop", [False, True])
+def test_adam_multi_matches_torch_adam_and_emits_the_packs(be, lr_drop):
+    """3-step trajectory of plain ranges (odd sizes, unaligned views) and 3x3 convolution weights (one / two sources, with
+    and without data-gradient layouts) == torch.optim.Adam(betas=(0.5, 0.999)); the packed layouts written in the same
+    launch == mnk_conv3x3_pack_all of the updated weights; a learning-rate change through the device scalars is seen."""
+    g = torch.Generator().manual_seed(21)
+    convs = [(21, 18, 7, True, True), (3, 35, 0, True, False), (40, 5, 0, False, False), (70, 33, 0, True, False)]
+    plains = [1, 5, 1000, 4096, 4097, 12345]
+    flat = torch.zeros(sum(plains) + 16)
+    params, off = [], 3                                   # offset 3: views that are not 16-byte aligned
+    for n in plains:
+        params.append(torch.randn(n, generator=g))
+        off += n
+    for cout, c0, c1, _, _ in convs:
+        params.append(torch.randn(cout, c0 + c1, 1, 3, 3, generator=g) * 0.1)
+    steps = 3
+    grads_seq = [[torch.randn(p.shape, generator=g) * (10.0 ** float(torch.randint(-4, 2, (1,), generator=g)))
+                  for p in params] for _ in range(steps)]
+    lr = 2e-4
+    # device state
+    P = [be.t(p.clone()) for p in params]
+    M = [be.zeros(*p.shape) for p in params]
+    V = [be.zeros(*p.shape) for p in params]
+    G = [be.zeros(*p.shape) for p in params]
+    rows, blocks, packs = [], 0, []
+    for k, p in enumerate(params):
+        if k < len(plains):
+            nb = be.query("mnk_adam_blocks", p.numel(), 0, 0, 0, 0)
+            rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks))
+            packs.append(None)
+        else:
+            cout, c0, c1, d0, d1 = convs[k - len(plains)]
+            wf = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
+            w0 = be.empty(be.query("mnk_conv3x3_packed_floats", c0, cout, 0)) if d0 else None
+            w1 = be.empty(be.query("mnk_conv3x3_packed_floats", c1, cout, 0)) if d1 and c1 else None
+            nb = be.query("mnk_adam_blocks", 0, cout, c0, c1, 1)
+            rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), wf.data_ptr(),
+                         w0.data_ptr() if w0 is not None else 0, w1.data_ptr() if w1 is not None else 0, cout, c0, c1, blocks))
+            packs.append((wf, w0, w1))
+        assert nb > 0
+        blocks += nb
+    descs = _table(be, np.array(rows, dtype=ADAM_DESC))
+    hyper = be.t(torch.tensor([lr, 0.5, 0.999, 1e-8, 0.0, 0.0, 1.0, 0.0, 1 - 0.5, 1 - 0.999], dtype=torch.float64).float())
+    ref_ps = [torch.nn.Parameter(p.clone()) for p in params]
+    opt = torch.optim.Adam(ref_ps, lr=lr, betas=(0.5, 0.999))
+    for it, grads in enumerate(grads_seq):
+        if lr_drop and it == 2:
+            lr *= 0.1
+            opt.param_groups[0]["lr"] = lr
+            hyper[0:1].copy_(be.t(torch.tensor([lr])))
+        for k, gr in enumerate(grads):
+            G[k].copy_(be.t(gr))
+            ref_ps[k].grad = gr.clone()
+        opt.step()
+        be.call("mnk_adam_tick", hyper)
+        be.call("mnk_adam_multi", descs, len(rows), blocks, hyper)
+        be.sync()
+        for k in range(len(params)):
+            scale = float(ref_ps[k].detach().abs().max()) + 1e-12
+            assert float((P[k].cpu() - ref_ps[k].detach()).abs().max()) <= 2e-6 * scale + 4e-7 * lr / 2e-4 * (it + 1), (it, k)
+            st = opt.state[ref_ps[k]]
+            assert relerr(M[k].cpu(), st["exp_avg"]) < 1e-5 and relerr(V[k].cpu(), st["exp_avg_sq"]) < 1e-5
+    assert float(hyper.cpu()[7]) == steps
+    for k, pk in enumerate(packs):
+        if pk is None:
+            continue
+        cout, c0, c1, d0, d1 = convs[k - len(plains)]
+        wf, w0, w1 = pk
+        rf = be.empty(wf.numel())
+        r0 = be.empty(w0.numel()) if w0 is not None else None
+        r1 = be.empty(w1.numel()) if w1 is not None else None
+        be.call("mnk_conv3x3_pack_all", P[k], rf, r0, r1, cout, c0, c1)
+        be.sync()
+        for a, b in ((wf, rf), (w0, r0), (w1, r1)):
+            if a is not None:
+                assert torch.equal(a.cpu().nan_to_num(nan=7.0), b.cpu().nan_to_num(nan=7.0))
