@@ -49,6 +49,75 @@ def all_reduce_sum_(t):
     return t
 
 
+def grads_active():
+    """True when gradients must be exchanged (several ranks, or the forced single-rank exercise)."""
+    return initialized() and (tdist.get_world_size() > 1 or _FORCE)
+
+
+def all_reduce_flat_(flat, chunk_mb=64.0):
+    """Sum a flat fp32 buffer over the ranks in place, as a few large collectives (xGMI rings are per-link bound: fewer,
+    larger messages) launched back to back; the caller's stream waits for them, the host does not."""
+    step = max(int(chunk_mb * 1024 * 1024 / 4), 1)
+    works = [tdist.all_reduce(flat[i:i + step], op=tdist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), step)]
+    for w in works:
+        w.wait()
+    return flat
+
+
+def average_grads_(params, bucket_mb=64.0):
+    """Generic (user-owned loop) gradient averaging: flat buckets, one all-reduce each, p.grad re-pointed at its slice of
+    the averaged bucket (no copy back)."""
+    ws = float(world_size())
+    limit = int(bucket_mb * 1024 * 1024 / 4)
+    cur, size, buckets = [], 0, []
+    for p in params:
+        if p.grad is None:
+            continue
+        cur.append(p)
+        size += p.grad.numel()
+        if size >= limit:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    launched = []
+    for ps in buckets:
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        launched.append((tdist.all_reduce(flat, op=tdist.ReduceOp.SUM, async_op=True), flat, ps))
+    for work, flat, ps in launched:
+        work.wait()
+        flat.div_(ws)
+        off = 0
+        for p in ps:
+            k = p.grad.numel()
+            p.grad = flat[off:off + k].view_as(p.grad)
+            off += k
+    return sum(len(ps) for ps in buckets)
+
+
+_AUTO = {"installed": False}
+
+
+def install_grad_averaging():
+    """A torch.optim pre-step hook that averages the stepped optimiser's gradients over the ranks: the reference's
+    unmodified train.py (`loss.backward(); optimizer.step()`, train.py:117-118,131-132) then trains data-parallel under
+    torch.distributed.run without an edit -- what DataParallel's backward did implicitly (train.py:104-105).  Installed by
+    sync_batchnorm.DataParallelWithCallback when a process group exists.  mnk.optim.MnkAdam exchanges its own flat buffer
+    and is skipped."""
+    if _AUTO["installed"]:
+        return False
+    from torch.optim.optimizer import register_optimizer_step_pre_hook
+
+    def pre_step(opt, args, kwargs):
+        if not grads_active() or getattr(opt, "_mnk_owns_exchange", False):
+            return
+        average_grads_([p for g in opt.param_groups for p in g["params"]])
+
+    register_optimizer_step_pre_hook(pre_step)
+    _AUTO["installed"] = True
+    return True
+
+
 def combine_bn_stats(sums, count):
     """Host-side statement of the SyncBN exchange for tests: returns (global sums, global count)."""
     if active():
@@ -65,8 +134,8 @@ class GradAverager:
     ~`bucket_mb` MB -- fewer, larger collectives: xGMI rings are per-link bound.  `arm()` before backward; a
     post-accumulate-grad hook launches a bucket's asynchronous all-reduce as soon as its last gradient has been
     written, so the exchange of early buckets runs under the rest of backward; `average()` after backward launches
-    whatever is left (parameters that received no gradient are skipped), waits, divides by the world size and copies
-    the averaged values back.  Launch order is a pure function of the autograd graph, hence identical on all ranks.
+    whatever is left (parameters that received no gradient are skipped), waits, divides by the world size and points
+    every `p.grad` at its slice of the averaged bucket (no copy back).  Launch order is a pure function of the autograd graph, hence identical on all ranks.
     Replaces DataParallel's implicit reduce-add + per-forward parameter broadcast (train.py:104-105)."""
 
     def __init__(self, params, bucket_mb=64.0, overlap=None):
@@ -138,7 +207,7 @@ class GradAverager:
             off = 0
             for p in ps:
                 k = p.grad.numel()
-                p.grad.copy_(flat[off:off + k].view_as(p.grad))
+                p.grad = flat[off:off + k].view_as(p.grad)       # no copy back: the gradient now lives in the bucket
                 off += k
             n += len(ps)
         self._launched = [None] * len(self.buckets)

@@ -103,28 +103,50 @@ class TrainStep:
     every optimiser step."""
 
     def __init__(self, generator, discriminator, kp_detector, train_params, fused_adam=None, use_graph=False):
+        """fused_adam: None / True -- mnk.optim.MnkAdam (one hand-written launch per optimiser step that also emits the
+        packed conv weights of the next iteration; weight-gradient split reductions of all layers in one launch; the flat
+        gradient buffer is what the ranks all-reduce); False -- stock torch.optim.Adam (non-fused) + per-layer
+        reductions + bucketed GradAverager, the structure of round 1, kept as the comparison path of the tests."""
         self.generator, self.discriminator, self.kp_detector = generator, discriminator, kp_detector
         self.tp = train_params
         lr = train_params['lr']
-        kw = {}
-        if fused_adam is None:
-            fused_adam = next(generator.parameters()).is_cuda
-        if fused_adam:
-            kw['fused'] = True
         self.use_graph = bool(use_graph)
-        if self.use_graph:
-            kw['capturable'] = True          # step counters live on the device so the update can be captured
+        self.mnk_adam = knobs.on("MNK_HAND_ADAM") if fused_adam is None else bool(fused_adam)
         self._graph = None
         self._static_x = None
         self._static_out = None
-        self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
-        self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
-        self.opt_k = torch.optim.Adam(kp_detector.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
+        self._weights_touched = True          # packed weights must be (re)made before the next iteration
+        if self.mnk_adam:
+            from . import optim as moptim
+            self.opt_g = moptim.MnkAdam(generator.parameters(), lr=lr, betas=(0.5, 0.999))
+            self.opt_d = moptim.MnkAdam(discriminator.parameters(), lr=lr, betas=(0.5, 0.999))
+            self.opt_k = moptim.MnkAdam(kp_detector.parameters(), lr=lr, betas=(0.5, 0.999))
+            for m in (generator, discriminator, kp_detector):     # a checkpoint load invalidates the packed copies
+                m.register_load_state_dict_post_hook(lambda *a, **k: self.weights_changed())
+        else:
+            kw = {'capturable': True} if self.use_graph else {}
+            if fused_adam is None and next(generator.parameters()).is_cuda:
+                kw['fused'] = True           # MNK_HAND_ADAM=0: round 1's default optimiser
+            self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
+            self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
+            self.opt_k = torch.optim.Adam(kp_detector.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
         self.gfull = GeneratorFullModel(kp_detector, generator, discriminator, train_params)
         self.dfull = DiscriminatorFullModel(kp_detector, generator, discriminator, train_params)
-        self.avg_gk = mdist.GradAverager(list(generator.parameters()) + list(kp_detector.parameters()))
-        self.avg_d = mdist.GradAverager(list(discriminator.parameters()))
-        self.avg_k = mdist.GradAverager(list(kp_detector.parameters()))
+        self.avg_gk = _Averager(self, (self.opt_g, self.opt_k),
+                                list(generator.parameters()) + list(kp_detector.parameters()))
+        self.avg_d = _Averager(self, (self.opt_d,), list(discriminator.parameters()))
+        self.avg_k = _Averager(self, (self.opt_k,), list(kp_detector.parameters()))
+
+    def weights_changed(self):
+        """Parameters were written from outside (load_state_dict does this by itself): the packed GEMM layouts are
+        re-made before the next iteration."""
+        self._weights_touched = True
+        mops.invalidate_packed_weights()
+
+    def _begin_iteration(self):
+        # every conv parameter seen so far packed in one launch -- unless the optimiser kernel of the previous iteration
+        # already wrote the layouts (mnk.optim.MnkAdam)
+        mops.repack_registered(only_if_stale=self.mnk_adam)
 
     def step(self, x):
         """Eager iteration, or -- with use_graph -- a replay of the whole iteration captured once as a hipGraph
@@ -133,6 +155,12 @@ class TrainStep:
             return self._eager_step(x)
         if self._graph is None:
             self._capture(x)
+        if self.mnk_adam:
+            if self._weights_touched:         # e.g. a checkpoint was loaded between two replays
+                mops.repack_registered()
+            for opt in (self.opt_g, self.opt_d, self.opt_k):
+                opt.sync_scalars()            # a scheduler's new learning rate reaches the device scalars
+        self._weights_touched = False
         for k in self._static_x:
             self._static_x[k].copy_(x[k], non_blocking=True)
         self._graph.replay()
@@ -160,6 +188,7 @@ class TrainStep:
         self._graph = graph
 
     def _eager_step(self, x, set_to_none=True):
+        self._weights_touched = False
         if knobs.on("MNK_DISC_SHARED"):
             return self._eager_step_shared(x)
         return self._eager_step_two_pass(x)
@@ -177,7 +206,7 @@ class TrainStep:
              detector unless train_params['detach_kp_discriminator'].
         Same losses and gradients as the two-pass form (tests/test_step.py), one discriminator forward less."""
         tp = self.tp
-        mops.repack_registered()           # every conv parameter seen so far: packed for this iteration in one launch
+        self._begin_iteration()
         g_params = list(self.generator.parameters())
         k_params = list(self.kp_detector.parameters())
         d_params = list(self.discriminator.parameters())
@@ -260,7 +289,7 @@ class TrainStep:
         d_params = list(self.discriminator.parameters())
         for p in d_params:
             p.requires_grad_(False)
-        mops.repack_registered()           # every conv parameter seen so far: packed for this iteration in one launch
+        self._begin_iteration()
         try:
             out = self.gfull(x)
             loss_values = [v.mean() for v in out[:-2]]
@@ -290,6 +319,27 @@ class TrainStep:
             self.opt_k.step()
             self.opt_k.zero_grad()
         return [v.detach() for v in loss_values], [v.detach() for v in d_values], generated
+
+
+class _Averager:
+    """What happens between a backward pass and the optimiser steps that consume it.  torch optimisers: the bucketed,
+    overlapped mnk.dist.GradAverager.  MnkAdam: every gradient lands in the optimiser's flat buffer (one reduction launch
+    for all weight-gradient partials + one multi-tensor gather) -- the exchange itself is part of MnkAdam.step."""
+
+    def __init__(self, step, opts, params):
+        self.opts = opts
+        self.legacy = None if step.mnk_adam else mdist.GradAverager(params)
+
+    def arm(self):
+        if self.legacy is not None:
+            self.legacy.arm()
+
+    def average(self):
+        if self.legacy is not None:
+            return self.legacy.average()
+        for opt in self.opts:
+            opt.materialize_grads()
+        return 0
 
 
 class Reconstructor:

@@ -15,6 +15,8 @@ KNOBS = {
     "MNK_DISC_BATCHED": ("1", "D(generated) and D(real) of a pass as one call on the batch [generated; real]"),
     "MNK_DISC_SHARED": ("1", "one discriminator forward per training iteration (0: the reference's two passes)"),
     "MNK_FUSED_FM_LOSS": ("1", "feature-matching L1 terms reduced on the device from the NHWC activations (14.59 -> 14.26 ms/step)"),
+    "MNK_HAND_ADAM": ("1", "TrainStep default optimiser = mnk.optim.MnkAdam (one launch, emits the packed weights; deferred "
+                           "weight-gradient reductions); 0: torch.optim.Adam(fused=True) + per-layer reductions (round 1)"),
     "MNK_PACK_MULTI": ("1", "re-pack every conv weight of the model in one launch per iteration (0: one launch per layer)"),
     "MNK_DIST_GRAPH": ("1", "with a process group: capture the iteration incl. its RCCL collectives as a hipGraph"),
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),

@@ -144,20 +144,81 @@ class Concat2Fn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------
 _PACK_CACHE = {}
 _PACK_EPOCH = [0]
+_PACK_REG = {}                     # id(parameter) -> _PackEntry
+_PACK_TABLE = {"dirty": True, "descs": None, "n": 0, "tiles": 0, "entries": (), "keep": []}
+_PACK_REG_VERSION = [0]            # bumped whenever an entry (or one of its buffers) is created or dropped
 
 
 def invalidate_packed_weights():
-    """Drop the inference-side packed-weight cache.  Fused optimisers update parameters without bumping
-    `Tensor._version`, so the version check alone cannot see an optimiser step: every optimiser step in the process
-    (hook below) and every replay of a captured training iteration (mnk.engine.TrainStep) calls this."""
+    """Parameters were written behind the library's back (`p.data.copy_`, a custom update): drop every packed copy --
+    the inference-side cache (keyed by this epoch) and the freshness of the training-side registry.  Optimiser steps do
+    this by themselves (hook below), for the parameters of that optimiser."""
+    _PACK_EPOCH[0] += 1
+    for e in _PACK_REG.values():
+        e.stamp = None
+
+
+def bump_inference_epoch():
+    """the no-grad cache only (a replayed training iteration re-packs its own weights on the device)"""
     _PACK_EPOCH[0] += 1
 
 
-try:  # any torch optimiser step anywhere invalidates the cache
+def _after_optimizer_step(opt, args, kwargs):
+    """Global post-step hook of torch.optim: the stepped optimiser's parameters changed (fused optimisers do not bump
+    `Tensor._version`, so the version check alone cannot see it).  An optimiser that wrote the packed layouts itself
+    (mnk.optim.MnkAdam) hands its entries over to be stamped fresh."""
+    _PACK_EPOCH[0] += 1
+    for g in opt.param_groups:
+        for p in g["params"]:
+            e = _PACK_REG.get(id(p))
+            if e is not None:
+                e.stamp = None
+    fresh = getattr(opt, "_mnk_fresh_entries", None)
+    if fresh:
+        for e in fresh:
+            w = e.wref()
+            if w is not None and e.wptr == w.data_ptr():
+                e.stamp = w._version
+        opt._mnk_fresh_entries = ()
+
+
+try:  # any torch optimiser step anywhere invalidates what it touched
     from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
-    _reg_hook(lambda opt, args, kwargs: invalidate_packed_weights())
+    _reg_hook(_after_optimizer_step)
 except Exception:  # pragma: no cover - older torch: TrainStep still invalidates explicitly
     pass
+
+
+# ---- gradient sinks: parameters whose gradient a kernel writes straight into an optimiser-owned flat buffer ------------
+_SINKS = {}                        # id(parameter) -> weakref to the owning mnk.optim.MnkAdam
+
+
+def register_grad_sink(p, owner):
+    _SINKS[id(p)] = weakref.ref(owner)
+
+
+def unregister_grad_sinks(ids, owner_id):
+    for i in ids:
+        r = _SINKS.get(i)
+        if r is not None and (r() is None or id(r()) == owner_id):
+            _SINKS.pop(i, None)
+
+
+def sink_owner(p):
+    r = _SINKS.get(id(p))
+    return r() if r is not None else None
+
+
+def pack_registry_version():
+    return _PACK_REG_VERSION[0]
+
+
+def pack_entry_of(p):
+    """the training-side packed-weight entry of a 3x3 convolution weight, if a training forward has created one"""
+    e = _PACK_REG.get(id(p))
+    if e is not None and e.wref() is p and e.wptr == p.data_ptr():
+        return e
+    return None
 
 
 def _packed_fwd_weight(weight, cout, c0, c1):
@@ -182,12 +243,9 @@ class _PackEntry:
 
     def fresh(self, weight, meta, need):
         return (self.wref() is weight and self.wptr == weight.data_ptr() and self.meta == meta
-                and self.stamp == (weight._version, _PACK_EPOCH[0])
+                and self.stamp is not None and self.stamp == weight._version
                 and all(self.wd[i] is not None for i in (0, 1) if need[i]))
 
-
-_PACK_REG = {}                     # id(parameter) -> _PackEntry
-_PACK_TABLE = {"dirty": True, "descs": None, "n": 0, "tiles": 0, "entries": (), "keep": []}
 
 
 def _pack_entry(weight, cout, c0, c1, need):
@@ -205,11 +263,13 @@ def _pack_entry(weight, cout, c0, c1, need):
         _PACK_REG[key] = e
         weakref.finalize(weight, _drop_pack_entry, key, weakref.ref(e))
         _PACK_TABLE["dirty"] = True
+        _PACK_REG_VERSION[0] += 1
     for i, cc in enumerate((c0, c1)):
         if need[i] and e.wd[i] is None:
             e.wd[i] = torch.empty(_query("mnk_conv3x3_packed_floats", cc, cout, 0), dtype=torch.float32,
                                   device=weight.device)
             _PACK_TABLE["dirty"] = True
+            _PACK_REG_VERSION[0] += 1
     _call("mnk_conv3x3_pack_all", weight, _p(weight), _p(e.wp), _p(e.wd[0]), _p(e.wd[1]), cout, c0, c1)
     e.stamp = None            # only repack_registered() vouches for freshness: a user-owned loop packs on every call
     return e
@@ -219,15 +279,26 @@ def _drop_pack_entry(key, eref):
     if _PACK_REG.get(key) is eref():
         _PACK_REG.pop(key, None)
         _PACK_TABLE["dirty"] = True
+        _PACK_REG_VERSION[0] += 1
 
 
-def repack_registered():
+def repack_registered(only_if_stale=False):
     """Re-pack EVERY registered conv parameter in one launch (mnk_conv3x3_pack_multi) -- the start of a training
     iteration (mnk.engine.TrainStep): ~40 per-layer pack launches become one.  Parameters first seen later in the
-    iteration (and everything, when called under stream capture before the table exists) fall back to per-layer packs."""
+    iteration (and everything, when called under stream capture before the table exists) fall back to per-layer packs.
+    only_if_stale: nothing to do when every entry is still fresh (the optimiser kernel of mnk.optim wrote the packs)."""
     t = _PACK_TABLE
     if not knobs.on("MNK_PACK_MULTI"):
         return False
+    if only_if_stale and _PACK_REG:
+        stale = False
+        for e in _PACK_REG.values():
+            w = e.wref()
+            if w is not None and (e.stamp is None or e.stamp != w._version or e.wptr != w.data_ptr()):
+                stale = True
+                break
+        if not stale:
+            return False
     if t["dirty"]:
         entries = [e for e in _PACK_REG.values() if e.wref() is not None and e.wptr == e.wref().data_ptr()]
         if not entries:
@@ -253,7 +324,7 @@ def repack_registered():
     for e in t["entries"]:
         w = e.wref()
         if w is not None:
-            e.stamp = (w._version, _PACK_EPOCH[0])
+            e.stamp = w._version
     return True
 
 
@@ -347,14 +418,27 @@ class Conv3x3Fn(torch.autograd.Function):
             grads[i] = dx
         dw = None
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(weight)
-            for src, cs, cc in ((x0, 0, c0), (x1, c0, c1)):
-                if src is None:
-                    continue
+            # an optimiser of mnk.optim owns this parameter: the GEMM writes (the partials of) its gradient towards the
+            # optimiser's flat buffer and the split reduction waits for the one launch that serves every layer
+            owner = sink_owner(weight)
+            taken = [False, False]
+            if owner is not None:
+                for i, (src, cs, cc) in enumerate(((x0, 0, c0), (x1, c0, c1))):
+                    if src is not None:
+                        taken[i] = owner.reducer.wgrad(weight, src, src.shape[-1], cc, int(ups) | 2, h, w, 3, 3, 1, dy,
+                                                       ld_dy, cout, cin, cs, n, h, w)
+            rest = [(src, cs, cc) for i, (src, cs, cc) in enumerate(((x0, 0, c0), (x1, c0, c1)))
+                    if src is not None and not taken[i]]
+            if rest:
+                dw = torch.zeros_like(weight) if len(rest) < (1 + (x1 is not None)) else torch.empty_like(weight)
+            for src, cs, cc in rest:
                 nws = _query("mnk_conv3x3_wgrad_workspace_floats", n, h, w, cc, cout)
                 ws = SCRATCH.get("ws", nws, dy) if nws else None
                 _call("mnk_conv3x3_wgrad", dy, _p(src), src.shape[-1], cc, int(ups) | 2, _p(dy), ld_dy, cout, _p(dw), cin,
                       cs, n, h, w, _p(ws), nws)      # | 2: MNK_CONV_CLEAN_PADS (x and dy are acts of this module)
+            if owner is not None and dw is not None:
+                owner.add_to_sink(weight, dw)        # a further contribution before the step (slow path)
+                dw = None
         db = None
         if has_bias and ctx.needs_input_grad[3]:
             slot, _DY_SUMS[0] = _DY_SUMS[0], None
@@ -530,11 +614,17 @@ class ConvKxKFn(torch.autograd.Function):
             _call("mnk_conv2d_fwd", dy, _p(dy), dy.shape[-1], cout, None, 0, 0, 2, ho, wo, kh, kw, kh - 1 - pad, _p(wp), None,
                   None, 0, _p(dx), dx.shape[-1], n, hi, wi, cin, _p(ws), nws, None)
         if ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS[0]:
-            dw = torch.empty_like(weight)
-            nws = _query("mnk_conv2d_wgrad_workspace_floats", n, ho, wo, cin, cout, kh, kw, pad)
-            ws = SCRATCH.get("ws", nws, dy) if nws else None
-            _call("mnk_conv2d_wgrad", dy, _p(x), x.shape[-1], cin, 0, hi, wi, kh, kw, pad, _p(dy), dy.shape[-1], cout, _p(dw),
-                  cin, 0, n, ho, wo, _p(ws), nws)
+            owner = sink_owner(weight)
+            if owner is None or not owner.reducer.wgrad(weight, x, x.shape[-1], cin, 0, hi, wi, kh, kw, pad, dy,
+                                                        dy.shape[-1], cout, cin, 0, n, ho, wo):
+                dw = torch.empty_like(weight)
+                nws = _query("mnk_conv2d_wgrad_workspace_floats", n, ho, wo, cin, cout, kh, kw, pad)
+                ws = SCRATCH.get("ws", nws, dy) if nws else None
+                _call("mnk_conv2d_wgrad", dy, _p(x), x.shape[-1], cin, 0, hi, wi, kh, kw, pad, _p(dy), dy.shape[-1], cout,
+                      _p(dw), cin, 0, n, ho, wo, _p(ws), nws)
+                if owner is not None:
+                    owner.add_to_sink(weight, dw)
+                    dw = None
         if has_bias and ctx.needs_input_grad[2] and not _SKIP_PARAM_GRADS[0]:
             db = channel_sums(dy, cout)[:cout]
         return dx, dw, db, None, None, None, None, None

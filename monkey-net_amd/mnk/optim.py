@@ -1,0 +1,292 @@
+"""The optimiser side of a training iteration on the gfx950 kernels: what
+torch.optim.Adam(params, lr, betas=(0.5, 0.999)) + the implicit gradient reductions are in train.py:81-83,118-136.
+
+`MnkAdam` is a torch.optim.Optimizer (param_groups, state_dict, lr schedulers keep working) whose step is ONE kernel
+launch over a descriptor table (mnk_adam_multi) that also writes the packed GEMM layouts of every 3x3 convolution weight
+for the next iteration.  It owns three flat fp32 buffers -- gradients, exp_avg, exp_avg_sq -- with one 16-byte aligned
+slice per parameter:
+
+* gradients land in their slice ("sink") without copies: the weight-gradient GEMMs of the convolutions run with
+  MNK_WGRAD_DEFER and leave their pixel-split partials in per-layer buffers; `materialize_grads()` reduces the partials
+  of ALL layers in one launch (mnk_wgrad_reduce_multi) straight into the sinks.  The small tensors that autograd hands to
+  `p.grad` (normalisation scales, biases, 1x1 weights) are gathered with one multi-tensor copy;
+* the flat gradient buffer is what the data-parallel exchange all-reduces (RCCL over xGMI): no bucket concatenation, no
+  copy back; the division by the world size is folded into the update (`grad_scale`);
+* learning rate, step count and bias corrections live in device memory, so a captured hipGraph follows a scheduler.
+"""
+import ctypes
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import dist as mdist
+from . import ops as mops
+
+ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("wp_fwd", "<u8"),
+                      ("wp_d0", "<u8"), ("wp_d1", "<u8"), ("Cout", "<i4"), ("C0", "<i4"), ("C1", "<i4"),
+                      ("block_begin", "<i4")])
+REDUCE_DESC = np.dtype([("part", "<u8"), ("dw", "<u8"), ("layout", "<i4"), ("splits", "<i4"), ("ntaps", "<i4"),
+                        ("Cout", "<i4"), ("C", "<i4"), ("Cin_total", "<i4"), ("c_start", "<i4"), ("accumulate", "<i4"),
+                        ("block_begin", "<i4"), ("reserved", "<i4")])
+
+
+class _Plan(ctypes.Structure):
+    _fields_ = [("layout", ctypes.c_int), ("splits", ctypes.c_int), ("part_floats", ctypes.c_size_t)]
+
+
+def _device_table(rec, device, keep):
+    t = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(device)
+    keep.append(t)          # captured graphs hold raw pointers to earlier tables: never free them
+    return t
+
+
+def _capturing(device):
+    return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+
+
+class DeferredReducer:
+    """Weight-gradient GEMMs of one optimiser's convolutions with their split reductions deferred to one launch."""
+
+    def __init__(self, owner):
+        self.owner = owner
+        self.recs = {}            # (id(weight), c_start) -> dict(part, row of REDUCE_DESC without block_begin, blocks)
+        self.pending = []         # keys launched since the last flush, in launch order
+        self.done = set()         # keys launched since zero_grad (pending or written directly by the GEMM)
+        self.tables = {}          # tuple(pending keys) -> (device table, n, blocks)
+        self.keep = []
+
+    def wgrad(self, weight, x, ld_x, c, flags, hi, wi, kh, kw, pad, dy, ld_dy, cout, cin_total, c_start, n, ho, wo):
+        """Launch the GEMM of d(weight)[:, c_start:c_start+c] into the owner's sink of `weight`; True when taken."""
+        own = self.owner
+        sink = own.sink(weight)
+        key = (id(weight), c_start)
+        if key in self.done:
+            return False                                   # a second contribution before the step: the caller accumulates
+        if x.data_ptr() % 16 or dy.data_ptr() % 16:
+            return False
+        rec = self.recs.get(key)
+        shape = (n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total)
+        if rec is None or rec["shape"] != shape:
+            if _capturing(weight.device):
+                raise RuntimeError("a convolution shape first seen during hipGraph capture (run one eager iteration first)")
+            plan = _Plan()
+            rc = _lib.lib().query("mnk_conv2d_wgrad_plan", n, ho, wo, c, cout, kh, kw, pad, ld_x, ctypes.byref(plan))
+            if rc != 0:
+                raise _lib.MnkError("mnk_conv2d_wgrad_plan failed: %s" % _lib.lib().cdll.mnk_last_error().decode())
+            part = torch.empty(max(int(plan.part_floats), 1), dtype=torch.float32, device=weight.device)
+            rec = {"shape": shape, "part": part, "splits": int(plan.splits), "nfloats": int(plan.part_floats),
+                   "row": (part.data_ptr(), sink.data_ptr(), int(plan.layout), int(plan.splits), kh * kw, cout, c, cin_total,
+                           c_start, 0), "blocks": cout * ((c + 63) // 64)}
+            self.recs[key] = rec
+            self.tables.clear()
+        mops._call("mnk_conv2d_wgrad", dy, mops._p(x), ld_x, c, int(flags) | 4, hi, wi, kh, kw, pad, mops._p(dy), ld_dy, cout,
+                   mops._p(sink), cin_total, c_start, n, ho, wo, mops._p(rec["part"]), rec["nfloats"])
+        if rec["splits"] > 0:
+            self.pending.append(key)
+        self.done.add(key)
+        own._written.add(id(weight))
+        return True
+
+    def flush(self):
+        """One launch reducing every pending layer's partials into its sink."""
+        if not self.pending:
+            return 0
+        keys = tuple(self.pending)
+        tab = self.tables.get(keys)
+        dev = self.recs[keys[0]]["part"].device
+        if tab is None:
+            if _capturing(dev):
+                raise RuntimeError("the set of deferred weight gradients changed during hipGraph capture")
+            rec = np.zeros(len(keys), dtype=REDUCE_DESC)
+            blocks = 0
+            for i, k in enumerate(keys):
+                r = self.recs[k]
+                rec[i] = r["row"] + (blocks, 0)
+                blocks += r["blocks"]
+            tab = (_device_table(rec, dev, self.keep), len(keys), blocks)
+            self.tables[keys] = tab
+        mops._call("mnk_wgrad_reduce_multi", tab[0], mops._p(tab[0]), tab[1], tab[2])
+        n = len(self.pending)
+        self.pending = []
+        return n
+
+    def drop(self):
+        self.pending = []
+        self.done.clear()
+
+
+class MnkAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(params, lr, betas, eps) semantics (no amsgrad / weight decay), one kernel launch per step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super(MnkAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if len(self.param_groups) != 1:
+            raise ValueError("MnkAdam takes one parameter group (train.py:81-83 builds one optimiser per network)")
+        ps = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+        if not ps:
+            raise ValueError("no trainable parameters")
+        dev = ps[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in ps):
+            raise ValueError("MnkAdam needs fp32 parameters on one device")
+        mops._check_device(ps[0])
+        self._params = ps
+        self.device = dev
+        off, self._off = 0, {}
+        for p in ps:
+            self._off[id(p)] = off
+            off += (p.numel() + 3) // 4 * 4                  # 16-byte aligned slices: float4 path of the kernel
+        self.numel = off
+        self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._sinks = {id(p): self.flat_grad[self._off[id(p)]:self._off[id(p)] + p.numel()].view_as(p) for p in ps}
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self.hyper = torch.tensor([g["lr"], b1, b2, g["eps"], 0.0, 0.0, 1.0, 0.0, 1.0 - b1, 1.0 - b2],
+                                  dtype=torch.float64).float().to(dev)
+        self._lr_on_device = float(g["lr"])
+        self._gscale_on_device = 1.0
+        self.steps_taken = 0
+        self.reducer = DeferredReducer(self)
+        self._written = set()            # ids of parameters whose sink was written by a kernel since zero_grad
+        self._mnk_owns_exchange = True   # mnk.dist's generic pre-step gradient averaging skips this optimiser
+        self._table = None               # (key, device table, n, blocks, entries)
+        self._keep = []
+        self._mnk_fresh_entries = ()
+        for p in ps:
+            mops.register_grad_sink(p, self)
+        weakref.finalize(self, mops.unregister_grad_sinks, [id(p) for p in ps], id(self))
+
+    # ---- gradient sinks ----------------------------------------------------------------------------------------------
+    def sink(self, p):
+        return self._sinks[id(p)]
+
+    def add_to_sink(self, p, grad):
+        """slow path: a further contribution to a parameter whose sink already holds one (a parameter used by two
+        backward passes before one step, e.g. train_params['detach_kp_discriminator'] = False)."""
+        self.materialize_grads()
+        self._sinks[id(p)].add_(grad)
+        self._written.add(id(p))
+
+    def materialize_grads(self):
+        """After backward: every gradient of this optimiser's parameters in its slice of the flat buffer, `p.grad`
+        pointing at it.  Idempotent (a second call finds nothing pending and every p.grad already in place)."""
+        self.reducer.flush()
+        dsts, srcs = [], []
+        for p in self._params:
+            s = self._sinks[id(p)]
+            gr = p.grad
+            if gr is None:
+                if id(p) in self._written:
+                    p.grad = s
+                continue
+            if gr.data_ptr() == s.data_ptr():
+                continue
+            if id(p) in self._written:       # kernel-written part + an autograd part (never in the shipped configs)
+                s.add_(gr)
+            else:
+                dsts.append(s)
+                srcs.append(gr.reshape(s.shape) if gr.shape != s.shape else gr)
+                self._written.add(id(p))
+            p.grad = s
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+
+    def zero_grad(self, set_to_none=True):
+        for p in self._params:
+            p.grad = None
+        self.reducer.drop()
+        self._written.clear()
+
+    # ---- the step ----------------------------------------------------------------------------------------------------
+    def sync_scalars(self, grad_scale=None):
+        """push a changed learning rate / gradient scale to the device scalars (outside a captured graph)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_device:
+            self.hyper[0:1].copy_(torch.tensor([lr], dtype=torch.float32))
+            self._lr_on_device = lr
+        if grad_scale is not None and float(grad_scale) != self._gscale_on_device:
+            self.hyper[6:7].copy_(torch.tensor([float(grad_scale)], dtype=torch.float32))
+            self._gscale_on_device = float(grad_scale)
+
+    def _build_table(self, active):
+        rows, blocks, entries = [], 0, []
+        for p in active:
+            o = self._off[id(p)]
+            g, m, v = self.flat_grad[o:], self.flat_m[o:], self.flat_v[o:]
+            e = mops.pack_entry_of(p)
+            if e is not None:
+                cout, c0, c1 = e.meta
+                nb = _lib.lib().query("mnk_adam_blocks", 0, cout, c0, c1, 1)
+                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), e.wp.data_ptr(),
+                             e.wd[0].data_ptr() if e.wd[0] is not None else 0,
+                             e.wd[1].data_ptr() if e.wd[1] is not None else 0, cout, c0, c1, blocks))
+                entries.append(e)
+            else:
+                nb = _lib.lib().query("mnk_adam_blocks", p.numel(), 0, 0, 0, 0)
+                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks))
+            blocks += nb
+        rec = np.array(rows, dtype=ADAM_DESC)
+        return _device_table(rec, self.device, self._keep), len(rows), blocks, tuple(entries)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not used by train.py")
+        self.materialize_grads()
+        active = [p for p in self._params if p.grad is not None]
+        if not active:
+            return None
+        ws = mdist.world_size() if mdist.grads_active() else 1
+        if ws > 1 or mdist._FORCE:
+            mdist.all_reduce_flat_(self.flat_grad)          # sum over ranks; the mean is folded into the update
+        if not _capturing(self.device):
+            self.sync_scalars(1.0 / ws)
+        key = (tuple(id(p) for p in active), tuple(p.data_ptr() for p in active), mops.pack_registry_version())
+        if self._table is None or self._table[0] != key:
+            if _capturing(self.device):
+                raise RuntimeError("the optimiser's tensor set changed during hipGraph capture (run one eager iteration first)")
+            self._table = (key,) + self._build_table(active)
+        _, tab, n, blocks, entries = self._table
+        mops._call("mnk_adam_tick", self.hyper, mops._p(self.hyper))
+        mops._call("mnk_adam_multi", self.hyper, mops._p(tab), n, blocks, mops._p(self.hyper))
+        self.steps_taken += 1
+        self._mnk_fresh_entries = entries          # re-stamped by the global post-step hook (mnk.ops)
+        return None
+
+    # ---- torch.optim.Adam's state_dict format (logger.py:43-66 saves / restores the three optimisers) --------------
+    def _views(self, p):
+        o = self._off[id(p)]
+        return self.flat_m[o:o + p.numel()].view_as(p), self.flat_v[o:o + p.numel()].view_as(p)
+
+    def state_dict(self):
+        step = float(self.hyper[7].item())
+        for p in self._params:
+            m, v = self._views(p)
+            self.state[p] = {"step": torch.tensor(step), "exp_avg": m, "exp_avg_sq": v}
+        sd = super(MnkAdam, self).state_dict()
+        self.state.clear()
+        for st in sd["state"].values():
+            st["exp_avg"] = st["exp_avg"].clone()
+            st["exp_avg_sq"] = st["exp_avg_sq"].clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super(MnkAdam, self).load_state_dict(state_dict)
+        step = 0.0
+        for p in self._params:
+            st = self.state.get(p)
+            if not st:
+                continue
+            m, v = self._views(p)
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            step = max(step, float(st["step"]))
+        self.state.clear()
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self.hyper.copy_(torch.tensor([g["lr"], b1, b2, g["eps"], 0.0, 0.0, self._gscale_on_device, step, 1.0 - b1,
+                                       1.0 - b2], dtype=torch.float64).float())
+        self._lr_on_device = float(g["lr"])

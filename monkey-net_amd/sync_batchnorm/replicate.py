@@ -6,6 +6,8 @@ parameters on every forward and runs one thread per GPU (train.py:104-105).  Her
 replica and its shard of the batch, so the wrapper only (a) moves the inputs to this rank's device and (b) calls the
 wrapped module; statistics and gradients are exchanged by `mnk.dist` (RCCL).  The class keeps the reference's name,
 constructor and call signature so train.py / reconstruction.py / transfer.py / demo.py run unchanged."""
+import warnings
+
 import torch
 from torch import nn
 
@@ -27,6 +29,16 @@ class DataParallelWithCallback(nn.Module):
         self.dim = dim
         self.device_ids = list(device_ids) if device_ids is not None else None
         self.output_device = output_device
+        from mnk import dist as mdist
+        if mdist.initialized() and mdist.world_size() > 1:
+            # one process per GPU under torch.distributed.run: SyncBN statistics are exchanged inside the BN wrappers
+            # (mnk.dist), and any optimiser's gradients are averaged right before its step -- train.py runs unchanged
+            mdist.install_grad_averaging()
+        elif self.device_ids is not None and len(self.device_ids) > 1:
+            warnings.warn("DataParallelWithCallback(device_ids=%r): this implementation runs ONE process per GPU -- launch "
+                          "the script under `python -m torch.distributed.run --nproc-per-node %d ...` (monkey-net_amd/"
+                          "run_reference.py joins the process group); without a process group the whole batch runs on "
+                          "%s alone." % (self.device_ids, len(self.device_ids), self._device()), stacklevel=2)
 
     def _device(self):
         for p in self.module.parameters():

@@ -20,7 +20,7 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _worker(rank, world, port, emu_path, out_dir):
+def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,7 +37,7 @@ def _worker(rank, world, port, emu_path, out_dir):
         m.load_state_dict(sd)
     src, drv = cases.smooth_pair(4, 32, 32)
     x = {"source": mdist.shard_batch(src).contiguous(), "video": mdist.shard_batch(drv).contiguous()}
-    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=False)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=mnk_adam)
     g_losses, d_losses, _ = step.step(x)
     # the losses are per-shard means: average them over ranks like the reference's gather + mean (train.py:114)
     lv = torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64)
@@ -56,7 +56,7 @@ def _worker(rank, world, port, emu_path, out_dir):
     dist.destroy_process_group()
 
 
-def _single(emu_path):
+def _single(emu_path, mnk_adam=False):
     _setup_paths()
     from mnk import _lib, engine
     from oracle import cases
@@ -69,7 +69,7 @@ def _single(emu_path):
         cases.perturb_state_dict(sd, 7 + i)
         m.load_state_dict(sd)
     src, drv = cases.smooth_pair(4, 32, 32)
-    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=False)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=mnk_adam)
     g_losses, d_losses, _ = step.step({"source": src, "video": drv})
     out = {"losses": torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64),
            "gen": gen.state_dict(), "kp": kpd.state_dict(), "disc": disc.state_dict()}
@@ -77,13 +77,15 @@ def _single(emu_path):
     return out
 
 
-def test_two_ranks_equal_one_rank_big_batch():
+@pytest.mark.parametrize("mnk_adam", [False, True], ids=["torch-adam+GradAverager", "mnk-adam-flat-buffer"])
+def test_two_ranks_equal_one_rank_big_batch(mnk_adam):
     from conftest import emu_library_path
+    from oracle import cases
     emu = emu_library_path()
-    ref = _single(emu)
+    ref = _single(emu, mnk_adam)
     with tempfile.TemporaryDirectory() as tmp:
-        port = 29500 + (os.getpid() % 2000)
-        mp.spawn(_worker, args=(2, port, emu, tmp), nprocs=2, join=True)
+        port = 29500 + (os.getpid() % 2000) + (1 if mnk_adam else 0)
+        mp.spawn(_worker, args=(2, port, emu, tmp, mnk_adam), nprocs=2, join=True)
         r0 = torch.load(os.path.join(tmp, "rank0.pt"), weights_only=False)
         r1 = torch.load(os.path.join(tmp, "rank1.pt"), weights_only=False)
     # ranks stay bit-identical replicas after the step (same averaged gradients, same all-reduced BN statistics)
@@ -92,10 +94,17 @@ def test_two_ranks_equal_one_rank_big_batch():
             assert torch.equal(r0[key][k], r1[key][k]), (key, k)
     # and the 2 x B/2 job matches the 1 x B job: losses, running statistics (SyncBN) and updated parameters
     assert float((r0["losses"] - ref["losses"]).abs().max()) < 5e-5 * float(ref["losses"].abs().max() + 1)
-    for key in ("gen", "kp"):
+    lr = cases.TINY2["train_params"]["lr"]
+    for key in ("gen", "kp", "disc"):
         for k, v in ref[key].items():
             if "running" in k:
                 assert float((r0[key][k] - v).abs().max()) < 1e-5 * (1 + float(v.abs().max())), (key, k)
+            elif v.is_floating_point() and not cases.is_noise_bias(k):
+                # updated parameters: one Adam step moves every element by ~lr * sign(gradient); the sum over two shards
+                # differs from the one-batch sum by rounding, which can flip the sign of a near-zero gradient element
+                d = (r0[key][k] - v).abs()
+                assert float(d.max()) <= 2.1 * lr, (key, k, float(d.max()))
+                assert float((d > 0.05 * lr).float().mean()) < 0.03, (key, k, float((d > 0.05 * lr).float().mean()))
 
 
 def test_grad_averager_and_shard_batch_single_process():
@@ -141,3 +150,48 @@ def _bucket_worker(rank, world, port, out_dir):
 def test_bucketed_overlapped_gradient_averaging():
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_bucket_worker, args=(2, port, None), nprocs=2, join=True)
+
+
+def _auto_worker(rank, world, port, out_dir):
+    """the reference's unmodified loop shape: loss.backward(); optimizer.step() -- averaging installed by the wrapper"""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sync_batchnorm import DataParallelWithCallback
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
+    ref.load_state_dict(net.state_dict())
+    par = DataParallelWithCallback(net, device_ids=[0, 1])        # a process group exists: installs the pre-step averaging
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(3)
+    full = torch.randn(8, 6, generator=g)
+    for _ in range(2):
+        opt.zero_grad()
+        par(full[rank * 4:(rank + 1) * 4]).mean().backward()
+        opt.step()
+    ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    for _ in range(2):      # the whole batch on one rank (its gradients are the same on both ranks: averaging is a no-op)
+        ropt.zero_grad()
+        ref(full).mean().backward()
+        ropt.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, atol=1e-6), (a, b)
+    dist.destroy_process_group()
+
+
+def test_unmodified_loop_gets_gradient_averaging_from_the_wrapper():
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_auto_worker, args=(2, port, None), nprocs=2, join=True)
+
+
+def test_wrapper_warns_about_device_ids_without_a_process_group():
+    _setup_paths()
+    import warnings
+    from sync_batchnorm import DataParallelWithCallback
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        DataParallelWithCallback(torch.nn.Linear(2, 2), device_ids=[0, 1, 2, 3])
+        DataParallelWithCallback(torch.nn.Linear(2, 2), device_ids=[0])
+        DataParallelWithCallback(torch.nn.Linear(2, 2))
+    assert len(w) == 1 and "torch.distributed.run" in str(w[0].message)
