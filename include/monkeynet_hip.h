@@ -209,8 +209,8 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
  * mnk_conv3x3_wgrad only run the GEMM and leave its partials in `ws`; mnk_conv2d_wgrad_plan says in which layout and how
  * many floats (`ws` must then be a buffer that lives until the reduction); mnk_wgrad_reduce_multi reduces the partials
  * of ANY number of layers in one launch, each into its slice dw[co][c_start + ci][tap] of a (Cout, Cin_total, kh, kw)
- * parameter gradient.  Descriptor table in device memory, sorted by block_begin; layer i owns blocks
- * [block_begin, block_begin + Cout * ceil(C / 64)); total_blocks = their sum.  Deterministic summation order. */
+ * parameter gradient.  Descriptor table in device memory, sorted by block_begin; layer i owns
+ * mnk_wgrad_reduce_blocks(splits, Cout, C) blocks from block_begin; total_blocks = their sum.  Deterministic order. */
 #define MNK_WGRAD_DEFER 4
 typedef struct MnkWgradPlan {
     int layout;          /* 0: tap-major partials [split][tap][Cout][C]; 1: parameter-major [split][Cout][C * ntaps] */
@@ -226,6 +226,7 @@ typedef struct MnkWgradReduceDesc {
     int block_begin;
     int reserved;
 } MnkWgradReduceDesc;
+int mnk_wgrad_reduce_blocks(int splits, int Cout, int C);
 int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream);
 
 /* ---- optimiser: torch.optim.Adam(lr, betas=(0.5, 0.999)) of train.py:81-83,118-136 for EVERY

@@ -1633,41 +1633,52 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* 
 }
 
 // ---- split reductions of MANY layers in one launch (deferred weight-gradient reductions of a whole backward pass) ----
-// Block b belongs to the layer whose [block_begin, block_begin + Cout * ceil(C / 64)) range contains it (binary search
-// over the descriptor table in device memory) and owns one output row co and one 64-channel ci tile, i.e. the
-// 64 * ntaps contiguous gradient floats dw[co][(c_start + ci0 .. +64) * ntaps + tap].  Threads = 4 split groups x 64
-// channels (tap-major partials) or 4 split groups x 64 consecutive words (parameter-major partials); group g sums the
-// splits g, g+4, ... with `ntaps` independent chains in flight, the groups are combined through LDS in a fixed order
-// (deterministic), and the (tap, ci) -> (ci, tap) transposition of the tap-major form happens on the way out.
+// Block b belongs to the layer whose [block_begin, block_begin + blocks) range contains it -- found with ONE coalesced
+// read of the table's block_begin column and an LDS count (a binary search over device memory costs ~6 dependent loads per
+// block, several microseconds on blocks that move 5 KB) -- and owns a 64-channel ci tile of
+//   * one output row co, when the layer has >= 4 pixel splits: threads = 4 split groups x 64 channels, group g sums the
+//     splits g, g+4, ... with `ntaps` independent chains in flight, the groups are combined through LDS in a fixed order;
+//   * four output rows, when it has fewer (the big-weight layers, where the "reduction" is mostly the (tap, ci) ->
+//     (ci, tap) transposition): thread group g owns row 4 * q + g and sums all its splits.
+// blocks = ceil(Cout / rows_per_block) * ceil(C / 64), rows_per_block = splits < 4 ? 4 : 1.  Deterministic.
+__device__ __forceinline__ int find_desc(const int* begins_stride_bytes_base, int stride_ints, int n, int b, int* sh) {
+    // sh: one LDS int; every thread of the block returns the index of the last descriptor with block_begin <= b
+    if (threadIdx.x == 0) *sh = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        if (i < n && begins_stride_bytes_base[(long)i * stride_ints] <= b) atomicAdd(sh, 1);    // LDS atomic, <= n per block
+    }
+    __syncthreads();
+    return *sh - 1;
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradReduceDesc* __restrict__ descs, int n) {
     __shared__ float sm[4][16 * 64 + 16];
-    int lo = 0, hi = n - 1;
+    __shared__ int sh_idx;
     const int b = blockIdx.x;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].block_begin <= b)
-            lo = mid;
-        else
-            hi = mid - 1;
-    }
-    const MnkWgradReduceDesc d = descs[lo];
+    const int di = find_desc(&descs[0].block_begin, (int)(sizeof(MnkWgradReduceDesc) / sizeof(int)), n, b, &sh_idx);
+    const MnkWgradReduceDesc d = descs[di];
     const int local = b - d.block_begin;
     const int ctiles = (d.C + 63) / 64;
-    const int co = local / ctiles, ci0 = (local - co * ctiles) * 64;
+    const int rpb = d.splits < 4 ? 4 : 1;
+    const int rq = local / ctiles, ci0 = (local - rq * ctiles) * 64;
     const int t = threadIdx.x, g = t >> 6, c = t & 63;
     const int ntaps = d.ntaps;
     const int cw = d.C - ci0 < 64 ? d.C - ci0 : 64;          // channels of this tile
-    const int lim = cw * ntaps;                              // gradient floats of this tile
-    float* dst = d.dw + ((long)co * d.Cin_total + d.c_start + ci0) * ntaps;
+    const int lim = cw * ntaps;                              // gradient floats of this tile (per row)
+    const int co = rpb == 1 ? rq : rq * 4 + g;               // the row this thread group reads
+    const bool row_ok = co < d.Cout;
     if (d.layout == 0) {
         // part[s][tap][co][ci]
         const long plane = (long)d.Cout * d.C, sstride = (long)ntaps * plane;
-        const bool ok = c < cw;
-        const float* src = d.part + (long)co * d.C + ci0 + (ok ? c : 0);
+        const bool ok = c < cw && row_ok;
+        const float* src = d.part + (long)(row_ok ? co : 0) * d.C + ci0 + (ok ? c : 0);
         float acc[16];
 #pragma unroll
         for (int tp = 0; tp < 16; ++tp) acc[tp] = 0.f;
-        for (int sp = g; sp < d.splits; sp += 4) {
+        const int s0 = rpb == 1 ? g : 0, sstep = rpb == 1 ? 4 : 1;
+        for (int sp = s0; sp < d.splits; sp += sstep) {
             const float* ps = src + (long)sp * sstride;
 #pragma unroll
             for (int tp = 0; tp < 16; ++tp)
@@ -1679,22 +1690,29 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
     } else {
         // part[s][co][ci * ntaps + tap]
         const long NT = (long)d.C * ntaps, sstride = (long)d.Cout * NT;
-        const float* src = d.part + (long)co * NT + (long)ci0 * ntaps;
+        const float* src = d.part + (long)(row_ok ? co : 0) * NT + (long)ci0 * ntaps;
+        const int s0 = rpb == 1 ? g : 0, sstep = rpb == 1 ? 4 : 1;
         for (int idx = c; idx < lim; idx += 64) {
             float v0 = 0.f, v1 = 0.f;
-            int sp = g;
-            for (; sp + 4 < d.splits; sp += 8) {
+            int sp = s0;
+            for (; sp + sstep < d.splits; sp += 2 * sstep) {
                 v0 += src[(long)sp * sstride + idx];
-                v1 += src[(long)(sp + 4) * sstride + idx];
+                v1 += src[(long)(sp + sstep) * sstride + idx];
             }
             if (sp < d.splits) v0 += src[(long)sp * sstride + idx];
-            sm[g][idx] = v0 + v1;
+            sm[g][idx] = row_ok ? v0 + v1 : 0.f;
         }
     }
     __syncthreads();
-    for (int idx = t; idx < lim; idx += 256) {
-        const float v = (sm[0][idx] + sm[1][idx]) + (sm[2][idx] + sm[3][idx]);
-        dst[idx] = d.accumulate ? dst[idx] + v : v;
+    if (rpb == 1) {
+        float* dst = d.dw + ((long)rq * d.Cin_total + d.c_start + ci0) * ntaps;
+        for (int idx = t; idx < lim; idx += 256) {
+            const float v = (sm[0][idx] + sm[1][idx]) + (sm[2][idx] + sm[3][idx]);
+            dst[idx] = d.accumulate ? dst[idx] + v : v;
+        }
+    } else if (row_ok) {
+        float* dst = d.dw + ((long)co * d.Cin_total + d.c_start + ci0) * ntaps;
+        for (int idx = c; idx < lim; idx += 64) dst[idx] = d.accumulate ? dst[idx] + sm[g][idx] : sm[g][idx];
     }
 }
 
@@ -2451,6 +2469,11 @@ int mnk_conv2d_wgrad_plan(int N, int Ho, int Wo, int C, int Cout, int kh, int kw
         plan->part_floats = (size_t)p.splits * Cout * ntaps * C;
     }
     return MNK_OK;
+}
+
+int mnk_wgrad_reduce_blocks(int splits, int Cout, int C) {
+    if (splits <= 0 || Cout <= 0 || C <= 0) return 0;
+    return ceil_div(Cout, splits < 4 ? 4 : 1) * ceil_div(C, 64);
 }
 
 int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream) {

@@ -49,16 +49,18 @@ constexpr int PLAIN_PER_BLOCK = 4096;       // floats of a plain range handled b
 __global__ void __launch_bounds__(256) adam_multi_kernel(const MnkAdamDesc* __restrict__ descs, int n,
                                                          const float* __restrict__ hyper) {
     __shared__ float T[16 * (16 * 17 + 1)];
-    int lo = 0, hi = n - 1;
+    __shared__ int sh_idx;
     const int b = blockIdx.x;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].block_begin <= b)
-            lo = mid;
-        else
-            hi = mid - 1;
+    // the block's descriptor: one coalesced read of the block_begin column + an LDS count (a binary search over device
+    // memory is ~8 dependent loads per block)
+    if (threadIdx.x == 0) sh_idx = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        if (i < n && descs[i].block_begin <= b) atomicAdd(&sh_idx, 1);      // LDS atomic, <= n per block
     }
-    const MnkAdamDesc d = descs[lo];
+    __syncthreads();
+    const MnkAdamDesc d = descs[sh_idx - 1];
     const int local = b - d.block_begin;
     Hyper h;
     h.b2 = hyper[2], h.eps = hyper[3], h.step_size = hyper[4], h.bc2_sqrt = hyper[5], h.gscale = hyper[6];

@@ -346,8 +346,9 @@ class Reconstructor:
     """Batched eval-mode frame generation -- what reconstruction.py:12-25,57-61 / transfer.py:65-79 do frame by frame:
     key-points of the source and of every driving frame, then one generator call per (source, driving) pair.  In eval
     mode BatchNorm uses running statistics, so frames are independent and (video, frame) folds into the batch.  With
-    use_graph the whole forward (kp detector x2 + generator, ~250 launches) is captured once as a hipGraph and
-    replayed per batch (BASELINE config 5: "hipGraph-captured generator forward")."""
+    use_graph the whole forward (kp detector x2 + generator, ~250 launches + the weight packs) is captured once as a
+    hipGraph and replayed per batch (BASELINE config 5: "hipGraph-captured generator forward").  The returned tensors of
+    the graph form are static buffers that the next call overwrites: clone what must survive."""
 
     def __init__(self, kp_detector, generator, use_graph=False):
         self.kp_detector, self.generator = kp_detector.eval(), generator.eval()
@@ -355,7 +356,6 @@ class Reconstructor:
         self._graph = None
         self._static_in = None
         self._static_out = None
-        self._epoch = -1
 
     @torch.no_grad()
     def _forward(self, source, driving):
@@ -368,9 +368,10 @@ class Reconstructor:
     def __call__(self, source, driving):
         if not self.use_graph:
             return self._forward(source, driving)
-        if (self._graph is None or self._static_in[0].shape != source.shape
-                or self._epoch != mops._PACK_EPOCH[0]):    # parameters were updated: the captured packs are stale
-            self._epoch = mops._PACK_EPOCH[0]
+        if self._graph is None or self._static_in[0].shape != source.shape:
+            # the captured forward contains its own weight-pack launches (ops._packed_fwd_weight under capture), so a
+            # replay always runs on the live parameters: optimiser steps, load_state_dict and in-place writes need no
+            # re-capture
             self._static_in = (source.clone(), driving.clone())
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -222,18 +222,27 @@ def pack_entry_of(p):
 
 
 def _packed_fwd_weight(weight, cout, c0, c1):
-    """Packed [Cout][chunk][tap][16] copy of a conv weight for NO-GRAD forwards (inference loops), cached per
-    parameter version and optimiser epoch.  Training forwards never use this cache (they take the registry entry
-    of _pack_entry: re-packed once per iteration by repack_registered(), or per call in a user-owned loop)."""
-    key = (id(weight), weight.device)
-    ver = (weight._version, _PACK_EPOCH[0])
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[1] == (cout, c0, c1) and hit[3] is weight:
-        return hit[2]
+    """Packed [Cout][chunk][tap][16] copy of a conv weight for NO-GRAD forwards (inference loops), cached per parameter
+    version, storage and optimiser epoch.  Training forwards never use this cache (they take the registry entry of
+    _pack_entry: re-packed once per iteration by repack_registered(), or per call in a user-owned loop).
+    Under hipGraph capture the cache is bypassed: the pack launch is recorded INTO the graph (its buffer lives in the
+    graph's memory pool), so every replay re-packs from the live parameter -- a replay after load_state_dict / an
+    in-place write can never combine old packed weights with new normalisation parameters."""
     n = _query("mnk_conv3x3_packed_floats", cout, c0, c1)
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+        wp = torch.empty(n, dtype=torch.float32, device=weight.device)
+        _call("mnk_conv3x3_pack_fwd", weight, _p(weight), _p(wp), cout, c0, c1)
+        return wp
+    key = (id(weight), weight.device)
+    ver = (weight._version, _PACK_EPOCH[0], weight.data_ptr())
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[1] == (cout, c0, c1) and hit[3]() is weight:
+        return hit[2]
     wp = torch.empty(n, dtype=torch.float32, device=weight.device)
     _call("mnk_conv3x3_pack_fwd", weight, _p(weight), _p(wp), cout, c0, c1)
-    _PACK_CACHE[key] = (ver, (cout, c0, c1), wp, weight)
+    if hit is None:
+        weakref.finalize(weight, _PACK_CACHE.pop, key, None)      # no entry (and no packed buffer) outlives its parameter
+    _PACK_CACHE[key] = (ver, (cout, c0, c1), wp, weakref.ref(weight))
     return wp
 
 

@@ -78,7 +78,7 @@ class DeferredReducer:
             part = torch.empty(max(int(plan.part_floats), 1), dtype=torch.float32, device=weight.device)
             rec = {"shape": shape, "part": part, "splits": int(plan.splits), "nfloats": int(plan.part_floats),
                    "row": (part.data_ptr(), sink.data_ptr(), int(plan.layout), int(plan.splits), kh * kw, cout, c, cin_total,
-                           c_start, 0), "blocks": cout * ((c + 63) // 64)}
+                           c_start, 0), "blocks": _lib.lib().query("mnk_wgrad_reduce_blocks", int(plan.splits), cout, c)}
             self.recs[key] = rec
             self.tables.clear()
         mops._call("mnk_conv2d_wgrad", dy, mops._p(x), ld_x, c, int(flags) | 4, hi, wi, kh, kw, pad, mops._p(dy), ld_dy, cout,

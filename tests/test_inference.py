@@ -59,3 +59,58 @@ def test_hipgraph_replay_equals_eager_launches():
         torch.cuda.synchronize()
         assert torch.equal(a["video_prediction"], b["video_prediction"]), it   # same kernels, same order: bit-equal
         assert torch.equal(a["kp_driving_mean"], b["kp_driving_mean"])
+
+
+@pytest.mark.gpu
+def test_graphed_reconstructor_follows_a_second_checkpoint():
+    """Evaluating another checkpoint with the SAME captured Reconstructor (load_state_dict between two replays): the
+    replay must run on the new convolution weights together with the new normalisation parameters -- the captured
+    forward re-packs from the live parameters (round-1 advisory: it replayed stale packed weights)."""
+    from conftest import Backend
+    from mnk import engine
+    be = Backend("hip")
+    gold = load("bair")
+    gen, kpd = _models(gold, be)
+    g = torch.Generator().manual_seed(4)
+    src = torch.rand(8, 3, 1, 64, 64, generator=g).to(be.device)
+    drv = torch.rand(8, 3, 1, 64, 64, generator=g).to(be.device)
+    graphed = engine.Reconstructor(kpd, gen, use_graph=True)
+    first = {k: v.clone() for k, v in graphed(src, drv).items()}
+    for seed, m in ((31, gen), (32, kpd)):                   # "checkpoint 2": every tensor changes
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        cases.perturb_state_dict(sd, seed, scale=0.05)
+        m.load_state_dict(sd)
+    second = {k: v.clone() for k, v in graphed(src, drv).items()}
+    fresh = engine.Reconstructor(kpd, gen, use_graph=False)(src, drv)
+    torch.cuda.synchronize()
+    assert float((second["video_prediction"] - first["video_prediction"]).abs().max()) > 1e-3
+    assert torch.equal(second["video_prediction"], fresh["video_prediction"])
+    assert torch.equal(second["kp_driving_mean"], fresh["kp_driving_mean"])
+
+
+def test_no_grad_pack_cache_sees_replaced_storage(be):
+    """`p.data = other` keeps the Parameter object and its version counter: the inference-side packed-weight cache is
+    also keyed by the storage address (round-1 advisory), and holds the parameter only weakly."""
+    import gc
+    import torch.nn.functional as F
+    from mnk import ops
+    torch.manual_seed(7)
+    w = torch.nn.Parameter(be.t(torch.randn(5, 4, 1, 3, 3) * 0.3))
+    x = torch.rand(1, 4, 1, 6, 6)
+    xa = ops.to_act(be.t(x))
+
+    def run():
+        with torch.no_grad():
+            y, _ = ops.conv3x3(xa, 4, w)
+        return ops.from_act(y, 5, 1).cpu()
+
+    def ref():
+        return F.conv2d(x[:, :, 0].double(), w.detach().cpu()[:, :, 0].double(), padding=1).float().unsqueeze(2)
+
+    assert float((run() - ref()).abs().max()) < 1e-5
+    w.data = be.t(torch.randn(5, 4, 1, 3, 3) * 0.3)
+    assert float((run() - ref()).abs().max()) < 1e-5, "stale packed weights after p.data = ..."
+    n0 = len(ops._PACK_CACHE)
+    del w
+    gc.collect()
+    assert len(ops._PACK_CACHE) == n0 - 1

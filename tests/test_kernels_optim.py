@@ -70,7 +70,7 @@ def test_deferred_wgrad_of_many_layers_reduced_in_one_launch(be, accumulate):
             if plan.splits > 0:
                 rows.append((part.data_ptr(), DW.data_ptr(), plan.layout, plan.splits, kh * kw, cout, c_cnt, c0 + c1,
                              c_start, accumulate, blocks, 0))
-                blocks += cout * ((c_cnt + 63) // 64)
+                blocks += be.query("mnk_wgrad_reduce_blocks", plan.splits, cout, c_cnt)
             else:
                 direct += 1
                 if accumulate:      # the direct form overwrites: the caller adds (rare path, not the kernel's business)

@@ -105,4 +105,5 @@ def test_identity_deformation(be):
     out = gen(src, kp_driving=kpv, kp_source=kpv)
     be.sync()
     assert out["video_prediction"].shape == (2, 3, 1, 16, 16)
-    assert _m(out["video_deformed"], src) < 1e-6            # identity grid, align_corners=True: exact resampling
+    assert _m(out["video_deformed"], src) < 4e-6            # identity grid, align_corners=True: the sample points are the
+                                                            # pixel centres up to the rounding of 2*j/(w-1)-1 (1.5e-6 measured)
