@@ -229,6 +229,30 @@ typedef struct MnkWgradReduceDesc {
 int mnk_wgrad_reduce_blocks(int splits, int Cout, int C);
 int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream);
 
+/* ---- grouped weight gradients (new): the tap-major GEMMs of MANY layers in one launch per tile shape.  Launched one by
+ * one, each layer must be cut into 2..86 pixel splits to fill 256 CUs and its split partials cross HBM twice (1.3 GB per
+ * iteration on BASELINE configs[1]); launched together, the tiles of all layers fill the chip and a layer is only split
+ * where its pixel range is long (~1024-pixel chunks; 0.2 GB).  Protocol: fill the geometry of n jobs (one per layer and
+ * source; pointers may still be NULL) -> mnk_wgrad_grouped_plan sets `variant` (< 0: not a tap-major shape -- run that
+ * layer through mnk_conv2d_wgrad), `splits` and `part_floats` -> give every job its operands and a `part` buffer ->
+ * mnk_wgrad_grouped_build serialises the launch tables into HOST memory (mnk_wgrad_grouped_table_bytes(n)); copy them
+ * to the device -> mnk_wgrad_grouped_launch(device copy, host copy).  The partials are tap-major [split][tap][Cout][C]:
+ * reduce them with mnk_wgrad_reduce_multi (layout 0, `splits` as planned). */
+typedef struct MnkWgradJob {
+    const float* x;
+    const float* dy;
+    float* part;
+    size_t part_floats;                      /* out (plan) */
+    int ld_x, C, flags, ld_dy, Cout;         /* flags: MNK_CONV_UPSAMPLED | MNK_CONV_CLEAN_PADS */
+    int N, Ho, Wo, Hi, Wi, kh, kw, pad;
+    int variant, splits;                     /* out (plan) */
+    int reserved;
+} MnkWgradJob;
+int mnk_wgrad_grouped_plan(MnkWgradJob* jobs, int n);
+size_t mnk_wgrad_grouped_table_bytes(int n);
+int mnk_wgrad_grouped_build(const MnkWgradJob* jobs, int n, void* host_table, size_t table_bytes);
+int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, void* stream);
+
 /* ---- optimiser: torch.optim.Adam(lr, betas=(0.5, 0.999)) of train.py:81-83,118-136 for EVERY
  * tensor of a model in one launch.  Formula of torch/optim/adam.py::_single_tensor_adam (no amsgrad / weight decay) in
  * fp32.  `hyper` = 10 floats in DEVICE memory [lr, beta1, beta2, eps, lr / (1 - beta1^t), sqrt(1 - beta2^t), grad_scale, t,

@@ -1296,6 +1296,20 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args 
     }
 }
 
+// index of the last record whose block_begin (an int column with `stride_ints` between rows) is <= b
+__device__ __forceinline__ int find_desc(const int* begins_stride_bytes_base, int stride_ints, int n, int b, int* sh) {
+    // sh: one LDS int; every thread of the block returns the index of the last descriptor with block_begin <= b
+    if (threadIdx.x == 0) *sh = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        if (i < n && begins_stride_bytes_base[(long)i * stride_ints] <= b) atomicAdd(sh, 1);    // LDS atomic, <= n per block
+    }
+    __syncthreads();
+    return *sh - 1;
+}
+
+
 // ---- weight gradient, tap-major form (the default for C >= 16) ---------------------------------------------------
 // The same pipeline as the forward kernel with K = pixels: one block owns a BM (co) x BN (ci) tile of ONE tap and a
 // range of pixels.  Per 16-pixel K step both operands are plain coalesced float4 reads along channels -- dy rows
@@ -1326,7 +1340,7 @@ struct WgradTapArgs {
 // the channel count get bit 30 added to their offset -- and the (h, w) of a row is advanced incrementally (16 pixels
 // per step wrap at most once), so a row costs ~10 vector instructions per step instead of ~35.
 template <int BM, int BN, int WM, int WN, int MODE>
-__global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs a) {
+__device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int bx, const int by, const int split) {
     static_assert(WM * WN == 4, "4 waves per block");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -1338,12 +1352,9 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];   // x-shifted [pixel][ci]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    int bx, by;
-    xcd_tile(a.xcd, bx, by);
     const int co0 = bx * BM;
     const int tap = by / a.gn;
     const int ci0 = (by - tap * a.gn) * BN;
-    const int split = blockIdx.z;
     const long p_begin = (long)split * a.pix_per_split;
     long p_end = p_begin + a.pix_per_split;
     if (p_end > a.M) p_end = a.M;
@@ -1547,6 +1558,39 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs 
         emit(FalseTag{});
 }
 
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs a) {
+    int bx, by;
+    xcd_tile(a.xcd, bx, by);
+    wgrad_tap_body<BM, BN, WM, WN, MODE>(a, bx, by, (int)blockIdx.z);
+}
+
+// ---- the same GEMM for MANY layers in one launch ("grouped"): a block looks up its job (layer, source), its tile and
+// its pixel chunk.  A backward pass has ~50 tap-major weight-gradient GEMMs of 27..650 tiles each; launched one by one,
+// every layer has to be cut into 2..86 pixel splits to fill 256 CUs, and the split partials (1.3 GB per iteration on
+// BASELINE configs[1]) are written by the GEMMs and read again by the reductions.  Launched together the tiles of all
+// layers fill the chip, so a layer is only split where its pixel range is long (chunks of ~1024 pixels): 0.2 GB.
+struct TapJobRec {
+    WgradTapArgs a;
+    int gm, gnt, splits, block_begin;     // tile grid (gnt = ci tiles x taps), pixel splits; blocks = gm * gnt * splits
+};
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_grouped_kernel(const TapJobRec* __restrict__ recs, int n) {
+    __shared__ int sh_idx;
+    const int b = blockIdx.x;
+    const int di = find_desc(&recs[0].block_begin, (int)(sizeof(TapJobRec) / sizeof(int)), n, b, &sh_idx);
+    // the record is wave-uniform: keep it in scalar registers (copied field by field through readfirstlane by the compiler
+    // when it can prove uniformity; `di` comes from LDS, so say it explicitly)
+    const TapJobRec* __restrict__ rp = recs + __builtin_amdgcn_readfirstlane(di);
+    const WgradTapArgs a = rp->a;
+    const int local = b - rp->block_begin;
+    const int gm = rp->gm, gnt = rp->gnt;
+    const int bx = local % gm, rest = local / gm;
+    const int by = rest % gnt, split = rest / gnt;
+    wgrad_tap_body<BM, BN, WM, WN, MODE>(a, bx, by, split);
+}
+
 // dw[co][(c_start + ci) * ntaps + tap] = sum_s part[s][tap][co][ci]: one block per (64-channel ci tile, co row);
 // reads are coalesced along ci with four independent split-sum chains per element (loads in flight), the
 // (tap, ci) -> (ci, tap) transposition goes through LDS, writes are contiguous runs of 64 * ntaps floats.
@@ -1641,18 +1685,6 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* 
 //   * four output rows, when it has fewer (the big-weight layers, where the "reduction" is mostly the (tap, ci) ->
 //     (ci, tap) transposition): thread group g owns row 4 * q + g and sums all its splits.
 // blocks = ceil(Cout / rows_per_block) * ceil(C / 64), rows_per_block = splits < 4 ? 4 : 1.  Deterministic.
-__device__ __forceinline__ int find_desc(const int* begins_stride_bytes_base, int stride_ints, int n, int b, int* sh) {
-    // sh: one LDS int; every thread of the block returns the index of the last descriptor with block_begin <= b
-    if (threadIdx.x == 0) *sh = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + (int)threadIdx.x;
-        if (i < n && begins_stride_bytes_base[(long)i * stride_ints] <= b) atomicAdd(sh, 1);    // LDS atomic, <= n per block
-    }
-    __syncthreads();
-    return *sh - 1;
-}
-
 __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradReduceDesc* __restrict__ descs, int n) {
     __shared__ float sm[4][16 * 64 + 16];
     __shared__ int sh_idx;
@@ -1933,6 +1965,58 @@ static void launch_wgrad_reduce(float* ws, int splits, int Cout, int NT, float* 
                        ld_out);
 }
 
+// ---- grouped tap-major weight gradients: plan / build / launch --------------------------------------------------------
+static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 1024);     // pixels per block of a grouped launch (multiple of 16)
+
+// pixel splits of one job of a grouped launch: chunks of ~g_wgroup_chunk pixels, at least 8 K steps each
+static void grouped_split(long M, int* splits, long* pix_per_split) {
+    const long steps = (M + BK - 1) / BK;
+    long sp = (M + g_wgroup_chunk - 1) / g_wgroup_chunk;
+    const long max_sp = steps / 8;
+    if (sp > max_sp) sp = max_sp;
+    if (sp < 1) sp = 1;
+    const long steps_per = (steps + sp - 1) / sp;
+    *pix_per_split = steps_per * BK;
+    *splits = (int)((steps + steps_per - 1) / steps_per);
+}
+
+// variant id of a tap-major job: 3 * tile + mode; tile 0: 128x128, 1: 128x64, 2: 64x128, 3: 32x128
+static int tap_tile_id(const TPlan& tp) {
+    if (tp.bm == 128 && tp.bn == 128) return 0;
+    if (tp.bm == 128) return 1;
+    if (tp.bm == 64) return 2;
+    return 3;
+}
+
+// loader mode + walk constants of the tap-major kernel for one pixel range length (shared by the single-layer entry)
+static int tap_mode(WgradTapArgs& g, int N, int H, int W, int Hi, int Wi, int kh, int kw, int pad, int ups, int clean, int ld_x,
+                    int ld_dy, long pix_per_split) {
+    const long span_a = pix_per_split * (long)ld_dy * 4, span_b = (pix_per_split + 2L * W + 2 * BK) * ld_x * 4;
+    bool walk = true;          // can a 16-pixel step be walked as columns / rows / frames with single wraps?
+    g.sw = BK;
+    g.sh = g.sn = 0;
+    if (W < BK) {
+        g.sw = 0;
+        const int r = BK / W;
+        if (BK % W != 0)
+            walk = false;
+        else if (r < H)
+            g.sh = r;
+        else if (r % H == 0)
+            g.sn = r / H;
+        else
+            walk = false;
+    }
+    return (g_fast_loader && clean && kh == 3 && kw == 3 && pad == 1 && walk && span_a < (1L << 29) && span_b < (1L << 29) &&
+            (!ups || (long)N * (Hi / 2) * (Wi / 2) * ld_x * 4 < (1L << 29)))
+               ? (ups ? 2 : 1) : 0;
+}
+
+struct GroupedHeader {
+    int magic, n, nvariants, reserved;
+    int first[12], count[12], blocks[12];     // per variant: first record, records, blocks (records are sorted by variant)
+};
+
 }  // namespace
 
 extern "C" {
@@ -2202,25 +2286,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
         {
             ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)g.M * Cout * (double)ntaps * C);
             // fast loader: 3x3 pad 1, clean pads, rows of >= 16 pixels, split ranges inside the 2^30-byte buffer window
-            const long span_a = tp.pix_per_split * (long)ld_dy * 4, span_b = (tp.pix_per_split + 2L * W + 2 * BK) * ld_x * 4;
-            bool walk = true;          // can a 16-pixel step be walked as columns / rows / frames with single wraps?
-            g.sw = BK;
-            g.sh = g.sn = 0;
-            if (W < BK) {
-                g.sw = 0;
-                const int r = BK / W;
-                if (BK % W != 0)
-                    walk = false;
-                else if (r < H)
-                    g.sh = r;
-                else if (r % H == 0)
-                    g.sn = r / H;
-                else
-                    walk = false;
-            }
-            const int mode = (g_fast_loader && clean && kh == 3 && kw == 3 && pad == 1 && walk && span_a < (1L << 29) &&
-                              span_b < (1L << 29) && (!ups || (long)N * (Hi / 2) * (Wi / 2) * ld_x * 4 < (1L << 29)))
-                                 ? (ups ? 2 : 1) : 0;
+            const int mode = tap_mode(g, N, H, W, Hi, Wi, kh, kw, pad, ups, clean, ld_x, ld_dy, tp.pix_per_split);
 #define MNK_WTAP(...)                                                                                            \
     do {                                                                                                         \
         if (mode == 1) hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<__VA_ARGS__, 1>), grid, dim3(256), 0, st, g);      \
@@ -2468,6 +2534,132 @@ int mnk_conv2d_wgrad_plan(int N, int Ho, int Wo, int C, int Cout, int kh, int kw
         plan->splits = p.splits;
         plan->part_floats = (size_t)p.splits * Cout * ntaps * C;
     }
+    return MNK_OK;
+}
+
+int mnk_wgrad_grouped_plan(MnkWgradJob* jobs, int n) {
+    MNK_REQUIRE(jobs && n > 0);
+    for (int i = 0; i < n; ++i) {
+        MnkWgradJob& j = jobs[i];
+        MNK_REQUIRE(j.N > 0 && j.Ho > 0 && j.Wo > 0 && j.C > 0 && j.Cout > 0 && j.kh > 0 && j.kw > 0 && j.pad >= 0);
+        const int ntaps = j.kh * j.kw;
+        const long M = (long)j.N * j.Ho * j.Wo;
+        TPlan tp = make_tplan(M, j.Cout, j.C, ntaps, j.ld_x);
+        j.variant = -1;
+        j.splits = 0;
+        j.part_floats = 0;
+        if (!tp.use) continue;                 // not a tap-major shape: the caller launches it on its own
+        long pps;
+        grouped_split(M, &j.splits, &pps);
+        WgradTapArgs g;
+        const int mode = tap_mode(g, j.N, j.Ho, j.Wo, j.Hi, j.Wi, j.kh, j.kw, j.pad, j.flags & MNK_CONV_UPSAMPLED,
+                                  (j.flags & MNK_CONV_CLEAN_PADS) ? 1 : 0, j.ld_x, j.ld_dy, pps);
+        j.variant = 3 * tap_tile_id(tp) + mode;
+        j.part_floats = (size_t)j.splits * ntaps * j.Cout * j.C;
+    }
+    return MNK_OK;
+}
+
+size_t mnk_wgrad_grouped_table_bytes(int n) { return n > 0 ? sizeof(GroupedHeader) + (size_t)n * sizeof(TapJobRec) : 0; }
+
+int mnk_wgrad_grouped_build(const MnkWgradJob* jobs, int n, void* host_table, size_t table_bytes) {
+    MNK_REQUIRE(jobs && n > 0 && host_table && table_bytes >= mnk_wgrad_grouped_table_bytes(n));
+    GroupedHeader* hd = (GroupedHeader*)host_table;
+    TapJobRec* recs = (TapJobRec*)((char*)host_table + sizeof(GroupedHeader));
+    hd->magic = 0x4d4e4b47;
+    hd->n = n;
+    hd->nvariants = 12;
+    hd->reserved = 0;
+    int k = 0;
+    for (int v = 0; v < 12; ++v) {
+        hd->first[v] = k;
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const MnkWgradJob& j = jobs[i];
+            MNK_REQUIRE(j.variant >= 0 && j.variant < 12);
+            if (j.variant != v) continue;
+            MNK_REQUIRE(j.x && j.dy && j.part && ((size_t)j.x % 16) == 0 && ((size_t)j.dy % 16) == 0);
+            const int ntaps = j.kh * j.kw, ups = j.flags & MNK_CONV_UPSAMPLED, clean = (j.flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
+            const long M = (long)j.N * j.Ho * j.Wo;
+            TPlan tp = make_tplan(M, j.Cout, j.C, ntaps, j.ld_x);
+            MNK_REQUIRE(tp.use && 3 * tap_tile_id(tp) == v - v % 3);
+            TapJobRec& r = recs[k];
+            WgradTapArgs& g = r.a;
+            int splits;
+            long pps;
+            grouped_split(M, &splits, &pps);
+            MNK_REQUIRE(splits == j.splits);
+            g.x = j.x;
+            g.ld_x = j.ld_x;
+            g.C = j.C;
+            g.ups = ups;
+            g.dy = j.dy;
+            g.ld_dy = j.ld_dy;
+            g.Cout = j.Cout;
+            g.H = j.Ho;
+            g.W = j.Wo;
+            g.Hi = j.Hi;
+            g.Wi = j.Wi;
+            g.ntaps = ntaps;
+            g.kw = j.kw;
+            g.pad = j.pad;
+            g.M = M;
+            g.pix_per_split = pps;
+            g.gn = tp.gn;
+            g.part = j.part;
+            g.xcd = 0;
+            g.clean = clean;
+            fast_div_consts((unsigned)j.Wo, &g.mulW, &g.shW);
+            fast_div_consts((unsigned)j.Ho, &g.mulH, &g.shH);
+            const int mode = tap_mode(g, j.N, j.Ho, j.Wo, j.Hi, j.Wi, j.kh, j.kw, j.pad, ups, clean, j.ld_x, j.ld_dy, pps);
+            MNK_REQUIRE(mode == v % 3);
+            r.gm = tp.gm;
+            r.gnt = tp.gn * ntaps;
+            r.splits = splits;
+            r.block_begin = blocks;
+            blocks += r.gm * r.gnt * r.splits;
+            ++k;
+        }
+        hd->count[v] = k - hd->first[v];
+        hd->blocks[v] = blocks;
+    }
+    MNK_REQUIRE(k == n);
+    return MNK_OK;
+}
+
+int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, void* stream) {
+    MNK_REQUIRE(device_table && host_table);
+    const GroupedHeader* hd = (const GroupedHeader*)host_table;
+    MNK_REQUIRE(hd->magic == 0x4d4e4b47 && hd->n > 0);
+    const TapJobRec* hrecs = (const TapJobRec*)((const char*)host_table + sizeof(GroupedHeader));
+    const TapJobRec* drecs = (const TapJobRec*)((const char*)device_table + sizeof(GroupedHeader));
+    hipStream_t st = (hipStream_t)stream;
+    for (int v = 0; v < 12; ++v) {
+        const int cnt = hd->count[v], blocks = hd->blocks[v];
+        if (!cnt) continue;
+        double flop = 0.0;
+        for (int i = 0; i < cnt; ++i) {
+            const WgradTapArgs& g = hrecs[hd->first[v] + i].a;
+            flop += 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
+        }
+        ProfScope prof(K_CONV_WGRAD, st, flop);
+        const TapJobRec* rv = drecs + hd->first[v];
+        const int mode = v % 3;
+#define MNK_WGROUP(...)                                                                                                        \
+    do {                                                                                                                       \
+        if (mode == 1) hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 1>), dim3(blocks), dim3(256), 0, st, rv, cnt);      \
+        else if (mode == 2) hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 2>), dim3(blocks), dim3(256), 0, st, rv, cnt); \
+        else hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 0>), dim3(blocks), dim3(256), 0, st, rv, cnt);                \
+    } while (0)
+        switch (v / 3) {
+            case 0: MNK_WGROUP(128, 128, 2, 2); break;
+            case 1: MNK_WGROUP(128, 64, 2, 2); break;
+            case 2: MNK_WGROUP(64, 128, 1, 4); break;
+            default: MNK_WGROUP(32, 128, 1, 4); break;
+        }
+#undef MNK_WGROUP
+    }
+    MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
 

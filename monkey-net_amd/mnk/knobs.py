@@ -17,6 +17,8 @@ KNOBS = {
     "MNK_FUSED_FM_LOSS": ("1", "feature-matching L1 terms reduced on the device from the NHWC activations (14.59 -> 14.26 ms/step)"),
     "MNK_HAND_ADAM": ("1", "TrainStep default optimiser = mnk.optim.MnkAdam (one launch, emits the packed weights; deferred "
                            "weight-gradient reductions); 0: torch.optim.Adam(fused=True) + per-layer reductions (round 1)"),
+    "MNK_WGRAD_GROUPED": ("1", "MnkAdam pipeline: the tap-major weight-gradient GEMMs of all layers in one launch per tile "
+                               "shape at the end of backward (0: one launch per layer during backward)"),
     "MNK_PACK_MULTI": ("1", "re-pack every conv weight of the model in one launch per iteration (0: one launch per layer)"),
     "MNK_DIST_GRAPH": ("1", "with a process group: capture the iteration incl. its RCCL collectives as a hipGraph"),
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),

@@ -32,6 +32,12 @@ REDUCE_DESC = np.dtype([("part", "<u8"), ("dw", "<u8"), ("layout", "<i4"), ("spl
                         ("block_begin", "<i4"), ("reserved", "<i4")])
 
 
+JOB = np.dtype([("x", "<u8"), ("dy", "<u8"), ("part", "<u8"), ("part_floats", "<u8"), ("ld_x", "<i4"), ("C", "<i4"),
+                ("flags", "<i4"), ("ld_dy", "<i4"), ("Cout", "<i4"), ("N", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"), ("Hi", "<i4"),
+                ("Wi", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("pad", "<i4"), ("variant", "<i4"), ("splits", "<i4"),
+                ("reserved", "<i4")])
+
+
 class _Plan(ctypes.Structure):
     _fields_ = [("layout", ctypes.c_int), ("splits", ctypes.c_int), ("part_floats", ctypes.c_size_t)]
 
@@ -47,18 +53,51 @@ def _capturing(device):
 
 
 class DeferredReducer:
-    """Weight-gradient GEMMs of one optimiser's convolutions with their split reductions deferred to one launch."""
+    """The weight-gradient GEMMs of one optimiser's convolutions, run as late and as together as possible:
+    * tap-major shapes (every layer wider than one 64-channel tile) are only RECORDED during backward and launched
+      together at flush time (mnk_wgrad_grouped_*: one launch per tile shape; the tiles of all layers fill the chip, so
+      a layer is split along pixels only where its pixel range is long) -- `x` and `dy` stay alive until then;
+    * the other shapes (nine-tap 16x16 kernel, LDS-halo, gather) launch at once with MNK_WGRAD_DEFER;
+    * ONE mnk_wgrad_reduce_multi launch then reduces the partials of all layers into the optimiser's flat buffer."""
 
     def __init__(self, owner):
         self.owner = owner
-        self.recs = {}            # (id(weight), c_start) -> dict(part, row of REDUCE_DESC without block_begin, blocks)
-        self.pending = []         # keys launched since the last flush, in launch order
-        self.done = set()         # keys launched since zero_grad (pending or written directly by the GEMM)
+        self.recs = {}            # (id(weight), c_start) -> dict(shape, part, row of REDUCE_DESC without block_begin, ...)
+        self.pending = []         # keys with partials waiting for the reduction, in launch order
+        self.jobs = []            # recorded grouped jobs: (key, x, dy, flags)
+        self.done = set()         # keys launched / recorded since zero_grad
         self.tables = {}          # tuple(pending keys) -> (device table, n, blocks)
         self.keep = []
 
+    def _record(self, key, weight, sink, shape, flags):
+        n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total, hi, wi, ld_dy, c_start = shape
+        if _capturing(weight.device):
+            raise RuntimeError("a convolution shape first seen during hipGraph capture (run one eager iteration first)")
+        lib = _lib.lib()
+        job = np.zeros(1, dtype=JOB)
+        job[0] = (0, 0, 0, 0, ld_x, c, flags, ld_dy, cout, n, ho, wo, hi, wi, kh, kw, pad, 0, 0, 0)
+        grouped = mops.knobs.on("MNK_WGRAD_GROUPED")
+        if grouped:
+            if lib.query("mnk_wgrad_grouped_plan", job.ctypes.data, 1) != 0:
+                raise _lib.MnkError("mnk_wgrad_grouped_plan failed: %s" % lib.cdll.mnk_last_error().decode())
+            grouped = int(job["variant"][0]) >= 0
+        if grouped:
+            layout, splits, nfloats = 0, int(job["splits"][0]), int(job["part_floats"][0])
+        else:
+            plan = _Plan()
+            if lib.query("mnk_conv2d_wgrad_plan", n, ho, wo, c, cout, kh, kw, pad, ld_x, ctypes.byref(plan)) != 0:
+                raise _lib.MnkError("mnk_conv2d_wgrad_plan failed: %s" % lib.cdll.mnk_last_error().decode())
+            layout, splits, nfloats = int(plan.layout), int(plan.splits), int(plan.part_floats)
+        part = torch.empty(max(nfloats, 1), dtype=torch.float32, device=weight.device)
+        rec = {"shape": shape, "part": part, "splits": splits, "nfloats": nfloats, "grouped": grouped, "job": job,
+               "row": (part.data_ptr(), sink.data_ptr(), layout, splits, kh * kw, cout, c, cin_total, c_start, 0),
+               "blocks": lib.query("mnk_wgrad_reduce_blocks", splits, cout, c) if splits > 0 else 0}
+        self.recs[key] = rec
+        self.tables.clear()
+        return rec
+
     def wgrad(self, weight, x, ld_x, c, flags, hi, wi, kh, kw, pad, dy, ld_dy, cout, cin_total, c_start, n, ho, wo):
-        """Launch the GEMM of d(weight)[:, c_start:c_start+c] into the owner's sink of `weight`; True when taken."""
+        """d(weight)[:, c_start:c_start+c] towards the owner's sink of `weight`; True when taken."""
         own = self.owner
         sink = own.sink(weight)
         key = (id(weight), c_start)
@@ -66,31 +105,50 @@ class DeferredReducer:
             return False                                   # a second contribution before the step: the caller accumulates
         if x.data_ptr() % 16 or dy.data_ptr() % 16:
             return False
+        shape = (n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total, hi, wi, ld_dy, c_start)
         rec = self.recs.get(key)
-        shape = (n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total)
         if rec is None or rec["shape"] != shape:
-            if _capturing(weight.device):
-                raise RuntimeError("a convolution shape first seen during hipGraph capture (run one eager iteration first)")
-            plan = _Plan()
-            rc = _lib.lib().query("mnk_conv2d_wgrad_plan", n, ho, wo, c, cout, kh, kw, pad, ld_x, ctypes.byref(plan))
-            if rc != 0:
-                raise _lib.MnkError("mnk_conv2d_wgrad_plan failed: %s" % _lib.lib().cdll.mnk_last_error().decode())
-            part = torch.empty(max(int(plan.part_floats), 1), dtype=torch.float32, device=weight.device)
-            rec = {"shape": shape, "part": part, "splits": int(plan.splits), "nfloats": int(plan.part_floats),
-                   "row": (part.data_ptr(), sink.data_ptr(), int(plan.layout), int(plan.splits), kh * kw, cout, c, cin_total,
-                           c_start, 0), "blocks": _lib.lib().query("mnk_wgrad_reduce_blocks", int(plan.splits), cout, c)}
-            self.recs[key] = rec
-            self.tables.clear()
-        mops._call("mnk_conv2d_wgrad", dy, mops._p(x), ld_x, c, int(flags) | 4, hi, wi, kh, kw, pad, mops._p(dy), ld_dy, cout,
-                   mops._p(sink), cin_total, c_start, n, ho, wo, mops._p(rec["part"]), rec["nfloats"])
+            rec = self._record(key, weight, sink, shape, int(flags))
+        if rec["grouped"]:
+            self.jobs.append((key, x, dy))                 # launched by flush(); the operands stay alive until then
+        else:
+            mops._call("mnk_conv2d_wgrad", dy, mops._p(x), ld_x, c, int(flags) | 4, hi, wi, kh, kw, pad, mops._p(dy), ld_dy,
+                       cout, mops._p(sink), cin_total, c_start, n, ho, wo, mops._p(rec["part"]), rec["nfloats"])
         if rec["splits"] > 0:
             self.pending.append(key)
         self.done.add(key)
         own._written.add(id(weight))
         return True
 
+    def _launch_grouped(self):
+        jobs, self.jobs = self.jobs, []
+        lib = _lib.lib()
+        dev = jobs[0][1].device
+        arr = np.zeros(len(jobs), dtype=JOB)
+        for i, (key, x, dy) in enumerate(jobs):
+            rec = self.recs[key]
+            arr[i] = rec["job"][0]
+            arr["x"][i], arr["dy"][i], arr["part"][i] = x.data_ptr(), dy.data_ptr(), rec["part"].data_ptr()
+        nbytes = lib.query("mnk_wgrad_grouped_table_bytes", len(jobs))
+        if _capturing(dev):
+            # the copy becomes a node of the graph: its pinned source must stay alive and untouched for every replay
+            host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+            if lib.query("mnk_wgrad_grouped_build", arr.ctypes.data, len(jobs), host.data_ptr(), nbytes) != 0:
+                raise _lib.MnkError("mnk_wgrad_grouped_build failed: %s" % lib.cdll.mnk_last_error().decode())
+            table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            table.copy_(host, non_blocking=True)
+            self.keep.extend((host, table))
+        else:
+            host = torch.zeros(nbytes, dtype=torch.uint8)
+            if lib.query("mnk_wgrad_grouped_build", arr.ctypes.data, len(jobs), host.data_ptr(), nbytes) != 0:
+                raise _lib.MnkError("mnk_wgrad_grouped_build failed: %s" % lib.cdll.mnk_last_error().decode())
+            table = host.to(dev)
+        mops._call("mnk_wgrad_grouped_launch", table, mops._p(table), host.data_ptr())
+
     def flush(self):
-        """One launch reducing every pending layer's partials into its sink."""
+        """The recorded GEMMs in a few grouped launches, then one launch reducing every pending layer's partials."""
+        if self.jobs:
+            self._launch_grouped()
         if not self.pending:
             return 0
         keys = tuple(self.pending)
@@ -114,6 +172,7 @@ class DeferredReducer:
 
     def drop(self):
         self.pending = []
+        self.jobs = []
         self.done.clear()
 
 

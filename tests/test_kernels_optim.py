@@ -177,3 +177,90 @@ def test_adam_multi_matches_torch_adam_and_emits_the_packs(be, lr_drop):
         for a, b in ((wf, rf), (w0, r0), (w1, r1)):
             if a is not None:
                 assert torch.equal(a.cpu().nan_to_num(nan=7.0), b.cpu().nan_to_num(nan=7.0))
+
+
+JOB = np.dtype([("x", "<u8"), ("dy", "<u8"), ("part", "<u8"), ("part_floats", "<u8"), ("ld_x", "<i4"), ("C", "<i4"),
+                ("flags", "<i4"), ("ld_dy", "<i4"), ("Cout", "<i4"), ("N", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"), ("Hi", "<i4"),
+                ("Wi", "<i4"), ("kh", "<i4"), ("kw", "<i4"), ("pad", "<i4"), ("variant", "<i4"), ("splits", "<i4"),
+                ("reserved", "<i4")])
+
+
+def test_grouped_weight_gradients_of_many_layers(be, monkeypatch):
+    """mnk_wgrad_grouped_*: the tap-major weight-gradient GEMMs of many layers (all four tile shapes, the three loaders, two
+    sources, up-sampled views, the 4x4 discriminator kernels, several pixel chunks per layer) in one launch per tile
+    shape + ONE reduction launch, against conv2d's weight gradient in fp64."""
+    assert JOB.itemsize == 96
+    layers = []
+    for case in CASES + HALO_CASES + WFAST_CASES:
+        n, h, w, c0, c1, cout, ups, _, _ = case
+        x0, x1, wt, b, r = _inputs(case)
+        layers.append((n, h, w, h, w, c0, c1, cout, ups, 3, 3, 1, x0, x1, wt))
+    g = torch.Generator().manual_seed(9)
+    for n, hi, wi, cin, cout in K4_CASES:
+        layers.append((n, hi - 3, wi - 3, hi, wi, cin, 0, cout, 0, 4, 4, 0, torch.randn(n, cin, hi, wi, generator=g), None,
+                       torch.randn(cout, cin, 4, 4, generator=g) * 0.2))
+    # a long pixel range: several chunks of the default 1024 pixels
+    gl = torch.Generator().manual_seed(10)
+    layers.append((3, 32, 48, 32, 48, 70, 0, 24, 0, 3, 3, 1, torch.randn(3, 70, 32, 48, generator=gl), None,
+                   torch.randn(24, 70, 3, 3, generator=gl) * 0.2))
+    jobs, meta, keep = [], [], []
+    for li, (n, ho, wo, hi, wi, c0, c1, cout, ups, kh, kw, pad, x0, x1, wt) in enumerate(layers):
+        gd = torch.Generator().manual_seed(100 + li)
+        dy = torch.randn(n, cout, ho, wo, generator=gd)
+        wd = wt.double().requires_grad_(True)
+        x = x0 if x1 is None else torch.cat([x0, x1], 1)
+        if ups:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        F.conv2d(x.double(), wd, None, padding=pad).backward(dy.double())
+        DY = be.t(to_nhwc(dy))
+        DW = be.empty(cout, c0 + c1, kh, kw)
+        keep.append((DY, DW, wd.grad))
+        for src, c_start, c_cnt in ((x0, 0, c0),) + (((x1, c0, c1),) if c1 else ()):
+            X = be.t(to_nhwc(src))
+            clean = 2 if li % 2 == 0 else 0            # both loader families
+            jobs.append((X.data_ptr(), DY.data_ptr(), 0, 0, X.shape[-1], c_cnt, int(ups) | clean, DY.shape[-1], cout, n, ho, wo,
+                         hi, wi, kh, kw, pad, 0, 0, 0))
+            meta.append((DW, c0 + c1, c_start, c_cnt, cout, kh * kw, X))
+    rec = np.array(jobs, dtype=JOB)
+    assert be.query("mnk_wgrad_grouped_plan", rec.ctypes.data, len(rec)) == 0
+    sel = [i for i in range(len(rec)) if rec["variant"][i] >= 0]
+    assert len(sel) >= 12 and len(set(int(rec["variant"][i]) // 3 for i in sel)) == 4, rec["variant"]
+    assert len(set(int(rec["variant"][i]) % 3 for i in sel)) == 3 and max(int(rec["splits"][i]) for i in sel) >= 4
+    grouped = rec[sel].copy()
+    parts, rows, blocks = [], [], 0
+    for k, i in enumerate(sel):
+        part = be.empty(int(grouped["part_floats"][k]))
+        parts.append(part)
+        grouped["part"][k] = part.data_ptr()
+        DW, cin_total, c_start, c_cnt, cout, ntaps, _ = meta[i]
+        rows.append((part.data_ptr(), DW.data_ptr(), 0, int(grouped["splits"][k]), ntaps, cout, c_cnt, cin_total, c_start, 0,
+                     blocks, 0))
+        blocks += be.query("mnk_wgrad_reduce_blocks", int(grouped["splits"][k]), cout, c_cnt)
+    nbytes = be.query("mnk_wgrad_grouped_table_bytes", len(grouped))
+    host = torch.zeros(nbytes, dtype=torch.uint8)
+    assert be.query("mnk_wgrad_grouped_build", grouped.ctypes.data, len(grouped), host.data_ptr(), nbytes) == 0
+    dev = be.t(host)
+    be.call("mnk_wgrad_grouped_launch", dev, host.data_ptr())
+    # the layers that are not tap-major shapes go through the single-layer entry (deferred reduction, as before)
+    for i in range(len(rec)):
+        if i in sel:
+            continue
+        DW, cin_total, c_start, c_cnt, cout, ntaps, X = meta[i]
+        j = rec[i]
+        plan = Plan()
+        assert be.query("mnk_conv2d_wgrad_plan", int(j["N"]), int(j["Ho"]), int(j["Wo"]), c_cnt, cout, int(j["kh"]), int(j["kw"]),
+                        int(j["pad"]), int(j["ld_x"]), ctypes.byref(plan)) == 0
+        part = be.empty(max(plan.part_floats, 1))
+        parts.append(part)
+        be.lib.call("mnk_conv2d_wgrad", int(j["x"]), int(j["ld_x"]), c_cnt, int(j["flags"]) | 2 | 4, int(j["Hi"]), int(j["Wi"]),
+                    int(j["kh"]), int(j["kw"]), int(j["pad"]), int(j["dy"]), int(j["ld_dy"]), cout, DW.data_ptr(), cin_total,
+                    c_start, int(j["N"]), int(j["Ho"]), int(j["Wo"]), part.data_ptr(), plan.part_floats, be.stream())
+        if plan.splits > 0:
+            rows.append((part.data_ptr(), DW.data_ptr(), plan.layout, plan.splits, ntaps, cout, c_cnt, cin_total, c_start, 0,
+                         blocks, 0))
+            blocks += be.query("mnk_wgrad_reduce_blocks", plan.splits, cout, c_cnt)
+    descs = _table(be, np.array(rows, dtype=REDUCE_DESC))
+    be.call("mnk_wgrad_reduce_multi", descs, len(rows), blocks)
+    be.sync()
+    for DY, DW, ref in keep:
+        assert relerr(DW.cpu(), ref) < 2e-6

@@ -2,7 +2,7 @@
 
 Usage: trace_groups.py trace.csv [--marker KERNEL_SUBSTR] [--skip N]
 The iterations are periodic, so the window between the end of the (N)th and of the last launch of a once-per-iteration
-kernel (default: pack_multi_kernel, the per-iteration weight re-layout) holds whole iterations only -- this drops MIOpen's find-mode
+kernel (default: softmax_kp_fwd_kernel, the key-point read-out of the one detector forward) holds whole iterations only -- this drops MIOpen's find-mode
 kernels (naive_conv_*, Im2d2Col, Cijk_*) that run during warm-up.  Also writes a kernel_stats-style csv of the window
 when --csv PATH is given.
 """
@@ -10,7 +10,7 @@ import argparse, collections, csv, re
 
 ap = argparse.ArgumentParser()
 ap.add_argument("trace")
-ap.add_argument("--marker", default="pack_multi_kernel")
+ap.add_argument("--marker", default="softmax_kp_fwd_kernel")
 ap.add_argument("--skip", type=int, default=2)
 ap.add_argument("--csv", default=None)
 a = ap.parse_args()
