@@ -31,6 +31,7 @@ extern "C" {
 #define MNK_EINVAL (-1)     /* invalid argument                              */
 #define MNK_ELAUNCH (-2)    /* hipLaunchKernel / runtime failure             */
 #define MNK_EWORKSPACE (-3) /* workspace too small                           */
+#define MNK_ECOMM (-4)      /* RCCL missing or a collective failed           */
 
 int mnk_version(void);
 const char* mnk_last_error(void);
@@ -277,6 +278,22 @@ typedef struct MnkAdamDesc {
 int mnk_adam_blocks(long n, int Cout, int C0, int C1, int packed);
 int mnk_adam_tick(float* hyper, void* stream);
 int mnk_adam_multi(const MnkAdamDesc* descs_device, int n, int total_blocks, const float* hyper, void* stream);
+
+/* ---- data-parallel collectives: RCCL all-reduce over xGMI on the CALLER's stream -- in order with
+ * the kernels, capturable into the iteration's hipGraph, no hand-over to a communication stream.  One process per GPU.
+ * mnk_comm_unique_id: rank 0 makes a 128-byte id (host memory) and the host layer gives it to every rank;
+ * mnk_comm_init: every rank (its GPU current) joins; `comm` is the only state.  mnk_comm_available() == 0 when
+ * librccl.so.1 cannot be loaded (and always in the CPU emulator build): the host layer then stays on its own transport.
+ *   mnk_allreduce_bnstats: the SyncBN exchange -- sums of one norm layer (2C floats) summed over ranks in place; replaces
+ *     reduce-to-master + broadcast of sync_batchnorm/batchnorm.py:95-111 (every rank finalises identically afterwards);
+ *   mnk_allreduce_grads: a flat gradient buffer summed (average = 0) or averaged (1) over ranks in place, in chunks of
+ *     chunk_floats grouped into one RCCL launch; replaces DataParallel's reduce-add + re-broadcast (train.py:104-105). */
+int mnk_comm_available(void);
+int mnk_comm_unique_id(void* id128);
+int mnk_comm_init(const void* id128, int rank, int world, void** comm_out);
+int mnk_comm_destroy(void* comm);
+int mnk_allreduce_bnstats(void* comm, float* sums, long n, void* stream);
+int mnk_allreduce_grads(void* comm, float* grads, long n, int average, long chunk_floats, void* stream);
 
 /* ---- grouped 1x1 convolution (SameBlock3D, modules/util.py:118, dense_motion_module.py:24-28) ----------- */
 int mnk_gconv1x1_fwd(const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, long rows,

@@ -1679,38 +1679,60 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(const float* 
 // ---- split reductions of MANY layers in one launch (deferred weight-gradient reductions of a whole backward pass) ----
 // Block b belongs to the layer whose [block_begin, block_begin + blocks) range contains it -- found with ONE coalesced
 // read of the table's block_begin column and an LDS count (a binary search over device memory costs ~6 dependent loads per
-// block, several microseconds on blocks that move 5 KB) -- and owns a 64-channel ci tile of
-//   * one output row co, when the layer has >= 4 pixel splits: threads = 4 split groups x 64 channels, group g sums the
-//     splits g, g+4, ... with `ntaps` independent chains in flight, the groups are combined through LDS in a fixed order;
-//   * four output rows, when it has fewer (the big-weight layers, where the "reduction" is mostly the (tap, ci) ->
-//     (ci, tap) transposition): thread group g owns row 4 * q + g and sums all its splits.
-// blocks = ceil(Cout / rows_per_block) * ceil(C / 64), rows_per_block = splits < 4 ? 4 : 1.  Deterministic.
+// block, several microseconds on blocks that move 5 KB) -- and owns a tw-channel ci tile of one output row (or of four
+// rows): thread group g sums the splits g, g + groups, ... with 2 * ntaps independent loads in flight, the groups are
+// combined through LDS in a fixed order (deterministic), and the (tap, ci) -> (ci, tap) transposition of the tap-major
+// partials happens on the way into LDS.  blocks = ceil(Cout / rows) * ceil(C / tw) with (tw, rows) = reduce_map(splits).
+// thread map of one layer: channel-tile width tw and thread groups = 256 / tw
+//   splits <  4 : tw = 64, the 4 groups own 4 different output rows (each sums all its splits);
+//   splits < 32 : tw = 64, the 4 groups share one row and split the splits;
+//   splits >= 32: tw = 16, 16 groups share one row (the many-split layers have tiny gradients: without this a 512-split
+//                 layer leaves ten blocks summing 128 partials in sequence -- the tail of the whole launch).
+__host__ __device__ __forceinline__ void reduce_map(int splits, int* tw, int* rows) {
+    *tw = splits >= 32 ? 16 : 64;
+    *rows = splits < 4 ? 4 : 1;
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradReduceDesc* __restrict__ descs, int n) {
-    __shared__ float sm[4][16 * 64 + 16];
+    __shared__ float sm[16 * 16 * 16 + 64];        // [group][channel * ntaps + tap], group stride tw * 16
     __shared__ int sh_idx;
     const int b = blockIdx.x;
     const int di = find_desc(&descs[0].block_begin, (int)(sizeof(MnkWgradReduceDesc) / sizeof(int)), n, b, &sh_idx);
     const MnkWgradReduceDesc d = descs[di];
     const int local = b - d.block_begin;
-    const int ctiles = (d.C + 63) / 64;
-    const int rpb = d.splits < 4 ? 4 : 1;
-    const int rq = local / ctiles, ci0 = (local - rq * ctiles) * 64;
-    const int t = threadIdx.x, g = t >> 6, c = t & 63;
+    int tw, rpb;
+    reduce_map(d.splits, &tw, &rpb);
+    const int groups = 256 / tw, gstride = tw * 16;
+    const int ctiles = (d.C + tw - 1) / tw;
+    const int rq = local / ctiles, ci0 = (local - rq * ctiles) * tw;
+    const int t = threadIdx.x, g = t / tw, c = t - g * tw;
     const int ntaps = d.ntaps;
-    const int cw = d.C - ci0 < 64 ? d.C - ci0 : 64;          // channels of this tile
+    const int cw = d.C - ci0 < tw ? d.C - ci0 : tw;          // channels of this tile
     const int lim = cw * ntaps;                              // gradient floats of this tile (per row)
     const int co = rpb == 1 ? rq : rq * 4 + g;               // the row this thread group reads
     const bool row_ok = co < d.Cout;
+    const int s0 = rpb == 1 ? g : 0, sstep = rpb == 1 ? groups : 1;
+    float* smg = sm + g * gstride;
     if (d.layout == 0) {
         // part[s][tap][co][ci]
         const long plane = (long)d.Cout * d.C, sstride = (long)ntaps * plane;
         const bool ok = c < cw && row_ok;
         const float* src = d.part + (long)(row_ok ? co : 0) * d.C + ci0 + (ok ? c : 0);
-        float acc[16];
+        float acc[16], acc2[16];
 #pragma unroll
-        for (int tp = 0; tp < 16; ++tp) acc[tp] = 0.f;
-        const int s0 = rpb == 1 ? g : 0, sstep = rpb == 1 ? 4 : 1;
-        for (int sp = s0; sp < d.splits; sp += sstep) {
+        for (int tp = 0; tp < 16; ++tp) acc[tp] = acc2[tp] = 0.f;
+        int sp = s0;
+        for (; sp + sstep < d.splits; sp += 2 * sstep) {       // two splits per trip: 2 * ntaps loads in flight
+            const float* ps = src + (long)sp * sstride;
+            const float* pt = ps + (long)sstep * sstride;
+#pragma unroll
+            for (int tp = 0; tp < 16; ++tp)
+                if (tp < ntaps) {
+                    acc[tp] += ps[(long)tp * plane];
+                    acc2[tp] += pt[(long)tp * plane];
+                }
+        }
+        if (sp < d.splits) {
             const float* ps = src + (long)sp * sstride;
 #pragma unroll
             for (int tp = 0; tp < 16; ++tp)
@@ -1718,13 +1740,12 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
         }
 #pragma unroll
         for (int tp = 0; tp < 16; ++tp)
-            if (tp < ntaps) sm[g][c * ntaps + tp] = ok ? acc[tp] : 0.f;      // already in (ci, tap) order
+            if (tp < ntaps) smg[c * ntaps + tp] = ok ? acc[tp] + acc2[tp] : 0.f;      // already in (ci, tap) order
     } else {
         // part[s][co][ci * ntaps + tap]
         const long NT = (long)d.C * ntaps, sstride = (long)d.Cout * NT;
         const float* src = d.part + (long)(row_ok ? co : 0) * NT + (long)ci0 * ntaps;
-        const int s0 = rpb == 1 ? g : 0, sstep = rpb == 1 ? 4 : 1;
-        for (int idx = c; idx < lim; idx += 64) {
+        for (int idx = c; idx < lim; idx += tw) {
             float v0 = 0.f, v1 = 0.f;
             int sp = s0;
             for (; sp + sstep < d.splits; sp += 2 * sstep) {
@@ -1732,19 +1753,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
                 v1 += src[(long)(sp + sstep) * sstride + idx];
             }
             if (sp < d.splits) v0 += src[(long)sp * sstride + idx];
-            sm[g][idx] = row_ok ? v0 + v1 : 0.f;
+            smg[idx] = row_ok ? v0 + v1 : 0.f;
         }
     }
     __syncthreads();
     if (rpb == 1) {
         float* dst = d.dw + ((long)rq * d.Cin_total + d.c_start + ci0) * ntaps;
         for (int idx = t; idx < lim; idx += 256) {
-            const float v = (sm[0][idx] + sm[1][idx]) + (sm[2][idx] + sm[3][idx]);
+            float v = 0.f;
+            for (int gg = 0; gg < groups; ++gg) v += sm[gg * gstride + idx];       // fixed order: deterministic
             dst[idx] = d.accumulate ? dst[idx] + v : v;
         }
     } else if (row_ok) {
         float* dst = d.dw + ((long)co * d.Cin_total + d.c_start + ci0) * ntaps;
-        for (int idx = c; idx < lim; idx += 64) dst[idx] = d.accumulate ? dst[idx] + sm[g][idx] : sm[g][idx];
+        for (int idx = c; idx < lim; idx += tw) dst[idx] = d.accumulate ? dst[idx] + smg[idx] : smg[idx];
     }
 }
 
@@ -2665,7 +2687,9 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
 
 int mnk_wgrad_reduce_blocks(int splits, int Cout, int C) {
     if (splits <= 0 || Cout <= 0 || C <= 0) return 0;
-    return ceil_div(Cout, splits < 4 ? 4 : 1) * ceil_div(C, 64);
+    int tw, rows;
+    reduce_map(splits, &tw, &rows);
+    return ceil_div(Cout, rows) * ceil_div(C, tw);
 }
 
 int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream) {

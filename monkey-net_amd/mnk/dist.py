@@ -44,7 +44,56 @@ def active():
     return _SYNC_BN and initialized() and (tdist.get_world_size() > 1 or _FORCE)
 
 
+# ---- the library's own RCCL communicator (include/monkeynet_hip.h: mnk_comm_*, mnk_allreduce_*) ------------------------
+# With the nccl (= RCCL) backend the two collectives of the hot path are issued by libmonkeynet_hip.so on the stream the
+# kernels run on: in order with producer and consumer, no event hand-over to torch.distributed's communication stream
+# (two event waits per collective, 84 small SyncBN collectives per iteration), capturable as they are.  torch.distributed
+# stays the rendezvous (it carries the 128-byte id) and the transport of everything else (gloo in the CPU tests).
+_COMM = {"tried": False, "handle": None}
+
+
+def direct_comm():
+    """The communicator handle (an int) or None: gloo / CPU builds / RCCL not loadable / MNK_RCCL_DIRECT=0."""
+    if _COMM["tried"]:
+        return _COMM["handle"]
+    _COMM["tried"] = True
+    try:
+        if not (knobs.on("MNK_RCCL_DIRECT") and initialized() and tdist.get_backend() == "nccl"):
+            return None
+        import ctypes
+        from . import _lib
+        lib = _lib.lib()
+        if not lib.is_device_build or not lib.cdll.mnk_comm_available():
+            return None
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if tdist.get_rank() == 0:
+            lib.call("mnk_comm_unique_id", ident.data_ptr())
+        on_dev = ident.to(dev)
+        tdist.broadcast(on_dev, 0)
+        ident = on_dev.cpu()
+        handle = ctypes.c_void_p()
+        lib.call("mnk_comm_init", ident.data_ptr(), tdist.get_rank(), tdist.get_world_size(), ctypes.byref(handle))
+        _COMM["handle"] = handle.value
+    except Exception as e:      # the torch.distributed path below is always there
+        import sys
+        sys.stderr.write("mnk.dist: direct RCCL communicator not available (%s: %s); using torch.distributed\n"
+                         % (type(e).__name__, e))
+        _COMM["handle"] = None
+    return _COMM["handle"]
+
+
+def _stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
 def all_reduce_sum_(t):
+    """SyncBN exchange: sum a small fp32 vector over the ranks in place."""
+    h = direct_comm() if t.is_cuda else None
+    if h is not None and t.dtype == torch.float32 and t.is_contiguous():
+        from . import _lib
+        _lib.lib().call("mnk_allreduce_bnstats", h, t.data_ptr(), t.numel(), _stream_of(t))
+        return t
     tdist.all_reduce(t, op=tdist.ReduceOp.SUM)
     return t
 
@@ -58,6 +107,11 @@ def all_reduce_flat_(flat, chunk_mb=64.0):
     """Sum a flat fp32 buffer over the ranks in place, as a few large collectives (xGMI rings are per-link bound: fewer,
     larger messages) launched back to back; the caller's stream waits for them, the host does not."""
     step = max(int(chunk_mb * 1024 * 1024 / 4), 1)
+    h = direct_comm() if flat.is_cuda else None
+    if h is not None and flat.dtype == torch.float32 and flat.is_contiguous():
+        from . import _lib
+        _lib.lib().call("mnk_allreduce_grads", h, flat.data_ptr(), flat.numel(), 0, step, _stream_of(flat))
+        return flat
     works = [tdist.all_reduce(flat[i:i + step], op=tdist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), step)]
     for w in works:
         w.wait()

@@ -22,6 +22,8 @@ KNOBS = {
     "MNK_PACK_MULTI": ("1", "re-pack every conv weight of the model in one launch per iteration (0: one launch per layer)"),
     "MNK_DIST_GRAPH": ("1", "with a process group: capture the iteration incl. its RCCL collectives as a hipGraph"),
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),
+    "MNK_RCCL_DIRECT": ("1", "nccl backend: SyncBN sums and flat gradient buffers are all-reduced by the library's own RCCL "
+                             "communicator on the kernels' stream (0: through torch.distributed)"),
     "MNK_GRAD_OVERLAP": ("1", "launch a gradient bucket's all-reduce as soon as its last gradient is written"),
 }
 

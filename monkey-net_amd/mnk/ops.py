@@ -404,12 +404,15 @@ class Conv3x3Fn(torch.autograd.Function):
         if sums is None:
             sums = y.new_empty(0)
         ctx.mark_non_differentiable(sums)
+        ctx.set_materialize_grads(False)     # `sums` never has a gradient: no zero tensor is made for it per backward
         return y, sums
 
     @staticmethod
     def backward(ctx, dy, _dsums):
         x0, x1, weight = ctx.saved_tensors
         c0, c1, ups, cout, n, h, w, has_bias, has_res = ctx.meta
+        if dy is None:                       # (materialize_grads is off) nothing flows into y
+            return (None,) * 10
         dy_in = dy
         dy = dy.contiguous()
         ld_dy = dy.shape[-1]
@@ -806,6 +809,7 @@ class SoftmaxKPFn(torch.autograd.Function):
         _call("mnk_softmax_kp_fwd", heat, _p(heat), ld, n, h, w, k, float(temperature), _p(mean), _p(var), _p(stat))
         ctx.save_for_backward(heat, mean, stat)
         ctx.meta = (k, float(temperature))
+        ctx.set_materialize_grads(False)     # backward makes the missing one itself (kp_variance given as a constant)
         return mean, var
 
     @staticmethod
