@@ -172,6 +172,53 @@ def cpu_baseline(cfg, batch, size, steps):
                       "%d threads), %.2f s/iteration" % (steps, batch, cores, dt)}
 
 
+def hot_path_only(step, x, iters, device):
+    """the hot path alone -- KPDetector (source + driving frame) + generator forward, and their
+    backward incl. every weight gradient, seeded with a fixed random dL/d(prediction); no discriminator, no losses, no
+    optimiser.  Captured as one hipGraph like the full iteration and timed with HIP events over `iters` replays."""
+    from mnk import engine
+    gen, kpd = step.generator, step.kp_detector
+    tp = step.tp
+    g = torch.Generator().manual_seed(99)
+    seed = torch.randn(x["video"].shape, generator=g).to(device)
+    opts = [o for o in (step.opt_g, step.opt_k) if hasattr(o, "materialize_grads")]
+
+    def one():
+        kp_joined = kpd(torch.cat([x["source"], x["video"]], dim=2))
+        out = gen(x["source"], **engine.split_kp(kp_joined, tp["detach_kp_generator"]))
+        torch.autograd.backward([out["video_prediction"]], [seed])
+        for o in opts:
+            o.materialize_grads()
+        step.opt_g.zero_grad(), step.opt_k.zero_grad()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            one()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize(device)
+    launch = "hipGraph replay"
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            one()
+        run = graph.replay
+    except Exception as e:      # pragma: no cover - capture is an optimisation
+        sys.stderr.write("hot-path-only capture failed (%s); timing eager launches\n" % type(e).__name__)
+        run, launch = one, "eager"
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) / iters, launch
+
+
 _JSON_FD = [None]
 
 
@@ -339,20 +386,23 @@ def main():
                     "avg_us": ms.value / n.value * 1e3, "work_per_step": work.value / prof_steps}
         lib.cdll.mnk_prof_reset()
         conv = kernels.get("conv3x3_igemm")
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s_b%d.json" % (args.config, args.batch))
+        traffic, traffic_src = None, None
+        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s_b%d.json" % (args.config, args.batch))
         if os.path.exists(pmc_file) and args.size == 64:
             # HBM-side bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc passes
-            # (FETCH_SIZE, WRITE_SIZE; tools/gpu_prof_pmc.sh + tools/pmc_summarize.py), gfx950 correction: 2 x FETCH_SIZE
+            # (FETCH_SIZE, WRITE_SIZE; tools/gpu_evidence.sh + tools/pmc_summarize.py), gfx950 correction: 2 x FETCH_SIZE.
+            # A number from a profile run, not from this run: `traffic_source` says which commit it was taken on.
             pm = json.load(open(pmc_file))
             n = f = w = 0.0
             for k, v in pm.items():
-                if "conv3x3_igemm" in k:
+                if isinstance(v, dict) and "conv3x3_igemm" in k:
                     n += v["launches"]
                     f += v["fetch_bytes_per_launch_raw"] * v["launches"]
                     w += v["write_bytes_per_launch"] * v["launches"]
             if n:
                 traffic = round((2 * f + w) / n)
+                traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (%s)" % (
+                    os.path.basename(pmc_file), pm.get("_measured_on", "commit not recorded"))
         if conv:
             achieved = conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12
             roofline = {"kernel": "conv3x3_igemm_kernel / conv3x3_igemm16_kernel: every forward + data-gradient launch "
@@ -360,8 +410,15 @@ def main():
                         "bound": "mfma",
                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "launches_per_step": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2),
                         "flop_per_launch": conv["work_per_step"] / conv["launches_per_step"]}
+    hot_ms, hot_launch = None, None
+    if not args.no_profile and not dist_mode:
+        try:
+            hot_ms, hot_launch = hot_path_only(eager, x, max(args.steps, 10), device)
+        except Exception as e:   # never lose the bench line to the extra measurement
+            sys.stderr.write("hot-path-only measurement failed: %s: %s\n" % (type(e).__name__, e))
     if world > 1 or force_dist:
         dist.barrier()
 
@@ -382,6 +439,13 @@ def main():
                        "global_batch": global_batch, "parallelism": "dp%d" % world,
                        "launch": launch,
                        "hot_path_conv_gflop_fwd_per_pair": round(flops["total"] / 1e9, 3)},
+            "hot_path_only_ms": None if hot_ms is None else round(hot_ms, 3),
+            "hot_path_only": None if hot_ms is None else {
+                "what": "KPDetector + generator forward and backward (all weight gradients), no discriminator / losses / "
+                        "optimiser", "launch": hot_launch,
+                "conv_tflops": round(3 * flops["total"] * args.batch / (hot_ms * 1e-3) / 1e12, 2),
+                "frac_of_fp32_mfma_peak": round(3 * flops["total"] * args.batch / (hot_ms * 1e-3) / 1e12
+                                                / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         if pcie is not None:

@@ -253,6 +253,10 @@ int mnk_wgrad_grouped_plan(MnkWgradJob* jobs, int n);
 size_t mnk_wgrad_grouped_table_bytes(int n);
 int mnk_wgrad_grouped_build(const MnkWgradJob* jobs, int n, void* host_table, size_t table_bytes);
 int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, void* stream);
+/* host -> device upload of a small table (launch tables, descriptor arrays) as kernel arguments: 3.5 KB per launch, no
+ * page-locked staging, an ordinary kernel node under hipGraph capture (the bytes are frozen at capture time).  `device`
+ * must be 16-byte aligned and hold bytes rounded up to 16. */
+int mnk_table_upload(const void* host, void* device, size_t bytes, void* stream);
 
 /* ---- optimiser: torch.optim.Adam(lr, betas=(0.5, 0.999)) of train.py:81-83,118-136 for EVERY
  * tensor of a model in one launch.  Formula of torch/optim/adam.py::_single_tensor_adam (no amsgrad / weight decay) in

@@ -1578,7 +1578,14 @@ struct TapJobRec {
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_grouped_kernel(const TapJobRec* __restrict__ recs, int n) {
     __shared__ int sh_idx;
-    const int b = blockIdx.x;
+    // XCD-aware order (see xcd_tile): workgroup L runs on XCD L % 8; XCD class c takes the contiguous range
+    // [c * per, (c + 1) * per) of the logical block order, in which the blocks that share a pixel chunk of a layer
+    // (all its co / ci tiles and taps) are neighbours -- so a chunk's activations are fetched into one L2, not eight
+    int b = blockIdx.x;
+    {
+        const unsigned total = gridDim.x, L = blockIdx.x, c = L & 7u, base = total >> 3, rem = total & 7u;
+        if (total >= 64) b = (int)(c * base + (c < rem ? c : rem) + (L >> 3));
+    }
     const int di = find_desc(&recs[0].block_begin, (int)(sizeof(TapJobRec) / sizeof(int)), n, b, &sh_idx);
     // the record is wave-uniform: keep it in scalar registers (copied field by field through readfirstlane by the compiler
     // when it can prove uniformity; `di` comes from LDS, so say it explicitly)
@@ -1988,7 +1995,7 @@ static void launch_wgrad_reduce(float* ws, int splits, int Cout, int NT, float* 
 }
 
 // ---- grouped tap-major weight gradients: plan / build / launch --------------------------------------------------------
-static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 1024);     // pixels per block of a grouped launch (multiple of 16)
+static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 512);     // pixels per block of a grouped launch (multiple of 16)
 
 // pixel splits of one job of a grouped launch: chunks of ~g_wgroup_chunk pixels, at least 8 K steps each
 static void grouped_split(long M, int* splits, long* pix_per_split) {

@@ -1,6 +1,7 @@
 // Error reporting + per-kernel event timing for libmonkeynet_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <vector>
 
@@ -78,7 +79,37 @@ static void drain() {
 
 }  // namespace mnk
 
+// ---- small host -> device table upload through kernel arguments -------------------------------------------------------
+// Launch tables (descriptor arrays of the multi-layer kernels) change whenever operand addresses change.  A hipMemcpyAsync
+// needs page-locked staging to be capturable and becomes a memcpy node of the graph; a kernel that carries the bytes in
+// its argument block is an ordinary kernel node, needs no staging buffer, and its bytes are frozen at capture time.
+namespace {
+struct Blob {
+    float4 v[224];            // 3584 bytes of payload per launch (kernel argument blocks are limited to 4 KB)
+};
+__global__ void __launch_bounds__(256) table_write_kernel(Blob blob, float4* __restrict__ dst, int n16) {
+    const int i = threadIdx.x;
+    if (i < n16) dst[i] = blob.v[i];
+}
+}  // namespace
+
 extern "C" {
+
+int mnk_table_upload(const void* host, void* device, size_t bytes, void* stream) {
+    MNK_REQUIRE(host && device && bytes > 0 && ((size_t)device % 16) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const char* src = (const char*)host;
+    char* dst = (char*)device;
+    for (size_t off = 0; off < bytes; off += sizeof(Blob)) {
+        Blob b;
+        const size_t k = bytes - off < sizeof(Blob) ? bytes - off : sizeof(Blob);
+        memset(&b, 0, sizeof(b));
+        memcpy(&b, src + off, k);
+        hipLaunchKernelGGL(table_write_kernel, dim3(1), dim3(256), 0, s, b, (float4*)(dst + off), (int)((k + 15) / 16));
+    }
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
 
 int mnk_version(void) { return 100; }
 const char* mnk_last_error(void) { return mnk::g_err; }

@@ -68,8 +68,6 @@ class DeferredReducer:
         self.done = set()         # keys launched / recorded since zero_grad
         self.tables = {}          # tuple(pending keys) -> (device table, n, blocks)
         self.keep = []
-        self._spare_pinned = None  # page-locked staging buffer for the launch table of a CAPTURED flush (made in eager mode:
-                                   # page-locking memory is not allowed while a stream is capturing)
 
     def _record(self, key, weight, sink, shape, flags):
         n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total, hi, wi, ld_dy, c_start = shape
@@ -132,25 +130,18 @@ class DeferredReducer:
             arr[i] = rec["job"][0]
             arr["x"][i], arr["dy"][i], arr["part"][i] = x.data_ptr(), dy.data_ptr(), rec["part"].data_ptr()
         nbytes = lib.query("mnk_wgrad_grouped_table_bytes", len(jobs))
+        host = np.zeros((nbytes + 15) // 16 * 16, dtype=np.uint8)
+        if lib.query("mnk_wgrad_grouped_build", arr.ctypes.data, len(jobs), host.ctypes.data, nbytes) != 0:
+            raise _lib.MnkError("mnk_wgrad_grouped_build failed: %s" % lib.cdll.mnk_last_error().decode())
+        # the table travels as kernel arguments: capturable as it is (frozen into the graph), no page-locked staging
+        table = torch.empty(host.size, dtype=torch.uint8, device=dev)
         if _capturing(dev):
-            # the copy becomes a node of the graph: its pinned source must stay alive and untouched for every replay
-            host = self._spare_pinned
-            if host is None or host.numel() < nbytes:
-                raise RuntimeError("hipGraph capture of a grouped weight-gradient launch needs one eager iteration first")
-            self._spare_pinned = None                     # this one now belongs to the graph
-            if lib.query("mnk_wgrad_grouped_build", arr.ctypes.data, len(jobs), host.data_ptr(), nbytes) != 0:
-                raise _lib.MnkError("mnk_wgrad_grouped_build failed: %s" % lib.cdll.mnk_last_error().decode())
-            table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            table.copy_(host, non_blocking=True)
-            self.keep.extend((host, table))
+            self.keep.append(table)
+        if dev.type == "cuda":
+            mops._call("mnk_table_upload", table, host.ctypes.data, mops._p(table), host.size)
         else:
-            host = torch.zeros(nbytes, dtype=torch.uint8)
-            if lib.query("mnk_wgrad_grouped_build", arr.ctypes.data, len(jobs), host.data_ptr(), nbytes) != 0:
-                raise _lib.MnkError("mnk_wgrad_grouped_build failed: %s" % lib.cdll.mnk_last_error().decode())
-            table = host.to(dev)
-            if dev.type == "cuda" and (self._spare_pinned is None or self._spare_pinned.numel() < nbytes):
-                self._spare_pinned = torch.zeros(nbytes + 4096, dtype=torch.uint8).pin_memory()
-        mops._call("mnk_wgrad_grouped_launch", table, mops._p(table), host.data_ptr())
+            table.copy_(torch.from_numpy(host))
+        mops._call("mnk_wgrad_grouped_launch", table, mops._p(table), host.ctypes.data)
 
     def flush(self):
         """The recorded GEMMs in a few grouped launches, then one launch reducing every pending layer's partials."""

@@ -264,3 +264,15 @@ def test_grouped_weight_gradients_of_many_layers(be, monkeypatch):
     be.sync()
     for DY, DW, ref in keep:
         assert relerr(DW.cpu(), ref) < 2e-6
+
+
+def test_table_upload_through_kernel_arguments(be):
+    """mnk_table_upload: a host table reaches device memory as kernel arguments (3.5 KB per launch, several launches)."""
+    g = torch.Generator().manual_seed(1)
+    for nbytes in (16, 3584, 3600, 12000):
+        host = torch.randint(0, 256, (nbytes,), generator=g, dtype=torch.uint8).numpy()
+        dev = be.zeros((nbytes + 15) // 16 * 16 // 4).view(torch.uint8) if be.kind == "emu" else \
+            torch.zeros((nbytes + 15) // 16 * 16, dtype=torch.uint8, device=be.device)
+        be.lib.call("mnk_table_upload", host.ctypes.data, dev.data_ptr(), nbytes, be.stream())
+        be.sync()
+        assert bytes(dev.cpu().numpy()[:nbytes]) == bytes(host)
