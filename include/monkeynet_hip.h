@@ -182,6 +182,29 @@ size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout);
 int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int flags, const float* dy, int ld_dy, int Cout, float* dw,
                       int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream);
 
+/* ---- sub-pixel forms of UpBlock3D: [nearest x2 up-sampling -> 3x3 / pad 1] (modules/util.py:83-85) ------------------------
+ * Output pixel (2i + a, 2j + b) of the up-sampled convolution only sees the 2 x 2 low-resolution neighbourhood
+ * (rows i + a - 1, i + a; columns j + b - 1, j + b), with weights that are sums of the 3x3 taps falling on the same input
+ * pixel.  So the forward is four 2x2 convolutions on the LOW-resolution input (one per phase (a, b), one launch) and the
+ * data gradient w.r.t. the low-resolution input is ONE 4x4 / stride 2 / pad 1 convolution over dy -- 4 instead of 9
+ * multiply-adds per output and channel pair in both directions, no up-sampled view, no mnk_sumpool2x2 pass.  Same result
+ * as mnk_conv3x3_fwd with MNK_CONV_UPSAMPLED up to the rounding of the pre-summed weights (<= 4 terms).  (H, W) = the LOW
+ * resolution; y / dy are (N, 2H, 2W) tensors; sources need clean pad channels.
+ *   wp_up       [4 phases][Cout][chunk][4 taps][16]           mnk_conv3x3_up_packed_floats
+ *   wp_up_dgrad [C][chunk over Cout][16 taps][16]              mnk_conv3x3_up_dgrad_packed_floats  (one source's channels) */
+size_t mnk_conv3x3_up_packed_floats(int Cout, int C0, int C1);
+size_t mnk_conv3x3_up_dgrad_packed_floats(int Cout, int c_count);
+int mnk_conv3x3_up_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream);
+int mnk_conv3x3_up_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream);
+size_t mnk_conv3x3_up_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
+size_t mnk_conv3x3_up_stats_floats(int N, int H, int W, int C0, int C1, int Cout);
+int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, const float* wp_up, const float* bias,
+                       float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, float* stats_partial,
+                       void* stream);
+size_t mnk_conv3x3_up_dgrad_workspace_floats(int N, int H, int W, int Cout, int C);
+int mnk_conv3x3_up_dgrad(const float* dy, int ld_dy, int Cout, const float* wp_up_dgrad, float* dx, int ld_dx, int N, int H,
+                         int W, int C, float* ws, size_t ws_floats, void* stream);
+
 /* ---- general K x K form of the same kernels (stride 1).  Used for the discriminator's nn.Conv3d((1,4,4)) without
  * padding (modules/discriminator.py:17-18; SURVEY.md section 8f row 1, the first "next" component): forward
  * kh = kw = 4, pad = 0; its data gradient is the same kernel on dy with pad = 3 and the flipped pack.

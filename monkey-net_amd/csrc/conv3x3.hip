@@ -63,6 +63,19 @@ struct ConvArgs {
     int xcd;           // re-chunk the launch order per XCD (xcd_tile)
     int clean;         // the sources' pad channels [C, ld) hold zeros (finite values): the 3x3 fast loader may be used
     unsigned mulW, shW, mulH, shH;   // division of an output pixel index (< 2^31) by W and H (fast_div)
+    // ---- K x K loader generalisations (ActLoaderK) ---------------------------------------------------------------
+    int stride;        // input pixel of output (h, w), tap (ky, kx): (h * stride + ky - pad_y, w * stride + kx - pad_x)
+    int pad_x;         // left padding (`pad` is the top padding); -1: same as `pad`
+    // ---- sub-pixel ("phase") form of [nearest x2 up-sampling -> 3x3 / pad 1] (UpBlock3D, modules/util.py:83-85) -------
+    // Output pixel (2i + a, 2j + b) only sees the 2 x 2 low-resolution neighbourhood rows {i + a - 1, i + a}, columns
+    // {j + b - 1, j + b}, with weights that are sums of the 3x3 taps falling on the same input pixel: four 2x2
+    // convolutions on the low-resolution input (one per phase (a, b)) instead of one 3x3 convolution on the 4x larger
+    // up-sampled view -- 4 instead of 9 multiply-adds per output and channel pair, same result up to the rounding of the
+    // pre-summed weights.  phases = 4: tile bx belongs to phase bx / tiles_per_phase; H, W, M are the LOW-resolution
+    // geometry of one phase; the weights of phase p start at wp + p * phase_wstride; output rows are scattered to
+    // (2i + a, 2j + b) of the (N, 2H, 2W) tensor.
+    int phases, tiles_per_phase;
+    long phase_wstride;
 };
 
 // buffer resource from values the compiler cannot prove wave-uniform (e.g. derived from a 64-bit division): pin the
@@ -113,7 +126,7 @@ struct ActLoader {
     int tail[RA];                  // real channels in ra[j] (<= 0: tap outside the image / chunk beyond C)
     int chunk, ky, kx, khh, Hs, Ws, hmax, wmax, lq;
 
-    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin) {
+    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin, int, int) {
         lq = lq_;
         Hs = a.ups ? a.Hi >> 1 : a.Hi;
         Ws = a.ups ? a.Wi >> 1 : a.Wi;
@@ -199,7 +212,7 @@ struct ActLoader3 {
     __amdgpu_buffer_rsrc_t r0, r1;
     int chunk, ky, kx, Ws, lq4;
 
-    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin) {
+    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin, int, int) {
         lq4 = lq_ * 16;
         const int Hs = UPS ? a.Hi >> 1 : a.Hi;
         Ws = UPS ? a.Wi >> 1 : a.Wi;
@@ -279,20 +292,23 @@ struct ActLoader3 {
 // tap (K*K <= 32); an out-of-image tap or a channel chunk beyond C reads zeros through the buffer range check.
 template <int RA>
 struct ActLoaderK {
-    unsigned b0[RA], b1[RA];       // byte offset of input pixel (h, w) -- tap (pad, pad) -- relative to the block base;
-                                   // may lie outside the image (pad > 0): it is only a base for the tap arithmetic
+    unsigned b0[RA], b1[RA];       // byte offset of input pixel (h * stride, w * stride) -- tap (pad_y, pad_x) -- relative to the
+                                   // block base; may lie outside the image (pad > 0): it is only a base for the tap arithmetic
     unsigned inv[RA];              // bit ky * kw + kx: the tap lies outside the image
     float4 ra[RA];
     __amdgpu_buffer_rsrc_t r0, r1;
-    int chunk, ky, kx, khh, lq4;
+    int chunk, ky, kx, khh, lq4, pady, padx;
 
-    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin) {
+    __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin, int pad_y, int pad_x) {
         lq4 = lq_ * 16;
         khh = a.ntaps / a.kw;
+        pady = pad_y;
+        padx = pad_x;
+        const int sd = a.stride;
         const unsigned mb = (unsigned)(m0 < a.M ? m0 : a.M - 1), tb = fast_div(mb, a.mulW, a.shW),
                        fb = fast_div(tb, a.mulH, a.shH);
-        // lowest address a valid tap of this block can have: input pixel (h0 - pad, -pad) of the first row's frame
-        long pbase = ((long)fb * a.Hi + (int)(tb - fb * (unsigned)a.H) - a.pad) * a.Wi - a.pad;
+        // lowest address a valid tap of this block can have: input pixel (h0 * stride - pad_y, -pad_x) of the first row's frame
+        long pbase = ((long)fb * a.Hi + (int)(tb - fb * (unsigned)a.H) * sd - pad_y) * a.Wi - pad_x;
         if (pbase < 0) pbase = 0;
         r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x0 + pbase * a.ld0), 0, 0x40000000, 0x00020000);
         r1 = __builtin_amdgcn_make_buffer_rsrc((void*)((a.x1 ? a.x1 : a.x0) + pbase * (a.x1 ? a.ld1 : a.ld0)), 0, 0x40000000,
@@ -302,16 +318,16 @@ struct ActLoaderK {
             long ml = m0 + lrow + 64 * j;
             if (ml > a.M - 1) ml = a.M - 1;
             const unsigned m = (unsigned)ml, tt = fast_div(m, a.mulW, a.shW), fr = fast_div(tt, a.mulH, a.shH);
-            const int w = (int)(m - tt * (unsigned)a.W), h = (int)(tt - fr * (unsigned)a.H);
+            const int w = (int)(m - tt * (unsigned)a.W) * sd, h = (int)(tt - fr * (unsigned)a.H) * sd;
             const long rel = ((long)fr * a.Hi + h) * a.Wi + w - pbase;
             b0[j] = (unsigned)(rel * a.ld0 * 4);
             b1[j] = (unsigned)(rel * a.ld1 * 4);
             unsigned mk = 0, bit = 1;
             for (int y = 0; y < khh; ++y) {
-                const int hh = h + y - a.pad;
+                const int hh = h + y - pad_y;
                 const bool rowbad = hh < 0 || hh >= a.Hi;
                 for (int x = 0; x < a.kw; ++x, bit <<= 1) {
-                    const int ww = w + x - a.pad;
+                    const int ww = w + x - pad_x;
                     if (rowbad || ww < 0 || ww >= a.Wi) mk |= bit;
                 }
             }
@@ -330,7 +346,7 @@ struct ActLoaderK {
         const int tap = ky * a.kw + kx;
         unsigned st = (unsigned)(cbase * 4 + lq4);
         st += (cbase * 4 + lq4 >= C * 4) ? 0x40000000u : 0u;
-        st += (unsigned)(((ky - a.pad) * a.Wi + (kx - a.pad)) * ldb);
+        st += (unsigned)(((ky - pady) * a.Wi + (kx - padx)) * ldb);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             unsigned off = (second ? b1[j] : b0[j]) + st;
@@ -371,17 +387,22 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     const int wm = wave / WN, wn = wave % WN;
     int bx, by;
     xcd_tile(a.xcd, bx, by);
-    const long m0 = (long)bx * BM;
+    // sub-pixel form: the M tiles of phase (pa, pb) are [phase * tiles_per_phase, ...); each phase has its own weights
+    // and its own top / left padding (rows i + pa - 1, i + pa of the low-resolution input)
+    const int phase = a.phases > 1 ? bx / a.tiles_per_phase : 0;
+    const int pa = phase >> 1, pb = phase & 1;
+    const long m0 = (long)(bx - phase * a.tiles_per_phase) * BM;
     const int n0 = by * BN;
     const int split = blockIdx.z;
     const int s_begin = split * a.ksteps_per_split;
     int s_end = s_begin + a.ksteps_per_split;
     if (s_end > a.ksteps) s_end = a.ksteps;
+    const float* const wpb = a.wp + (long)phase * a.phase_wstride;
 
     // ---- per-thread global->LDS assignment: row inside a 64-row slab, float4 column (4 channels) --------------
     const int lrow = t >> 2, lq = t & 3;
     typename LoaderSel<RA, MODE>::type L;
-    L.setup(a, m0, lrow, lq, s_begin);
+    L.setup(a, m0, lrow, lq, s_begin, a.pad - pa, (a.pad_x < 0 ? a.pad : a.pad_x) - pb);
     constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
     const long KT = (long)a.ksteps * BK;     // packed row length
     static_assert(RB <= 2, "at most two weight rows per thread");
@@ -392,7 +413,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
 
     auto load_step = [&](int s) __attribute__((always_inline)) {
         L.load(a);
-        const float* wsrc_ptr = a.wp + (long)s * BK;
+        const float* wsrc_ptr = wpb + (long)s * BK;
         rb0 = *reinterpret_cast<const float4*>(wsrc_ptr + woff0);
         if constexpr (RB > 1) rb1 = *reinterpret_cast<const float4*>(wsrc_ptr + woff1);
     };
@@ -479,11 +500,19 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     // load -> wait -> store chains), stores are predicated.
     const bool split_out = a.splits > 1;
     const unsigned ldo = split_out ? (unsigned)a.ldw : (unsigned)a.ld_y;          // 32-bit element offsets (host check)
-    float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
+    // split partials of the sub-pixel form are phase-major: [split][phase][M][ldw]
+    float* const obase = split_out ? a.ws + ((long)split * a.phases + phase) * a.M * a.ldw : a.y;
     const int co_lim = split_out ? a.ldw : a.ld_y;
     const bool use_res = !split_out && a.residual;
     const bool full = m0 + BM <= a.M;             // every row of the tile is a real pixel: no per-row guards
     const unsigned mrow0 = (unsigned)m0 + wm * (BM / WM) + 4 * fk, Mu = (unsigned)a.M;
+    const bool scatter = a.phases > 1 && !split_out;   // row m = (n, i, j) of the phase -> pixel (2i + pa, 2j + pb) of y
+    auto out_row = [&](unsigned m) __attribute__((always_inline)) -> unsigned {
+        if (!scatter) return m;
+        const unsigned tt = fast_div(m, a.mulW, a.shW), fr = fast_div(tt, a.mulH, a.shH);
+        const unsigned j = m - tt * (unsigned)a.W, i = tt - fr * (unsigned)a.H;
+        return ((fr * (unsigned)a.H + i) * 2u + (unsigned)pa) * (2u * (unsigned)a.W) + 2u * j + (unsigned)pb;
+    };
     int cov[TN];
     float bv[TN], s1[TN], s2[TN];
 #pragma unroll
@@ -519,7 +548,10 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
                         float v = acc[i][j][r];
                         if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
                         if (FULL || mb + ro < Mu) {
-                            obase[off0 + ro * ldo] = v;
+                            if (scatter)
+                                obase[out_row(mb + ro) * ldo + (unsigned)co] = v;
+                            else
+                                obase[off0 + ro * ldo] = v;
                             s1[j] += v;
                             s2[j] = fmaf(v, v, s2[j]);
                         }
@@ -586,7 +618,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     if (s_end > a.ksteps) s_end = a.ksteps;
     const int lrow = t >> 2, lq = t & 3;
     typename LoaderSel<RA, MODE>::type L;
-    L.setup(a, m0, lrow, lq, s_begin);
+    L.setup(a, m0, lrow, lq, s_begin, a.pad, a.pad_x < 0 ? a.pad : a.pad_x);
     const long KT = (long)a.ksteps * BK;
     const int wco = n0 + (lrow < BN ? lrow : 0);           // rows beyond BN / Cout: clamped, never stored
     const unsigned woff = (unsigned)((wco < a.Cout ? wco : a.Cout - 1) * KT) + lq * 4;
@@ -730,10 +762,13 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
 __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float* __restrict__ ws, int splits, long M,
                                                                     int ldw, const float* __restrict__ bias,
                                                                     const float* __restrict__ residual, int ld_res,
-                                                                    float* __restrict__ y, int ld_y, int Cout) {
+                                                                    float* __restrict__ y, int ld_y, int Cout, int phases,
+                                                                    int H, int W) {
+    // phases = 4: partials are [split][phase][M][ldw] over the low-resolution pixels (n, i, j) of each sub-pixel phase;
+    // the sum goes to pixel (2i + pa, 2j + pb) of the (N, 2H, 2W) output
     __shared__ float sm[4][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const long total = M * ld_y;
+    const long rows = M * phases, total = rows * ld_y;
     for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
         const long i = base + o;
         long m = 0;
@@ -743,18 +778,25 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float*
             m = i / ld_y;
             co = (int)(i - m * ld_y);
             if (co < Cout)
-                for (int s = g; s < splits; s += 4) v += ws[((long)s * M + m) * ldw + co];
+                for (int s = g; s < splits; s += 4) v += ws[((long)s * rows + m) * ldw + co];
         }
         sm[g][o] = v;
         __syncthreads();
         if (g == 0 && i < total) {
             float r = 0.f;
+            long orow = m;
+            if (phases > 1) {
+                const long ph = m / M, mm = m - ph * M;
+                const long tt = mm / W, fr = tt / H;
+                const long jj = mm - tt * W, ii = tt - fr * H;
+                orow = ((fr * H + ii) * 2 + (ph >> 1)) * (2L * W) + 2 * jj + (ph & 1);
+            }
             if (co < Cout) {
                 r = (sm[0][o] + sm[1][o]) + (sm[2][o] + sm[3][o]);
                 if (bias) r += bias[co];
-                if (residual) r += residual[m * ld_res + co];
+                if (residual) r += residual[orow * ld_res + co];
             }
-            y[i] = r;
+            y[orow * ld_y + co] = r;
         }
         __syncthreads();
     }
@@ -796,6 +838,78 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
         const int ci = (int)(t / chunks);
         const int co = chunk * 16 + k16;
         wp[i] = co < Cout ? w[((long)co * Cin_total + c_start + ci) * ntaps + (ntaps - 1 - tap)] : 0.f;
+    }
+}
+
+// ---- packs of the sub-pixel forms of [nearest x2 up-sampling -> 3x3 / pad 1] (ConvArgs::phases) -----------------------
+// S(a, u): the 3x3 kernel rows that fall on low-resolution row i + a - 1 + u for an output row 2i + a:
+//   S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}                       (same sets for columns)
+// D(t): the 3x3 kernel rows whose gradient reaches low-resolution row i from up-sampled-output row 2i - 1 + t:
+//   D(0) = {2}, D(1) = {1,2}, D(2) = {0,1}, D(3) = {0}
+__device__ __forceinline__ void phase_set(int a, int u, int& lo, int& hi) {      // S(a, u) = [lo, hi]
+    lo = a == 0 ? (u == 0 ? 0 : 1) : (u == 0 ? 0 : 2);
+    hi = a == 0 ? (u == 0 ? 0 : 2) : (u == 0 ? 1 : 2);
+}
+__device__ __forceinline__ void dgrad_set(int t, int& lo, int& hi) {             // D(t) = [lo, hi]
+    lo = t == 0 ? 2 : (t == 1 ? 1 : 0);
+    hi = t == 0 ? 2 : (t == 1 ? 2 : (t == 2 ? 1 : 0));
+}
+
+// forward: wp[phase][co][chunk][tap4 = 2u + v][16] = sum_{ky in S(a,u)} sum_{kx in S(b,v)} w[co][ci][ky][kx], phase = 2a + b
+__global__ void __launch_bounds__(256) pack_up_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                                          int C0, int C1, int C0p, int C1p) {
+    const int Cin = C0 + C1, chunks = (C0p + C1p) / 16;
+    const long per_phase = (long)Cout * chunks * 64, total = 4 * per_phase;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int phase = (int)(i / per_phase);
+        long t = i - phase * per_phase;
+        const int k16 = (int)(t & 15);
+        t >>= 4;
+        const int tap = (int)(t & 3);
+        t >>= 2;
+        const int chunk = (int)(t % chunks), co = (int)(t / chunks);
+        const int k = chunk * 16 + k16;
+        int ci = -1;
+        if (k < C0p) {
+            if (k < C0) ci = k;
+        } else if (k - C0p < C1) {
+            ci = C0 + k - C0p;
+        }
+        float v = 0.f;
+        if (ci >= 0) {
+            int y0, y1, x0, x1;
+            phase_set(phase >> 1, tap >> 1, y0, y1);
+            phase_set(phase & 1, tap & 1, x0, x1);
+            const float* wr = w + ((long)co * Cin + ci) * 9;
+            for (int ky = y0; ky <= y1; ++ky)
+                for (int kx = x0; kx <= x1; ++kx) v += wr[ky * 3 + kx];
+        }
+        wp[i] = v;
+    }
+}
+
+// data gradient w.r.t. the low-resolution input, source channels [c_start, c_start + c_count): a 4x4 / stride 2 / pad 1
+// convolution over dy:  wp[ci][chunk(co)][tap16 = 4 ty + tx][16] = sum_{ky in D(ty)} sum_{kx in D(tx)} w[co][c_start+ci][ky][kx]
+__global__ void __launch_bounds__(256) pack_up_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
+                                                            int Cin_total, int c_start, int c_count, int chunks) {
+    const long total = (long)c_count * chunks * 256;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k16 = (int)(i & 15);
+        long t = i >> 4;
+        const int tap = (int)(t & 15);
+        t >>= 4;
+        const int chunk = (int)(t % chunks), ci = (int)(t / chunks);
+        const int co = chunk * 16 + k16;
+        float v = 0.f;
+        if (co < Cout) {
+            int y0, y1, x0, x1;
+            dgrad_set(tap >> 2, y0, y1);
+            dgrad_set(tap & 3, x0, x1);
+            const float* wr = w + ((long)co * Cin_total + c_start + ci) * 9;
+            for (int ky = y0; ky <= y1; ++ky)
+                for (int kx = x0; kx <= x1; ++kx) v += wr[ky * 3 + kx];
+        }
+        wp[i] = v;
     }
 }
 
@@ -1803,19 +1917,20 @@ static int g_fast_loader = env_int("MNK_FAST_LOADER", 1);
 static int g_kxk_fast = env_int("MNK_KXK_FAST", 1);     // buffer-load loader for K x K / any pad (MODE 3)
 static int g_mfma16 = env_int("MNK_MFMA16", 1);
 
-static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9) {
+static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 1) {
+    // phases > 1 (sub-pixel form): M = pixels of ONE phase, p.gm = tiles of one phase; the launch has phases * gm M tiles
     Plan p;
     p.bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
-    if (g_mfma16) {              // narrow outputs: 16x16x4 MFMA tiles (BN = 16 / 48), see conv3x3_igemm16_kernel
+    if (g_mfma16 && phases == 1) {   // narrow outputs: 16x16x4 MFMA tiles (BN = 16 / 48), see conv3x3_igemm16_kernel
         if (Cout <= 16) p.bn = 16;
         else if (Cout > 32 && Cout <= 48) p.bn = 48;
     }
     p.gn = ceil_div(Cout, p.bn);
     p.bm = 128;
-    if (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn < g_bm64_tiles) p.bm = 64;
+    if (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn * phases < g_bm64_tiles) p.bm = 64;
     p.gm = ceil_div(M, p.bm);
     p.ksteps = ntaps * chunks;
-    long tiles = (long)p.gm * p.gn;
+    long tiles = (long)p.gm * p.gn * phases;
     int splits = 1;
     if (tiles < g_split_tiles) {
         splits = (int)((g_split_target + tiles - 1) / tiles);
@@ -2123,15 +2238,25 @@ size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, 
     return p.splits > 1 ? 0 : (size_t)p.gm * 2 * round_up(Cout, 4);
 }
 
-int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, int Hi, int Wi, int kh,
-                   int kw, int pad, const float* wp, const float* bias, const float* residual, int ld_res, float* y,
-                   int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats, float* stats_partial,
-                   void* stream) {
+}  // extern "C"
+
+// general form behind mnk_conv2d_fwd / mnk_conv3x3_up_fwd / mnk_conv3x3_up_dgrad:
+//   phases == 1: Ho x Wo outputs, input pixel of output (h, w), tap (ky, kx) = (h * stride + ky - pad, w * stride + kx - pad)
+//   phases == 4: the sub-pixel form of [nearest x2 -> 3x3 / pad 1] (ConvArgs): kh = kw = 2, pad = 1, (Hi, Wi) = (Ho, Wo) =
+//                the LOW resolution; y is the (N, 2 Ho, 2 Wo) tensor; wp = four per-phase packs
+static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, int Hi, int Wi, int kh,
+                           int kw, int pad, int stride, int phases, const float* wp, const float* bias, const float* residual,
+                           int ld_res, float* y, int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats,
+                           float* stats_partial, void* stream) {
     MNK_REQUIRE(flags >= 0 && flags <= 3);
     const int ups = flags & MNK_CONV_UPSAMPLED, clean = (flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
     MNK_REQUIRE(x0 && wp && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
-    MNK_REQUIRE(kh > 0 && kw > 0 && pad >= 0 && Hi > 0 && Wi > 0);
-    MNK_REQUIRE(Ho == Hi + 2 * pad - kh + 1 && Wo == Wi + 2 * pad - kw + 1);
+    MNK_REQUIRE(kh > 0 && kw > 0 && pad >= 0 && Hi > 0 && Wi > 0 && stride >= 1 && (phases == 1 || phases == 4));
+    if (phases == 4)
+        MNK_REQUIRE(kh == 2 && kw == 2 && pad == 1 && stride == 1 && Ho == Hi && Wo == Wi && !ups && clean && !residual);
+    else
+        MNK_REQUIRE(Ho == (Hi + 2 * pad - kh) / stride + 1 && Wo == (Wi + 2 * pad - kw) / stride + 1);
+    MNK_REQUIRE(stride == 1 || (clean && !ups));
     MNK_REQUIRE(ld0 % 4 == 0 && ld0 >= C0 && ld_y % 4 == 0 && ld_y >= Cout && ld_y <= round_up(Cout, 16));
     MNK_REQUIRE(C1 == 0 || (x1 && ld1 % 4 == 0 && ld1 >= C1));
     MNK_REQUIRE(!ups || (Hi % 2 == 0 && Wi % 2 == 0));
@@ -2164,11 +2289,17 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     a.pad = pad;
     a.Cout = Cout;
     a.M = (long)N * Ho * Wo;
-    MNK_REQUIRE(a.M < (1L << 31) && a.M * round_up(Cout, 16) < (1L << 32) && (!residual || a.M * ld_res < (1L << 32)));
+    MNK_REQUIRE(a.M * phases < (1L << 31) && a.M * phases * round_up(Cout, 16) < (1L << 32) &&
+                (!residual || a.M * ld_res < (1L << 32)));
     fast_div_consts((unsigned)Wo, &a.mulW, &a.shW);
     fast_div_consts((unsigned)Ho, &a.mulH, &a.shH);
     a.chunks = (a.C0p + a.C1p) / 16;
-    Plan p = make_plan(a.M, Cout, a.chunks, ntaps);
+    a.stride = stride;
+    a.pad_x = -1;
+    Plan p = make_plan(a.M, Cout, a.chunks, ntaps, phases);
+    a.phases = phases;
+    a.tiles_per_phase = p.gm;
+    a.phase_wstride = (long)Cout * ntaps * (a.C0p + a.C1p);
     a.ksteps = p.ksteps;
     a.ksteps_per_split = p.ksteps_per_split;
     a.splits = p.splits;
@@ -2177,23 +2308,31 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     a.stats = stats_partial;
     a.xcd = g_xcd_remap;
     MNK_REQUIRE(!stats_partial || (p.splits == 1 && ld_y == round_up(Cout, 4)));
-    if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * a.M * p.ldw)) {
-        set_error("mnk_conv2d_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * a.M * p.ldw);
+    if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * phases * a.M * p.ldw)) {
+        set_error("mnk_conv2d_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * phases * a.M * p.ldw);
         return MNK_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(p.gm, p.gn, p.splits);
+    dim3 grid(p.gm * phases, p.gn, p.splits);
     {
-        ProfScope prof(K_CONV_FWD, s, 2.0 * (double)a.M * Cout * (double)ntaps * (C0 + C1));
+        // algorithmic FLOPs of the convolution this launch stands for: the sub-pixel form computes a 3x3 convolution on
+        // 4 M output pixels; a stride-2 4x4 data gradient stands for the 3x3 data gradient at 4 M pixels
+        const double alg = phases == 4 ? 2.0 * 4.0 * (double)a.M * Cout * 9.0 * (C0 + C1)
+                                       : (stride == 2 ? 2.0 * 4.0 * (double)a.M * Cout * 9.0 * (C0 + C1)
+                                                      : 2.0 * (double)a.M * Cout * (double)ntaps * (C0 + C1));
+        ProfScope prof(K_CONV_FWD, s, alg);
         // loader: the 3x3 / pad 1 fast form when the caller vouches for clean pad channels and a block's pixel span
         // fits the 2^30-byte buffer window (always, short of ~2 M-float pixel rows)
         const long span = ((long)BK * 8 + 3L * (ups ? Wi / 2 : Wi) + 8) * (ld0 > ld1 ? ld0 : ld1) * 4;
-        int mode = (g_fast_loader && a.clean && kh == 3 && kw == 3 && pad == 1 && span < (1L << 29) &&
-                    (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0)) ? (ups ? 2 : 1) : 0;
+        int mode = (g_fast_loader && a.clean && kh == 3 && kw == 3 && pad == 1 && stride == 1 && phases == 1 &&
+                    span < (1L << 29) && (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0)) ? (ups ? 2 : 1) : 0;
         // any other K x K / pad (the discriminator's 4x4 convolutions and their pad-3 data gradients): ActLoaderK.  A
         // block's 128 output pixels span at most 128 * kh * kw + (kh + 3) * Wi input pixels (a 1x1 output per frame
         // advances a whole kh x kw input frame per output pixel; plus the rows of the taps)
-        const long span_k = (128L * kh * kw + (long)(kh + 3) * Wi) * (ld0 > ld1 ? ld0 : ld1) * 4;
+        const long span_k = (128L * kh * kw * stride * stride + (long)(kh + 3) * Wi) * (ld0 > ld1 ? ld0 : ld1) * 4;
+        MNK_REQUIRE((stride == 1 && phases == 1) ||
+                    (g_fast_loader && g_kxk_fast && ntaps <= 32 && span_k < (1L << 29) && (size_t)x0 % 16 == 0 &&
+                     (!x1 || (size_t)x1 % 16 == 0)));          // strided / sub-pixel forms exist for the K x K buffer loader only
         if (mode == 0 && g_fast_loader && g_kxk_fast && a.clean && !ups && ntaps <= 32 && pad >= 0 && pad < kh && pad < kw &&
             span_k < (1L << 29) && (size_t)x0 % 16 == 0 && (!x1 || (size_t)x1 % 16 == 0))
             mode = 3;
@@ -2231,11 +2370,21 @@ int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, i
     }
     if (p.splits > 1) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
-        hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * ld_y * 4, 8192)), dim3(256), 0, s, ws, p.splits, a.M,
-                           p.ldw, bias, residual, ld_res, y, ld_y, Cout);
+        hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * phases * ld_y * 4, 8192)), dim3(256), 0, s, ws,
+                           p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W);
     }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+extern "C" {
+
+int mnk_conv2d_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, int Hi, int Wi, int kh,
+                   int kw, int pad, const float* wp, const float* bias, const float* residual, int ld_res, float* y,
+                   int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats, float* stats_partial,
+                   void* stream) {
+    return conv2d_fwd_impl(x0, ld0, C0, x1, ld1, C1, flags, Hi, Wi, kh, kw, pad, 1, 1, wp, bias, residual, ld_res, y, ld_y, N,
+                           Ho, Wo, Cout, ws, ws_floats, stats_partial, stream);
 }
 
 size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad) {
@@ -2706,6 +2855,66 @@ int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int to
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(256), 0, s, descs_device, n);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+// ---- sub-pixel forms of UpBlock3D's [nearest x2 -> 3x3 / pad 1] (modules/util.py:83-85): (H, W) = LOW resolution -----------
+size_t mnk_conv3x3_up_packed_floats(int Cout, int C0, int C1) {
+    if (Cout <= 0 || C0 <= 0 || C1 < 0) return 0;
+    return (size_t)16 * Cout * (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0));
+}
+size_t mnk_conv3x3_up_dgrad_packed_floats(int Cout, int c_count) {
+    if (Cout <= 0 || c_count <= 0) return 0;
+    return (size_t)c_count * 16 * round_up(Cout, 16);
+}
+int mnk_conv3x3_up_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1, void* stream) {
+    MNK_REQUIRE(w && wp && Cout > 0 && C0 > 0 && C1 >= 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int C0p = round_up(C0, 16), C1p = C1 > 0 ? round_up(C1, 16) : 0;
+    const long total = (long)16 * Cout * (C0p + C1p);
+    ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
+    hipLaunchKernelGGL(pack_up_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, C0, C1, C0p, C1p);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+int mnk_conv3x3_up_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream) {
+    MNK_REQUIRE(w && wp && Cout > 0 && Cin_total > 0 && c_start >= 0 && c_count > 0 && c_start + c_count <= Cin_total);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = round_up(Cout, 16) / 16;
+    const long total = (long)c_count * chunks * 256;
+    ProfScope prof(K_CONV_REDUCE, s, (double)total * 8);
+    hipLaunchKernelGGL(pack_up_dgrad_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, wp, Cout, Cin_total, c_start, c_count,
+                       chunks);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+size_t mnk_conv3x3_up_workspace_floats(int N, int H, int W, int C0, int C1, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
+    Plan p = make_plan((long)N * H * W, Cout, chunks, 4, 4);
+    return p.splits > 1 ? (size_t)p.splits * 4 * N * H * W * p.ldw : 0;
+}
+size_t mnk_conv3x3_up_stats_floats(int N, int H, int W, int C0, int C1, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
+    Plan p = make_plan((long)N * H * W, Cout, chunks, 4, 4);
+    return p.splits > 1 ? 0 : (size_t)4 * p.gm * 2 * round_up(Cout, 4);
+}
+int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, const float* wp_up, const float* bias,
+                       float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, float* stats_partial,
+                       void* stream) {
+    return conv2d_fwd_impl(x0, ld0, C0, x1, ld1, C1, MNK_CONV_CLEAN_PADS, H, W, 2, 2, 1, 1, 4, wp_up, bias, nullptr, 0, y, ld_y, N,
+                           H, W, Cout, ws, ws_floats, stats_partial, stream);
+}
+// data gradient w.r.t. one low-resolution source of an up-sampled convolution: dy (N, 2H, 2W, Cout) -> dx (N, H, W, C)
+size_t mnk_conv3x3_up_dgrad_workspace_floats(int N, int H, int W, int Cout, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0) return 0;
+    Plan p = make_plan((long)N * H * W, C, round_up(Cout, 16) / 16, 16, 1);
+    return p.splits > 1 ? (size_t)p.splits * N * H * W * p.ldw : 0;
+}
+int mnk_conv3x3_up_dgrad(const float* dy, int ld_dy, int Cout, const float* wp_up_dgrad, float* dx, int ld_dx, int N, int H,
+                         int W, int C, float* ws, size_t ws_floats, void* stream) {
+    return conv2d_fwd_impl(dy, ld_dy, Cout, nullptr, 0, 0, MNK_CONV_CLEAN_PADS, 2 * H, 2 * W, 4, 4, 1, 2, 1, wp_up_dgrad, nullptr,
+                           nullptr, 0, dx, ld_dx, N, H, W, C, ws, ws_floats, nullptr, stream);
 }
 
 // ---- 3x3 / pad 1 forms (the hot path's nn.Conv3d (1,3,3)) ------------------------------------------------------------

@@ -344,3 +344,62 @@ def test_conv4x4_nopad_forward_dgrad_wgrad(be, case, clean):
     assert relerr(from_nhwc(Y.cpu(), cout), ref) < 2e-6
     assert relerr(from_nhwc(DX.cpu(), cin), xd.grad) < 2e-6
     assert relerr(DW.cpu(), wd.grad) < 2e-6
+
+
+# ---- sub-pixel forms of [nearest x2 up-sampling -> 3x3 / pad 1] (UpBlock3D): (n, h_low, w_low, c0, c1, cout, bias)
+UP_CASES = [(2, 4, 4, 16, 10, 70, True),        # two sources, 64x128 tile, split-K (few tiles)
+            (1, 1, 1, 32, 0, 24, True),         # 1x1 -> 2x2 (every tap of some phases falls outside)
+            (3, 3, 5, 20, 0, 136, False),       # odd sizes, two N tiles
+            (2, 16, 16, 24, 17, 40, True),      # no split-K: scattered epilogue + fused statistics
+            (6, 32, 32, 5, 0, 20, True),        # many tiles, XCD re-chunked order, 128x32 tile
+            (2, 8, 8, 72, 0, 130, True)]
+
+
+@pytest.mark.parametrize("case", UP_CASES)
+def test_conv3x3_upsampled_subpixel_forward_and_dgrad(be, case):
+    """mnk_conv3x3_up_fwd (four 2x2 phase convolutions on the low-resolution input) and mnk_conv3x3_up_dgrad (one 4x4 /
+    stride 2 convolution over dy) against conv2d(interpolate(x, 2, 'nearest')) and its input gradient in fp64."""
+    n, h, w, c0, c1, cout, bias = case
+    g = torch.Generator().manual_seed(31)
+    x0 = torch.randn(n, c0, h, w, generator=g)
+    x1 = torch.randn(n, c1, h, w, generator=g) if c1 else None
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) if bias else None
+    x = (x0 if x1 is None else torch.cat([x0, x1], 1)).double().requires_grad_(True)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt.double(), None if b is None else b.double(), padding=1)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    W = be.t(wt)
+    wp = be.empty(be.query("mnk_conv3x3_up_packed_floats", cout, c0, c1))
+    be.call("mnk_conv3x3_up_pack_fwd", W, wp, cout, c0, c1)
+    X0 = be.t(to_nhwc(x0))
+    X1 = be.t(to_nhwc(x1)) if c1 else None
+    ldy = ceil4(cout)
+    Y = be.empty(n, 2 * h, 2 * w, ldy)
+    nws = be.query("mnk_conv3x3_up_workspace_floats", n, h, w, c0, c1, cout)
+    ws = be.empty(max(nws, 1))
+    nst = be.query("mnk_conv3x3_up_stats_floats", n, h, w, c0, c1, cout)
+    st = be.empty(nst) if nst else None
+    be.call("mnk_conv3x3_up_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if c1 else 0, c1, wp, be.t(b) if bias else None, Y, ldy,
+            n, h, w, cout, ws, nws, st)
+    be.sync()
+    assert relerr(from_nhwc(Y.cpu(), cout), ref) < 2e-6
+    assert torch.all(Y.cpu()[..., cout:] == 0), "pad channels of the output must be written as zero"
+    if nst:
+        sums = be.empty(2 * cout)
+        be.call("mnk_bn_stats_finish", st, nst // (2 * ldy), ldy, cout, sums)
+        be.sync()
+        yd = ref.detach()
+        assert relerr(sums.cpu(), torch.cat([yd.sum(dim=(0, 2, 3)), (yd * yd).sum(dim=(0, 2, 3))])) < 1e-5
+    DY = be.t(to_nhwc(dy.float()))
+    for c_start, c_cnt in ((0, c0),) + (((c0, c1),) if c1 else ()):
+        wd = be.empty(be.query("mnk_conv3x3_up_dgrad_packed_floats", cout, c_cnt))
+        be.call("mnk_conv3x3_up_pack_dgrad", W, wd, cout, c0 + c1, c_start, c_cnt)
+        ld = ceil4(c_cnt)
+        DX = be.empty(n, h, w, ld)
+        nws2 = be.query("mnk_conv3x3_up_dgrad_workspace_floats", n, h, w, cout, c_cnt)
+        ws2 = be.empty(max(nws2, 1))
+        be.call("mnk_conv3x3_up_dgrad", DY, ldy, cout, wd, DX, ld, n, h, w, c_cnt, ws2, nws2)
+        be.sync()
+        assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
+        assert torch.all(DX.cpu()[..., c_cnt:] == 0)
