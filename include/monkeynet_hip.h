@@ -161,6 +161,8 @@ typedef struct MnkPackDesc {
     float* wp_d0;
     float* wp_d1;
     int Cout, C0, C1, tile_begin;
+    int flags;      /* bit 0: an up-sampled convolution -- emit the packs of its sub-pixel forms (mnk_conv3x3_up_*) instead */
+    int reserved;
 } MnkPackDesc;
 int mnk_conv3x3_pack_multi(const MnkPackDesc* descs_device, int n, int total_tiles, void* stream);
 size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
@@ -237,11 +239,19 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
  * mnk_wgrad_reduce_blocks(splits, Cout, C) blocks from block_begin; total_blocks = their sum.  Deterministic order. */
 #define MNK_WGRAD_DEFER 4
 typedef struct MnkWgradPlan {
-    int layout;          /* 0: tap-major partials [split][tap][Cout][C]; 1: parameter-major [split][Cout][C * ntaps] */
+    int layout;          /* 0: tap-major partials [split][tap][Cout][C]; 1: parameter-major [split][Cout][C * ntaps];
+                          * 2: tap-major with the 16 pseudo taps of the sub-pixel form (mnk_conv2d_wgrad_plan2) */
     int splits;          /* 0: the GEMM writes dw itself -- nothing to reduce */
     size_t part_floats;  /* floats of `ws` the GEMM fills under MNK_WGRAD_DEFER */
 } MnkWgradPlan;
 int mnk_conv2d_wgrad_plan(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad, int ld_x, MnkWgradPlan* plan);
+/* the same with the `flags` the GEMM will be called with: an up-sampled 3x3 layer with clean sources (MNK_CONV_UPSAMPLED |
+ * MNK_CONV_CLEAN_PADS) runs in its sub-pixel form -- 16 pseudo taps over the low-resolution pixels (4/9 of the multiply-adds)
+ * -- and leaves layout 2: [split][16][Cout][C], folded into the nine kernel taps by mnk_wgrad_reduce_multi */
+int mnk_conv2d_wgrad_plan2(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad, int ld_x, int flags,
+                           MnkWgradPlan* plan);
+/* workspace of mnk_conv3x3_wgrad for an up-sampled layer (either form; Ho, Wo = the up-sampled size) */
+size_t mnk_conv3x3_up_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout);
 typedef struct MnkWgradReduceDesc {
     const float* part;
     float* dw;           /* start of the (Cout, Cin_total, ntaps) gradient */
@@ -301,6 +311,8 @@ typedef struct MnkAdamDesc {
     float* wp_d0;
     float* wp_d1;
     int Cout, C0, C1, block_begin;
+    int flags;      /* bit 0: an up-sampled convolution -- emit the packs of its sub-pixel forms (mnk_conv3x3_up_*) */
+    int reserved;
 } MnkAdamDesc;
 int mnk_adam_blocks(long n, int Cout, int C0, int C1, int packed);
 int mnk_adam_tick(float* hyper, void* stream);

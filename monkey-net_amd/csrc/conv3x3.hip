@@ -846,14 +846,8 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
 //   S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}                       (same sets for columns)
 // D(t): the 3x3 kernel rows whose gradient reaches low-resolution row i from up-sampled-output row 2i - 1 + t:
 //   D(0) = {2}, D(1) = {1,2}, D(2) = {0,1}, D(3) = {0}
-__device__ __forceinline__ void phase_set(int a, int u, int& lo, int& hi) {      // S(a, u) = [lo, hi]
-    lo = a == 0 ? (u == 0 ? 0 : 1) : (u == 0 ? 0 : 2);
-    hi = a == 0 ? (u == 0 ? 0 : 2) : (u == 0 ? 1 : 2);
-}
-__device__ __forceinline__ void dgrad_set(int t, int& lo, int& hi) {             // D(t) = [lo, hi]
-    lo = t == 0 ? 2 : (t == 1 ? 1 : 0);
-    hi = t == 0 ? 2 : (t == 1 ? 2 : (t == 2 ? 1 : 0));
-}
+__device__ __forceinline__ void phase_set(int a, int u, int& lo, int& hi) { up_phase_set(a, u, lo, hi); }
+__device__ __forceinline__ void dgrad_set(int t, int& lo, int& hi) { up_dgrad_set(t, lo, hi); }
 
 // forward: wp[phase][co][chunk][tap4 = 2u + v][16] = sum_{ky in S(a,u)} sum_{kx in S(b,v)} w[co][ci][ky][kx], phase = 2a + b
 __global__ void __launch_bounds__(256) pack_up_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
@@ -938,7 +932,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const MnkPackDesc* __re
     const int local = b - d.tile_begin;
     const int C0p = round_up16(d.C0), C1p = d.C1 > 0 ? round_up16(d.C1) : 0, tiles_x = (C0p + C1p) / 16;
     const int cot = local / tiles_x, cc = local - cot * tiles_x;
-    pack_tile<9>(T, d.w, d.wp_fwd, d.wp_d0, d.wp_d1, d.Cout, d.C0, d.C1, C0p, C1p, 9, cc, cot);
+    pack_tile<9>(T, d.w, d.wp_fwd, d.wp_d0, d.wp_d1, d.Cout, d.C0, d.C1, C0p, C1p, 9, cc, cot, d.flags & 1);
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------
@@ -1446,6 +1440,9 @@ struct WgradTapArgs {
     int xcd;             // re-chunk the launch order per XCD (xcd_tile)
     int clean;           // pad channels of x and dy hold zeros: the buffer-load fast path may be used
     int sw, sh, sn;      // fast path: one 16-pixel K step = sw columns + sh rows + sn frames
+    // MODE 3 -- sub-pixel form of an up-sampled 3x3 convolution: H, W, M are the LOW resolution; the 16 "taps" are
+    // t = 4 * (2a + b) + (2u + v): dWeff[t] = sum_{n,i,j} dy[n, 2i+a, 2j+b] (x) x[n, i+a-1+u, j+b-1+v]  (4/9 of the multiply-adds of
+    // the nine-tap form; the reduction folds the 16 pseudo taps into the nine kernel taps)
 };
 
 // MODE 0: generic loader (any K x K, masks, clamps, magic-number division per row and step).  MODE 1 / 2: 3x3 pad 1 with
@@ -1473,7 +1470,10 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
     long p_end = p_begin + a.pix_per_split;
     if (p_end > a.M) p_end = a.M;
     const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
-    const int dyt = tap / a.kw - a.pad, dxt = tap % a.kw - a.pad;
+    constexpr bool SUBPIX = MODE == 3, FAST = MODE == 1 || MODE == 2;
+    const int ph_a = (tap >> 3) & 1, ph_b = (tap >> 2) & 1;                      // SUBPIX: output phase of this pseudo tap
+    const int dyt = SUBPIX ? ph_a - 1 + ((tap >> 1) & 1) : tap / a.kw - a.pad;   // SUBPIX: low-resolution row / column offset
+    const int dxt = SUBPIX ? ph_b - 1 + (tap & 1) : tap % a.kw - a.pad;
     const int hmax = a.Hi - 1, wmax = a.Wi - 1;
     const unsigned plast = (unsigned)(a.M - 1), pend = (unsigned)p_end;
 
@@ -1488,7 +1488,13 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
     auto load_a = [&](unsigned p, float4& v, int& tl) __attribute__((always_inline)) {
         tl = p < pend ? tail_a : 0;
         const unsigned pe = p < plast ? p : plast;
-        v = *reinterpret_cast<const float4*>(a.dy + (unsigned long)pe * (unsigned)a.ld_dy + coa_e);
+        unsigned long row = pe;
+        if constexpr (SUBPIX) {          // low-resolution pixel (n, i, j) -> pixel (2i + a, 2j + b) of the up-sampled dy
+            const unsigned q = fast_div(pe, a.mulW, a.shW), n = fast_div(q, a.mulH, a.shH);
+            const unsigned j = pe - q * (unsigned)a.W, i = q - n * (unsigned)a.H;
+            row = ((unsigned long)(n * (unsigned)a.H + i) * 2u + (unsigned)ph_a) * (2u * (unsigned)a.W) + 2u * j + (unsigned)ph_b;
+        }
+        v = *reinterpret_cast<const float4*>(a.dy + row * (unsigned)a.ld_dy + coa_e);
     };
     auto load_b = [&](unsigned p, float4& v, int& tl) __attribute__((always_inline)) {
         const unsigned pe = p < plast ? p : plast;
@@ -1504,14 +1510,14 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
         const unsigned pix = (n * (unsigned)Hs + (unsigned)(hh >> a.ups)) * (unsigned)Ws + (unsigned)(ww >> a.ups);
         v = *reinterpret_cast<const float4*>(a.x + (unsigned long)pix * (unsigned)a.ld_x + cib_e);
     };
-    // ---- fast loader state (MODE != 0) -----------------------------------------------------------------------
+    // ---- fast loader state (MODE 1 / 2) ---------------------------------------------------------------------
     constexpr bool FUPS = MODE == 2;
     __amdgpu_buffer_rsrc_t rsa, rsb;
     unsigned aoff0 = 0, aoff1 = 0, boff0 = 0, boff1 = 0;     // running byte offsets (non-ups B: linear in the pixel)
     int bw0 = 0, bh0 = 0, bn0 = 0, bw1 = 0, bh1 = 0, bn1 = 0;  // (w, h, frame relative to the first) of the B rows
     const int ldy4 = a.ld_dy * 4, ldx4 = a.ld_x * 4;
     const int hbad = dyt < 0 ? 0 : (dyt > 0 ? a.H - 1 : -1), wbad = dxt < 0 ? 0 : (dxt > 0 ? a.W - 1 : -1);
-    if constexpr (MODE != 0) {
+    if constexpr (FAST) {
         rsa = uniform_rsrc(a.dy + p_begin * a.ld_dy, (unsigned)((p_end - p_begin) * ldy4));
         const unsigned tail_flag_a = tail_a > 0 ? 0u : 0x40000000u, tail_flag_b = tail_b > 0 ? 0u : 0x40000000u;
         aoff0 = (unsigned)(ar * ldy4 + (int)coa_e * 4) + tail_flag_a;
@@ -1554,7 +1560,7 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
         if constexpr (FUPS) n += a.sn + (hw ? 1 : 0);
     };
     auto load_step = [&](long p0) __attribute__((always_inline)) {
-        if constexpr (MODE != 0) {
+        if constexpr (FAST) {
             ra0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsa, aoff0, 0, 0));
             aoff0 += (unsigned)(BK * ldy4);
             if constexpr (RA > 1) {
@@ -1572,7 +1578,7 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
         }
     };
     auto masked = [&](float4 v, int tl) __attribute__((always_inline)) {
-        if constexpr (MODE != 0) return v;
+        if constexpr (FAST) return v;
         v.x = tl < 1 ? 0.f : v.x;
         v.y = tl < 2 ? 0.f : v.y;
         v.z = tl < 3 ? 0.f : v.z;
@@ -1716,9 +1722,29 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_grouped_kernel(const
 // reads are coalesced along ci with four independent split-sum chains per element (loads in flight), the
 // (tap, ci) -> (ci, tap) transposition goes through LDS, writes are contiguous runs of 64 * ntaps floats.
 // Fixed summation order (deterministic).
+// the pseudo taps of the sub-pixel form that contribute to kernel row (column) k: (a, u) with k in S(a, u) -- two each
+__device__ __forceinline__ void up_fold_pairs(int k, int& a0, int& u0, int& a1, int& u1) {
+    // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+    a0 = 0, u0 = k == 0 ? 0 : 1;          // k = 0: (0,0); k = 1, 2: (0,1)
+    a1 = 1, u1 = k == 2 ? 1 : 0;          // k = 0, 1: (1,0); k = 2: (1,1)
+}
+// dW[ky][kx] from the 16 pseudo-tap sums acc[4 * (2a + b) + 2u + v]
+__device__ __forceinline__ float up_fold(const float* acc, int ky, int kx, int stride) {
+    int ya[2], yu[2], xb[2], xv[2];
+    up_fold_pairs(ky, ya[0], yu[0], ya[1], yu[1]);
+    up_fold_pairs(kx, xb[0], xv[0], xb[1], xv[1]);
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) v += acc[(4 * (2 * ya[p] + xb[q]) + 2 * yu[p] + xv[q]) * stride];
+    return v;
+}
+
 __global__ void __launch_bounds__(256) conv3x3_wgrad_tap_reduce_kernel(const float* __restrict__ part, int splits,
                                                                        int ntaps, int Cout, int C,
-                                                                       float* __restrict__ dw, long ld_out) {
+                                                                       float* __restrict__ dw, long ld_out, int up) {
+    // up: `ntaps` = 16 pseudo taps of the sub-pixel form in `part`, folded into the 9 kernel taps of dw
     __shared__ float tile[16][65];
     const int t = threadIdx.x;
     const int ci0 = blockIdx.x * 64, co = blockIdx.y;
@@ -1741,11 +1767,12 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_tap_reduce_kernel(const flo
         tile[tp][c] = c_ok ? (v0 + v1) + (v2 + v3) : 0.f;
     }
     __syncthreads();
-    float* dst = dw + (long)co * ld_out + (long)ci0 * ntaps;
-    const int lim = (C - ci0 < 64 ? C - ci0 : 64) * ntaps;
+    const int nout = up ? 9 : ntaps;
+    float* dst = dw + (long)co * ld_out + (long)ci0 * nout;
+    const int lim = (C - ci0 < 64 ? C - ci0 : 64) * nout;
     for (int idx = t; idx < lim; idx += 256) {
-        const int cc = idx / ntaps, tp = idx - cc * ntaps;
-        dst[idx] = tile[tp][cc];
+        const int cc = idx / nout, tp = idx - cc * nout;
+        dst[idx] = up ? up_fold(&tile[0][cc], tp / 3, tp % 3, 65) : tile[tp][cc];
     }
 }
 
@@ -1834,9 +1861,10 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
     const bool row_ok = co < d.Cout;
     const int s0 = rpb == 1 ? g : 0, sstep = rpb == 1 ? groups : 1;
     float* smg = sm + g * gstride;
-    if (d.layout == 0) {
-        // part[s][tap][co][ci]
-        const long plane = (long)d.Cout * d.C, sstride = (long)ntaps * plane;
+    if (d.layout == 0 || d.layout == 2) {
+        // part[s][tap][co][ci]; layout 2: 16 pseudo taps of the sub-pixel form, folded into the 9 kernel taps below
+        const int nin = d.layout == 2 ? 16 : ntaps;
+        const long plane = (long)d.Cout * d.C, sstride = (long)nin * plane;
         const bool ok = c < cw && row_ok;
         const float* src = d.part + (long)(row_ok ? co : 0) * d.C + ci0 + (ok ? c : 0);
         float acc[16], acc2[16];
@@ -1848,7 +1876,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
             const float* pt = ps + (long)sstep * sstride;
 #pragma unroll
             for (int tp = 0; tp < 16; ++tp)
-                if (tp < ntaps) {
+                if (tp < nin) {
                     acc[tp] += ps[(long)tp * plane];
                     acc2[tp] += pt[(long)tp * plane];
                 }
@@ -1857,11 +1885,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
             const float* ps = src + (long)sp * sstride;
 #pragma unroll
             for (int tp = 0; tp < 16; ++tp)
-                if (tp < ntaps) acc[tp] += ps[(long)tp * plane];
+                if (tp < nin) acc[tp] += ps[(long)tp * plane];
         }
 #pragma unroll
-        for (int tp = 0; tp < 16; ++tp)
-            if (tp < ntaps) smg[c * ntaps + tp] = ok ? acc[tp] + acc2[tp] : 0.f;      // already in (ci, tap) order
+        for (int tp = 0; tp < 16; ++tp) acc[tp] += acc2[tp];
+        if (d.layout == 2) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) smg[c * 9 + tp] = ok ? up_fold(acc, tp / 3, tp % 3, 1) : 0.f;
+        } else {
+#pragma unroll
+            for (int tp = 0; tp < 16; ++tp)
+                if (tp < ntaps) smg[c * ntaps + tp] = ok ? acc[tp] : 0.f;      // already in (ci, tap) order
+        }
     } else {
         // part[s][co][ci * ntaps + tap]
         const long NT = (long)d.C * ntaps, sstride = (long)d.Cout * NT;
@@ -2110,7 +2145,20 @@ static void launch_wgrad_reduce(float* ws, int splits, int Cout, int NT, float* 
 }
 
 // ---- grouped tap-major weight gradients: plan / build / launch --------------------------------------------------------
-static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 512);     // pixels per block of a grouped launch (multiple of 16)
+static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 512);
+static int g_up_subpixel = env_int("MNK_UP_SUBPIXEL", 1);     // weight gradients of up-sampled convolutions: sub-pixel form
+
+// the sub-pixel tap-major plan of an up-sampled 3x3 layer (flags: UPSAMPLED | CLEAN_PADS), or use = false
+static TPlan make_up_tplan(int N, int Ho, int Wo, int Cout, int C, int kh, int kw, int pad, int ld_x, int flags) {
+    TPlan tp;
+    tp.use = false;
+    if (!(g_up_subpixel && (flags & MNK_CONV_UPSAMPLED) && (flags & MNK_CONV_CLEAN_PADS) && kh == 3 && kw == 3 && pad == 1 &&
+          Ho % 2 == 0 && Wo % 2 == 0))
+        return tp;
+    TPlan base = make_tplan((long)N * Ho * Wo, Cout, C, 9, ld_x);
+    if (!base.use) return tp;                       // narrow layers keep their own kernels
+    return make_tplan((long)N * (Ho / 2) * (Wo / 2), Cout, C, 16, ld_x);
+}     // pixels per block of a grouped launch (multiple of 16)
 
 // pixel splits of one job of a grouped launch: chunks of ~g_wgroup_chunk pixels, at least 8 K steps each
 static void grouped_split(long M, int* splits, long* pix_per_split) {
@@ -2124,7 +2172,7 @@ static void grouped_split(long M, int* splits, long* pix_per_split) {
     *splits = (int)((steps + steps_per - 1) / steps_per);
 }
 
-// variant id of a tap-major job: 3 * tile + mode; tile 0: 128x128, 1: 128x64, 2: 64x128, 3: 32x128
+// variant id of a tap-major job: 4 * tile + mode; tile 0: 128x128, 1: 128x64, 2: 64x128, 3: 32x128; mode 3: sub-pixel form
 static int tap_tile_id(const TPlan& tp) {
     if (tp.bm == 128 && tp.bn == 128) return 0;
     if (tp.bm == 128) return 1;
@@ -2134,7 +2182,11 @@ static int tap_tile_id(const TPlan& tp) {
 
 // loader mode + walk constants of the tap-major kernel for one pixel range length (shared by the single-layer entry)
 static int tap_mode(WgradTapArgs& g, int N, int H, int W, int Hi, int Wi, int kh, int kw, int pad, int ups, int clean, int ld_x,
-                    int ld_dy, long pix_per_split) {
+                    int ld_dy, long pix_per_split, int subpix = 0) {
+    if (subpix) {
+        g.sw = g.sh = g.sn = 0;
+        return 3;
+    }
     const long span_a = pix_per_split * (long)ld_dy * 4, span_b = (pix_per_split + 2L * W + 2 * BK) * ld_x * 4;
     bool walk = true;          // can a 16-pixel step be walked as columns / rows / frames with single wraps?
     g.sw = BK;
@@ -2158,7 +2210,7 @@ static int tap_mode(WgradTapArgs& g, int N, int H, int W, int Hi, int Wi, int kh
 
 struct GroupedHeader {
     int magic, n, nvariants, reserved;
-    int first[12], count[12], blocks[12];     // per variant: first record, records, blocks (records are sorted by variant)
+    int first[16], count[16], blocks[16];     // per variant: first record, records, blocks (records are sorted by variant)
 };
 
 }  // namespace
@@ -2413,6 +2465,14 @@ size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout,
     return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
 }
 
+size_t mnk_conv3x3_up_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout) {
+    if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || Cout <= 0) return 0;
+    TPlan up = make_up_tplan(N, Ho, Wo, Cout, C, 3, 3, 1, round_up(C, 4), MNK_CONV_UPSAMPLED | MNK_CONV_CLEAN_PADS);
+    const size_t a = up.use ? (size_t)(up.splits + up.groups) * 16 * Cout * C : 0;
+    const size_t b = mnk_conv2d_wgrad_workspace_floats(N, Ho, Wo, C, Cout, 3, 3, 1);
+    return a > b ? a : b;
+}
+
 int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi, int kh, int kw, int pad, const float* dy,
                      int ld_dy, int Cout, float* dw, int Cin_total, int c_start, int N, int Ho, int Wo, float* ws,
                      size_t ws_floats, void* stream) {
@@ -2428,6 +2488,59 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
     MNK_REQUIRE(c_start >= 0 && c_start + C <= Cin_total && (!ups || (Hi % 2 == 0 && Wi % 2 == 0)));
     const int ntaps = kh * kw;
     const int H = Ho, W = Wo;
+    {   // up-sampled 3x3 layer with clean sources: the sub-pixel form (16 pseudo taps over the LOW-resolution pixels)
+        TPlan up = make_up_tplan(N, Ho, Wo, Cout, C, kh, kw, pad, ld_x, flags);
+        if (up.use && (size_t)x % 16 == 0 && (size_t)dy % 16 == 0) {
+            const int Hl = Ho / 2, Wl = Wo / 2;
+            const size_t need = (size_t)(up.splits + (defer ? 0 : up.groups)) * 16 * Cout * C;
+            if (!ws || ws_floats < need) {
+                set_error("mnk_conv2d_wgrad: workspace too small (%zu < %zu floats)", ws_floats, need);
+                return MNK_EWORKSPACE;
+            }
+            WgradTapArgs g;
+            g.x = x, g.ld_x = ld_x, g.C = C, g.ups = 0, g.dy = dy, g.ld_dy = ld_dy, g.Cout = Cout;
+            g.H = Hl, g.W = Wl, g.Hi = Hl, g.Wi = Wl, g.ntaps = 16, g.kw = 4, g.pad = 0;
+            g.M = (long)N * Hl * Wl;
+            g.pix_per_split = up.pix_per_split;
+            g.gn = up.gn;
+            g.part = ws;
+            g.xcd = g_xcd_remap;
+            g.clean = 1;
+            g.sw = g.sh = g.sn = 0;
+            fast_div_consts((unsigned)Wl, &g.mulW, &g.shW);
+            fast_div_consts((unsigned)Hl, &g.mulH, &g.shH);
+            hipStream_t st = (hipStream_t)stream;
+            dim3 grid(up.gm, up.gn * 16, up.splits);
+            {
+                ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)N * Ho * Wo * Cout * 9.0 * C);
+                if (up.bm == 128 && up.bn == 128)
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
+                else if (up.bm == 128)
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, st, g);
+                else if (up.bm == 64)
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<64, 128, 1, 4, 3>), grid, dim3(256), 0, st, g);
+                else
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<32, 128, 1, 4, 3>), grid, dim3(256), 0, st, g);
+            }
+            if (!defer) {
+                ProfScope prof(K_CONV_REDUCE, st, (double)(up.splits + 1) * 16 * Cout * C * 4);
+                const long n = (long)16 * Cout * C;
+                const float* src = ws;
+                int nsum = up.splits;
+                if (up.groups) {
+                    float* part2 = ws + (size_t)up.splits * n;
+                    hipLaunchKernelGGL(conv3x3_wgrad_group_sum_kernel, dim3(grid_for(n, 1024), up.groups), dim3(256), 0, st, ws, n,
+                                       up.splits, up.per_group, part2);
+                    src = part2;
+                    nsum = up.groups;
+                }
+                hipLaunchKernelGGL(conv3x3_wgrad_tap_reduce_kernel, dim3(ceil_div(C, 64), Cout), dim3(256), 0, st, src, nsum, 16,
+                                   Cout, C, dw + (long)c_start * 9, (long)Cin_total * 9, 1);
+            }
+            MNK_LAUNCH_CHECK();
+            return MNK_OK;
+        }
+    }
     TPlan tp = make_tplan((long)N * H * W, Cout, C, ntaps, ld_x);
     if (tp.use && ((size_t)x % 16 != 0 || (size_t)dy % 16 != 0)) tp.use = false;
     if (tp.use) {
@@ -2494,7 +2607,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
                 nsum = tp.groups;
             }
             hipLaunchKernelGGL(conv3x3_wgrad_tap_reduce_kernel, dim3(ceil_div(C, 64), Cout), dim3(256), 0, st, src, nsum,
-                               ntaps, Cout, C, dw + (long)c_start * ntaps, (long)Cin_total * ntaps);
+                               ntaps, Cout, C, dw + (long)c_start * ntaps, (long)Cin_total * ntaps, 0);
         }
         MNK_LAUNCH_CHECK();
         return MNK_OK;
@@ -2559,7 +2672,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
                     nsum = groups;
                 }
                 hipLaunchKernelGGL(conv3x3_wgrad_tap_reduce_kernel, dim3(ceil_div(C, 64), Cout), dim3(256), 0, sn, src, nsum, 9,
-                                   Cout, C, dstn, ldn);
+                                   Cout, C, dstn, ldn, 0);
             }
             MNK_LAUNCH_CHECK();
             return MNK_OK;
@@ -2676,11 +2789,25 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
 // under MNK_WGRAD_DEFER: layout 0 = tap-major partials [split][tap][Cout][C], 1 = parameter-major [split][Cout][C*ntaps];
 // splits == 0: the GEMM writes dw itself (nothing to reduce)
 int mnk_conv2d_wgrad_plan(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad, int ld_x, MnkWgradPlan* plan) {
+    return mnk_conv2d_wgrad_plan2(N, Ho, Wo, C, Cout, kh, kw, pad, ld_x, 0, plan);
+}
+
+int mnk_conv2d_wgrad_plan2(int N, int Ho, int Wo, int C, int Cout, int kh, int kw, int pad, int ld_x, int flags,
+                           MnkWgradPlan* plan) {
     MNK_REQUIRE(plan && N > 0 && Ho > 0 && Wo > 0 && C > 0 && Cout > 0 && kh > 0 && kw > 0 && pad >= 0 && ld_x >= C);
     const int ntaps = kh * kw;
     plan->layout = 0;
     plan->splits = 0;
     plan->part_floats = 0;
+    {
+        TPlan up = make_up_tplan(N, Ho, Wo, Cout, C, kh, kw, pad, ld_x, flags);
+        if (up.use) {                       // sub-pixel form: 16 pseudo taps, folded by the reduction (layout 2)
+            plan->layout = 2;
+            plan->splits = up.splits;
+            plan->part_floats = (size_t)up.splits * 16 * Cout * C;
+            return MNK_OK;
+        }
+    }
     TPlan tp = make_tplan((long)N * Ho * Wo, Cout, C, ntaps, ld_x);
     if (tp.use) {
         plan->splits = tp.splits;
@@ -2715,14 +2842,27 @@ int mnk_conv2d_wgrad_plan(int N, int Ho, int Wo, int C, int Cout, int kh, int kw
     return MNK_OK;
 }
 
+// the tap-major plan of a job: the sub-pixel form for up-sampled layers with clean sources, else the plain one
+static TPlan job_plan(const MnkWgradJob& j, int* subpix, long* M, int* ntaps, int* H, int* W) {
+    TPlan up = make_up_tplan(j.N, j.Ho, j.Wo, j.Cout, j.C, j.kh, j.kw, j.pad, j.ld_x, j.flags);
+    if (up.use) {
+        *subpix = 1, *ntaps = 16, *H = j.Ho / 2, *W = j.Wo / 2;
+        *M = (long)j.N * *H * *W;
+        return up;
+    }
+    *subpix = 0, *ntaps = j.kh * j.kw, *H = j.Ho, *W = j.Wo;
+    *M = (long)j.N * j.Ho * j.Wo;
+    return make_tplan(*M, j.Cout, j.C, *ntaps, j.ld_x);
+}
+
 int mnk_wgrad_grouped_plan(MnkWgradJob* jobs, int n) {
     MNK_REQUIRE(jobs && n > 0);
     for (int i = 0; i < n; ++i) {
         MnkWgradJob& j = jobs[i];
         MNK_REQUIRE(j.N > 0 && j.Ho > 0 && j.Wo > 0 && j.C > 0 && j.Cout > 0 && j.kh > 0 && j.kw > 0 && j.pad >= 0);
-        const int ntaps = j.kh * j.kw;
-        const long M = (long)j.N * j.Ho * j.Wo;
-        TPlan tp = make_tplan(M, j.Cout, j.C, ntaps, j.ld_x);
+        int subpix, ntaps, H, W;
+        long M;
+        TPlan tp = job_plan(j, &subpix, &M, &ntaps, &H, &W);
         j.variant = -1;
         j.splits = 0;
         j.part_floats = 0;
@@ -2731,8 +2871,8 @@ int mnk_wgrad_grouped_plan(MnkWgradJob* jobs, int n) {
         grouped_split(M, &j.splits, &pps);
         WgradTapArgs g;
         const int mode = tap_mode(g, j.N, j.Ho, j.Wo, j.Hi, j.Wi, j.kh, j.kw, j.pad, j.flags & MNK_CONV_UPSAMPLED,
-                                  (j.flags & MNK_CONV_CLEAN_PADS) ? 1 : 0, j.ld_x, j.ld_dy, pps);
-        j.variant = 3 * tap_tile_id(tp) + mode;
+                                  (j.flags & MNK_CONV_CLEAN_PADS) ? 1 : 0, j.ld_x, j.ld_dy, pps, subpix);
+        j.variant = 4 * tap_tile_id(tp) + mode;
         j.part_floats = (size_t)j.splits * ntaps * j.Cout * j.C;
     }
     return MNK_OK;
@@ -2746,21 +2886,22 @@ int mnk_wgrad_grouped_build(const MnkWgradJob* jobs, int n, void* host_table, si
     TapJobRec* recs = (TapJobRec*)((char*)host_table + sizeof(GroupedHeader));
     hd->magic = 0x4d4e4b47;
     hd->n = n;
-    hd->nvariants = 12;
+    hd->nvariants = 16;
     hd->reserved = 0;
     int k = 0;
-    for (int v = 0; v < 12; ++v) {
+    for (int v = 0; v < 16; ++v) {
         hd->first[v] = k;
         int blocks = 0;
         for (int i = 0; i < n; ++i) {
             const MnkWgradJob& j = jobs[i];
-            MNK_REQUIRE(j.variant >= 0 && j.variant < 12);
+            MNK_REQUIRE(j.variant >= 0 && j.variant < 16);
             if (j.variant != v) continue;
             MNK_REQUIRE(j.x && j.dy && j.part && ((size_t)j.x % 16) == 0 && ((size_t)j.dy % 16) == 0);
-            const int ntaps = j.kh * j.kw, ups = j.flags & MNK_CONV_UPSAMPLED, clean = (j.flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
-            const long M = (long)j.N * j.Ho * j.Wo;
-            TPlan tp = make_tplan(M, j.Cout, j.C, ntaps, j.ld_x);
-            MNK_REQUIRE(tp.use && 3 * tap_tile_id(tp) == v - v % 3);
+            const int ups = j.flags & MNK_CONV_UPSAMPLED, clean = (j.flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
+            int subpix, ntaps, H, W;
+            long M;
+            TPlan tp = job_plan(j, &subpix, &M, &ntaps, &H, &W);
+            MNK_REQUIRE(tp.use && tap_tile_id(tp) == v / 4);
             TapJobRec& r = recs[k];
             WgradTapArgs& g = r.a;
             int splits;
@@ -2770,27 +2911,27 @@ int mnk_wgrad_grouped_build(const MnkWgradJob* jobs, int n, void* host_table, si
             g.x = j.x;
             g.ld_x = j.ld_x;
             g.C = j.C;
-            g.ups = ups;
+            g.ups = subpix ? 0 : ups;
             g.dy = j.dy;
             g.ld_dy = j.ld_dy;
             g.Cout = j.Cout;
-            g.H = j.Ho;
-            g.W = j.Wo;
-            g.Hi = j.Hi;
-            g.Wi = j.Wi;
+            g.H = H;
+            g.W = W;
+            g.Hi = subpix ? H : j.Hi;
+            g.Wi = subpix ? W : j.Wi;
             g.ntaps = ntaps;
-            g.kw = j.kw;
-            g.pad = j.pad;
+            g.kw = subpix ? 4 : j.kw;
+            g.pad = subpix ? 0 : j.pad;
             g.M = M;
             g.pix_per_split = pps;
             g.gn = tp.gn;
             g.part = j.part;
             g.xcd = 0;
             g.clean = clean;
-            fast_div_consts((unsigned)j.Wo, &g.mulW, &g.shW);
-            fast_div_consts((unsigned)j.Ho, &g.mulH, &g.shH);
-            const int mode = tap_mode(g, j.N, j.Ho, j.Wo, j.Hi, j.Wi, j.kh, j.kw, j.pad, ups, clean, j.ld_x, j.ld_dy, pps);
-            MNK_REQUIRE(mode == v % 3);
+            fast_div_consts((unsigned)W, &g.mulW, &g.shW);
+            fast_div_consts((unsigned)H, &g.mulH, &g.shH);
+            const int mode = tap_mode(g, j.N, j.Ho, j.Wo, j.Hi, j.Wi, j.kh, j.kw, j.pad, ups, clean, j.ld_x, j.ld_dy, pps, subpix);
+            MNK_REQUIRE(mode == v % 4);
             r.gm = tp.gm;
             r.gnt = tp.gn * ntaps;
             r.splits = splits;
@@ -2812,24 +2953,25 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
     const TapJobRec* hrecs = (const TapJobRec*)((const char*)host_table + sizeof(GroupedHeader));
     const TapJobRec* drecs = (const TapJobRec*)((const char*)device_table + sizeof(GroupedHeader));
     hipStream_t st = (hipStream_t)stream;
-    for (int v = 0; v < 12; ++v) {
+    for (int v = 0; v < 16; ++v) {
         const int cnt = hd->count[v], blocks = hd->blocks[v];
         if (!cnt) continue;
         double flop = 0.0;
         for (int i = 0; i < cnt; ++i) {
-            const WgradTapArgs& g = hrecs[hd->first[v] + i].a;
-            flop += 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
+            const WgradTapArgs& g = hrecs[hd->first[v] + i].a;      // algorithmic: the sub-pixel form stands for 9 taps at 4 M pixels
+            flop += v % 4 == 3 ? 2.0 * 4.0 * (double)g.M * g.Cout * 9.0 * g.C : 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
         }
         ProfScope prof(K_CONV_WGRAD, st, flop);
         const TapJobRec* rv = drecs + hd->first[v];
-        const int mode = v % 3;
+        const int mode = v % 4;
 #define MNK_WGROUP(...)                                                                                                        \
     do {                                                                                                                       \
         if (mode == 1) hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 1>), dim3(blocks), dim3(256), 0, st, rv, cnt);      \
         else if (mode == 2) hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 2>), dim3(blocks), dim3(256), 0, st, rv, cnt); \
+        else if (mode == 3) hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 3>), dim3(blocks), dim3(256), 0, st, rv, cnt); \
         else hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 0>), dim3(blocks), dim3(256), 0, st, rv, cnt);                \
     } while (0)
-        switch (v / 3) {
+        switch (v / 4) {
             case 0: MNK_WGROUP(128, 128, 2, 2); break;
             case 1: MNK_WGROUP(128, 64, 2, 2); break;
             case 2: MNK_WGROUP(64, 128, 1, 4); break;

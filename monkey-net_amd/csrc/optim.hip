@@ -116,7 +116,10 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const MnkAdamDesc* __re
         T[r * g.cos + ci * g.ntp + tap] = p;
     }
     __syncthreads();
-    pack_tile_emit<9>(T, g, d.wp_fwd, d.wp_d0, d.wp_d1, d.Cout, cc, cot);
+    if (d.flags & 1)       // an up-sampled convolution (UpBlock3D): the packs of its sub-pixel forms
+        pack_tile_emit_up(T, g, d.wp_fwd, d.wp_d0, d.wp_d1, d.Cout, cc, cot);
+    else
+        pack_tile_emit<9>(T, g, d.wp_fwd, d.wp_d0, d.wp_d1, d.Cout, cc, cot);
 }
 
 }  // namespace

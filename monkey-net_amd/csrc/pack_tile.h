@@ -61,10 +61,56 @@ __device__ __forceinline__ void pack_tile_emit(const float* T, const PackTileGeo
         }
 }
 
+// ---- the same tile as the packs of the sub-pixel forms of an up-sampled 3x3 convolution (conv3x3.hip: ConvArgs::phases) ----
+// forward  wf[phase = 2a + b][co][chunk][tap4 = 2u + v][16 ci] = sum_{ky in S(a,u)} sum_{kx in S(b,v)} w[co][ci][ky][kx]
+// dgrad    wd[ci][chunk over co][tap16 = 4 ty + tx][16 co]      = sum_{ky in D(ty)} sum_{kx in D(tx)} w[co][ci][ky][kx]
+//   S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2};  D(0) = {2}, D(1) = {1,2}, D(2) = {0,1}, D(3) = {0}
+__device__ __forceinline__ void up_phase_set(int a, int u, int& lo, int& hi) {
+    lo = a == 0 ? (u == 0 ? 0 : 1) : (u == 0 ? 0 : 2);
+    hi = a == 0 ? (u == 0 ? 0 : 2) : (u == 0 ? 1 : 2);
+}
+__device__ __forceinline__ void up_dgrad_set(int t, int& lo, int& hi) {
+    lo = t == 0 ? 2 : (t == 1 ? 1 : 0);
+    hi = t == 0 ? 2 : (t == 1 ? 2 : (t == 2 ? 1 : 0));
+}
+
+__device__ __forceinline__ void pack_tile_emit_up(const float* T, const PackTileGeom& g, float* __restrict__ wf,
+                                                  float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int cc, int cot) {
+    const int t = threadIdx.x;
+    for (int i = t; i < 4096; i += 256) {           // forward: 16 co x 4 phases x 4 taps x 16 ci
+        const int k16 = i & 15, tap4 = (i >> 4) & 3, phase = (i >> 6) & 3, r = i >> 8;
+        const int co = g.co0 + r;
+        if (co >= Cout) continue;
+        int y0, y1, x0, x1;
+        up_phase_set(phase >> 1, tap4 >> 1, y0, y1);
+        up_phase_set(phase & 1, tap4 & 1, x0, x1);
+        const float* tp = T + r * g.cos + k16 * g.ntp;
+        float v = 0.f;
+        for (int ky = y0; ky <= y1; ++ky)
+            for (int kx = x0; kx <= x1; ++kx) v += tp[ky * 3 + kx];
+        wf[((((size_t)phase * Cout + co) * g.chunks + cc) * 4 + tap4) * 16 + k16] = v;
+    }
+    float* wd = g.second ? wd1 : wd0;
+    if (wd)
+        for (int i = t; i < 4096; i += 256) {       // data gradient: 16 ci x 16 taps x 16 co
+            const int k16 = i & 15, tap16 = (i >> 4) & 15, r = i >> 8;
+            const int ci = g.ci0 + r;
+            if (ci >= g.Cs) continue;
+            int y0, y1, x0, x1;
+            up_dgrad_set(tap16 >> 2, y0, y1);
+            up_dgrad_set(tap16 & 3, x0, x1);
+            const float* tp = T + k16 * g.cos + r * g.ntp;
+            float v = 0.f;
+            for (int ky = y0; ky <= y1; ++ky)
+                for (int kx = x0; kx <= x1; ++kx) v += tp[ky * 3 + kx];
+            wd[(((size_t)ci * g.dchunks + cot) * 16 + tap16) * 16 + k16] = v;
+        }
+}
+
 template <int NT>
 __device__ __forceinline__ void pack_tile(float* T, const float* __restrict__ w, float* __restrict__ wf,
                                           float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int C0, int C1,
-                                          int C0p, int C1p, int ntaps_rt, int cc, int cot) {
+                                          int C0p, int C1p, int ntaps_rt, int cc, int cot, int up = 0) {
     const PackTileGeom g = pack_tile_geom<NT>(Cout, C0, C1, C0p, C1p, ntaps_rt, cc, cot);
     const int ntaps = NT ? NT : g.ntaps;
     const int run = 16 * ntaps;
@@ -78,7 +124,10 @@ __device__ __forceinline__ void pack_tile(float* T, const float* __restrict__ w,
         T[r * g.cos + ci * g.ntp + tap] = v;
     }
     __syncthreads();
-    pack_tile_emit<NT>(T, g, wf, wd0, wd1, Cout, cc, cot);
+    if (up)
+        pack_tile_emit_up(T, g, wf, wd0, wd1, Cout, cc, cot);
+    else
+        pack_tile_emit<NT>(T, g, wf, wd0, wd1, Cout, cc, cot);
 }
 
 }  // namespace mnk

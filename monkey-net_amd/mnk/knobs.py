@@ -19,6 +19,8 @@ KNOBS = {
                            "weight-gradient reductions); 0: torch.optim.Adam(fused=True) + per-layer reductions (round 1)"),
     "MNK_WGRAD_GROUPED": ("1", "MnkAdam pipeline: the tap-major weight-gradient GEMMs of all layers in one launch per tile "
                                "shape at the end of backward (0: one launch per layer during backward)"),
+    "MNK_UP_SUBPIXEL": ("1", "UpBlock3D convolutions in their sub-pixel forms (four 2x2 phase convolutions forward, one 4x4 "
+                             "stride-2 convolution for the data gradient; 0: 3x3 over the up-sampled view + sum-pool)"),
     "MNK_PACK_MULTI": ("1", "re-pack every conv weight of the model in one launch per iteration (0: one launch per layer)"),
     "MNK_DIST_GRAPH": ("1", "with a process group: capture the iteration incl. its RCCL collectives as a hipGraph"),
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),

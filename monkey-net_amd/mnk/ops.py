@@ -221,28 +221,35 @@ def pack_entry_of(p):
     return None
 
 
-def _packed_fwd_weight(weight, cout, c0, c1):
+def subpixel(ups):
+    """UpBlock3D convolutions run in their sub-pixel forms (mnk_conv3x3_up_*): MNK_UP_SUBPIXEL=0 restores the 3x3
+    convolution over the up-sampled view."""
+    return bool(ups) and knobs.on("MNK_UP_SUBPIXEL")
+
+
+def _packed_fwd_weight(weight, cout, c0, c1, up=False):
     """Packed [Cout][chunk][tap][16] copy of a conv weight for NO-GRAD forwards (inference loops), cached per parameter
     version, storage and optimiser epoch.  Training forwards never use this cache (they take the registry entry of
     _pack_entry: re-packed once per iteration by repack_registered(), or per call in a user-owned loop).
     Under hipGraph capture the cache is bypassed: the pack launch is recorded INTO the graph (its buffer lives in the
     graph's memory pool), so every replay re-packs from the live parameter -- a replay after load_state_dict / an
     in-place write can never combine old packed weights with new normalisation parameters."""
-    n = _query("mnk_conv3x3_packed_floats", cout, c0, c1)
+    n = _query("mnk_conv3x3_up_packed_floats" if up else "mnk_conv3x3_packed_floats", cout, c0, c1)
+    pack = "mnk_conv3x3_up_pack_fwd" if up else "mnk_conv3x3_pack_fwd"
     if weight.is_cuda and torch.cuda.is_current_stream_capturing():
         wp = torch.empty(n, dtype=torch.float32, device=weight.device)
-        _call("mnk_conv3x3_pack_fwd", weight, _p(weight), _p(wp), cout, c0, c1)
+        _call(pack, weight, _p(weight), _p(wp), cout, c0, c1)
         return wp
     key = (id(weight), weight.device)
     ver = (weight._version, _PACK_EPOCH[0], weight.data_ptr())
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[1] == (cout, c0, c1) and hit[3]() is weight:
+    if hit is not None and hit[0] == ver and hit[1] == (cout, c0, c1, up) and hit[3]() is weight:
         return hit[2]
     wp = torch.empty(n, dtype=torch.float32, device=weight.device)
-    _call("mnk_conv3x3_pack_fwd", weight, _p(weight), _p(wp), cout, c0, c1)
+    _call(pack, weight, _p(weight), _p(wp), cout, c0, c1)
     if hit is None:
         weakref.finalize(weight, _PACK_CACHE.pop, key, None)      # no entry (and no packed buffer) outlives its parameter
-    _PACK_CACHE[key] = (ver, (cout, c0, c1), wp, weakref.ref(weight))
+    _PACK_CACHE[key] = (ver, (cout, c0, c1, up), wp, weakref.ref(weight))
     return wp
 
 
@@ -257,17 +264,19 @@ class _PackEntry:
 
 
 
-def _pack_entry(weight, cout, c0, c1, need):
+def _pack_entry(weight, cout, c0, c1, need, up=False):
     """The (packed, up to date) registry entry of `weight`: packs with one per-layer launch unless the entry is fresh
-    (repack_registered() ran since the last optimiser step)."""
-    meta = (cout, c0, c1)
+    (repack_registered() ran since the last optimiser step).  up: the packs of the sub-pixel forms of an up-sampled
+    convolution (mnk_conv3x3_up_fwd / _up_dgrad) instead of the 3x3 layouts."""
+    meta = (cout, c0, c1, bool(up))
     e = _PACK_REG.get(id(weight))
     if e is not None and e.fresh(weight, meta, need):
         return e
     if e is None or e.wref() is not weight or e.wptr != weight.data_ptr() or e.meta != meta:
         e = _PackEntry()
         e.wref, e.wptr, e.meta, e.wd, e.stamp = weakref.ref(weight), weight.data_ptr(), meta, [None, None], None
-        e.wp = torch.empty(_query("mnk_conv3x3_packed_floats", cout, c0, c1), dtype=torch.float32, device=weight.device)
+        e.wp = torch.empty(_query("mnk_conv3x3_up_packed_floats" if up else "mnk_conv3x3_packed_floats", cout, c0, c1),
+                           dtype=torch.float32, device=weight.device)
         key = id(weight)
         _PACK_REG[key] = e
         weakref.finalize(weight, _drop_pack_entry, key, weakref.ref(e))
@@ -275,11 +284,17 @@ def _pack_entry(weight, cout, c0, c1, need):
         _PACK_REG_VERSION[0] += 1
     for i, cc in enumerate((c0, c1)):
         if need[i] and e.wd[i] is None:
-            e.wd[i] = torch.empty(_query("mnk_conv3x3_packed_floats", cc, cout, 0), dtype=torch.float32,
-                                  device=weight.device)
+            nd = _query("mnk_conv3x3_up_dgrad_packed_floats", cout, cc) if up else _query("mnk_conv3x3_packed_floats", cc, cout, 0)
+            e.wd[i] = torch.empty(nd, dtype=torch.float32, device=weight.device)
             _PACK_TABLE["dirty"] = True
             _PACK_REG_VERSION[0] += 1
-    _call("mnk_conv3x3_pack_all", weight, _p(weight), _p(e.wp), _p(e.wd[0]), _p(e.wd[1]), cout, c0, c1)
+    if up:
+        _call("mnk_conv3x3_up_pack_fwd", weight, _p(weight), _p(e.wp), cout, c0, c1)
+        for i, (cs, cc) in enumerate(((0, c0), (c0, c1))):
+            if e.wd[i] is not None:
+                _call("mnk_conv3x3_up_pack_dgrad", weight, _p(weight), _p(e.wd[i]), cout, c0 + c1, cs, cc)
+    else:
+        _call("mnk_conv3x3_pack_all", weight, _p(weight), _p(e.wp), _p(e.wd[0]), _p(e.wd[1]), cout, c0, c1)
     e.stamp = None            # only repack_registered() vouches for freshness: a user-owned loop packs on every call
     return e
 
@@ -316,13 +331,13 @@ def repack_registered(only_if_stale=False):
         if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
             return False                     # building the table needs a host-to-device copy
         entries = [e for e in entries if e.wp.device == dev]
-        rec = np.zeros(len(entries), dtype=np.dtype([("p", "<u8", 4), ("i", "<i4", 4)]))
+        rec = np.zeros(len(entries), dtype=np.dtype([("p", "<u8", 4), ("i", "<i4", 6)]))
         tiles = 0
         for k, e in enumerate(entries):
-            cout, c0, c1 = e.meta
+            cout, c0, c1, up = e.meta
             rec["p"][k] = (e.wptr, e.wp.data_ptr(), e.wd[0].data_ptr() if e.wd[0] is not None else 0,
                            e.wd[1].data_ptr() if e.wd[1] is not None else 0)
-            rec["i"][k] = (cout, c0, c1, tiles)
+            rec["i"][k] = (cout, c0, c1, tiles, int(up), 0)
             tiles += ((ceil16(c0) + (ceil16(c1) if c1 else 0)) // 16) * ((cout + 15) // 16)
         descs = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev)
         t["keep"].append(descs)              # captured graphs hold raw pointers to earlier tables: never free them
@@ -337,19 +352,30 @@ def repack_registered(only_if_stale=False):
     return True
 
 
-def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats=False):
+def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats=False, up=False):
     """One conv launch.  With want_stats the BatchNorm sums of the output come out of the conv epilogue (finished by a
-    tiny second-stage kernel) instead of a separate pass over y; returns (y, sums or None)."""
+    tiny second-stage kernel) instead of a separate pass over y; returns (y, sums or None).  up: `wp` holds the
+    sub-pixel packs of an up-sampled convolution and (h, w) is the up-sampled size."""
     y = torch.empty(n, h, w, ceil4(cout), dtype=torch.float32, device=x0.device)
-    nws = _query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
-    ws = SCRATCH.get("ws", nws, x0) if nws else None
-    nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats else 0
-    st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None   # lives until the norm layer reads it
-    # flags: bit 0 = nearest x2 up-sampled view, bit 1 = MNK_CONV_CLEAN_PADS -- every act this module produces has zero
-    # pad channels (tests/test_modules.py::test_pad_channels_are_written pins that), so the fast 3x3 loader applies
-    _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
-          int(ups) | 2, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
-          y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
+    if up:
+        assert ups and residual is None
+        hl, wl = h // 2, w // 2
+        nws = _query("mnk_conv3x3_up_workspace_floats", n, hl, wl, c0, c1, cout)
+        ws = SCRATCH.get("ws", nws, x0) if nws else None
+        nst = _query("mnk_conv3x3_up_stats_floats", n, hl, wl, c0, c1, cout) if want_stats else 0
+        st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None
+        _call("mnk_conv3x3_up_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1, _p(wp),
+              _p(bias), _p(y), y.shape[-1], n, hl, wl, cout, _p(ws), nws, _p(st))
+    else:
+        nws = _query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
+        ws = SCRATCH.get("ws", nws, x0) if nws else None
+        nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats else 0
+        st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None   # lives until the norm layer reads it
+        # flags: bit 0 = nearest x2 up-sampled view, bit 1 = MNK_CONV_CLEAN_PADS -- every act this module produces has zero
+        # pad channels (tests/test_modules.py::test_pad_channels_are_written pins that), so the fast 3x3 loader applies
+        _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
+              int(ups) | 2, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
+              y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
     sums = None
     if want_stats:
         if nst and not mdist.active():
@@ -390,15 +416,17 @@ class Conv3x3Fn(torch.autograd.Function):
         assert weight.shape[1] == c0 + c1 and weight.is_contiguous()
         n, hs, ws_, _ = x0.shape
         h, w = (hs * 2, ws_ * 2) if ups else (hs, ws_)
+        up = subpixel(ups) and residual is None
         if track:
             # a backward will follow: the parameter changes every step -> packed per iteration (forward + the
             # data-gradient layouts the backward will need), by repack_registered() or one launch here
             need = [bool(cc and ctx.needs_input_grad[i]) for i, cc in enumerate((c0, c1))]
-            e = _pack_entry(weight, cout, c0, c1, need)
+            e = _pack_entry(weight, cout, c0, c1, need, up)
             wp, ctx.wd = e.wp, list(e.wd)
         else:
-            wp = _packed_fwd_weight(weight, cout, c0, c1)
-        y, sums = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats)
+            wp = _packed_fwd_weight(weight, cout, c0, c1, up)
+        y, sums = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats, up)
+        ctx.up = up
         ctx.save_for_backward(x0, x1, weight)
         ctx.meta = (c0, c1, ups, cout, n, h, w, bias is not None, residual is not None)
         if sums is None:
@@ -422,6 +450,16 @@ class Conv3x3Fn(torch.autograd.Function):
             if src is None or not ctx.needs_input_grad[i]:
                 continue
             wp = ctx.wd[i]                       # packed in the forward (mnk_conv3x3_pack_all)
+            if ctx.up:
+                # data gradient w.r.t. the low-resolution source: one 4x4 / stride 2 convolution over dy (no gradient of
+                # the up-sampled view, no 2x2 sum-pool pass)
+                dx = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
+                nws = _query("mnk_conv3x3_up_dgrad_workspace_floats", n, h // 2, w // 2, cout, cc)
+                ws = SCRATCH.get("ws", nws, dy) if nws else None
+                _call("mnk_conv3x3_up_dgrad", dy, _p(dy), ld_dy, cout, _p(wp), _p(dx), dx.shape[-1], n, h // 2, w // 2, cc,
+                      _p(ws), nws)
+                grads[i] = dx
+                continue
             dx, _ = _conv_launch(dy, cout, None, 0, 0, wp, None, None, n, h, w, cc)
             if ups:
                 dxs = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
@@ -444,7 +482,8 @@ class Conv3x3Fn(torch.autograd.Function):
             if rest:
                 dw = torch.zeros_like(weight) if len(rest) < (1 + (x1 is not None)) else torch.empty_like(weight)
             for src, cs, cc in rest:
-                nws = _query("mnk_conv3x3_wgrad_workspace_floats", n, h, w, cc, cout)
+                nws = _query("mnk_conv3x3_up_wgrad_workspace_floats" if ups else "mnk_conv3x3_wgrad_workspace_floats", n, h, w,
+                             cc, cout)
                 ws = SCRATCH.get("ws", nws, dy) if nws else None
                 _call("mnk_conv3x3_wgrad", dy, _p(src), src.shape[-1], cc, int(ups) | 2, _p(dy), ld_dy, cout, _p(dw), cin,
                       cs, n, h, w, _p(ws), nws)      # | 2: MNK_CONV_CLEAN_PADS (x and dy are acts of this module)

@@ -26,7 +26,7 @@ from . import ops as mops
 
 ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("wp_fwd", "<u8"),
                       ("wp_d0", "<u8"), ("wp_d1", "<u8"), ("Cout", "<i4"), ("C0", "<i4"), ("C1", "<i4"),
-                      ("block_begin", "<i4")])
+                      ("block_begin", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
 REDUCE_DESC = np.dtype([("part", "<u8"), ("dw", "<u8"), ("layout", "<i4"), ("splits", "<i4"), ("ntaps", "<i4"),
                         ("Cout", "<i4"), ("C", "<i4"), ("Cin_total", "<i4"), ("c_start", "<i4"), ("accumulate", "<i4"),
                         ("block_begin", "<i4"), ("reserved", "<i4")])
@@ -81,12 +81,13 @@ class DeferredReducer:
             if lib.query("mnk_wgrad_grouped_plan", job.ctypes.data, 1) != 0:
                 raise _lib.MnkError("mnk_wgrad_grouped_plan failed: %s" % lib.cdll.mnk_last_error().decode())
             grouped = int(job["variant"][0]) >= 0
-        if grouped:
-            layout, splits, nfloats = 0, int(job["splits"][0]), int(job["part_floats"][0])
+        if grouped:       # variant % 4 == 3: the sub-pixel form of an up-sampled layer (16 pseudo taps, layout 2)
+            layout = 2 if int(job["variant"][0]) % 4 == 3 else 0
+            splits, nfloats = int(job["splits"][0]), int(job["part_floats"][0])
         else:
             plan = _Plan()
-            if lib.query("mnk_conv2d_wgrad_plan", n, ho, wo, c, cout, kh, kw, pad, ld_x, ctypes.byref(plan)) != 0:
-                raise _lib.MnkError("mnk_conv2d_wgrad_plan failed: %s" % lib.cdll.mnk_last_error().decode())
+            if lib.query("mnk_conv2d_wgrad_plan2", n, ho, wo, c, cout, kh, kw, pad, ld_x, flags, ctypes.byref(plan)) != 0:
+                raise _lib.MnkError("mnk_conv2d_wgrad_plan2 failed: %s" % lib.cdll.mnk_last_error().decode())
             layout, splits, nfloats = int(plan.layout), int(plan.splits), int(plan.part_floats)
         part = torch.empty(max(nfloats, 1), dtype=torch.float32, device=weight.device)
         rec = {"shape": shape, "part": part, "splits": splits, "nfloats": nfloats, "grouped": grouped, "job": job,
@@ -275,15 +276,15 @@ class MnkAdam(torch.optim.Optimizer):
             g, m, v = self.flat_grad[o:], self.flat_m[o:], self.flat_v[o:]
             e = mops.pack_entry_of(p)
             if e is not None:
-                cout, c0, c1 = e.meta
+                cout, c0, c1, up = e.meta
                 nb = _lib.lib().query("mnk_adam_blocks", 0, cout, c0, c1, 1)
                 rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), e.wp.data_ptr(),
                              e.wd[0].data_ptr() if e.wd[0] is not None else 0,
-                             e.wd[1].data_ptr() if e.wd[1] is not None else 0, cout, c0, c1, blocks))
+                             e.wd[1].data_ptr() if e.wd[1] is not None else 0, cout, c0, c1, blocks, int(up), 0))
                 entries.append(e)
             else:
                 nb = _lib.lib().query("mnk_adam_blocks", p.numel(), 0, 0, 0, 0)
-                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks))
+                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks, 0, 0))
             blocks += nb
         rec = np.array(rows, dtype=ADAM_DESC)
         return _device_table(rec, self.device, self._keep), len(rows), blocks, tuple(entries)

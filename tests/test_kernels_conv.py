@@ -225,36 +225,51 @@ def test_pack_all_equals_separate_packs(be):
 
 def test_pack_multi_equals_pack_all_per_layer(be):
     """mnk_conv3x3_pack_multi (every layer of a model in one launch, descriptor table in device memory) == one
-    mnk_conv3x3_pack_all per layer, including layers without data-gradient layouts and two-source layers."""
+    mnk_conv3x3_pack_all per layer, including layers without data-gradient layouts and two-source layers; layers flagged
+    as up-sampled convolutions get the packs of their sub-pixel forms (== mnk_conv3x3_up_pack_fwd / _up_pack_dgrad)."""
     import numpy as np
-    layers = [(21, 18, 7, True, True), (3, 35, 0, True, False), (40, 5, 0, False, False), (16, 16, 16, False, True),
-              (70, 33, 0, True, False)]
+    layers = [(21, 18, 7, True, True, 0), (3, 35, 0, True, False, 0), (40, 5, 0, False, False, 0), (16, 16, 16, False, True, 0),
+              (70, 33, 0, True, False, 0), (21, 18, 7, True, True, 1), (40, 5, 0, False, False, 1), (33, 70, 20, True, True, 1)]
     g = torch.Generator().manual_seed(12)
-    rec = np.zeros(len(layers), dtype=np.dtype([("p", "<u8", 4), ("i", "<i4", 4)]))
+    rec = np.zeros(len(layers), dtype=np.dtype([("p", "<u8", 4), ("i", "<i4", 6)]))
     keep, tiles = [], 0
-    for k, (cout, c0, c1, d0, d1) in enumerate(layers):
+    for k, (cout, c0, c1, d0, d1, up) in enumerate(layers):
         wt = be.t(torch.randn(cout, c0 + c1, 1, 3, 3, generator=g))
         bufs = []
         for _ in range(2):                    # [0]: pack_multi's outputs, [1]: the per-layer reference
-            f = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1)).fill_(float("nan"))
-            a0 = be.empty(be.query("mnk_conv3x3_packed_floats", c0, cout, 0)).fill_(float("nan")) if d0 else None
-            a1 = be.empty(be.query("mnk_conv3x3_packed_floats", c1, cout, 0)).fill_(float("nan")) if d1 and c1 else None
+            nf = be.query("mnk_conv3x3_up_packed_floats" if up else "mnk_conv3x3_packed_floats", cout, c0, c1)
+            n0 = be.query("mnk_conv3x3_up_dgrad_packed_floats", cout, c0) if up else be.query("mnk_conv3x3_packed_floats", c0, cout, 0)
+            n1 = (be.query("mnk_conv3x3_up_dgrad_packed_floats", cout, c1) if up else
+                  be.query("mnk_conv3x3_packed_floats", c1, cout, 0)) if c1 else 0
+            f = be.empty(nf).fill_(float("nan"))
+            a0 = be.empty(n0).fill_(float("nan")) if d0 else None
+            a1 = be.empty(n1).fill_(float("nan")) if d1 and c1 else None
             bufs.append((f, a0, a1))
-        be.call("mnk_conv3x3_pack_all", wt, *bufs[1], cout, c0, c1)
+        if up:
+            be.call("mnk_conv3x3_up_pack_fwd", wt, bufs[1][0], cout, c0, c1)
+            if bufs[1][1] is not None:
+                be.call("mnk_conv3x3_up_pack_dgrad", wt, bufs[1][1], cout, c0 + c1, 0, c0)
+            if bufs[1][2] is not None:
+                be.call("mnk_conv3x3_up_pack_dgrad", wt, bufs[1][2], cout, c0 + c1, c0, c1)
+        else:
+            be.call("mnk_conv3x3_pack_all", wt, *bufs[1], cout, c0, c1)
         f, a0, a1 = bufs[0]
         rec["p"][k] = (wt.data_ptr(), f.data_ptr(), a0.data_ptr() if a0 is not None else 0,
                        a1.data_ptr() if a1 is not None else 0)
-        rec["i"][k] = (cout, c0, c1, tiles)
+        rec["i"][k] = (cout, c0, c1, tiles, up, 0)
         tiles += ((c0 + 15) // 16 + (c1 + 15) // 16) * ((cout + 15) // 16)
-        keep.append((wt, bufs))
+        keep.append((wt, bufs, up))
     descs = be.t(torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()))
     be.call("mnk_conv3x3_pack_multi", descs, len(layers), tiles)
     be.sync()
-    for wt, (got, ref) in keep:
+    for wt, (got, ref), up in keep:
         for a, b in zip(got, ref):
             assert (a is None) == (b is None)
             if a is not None:
-                assert torch.equal(a.cpu().nan_to_num(nan=7.0), b.cpu().nan_to_num(nan=7.0))
+                if up:      # sums of up to four taps: the tile kernel and the element kernel add in the same order
+                    assert float((a.cpu() - b.cpu()).abs().max()) <= 1e-6 * float(b.cpu().abs().max())
+                else:
+                    assert torch.equal(a.cpu().nan_to_num(nan=7.0), b.cpu().nan_to_num(nan=7.0))
 
 
 def test_sumpool2x2(be):

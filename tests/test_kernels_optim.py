@@ -21,11 +21,11 @@ REDUCE_DESC = np.dtype([("part", "<u8"), ("dw", "<u8"), ("layout", "<i4"), ("spl
                         ("block_begin", "<i4"), ("reserved", "<i4")])
 ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("wp_fwd", "<u8"),
                       ("wp_d0", "<u8"), ("wp_d1", "<u8"), ("Cout", "<i4"), ("C0", "<i4"), ("C1", "<i4"),
-                      ("block_begin", "<i4")])
+                      ("block_begin", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
 
 
 def test_descriptor_sizes_match_the_header():
-    assert REDUCE_DESC.itemsize == 56 and ADAM_DESC.itemsize == 80
+    assert REDUCE_DESC.itemsize == 56 and ADAM_DESC.itemsize == 88
 
 
 def _table(be, rec):
@@ -107,7 +107,9 @@ def test_adam_multi_matches_torch_adam_and_emits_the_packs(be, lr_drop):
     and without data-gradient layouts) == torch.optim.Adam(betas=(0.5, 0.999)); the packed layouts written in the same
     launch == mnk_conv3x3_pack_all of the updated weights; a learning-rate change through the device scalars is seen."""
     g = torch.Generator().manual_seed(21)
-    convs = [(21, 18, 7, True, True), (3, 35, 0, True, False), (40, 5, 0, False, False), (70, 33, 0, True, False)]
+    convs = [(21, 18, 7, True, True), (3, 35, 0, True, False), (40, 5, 0, False, False), (70, 33, 0, True, False),
+             (21, 18, 7, True, True), (33, 20, 0, True, False)]
+    ups = [0, 0, 0, 0, 1, 1]          # the last two are up-sampled convolutions: the packs of their sub-pixel forms
     plains = [1, 5, 1000, 4096, 4097, 12345]
     flat = torch.zeros(sum(plains) + 16)
     params, off = [], 3                                   # offset 3: views that are not 16-byte aligned
@@ -129,16 +131,23 @@ def test_adam_multi_matches_torch_adam_and_emits_the_packs(be, lr_drop):
     for k, p in enumerate(params):
         if k < len(plains):
             nb = be.query("mnk_adam_blocks", p.numel(), 0, 0, 0, 0)
-            rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks))
+            rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks, 0, 0))
             packs.append(None)
         else:
             cout, c0, c1, d0, d1 = convs[k - len(plains)]
-            wf = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
-            w0 = be.empty(be.query("mnk_conv3x3_packed_floats", c0, cout, 0)) if d0 else None
-            w1 = be.empty(be.query("mnk_conv3x3_packed_floats", c1, cout, 0)) if d1 and c1 else None
+            up = ups[k - len(plains)]
+            if up:
+                wf = be.empty(be.query("mnk_conv3x3_up_packed_floats", cout, c0, c1))
+                w0 = be.empty(be.query("mnk_conv3x3_up_dgrad_packed_floats", cout, c0)) if d0 else None
+                w1 = be.empty(be.query("mnk_conv3x3_up_dgrad_packed_floats", cout, c1)) if d1 and c1 else None
+            else:
+                wf = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
+                w0 = be.empty(be.query("mnk_conv3x3_packed_floats", c0, cout, 0)) if d0 else None
+                w1 = be.empty(be.query("mnk_conv3x3_packed_floats", c1, cout, 0)) if d1 and c1 else None
             nb = be.query("mnk_adam_blocks", 0, cout, c0, c1, 1)
             rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), wf.data_ptr(),
-                         w0.data_ptr() if w0 is not None else 0, w1.data_ptr() if w1 is not None else 0, cout, c0, c1, blocks))
+                         w0.data_ptr() if w0 is not None else 0, w1.data_ptr() if w1 is not None else 0, cout, c0, c1, blocks,
+                         up, 0))
             packs.append((wf, w0, w1))
         assert nb > 0
         blocks += nb
@@ -172,11 +181,19 @@ def test_adam_multi_matches_torch_adam_and_emits_the_packs(be, lr_drop):
         rf = be.empty(wf.numel())
         r0 = be.empty(w0.numel()) if w0 is not None else None
         r1 = be.empty(w1.numel()) if w1 is not None else None
-        be.call("mnk_conv3x3_pack_all", P[k], rf, r0, r1, cout, c0, c1)
+        if ups[k - len(plains)]:
+            be.call("mnk_conv3x3_up_pack_fwd", P[k], rf, cout, c0, c1)
+            if r0 is not None:
+                be.call("mnk_conv3x3_up_pack_dgrad", P[k], r0, cout, c0 + c1, 0, c0)
+            if r1 is not None:
+                be.call("mnk_conv3x3_up_pack_dgrad", P[k], r1, cout, c0 + c1, c0, c1)
+        else:
+            be.call("mnk_conv3x3_pack_all", P[k], rf, r0, r1, cout, c0, c1)
         be.sync()
         for a, b in ((wf, rf), (w0, r0), (w1, r1)):
             if a is not None:
-                assert torch.equal(a.cpu().nan_to_num(nan=7.0), b.cpu().nan_to_num(nan=7.0))
+                assert float((a.cpu().nan_to_num(nan=7.0) - b.cpu().nan_to_num(nan=7.0)).abs().max()) <= \
+                    1e-6 * float(b.cpu().nan_to_num(nan=7.0).abs().max())
 
 
 JOB = np.dtype([("x", "<u8"), ("dy", "<u8"), ("part", "<u8"), ("part_floats", "<u8"), ("ld_x", "<i4"), ("C", "<i4"),

@@ -55,12 +55,22 @@ def main():
             bias = torch.randn(cout, device=dev)
             dy = torch.randn(frames, h, w, ops.ceil4(cout), device=dev)
             fl = 2.0 * 9 * cin * cout * h * w * frames
-            wp = ops._packed_fwd_weight(wt, cout, cin, 0)
-            t_f = timeit(lambda: ops._conv_launch(x, cin, None, 0, ups, wp, bias, None, frames, h, w, cout, STATS), args.iters)
-            npk = ops._query("mnk_conv3x3_packed_floats", cin, cout, 0)
-            wpd = torch.empty(npk, device=dev)
-            ops._call("mnk_conv3x3_pack_dgrad", dy, wt.data_ptr(), wpd.data_ptr(), cout, cin, 0, cin)
-            t_d = timeit(lambda: ops._conv_launch(dy, cout, None, 0, 0, wpd, None, None, frames, h, w, cin), args.iters)
+            up = ops.subpixel(ups)          # UpBlock3D layers: the sub-pixel forms (MNK_UP_SUBPIXEL=0: the up-sampled view)
+            wp = ops._packed_fwd_weight(wt, cout, cin, 0, up)
+            t_f = timeit(lambda: ops._conv_launch(x, cin, None, 0, ups, wp, bias, None, frames, h, w, cout, STATS, up), args.iters)
+            if up:
+                wpd = torch.empty(ops._query("mnk_conv3x3_up_dgrad_packed_floats", cout, cin), device=dev)
+                ops._call("mnk_conv3x3_up_pack_dgrad", dy, wt.data_ptr(), wpd.data_ptr(), cout, cin, 0, cin)
+                dxl = torch.empty(frames, hs, ws_, ops.ceil4(cin), device=dev)
+                nwd = ops._query("mnk_conv3x3_up_dgrad_workspace_floats", frames, hs, ws_, cout, cin)
+                wsd = torch.empty(max(nwd, 1), device=dev)
+                t_d = timeit(lambda: ops._call("mnk_conv3x3_up_dgrad", dy, dy.data_ptr(), dy.shape[-1], cout, wpd.data_ptr(),
+                                               dxl.data_ptr(), dxl.shape[-1], frames, hs, ws_, cin, wsd.data_ptr(), nwd), args.iters)
+            else:
+                npk = ops._query("mnk_conv3x3_packed_floats", cin, cout, 0)
+                wpd = torch.empty(npk, device=dev)
+                ops._call("mnk_conv3x3_pack_dgrad", dy, wt.data_ptr(), wpd.data_ptr(), cout, cin, 0, cin)
+                t_d = timeit(lambda: ops._conv_launch(dy, cout, None, 0, 0, wpd, None, None, frames, h, w, cin), args.iters)
             dw = torch.empty_like(wt)
             nws = ops._query("mnk_conv3x3_wgrad_workspace_floats", frames, h, w, cin, cout)
             ws = torch.empty(max(nws, 1), device=dev)
