@@ -261,6 +261,9 @@ typedef struct MnkWgradReduceDesc {
     int reserved;
 } MnkWgradReduceDesc;
 int mnk_wgrad_reduce_blocks(int splits, int Cout, int C);
+/* launch-plan switches (MNK_UP_SUBPIXEL, MNK_WGROUP_CHUNK, MNK_WTAP_TARGET, MNK_WN16_TARGET, MNK_SPLIT_TARGET, MNK_SPLIT_TILES,
+ * MNK_BM64_TILES, MNK_XCD_REMAP) are read from the environment when the library is loaded; this changes one afterwards */
+int mnk_set_tuning(const char* name, int value);
 int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream);
 
 /* ---- grouped weight gradients (new): the tap-major GEMMs of MANY layers in one launch per tile shape.  Launched one by

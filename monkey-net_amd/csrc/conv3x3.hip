@@ -23,6 +23,7 @@
 // Small problems (deep hourglass levels: 4x4 / 2x2 maps with 1024 channels) are split along K across blockIdx.z
 // with a deterministic second-pass reduction (no atomics), which also applies bias and the residual add.
 #include <stdlib.h>
+#include <string.h>
 
 #include "mnk_common.h"
 #include "pack_tile.h"
@@ -2981,6 +2982,22 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
     }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+// launch-plan switches are read from the environment when the library is loaded; this sets one afterwards (A/B runs, tests)
+int mnk_set_tuning(const char* name, int value) {
+    MNK_REQUIRE(name);
+    struct { const char* n; int* v; } knobs[] = {{"MNK_UP_SUBPIXEL", &g_up_subpixel}, {"MNK_WGROUP_CHUNK", &g_wgroup_chunk},
+                                                  {"MNK_WTAP_TARGET", &g_wtap_target}, {"MNK_WN16_TARGET", &g_wn16_target},
+                                                  {"MNK_SPLIT_TARGET", &g_split_target}, {"MNK_SPLIT_TILES", &g_split_tiles},
+                                                  {"MNK_BM64_TILES", &g_bm64_tiles}, {"MNK_XCD_REMAP", &g_xcd_remap}};
+    for (auto& k : knobs)
+        if (strcmp(k.n, name) == 0) {
+            *k.v = value;
+            return MNK_OK;
+        }
+    set_error("mnk_set_tuning: unknown switch %s", name);
+    return MNK_EINVAL;
 }
 
 int mnk_wgrad_reduce_blocks(int splits, int Cout, int C) {

@@ -37,7 +37,9 @@ def parse_header(path=HEADER):
                 ty = a[: a.rfind(nm)].strip()
                 if "*" in ty:
                     base = ty.replace("const", "").replace("*", "").strip()
-                    if base in ("uint64_t", "double") and name.startswith("mnk_prof"):
+                    if base == "char":
+                        argtypes.append(ctypes.c_char_p)
+                    elif base in ("uint64_t", "double") and name.startswith("mnk_prof"):
                         argtypes.append(ctypes.POINTER(_CTYPES[base]))
                     else:
                         argtypes.append(ctypes.c_void_p)

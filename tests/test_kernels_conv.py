@@ -160,7 +160,8 @@ def test_conv3x3_wgrad(be, case, clean):
     DW = be.empty(cout, c0 + c1, 3, 3)
     for src, c_start, c_cnt in ((x0, 0, c0),) + (((x1, c0, c1),) if c1 else ()):
         X = be.t(to_nhwc(src, pad_value=0.0 if clean else float("nan")))
-        nws = be.query("mnk_conv3x3_wgrad_workspace_floats", n, h, w, c_cnt, cout)
+        nws = be.query("mnk_conv3x3_up_wgrad_workspace_floats" if ups else "mnk_conv3x3_wgrad_workspace_floats", n, h, w, c_cnt,
+                       cout)
         ws = be.empty(max(nws, 1))
         be.call("mnk_conv3x3_wgrad", X, X.shape[-1], c_cnt, int(ups) | (2 if clean else 0), DY, DY.shape[-1], cout, DW,
                 c0 + c1, c_start, n, h, w, ws, nws)

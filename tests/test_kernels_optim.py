@@ -62,7 +62,8 @@ def test_deferred_wgrad_of_many_layers_reduced_in_one_launch(be, accumulate):
             X = be.t(to_nhwc(src))
             plan = Plan()
             his, wis = (hi // 2, wi // 2) if ups else (hi, wi)
-            assert be.query("mnk_conv2d_wgrad_plan", n, ho, wo, c_cnt, cout, kh, kw, pad, X.shape[-1], ctypes.byref(plan)) == 0
+            assert be.query("mnk_conv2d_wgrad_plan2", n, ho, wo, c_cnt, cout, kh, kw, pad, X.shape[-1], int(ups) | 2,
+                            ctypes.byref(plan)) == 0
             part = be.empty(max(plan.part_floats, 1))
             tgt = DW if not (plan.splits == 0 and accumulate) else be.empty(cout, c0 + c1, kh, kw)
             be.call("mnk_conv2d_wgrad", X, X.shape[-1], c_cnt, int(ups) | 2 | 4, hi, wi, kh, kw, pad, DY, DY.shape[-1], cout,
@@ -80,7 +81,7 @@ def test_deferred_wgrad_of_many_layers_reduced_in_one_launch(be, accumulate):
         keep.append((DY, DW, wd.grad, base))
     rec = np.array(rows, dtype=REDUCE_DESC)
     layouts = set(int(r["layout"]) for r in rec)
-    assert layouts == {0, 1} and direct > 0 and len(rec) > 12, (layouts, direct, len(rec))
+    assert layouts == {0, 1, 2} and direct > 0 and len(rec) > 12, (layouts, direct, len(rec))
     descs = _table(be, rec)
     be.call("mnk_wgrad_reduce_multi", descs, len(rec), blocks)
     be.sync()
@@ -202,7 +203,16 @@ JOB = np.dtype([("x", "<u8"), ("dy", "<u8"), ("part", "<u8"), ("part_floats", "<
                 ("reserved", "<i4")])
 
 
-def test_grouped_weight_gradients_of_many_layers(be, monkeypatch):
+@pytest.mark.parametrize("subpixel", [1, 0], ids=["up-layers-subpixel", "up-layers-upsampled-view"])
+def test_grouped_weight_gradients_of_many_layers(be, subpixel):
+    try:
+        be.lib.call("mnk_set_tuning", b"MNK_UP_SUBPIXEL", subpixel)
+        _grouped_weight_gradients(be, subpixel)
+    finally:
+        be.lib.call("mnk_set_tuning", b"MNK_UP_SUBPIXEL", 1)
+
+
+def _grouped_weight_gradients(be, subpixel):
     """mnk_wgrad_grouped_*: the tap-major weight-gradient GEMMs of many layers (all four tile shapes, the three loaders, two
     sources, up-sampled views, the 4x4 discriminator kernels, several pixel chunks per layer) in one launch per tile
     shape + ONE reduction launch, against conv2d's weight gradient in fp64."""
@@ -241,8 +251,9 @@ def test_grouped_weight_gradients_of_many_layers(be, monkeypatch):
     rec = np.array(jobs, dtype=JOB)
     assert be.query("mnk_wgrad_grouped_plan", rec.ctypes.data, len(rec)) == 0
     sel = [i for i in range(len(rec)) if rec["variant"][i] >= 0]
-    assert len(sel) >= 12 and len(set(int(rec["variant"][i]) // 3 for i in sel)) == 4, rec["variant"]
-    assert len(set(int(rec["variant"][i]) % 3 for i in sel)) == 3 and max(int(rec["splits"][i]) for i in sel) >= 4
+    assert len(sel) >= 12 and len(set(int(rec["variant"][i]) // 4 for i in sel)) == 4, rec["variant"]
+    modes = set(int(rec["variant"][i]) % 4 for i in sel)       # loaders: generic, 3x3 buffer loads, + up-sampled view / sub-pixel
+    assert modes == ({0, 1, 3} if subpixel else {0, 1, 2}) and max(int(rec["splits"][i]) for i in sel) >= 4
     grouped = rec[sel].copy()
     parts, rows, blocks = [], [], 0
     for k, i in enumerate(sel):
@@ -250,8 +261,8 @@ def test_grouped_weight_gradients_of_many_layers(be, monkeypatch):
         parts.append(part)
         grouped["part"][k] = part.data_ptr()
         DW, cin_total, c_start, c_cnt, cout, ntaps, _ = meta[i]
-        rows.append((part.data_ptr(), DW.data_ptr(), 0, int(grouped["splits"][k]), ntaps, cout, c_cnt, cin_total, c_start, 0,
-                     blocks, 0))
+        rows.append((part.data_ptr(), DW.data_ptr(), 2 if int(grouped["variant"][k]) % 4 == 3 else 0, int(grouped["splits"][k]),
+                     ntaps, cout, c_cnt, cin_total, c_start, 0, blocks, 0))
         blocks += be.query("mnk_wgrad_reduce_blocks", int(grouped["splits"][k]), cout, c_cnt)
     nbytes = be.query("mnk_wgrad_grouped_table_bytes", len(grouped))
     host = torch.zeros(nbytes, dtype=torch.uint8)
@@ -265,8 +276,8 @@ def test_grouped_weight_gradients_of_many_layers(be, monkeypatch):
         DW, cin_total, c_start, c_cnt, cout, ntaps, X = meta[i]
         j = rec[i]
         plan = Plan()
-        assert be.query("mnk_conv2d_wgrad_plan", int(j["N"]), int(j["Ho"]), int(j["Wo"]), c_cnt, cout, int(j["kh"]), int(j["kw"]),
-                        int(j["pad"]), int(j["ld_x"]), ctypes.byref(plan)) == 0
+        assert be.query("mnk_conv2d_wgrad_plan2", int(j["N"]), int(j["Ho"]), int(j["Wo"]), c_cnt, cout, int(j["kh"]), int(j["kw"]),
+                        int(j["pad"]), int(j["ld_x"]), int(j["flags"]) | 2, ctypes.byref(plan)) == 0
         part = be.empty(max(plan.part_floats, 1))
         parts.append(part)
         be.lib.call("mnk_conv2d_wgrad", int(j["x"]), int(j["ld_x"]), c_cnt, int(j["flags"]) | 2 | 4, int(j["Hi"]), int(j["Wi"]),
