@@ -1530,6 +1530,10 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
         const long total_src = FUPS ? (a.M / frame_px) * Hs * Ws : a.M;
         long nrec = (total_src - pb0) * ldx4;
         if (nrec > 0x40000000L) nrec = 0x40000000L;
+        // a split that starts in the last image row has pb0 > total_src for the taps of the row below (every row of it is
+        // "bad"): an empty buffer -- a negative length would wrap to ~4 GB of "valid" range and the bit-30 offsets of the
+        // bad rows would be dereferenced (seen as a memory fault at 256x256: three image rows per split)
+        if (nrec < 0) nrec = 0;
         rsb = uniform_rsrc(a.x + pb0 * a.ld_x, (unsigned)nrec);
         auto init_b = [&](long p, int& w, int& h, int& n, unsigned& off) __attribute__((always_inline)) {
             const unsigned up = (unsigned)p, q = fast_div(up, a.mulW, a.shW), fr = fast_div(q, a.mulH, a.shH);
@@ -2146,7 +2150,7 @@ static void launch_wgrad_reduce(float* ws, int splits, int Cout, int NT, float* 
 }
 
 // ---- grouped tap-major weight gradients: plan / build / launch --------------------------------------------------------
-static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 512);
+static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 256);
 static int g_up_subpixel = env_int("MNK_UP_SUBPIXEL", 1);     // weight gradients of up-sampled convolutions: sub-pixel form
 
 // the sub-pixel tap-major plan of an up-sampled 3x3 layer (flags: UPSAMPLED | CLEAN_PADS), or use = false

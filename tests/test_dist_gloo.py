@@ -104,7 +104,8 @@ def test_two_ranks_equal_one_rank_big_batch(mnk_adam):
                 # differs from the one-batch sum by rounding, which can flip the sign of a near-zero gradient element
                 d = (r0[key][k] - v).abs()
                 assert float(d.max()) <= 2.1 * lr, (key, k, float(d.max()))
-                assert float((d > 0.05 * lr).float().mean()) < 0.03, (key, k, float((d > 0.05 * lr).float().mean()))
+                flipped = int((d > 0.05 * lr).sum())          # (one element of a 32-element vector is already 3.1 %)
+                assert flipped <= max(2, 0.03 * d.numel()), (key, k, flipped, d.numel())
 
 
 def test_grad_averager_and_shard_batch_single_process():

@@ -139,6 +139,7 @@ WFAST_CASES = [
     (2, 32, 16, 20, 0, 136, 1, False, False),
     (2, 16, 48, 80, 0, 40, 1, False, False),
     (3, 6, 20, 72, 0, 24, 0, False, False),
+    (1, 32, 128, 64, 0, 128, 0, False, False),   # one image row per pixel split: the last split's buffer of the row below is empty
 ]
 
 

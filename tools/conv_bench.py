@@ -72,7 +72,8 @@ def main():
                 ops._call("mnk_conv3x3_pack_dgrad", dy, wt.data_ptr(), wpd.data_ptr(), cout, cin, 0, cin)
                 t_d = timeit(lambda: ops._conv_launch(dy, cout, None, 0, 0, wpd, None, None, frames, h, w, cin), args.iters)
             dw = torch.empty_like(wt)
-            nws = ops._query("mnk_conv3x3_wgrad_workspace_floats", frames, h, w, cin, cout)
+            nws = ops._query("mnk_conv3x3_up_wgrad_workspace_floats" if ups else "mnk_conv3x3_wgrad_workspace_floats", frames, h, w,
+                             cin, cout)
             ws = torch.empty(max(nws, 1), device=dev)
 
             def wg():
