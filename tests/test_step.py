@@ -130,8 +130,9 @@ def _compare_step_forms(be, monkeypatch, rec_def, detach_d, detach_g, base, othe
                 if ref.is_floating_point() and not cases.is_noise_bias(k):   # (a pure-noise gradient moves by +-lr)
                     d = float((final1[n][k] - ref).abs().max())
                     assert d <= 2.5 * lr * iters + 1e-4 * float(ref.abs().max()) or "running" in k, (n, k, d)
-                    frac = float(((final1[n][k] - ref).abs() > 0.05 * lr).float().mean())
-                    assert frac < 0.05 or "running" in k, (n, k, frac)      # (2.8 % of a 1 728-element tensor measured)
+                    flipped = int(((final1[n][k] - ref).abs() > 0.05 * lr).sum())
+                    # (2.8 % of a 1 728-element tensor and 1 of 16 elements measured on the MI355X)
+                    assert flipped <= max(2, 0.05 * ref.numel()) or "running" in k, (n, k, flipped, ref.numel())
     checked = 0
     for name in ("g", "d", "k"):
         for k, ref in grads2[name].items():
