@@ -373,6 +373,18 @@ int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, fl
 int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, void* stream);
 int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* dout, float* dvar, void* stream);
 
+/* ---- transfer-time key-point normalisation (transfer.py:31-62 normalize_kp) ------------------
+ * mnk_kp_hull_area: area of the convex hull of K (3..32) points [K][2] -> *area (device scalar) -- scipy.spatial.ConvexHull
+ *   (points).volume of transfer.py:34-35, which the reference evaluates on the host (a device -> host copy per video).
+ * mnk_kp_normalize: kp of a driving video mean_v [B][D][K][2] / var_v [B][D][K][4] relative to its first frame, moved onto
+ *   the source's key-points mean_a / var_a [B][1][K][.]:  move_location (scaled by sqrt(*area_a / *area_v) when both are
+ *   given), clip_mean (clamp to [-1, 1]), adapt_variance (var_v inverse(var_v[:, 0]) var_a, symmetrised, eigenvalues <= 0
+ *   lifted to 1e-6: make_symetric_matrix, transfer.py:17-28).  var_out NULL: means only. */
+int mnk_kp_hull_area(const float* points, int K, float* area, void* stream);
+int mnk_kp_normalize(const float* mean_v, const float* var_v, const float* mean_a, const float* var_a, int B, int D, int K,
+                     const float* area_a, const float* area_v, int move_location, int clip_mean, int adapt_variance,
+                     float* mean_out, float* var_out, void* stream);
+
 /* ---- key-point -> movement embedding (modules/movement_embedding.py:42-92, keypoint_detector.py:7-40) ----
  * one kernel renders, per slot (background first when add_bg): [heat-map (driving - source when
  * heatmap_diff), (dx,dy) maps, source image translated by kp_source - kp_driving].  Frames f = b*d + j use

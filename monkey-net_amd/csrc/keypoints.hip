@@ -529,6 +529,112 @@ __global__ void __launch_bounds__(256) kp_clip_var_bwd_kernel(const float* __res
         make_float4(fmaf(g.x, f, k * da), fmaf(g.y, f, k * db), fmaf(g.z, f, k * dc), fmaf(g.w, f, k * dd));
 }
 
+
+// ---- transfer-time key-point normalisation (transfer.py:31-62 normalize_kp) on the device --------------------------------
+// area of the convex hull of K <= 32 points (scipy.spatial.ConvexHull(points).volume in 2-D): Andrew's monotone chain and
+// the shoelace formula, one thread (transfer.py:34-36 uses the hulls of the first frame's key-points only)
+__global__ void kp_hull_area_kernel(const float* __restrict__ pts, int K, float* __restrict__ area) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float x[32], y[32];
+    for (int i = 0; i < K; ++i) {
+        x[i] = pts[2 * i];
+        y[i] = pts[2 * i + 1];
+    }
+    for (int i = 1; i < K; ++i) {          // insertion sort by (x, y)
+        const float xi = x[i], yi = y[i];
+        int j = i - 1;
+        while (j >= 0 && (x[j] > xi || (x[j] == xi && y[j] > yi))) {
+            x[j + 1] = x[j];
+            y[j + 1] = y[j];
+            --j;
+        }
+        x[j + 1] = xi;
+        y[j + 1] = yi;
+    }
+    int hull[66];
+    int n = 0;
+    auto cross = [&](int o, int a, int b) { return (x[a] - x[o]) * (y[b] - y[o]) - (y[a] - y[o]) * (x[b] - x[o]); };
+    for (int i = 0; i < K; ++i) {          // lower hull
+        while (n >= 2 && cross(hull[n - 2], hull[n - 1], i) <= 0.f) --n;
+        hull[n++] = i;
+    }
+    const int lower = n + 1;
+    for (int i = K - 2; i >= 0; --i) {     // upper hull
+        while (n >= lower && cross(hull[n - 2], hull[n - 1], i) <= 0.f) --n;
+        hull[n++] = i;
+    }
+    --n;                                   // the last point repeats the first
+    float a2 = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const int p = hull[i], q = hull[(i + 1) % n];
+        a2 += x[p] * y[q] - x[q] * y[p];
+    }
+    *area = 0.5f * fabsf(a2);
+}
+
+// one thread per (batch entry b, driving frame f, key-point k):
+//   mean' = (mean_v[b,f,k] - mean_v[b,0,k]) * sqrt(area_a / area_v) + mean_a[b,0,k]      (move_location; then clamp to [-1,1])
+//   var'  = sym_posdef( var_v[b,f,k] * inverse(var_v[b,0,k]) * var_a[b,0,k] )            (adapt_variance)
+// sym_posdef = make_symetric_matrix (transfer.py:17-28): (A + A^T) / 2 with eigenvalues <= 0 replaced by 1e-6 (closed form
+// for 2x2: the matrix itself when both eigenvalues are positive)
+__global__ void __launch_bounds__(256) kp_normalize_kernel(const float* __restrict__ mean_v, const float* __restrict__ var_v,
+                                                           const float* __restrict__ mean_a, const float* __restrict__ var_a,
+                                                           int B, int D, int K, const float* __restrict__ area_a,
+                                                           const float* __restrict__ area_v, int move_location, int clip_mean,
+                                                           int adapt_variance, float* __restrict__ mean_out,
+                                                           float* __restrict__ var_out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * D * K) return;
+    const int k = (int)(i % K);
+    const int b = (int)(i / ((long)D * K));
+    const long first = ((long)b * D) * K + k, app = (long)b * K + k;
+    float mx = mean_v[2 * i], my = mean_v[2 * i + 1];
+    if (move_location) {
+        const float mult = (area_a && area_v) ? sqrtf(*area_a) / sqrtf(*area_v) : 1.f;
+        mx = (mx - mean_v[2 * first]) * mult + mean_a[2 * app];
+        my = (my - mean_v[2 * first + 1]) * mult + mean_a[2 * app + 1];
+    }
+    if (clip_mean) {
+        mx = fminf(fmaxf(mx, -1.f), 1.f);
+        my = fminf(fmaxf(my, -1.f), 1.f);
+    }
+    mean_out[2 * i] = mx;
+    mean_out[2 * i + 1] = my;
+    if (!var_out) return;
+    float v00 = var_v[4 * i], v01 = var_v[4 * i + 1], v10 = var_v[4 * i + 2], v11 = var_v[4 * i + 3];
+    if (adapt_variance) {
+        const float f00 = var_v[4 * first], f01 = var_v[4 * first + 1], f10 = var_v[4 * first + 2], f11 = var_v[4 * first + 3];
+        const float det = f00 * f11 - f01 * f10;
+        const float i00 = f11 / det, i01 = -f01 / det, i10 = -f10 / det, i11 = f00 / det;     // matrix_inverse, eps = 0
+        const float t00 = v00 * i00 + v01 * i10, t01 = v00 * i01 + v01 * i11;
+        const float t10 = v10 * i00 + v11 * i10, t11 = v10 * i01 + v11 * i11;
+        const float a00 = var_a[4 * app], a01 = var_a[4 * app + 1], a10 = var_a[4 * app + 2], a11 = var_a[4 * app + 3];
+        float r00 = t00 * a00 + t01 * a10, r01 = t00 * a01 + t01 * a11;
+        float r10 = t10 * a00 + t11 * a10, r11 = t10 * a01 + t11 * a11;
+        // symmetrise, then lift non-positive eigenvalues to 1e-6
+        const float p = r00, q = 0.5f * (r01 + r10), r = r11;
+        const float half = 0.5f * (p + r), dif = 0.5f * (p - r), rad = sqrtf(dif * dif + q * q);
+        float l1 = half + rad, l2 = half - rad;
+        r00 = p, r01 = r10 = q, r11 = r;
+        if (l1 <= 0.f || l2 <= 0.f) {
+            // unit eigenvector of l1: (q, l1 - p) or (l1 - r, q), whichever is better conditioned; l2's is orthogonal
+            float ex = q, ey = l1 - p;
+            if (fabsf(l1 - r) > fabsf(l1 - p)) ex = l1 - r, ey = q;
+            const float nrm = sqrtf(ex * ex + ey * ey);
+            if (nrm > 0.f) ex /= nrm, ey /= nrm; else ex = 1.f, ey = 0.f;
+            const float d1 = l1 <= 0.f ? 1e-6f : l1, d2 = l2 <= 0.f ? 1e-6f : l2;
+            r00 = d1 * ex * ex + d2 * ey * ey;
+            r01 = r10 = (d1 - d2) * ex * ey;
+            r11 = d1 * ey * ey + d2 * ex * ex;
+        }
+        v00 = r00, v01 = r01, v10 = r10, v11 = r11;
+    }
+    var_out[4 * i] = v00;
+    var_out[4 * i + 1] = v01;
+    var_out[4 * i + 2] = v10;
+    var_out[4 * i + 3] = v11;
+}
+
 }  // namespace
 
 extern "C" {
@@ -624,6 +730,28 @@ int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_KEYPOINT, s, (double)M * 48);
     hipLaunchKernelGGL(kp_clip_var_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, clip, M, dout, dvar);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_kp_hull_area(const float* points, int K, float* area, void* stream) {
+    MNK_REQUIRE(points && area && K >= 3 && K <= 32);
+    hipLaunchKernelGGL(kp_hull_area_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, points, K, area);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_kp_normalize(const float* mean_v, const float* var_v, const float* mean_a, const float* var_a, int B, int D, int K,
+                     const float* area_a, const float* area_v, int move_location, int clip_mean, int adapt_variance,
+                     float* mean_out, float* var_out, void* stream) {
+    MNK_REQUIRE(mean_v && mean_a && mean_out && B > 0 && D > 0 && K > 0 && (!var_out || var_v));
+    MNK_REQUIRE(!adapt_variance || (var_v && var_a && var_out));
+    MNK_REQUIRE((area_a == nullptr) == (area_v == nullptr));
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)B * D * K;
+    ProfScope prof(K_KEYPOINT, s, (double)n * 48);
+    hipLaunchKernelGGL(kp_normalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mean_v, var_v, mean_a, var_a, B, D,
+                       K, area_a, area_v, move_location, clip_mean, adapt_variance, mean_out, var_out);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

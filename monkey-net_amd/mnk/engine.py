@@ -387,3 +387,63 @@ class Reconstructor:
         self._static_in[1].copy_(driving, non_blocking=True)
         self._graph.replay()
         return self._static_out
+
+
+def normalize_kp(kp_video, kp_appearance, movement_mult=False, move_location=False, adapt_variance=False, clip_mean=False):
+    """transfer.py:31-62 on the device, same arguments and return value (a new key-point dict): the convex-hull areas
+    (transfer.py:34-36; the reference copies the key-points to the host for scipy), the re-centring on the source's
+    key-points and the covariance transfer with its symmetric positive-definite repair are two kernel launches, no
+    host synchronisation."""
+    mean_v = kp_video['mean'].contiguous().float()
+    mops._check_device(mean_v)
+    b, d, k, _ = mean_v.shape
+    mean_a = kp_appearance['mean'].contiguous().float()
+    has_var = 'var' in kp_video
+    var_v = kp_video['var'].contiguous().float() if has_var else None
+    var_a = kp_appearance['var'].contiguous().float() if has_var and 'var' in kp_appearance else None
+    adapt = bool(adapt_variance and has_var)
+    if clip_mean and not move_location:
+        raise NameError("clip_mean without move_location is an error in the reference too (transfer.py:49)")
+    if not (move_location or adapt):
+        return {key: v for key, v in kp_video.items()}
+    area_a = area_v = None
+    if movement_mult:
+        area_a = torch.empty(1, dtype=torch.float32, device=mean_v.device)
+        area_v = torch.empty(1, dtype=torch.float32, device=mean_v.device)
+        mops._call("mnk_kp_hull_area", mean_v, mops._p(mean_a), k, mops._p(area_a))      # kp_appearance['mean'][0, 0]
+        mops._call("mnk_kp_hull_area", mean_v, mops._p(mean_v), k, mops._p(area_v))      # kp_video['mean'][0, 0]
+    mean_out = torch.empty_like(mean_v)
+    var_out = torch.empty_like(var_v) if has_var else None
+    mops._call("mnk_kp_normalize", mean_v, mops._p(mean_v), mops._p(var_v), mops._p(mean_a), mops._p(var_a), b, d, k,
+               mops._p(area_a), mops._p(area_v), int(bool(move_location)), int(bool(clip_mean)), int(adapt), mops._p(mean_out),
+               mops._p(var_out))
+    out = {key: v for key, v in kp_video.items()}
+    out['mean'] = mean_out
+    if has_var:
+        out['var'] = var_out
+    return out
+
+
+class Transfer:
+    """transfer.py:65-79 transfer_one without its per-frame Python loops: ONE key-point detector call over all driving
+    frames (the detector folds the time axis into the batch), normalize_kp on the device, and ONE generator call with the
+    (video, frame) pairs folded into the batch.  Eval mode (running BatchNorm statistics), so frames are independent.
+    Returns the dict transfer_one returns."""
+
+    def __init__(self, kp_detector, generator, normalization_params):
+        self.kp_detector, self.generator = kp_detector.eval(), generator.eval()
+        self.params = dict(normalization_params)
+
+    @torch.no_grad()
+    def __call__(self, source_image, driving_video):
+        b, c, d, h, w = driving_video.shape
+        kp_driving = self.kp_detector(driving_video)                     # (B, d, K, .)
+        kp_source = self.kp_detector(source_image)                       # (B, 1, K, .)
+        kp_norm = normalize_kp(kp_driving, kp_source, **self.params)
+        fold = lambda t: t.reshape((b * d, 1) + t.shape[2:])             # frame f of video v -> batch entry v * d + f
+        rep = lambda t: t.repeat_interleave(d, dim=0)
+        out = self.generator(rep(source_image), kp_driving={k: fold(v) for k, v in kp_norm.items()},
+                             kp_source={k: rep(v) for k, v in kp_source.items()})
+        unfold = lambda t: t.reshape(b, d, c, h, w).permute(0, 2, 1, 3, 4)       # (B*d, C, 1, H, W) -> (B, C, d, H, W)
+        return {"video_prediction": unfold(out["video_prediction"]), "video_deformed": unfold(out["video_deformed"]),
+                "kp_driving": kp_driving, "kp_source": kp_source, "kp_norm": kp_norm}

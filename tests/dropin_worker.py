@@ -202,6 +202,48 @@ def scenario_transfer():
     return errs
 
 
+def scenario_transfer_batched():
+    """mnk.engine.Transfer (one detector call, device-side normalize_kp, one generator call) and mnk.engine.normalize_kp
+    against the REFERENCE's transfer_one / normalize_kp (transfer.py:31-79, scipy convex hulls, numpy eigen-decomposition)
+    running frame by frame on the same drop-in modules -- for every normalisation variant of the shipped configs."""
+    import transfer as ref_transfer
+    from mnk import engine
+    gold, gen, kpd = _eval_models()
+    gen.eval(), kpd.eval()
+    src, _ = cases.smooth_pair(2, gold["size"], gold["size"], seed=11)
+    driving = torch.cat([cases.smooth_pair(2, gold["size"], gold["size"], seed=20 + i)[1] for i in range(3)], dim=2)
+    worst = {}
+    variants = [dict(movement_mult=False, move_location=True, adapt_variance=True, clip_mean=True),
+                dict(movement_mult=True, move_location=True, adapt_variance=True, clip_mean=False),
+                dict(movement_mult=False, move_location=False, adapt_variance=False, clip_mean=False),
+                dict(movement_mult=True, move_location=True, adapt_variance=False, clip_mean=True)]
+    for params in variants:
+        with torch.no_grad():
+            exp = ref_transfer.transfer_one(gen, kpd, src, driving, {"normalization_params": params})
+        got = engine.Transfer(kpd, gen, params)(src, driving)
+        for k in ("video_prediction", "video_deformed"):
+            e = float((got[k].double() - exp[k].double()).abs().max())
+            worst[k] = max(worst.get(k, 0.0), e)
+        for k in ("mean", "var"):
+            e = float((got["kp_norm"][k].double() - exp["kp_norm"][k].double()).abs().max())
+            worst["kp_norm_" + k] = max(worst.get("kp_norm_" + k, 0.0), e)
+    # the covariance repair: a covariance product with a non-positive eigenvalue (make_symetric_matrix, transfer.py:17-28)
+    g = torch.Generator().manual_seed(8)
+    kp_v = cases.random_kp(2, 3, 4, seed=31)
+    kp_a = cases.random_kp(2, 1, 4, seed=32)
+    kp_a["var"][0, 0, 1] = torch.tensor([[0.02, 0.05], [0.05, 0.01]])        # indefinite after the transfer
+    kp_a["var"][1, 0, 2] = torch.tensor([[-0.03, 0.0], [0.0, 0.02]])
+    params = dict(movement_mult=False, move_location=True, adapt_variance=True, clip_mean=False)
+    exp = ref_transfer.normalize_kp(kp_v, kp_a, **params)
+    got = engine.normalize_kp(kp_v, kp_a, **params)
+    worst["repair_var"] = float((got["var"].double() - exp["var"].double()).abs().max())
+    worst["repair_mean"] = float((got["mean"].double() - exp["mean"].double()).abs().max())
+    assert worst["video_prediction"] < 2e-5 and worst["video_deformed"] < 2e-4, worst
+    assert worst["kp_norm_mean"] < 2e-6 and worst["kp_norm_var"] < 2e-6, worst
+    assert worst["repair_var"] < 2e-6 and worst["repair_mean"] < 1e-6, worst
+    return worst
+
+
 if __name__ == "__main__":
     res = globals()["scenario_" + sys.argv[1]]()
     print("DROPIN_RESULT " + json.dumps(res))

@@ -48,6 +48,11 @@ def test_reference_transfer_one_with_normalize_kp():
     assert res["video_prediction"] < 5e-5
 
 
+def test_batched_transfer_and_device_normalize_kp_match_the_reference_loop():
+    res = _run("transfer_batched")
+    assert res["video_prediction"] < 2e-5 and res["repair_var"] < 2e-6
+
+
 def test_launcher_puts_the_drop_in_first(tmp_path):
     """monkey-net_amd/run_reference.py: `python run.py` would resolve `modules` in the script's own directory."""
     script = tmp_path / "probe.py"

@@ -114,3 +114,44 @@ def test_no_grad_pack_cache_sees_replaced_storage(be):
     del w
     gc.collect()
     assert len(ops._PACK_CACHE) == n0 - 1
+
+
+def test_batched_transfer_equals_the_frame_loop_and_normalize_kp_its_formulas(be):
+    """mnk.engine.Transfer folds transfer.py:65-79's per-frame loops into one detector and one generator call; here against
+    the same modules driven frame by frame, with the key-point normalisation (transfer.py:31-62) restated in torch + scipy
+    (convex-hull area) + numpy (symmetric eigen-repair).  (Against the reference's own transfer_one: test_dropin_reference.)"""
+    import numpy as np
+    from scipy.spatial import ConvexHull
+    from mnk import engine
+    from modules.util import matrix_inverse
+    gold = load("tiny")
+    gen, disc, kpd = build(gold["cfg"])
+    gen.load_state_dict(gold["state"]["generator"]), kpd.load_state_dict(gold["state"]["kp_detector"])
+    gen.to(be.device).eval(), kpd.to(be.device).eval()
+    src, _ = cases.smooth_pair(2, gold["size"], gold["size"], seed=11)
+    driving = torch.cat([cases.smooth_pair(2, gold["size"], gold["size"], seed=20 + i)[1] for i in range(3)], dim=2)
+    src, driving = be.t(src), be.t(driving)
+    params = dict(movement_mult=True, move_location=True, adapt_variance=True, clip_mean=True)
+    got = engine.Transfer(kpd, gen, params)(src, driving)
+    be.sync()
+    with torch.no_grad():
+        kp_d = {k: torch.cat([kpd(driving[:, :, i:i + 1])[k] for i in range(3)], dim=1) for k in ("mean", "var")}
+        kp_s = kpd(src)
+        mv, vv, ma, va = (t.cpu().double() for t in (kp_d["mean"], kp_d["var"], kp_s["mean"], kp_s["var"]))
+        mult = np.sqrt(ConvexHull(ma[0, 0].numpy()).volume) / np.sqrt(ConvexHull(mv[0, 0].numpy()).volume)
+        mean = ((mv - mv[:, 0:1]) * mult + ma).clamp(-1, 1)
+        var = torch.matmul(torch.matmul(vv, matrix_inverse(vv[:, 0:1])), va)
+        sym = (var + var.transpose(-1, -2)) / 2
+        ev, eu = np.linalg.eigh(sym.numpy())
+        ev[ev <= 0] = 1e-6
+        var = torch.from_numpy(np.einsum("...ij,...j,...kj->...ik", eu, ev, eu))
+        assert float((got["kp_norm"]["mean"].cpu().double() - mean).abs().max()) < 2e-6
+        assert float((got["kp_norm"]["var"].cpu().double() - var).abs().max()) < 2e-6
+        frames = []
+        for i in range(3):
+            kp_i = {k: v[:, i:i + 1] for k, v in got["kp_norm"].items()}
+            frames.append(gen(src, kp_driving=kp_i, kp_source=kp_s)["video_prediction"])
+        loop = torch.cat(frames, dim=2)
+    be.sync()
+    assert got["video_prediction"].shape == loop.shape == (2, 3, 3, gold["size"], gold["size"])
+    assert float((got["video_prediction"] - loop).abs().max()) < 2e-6
