@@ -493,7 +493,9 @@ class Conv3x3Fn(torch.autograd.Function):
         db = None
         if has_bias and ctx.needs_input_grad[3]:
             slot, _DY_SUMS[0] = _DY_SUMS[0], None
-            if slot is not None and slot[0] is dy_in and slot[1].numel() == cout:
+            if slot is not None and slot[0] is dy_in and slot[1] is None:
+                db = None                      # a training-mode BatchNorm follows: the bias gradient is exactly zero
+            elif slot is not None and slot[0] is dy_in and slot[1].numel() == cout:
                 db = slot[1]                   # column sums of dy came out of the norm layer's backward pass
             else:
                 db = channel_sums(dy, cout)[:cout]
@@ -577,11 +579,20 @@ class BNActFn(torch.autograd.Function):
         if training and mdist.active():
             sums = mdist.all_reduce_sum_(sums.clone())
         dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
-        dy_sums = torch.empty(c, dtype=torch.float32, device=y.device)
-        _call("mnk_bn_act_bwd_apply_colsum", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale),
-              _p(beta), _p(sums), count, int(training), _p(dy), ld, n, h, w, c, int(relu), int(pool), _p(dy_sums), _p(ws),
-              nws)
-        _DY_SUMS[0] = (dy, dy_sums)          # picked up by Conv3x3Fn.backward when it receives this very tensor
+        if training and knobs.on("MNK_BN_ZERO_BIAS_GRAD"):
+            # training-mode statistics: sum over pixels of dy = scale * (sum g - N * mean(g) - k2 * sum xhat) == 0 exactly, so
+            # the bias gradient of the convolution in front (util.py:54-56,80-81,99-100) is analytically zero; the reference
+            # computes its rounding noise.  No reduction is spent on it: that bias simply receives no gradient (an optimiser
+            # then leaves it alone -- BatchNorm cancels any bias anyway).  MNK_BN_ZERO_BIAS_GRAD=0 computes the noise.
+            _call("mnk_bn_act_bwd_apply", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta),
+                  _p(sums), count, 1, _p(dy), ld, n, h, w, c, int(relu), int(pool))
+            _DY_SUMS[0] = (dy, None)
+        else:
+            dy_sums = torch.empty(c, dtype=torch.float32, device=y.device)
+            _call("mnk_bn_act_bwd_apply_colsum", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale),
+                  _p(beta), _p(sums), count, int(training), _p(dy), ld, n, h, w, c, int(relu), int(pool), _p(dy_sums), _p(ws),
+                  nws)
+            _DY_SUMS[0] = (dy, dy_sums)      # picked up by Conv3x3Fn.backward when it receives this very tensor
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 

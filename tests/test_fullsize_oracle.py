@@ -50,7 +50,8 @@ def check_records(grads, records, factor=8.0, floor=2e-4, report=None):
     worst = (0.0, None)
     checked = 0
     for m, recs in records.items():
-        assert set(grads[m]) == set(recs), (m, set(grads[m]) ^ set(recs))
+        # (the biases in front of a training-mode BatchNorm have an analytically zero gradient and may get none at all)
+        assert all(cases.is_noise_bias(k) for k in set(grads[m]) ^ set(recs)), (m, set(grads[m]) ^ set(recs))
         top = max(r["norm"] for r in recs.values())
         med = _noise_floor(recs)
         for k, r in recs.items():
@@ -131,7 +132,7 @@ def _full_iteration(be, gold, tag):
     report.append(("video_prediction vs oracle", float((pred - o_gen["video_prediction"].detach().double()).abs().max()),
                    8 * sp["pred"] + 4e-6))
     for m in ("generator", "kp_detector"):
-        assert set(o_grads[m]) == set(seen[m])
+        assert all(cases.is_noise_bias(k) for k in set(o_grads[m]) ^ set(seen[m])), set(o_grads[m]) ^ set(seen[m])
         top = max(float(v.norm()) for v in o_grads[m].values())
         for k, og in o_grads[m].items():
             if cases.is_noise_bias(k):

@@ -111,8 +111,8 @@ def test_tiny_forward_backward_train(be, name):
     gold = load(name)
     out, grads, gen, kpd = run_case(be, gold, train=True, backward=True)
     check_outputs(out, gold, "train")
-    assert set(grads["generator"]) == set(gold["grad64"]["generator"])
-    assert set(grads["kp_detector"]) == set(gold["grad64"]["kp_detector"])
+    for m in ("generator", "kp_detector"):     # a bias in front of a training-mode BatchNorm may get no gradient (exactly zero)
+        assert all(cases.is_noise_bias(k) for k in set(grads[m]) ^ set(gold["grad64"][m])), m
     check_grads(grads, gold)
     # running statistics after one training forward (batchnorm.py:119-123)
     for m, mod in (("generator", gen), ("kp_detector", kpd)):
