@@ -27,10 +27,11 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[
     line = f"{k:58s} n={n:4d}"
     if dur[k]:
         line += f" {dur[k]/n/1e3:8.1f} us"
+        # GRBM_GUI_ACTIVE is summed over the 8 XCD instances of the counter; SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
         if "GRBM_GUI_ACTIVE" in v:
-            line += f" clk {v['GRBM_GUI_ACTIVE']/dur[k]:.2f} GHz"
+            line += f" clk {v['GRBM_GUI_ACTIVE']/8/dur[k]:.2f} GHz"
         if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
-            line += f" mfma_busy/(gui*1024) {v['SQ_VALU_MFMA_BUSY_CYCLES']/(v['GRBM_GUI_ACTIVE']*1024):.3f}"
+            line += f" mfma_busy_per_simd {v['SQ_VALU_MFMA_BUSY_CYCLES']/(v['GRBM_GUI_ACTIVE']/8*1024):.3f}"
     for c in names:
         if c.startswith("SQ_") and c not in ("SQ_WAVE_CYCLES",):
             line += f" {c[3:]}={v.get(c,0)/wc:.3f}"
