@@ -114,6 +114,20 @@ int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int l
                                 double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu,
                                 int pool, float* dy_sums, float* ws, size_t ws_floats, void* stream);
 
+/* ---- small layers (N*H*W <= mnk_bn_small_rows() pixel rows: the 2x2 ... 16x16 levels of the hourglasses): the whole
+ * training-mode BatchNorm (+ReLU, +2x2 pool) of one rank in ONE launch per direction instead of four -- a block owns a tile of
+ * channels over all rows, so the column sums never leave it.  Forward: optionally sums the split-K partials `ws`
+ * ([split][phase][M][ldw], what mnk_conv3x3_fwd / mnk_conv3x3_up_fwd leave behind under MNK_CONV_DEFER_SPLITK) + bias into y
+ * first; then statistics, mean / inv-std / scale, running statistics (batchnorm.py:113-125) and the apply pass
+ * (util.py:56-57,81-87,100-107).  Backward: sums = [dbeta | dgamma], dy.  Not for SyncBN over several ranks. */
+int mnk_bn_small_rows(void);
+int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const float* bias, float* y, int ld_y, int N, int H, int W,
+                     int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* mean, float* invstd, float* scale, float* z, int ld_z, int relu, int pool, void* stream);
+int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,
+                     const float* scale, const float* beta, double count, int N, int H, int W, int C, int relu, int pool,
+                     float* sums, float* dy, int ld_dy, void* stream);
+
 /* ---- general normalisation forms: `frames` / per_frame = statistics per frame (nn.InstanceNorm3d of the discriminator,
  * modules/discriminator.py:19-22,29-30: sums [2][frames*C], mean/invstd/scale [frames*C], beta [C]); `slope` selects
  * the fused activation: < 0 none, 0 ReLU, > 0 LeakyReLU(slope) (discriminator.py:31).  With odd H / W the average pool
@@ -176,6 +190,12 @@ size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout);
  * ~10 % slower); with it the 3x3 kernels use raw buffer loads whose out-of-range lanes read zero. */
 #define MNK_CONV_UPSAMPLED 1
 #define MNK_CONV_CLEAN_PADS 2
+/* (= 4, forward only) a split-K launch leaves its partials in `ws` -- [split][phase][M][round_up(Cout, 4)], bias NOT added,
+ * mnk_conv3x3_splits / mnk_conv3x3_up_splits of them -- and the caller sums them (mnk_bn_small_fwd does, together with the
+ * normalisation that follows); y is not written */
+#define MNK_CONV_DEFER_SPLITK 4
+int mnk_conv3x3_splits(int N, int H, int W, int C0, int C1, int Cout);
+int mnk_conv3x3_up_splits(int N, int H, int W, int C0, int C1, int Cout);
 int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp,
                     const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
                     int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream);
@@ -200,9 +220,9 @@ int mnk_conv3x3_up_pack_fwd(const float* w, float* wp, int Cout, int C0, int C1,
 int mnk_conv3x3_up_pack_dgrad(const float* w, float* wp, int Cout, int Cin_total, int c_start, int c_count, void* stream);
 size_t mnk_conv3x3_up_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
 size_t mnk_conv3x3_up_stats_floats(int N, int H, int W, int C0, int C1, int Cout);
-int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, const float* wp_up, const float* bias,
-                       float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, float* stats_partial,
-                       void* stream);
+int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp_up,
+                       const float* bias, float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats,
+                       float* stats_partial, void* stream);     /* flags: 0 or MNK_CONV_DEFER_SPLITK */
 size_t mnk_conv3x3_up_dgrad_workspace_floats(int N, int H, int W, int Cout, int C);
 int mnk_conv3x3_up_dgrad(const float* dy, int ld_dy, int Cout, const float* wp_up_dgrad, float* dx, int ld_dx, int N, int H,
                          int W, int C, float* ws, size_t ws_floats, void* stream);

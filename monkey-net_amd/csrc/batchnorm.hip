@@ -428,6 +428,197 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
     }
 }
 
+
+// ---- small layers: the whole training-mode BatchNorm (+ReLU, +2x2 pool) of one layer in ONE launch ---------------------
+// The deep levels of the hourglasses (4x4 ... 16x16 maps, 256 ... 1024 channels) have a few thousand pixel rows: the
+// general path spends four launches of ~5 us each on them per direction (split-K reduction of the convolution in front,
+// statistics partials, second stage + finalisation, apply).  Here one block owns a tile of TXQ channel quads over ALL
+// rows, so the column sums never leave the block:
+//   forward : [sum of the convolution's split-K partials + bias -> y] -> sum / sum of squares -> mean, inv-std, scale,
+//             running statistics -> z = [pool] relu((y - mean) * scale + beta)
+//   backward: sum g, sum g*xhat (= dbeta, dgamma) -> dy = scale * (g - sum_g / n - xhat * sum_gx / n)
+// Single rank only (SyncBN has an all-reduce between the two halves).  rows <= kSmallRows.
+constexpr int kSmallRows = 2048;
+
+__device__ __forceinline__ void small_tree_sum2(float4* red0, float4* red1, float4& a, float4& b, int tx_n, int ty_n, int tx,
+                                                int ty) {
+    red0[threadIdx.x] = a;
+    red1[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = ty_n >> 1; s > 0; s >>= 1) {
+        if (ty < s) {
+            red0[threadIdx.x] = f4_add(red0[threadIdx.x], red0[threadIdx.x + s * tx_n]);
+            red1[threadIdx.x] = f4_add(red1[threadIdx.x], red1[threadIdx.x + s * tx_n]);
+        }
+        __syncthreads();
+    }
+    a = red0[tx];          // every thread gets the totals of its quad (thread layout: index = ty * tx_n + tx)
+    b = red1[tx];
+    __syncthreads();
+}
+
+struct SmallFwdArgs {
+    const float* ws;       // split-K partials [split][phase][M][ldw] of the convolution in front, or NULL (y is complete)
+    int splits, ldw, phases;
+    const float* bias;
+    float* y;
+    int ld_y, N, H, W, C;  // y geometry (the up-sampled size for the sub-pixel form)
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    float momentum, eps;
+    float *mean, *invstd, *scale, *z;
+    int ld_z, relu, pool, tx_n;
+};
+
+__global__ void __launch_bounds__(256) bn_small_fwd_kernel(SmallFwdArgs a) {
+    __shared__ float4 red0[256], red1[256];
+    const int tx_n = a.tx_n, ty_n = 256 / tx_n;
+    const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+    const int nv = a.ld_y / 4, q = blockIdx.x * tx_n + tx;
+    const bool qok = q < nv;
+    const int rows = a.N * a.H * a.W, rem = a.C - q * 4;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (qok) {
+        if (a.ws) {
+            const float4 bv = a.bias ? ld4_guard(a.bias, q, a.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int Hl = a.H >> 1, Wl = a.W >> 1;
+            const long Mlow = (long)a.N * Hl * Wl, prows = a.phases > 1 ? 4 * Mlow : (long)rows;
+            for (int r = ty; r < rows; r += ty_n) {
+                long pr = r;
+                if (a.phases > 1) {          // output pixel (n, Y, X) <- row (n, Y>>1, X>>1) of phase 2 (Y&1) + (X&1)
+                    const int X = r % a.W, t = r / a.W, Y = t % a.H, n = t / a.H;
+                    pr = (long)((Y & 1) * 2 + (X & 1)) * Mlow + ((long)n * Hl + (Y >> 1)) * Wl + (X >> 1);
+                }
+                float4 v = bv;
+                for (int sp = 0; sp < a.splits; ++sp)
+                    v = f4_add(v, *reinterpret_cast<const float4*>(a.ws + ((long)sp * prows + pr) * a.ldw + q * 4));
+                if (rem < 4) {               // columns beyond Cout hold the results of clamped weight rows
+                    if (rem < 2) v.y = 0.f;
+                    if (rem < 3) v.z = 0.f;
+                    v.w = 0.f;
+                    if (rem < 1) v.x = 0.f;
+                }
+                *reinterpret_cast<float4*>(a.y + (long)r * a.ld_y + q * 4) = v;
+                s1 = f4_add(s1, v);
+                s2 = f4_fma(v, v, s2);
+            }
+        } else {
+            for (int r = ty; r < rows; r += ty_n) {
+                const float4 v = *reinterpret_cast<const float4*>(a.y + (long)r * a.ld_y + q * 4);
+                s1 = f4_add(s1, v);
+                s2 = f4_fma(v, v, s2);
+            }
+        }
+    }
+    small_tree_sum2(red0, red1, s1, s2, tx_n, ty_n, tx, ty);       // also orders the y writes of the block before the reads below
+    const double count = (double)rows;
+    float mq[4], sq[4], iq[4];
+    const float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = q * 4 + e;
+        const double m = (double)t1[e] / count;
+        double v = (double)t2[e] / count - m * m;
+        if (v < 0.0) v = 0.0;
+        const float mf = (float)m, is = 1.0f / sqrtf((float)v + a.eps);
+        mq[e] = mf;
+        iq[e] = is;
+        sq[e] = (qok && c < a.C) ? a.gamma[c] * is : 0.f;
+        if (ty == 0 && qok && c < a.C) {
+            a.mean[c] = mf;
+            a.invstd[c] = is;
+            a.scale[c] = sq[e];
+            const float unbiased = (float)(v * count / (count - 1.0));
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mf;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
+        }
+    }
+    if (!qok) return;
+    const float4 be = ld4_guard(a.beta, q, a.C);
+    const float slope = a.relu ? 0.f : -1.f;
+    const float4 m = make_float4(mq[0], mq[1], mq[2], mq[3]), sc = make_float4(sq[0], sq[1], sq[2], sq[3]);
+    if (a.pool) {
+        const int Ho = a.H / 2, Wo = a.W / 2, orows = a.N * Ho * Wo;
+        for (int p = ty; p < orows; p += ty_n) {
+            const int wo = p % Wo, t = p / Wo, ho = t % Ho, n = t / Ho;
+            const float* yb = a.y + (((long)n * a.H + 2 * ho) * a.W + 2 * wo) * a.ld_y + q * 4;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float4 v = *reinterpret_cast<const float4*>(yb + ((long)dy * a.W + dx) * a.ld_y);
+                    o.x += act_apply(fmaf(v.x - m.x, sc.x, be.x), slope);
+                    o.y += act_apply(fmaf(v.y - m.y, sc.y, be.y), slope);
+                    o.z += act_apply(fmaf(v.z - m.z, sc.z, be.z), slope);
+                    o.w += act_apply(fmaf(v.w - m.w, sc.w, be.w), slope);
+                }
+            *reinterpret_cast<float4*>(a.z + (long)p * a.ld_z + q * 4) = make_float4(o.x * 0.25f, o.y * 0.25f, o.z * 0.25f, o.w * 0.25f);
+        }
+    } else {
+        for (int r = ty; r < rows; r += ty_n) {
+            const float4 v = *reinterpret_cast<const float4*>(a.y + (long)r * a.ld_y + q * 4);
+            float4 o;
+            o.x = act_apply(fmaf(v.x - m.x, sc.x, be.x), slope);
+            o.y = act_apply(fmaf(v.y - m.y, sc.y, be.y), slope);
+            o.z = act_apply(fmaf(v.z - m.z, sc.z, be.z), slope);
+            o.w = act_apply(fmaf(v.w - m.w, sc.w, be.w), slope);
+            *reinterpret_cast<float4*>(a.z + (long)r * a.ld_z + q * 4) = o;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_small_bwd_kernel(BwdLoader L, double count, int rows, int nv, int tx_n,
+                                                           float* __restrict__ sums, float* __restrict__ dy, int ld_dy) {
+    __shared__ float4 red0[256], red1[256];
+    const int ty_n = 256 / tx_n;
+    const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+    const int q = blockIdx.x * tx_n + tx;
+    const bool qok = q < nv;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    BwdLoader::State st;
+    L.init(st);
+    if (qok)
+        for (int r = ty; r < rows; r += ty_n) {
+            float4 g, xh;
+            L.load(r, q, st, g, xh);
+            a = f4_add(a, g);
+            b = f4_fma(g, xh, b);
+        }
+    small_tree_sum2(red0, red1, a, b, tx_n, ty_n, tx, ty);
+    if (!qok) return;
+    const int C = L.C, rem = C - q * 4;
+    if (ty == 0) {                         // dbeta = sum g, dgamma = sum g * xhat
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < C) {
+                sums[q * 4 + e] = av[e];
+                sums[C + q * 4 + e] = bv[e];
+            }
+    }
+    const float inv = (float)(1.0 / count);
+    const float4 k1 = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv), k2 = make_float4(b.x * inv, b.y * inv, b.z * inv, b.w * inv);
+    const float4 sc = ld4_guard(L.scale, q, C);
+    for (int r = ty; r < rows; r += ty_n) {
+        float4 g, xh;
+        L.load(r, q, st, g, xh);
+        float4 o;
+        o.x = sc.x * (g.x - k1.x - xh.x * k2.x);
+        o.y = sc.y * (g.y - k1.y - xh.y * k2.y);
+        o.z = sc.z * (g.z - k1.z - xh.z * k2.z);
+        o.w = sc.w * (g.w - k1.w - xh.w * k2.w);
+        if (rem < 4) {  // keep pad channels of dy at zero
+            if (rem < 2) o.y = 0.f;
+            if (rem < 3) o.z = 0.f;
+            o.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(dy + (long)r * ld_dy + q * 4) = o;
+    }
+}
+
+static inline int small_txn(int nv) { return nv >= 128 ? 4 : (nv >= 64 ? 2 : 1); }
+
 static inline int grid_for(long total, int cap = 2048) {
     long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -652,5 +843,39 @@ int mnk_bn_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz, i
                          void* stream) {
     return mnk_norm_act_bwd_apply(y, ld_y, dz, ld_dz, dz_off, mean, invstd, scale, beta, 0, sums, count, training, dy,
                                   ld_dy, N, H, W, C, relu ? 0.f : -1.f, pool, stream);
+}
+
+// ---- small layers: one launch per direction (single-rank training-mode BatchNorm) ------------------------------------------
+int mnk_bn_small_rows(void) { return kSmallRows; }
+
+int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const float* bias, float* y, int ld_y, int N, int H, int W,
+                     int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, float* mean, float* invstd, float* scale, float* z, int ld_z, int relu, int pool, void* stream) {
+    MNK_REQUIRE(y && gamma && beta && running_mean && running_var && mean && invstd && scale && z && N > 0 && H > 0 && W > 0);
+    MNK_REQUIRE(C > 0 && ld_y % 4 == 0 && ld_y == round_up(C, 4) && ld_z == ld_y && (long)N * H * W <= kSmallRows && (long)N * H * W > 1);
+    MNK_REQUIRE(!ws || (splits >= 1 && ldw == ld_y && (phases == 1 || (phases == 4 && H % 2 == 0 && W % 2 == 0))));
+    MNK_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0));
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_APPLY, s, (double)N * H * W * C * 4 * 3.0);
+    SmallFwdArgs a{ws, splits, ldw, phases, bias, y, ld_y, N, H, W, C, gamma, beta, running_mean, running_var, momentum, eps,
+                   mean, invstd, scale, z, ld_z, relu, pool, small_txn(ld_y / 4)};
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(ld_y / 4, a.tx_n)), dim3(256), 0, s, a);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,
+                     const float* scale, const float* beta, double count, int N, int H, int W, int C, int relu, int pool,
+                     float* sums, float* dy, int ld_dy, void* stream) {
+    MNK_REQUIRE(y && dz && mean && invstd && scale && beta && sums && dy && N > 0 && H > 0 && W > 0 && C > 0 && count > 1);
+    MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && ld_dy % 4 == 0 && ld_dy >= round_up(C, 4) && ld_dz >= C);
+    MNK_REQUIRE((long)N * H * W <= kSmallRows && (!pool || (H % 2 == 0 && W % 2 == 0)));
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_BWD, s, (double)N * H * W * C * 4 * 5.0);
+    const int nv = round_up(C, 4) / 4, txn = small_txn(nv);
+    BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, 0, H, W, C, pool, 0, relu ? 0.f : -1.f};
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(ceil_div(nv, txn)), dim3(256), 0, s, L, count, N * H * W, nv, txn, sums, dy, ld_dy);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
 }
 }

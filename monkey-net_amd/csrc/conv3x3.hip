@@ -2305,8 +2305,11 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
                            int kw, int pad, int stride, int phases, const float* wp, const float* bias, const float* residual,
                            int ld_res, float* y, int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats,
                            float* stats_partial, void* stream) {
-    MNK_REQUIRE(flags >= 0 && flags <= 3);
+    MNK_REQUIRE(flags >= 0 && flags <= 7);
     const int ups = flags & MNK_CONV_UPSAMPLED, clean = (flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
+    // MNK_CONV_DEFER_SPLITK: a split-K launch leaves its partials in `ws` ([split][phase][M][ldw], bias not added) and the
+    // caller sums them (mnk_bn_small_fwd does, together with the normalisation that follows)
+    const bool defer_splitk = (flags & MNK_CONV_DEFER_SPLITK) != 0;
     MNK_REQUIRE(x0 && wp && y && N > 0 && Ho > 0 && Wo > 0 && Cout > 0 && C0 > 0 && C1 >= 0);
     MNK_REQUIRE(kh > 0 && kw > 0 && pad >= 0 && Hi > 0 && Wi > 0 && stride >= 1 && (phases == 1 || phases == 4));
     if (phases == 4)
@@ -2425,7 +2428,7 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
 #undef MNK_IGEMM
 #undef MNK_IGEMM_MODE
     }
-    if (p.splits > 1) {
+    if (p.splits > 1 && !defer_splitk) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
         hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * phases * ld_y * 4, 8192)), dim3(256), 0, s, ws,
                            p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W);
@@ -3062,11 +3065,21 @@ size_t mnk_conv3x3_up_stats_floats(int N, int H, int W, int C0, int C1, int Cout
     Plan p = make_plan((long)N * H * W, Cout, chunks, 4, 4);
     return p.splits > 1 ? 0 : (size_t)4 * p.gm * 2 * round_up(Cout, 4);
 }
-int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, const float* wp_up, const float* bias,
-                       float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats, float* stats_partial,
-                       void* stream) {
-    return conv2d_fwd_impl(x0, ld0, C0, x1, ld1, C1, MNK_CONV_CLEAN_PADS, H, W, 2, 2, 1, 1, 4, wp_up, bias, nullptr, 0, y, ld_y, N,
-                           H, W, Cout, ws, ws_floats, stats_partial, stream);
+int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp_up,
+                       const float* bias, float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats,
+                       float* stats_partial, void* stream) {
+    MNK_REQUIRE((flags & ~MNK_CONV_DEFER_SPLITK) == 0);
+    return conv2d_fwd_impl(x0, ld0, C0, x1, ld1, C1, MNK_CONV_CLEAN_PADS | flags, H, W, 2, 2, 1, 1, 4, wp_up, bias, nullptr, 0, y,
+                           ld_y, N, H, W, Cout, ws, ws_floats, stats_partial, stream);
+}
+// pixel-independent K splits of the launches above (1: no split): what a caller that sums the partials itself must know
+int mnk_conv3x3_splits(int N, int H, int W, int C0, int C1, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    return make_plan((long)N * H * W, Cout, (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16, 9, 1).splits;
+}
+int mnk_conv3x3_up_splits(int N, int H, int W, int C0, int C1, int Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    return make_plan((long)N * H * W, Cout, (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16, 4, 4).splits;
 }
 // data gradient w.r.t. one low-resolution source of an up-sampled convolution: dy (N, 2H, 2W, Cout) -> dx (N, H, W, C)
 size_t mnk_conv3x3_up_dgrad_workspace_floats(int N, int H, int W, int Cout, int C) {

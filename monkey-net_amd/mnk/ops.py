@@ -352,30 +352,52 @@ def repack_registered(only_if_stale=False):
     return True
 
 
+# a split-K convolution whose partials a small-layer BatchNorm will sum: y.data_ptr() -> (ws, splits, phases, bias)
+_SPLIT_PENDING = {}
+
+
+def small_bn(rows, training=True):
+    """the one-launch BatchNorm forms of small layers apply: single rank, training statistics, few pixel rows"""
+    return (training and knobs.on("MNK_BN_SMALL") and not mdist.active() and 1 < rows <= _query("mnk_bn_small_rows"))
+
+
 def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats=False, up=False):
     """One conv launch.  With want_stats the BatchNorm sums of the output come out of the conv epilogue (finished by a
     tiny second-stage kernel) instead of a separate pass over y; returns (y, sums or None).  up: `wp` holds the
     sub-pixel packs of an up-sampled convolution and (h, w) is the up-sampled size."""
     y = torch.empty(n, h, w, ceil4(cout), dtype=torch.float32, device=x0.device)
+    # a small layer whose BatchNorm follows at once (want_stats): that one-launch kernel makes its own statistics and,
+    # when this convolution is split along K, also sums the partials -- no separate reduction, no epilogue statistics
+    small = want_stats and residual is None and small_bn(n * h * w)
+    if _SPLIT_PENDING:
+        raise RuntimeError("a split-K convolution is still waiting for the BatchNorm that sums its partials")
     if up:
         assert ups and residual is None
         hl, wl = h // 2, w // 2
         nws = _query("mnk_conv3x3_up_workspace_floats", n, hl, wl, c0, c1, cout)
         ws = SCRATCH.get("ws", nws, x0) if nws else None
-        nst = _query("mnk_conv3x3_up_stats_floats", n, hl, wl, c0, c1, cout) if want_stats else 0
+        nst = _query("mnk_conv3x3_up_stats_floats", n, hl, wl, c0, c1, cout) if want_stats and not small else 0
         st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None
-        _call("mnk_conv3x3_up_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1, _p(wp),
-              _p(bias), _p(y), y.shape[-1], n, hl, wl, cout, _p(ws), nws, _p(st))
+        defer = 4 if small and nws else 0
+        _call("mnk_conv3x3_up_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1, defer,
+              _p(wp), _p(bias), _p(y), y.shape[-1], n, hl, wl, cout, _p(ws), nws, _p(st))
+        if defer:
+            _SPLIT_PENDING[y.data_ptr()] = (ws, _query("mnk_conv3x3_up_splits", n, hl, wl, c0, c1, cout), 4, bias)
     else:
         nws = _query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
         ws = SCRATCH.get("ws", nws, x0) if nws else None
-        nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats else 0
+        nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats and not small else 0
         st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None   # lives until the norm layer reads it
+        defer = 4 if small and nws else 0
         # flags: bit 0 = nearest x2 up-sampled view, bit 1 = MNK_CONV_CLEAN_PADS -- every act this module produces has zero
         # pad channels (tests/test_modules.py::test_pad_channels_are_written pins that), so the fast 3x3 loader applies
         _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
-              int(ups) | 2, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
+              int(ups) | 2 | defer, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
               y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
+        if defer:
+            _SPLIT_PENDING[y.data_ptr()] = (ws, _query("mnk_conv3x3_splits", n, h, w, c0, c1, cout), 1, bias)
+    if small:
+        return y, y.new_empty(0)
     sums = None
     if want_stats:
         if nst and not mdist.active():
@@ -529,6 +551,22 @@ class BNActFn(torch.autograd.Function):
         invstd = torch.empty_like(mean)
         scale = torch.empty_like(mean)
         count = float(rows)
+        pending = _SPLIT_PENDING.pop(y.data_ptr(), None)
+        ctx.small = False
+        if small_bn(rows, training) and ld == ceil4(c) and h % (2 if pool else 1) == 0 and w % (2 if pool else 1) == 0:
+            # the whole layer in one launch (csrc/batchnorm.hip: bn_small_fwd_kernel)
+            ho, wo = (h // 2, w // 2) if pool else (h, w)
+            z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
+            ws_, splits, phases, bias = pending if pending is not None else (None, 0, 1, None)
+            _call("mnk_bn_small_fwd", y, _p(ws_), splits, ld, phases, _p(bias), _p(y), ld, n, h, w, c, _p(gamma), _p(beta),
+                  _p(running_mean), _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(z),
+                  z.shape[-1], int(relu), int(pool))
+            ctx.save_for_backward(y, mean, invstd, scale, beta)
+            ctx.meta = (c, training, relu, pool, count)
+            ctx.small = True
+            return z
+        if pending is not None:
+            raise RuntimeError("split-K partials were deferred to a BatchNorm that does not take the small-layer path")
         if training:
             if rows * mdist.world_size() <= 1:
                 raise ValueError("BatchNorm needs more than one value per channel in training mode "
@@ -570,6 +608,13 @@ class BNActFn(torch.autograd.Function):
         dz = dz.contiguous()
         n, h, w, ld = y.shape
         rows = n * h * w
+        if ctx.small and knobs.on("MNK_BN_ZERO_BIAS_GRAD"):
+            sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
+            dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
+            _call("mnk_bn_small_bwd", y, _p(y), ld, _p(dz), dz.shape[-1], _p(mean), _p(invstd), _p(scale), _p(beta), count, n, h,
+                  w, c, int(relu), int(pool), _p(sums), _p(dy), ld)
+            _DY_SUMS[0] = (dy, None)
+            return dy, sums[c:], sums[:c], None, None, None, None, None, None, None, None, None
         nws = _query("mnk_bn_workspace_floats", rows, ceil4(c))
         ws = SCRATCH.get("ws", nws, y)
         sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)

@@ -207,3 +207,89 @@ def test_instance_norm_leaky_pool(be, shape, pool):
     # affine gradients = per-frame sums added over the frames
     assert relerr(bs.cpu()[:n * c].view(n, c).sum(0), bd.grad) < 1e-4
     assert relerr(bs.cpu()[n * c:].view(n, c).sum(0), gd.grad) < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 6, 4), (3, 45, 4, 6), (2, 300, 2, 2), (1, 64, 16, 16), (4, 520, 8, 8), (2, 1024, 2, 2)])
+@pytest.mark.parametrize("pool", [0, 1])
+def test_bn_small_layer_one_launch_forms(be, shape, pool):
+    """mnk_bn_small_fwd / _bwd (statistics + finalisation + apply, and the whole backward, in one launch each) against
+    F.batch_norm(training) + relu + avg_pool2d in fp64."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g) * 0.3
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    z = F.relu(F.batch_norm(xd, rm, rv, gd, bd, True, 0.1, 1e-5))
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    dz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(dz)
+    assert n * h * w <= be.query("mnk_bn_small_rows")
+    ld = ceil4(c)
+    X = be.t(to_nhwc(x))
+    mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+    RM, RV, G, Bt = be.t(rm0.clone()), be.t(rv0.clone()), be.t(gamma), be.t(beta)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    Z = be.empty(n, ho, wo, ld)
+    be.call("mnk_bn_small_fwd", None, 0, ld, 1, None, X, ld, n, h, w, c, G, Bt, RM, RV, 0.1, 1e-5, mean, invstd, scale, Z, ld, 1,
+            pool)
+    be.sync()
+    assert maxerr(from_nhwc(Z.cpu(), c), z) < 2e-5
+    assert torch.all(Z.cpu()[..., c:] == 0)
+    assert maxerr(RM.cpu(), rm) < 1e-5 and maxerr(RV.cpu(), rv) < 1e-4
+    DZ = be.t(to_nhwc(dz.float()))
+    bs, DY = be.empty(2 * c), be.empty(n, h, w, ld)
+    be.call("mnk_bn_small_bwd", X, ld, DZ, ld, mean, invstd, scale, Bt, float(n * h * w), n, h, w, c, 1, pool, bs, DY, ld)
+    be.sync()
+    assert relerr(bs.cpu()[:c], bd.grad) < 1e-4 and relerr(bs.cpu()[c:], gd.grad) < 1e-4
+    assert relerr(from_nhwc(DY.cpu(), c), xd.grad) < 1e-4
+    assert torch.all(DY.cpu()[..., c:] == 0)
+
+
+@pytest.mark.parametrize("up", [0, 1], ids=["3x3", "sub-pixel-up"])
+def test_bn_small_sums_the_split_k_partials_of_the_convolution_in_front(be, up):
+    """a split-K convolution (few output tiles) run with MNK_CONV_DEFER_SPLITK leaves [split][phase][M][ldw] partials; the
+    small-layer BatchNorm kernel sums them (+ bias) into y, for the plain 3x3 form and for the sub-pixel form of an
+    up-sampled convolution (phase-major partials scattered to (2i + a, 2j + b))."""
+    n, hl, wl, cin, cout = 3, 4, 4, 40, 136
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n, cin, hl, wl, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    h, w = (2 * hl, 2 * wl) if up else (hl, wl)
+    xin = F.interpolate(x.double(), scale_factor=2, mode="nearest") if up else x.double()
+    yref = F.conv2d(xin, wt.double(), b.double(), padding=1)
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    rm, rv = torch.zeros(cout).double(), torch.ones(cout).double()
+    zref = F.relu(F.batch_norm(yref, rm, rv, gamma.double(), beta.double(), True, 0.1, 1e-5))
+    X, W = be.t(to_nhwc(x)), be.t(wt)
+    ld = ceil4(cout)
+    Y = be.empty(n, h, w, ld)
+    if up:
+        wp = be.empty(be.query("mnk_conv3x3_up_packed_floats", cout, cin, 0))
+        be.call("mnk_conv3x3_up_pack_fwd", W, wp, cout, cin, 0)
+        nws = be.query("mnk_conv3x3_up_workspace_floats", n, hl, wl, cin, 0, cout)
+        splits = be.query("mnk_conv3x3_up_splits", n, hl, wl, cin, 0, cout)
+        ws = be.empty(nws)
+        be.call("mnk_conv3x3_up_fwd", X, X.shape[-1], cin, None, 0, 0, 4, wp, be.t(b), Y, ld, n, hl, wl, cout, ws, nws, None)
+    else:
+        wp = be.empty(be.query("mnk_conv3x3_packed_floats", cout, cin, 0))
+        be.call("mnk_conv3x3_pack_fwd", W, wp, cout, cin, 0)
+        nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, cin, 0, cout)
+        splits = be.query("mnk_conv3x3_splits", n, h, w, cin, 0, cout)
+        ws = be.empty(nws)
+        be.call("mnk_conv3x3_fwd", X, X.shape[-1], cin, None, 0, 0, 2 | 4, wp, be.t(b), None, 0, Y, ld, n, h, w, cout, ws, nws, None)
+    assert splits > 1 and nws > 0
+    mean, invstd, scale = be.empty(cout), be.empty(cout), be.empty(cout)
+    RM, RV = be.zeros(cout), be.t(torch.ones(cout))
+    Z = be.empty(n, h, w, ld)
+    be.call("mnk_bn_small_fwd", ws, splits, ld, 4 if up else 1, be.t(b), Y, ld, n, h, w, cout, be.t(gamma), be.t(beta), RM, RV,
+            0.1, 1e-5, mean, invstd, scale, Z, ld, 1, 0)
+    be.sync()
+    assert relerr(from_nhwc(Y.cpu(), cout), yref) < 2e-6
+    assert torch.all(Y.cpu()[..., cout:] == 0)
+    assert maxerr(from_nhwc(Z.cpu(), cout), zref) < 2e-5

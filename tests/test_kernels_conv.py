@@ -397,7 +397,7 @@ def test_conv3x3_upsampled_subpixel_forward_and_dgrad(be, case):
     ws = be.empty(max(nws, 1))
     nst = be.query("mnk_conv3x3_up_stats_floats", n, h, w, c0, c1, cout)
     st = be.empty(nst) if nst else None
-    be.call("mnk_conv3x3_up_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if c1 else 0, c1, wp, be.t(b) if bias else None, Y, ldy,
+    be.call("mnk_conv3x3_up_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if c1 else 0, c1, 0, wp, be.t(b) if bias else None, Y, ldy,
             n, h, w, cout, ws, nws, st)
     be.sync()
     assert relerr(from_nhwc(Y.cpu(), cout), ref) < 2e-6
