@@ -114,7 +114,7 @@ int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int l
                                 double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu,
                                 int pool, float* dy_sums, float* ws, size_t ws_floats, void* stream);
 
-/* ---- small layers (N*H*W <= mnk_bn_small_rows() pixel rows: the 2x2 ... 16x16 levels of the hourglasses): the whole
+/* ---- small layers (N*H*W <= mnk_bn_small_rows() pixel rows, 512 by default: the 2x2 / 4x4 levels of the hourglasses): the whole
  * training-mode BatchNorm (+ReLU, +2x2 pool) of one rank in ONE launch per direction instead of four -- a block owns a tile of
  * channels over all rows, so the column sums never leave it.  Forward: optionally sums the split-K partials `ws`
  * ([split][phase][M][ldw], what mnk_conv3x3_fwd / mnk_conv3x3_up_fwd leave behind under MNK_CONV_DEFER_SPLITK) + bias into y

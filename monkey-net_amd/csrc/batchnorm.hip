@@ -3,6 +3,8 @@
 // (modules/discriminator.py:19-22,29-30); fused with ReLU / LeakyReLU(slope) and the (1,2,2) average pool.
 // HBM-bound: float4 along channels, a 2-D thread map (channel-quad x row) so that every thread keeps its
 // channel quad in registers while it walks rows; column sums are finished in LDS and by a tiny second pass.
+#include <stdlib.h>
+
 #include "mnk_common.h"
 
 using namespace mnk;
@@ -437,8 +439,16 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
 //   forward : [sum of the convolution's split-K partials + bias -> y] -> sum / sum of squares -> mean, inv-std, scale,
 //             running statistics -> z = [pool] relu((y - mean) * scale + beta)
 //   backward: sum g, sum g*xhat (= dbeta, dgamma) -> dy = scale * (g - sum_g / n - xhat * sum_gx / n)
-// Single rank only (SyncBN has an all-reduce between the two halves).  rows <= kSmallRows.
-constexpr int kSmallRows = 2048;
+// Single rank only (SyncBN has an all-reduce between the two halves).  rows <= mnk_bn_small_rows().
+static int small_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+// defaults from the MI355X A/B (profiles/README.md): 512 rows with one channel quad per block is the only setting that beats
+// the general four-launch path (12.39 vs 12.42 ms per iteration); 2048 rows / 4 quads per block LOSES 0.3 ms -- a handful of
+// blocks walking 32+ rows each is slower than four well-filled launches
+static int g_small_rows = small_env("MNK_BN_SMALL_ROWS", 512);
+static int g_small_txn = small_env("MNK_BN_SMALL_TXN", 1);           // channel quads per block: 0 = by channel count
 
 __device__ __forceinline__ void small_tree_sum2(float4* red0, float4* red1, float4& a, float4& b, int tx_n, int ty_n, int tx,
                                                 int ty) {
@@ -617,7 +627,7 @@ __global__ void __launch_bounds__(256) bn_small_bwd_kernel(BwdLoader L, double c
     }
 }
 
-static inline int small_txn(int nv) { return nv >= 128 ? 4 : (nv >= 64 ? 2 : 1); }
+static inline int small_txn(int nv) { return g_small_txn ? g_small_txn : (nv >= 128 ? 4 : (nv >= 64 ? 2 : 1)); }
 
 static inline int grid_for(long total, int cap = 2048) {
     long b = (total + 255) / 256;
@@ -846,13 +856,13 @@ int mnk_bn_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz, i
 }
 
 // ---- small layers: one launch per direction (single-rank training-mode BatchNorm) ------------------------------------------
-int mnk_bn_small_rows(void) { return kSmallRows; }
+int mnk_bn_small_rows(void) { return g_small_rows; }
 
 int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const float* bias, float* y, int ld_y, int N, int H, int W,
                      int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, float* mean, float* invstd, float* scale, float* z, int ld_z, int relu, int pool, void* stream) {
     MNK_REQUIRE(y && gamma && beta && running_mean && running_var && mean && invstd && scale && z && N > 0 && H > 0 && W > 0);
-    MNK_REQUIRE(C > 0 && ld_y % 4 == 0 && ld_y == round_up(C, 4) && ld_z == ld_y && (long)N * H * W <= kSmallRows && (long)N * H * W > 1);
+    MNK_REQUIRE(C > 0 && ld_y % 4 == 0 && ld_y == round_up(C, 4) && ld_z == ld_y && (long)N * H * W <= 4096 && (long)N * H * W > 1);
     MNK_REQUIRE(!ws || (splits >= 1 && ldw == ld_y && (phases == 1 || (phases == 4 && H % 2 == 0 && W % 2 == 0))));
     MNK_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0));
     hipStream_t s = (hipStream_t)stream;
@@ -869,7 +879,7 @@ int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const
                      float* sums, float* dy, int ld_dy, void* stream) {
     MNK_REQUIRE(y && dz && mean && invstd && scale && beta && sums && dy && N > 0 && H > 0 && W > 0 && C > 0 && count > 1);
     MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && ld_dy % 4 == 0 && ld_dy >= round_up(C, 4) && ld_dz >= C);
-    MNK_REQUIRE((long)N * H * W <= kSmallRows && (!pool || (H % 2 == 0 && W % 2 == 0)));
+    MNK_REQUIRE((long)N * H * W <= 4096 && (!pool || (H % 2 == 0 && W % 2 == 0)));
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_BWD, s, (double)N * H * W * C * 4 * 5.0);
     const int nv = round_up(C, 4) / 4, txn = small_txn(nv);

@@ -23,8 +23,8 @@ KNOBS = {
                              "stride-2 convolution for the data gradient; 0: 3x3 over the up-sampled view + sum-pool)"),
     "MNK_BN_ZERO_BIAS_GRAD": ("1", "the bias of a convolution in front of a training-mode BatchNorm gets no gradient (it is "
                                    "analytically zero; 0: compute the rounding noise the reference computes)"),
-    "MNK_BN_SMALL": ("1", "small layers (<= 2048 pixel rows): split-K sum + BatchNorm statistics + finalisation + apply in one "
-                          "launch, and the backward in one launch (0: the general multi-launch forms)"),
+    "MNK_BN_SMALL": ("1", "small layers (<= 512 pixel rows): split-K sum + BatchNorm statistics + finalisation + apply in one "
+                          "launch, and the backward in one launch (0: the general multi-launch forms; measured 12.39 vs 12.42 ms)"),
     "MNK_PACK_MULTI": ("1", "re-pack every conv weight of the model in one launch per iteration (0: one launch per layer)"),
     "MNK_DIST_GRAPH": ("1", "with a process group: capture the iteration incl. its RCCL collectives as a hipGraph"),
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),
