@@ -284,6 +284,12 @@ int mnk_wgrad_reduce_blocks(int splits, int Cout, int C);
 /* launch-plan switches (MNK_UP_SUBPIXEL, MNK_WGROUP_CHUNK, MNK_WTAP_TARGET, MNK_WN16_TARGET, MNK_SPLIT_TARGET, MNK_SPLIT_TILES,
  * MNK_BM64_TILES, MNK_XCD_REMAP) are read from the environment when the library is loaded; this changes one afterwards */
 int mnk_set_tuning(const char* name, int value);
+/* the forward / data-gradient GEMM's launch plan is a rule (tile by channel count, 64-row tiles and split-K for few-tile
+ * layers) overridden, for the benchmark configurations' layer shapes, by plans measured on the MI355X (csrc/plan_table.h;
+ * MNK_PLAN_TABLE=0 ignores it).  MNK_FORCE_BM / MNK_FORCE_BN / MNK_FORCE_SPLITS (mnk_set_tuning, 0 = off) force a plan for the
+ * sweep that makes the table (tools/plan_tune.py); mnk_last_plan reports the plan of the last such launch or size query:
+ * {M, Cout, chunks, taps, phases, bm, bn, splits}. */
+int mnk_last_plan(long* out8);
 int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int total_blocks, void* stream);
 
 /* ---- grouped weight gradients (new): the tap-major GEMMs of MANY layers in one launch per tile shape.  Launched one by

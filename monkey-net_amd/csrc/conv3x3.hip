@@ -1952,10 +1952,29 @@ static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = 
 // mid-size layers (fewer than ~2 blocks per CU with 128-row tiles) use 64-row tiles: twice the blocks, so every SIMD
 // has a second wave to overlap loads with MFMA, and less (or no) split-K
 static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
+static int g_split64_tiles = env_int("MNK_SPLIT64_TILES", 384), g_split64_target = env_int("MNK_SPLIT64_TARGET", 1024);
+static double g_bn128_work = (double)env_int("MNK_BN128_KWORK", 8388) * 1000.0;   // pixels x channels from which 128-wide tiles are used
 static int g_xcd_remap = env_int("MNK_XCD_REMAP", 1);
 static int g_fast_loader = env_int("MNK_FAST_LOADER", 1);
 static int g_kxk_fast = env_int("MNK_KXK_FAST", 1);     // buffer-load loader for K x K / any pad (MODE 3)
 static int g_mfma16 = env_int("MNK_MFMA16", 1);
+
+struct PlanRow {
+    long M;
+    int Cout, chunks, ntaps, phases, bm, bn, splits;
+};
+static const PlanRow g_tuned_rows[] = {
+#include "plan_table.h"
+    {0, 0, 0, 0, 0, 0, 0, 0}};
+static int g_plan_table = env_int("MNK_PLAN_TABLE", 1), g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+static long g_last_plan[8];
+
+// block tiles the GEMM kernels are instantiated for (conv2d_fwd_impl's dispatch)
+static bool plan_tile_ok(int bm, int bn, int Cout, int phases) {
+    if (bn == 16 || bn == 48) return bm == 128 && phases == 1 && g_mfma16 && Cout <= bn;
+    if (bn == 32) return bm == 128;
+    return (bn == 64 || bn == 128) && (bm == 64 || bm == 128);
+}
 
 static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 1) {
     // phases > 1 (sub-pixel form): M = pixels of ONE phase, p.gm = tiles of one phase; the launch has phases * gm M tiles
@@ -1965,22 +1984,63 @@ static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 
         if (Cout <= 16) p.bn = 16;
         else if (Cout > 32 && Cout <= 48) p.bn = 48;
     }
+    // measured on the MI355X over both benchmark configurations' layer shapes (tools/plan_tune.py, profiles/r02_plan_tune_*.txt):
+    // the 64x64 tile (56 registers, 20 KB of LDS: 8 blocks per CU) is the fastest instantiation for every layer wider than
+    // 48 channels -- by 5..40 % where 128-wide tiles left CUs idle or forced a split-K the 64x64 plan does not need -- except
+    // large layers whose width is a multiple of 128 (>= 65536 pixels x 128 channels: level with the 128x128 tile)
+    // (MNK_BN128_KWORK < 0: the previous rule -- 128-wide tiles for every layer wider than 64 channels -- for A/B runs)
+    const bool small_tiles = g_bn128_work >= 0.0;
+    if (small_tiles && p.bn == 128 && (Cout % 128 != 0 || (double)M * phases * Cout < g_bn128_work)) p.bn = 64;
     p.gn = ceil_div(Cout, p.bn);
     p.bm = 128;
-    if (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn * phases < g_bm64_tiles) p.bm = 64;
+    if ((small_tiles && p.bn == 64) || (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn * phases < g_bm64_tiles)) p.bm = 64;
     p.gm = ceil_div(M, p.bm);
     p.ksteps = ntaps * chunks;
     long tiles = (long)p.gm * p.gn * phases;
     int splits = 1;
-    if (tiles < g_split_tiles) {
+    if (small_tiles && p.bn == 64 && p.bm == 64) {
+        // 64x64 tiles (same sweep): a CU holds eight of these blocks, and the fastest plans put ~1024 blocks on the 256 CUs
+        // with >= 16 K steps each; layers that already have a block per CU only gain once a split is >= 32 steps deep (the
+        // partials cross HBM twice and, in front of a BatchNorm, a split plan's epilogue cannot produce the statistics)
+        if (tiles < g_split64_tiles) {
+            splits = (int)((g_split64_target + tiles / 2) / tiles);
+            if (splits > p.ksteps / 16) splits = p.ksteps / 16;
+            if (splits < 1) splits = 1;
+            if (tiles >= 192 && p.ksteps / splits < 32) splits = 1;
+        }
+    } else if (tiles < g_split_tiles) {
         splits = (int)((g_split_target + tiles - 1) / tiles);
         int max_splits = p.ksteps / g_split_minsteps;      // keep >= 6 K steps (96 deep) per split
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
+    // measured plans: the benchmark configurations' layer shapes were swept on the MI355X (tools/plan_tune.py -> plan_table.h);
+    // a forced plan (mnk_set_tuning MNK_FORCE_BM / _BN / _SPLITS) is what that sweep drives.  Anything the kernels have no
+    // instantiation for keeps the rule's choice.
+    int want_bm = 0, want_bn = 0, want_splits = 0;
+    if (g_plan_table)
+        for (const PlanRow* r = g_tuned_rows; r->M; ++r)
+            if (r->M == M && r->Cout == Cout && r->chunks == chunks && r->ntaps == ntaps && r->phases == phases) {
+                want_bm = r->bm, want_bn = r->bn, want_splits = r->splits;
+                break;
+            }
+    if (g_force_bm) want_bm = g_force_bm;
+    if (g_force_bn) want_bn = g_force_bn;
+    if (g_force_splits) want_splits = g_force_splits;
+    if (want_bm || want_bn) {
+        const int bm = want_bm ? want_bm : p.bm, bn = want_bn ? want_bn : p.bn;
+        if (plan_tile_ok(bm, bn, Cout, phases)) {
+            p.bm = bm, p.bn = bn;
+            p.gn = ceil_div(Cout, p.bn);
+            p.gm = ceil_div(M, p.bm);
+        }
+    }
+    if (want_splits > 0) splits = want_splits > p.ksteps ? p.ksteps : want_splits;
     p.ksteps_per_split = (p.ksteps + splits - 1) / splits;
     p.splits = (p.ksteps + p.ksteps_per_split - 1) / p.ksteps_per_split;
     p.ldw = round_up(Cout, 4);
+    g_last_plan[0] = M, g_last_plan[1] = Cout, g_last_plan[2] = chunks, g_last_plan[3] = ntaps, g_last_plan[4] = phases;
+    g_last_plan[5] = p.bm, g_last_plan[6] = p.bn, g_last_plan[7] = p.splits;
     return p;
 }
 
@@ -2997,7 +3057,9 @@ int mnk_set_tuning(const char* name, int value) {
     struct { const char* n; int* v; } knobs[] = {{"MNK_UP_SUBPIXEL", &g_up_subpixel}, {"MNK_WGROUP_CHUNK", &g_wgroup_chunk},
                                                   {"MNK_WTAP_TARGET", &g_wtap_target}, {"MNK_WN16_TARGET", &g_wn16_target},
                                                   {"MNK_SPLIT_TARGET", &g_split_target}, {"MNK_SPLIT_TILES", &g_split_tiles},
-                                                  {"MNK_BM64_TILES", &g_bm64_tiles}, {"MNK_XCD_REMAP", &g_xcd_remap}};
+                                                  {"MNK_BM64_TILES", &g_bm64_tiles}, {"MNK_XCD_REMAP", &g_xcd_remap},
+                                                  {"MNK_PLAN_TABLE", &g_plan_table}, {"MNK_FORCE_BM", &g_force_bm},
+                                                  {"MNK_FORCE_BN", &g_force_bn}, {"MNK_FORCE_SPLITS", &g_force_splits}};
     for (auto& k : knobs)
         if (strcmp(k.n, name) == 0) {
             *k.v = value;
@@ -3005,6 +3067,13 @@ int mnk_set_tuning(const char* name, int value) {
         }
     set_error("mnk_set_tuning: unknown switch %s", name);
     return MNK_EINVAL;
+}
+
+// the last forward / data-gradient launch plan that was made: {M, Cout, chunks, taps, phases, bm, bn, splits}
+int mnk_last_plan(long* out8) {
+    MNK_REQUIRE(out8);
+    for (int i = 0; i < 8; ++i) out8[i] = g_last_plan[i];
+    return MNK_OK;
 }
 
 int mnk_wgrad_reduce_blocks(int splits, int Cout, int C) {

@@ -255,7 +255,7 @@ def test_bn_small_sums_the_split_k_partials_of_the_convolution_in_front(be, up):
     """a split-K convolution (few output tiles) run with MNK_CONV_DEFER_SPLITK leaves [split][phase][M][ldw] partials; the
     small-layer BatchNorm kernel sums them (+ bias) into y, for the plain 3x3 form and for the sub-pixel form of an
     up-sampled convolution (phase-major partials scattered to (2i + a, 2j + b))."""
-    n, hl, wl, cin, cout = 3, 4, 4, 40, 136
+    n, hl, wl, cin, cout = 3, 4, 4, 136, 72       # >= 32 K steps in both forms: split along K
     g = torch.Generator().manual_seed(8)
     x = torch.randn(n, cin, hl, wl, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.2

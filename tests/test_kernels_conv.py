@@ -420,3 +420,40 @@ def test_conv3x3_upsampled_subpixel_forward_and_dgrad(be, case):
         be.sync()
         assert relerr(from_nhwc(DX.cpu(), c_cnt), x.grad[:, c_start:c_start + c_cnt]) < 2e-6
         assert torch.all(DX.cpu()[..., c_cnt:] == 0)
+
+
+# ---- measured / forced launch plans (csrc/plan_table.h, tools/plan_tune.py) -------------------------------------------------
+def _last_plan(be):
+    import numpy as np
+    out = np.zeros(8, dtype=np.int64)
+    be.lib.call("mnk_last_plan", out.ctypes.data)
+    return tuple(int(v) for v in out)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 40, 0, 70, 0, True, False), (2, 8, 8, 16, 10, 40, 1, True, False),
+                                  (1, 8, 8, 20, 0, 12, 0, True, True)])
+def test_forced_launch_plans_compute_the_same_convolution(be, case):
+    """every (block tile, split-K) plan the sweep may force -- and so every row csrc/plan_table.h may hold -- is the same
+    convolution; a plan the kernels have no instantiation for is refused and the rule's plan runs."""
+    x0, x1, wt, b, r = _inputs(case, seed=5)
+    ref = _ref_fwd(case, x0, x1, wt, b, r)
+    cout = case[5]
+    seen = set()
+    try:
+        for bm, bn, splits in [(0, 0, 0), (64, 128, 1), (128, 128, 2), (64, 64, 3), (128, 64, 1), (128, 32, 4), (128, 48, 1),
+                               (128, 16, 2), (64, 32, 1), (64, 16, 1), (0, 0, 7)]:
+            for name, v in (("MNK_FORCE_BM", bm), ("MNK_FORCE_BN", bn), ("MNK_FORCE_SPLITS", splits)):
+                be.lib.call("mnk_set_tuning", name.encode(), v)
+            Y = _run_fwd(be, case, x0, x1, wt, b, r, clean=True)
+            plan = _last_plan(be)
+            assert plan[1] == cout and plan[3] == 9 and plan[4] == 1
+            if bn in (16, 48) and cout > bn or (bm, bn) in ((64, 32), (64, 16)):
+                assert plan[5:7] != (bm, bn)                       # refused: no such kernel
+            elif bm:
+                assert plan[5:7] == (bm, bn), (plan, bm, bn)
+            seen.add(plan[5:])
+            assert relerr(from_nhwc(Y, cout), ref) < 2e-6, plan
+    finally:
+        for name in ("MNK_FORCE_BM", "MNK_FORCE_BN", "MNK_FORCE_SPLITS"):
+            be.lib.call("mnk_set_tuning", name.encode(), 0)
+    assert len(seen) >= 6
