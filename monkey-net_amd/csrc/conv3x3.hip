@@ -1846,6 +1846,41 @@ __host__ __device__ __forceinline__ void reduce_map(int splits, int* tw, int* ro
     *rows = splits < 4 ? 4 : 1;
 }
 
+// parameter-major partials part[s][co][ci * ntaps + tap]: this thread's elements src[0], src[TW], ... (those below `left`)
+// summed over the splits s0, s0 + sstep, ... into out[0], out[TW], ...; TW is a compile-time constant so that the eight
+// elements of a pass share one address register pair (immediate offsets)
+template <int TW>
+__device__ __forceinline__ void reduce_param_major(const float* __restrict__ src, long sstride, int splits, int s0, int sstep,
+                                                   int left, bool row_ok, float* __restrict__ out) {
+    const int nk = (left + TW - 1) / TW;                         // elements of this thread (<= 0: none)
+    for (int k0 = 0; k0 < nk; k0 += 8) {                         // eight elements x two splits in flight
+        float a0[8], a1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a0[k] = a1[k] = 0.f;
+        const float* sk = src + k0 * TW;
+        int sp = s0;
+        for (; sp + sstep < splits; sp += 2 * sstep) {
+            const float* ps = sk + (long)sp * sstride;
+            const float* pt = ps + (long)sstep * sstride;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < nk) {
+                    a0[k] += ps[k * TW];
+                    a1[k] += pt[k * TW];
+                }
+        }
+        if (sp < splits) {
+            const float* ps = sk + (long)sp * sstride;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < nk) a0[k] += ps[k * TW];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k0 + k < nk) out[(k0 + k) * TW] = row_ok ? a0[k] + a1[k] : 0.f;
+    }
+}
+
 __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradReduceDesc* __restrict__ descs, int n) {
     __shared__ float sm[16 * 16 * 16 + 64];        // [group][channel * ntaps + tap], group stride tw * 16
     __shared__ int sh_idx;
@@ -1905,17 +1940,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
     } else {
         // part[s][co][ci * ntaps + tap]
         const long NT = (long)d.C * ntaps, sstride = (long)d.Cout * NT;
-        const float* src = d.part + (long)(row_ok ? co : 0) * NT + (long)ci0 * ntaps;
-        for (int idx = c; idx < lim; idx += tw) {
-            float v0 = 0.f, v1 = 0.f;
-            int sp = s0;
-            for (; sp + sstep < d.splits; sp += 2 * sstep) {
-                v0 += src[(long)sp * sstride + idx];
-                v1 += src[(long)(sp + sstep) * sstride + idx];
-            }
-            if (sp < d.splits) v0 += src[(long)sp * sstride + idx];
-            smg[idx] = row_ok ? v0 + v1 : 0.f;
-        }
+        // a thread owns the elements c, c + tw, ... of the tile's lim = cw * ntaps contiguous floats (at most ntaps of them)
+        // and walks the splits with eight of them in flight (one at a time meant two loads in flight and ntaps passes over
+        // the splits: the 512-split 45 -> 45 layers' blocks were the tail of the launch)
+        const float* src = d.part + (long)(row_ok ? co : 0) * NT + (long)ci0 * ntaps + c;
+        if (tw == 16)
+            reduce_param_major<16>(src, sstride, d.splits, s0, sstep, lim - c, row_ok, smg + c);
+        else
+            reduce_param_major<64>(src, sstride, d.splits, s0, sstep, lim - c, row_ok, smg + c);
     }
     __syncthreads();
     if (rpb == 1) {
@@ -1952,7 +1984,8 @@ static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = 
 // mid-size layers (fewer than ~2 blocks per CU with 128-row tiles) use 64-row tiles: twice the blocks, so every SIMD
 // has a second wave to overlap loads with MFMA, and less (or no) split-K
 static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
-static int g_split64_tiles = env_int("MNK_SPLIT64_TILES", 384), g_split64_target = env_int("MNK_SPLIT64_TARGET", 1024);
+static int g_split64_tiles = env_int("MNK_SPLIT64_TILES", 384), g_split64_target = env_int("MNK_SPLIT64_TARGET", 1024),
+           g_split64_deep = env_int("MNK_SPLIT64_DEEP", 32), g_split64_minsteps = env_int("MNK_SPLIT64_MINSTEPS", 16);
 static double g_bn128_work = (double)env_int("MNK_BN128_KWORK", 8388) * 1000.0;   // pixels x channels from which 128-wide tiles are used
 static int g_xcd_remap = env_int("MNK_XCD_REMAP", 1);
 static int g_fast_loader = env_int("MNK_FAST_LOADER", 1);
@@ -2004,9 +2037,9 @@ static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 
         // partials cross HBM twice and, in front of a BatchNorm, a split plan's epilogue cannot produce the statistics)
         if (tiles < g_split64_tiles) {
             splits = (int)((g_split64_target + tiles / 2) / tiles);
-            if (splits > p.ksteps / 16) splits = p.ksteps / 16;
+            if (splits > p.ksteps / g_split64_minsteps) splits = p.ksteps / g_split64_minsteps;
             if (splits < 1) splits = 1;
-            if (tiles >= 192 && p.ksteps / splits < 32) splits = 1;
+            if (tiles >= 192 && p.ksteps / splits < g_split64_deep) splits = 1;
         }
     } else if (tiles < g_split_tiles) {
         splits = (int)((g_split_target + tiles - 1) / tiles);
@@ -2141,7 +2174,8 @@ struct TPlan {
     long pix_per_split;
 };
 static int g_wgrad_tap = env_int("MNK_WGRAD_TAP", 1), g_wtap_target = env_int("MNK_WTAP_TARGET", 768),
-           g_wtap_minsteps = env_int("MNK_WTAP_MINSTEPS", 8), g_wtap_minc = env_int("MNK_WTAP_MINC", 16);
+           g_wtap_minsteps = env_int("MNK_WTAP_MINSTEPS", 8), g_wtap_minc = env_int("MNK_WTAP_MINC", 16),
+           g_wtap_bm_max = env_int("MNK_WTAP_BM_MAX", 128);       // 64: no 128-row tiles (A/B runs)
 
 static TPlan make_tplan(long M, int Cout, int C, int ntaps, int ld_x) {
     TPlan p;
@@ -2152,6 +2186,7 @@ static TPlan make_tplan(long M, int Cout, int C, int ntaps, int ld_x) {
             ld_x % 4 == 0 && ld_x >= round_up(C, 4) && M < (1L << 31);
     if (!p.use) return p;
     p.bm = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
+    if (p.bm > g_wtap_bm_max) p.bm = g_wtap_bm_max;
     p.bn = (C > 64 || p.bm <= 64) ? 128 : 64;   // tiles in use: 128x128, 128x64, 64x128, 32x128
     p.gm = ceil_div(Cout, p.bm);
     p.gn = ceil_div(C, p.bn);
