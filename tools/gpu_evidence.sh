@@ -11,17 +11,6 @@ COMMIT="$(cat .gpurun_commit 2>/dev/null || echo unknown)"
 echo "== pytest -m gpu + smoke" | tee -a "$S"
 timeout 900 python -m pytest tests -q -m gpu > "$OUT/pytest_gpu.log" 2>&1; echo "rc=$?" | tee -a "$S"; tail -3 "$OUT/pytest_gpu.log" | cut -c1-200 | tee -a "$S"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-200 | tee -a "$S"
-echo "== bench (default: moving-gif, roofline + cpu_baseline + hot_path_only)" | tee -a "$S"
-timeout 900 python bench.py > "$OUT/bench_moving-gif_b32.json" 2> "$OUT/bench.err"; echo "rc=$?" | tee -a "$S"; cut -c1-900 "$OUT/bench_moving-gif_b32.json" | tee -a "$S"
-timeout 400 python bench.py --config taichi --no-cpu-baseline > "$OUT/bench_taichi_b32.json" 2> "$OUT/bench_taichi.err"; echo "taichi rc=$?" | tee -a "$S"; cut -c1-300 "$OUT/bench_taichi_b32.json" | tee -a "$S"
-echo "== rocprofv3 kernel stats (eager iteration)" | tee -a "$S"
-CMD="python $PWD/bench.py --steps 5 --warmup 2 --graph 0 --no-cpu-baseline --no-profile"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- $CMD > "$OLDPWD/$OUT/rocprof.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
-f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/moving-gif_b32_eager_kernel_stats.csv"
-t=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
-[ -n "$t" ] && python tools/trace_groups.py "$t" --csv "$OUT/moving-gif_b32_steady_kernel_stats.csv" > "$OUT/moving-gif_b32_steady_groups.txt" 2>&1
-head -45 "$OUT/moving-gif_b32_steady_groups.txt" | cut -c1-130 | tee -a "$S"
-find "$OUT" -name "*kernel_trace*" -size +4M -delete
 echo "== pmc FETCH_SIZE / WRITE_SIZE (separate passes)" | tee -a "$S"
 CMD2="python $PWD/bench.py --steps 2 --warmup 2 --graph 0 --no-cpu-baseline --no-profile"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OLDPWD/$OUT/pmc_fetch" -o f -- $CMD2 > "$OLDPWD/$OUT/pmc_fetch.log" 2>&1 ); echo "fetch rc=$?" | tee -a "$S"
@@ -35,6 +24,19 @@ except Exception as e:
     print("pmc stamp:", e)
 P
 find "$OUT" -name "*counter_collection*" -size +8M -delete; find "$OUT" -name "*kernel_trace*" -size +4M -delete
+# bench.py reads roofline.traffic from profiles/: the file of THIS build
+cp "$OUT/pmc_traffic_moving-gif_b32.json" "profiles/${R}_pmc_traffic_moving-gif_b32.json" 2>/dev/null
+echo "== bench (default: moving-gif, roofline + cpu_baseline + hot_path_only)" | tee -a "$S"
+timeout 900 python bench.py > "$OUT/bench_moving-gif_b32.json" 2> "$OUT/bench.err"; echo "rc=$?" | tee -a "$S"; cut -c1-900 "$OUT/bench_moving-gif_b32.json" | tee -a "$S"
+timeout 400 python bench.py --config taichi --no-cpu-baseline > "$OUT/bench_taichi_b32.json" 2> "$OUT/bench_taichi.err"; echo "taichi rc=$?" | tee -a "$S"; cut -c1-300 "$OUT/bench_taichi_b32.json" | tee -a "$S"
+echo "== rocprofv3 kernel stats (eager iteration)" | tee -a "$S"
+CMD="python $PWD/bench.py --steps 5 --warmup 2 --graph 0 --no-cpu-baseline --no-profile"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- $CMD > "$OLDPWD/$OUT/rocprof.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
+f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/moving-gif_b32_eager_kernel_stats.csv"
+t=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
+[ -n "$t" ] && python tools/trace_groups.py "$t" --csv "$OUT/moving-gif_b32_steady_kernel_stats.csv" > "$OUT/moving-gif_b32_steady_groups.txt" 2>&1
+head -45 "$OUT/moving-gif_b32_steady_groups.txt" | cut -c1-130 | tee -a "$S"
+find "$OUT" -name "*kernel_trace*" -size +4M -delete
 echo "== SQ pass over the per-layer conv bench (moving-gif): MFMA busy, clock" | tee -a "$S"
 CMD3="python $PWD/tools/conv_bench.py --config moving-gif --batch 32 --iters 3"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$OLDPWD/$OUT/sq" -o s -- $CMD3 > "$OLDPWD/$OUT/sq.log" 2>&1 ); echo "sq rc=$?" | tee -a "$S"
