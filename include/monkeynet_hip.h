@@ -376,7 +376,8 @@ int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy
 int mnk_conv1x1_sigmoid_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B,
                             int D, int H, int W, int Cout, void* stream);
 size_t mnk_conv1x1_workspace_floats(long rows, int Cin, int Cout);
-/* general form: act = 1 sigmoid, 0 linear (the discriminator's score head nn.Conv3d(C, 1, 1), discriminator.py:59,77) */
+/* general form: act = 1 sigmoid, 0 linear (the discriminator's score head nn.Conv3d(C, 1, 1), discriminator.py:59,77).
+ * mnk_conv1x1_bwd: dw == NULL (with dbias, ws ignored) computes the data gradient only, dx == NULL the parameter gradients only */
 int mnk_conv1x1_fwd(const float* x, int ld_x, int Cin, const float* w, const float* bias, float* out, int B, int D, int H,
                     int W, int Cout, int act, void* stream);
 int mnk_conv1x1_bwd(const float* x, int ld_x, int Cin, const float* w, const float* out, const float* dout, float* dx,

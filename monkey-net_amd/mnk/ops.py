@@ -877,11 +877,14 @@ class Conv1x1SigmoidFn(torch.autograd.Function):
         dout = dout.contiguous()
         n, h, w, ld = x.shape
         cout = weight.shape[0]
-        dx = torch.empty_like(x)
-        dw = torch.empty_like(weight)
-        db = torch.empty(cout, dtype=torch.float32, device=x.device)
-        nws = _query("mnk_conv1x1_workspace_floats", n * h * w, cin, cout)
-        ws = SCRATCH.get("ws", nws, x)
+        need_w = ctx.needs_input_grad[1] and not _SKIP_PARAM_GRADS[0]     # (no_param_grads: input gradients only)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if need_w else None
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if need_w else None
+        if dx is None and dw is None:
+            return None, None, None, None, None, None
+        nws = _query("mnk_conv1x1_workspace_floats", n * h * w, cin, cout) if need_w else 0
+        ws = SCRATCH.get("ws", nws, x) if need_w else None
         _call("mnk_conv1x1_bwd", x, _p(x), ld, cin, _p(weight), _p(out), _p(dout), _p(dx), ld, _p(dw), _p(db), b, d,
               h, w, cout, act, _p(ws), nws)
         return dx, dw, db if has_bias else None, None, None, None

@@ -39,10 +39,14 @@ def test_gconv1x1(be, G, S):
     assert relerr(DB.cpu(), bd.grad) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout,D", [(45, 3, 1), (13, 1, 2), (70, 4, 1)])
-def test_conv1x1_sigmoid(be, cin, cout, D):
+@pytest.mark.parametrize("cin,cout,D,hw", [(45, 3, 1, (6, 5)), (13, 1, 2, (6, 5)), (70, 4, 1, (6, 5)), (45, 3, 1, (20, 23)),
+                                            (8, 2, 1, (362, 363)), (200, 1, 1, (1, 3)), (35, 2, 1, (6, 5))])
+def test_conv1x1_sigmoid(be, cin, cout, D, hw):
+    """the row-tile forms (one partial tile, several tiles, and -- 262 812 pixel rows -- blocks that walk more than one
+    tile: the 2048-block cap of the weight-gradient partials), the few-rows x many-channels forms (rows wider than 64
+    floats: a wavefront per pixel row); the thread-per-pixel kernels remain for tensors that are not 16-byte aligned."""
     g = torch.Generator().manual_seed(1)
-    B, H, W = 2, 6, 5
+    B, (H, W) = 2, hw
     x = torch.randn(B * D, cin, H, W, generator=g)
     wt = torch.randn(cout, cin, generator=g) * 0.3
     b = torch.randn(cout, generator=g)
@@ -64,6 +68,14 @@ def test_conv1x1_sigmoid(be, cin, cout, D):
     assert maxerr(OUT.cpu(), ref) < 1e-6
     assert relerr(from_nhwc(DX.cpu(), cin), xd.grad) < 1e-5 and torch.all(DX.cpu()[..., cin:] == 0)
     assert relerr(DW.cpu(), wd.grad) < 1e-5 and relerr(DB.cpu(), bd.grad) < 1e-5
+    # data gradient only / parameter gradients only (NULL dw / NULL dx)
+    DX2, DW2, DB2 = be.empty(B * D, H, W, ld), be.empty(cout, cin), be.empty(cout)
+    be.call("mnk_conv1x1_sigmoid_bwd", X, ld, cin, be.t(wt), OUT, be.t(dout.float()), DX2, ld, None, None, B, D, H, W, cout,
+            None, 0)
+    be.call("mnk_conv1x1_sigmoid_bwd", X, ld, cin, be.t(wt), OUT, be.t(dout.float()), None, ld, DW2, DB2, B, D, H, W, cout,
+            ws, nws)
+    be.sync()
+    assert torch.equal(DX2.cpu(), DX.cpu()) and relerr(DW2.cpu(), wd.grad) < 1e-5 and relerr(DB2.cpu(), bd.grad) < 1e-5
 
 
 @pytest.mark.parametrize("use_mask,use_corr", [(1, 1), (1, 0), (0, 1)])
