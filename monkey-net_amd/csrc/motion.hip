@@ -497,37 +497,53 @@ __global__ void __launch_bounds__(256) motion_field_fwd_kernel(const float* __re
 }
 
 // one block per frame: writes dpred for its pixels and reduces ddelta[n][k][2] = sum_p m_k(p) * dfield(p)
-__global__ void __launch_bounds__(256) motion_field_bwd_kernel(const float* __restrict__ pred, int ld,
-                                                               const float* __restrict__ delta,
-                                                               const float* __restrict__ dfield, int h, int w, int K,
-                                                               int use_mask, int use_corr, float* __restrict__ dpred,
-                                                               int ld_d, float* __restrict__ ddelta) {
-    __shared__ float red[4 * 2 * MAXS];
+// one block per frame (the mask's delta gradient is a per-frame sum): 1024 threads, because a batch is only 32 blocks and a
+// pixel costs S exponentials (256 threads, three exponentials per slot: 40 us)
+constexpr int MF_THREADS = 1024;
+__global__ void __launch_bounds__(MF_THREADS) motion_field_bwd_kernel(const float* __restrict__ pred, int ld,
+                                                                      const float* __restrict__ delta,
+                                                                      const float* __restrict__ dfield, int h, int w, int K,
+                                                                      int use_mask, int use_corr, float* __restrict__ dpred,
+                                                                      int ld_d, float* __restrict__ ddelta) {
+    __shared__ float red[(MF_THREADS / 64) * 2 * MAXS];
     const int n = blockIdx.x;
     const int P = h * w, S = K + 1;
     float dd[2 * MAXS];
 #pragma unroll
     for (int k = 0; k < 2 * MAXS; ++k) dd[k] = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) {
+    for (int p = threadIdx.x; p < P; p += MF_THREADS) {
         const long i = (long)n * P + p;
         const float* pr = pred + i * ld;
         float* dp = dpred + i * ld_d;
         const float gx = dfield[i * 2], gy = dfield[i * 2 + 1];
         int o = 0;
         if (use_mask) {
+            float e[MAXS];
             float mx = -INFINITY;
-            for (int k = 0; k < S; ++k) mx = fmaxf(mx, pr[k]);
-            float den = 0.f;
-            for (int k = 0; k < S; ++k) den += expf(pr[k] - mx);
-            float dot = 0.f;
-            for (int k = 0; k < S; ++k) {
-                const float m = expf(pr[k] - mx) / den;
-                dot += m * (delta[((long)n * S + k) * 2] * gx + delta[((long)n * S + k) * 2 + 1] * gy);
-            }
 #pragma unroll
             for (int k = 0; k < MAXS; ++k)
                 if (k < S) {
-                    const float m = expf(pr[k] - mx) / den;
+                    e[k] = pr[k];
+                    mx = fmaxf(mx, e[k]);
+                }
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k)
+                if (k < S) {
+                    e[k] = expf(e[k] - mx);
+                    den += e[k];
+                }
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k)
+                if (k < S) {
+                    const float m = e[k] / den;
+                    dot += m * (delta[((long)n * S + k) * 2] * gx + delta[((long)n * S + k) * 2 + 1] * gy);
+                }
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k)
+                if (k < S) {
+                    const float m = e[k] / den;
                     const float dm = delta[((long)n * S + k) * 2] * gx + delta[((long)n * S + k) * 2 + 1] * gy;
                     dp[k] = m * (dm - dot);
                     dd[2 * k] += m * gx;
@@ -553,7 +569,9 @@ __global__ void __launch_bounds__(256) motion_field_bwd_kernel(const float* __re
         __syncthreads();
         if (threadIdx.x < 2 * S) {
             const int k = threadIdx.x;
-            ddelta[(long)n * S * 2 + k] = red[k] + red[2 * MAXS + k] + red[4 * MAXS + k] + red[6 * MAXS + k];
+            float s = 0.f;
+            for (int wv = 0; wv < MF_THREADS / 64; ++wv) s += red[wv * 2 * MAXS + k];
+            ddelta[(long)n * S * 2 + k] = s;
         }
     } else if (threadIdx.x < 2 * S) {
         ddelta[(long)n * S * 2 + threadIdx.x] = 0.f;
@@ -937,7 +955,7 @@ int mnk_motion_field_bwd(const float* pred, int ld, const float* delta, const fl
     MNK_REQUIRE(ld >= (K + 1) * (use_mask ? 1 : 0) + 2 * (use_correction ? 1 : 0) && ld_d >= ld - 3);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_FIELD, s, (double)N * h * w * (ld + ld_d + 2) * 4);
-    hipLaunchKernelGGL(motion_field_bwd_kernel, dim3(N), dim3(256), 0, s, pred, ld, delta, dfield, h, w, K, use_mask,
+    hipLaunchKernelGGL(motion_field_bwd_kernel, dim3(N), dim3(MF_THREADS), 0, s, pred, ld, delta, dfield, h, w, K, use_mask,
                        use_correction, dpred, ld_d, ddelta);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
