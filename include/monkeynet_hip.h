@@ -465,6 +465,18 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
 int mnk_pair_l1_fwd(const float* a, int ld, long rows, int C, int B, float weight, float* out, void* stream);
 int mnk_pair_l1_bwd(const float* a, int ld, long rows, int C, int B, float weight, const float* g, float* da,
                     void* stream);
+/* image-level term of the same loss (losses.py:8-12 on NCDHW frames: train.py:39-42 reconstruction_deformed, map 0 of
+ * 'reconstruction'): out[i] = weight * mean_j |a[i][j] - b[i][j]| over n contiguous floats per sample; backward:
+ * da = g[i] * weight / n * sign(a - b), db = -da (either may be NULL) */
+int mnk_l1_mean_fwd(const float* a, const float* b, long n, int B, float weight, float* out, void* stream);
+int mnk_l1_mean_bwd(const float* a, const float* b, long n, int B, float weight, const float* g, float* da, float* db,
+                    void* stream);
+/* LSGAN terms (losses.py:15-21) from the score maps of the batched discriminator pass, score[2B][n] = [generated | real]:
+ * gen[i] = w_gen * mean_j (1 - sf)^2, disc[i] = w_disc * mean_j ((1 - sr)^2 + sf^2); backward from the upstream gradients
+ * of the two vectors (either may be NULL) */
+int mnk_gan_terms_fwd(const float* score, int n, int B, float w_gen, float w_disc, float* gen, float* disc, void* stream);
+int mnk_gan_terms_bwd(const float* score, int n, int B, float w_gen, float w_disc, const float* ggen, const float* gdisc,
+                      float* dscore, void* stream);
 
 #ifdef __cplusplus
 }

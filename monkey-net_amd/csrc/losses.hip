@@ -67,6 +67,72 @@ __global__ void __launch_bounds__(256) pair_l1_bwd_kernel(const float* __restric
     }
 }
 
+// ---- image-level L1 term and the LSGAN terms (modules/losses.py:8-21; train.py:36-53,66-75) ------------------------
+// out[i] = scale * sum_j |a[i][j] - b[i][j]| over n contiguous floats per sample (scale = weight / n)
+__global__ void __launch_bounds__(L1_THREADS) l1_mean_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                 long n, float scale, float* __restrict__ out) {
+    __shared__ float red[L1_THREADS / 64];
+    const float* pa = a + (long)blockIdx.x * n;
+    const float* pb = b + (long)blockIdx.x * n;
+    float acc = 0.f;
+    for (long j = threadIdx.x; j < n; j += L1_THREADS) acc += fabsf(pa[j] - pb[j]);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < L1_THREADS / 64; ++w) tot += red[w];
+        out[blockIdx.x] = tot * scale;
+    }
+}
+
+// da[i][j] = g[i] * scale * sign(a - b), db = -da (either may be NULL)
+__global__ void __launch_bounds__(256) l1_mean_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                          long total, float scale, const float* __restrict__ g,
+                                                          float* __restrict__ da, float* __restrict__ db) {
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const float k = g[q / n] * scale * sgn(a[q] - b[q]);
+        if (da) da[q] = k;
+        if (db) db[q] = -k;
+    }
+}
+
+// score[2B][n]: rows [0, B) of the generated frames, [B, 2B) of the real ones (the batched discriminator pass)
+//   gen[i]  = wg * mean_j (1 - sf[i][j])^2                       (generator_gan_loss)
+//   disc[i] = wd * mean_j ((1 - sr[i][j])^2 + sf[i][j]^2)         (discriminator_gan_loss)
+__global__ void __launch_bounds__(64) gan_terms_fwd_kernel(const float* __restrict__ score, int n, int B, float wg, float wd,
+                                                           float* __restrict__ gen, float* __restrict__ disc) {
+    const int i = blockIdx.x;
+    const float* sf = score + (long)i * n;
+    const float* sr = score + (long)(B + i) * n;
+    float ag = 0.f, ad = 0.f;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const float f = sf[j], r = sr[j];
+        ag += (1.f - f) * (1.f - f);
+        ad += (1.f - r) * (1.f - r) + f * f;
+    }
+    ag = wave_sum(ag);
+    ad = wave_sum(ad);
+    if (threadIdx.x == 0) {
+        gen[i] = wg * (ag / (float)n);
+        disc[i] = wd * (ad / (float)n);
+    }
+}
+
+// dscore from the upstream gradients of both vectors (either may be NULL = zero)
+__global__ void __launch_bounds__(256) gan_terms_bwd_kernel(const float* __restrict__ score, int n, int B, float wg, float wd,
+                                                            const float* __restrict__ ggen, const float* __restrict__ gdisc,
+                                                            float* __restrict__ dscore) {
+    const long half = (long)B * n;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < 2 * half; q += (long)gridDim.x * 256) {
+        const bool real = q >= half;
+        const long i = (real ? q - half : q) / n;
+        const float v = score[q];
+        const float gg = ggen ? ggen[i] * wg / (float)n : 0.f, gd = gdisc ? gdisc[i] * wd / (float)n : 0.f;
+        dscore[q] = real ? gd * (-2.f) * (1.f - v) : gg * (-2.f) * (1.f - v) + gd * 2.f * v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -94,6 +160,50 @@ int mnk_pair_l1_bwd(const float* a, int ld, long rows, int C, int B, float weigh
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(pair_l1_bwd_kernel, dim3(blocks), dim3(256), 0, s, a, ld, rows, C, B,
                        weight / (float)((double)rows * C), g, da);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_l1_mean_fwd(const float* a, const float* b, long n, int B, float weight, float* out, void* stream) {
+    MNK_REQUIRE(a && b && out && n > 0 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LOSS, s, 2.0 * B * n * 4);
+    hipLaunchKernelGGL(l1_mean_fwd_kernel, dim3(B), dim3(L1_THREADS), 0, s, a, b, n, weight / (float)n, out);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_l1_mean_bwd(const float* a, const float* b, long n, int B, float weight, const float* g, float* da, float* db,
+                    void* stream) {
+    MNK_REQUIRE(a && b && g && (da || db) && n > 0 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LOSS, s, 4.0 * B * n * 4);
+    const long total = (long)B * n;
+    int blocks = ceil_div(total, 256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(l1_mean_bwd_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, s, a, b, n, total, weight / (float)n, g,
+                       da, db);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_gan_terms_fwd(const float* score, int n, int B, float w_gen, float w_disc, float* gen, float* disc, void* stream) {
+    MNK_REQUIRE(score && gen && disc && n > 0 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LOSS, s, 2.0 * B * n * 4);
+    hipLaunchKernelGGL(gan_terms_fwd_kernel, dim3(B), dim3(64), 0, s, score, n, B, w_gen, w_disc, gen, disc);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_gan_terms_bwd(const float* score, int n, int B, float w_gen, float w_disc, const float* ggen, const float* gdisc,
+                      float* dscore, void* stream) {
+    MNK_REQUIRE(score && dscore && (ggen || gdisc) && n > 0 && B > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LOSS, s, 4.0 * B * n * 4);
+    int blocks = ceil_div(2L * B * n, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(gan_terms_bwd_kernel, dim3(blocks), dim3(256), 0, s, score, n, B, w_gen, w_disc, ggen, gdisc, dscore);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

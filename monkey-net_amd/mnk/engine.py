@@ -12,9 +12,14 @@ from . import ops as mops
 
 def split_kp(kp_joined, detach=False):
     """Frame 0 of the joined key-points is the source, the rest is the driving video (train.py:14-21)."""
-    f = (lambda t: t.detach()) if detach else (lambda t: t)
-    return {'kp_driving': {k: f(v[:, 1:]) for k, v in kp_joined.items()},
-            'kp_source': {k: f(v[:, :1]) for k, v in kp_joined.items()}}
+    out = {'kp_driving': {}, 'kp_source': {}}
+    for k, v in kp_joined.items():
+        if detach:
+            v = v.detach()
+        # one split node instead of two slices: its backward is one concatenation (two slice nodes: two zero fills, two
+        # copies and the sum of the two padded gradients)
+        out['kp_source'][k], out['kp_driving'][k] = v.split([1, v.shape[1] - 1], dim=1)
+    return out
 
 
 def discriminate_pair(discriminator, fake, real, kp_dict):
@@ -35,26 +40,23 @@ def fused_pair_losses(discriminator, fake, real, kp_dict, video_deformed, loss_w
     feature-matching terms of the down-block outputs reduced on the device from the NHWC activations (ops.PairL1Fn)
     instead of from NCDHW copies of every feature map.  Needs a discriminator with forward_acts (the gfx950-kernel
     one).  Returns (generator loss vectors in generator_loss's order, discriminator loss vectors)."""
-    from modules.losses import reconstruction_loss
     b = fake.shape[0]
     kp2 = {name: {k: torch.cat([v, v], dim=0) for k, v in kp.items()} for name, kp in kp_dict.items()}
     acts, score = discriminator.forward_acts(torch.cat([fake, real], dim=0), **kp2)
-    score_fake, score_real = score[:b], score[b:]
     w = loss_weights
     g_values = []
     if w['reconstruction_deformed'] != 0:
-        g_values.append(reconstruction_loss(real, video_deformed, w['reconstruction_deformed']))
+        g_values.append(mops.L1MeanFn.apply(real, video_deformed, w['reconstruction_deformed']))
     if w['reconstruction'] != 0:
         rec = w['reconstruction']
         if rec[0] != 0:                               # map 0 is the frame itself
-            g_values.append(reconstruction_loss(fake, real, weight=rec[0]))
+            g_values.append(mops.L1MeanFn.apply(fake, real, rec[0]))
         for i, (act, c) in enumerate(acts, start=1):
             if i < len(rec) and rec[i] != 0:
                 g_values.append(mops.PairL1Fn.apply(act, c, b, float(rec[i])))
-    flat = lambda t: t.reshape(t.shape[0], -1).mean(-1)      # losses.mean_batch
-    g_values.append(w['generator_gan'] * flat((1 - score_fake) ** 2))
-    d_values = [w['discriminator_gan'] * flat((1 - score_real) ** 2 + score_fake ** 2)]
-    return g_values, d_values
+    gen_gan, disc_gan = mops.GanTermsFn.apply(score, b, w['generator_gan'], w['discriminator_gan'])
+    g_values.append(gen_gan)
+    return g_values, [disc_gan]
 
 
 class GeneratorFullModel(torch.nn.Module):
@@ -221,8 +223,12 @@ class TrainStep:
             g_vec, d_vec = fused_pair_losses(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False),
                                              generated['video_deformed'], tp['loss_weights'])
             generated.update(split_kp(kp_joined, False))
-            loss_values, d_values = [v.mean() for v in g_vec], [v.mean() for v in d_vec]
+            # batch means of all terms in one reduction (the reference: [val.mean() for val in losses], train.py:114)
+            g_means, d_means = torch.stack(g_vec).mean(1), torch.stack(d_vec).mean(1)
+            loss_values, d_values = list(g_means.unbind(0)), list(d_means.unbind(0))
+            g_total_fused, d_total_fused = g_means.sum(), d_means.sum()
         else:
+            g_total_fused = d_total_fused = None
             maps_generated, maps_real = discriminate_pair(self.discriminator, fake_leaf, x['video'],
                                                           split_kp(kp_leaf, False))
             generated.update(split_kp(kp_joined, False))
@@ -232,7 +238,7 @@ class TrainStep:
             d_values = [v.mean() for v in discriminator_loss(
                 discriminator_maps_generated=maps_generated, discriminator_maps_real=maps_real,
                 loss_weights=tp['loss_weights'])]
-        g_total = sum(loss_values)
+        g_total = g_total_fused if g_total_fused is not None else sum(loss_values)
         # 1. through the discriminator only
         leaves = [fake_leaf] + [kp_leaf[k] for k in kp_names]
         with mops.no_param_grads():
@@ -258,7 +264,7 @@ class TrainStep:
             self.opt_k.zero_grad()
         # 3. the discriminator loss through the retained discriminator graph
         self.avg_d.arm()
-        d_total = sum(d_values)
+        d_total = d_total_fused if d_total_fused is not None else sum(d_values)
         if tp['detach_kp_discriminator']:
             with mops.no_leaf_input_grads():     # nothing below the discriminator's first convolution is asked for
                 torch.autograd.backward(d_total, inputs=d_params)

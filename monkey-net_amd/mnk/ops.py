@@ -819,6 +819,65 @@ class PairL1Fn(torch.autograd.Function):
         return da, None, None, None
 
 
+class L1MeanFn(torch.autograd.Function):
+    """weight * mean_batch(|prediction - target|) (modules/losses.py:8-12) of two equally shaped contiguous tensors
+    (the frames themselves: reconstruction_deformed, map 0 of 'reconstruction') -> tensor (B,).  One launch each way
+    instead of sub / abs / mean / mul and their four backward nodes."""
+
+    @staticmethod
+    def forward(ctx, prediction, target, weight):
+        _check_device(prediction)
+        assert prediction.shape == target.shape
+        prediction, target = prediction.contiguous(), target.contiguous()
+        b = prediction.shape[0]
+        out = torch.empty(b, dtype=torch.float32, device=prediction.device)
+        _call("mnk_l1_mean_fwd", prediction, _p(prediction), _p(target), prediction.numel() // b, b, float(weight), _p(out))
+        ctx.save_for_backward(prediction, target)
+        ctx.weight = float(weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is None and db is None:
+            return None, None, None
+        n = a.shape[0]
+        _call("mnk_l1_mean_bwd", a, _p(a), _p(b), a.numel() // n, n, ctx.weight, _p(g.contiguous()), _p(da), _p(db))
+        return da, db, None
+
+
+class GanTermsFn(torch.autograd.Function):
+    """(generator_gan_loss, discriminator_gan_loss) of modules/losses.py:15-21 from the score maps of the batched
+    discriminator pass [generated | real] (2B samples) -> two tensors (B,).  One launch each way; the score tensor is
+    not sliced (a slice's backward is a zero fill and a copy)."""
+
+    @staticmethod
+    def forward(ctx, score, b, w_gen, w_disc):
+        _check_device(score)
+        score = score.contiguous()
+        assert score.shape[0] == 2 * b
+        gen = torch.empty(b, dtype=torch.float32, device=score.device)
+        disc = torch.empty(b, dtype=torch.float32, device=score.device)
+        _call("mnk_gan_terms_fwd", score, _p(score), score.numel() // (2 * b), b, float(w_gen), float(w_disc), _p(gen), _p(disc))
+        ctx.save_for_backward(score)
+        ctx.meta = (b, float(w_gen), float(w_disc))
+        ctx.set_materialize_grads(False)
+        return gen, disc
+
+    @staticmethod
+    def backward(ctx, ggen, gdisc):
+        score, = ctx.saved_tensors
+        b, w_gen, w_disc = ctx.meta
+        if ggen is None and gdisc is None:
+            return None, None, None, None
+        ds = torch.empty_like(score)
+        _call("mnk_gan_terms_bwd", score, _p(score), score.numel() // (2 * b), b, w_gen, w_disc,
+              _p(ggen.contiguous()) if ggen is not None else None, _p(gdisc.contiguous()) if gdisc is not None else None, _p(ds))
+        return ds, None, None, None
+
+
 class GConv1x1Fn(torch.autograd.Function):
     """nn.Conv3d(kernel (1,1,1), groups=num_kp+1) of SameBlock3D (dense_motion_module.py:24-28)."""
 

@@ -48,3 +48,61 @@ def test_pair_l1_autograd_function(be):
     (ref * gout.double()).sum().backward()
     assert relerr(out.detach().cpu(), ref.detach()) < 2e-6
     assert maxerr(from_nhwc(act.grad.cpu(), c), x64.grad) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 1, 9, 7), (2, 3, 1, 64, 64), (4, 1, 1, 1, 5)])
+def test_l1_mean_and_its_autograd_function(be, shape):
+    """mnk_l1_mean_fwd / _bwd == weight * mean_batch(|prediction - target|) of modules/losses.py:8-12 on NCDHW frames."""
+    from mnk import ops
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    b.view(-1)[:3] = a.view(-1)[:3]                         # exact ties: gradient 0
+    n = shape[0]
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = 7.0 * (a64 - b64).abs().reshape(n, -1).mean(-1)
+    gout = torch.randn(n, generator=g)
+    (ref * gout.double()).sum().backward()
+    A, B = be.t(a).requires_grad_(True), be.t(b).requires_grad_(True)
+    out = ops.L1MeanFn.apply(A, B, 7)
+    (out * be.t(gout)).sum().backward()
+    be.sync()
+    assert relerr(out.detach().cpu(), ref.detach()) < 2e-6
+    assert maxerr(A.grad.cpu(), a64.grad) < 1e-6 * (1 + float(a64.grad.abs().max()))
+    assert maxerr(B.grad.cpu(), b64.grad) < 1e-6 * (1 + float(b64.grad.abs().max()))
+    assert float(A.grad.cpu().view(-1)[0]) == 0.0
+    # only one side asks for a gradient (reconstruction_deformed: the real frames are data)
+    A2, B2 = be.t(a), be.t(b).requires_grad_(True)
+    (ops.L1MeanFn.apply(A2, B2, 7) * be.t(gout)).sum().backward()
+    be.sync()
+    assert torch.equal(B2.grad.cpu(), B.grad.cpu())
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 1, 1, 1), (2, 1, 1, 5, 4)])
+def test_gan_terms_match_the_loss_module(be, shape):
+    """GanTermsFn == (generator_gan_loss, discriminator_gan_loss) of modules/losses.py on the batched score maps, for the
+    three ways the step differentiates them: the generator term alone, the discriminator term alone, both."""
+    from mnk import ops
+    from modules import losses
+    b = shape[0]
+    g = torch.Generator().manual_seed(6)
+    score = torch.randn((2 * b,) + tuple(shape[1:]), generator=g)
+    s64 = score.double().requires_grad_(True)
+    ref_g = losses.generator_gan_loss([s64[:b]], 1.5)
+    ref_d = losses.discriminator_gan_loss([s64[:b]], [s64[b:]], 0.75)
+    gg, gd = torch.randn(b, generator=g), torch.randn(b, generator=g)
+    S = be.t(score).requires_grad_(True)
+    gen, disc = ops.GanTermsFn.apply(S, b, 1.5, 0.75)
+    be.sync()
+    assert relerr(gen.detach().cpu(), ref_g.detach()) < 2e-6 and relerr(disc.detach().cpu(), ref_d.detach()) < 2e-6
+    for use_g, use_d in ((True, False), (False, True), (True, True)):
+        S.grad, s64.grad = None, None
+        tot = (gen * be.t(gg)).sum() * float(use_g) + (disc * be.t(gd)).sum() * float(use_d)
+        ref = (ref_g * gg.double()).sum() * float(use_g) + (ref_d * gd.double()).sum() * float(use_d)
+        if use_g and not use_d:
+            tot, ref = (gen * be.t(gg)).sum(), (ref_g * gg.double()).sum()
+        if use_d and not use_g:
+            tot, ref = (disc * be.t(gd)).sum(), (ref_d * gd.double()).sum()
+        tot.backward(retain_graph=True)
+        ref.backward(retain_graph=True)
+        be.sync()
+        assert maxerr(S.grad.cpu(), s64.grad) < 1e-6 * (1 + float(s64.grad.abs().max()))
