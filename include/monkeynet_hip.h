@@ -63,6 +63,10 @@ int mnk_resize_nearest(const float* src, int ld_src, int Hs, int Ws, float* dst,
                        int Wd, int N, int C, void* stream);
 int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
                            int Hs, int Ws, int N, int C, void* stream);
+/* the same, added to dsrc (several resized copies of one tensor: generator.py:72 resizes the key-point embedding once per
+ * skip) */
+int mnk_resize_nearest_bwd_accumulate(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                                      int Hs, int Ws, int N, int C, void* stream);
 /* the same with bilinear, align_corners=False weights (interpolation_mode='trilinear' with unchanged depth, vox configs);
  * the adjoint ACCUMULATES into dsrc (zero it first) */
 int mnk_resize_bilinear(const float* src, int ld_src, int Hs, int Ws, float* dst, int ld_dst, int dst_off, int Hd,

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) resize_nearest_kernel(const float* __rest
 __global__ void __launch_bounds__(256) resize_nearest_bwd_kernel(const float* __restrict__ ddst, int ld_dst,
                                                                  int dst_off, int Hd, int Wd,
                                                                  float* __restrict__ dsrc, int ld_src, int Hs, int Ws,
-                                                                 int N, int C) {
+                                                                 int N, int C, int accumulate) {
     const long total = (long)N * Hs * Ws * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int c = (int)(i % C);
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) resize_nearest_bwd_kernel(const float* __
                 acc += ddst[(((long)n * Hd + h) * Wd + w) * ld_dst + dst_off + c];
             }
         }
-        dsrc[p * ld_src + c] = acc;
+        dsrc[p * ld_src + c] = accumulate ? dsrc[p * ld_src + c] + acc : acc;
     }
 }
 
@@ -269,17 +269,27 @@ int mnk_resize_nearest(const float* src, int ld_src, int Hs, int Ws, float* dst,
     return MNK_OK;
 }
 
-int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
-                           int Hs, int Ws, int N, int C, void* stream) {
+static int resize_nearest_bwd_impl(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                                   int Hs, int Ws, int N, int C, int accumulate, void* stream) {
     MNK_REQUIRE(ddst && dsrc && N > 0 && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && ld_src >= C &&
                 dst_off >= 0 && dst_off + C <= ld_dst);
     hipStream_t s = (hipStream_t)stream;
     long total = (long)N * Hs * Ws * C;
     ProfScope prof(K_LAYOUT, s, (double)total * 8);
     hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, ddst, ld_dst, dst_off, Hd, Wd,
-                       dsrc, ld_src, Hs, Ws, N, C);
+                       dsrc, ld_src, Hs, Ws, N, C, accumulate);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                           int Hs, int Ws, int N, int C, void* stream) {
+    return resize_nearest_bwd_impl(ddst, ld_dst, dst_off, Hd, Wd, dsrc, ld_src, Hs, Ws, N, C, 0, stream);
+}
+
+int mnk_resize_nearest_bwd_accumulate(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
+                                      int Hs, int Ws, int N, int C, void* stream) {
+    return resize_nearest_bwd_impl(ddst, ld_dst, dst_off, Hd, Wd, dsrc, ld_src, Hs, Ws, N, C, 1, stream);
 }
 
 int mnk_resize_bilinear(const float* src, int ld_src, int Hs, int Ws, float* dst, int ld_dst, int dst_off, int Hd,

@@ -119,10 +119,12 @@ class Concat2Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, ca, b, cb):
         n, h, w, _ = a.shape
-        out = torch.zeros(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)
+        # ca a multiple of 4: copying b with its (zero) pad channels writes every column of the output -- no zero fill
+        whole = ca % 4 == 0 and b.shape[-1] == ceil4(cb)
+        out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)
         rows = n * h * w
         _call("mnk_copy_channels", a, _p(a), a.shape[-1], 0, _p(out), out.shape[-1], 0, ca, rows, 0)
-        _call("mnk_copy_channels", a, _p(b), b.shape[-1], 0, _p(out), out.shape[-1], ca, cb, rows, 0)
+        _call("mnk_copy_channels", a, _p(b), b.shape[-1], 0, _p(out), out.shape[-1], ca, ceil4(cb) if whole else cb, rows, 0)
         ctx.meta = (ca, cb, a.shape[-1], b.shape[-1])
         return out
 
@@ -132,10 +134,13 @@ class Concat2Fn(torch.autograd.Function):
         g = g.contiguous()
         n, h, w, ld = g.shape
         rows = n * h * w
-        ga = torch.zeros(n, h, w, lda, dtype=torch.float32, device=g.device)
-        gb = torch.zeros(n, h, w, ldb, dtype=torch.float32, device=g.device)
+        # (the incoming gradient is an act of this library: its pad channels are zero)
+        whole = ca % 4 == 0 and lda == ca and ldb == ceil4(cb) and ld == ca + ldb
+        alloc = torch.empty if whole else torch.zeros
+        ga = alloc(n, h, w, lda, dtype=torch.float32, device=g.device)
+        gb = alloc(n, h, w, ldb, dtype=torch.float32, device=g.device)
         _call("mnk_copy_channels", g, _p(g), ld, 0, _p(ga), lda, 0, ca, rows, 0)
-        _call("mnk_copy_channels", g, _p(g), ld, ca, _p(gb), ldb, 0, cb, rows, 0)
+        _call("mnk_copy_channels", g, _p(g), ld, ca, _p(gb), ldb, 0, ldb if whole else cb, rows, 0)
         return ga, None, gb, None
 
 
@@ -1103,11 +1108,14 @@ class WarpSkipFn(torch.autograd.Function):
         _check_device(inp)
         n, h, w, ld_in = inp.shape
         _, hf, wf, _ = field.shape
-        out = torch.zeros(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
+        # c a multiple of 4: the warp writes whole channel quads and the resized embedding, copied with its (zero) pad
+        # channels, the rest of every pixel row -- no zero fill of the output
+        whole = c % 4 == 0 and (emb is None or emb.shape[-1] == ceil4(ke))
+        out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
         _call("mnk_deform_fwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(out), out.shape[-1], 0, n)
         if emb is not None:
             _call("mnk_resize_nearest" if mode == 0 else "mnk_resize_bilinear", inp, _p(emb), emb.shape[-1], emb.shape[1], emb.shape[2], _p(out), out.shape[-1], c,
-                  h, w, n, ke)
+                  h, w, n, ceil4(ke) if whole else ke)
         ctx.save_for_backward(inp, field, emb)
         ctx.meta = (c, ke, mode)
         return out
@@ -1126,10 +1134,74 @@ class WarpSkipFn(torch.autograd.Function):
                   _p(dinp), _p(dfield), n)
         demb = None
         if emb is not None and ctx.needs_input_grad[2]:
-            demb = torch.zeros_like(emb)
+            # nearest: the adjoint is a gather that writes every source pixel; with c a multiple of 4 it also reads the
+            # (zero) pad channels of dout and so writes demb's pads itself
+            whole = mode == 0 and c % 4 == 0 and emb.shape[-1] == ceil4(ke) and dout.shape[-1] == c + emb.shape[-1]
+            demb = torch.empty_like(emb) if whole else torch.zeros_like(emb)
             _call("mnk_resize_nearest_bwd" if mode == 0 else "mnk_resize_bilinear_bwd", inp, _p(dout), dout.shape[-1], c, h, w, _p(demb), emb.shape[-1], emb.shape[1],
-                  emb.shape[2], n, ke)
+                  emb.shape[2], n, emb.shape[-1] if whole else ke)
         return dinp, dfield, demb, None, None, None
+
+
+class WarpAllFn(torch.autograd.Function):
+    """Every deform_input of one generator forward (generator.py:66-73 the skips, :78 the source frame) as ONE autograd node.
+    They all read the same deformation field, so as separate nodes each backward zero-fills its own field gradient and
+    autograd adds the eight of them up; here the warp backward kernels accumulate into one zeroed buffer (they add
+    atomically anyway).  forward(field, emb, mode, specs, *inps) with specs = ((c, ke), ...) per input; returns one
+    [warp(inp) | resize(emb)] act per input (ke = 0: no embedding behind it)."""
+
+    @staticmethod
+    def forward(ctx, field, emb, mode, specs, *inps):
+        _check_device(field)
+        _, hf, wf, _ = field.shape
+        outs = []
+        for inp, (c, ke) in zip(inps, specs):
+            n, h, w, ld_in = inp.shape
+            e = emb if ke else None
+            whole = c % 4 == 0 and (e is None or e.shape[-1] == ceil4(ke))      # see WarpSkipFn.forward
+            out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
+            _call("mnk_deform_fwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(out), out.shape[-1], 0, n)
+            if e is not None:
+                _call("mnk_resize_nearest" if mode == 0 else "mnk_resize_bilinear", inp, _p(e), e.shape[-1], e.shape[1],
+                      e.shape[2], _p(out), out.shape[-1], c, h, w, n, ceil4(ke) if whole else ke)
+            outs.append(out)
+        ctx.save_for_backward(field, emb, *inps)
+        ctx.meta = (mode, tuple(specs))
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        field, emb = ctx.saved_tensors[:2]
+        inps = ctx.saved_tensors[2:]
+        mode, specs = ctx.meta
+        _, hf, wf, _ = field.shape
+        dfield = torch.zeros_like(field) if ctx.needs_input_grad[0] and any(d is not None for d in douts) else None
+        demb = None
+        dinps = []
+        for i, (inp, (c, ke), dout) in enumerate(zip(inps, specs, douts)):
+            if dout is None:
+                dinps.append(None)
+                continue
+            dout = dout.contiguous()
+            n, h, w, ld_in = inp.shape
+            dinp = torch.zeros_like(inp) if ctx.needs_input_grad[4 + i] else None
+            if dinp is not None or dfield is not None:
+                _call("mnk_deform_bwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(dout), dout.shape[-1], 0,
+                      _p(dinp), _p(dfield), n)
+            dinps.append(dinp)
+            if ke and emb is not None and ctx.needs_input_grad[1]:
+                # the first contribution writes demb (nearest: a gather over the source pixels that, with c a multiple of 4,
+                # also copies the zero pad channels of dout), the others are added by the kernels
+                whole = mode == 0 and c % 4 == 0 and emb.shape[-1] == ceil4(ke) and dout.shape[-1] == c + emb.shape[-1]
+                first = demb is None
+                if first:
+                    demb = torch.empty_like(emb) if whole else torch.zeros_like(emb)
+                name = ("mnk_resize_nearest_bwd" if first else "mnk_resize_nearest_bwd_accumulate") if mode == 0 \
+                    else "mnk_resize_bilinear_bwd"                  # (bilinear: atomic adds into the zeroed buffer)
+                _call(name, inp, _p(dout), dout.shape[-1], c, h, w, _p(demb), emb.shape[-1], emb.shape[1], emb.shape[2], n,
+                      emb.shape[-1] if whole else ke)
+        return (dfield, demb, None, None) + tuple(dinps)
 
 
 # convenience wrappers ---------------------------------------------------------------------------------------------

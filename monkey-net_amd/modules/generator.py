@@ -73,8 +73,11 @@ class MotionTransferGenerator(nn.Module):
         emb, ke = None, 0
         if self.kp_embedding_module is not None:
             emb, ke = self.kp_embedding_module.forward_act(source_image, kp_driving, kp_source)
-        warped = [(ops.WarpSkipFn.apply(a, field, emb, c, ke, mode), c + ke) for a, c in skips]
-        deformed_img = ops.WarpSkipFn.apply(src_act, field, None, self.num_channels, 0, mode)
+        # all warps of this forward as one autograd node: one shared field-gradient buffer (ops.WarpAllFn)
+        specs = tuple((c, ke) for _, c in skips) + ((self.num_channels, 0),)
+        outs = ops.WarpAllFn.apply(field, emb, mode, specs, *([a for a, _ in skips] + [src_act]))
+        warped = [(o, c + ke) for o, (_, c) in zip(outs[:-1], skips)]
+        deformed_img = outs[-1]
         video_deformed = ops.from_act(deformed_img, self.num_channels, b)
         out, c = self.video_decoder.forward_act(warped)
         last, sums = None, None

@@ -144,6 +144,9 @@ def test_copy_channels_and_resize(be):
         sr = s.clone().requires_grad_(True)
         F.interpolate(sr, size=(hd, wd), mode="nearest").backward(dd)
         assert maxerr(DS.cpu()[..., :3].permute(0, 3, 1, 2), sr.grad) < 1e-6
+        be.call("mnk_resize_nearest_bwd_accumulate", DD, 8, 2, hd, wd, DS, 4, hs, ws, 2, 3)     # added to what is there
+        be.sync()
+        assert maxerr(DS.cpu()[..., :3].permute(0, 3, 1, 2), 2 * sr.grad) < 2e-6
 
 
 def test_resize_bilinear(be):
