@@ -1,22 +1,30 @@
 #!/usr/bin/env python
 """Benchmark of the Monkey-Net frame-generation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1 without RANK in the environment: re-executes itself under `python -m torch.distributed.run --nnodes=1
+     --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU over RCCL; the driver's own launch is left alone)
 
 A "step" is one full training iteration of train.py:110-136 on one synthetic batch: KPDetector (source + driving
 frame) -> generator -> discriminator on (generated, real) -> losses -> backward -> Adam (generator, kp detector),
 then the discriminator update (mnk.engine.TrainStep: same losses and gradients as train.py's two passes, with one
 discriminator forward serving both).  KPDetector / DenseMotionModule / generator and the discriminator run forward
-and backward on the hand-written gfx950 kernels (libmonkeynet_hip.so); the losses and Adam are stock PyTorch-ROCm
-ops.  Data: synthetic U[0,1) frame pairs (BASELINE.md section 2 protocol), random-init
-weights of the named configuration; inputs are resident in HBM before the timed region.
+and backward on the hand-written gfx950 kernels (libmonkeynet_hip.so), and so do the loss terms and the three Adam
+steps (mnk.optim.MnkAdam: one launch per optimiser that also emits the packed weights of the next forward); what
+is left on stock PyTorch-ROCm ops is autograd's own gradient accumulation and the batch means of the loss vectors
+(SURVEY.md section 8f).  With several ranks the SyncBN statistics and the flat gradient buffer are all-reduced by the
+library's own RCCL communicator inside the timed step.  Data: synthetic U[0,1) frame pairs (BASELINE.md section 2
+protocol), random-init weights of the named configuration; inputs are resident in HBM before the timed region.
 
 One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one generated driving frame = one
 (source, driving) pair), whole-job aggregate over all ranks (weak scaling: fixed per-GPU batch), plus
   roofline      -- the conv implicit-GEMM kernels (every forward + data-gradient launch): algorithmic FLOPs (2*MAC of
                    the true, un-padded convolution) / kernel duration from HIP events stamped with each launch's own
                    begin and end on the launch stream (hipExtLaunchKernelGGL) in two profiled eager iterations after
-                   the timed region, against the 157.3 TFLOP/s fp32-MFMA peak of MI355X_MICROARCH.md;
+                   the timed region, against the 157.3 TFLOP/s fp32-MFMA peak of MI355X_MICROARCH.md; `traffic` =
+                   HBM bytes per launch from the committed PMC passes of the same build (profiles/, `traffic_source`);
+  hot_path_only_ms -- SURVEY section 8a alone (KPDetector + generator forward and backward with every weight gradient
+                   materialised; no discriminator, losses or optimiser) as a hipGraph replay, next to the whole step;
   cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
                    host's cores on a bounded sample of the same workload (rank 0, N == 1 only).
 """
