@@ -152,7 +152,11 @@ class TrainStep:
 
     def step(self, x):
         """Eager iteration, or -- with use_graph -- a replay of the whole iteration captured once as a hipGraph
-        (several hundred small launches per iteration make the eager path launch/host bound)."""
+        (several hundred small launches per iteration make the eager path launch/host bound).  The first call captures:
+        it runs warm-up iterations to size buffers and create optimiser state, then puts parameters, buffers and
+        optimiser state back, so that every call -- the first one included -- applies exactly one update.  With
+        use_graph the returned losses and `generated` are static buffers that the next call overwrites: clone what
+        must survive."""
         if not self.use_graph:
             return self._eager_step(x)
         if self._graph is None:
@@ -177,6 +181,7 @@ class TrainStep:
         assert not mdist.active() or knobs.on("MNK_DIST_GRAPH"), \
             "graph capture with torch.distributed active was disabled (MNK_DIST_GRAPH=0)"
         self._static_x = {k: v.clone() for k, v in x.items()}
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -188,6 +193,37 @@ class TrainStep:
         with torch.cuda.graph(graph):
             self._static_out = self._eager_step(self._static_x, set_to_none=True)
         self._graph = graph
+        self._restore(snap)
+
+    def _snapshot(self):
+        """Everything the warm-up iterations of the capture change: parameters, buffers (BatchNorm running statistics),
+        optimiser state.  Restored IN PLACE (the captured graph holds these addresses)."""
+        mods = (self.generator, self.discriminator, self.kp_detector)
+        tensors = [t for m in mods for t in list(m.parameters()) + list(m.buffers())]
+        snap = {"tensors": [(t, t.detach().clone()) for t in tensors]}
+        opts = (self.opt_g, self.opt_d, self.opt_k)
+        if self.mnk_adam:
+            snap["opt"] = [(o.flat_m.clone(), o.flat_v.clone(), o.hyper.clone()) for o in opts]
+        else:
+            snap["opt"] = [{p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                            for p, st in o.state.items()} for o in opts]
+        return snap
+
+    def _restore(self, snap):
+        with torch.no_grad():
+            for t, c in snap["tensors"]:
+                t.copy_(c)
+            for o, saved in zip((self.opt_g, self.opt_d, self.opt_k), snap["opt"]):
+                if self.mnk_adam:
+                    o.flat_m.copy_(saved[0])
+                    o.flat_v.copy_(saved[1])
+                    o.hyper.copy_(saved[2])
+                    continue
+                for p, st in o.state.items():           # state created by the warm-up: back to its initial zeros
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(saved[p][k]) if p in saved else v.zero_()
+        self.weights_changed()                          # the packed copies belong to the warm-up's parameters
 
     def _eager_step(self, x, set_to_none=True):
         self._weights_touched = False

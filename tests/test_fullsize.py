@@ -94,10 +94,12 @@ def test_eval_generation_is_frame_independent_at_batch_32():
         assert float((full[k] - joined).abs().max()) < 2e-5, k
 
 
-def test_full_size_training_iterations_graph_replay_equals_eager():
+@pytest.mark.parametrize("mnk_adam", [True, False], ids=["mnk-adam", "torch-adam-capturable"])
+def test_full_size_training_iterations_graph_replay_equals_eager(mnk_adam):
     """Same initial weights and inputs: TrainStep(use_graph=True) runs three eager warm-up iterations, captures the
-    fourth and replays it -- so replay k must give the losses of eager iteration 3 + k (same kernels in the same order,
-    fused Adam included; the fp32 atomics of the warp backward are the only non-deterministic sums)."""
+    iteration, puts parameters / running statistics / optimiser state back and replays -- so replay k must give the
+    losses of eager iteration k: the first call applies exactly one update (same kernels in the same order, the
+    optimiser included; the fp32 atomics of the warp backward are the only non-deterministic sums)."""
     from mnk import engine, configs
     cfg = configs.get("moving-gif")
     src, drv = cases.synthetic_pair(32, 64, 64)
@@ -107,7 +109,7 @@ def test_full_size_training_iterations_graph_replay_equals_eager():
         gen, disc, kpd = _models()
         # the same (capturable, fused) Adam in both runs: Adam's first updates are sign-like, so two optimiser
         # implementations separate quickly (tests/test_step.py) -- here only the launch mechanism may differ
-        step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=True, use_graph=True)
+        step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=mnk_adam, use_graph=True)
         out = []
         for _ in range(n):
             g_l, d_l, _ = step.step(x) if use_graph else step._eager_step(x)
@@ -118,11 +120,11 @@ def test_full_size_training_iterations_graph_replay_equals_eager():
     def dev(p, q):
         return max(abs(u - v) / max(1.0, abs(v)) for u, v in zip(p, q))
 
-    eager, eager2 = run(False, 6), run(False, 6)     # two identical eager runs: the yard-stick.  The fp32 atomics of
-    graph = run(True, 3)                             # the warp backward + Adam's sign-like first updates make them
-    for k in range(3):                               # separate by ~1e-2 within three iterations (measured: 2.1e-2)
+    eager, eager2 = run(False, 5), run(False, 5)     # two identical eager runs: the yard-stick.  The fp32 atomics of
+    graph = run(True, 4)                             # the warp backward + Adam's sign-like first updates make them
+    for k in range(4):                               # separate by ~1e-2 within three iterations (measured: 2.1e-2)
         a = graph[k]
         assert all(v == v and abs(v) < 1e6 for v in a), ("non-finite loss in replay", k, a)
-        noise = dev(eager[3 + k], eager2[3 + k])
-        assert dev(a, eager[3 + k]) <= 4 * noise + 5e-3, (k, dev(a, eager[3 + k]), noise)
-        assert dev(a, eager[3 + k]) < dev(a, eager[2 + k]), "replay k must be iteration 3 + k, not an earlier one"
+        noise = dev(eager[k], eager2[k])
+        assert dev(a, eager[k]) <= 4 * noise + 5e-3, (k, dev(a, eager[k]), noise)
+        assert dev(a, eager[k]) < dev(a, eager[k + 1]), "replay k must be iteration k: the warm-up updates are undone"
