@@ -30,6 +30,8 @@ KNOBS = {
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),
     "MNK_RCCL_DIRECT": ("1", "nccl backend: SyncBN sums and flat gradient buffers are all-reduced by the library's own RCCL "
                              "communicator on the kernels' stream (0: through torch.distributed)"),
+    "MNK_TWO_STREAMS": ("0", "generator forward: the appearance encoder on a second stream next to the dense-motion network "
+                             "(its backward follows on that stream); experiment, measured no gain -> off"),
     "MNK_GRAD_OVERLAP": ("1", "launch a gradient bucket's all-reduce as soon as its last gradient is written"),
 }
 

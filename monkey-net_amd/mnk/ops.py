@@ -38,15 +38,15 @@ def _check_device(t):
 
 
 class _Scratch:
-    """Grow-only scratch buffers, one per (purpose, device).  All launches of this process go to one stream per
-    device, so reusing them between consecutive kernels is ordered by the stream."""
+    """Grow-only scratch buffers, one per (purpose, device, stream): reuse between consecutive kernels of a stream is
+    ordered by that stream, and a branch of work on a second stream gets buffers of its own."""
 
     def __init__(self):
         self.bufs = {}
 
     def get(self, key, nfloats, like):
         nfloats = max(int(nfloats), 1)
-        k = (key, like.device)
+        k = (key, like.device, _stream(like))
         buf = self.bufs.get(k)
         if buf is None or buf.numel() < nfloats:
             buf = torch.empty(int(nfloats * 1.25) + 1024, dtype=torch.float32, device=like.device)
