@@ -304,7 +304,10 @@ int mnk_wgrad_reduce_multi(const MnkWgradReduceDesc* descs_device, int n, int to
  * layer through mnk_conv2d_wgrad), `splits` and `part_floats` -> give every job its operands and a `part` buffer ->
  * mnk_wgrad_grouped_build serialises the launch tables into HOST memory (mnk_wgrad_grouped_table_bytes(n)); copy them
  * to the device -> mnk_wgrad_grouped_launch(device copy, host copy).  The partials are tap-major [split][tap][Cout][C]:
- * reduce them with mnk_wgrad_reduce_multi (layout 0, `splits` as planned). */
+ * reduce them with mnk_wgrad_reduce_multi (layout 0, `splits` as planned; layout 2 for variants with variant % 4 == 3: the
+ * sub-pixel form).  Variants >= 16: narrow 3x3 layers (C, Cout <= 64) on the nine-tap 16x16-MFMA kernel, grouped the same
+ * way (~128 blocks per layer instead of the 512 a layer needs alone: the eight 45 -> 45 convolutions of the refinement
+ * stack write 9 instead of 37 MB of partials each); their partials are tap-major too (layout 0). */
 typedef struct MnkWgradJob {
     const float* x;
     const float* dy;

@@ -1247,13 +1247,13 @@ struct WgradN16Args {
 };
 
 template <int NCT, int NCI>     // 16-wide co / ci tiles in use (1..3): narrower layers skip the padded tiles at compile time
-__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args a) {
+__device__ __forceinline__ void wgrad_n16_body(const WgradN16Args& a, int bxi, int byi, int split) {
     constexpr int LD = 48, HW2 = 10, HP = 100;
     constexpr int XP = (HP * 12 + 255) / 256;                       // x loader passes (5)
     __shared__ __attribute__((aligned(16))) float As[64][LD];       // dy tile [pixel][co]
     __shared__ __attribute__((aligned(16))) float Xs[HP][LD];       // x tile with halo [staged pixel][ci]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int co0 = blockIdx.x * 48, ci0 = blockIdx.y * 48, split = blockIdx.z;
+    const int co0 = bxi * 48, ci0 = byi * 48;
     const long tile_begin = (long)split * a.tiles_per_split;
     long tile_end = tile_begin + a.tiles_per_split;
     if (tile_end > a.total_tiles) tile_end = a.total_tiles;
@@ -1403,6 +1403,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args 
                 }
             }
     }
+}
+
+template <int NCT, int NCI>
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_kernel(WgradN16Args a) {
+    wgrad_n16_body<NCT, NCI>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // index of the last record whose block_begin (an int column with `stride_ints` between rows) is <= b
@@ -1721,6 +1726,28 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_grouped_kernel(const
     const int bx = local % gm, rest = local / gm;
     const int by = rest % gnt, split = rest / gnt;
     wgrad_tap_body<BM, BN, WM, WN, MODE>(a, bx, by, split);
+}
+
+// the nine-tap 16x16 kernel for MANY narrow layers in one launch (the eight 45 -> 45 convolutions of the refinement stack:
+// launched one by one each needs 512 pixel splits to fill the chip -- 37 MB of partials per layer; together 128 do)
+struct N16JobRec {      // same size and block_begin offset as TapJobRec (one table, one lookup)
+    WgradN16Args a;
+    char pad[sizeof(WgradTapArgs) - sizeof(WgradN16Args)];
+    int gm, gn, splits, block_begin;
+};
+static_assert(sizeof(N16JobRec) == sizeof(TapJobRec), "grouped job records share one table");
+
+template <int NCT, int NCI>
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_grouped_kernel(const N16JobRec* __restrict__ recs, int n) {
+    __shared__ int sh_idx;
+    const int b = blockIdx.x;
+    const int di = find_desc(&recs[0].block_begin, (int)(sizeof(N16JobRec) / sizeof(int)), n, b, &sh_idx);
+    const N16JobRec* __restrict__ rp = recs + __builtin_amdgcn_readfirstlane(di);
+    const WgradN16Args a = rp->a;
+    const int local = b - rp->block_begin;
+    const int gm = rp->gm, gn = rp->gn;
+    const int bx = local % gm, rest = local / gm;
+    wgrad_n16_body<NCT, NCI>(a, bx, rest % gn, rest / gn);
 }
 
 // dw[co][(c_start + ci) * ntaps + tap] = sum_s part[s][tap][co][ci]: one block per (64-channel ci tile, co row);
@@ -2147,7 +2174,12 @@ struct NPlan {
 static int g_wgrad_n16 = env_int("MNK_WGRAD_N16", 1), g_wn16_target = env_int("MNK_WN16_TARGET", 512),
            g_wn16_mintiles = env_int("MNK_WN16_MINTILES", 2), g_wn16_minc = env_int("MNK_WN16_MINC", 1);
 
-static NPlan make_nplan(int N, int H, int W, int Cout, int C, int ld_x) {
+// blocks per layer of a grouped nine-tap launch: layers with all 3 x 3 channel tiles in use come in numbers (the eight
+// 45 -> 45 convolutions of the refinement stack), the narrower ones are one or two per launch and need more blocks each
+static int g_wn16_group_target = env_int("MNK_WN16_GROUP_TARGET", 128), g_wn16_group_target_few = env_int("MNK_WN16_GROUP_FEW", 256);
+static int n16_group_target(int Cout, int C) { return (Cout > 32 && C > 32) ? g_wn16_group_target : g_wn16_group_target_few; }
+
+static NPlan make_nplan(int N, int H, int W, int Cout, int C, int ld_x, int target = 0) {
     NPlan p;
     p.use = g_wgrad_n16 && C <= 64 && Cout <= 64 && C >= g_wn16_minc && H % 8 == 0 && W % 8 == 0 && ld_x % 4 == 0 &&
             ld_x >= round_up(C, 4) && (long)N * H * W < (1L << 31);
@@ -2158,7 +2190,7 @@ static NPlan make_nplan(int N, int H, int W, int Cout, int C, int ld_x) {
     p.tiles_per_img = (H / 8) * p.tiles_w;
     p.total_tiles = (long)N * p.tiles_per_img;
     const long base = (long)p.gm * p.gn;
-    long splits = (g_wn16_target + base - 1) / base;
+    long splits = ((target > 0 ? target : g_wn16_target) + base - 1) / base;
     if (splits > p.total_tiles / g_wn16_mintiles) splits = p.total_tiles / g_wn16_mintiles;
     if (splits < 1) splits = 1;
     p.tiles_per_split = (p.total_tiles + splits - 1) / splits;
@@ -2310,7 +2342,7 @@ static int tap_mode(WgradTapArgs& g, int N, int H, int W, int Hi, int Wi, int kh
 
 struct GroupedHeader {
     int magic, n, nvariants, reserved;
-    int first[16], count[16], blocks[16];     // per variant: first record, records, blocks (records are sorted by variant)
+    int first[32], count[32], blocks[32];     // per variant: first record, records, blocks (records are sorted by variant)
 };
 
 }  // namespace
@@ -2969,7 +3001,20 @@ int mnk_wgrad_grouped_plan(MnkWgradJob* jobs, int n) {
         j.variant = -1;
         j.splits = 0;
         j.part_floats = 0;
-        if (!tp.use) continue;                 // not a tap-major shape: the caller launches it on its own
+        if (!tp.use) {
+            // narrow 3x3 layers: the nine-tap 16x16 kernel, grouped (variants 16 + 3 * (co tiles - 1) + (ci tiles - 1));
+            // anything else (LDS-halo, gather, K x K) is launched by the caller on its own
+            if (g_wn16_group_target > 0 && j.kh == 3 && j.kw == 3 && j.pad == 1) {
+                NPlan np = make_nplan(j.N, j.Ho, j.Wo, j.Cout, j.C, j.ld_x, n16_group_target(j.Cout, j.C));
+                if (np.use && np.splits > 1) {
+                    const int nct = j.Cout > 32 ? 3 : (j.Cout > 16 ? 2 : 1), nci = j.C > 32 ? 3 : (j.C > 16 ? 2 : 1);
+                    j.variant = 16 + 3 * (nct - 1) + (nci - 1);
+                    j.splits = np.splits;
+                    j.part_floats = (size_t)np.splits * j.Cout * 9 * j.C;
+                }
+            }
+            continue;
+        }
         long pps;
         grouped_split(M, &j.splits, &pps);
         WgradTapArgs g;
@@ -2989,18 +3034,32 @@ int mnk_wgrad_grouped_build(const MnkWgradJob* jobs, int n, void* host_table, si
     TapJobRec* recs = (TapJobRec*)((char*)host_table + sizeof(GroupedHeader));
     hd->magic = 0x4d4e4b47;
     hd->n = n;
-    hd->nvariants = 16;
+    hd->nvariants = 25;
     hd->reserved = 0;
     int k = 0;
-    for (int v = 0; v < 16; ++v) {
+    for (int v = 0; v < 25; ++v) {
         hd->first[v] = k;
         int blocks = 0;
         for (int i = 0; i < n; ++i) {
             const MnkWgradJob& j = jobs[i];
-            MNK_REQUIRE(j.variant >= 0 && j.variant < 16);
+            MNK_REQUIRE(j.variant >= 0 && j.variant < 25);
             if (j.variant != v) continue;
             MNK_REQUIRE(j.x && j.dy && j.part && ((size_t)j.x % 16) == 0 && ((size_t)j.dy % 16) == 0);
             const int ups = j.flags & MNK_CONV_UPSAMPLED, clean = (j.flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
+            if (v >= 16) {          // nine-tap 16x16 job
+                NPlan np = make_nplan(j.N, j.Ho, j.Wo, j.Cout, j.C, j.ld_x, n16_group_target(j.Cout, j.C));
+                MNK_REQUIRE(np.use && np.splits == j.splits && np.splits > 1);
+                N16JobRec& r = reinterpret_cast<N16JobRec*>(recs)[k];
+                WgradN16Args& g = r.a;
+                g.x = j.x, g.ld_x = j.ld_x, g.C = j.C, g.ups = ups, g.dy = j.dy, g.ld_dy = j.ld_dy, g.Cout = j.Cout;
+                g.H = j.Ho, g.W = j.Wo, g.tiles_w = np.tiles_w, g.tiles_per_img = np.tiles_per_img;
+                g.total_tiles = np.total_tiles, g.tiles_per_split = np.tiles_per_split;
+                g.NT = 9 * j.C, g.splits = np.splits, g.out = j.part, g.ld_out = g.NT;
+                r.gm = np.gm, r.gn = np.gn, r.splits = np.splits, r.block_begin = blocks;
+                blocks += np.gm * np.gn * np.splits;
+                ++k;
+                continue;
+            }
             int subpix, ntaps, H, W;
             long M;
             TPlan tp = job_plan(j, &subpix, &M, &ntaps, &H, &W);
@@ -3082,6 +3141,25 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
         }
 #undef MNK_WGROUP
     }
+    for (int v = 16; v < 25; ++v) {
+        const int cnt = hd->count[v], blocks = hd->blocks[v];
+        if (!cnt) continue;
+        const N16JobRec* hn = reinterpret_cast<const N16JobRec*>(hrecs) + hd->first[v];
+        double flop = 0.0;
+        for (int i = 0; i < cnt; ++i) {
+            const WgradN16Args& g = hn[i].a;
+            flop += 2.0 * (double)g.total_tiles * 64.0 * g.Cout * 9.0 * g.C;
+        }
+        ProfScope prof(K_CONV_WGRAD, st, flop);
+        const N16JobRec* rv = reinterpret_cast<const N16JobRec*>(drecs) + hd->first[v];
+        const int nct = (v - 16) / 3 + 1, nci = (v - 16) % 3 + 1;
+#define MNK_N16G(T, I)                                                                                                  \
+    if (nct == T && nci == I) hipLaunchKernelGGL((conv3x3_wgrad_n16_grouped_kernel<T, I>), dim3(blocks), dim3(256), 0, st, rv, cnt)
+        MNK_N16G(3, 3); MNK_N16G(3, 2); MNK_N16G(3, 1);
+        MNK_N16G(2, 3); MNK_N16G(2, 2); MNK_N16G(2, 1);
+        MNK_N16G(1, 3); MNK_N16G(1, 2); MNK_N16G(1, 1);
+#undef MNK_N16G
+    }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -3094,7 +3172,9 @@ int mnk_set_tuning(const char* name, int value) {
                                                   {"MNK_SPLIT_TARGET", &g_split_target}, {"MNK_SPLIT_TILES", &g_split_tiles},
                                                   {"MNK_BM64_TILES", &g_bm64_tiles}, {"MNK_XCD_REMAP", &g_xcd_remap},
                                                   {"MNK_PLAN_TABLE", &g_plan_table}, {"MNK_FORCE_BM", &g_force_bm},
-                                                  {"MNK_FORCE_BN", &g_force_bn}, {"MNK_FORCE_SPLITS", &g_force_splits}};
+                                                  {"MNK_FORCE_BN", &g_force_bn}, {"MNK_FORCE_SPLITS", &g_force_splits},
+                                                  {"MNK_WN16_GROUP_TARGET", &g_wn16_group_target},
+                                                  {"MNK_WN16_GROUP_FEW", &g_wn16_group_target_few}};
     for (auto& k : knobs)
         if (strcmp(k.n, name) == 0) {
             *k.v = value;

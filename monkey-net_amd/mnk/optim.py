@@ -81,8 +81,9 @@ class DeferredReducer:
             if lib.query("mnk_wgrad_grouped_plan", job.ctypes.data, 1) != 0:
                 raise _lib.MnkError("mnk_wgrad_grouped_plan failed: %s" % lib.cdll.mnk_last_error().decode())
             grouped = int(job["variant"][0]) >= 0
-        if grouped:       # variant % 4 == 3: the sub-pixel form of an up-sampled layer (16 pseudo taps, layout 2)
-            layout = 2 if int(job["variant"][0]) % 4 == 3 else 0
+        if grouped:       # variant % 4 == 3: the sub-pixel form of an up-sampled layer (16 pseudo taps, layout 2);
+            v = int(job["variant"][0])                  # variants >= 16: the nine-tap 16x16 kernel (tap-major partials too)
+            layout = 2 if (v < 16 and v % 4 == 3) else 0
             splits, nfloats = int(job["splits"][0]), int(job["part_floats"][0])
         else:
             plan = _Plan()

@@ -230,6 +230,11 @@ def _grouped_weight_gradients(be, subpixel):
     gl = torch.Generator().manual_seed(10)
     layers.append((3, 32, 48, 32, 48, 70, 0, 24, 0, 3, 3, 1, torch.randn(3, 70, 32, 48, generator=gl), None,
                    torch.randn(24, 70, 3, 3, generator=gl) * 0.2))
+    # narrow layers on 8-aligned maps: the nine-tap 16x16 kernel, grouped (variants >= 16), plain and up-sampled
+    layers.append((4, 16, 24, 16, 24, 20, 0, 45, 0, 3, 3, 1, torch.randn(4, 20, 16, 24, generator=gl), None,
+                   torch.randn(45, 20, 3, 3, generator=gl) * 0.2))
+    layers.append((2, 16, 16, 16, 16, 45, 0, 45, 0, 3, 3, 1, torch.randn(2, 45, 16, 16, generator=gl), None,
+                   torch.randn(45, 45, 3, 3, generator=gl) * 0.2))
     jobs, meta, keep = [], [], []
     for li, (n, ho, wo, hi, wi, c0, c1, cout, ups, kh, kw, pad, x0, x1, wt) in enumerate(layers):
         gd = torch.Generator().manual_seed(100 + li)
@@ -251,9 +256,12 @@ def _grouped_weight_gradients(be, subpixel):
     rec = np.array(jobs, dtype=JOB)
     assert be.query("mnk_wgrad_grouped_plan", rec.ctypes.data, len(rec)) == 0
     sel = [i for i in range(len(rec)) if rec["variant"][i] >= 0]
-    assert len(sel) >= 12 and len(set(int(rec["variant"][i]) // 4 for i in sel)) == 4, rec["variant"]
-    modes = set(int(rec["variant"][i]) % 4 for i in sel)       # loaders: generic, 3x3 buffer loads, + up-sampled view / sub-pixel
-    assert modes == ({0, 1, 3} if subpixel else {0, 1, 2}) and max(int(rec["splits"][i]) for i in sel) >= 4
+    tap = [i for i in sel if rec["variant"][i] < 16]
+    n16 = [i for i in sel if rec["variant"][i] >= 16]
+    assert len(tap) >= 12 and len(set(int(rec["variant"][i]) // 4 for i in tap)) == 4, rec["variant"]
+    assert len(set(int(rec["variant"][i]) for i in n16)) >= 2 and all(int(rec["splits"][i]) > 1 for i in n16), rec["variant"]
+    modes = set(int(rec["variant"][i]) % 4 for i in tap)       # loaders: generic, 3x3 buffer loads, + up-sampled view / sub-pixel
+    assert modes == ({0, 1, 3} if subpixel else {0, 1, 2}) and max(int(rec["splits"][i]) for i in tap) >= 4
     grouped = rec[sel].copy()
     parts, rows, blocks = [], [], 0
     for k, i in enumerate(sel):
@@ -261,7 +269,8 @@ def _grouped_weight_gradients(be, subpixel):
         parts.append(part)
         grouped["part"][k] = part.data_ptr()
         DW, cin_total, c_start, c_cnt, cout, ntaps, _ = meta[i]
-        rows.append((part.data_ptr(), DW.data_ptr(), 2 if int(grouped["variant"][k]) % 4 == 3 else 0, int(grouped["splits"][k]),
+        v = int(grouped["variant"][k])
+        rows.append((part.data_ptr(), DW.data_ptr(), 2 if (v < 16 and v % 4 == 3) else 0, int(grouped["splits"][k]),
                      ntaps, cout, c_cnt, cin_total, c_start, 0, blocks, 0))
         blocks += be.query("mnk_wgrad_reduce_blocks", int(grouped["splits"][k]), cout, c_cnt)
     nbytes = be.query("mnk_wgrad_grouped_table_bytes", len(grouped))
@@ -290,8 +299,8 @@ def _grouped_weight_gradients(be, subpixel):
     descs = _table(be, np.array(rows, dtype=REDUCE_DESC))
     be.call("mnk_wgrad_reduce_multi", descs, len(rows), blocks)
     be.sync()
-    for DY, DW, ref in keep:
-        assert relerr(DW.cpu(), ref) < 2e-6
+    for li, (DY, DW, ref) in enumerate(keep):
+        assert relerr(DW.cpu(), ref) < 2e-6, (li, layers[li][:12], relerr(DW.cpu(), ref))
 
 
 def test_table_upload_through_kernel_arguments(be):
