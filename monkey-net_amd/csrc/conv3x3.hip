@@ -2278,6 +2278,7 @@ static void launch_wgrad_reduce(float* ws, int splits, int Cout, int NT, float* 
 
 // ---- grouped tap-major weight gradients: plan / build / launch --------------------------------------------------------
 static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 256);
+static int g_wgroup_long = env_int("MNK_WGROUP_LONG", 1), g_wgroup_long_from = env_int("MNK_WGROUP_LONG_FROM", 128);
 static int g_up_subpixel = env_int("MNK_UP_SUBPIXEL", 1);     // weight gradients of up-sampled convolutions: sub-pixel form
 
 // the sub-pixel tap-major plan of an up-sampled 3x3 layer (flags: UPSAMPLED | CLEAN_PADS), or use = false
@@ -2295,7 +2296,9 @@ static TPlan make_up_tplan(int N, int Ho, int Wo, int Cout, int C, int kh, int k
 // pixel splits of one job of a grouped launch: chunks of ~g_wgroup_chunk pixels, at least 8 K steps each
 static void grouped_split(long M, int* splits, long* pix_per_split) {
     const long steps = (M + BK - 1) / BK;
-    long sp = (M + g_wgroup_chunk - 1) / g_wgroup_chunk;
+    long chunk = g_wgroup_chunk;
+    if (g_wgroup_long > 1 && M / chunk >= g_wgroup_long_from) chunk *= g_wgroup_long;     // long layers: longer chunks, fewer partials
+    long sp = (M + chunk - 1) / chunk;
     const long max_sp = steps / 8;
     if (sp > max_sp) sp = max_sp;
     if (sp < 1) sp = 1;
