@@ -483,13 +483,27 @@ static int fill_embed_args(EmbedArgs& a, const float* img, int ld_img, int Cimg,
 }
 
 // ---- clip_variance (keypoint_detector.py:62-65): var * max(clip, sigma_min(var)) / sigma_min(var), with the closed
-// form of the smallest singular value of a 2x2 matrix (modules/util.py:244-255), operation order of the reference.
-__device__ __forceinline__ void sigma_min_2x2(float a, float b, float c, float d, float& s2, float& sg) {
+// form of the singular values of a 2x2 matrix (modules/util.py:244-255): sigma^2 = (s1 -+ s2) / 2.  The reference takes
+// sigma_min from the difference; for a nearly singular covariance (a heat-map stretched along a line: det ~ 1e-6 at entries
+// ~ 0.4) sigma_min^2 is far below the rounding of s1, the difference is pure rounding noise -- zero or negative as often as
+// not -- and the clipped variance comes out inf / NaN (measured: one of 24 initialisation seeds of a fixed-batch run went
+// non-finite within four iterations).  Here sigma_max comes from the SUM (no cancellation) and sigma_min = |det| / sigma_max
+// (the product of the singular values is |det|; det by Kahan's fma scheme): identical in exact arithmetic, equal to rounding
+// where the reference's form is accurate, and equal to the fp64 reference where it is not.
+__device__ __forceinline__ float det_2x2(float a, float b, float c, float d) {
+    const float w = b * c;
+    const float e = fmaf(-b, c, w);        // rounding error of w
+    const float f = fmaf(a, d, -w);
+    return f + e;
+}
+
+__device__ __forceinline__ void sigma_2x2(float a, float b, float c, float d, float& s2, float& smax, float& sg) {
     const float s1 = a * a + b * b + c * c + d * d;
     const float t = a * a + b * b - c * c - d * d;
     const float u = a * c + b * d;
     s2 = sqrtf(t * t + 4.f * (u * u));
-    sg = sqrtf((s1 - s2) / 2.f);
+    smax = sqrtf((s1 + s2) * 0.5f);
+    sg = fabsf(det_2x2(a, b, c, d)) / smax;
 }
 
 __global__ void __launch_bounds__(256) kp_clip_var_fwd_kernel(const float* __restrict__ var, float clip, long M,
@@ -497,13 +511,16 @@ __global__ void __launch_bounds__(256) kp_clip_var_fwd_kernel(const float* __res
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const float4 v = *reinterpret_cast<const float4*>(var + i * 4);
-    float s2, sg;
-    sigma_min_2x2(v.x, v.y, v.z, v.w, s2, sg);
+    float s2, smax, sg;
+    sigma_2x2(v.x, v.y, v.z, v.w, s2, smax, sg);
     const float mx = fmaxf(clip, sg);
     *reinterpret_cast<float4*>(out + i * 4) = make_float4((mx * v.x) / sg, (mx * v.y) / sg, (mx * v.z) / sg, (mx * v.w) / sg);
 }
 
-// dvar = dout * mx / sg + g_sg * d sigma_min / d var,  g_sg = sum_ij dout_ij v_ij ([sg > clip] / sg - mx / sg^2)
+// dvar = dout * mx / sg + g_sg * d sigma_min / d var,  g_sg = sum_ij dout_ij v_ij ([sg > clip] / sg - mx / sg^2);
+// sigma_min = |det| / sigma_max:  d sigma_min = sign(det) d det / sigma_max - sigma_min d sigma_max / sigma_max,
+// d det = (d, -c, -b, a),  sigma_max = sqrt((s1 + s2) / 2): d sigma_max = (d s1 + d s2) / (4 sigma_max),
+// d s2 = (t dt + 4 u du) / s2  -- sums only, no cancellation
 __global__ void __launch_bounds__(256) kp_clip_var_bwd_kernel(const float* __restrict__ var, float clip, long M,
                                                               const float* __restrict__ dout, float* __restrict__ dvar) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -511,22 +528,25 @@ __global__ void __launch_bounds__(256) kp_clip_var_bwd_kernel(const float* __res
     const float4 v = *reinterpret_cast<const float4*>(var + i * 4);
     const float4 g = *reinterpret_cast<const float4*>(dout + i * 4);
     const float a = v.x, b = v.y, c = v.z, d = v.w;
-    float s2, sg;
-    sigma_min_2x2(a, b, c, d, s2, sg);
+    float s2, smax, sg;
+    sigma_2x2(a, b, c, d, s2, smax, sg);
     const float mx = fmaxf(clip, sg);
     const float dmx = sg > clip ? 1.f : (sg == clip ? 0.5f : 0.f);      // torch.max splits the gradient on ties
     const float gv = g.x * a + g.y * b + g.z * c + g.w * d;
     const float g_sg = gv * (dmx / sg - mx / (sg * sg));
-    // sigma = sqrt((s1 - s2) / 2):  d sigma = (d s1 - d s2) / (4 sigma),  d s2 = (t dt + 4 u du) / s2
     const float t = a * a + b * b - c * c - d * d, u = a * c + b * d;
-    const float k = g_sg / (4.f * sg);
-    const float da = 2.f * a - (t * 2.f * a + 4.f * u * c) / s2;
-    const float db = 2.f * b - (t * 2.f * b + 4.f * u * d) / s2;
-    const float dc = 2.f * c - (-t * 2.f * c + 4.f * u * a) / s2;
-    const float dd = 2.f * d - (-t * 2.f * d + 4.f * u * b) / s2;
+    const float sgn = det_2x2(a, b, c, d) < 0.f ? -1.f : 1.f;
+    // d sigma_max / d(a, b, c, d); an isotropic matrix has s2 = 0 and d s2 = 0 (the two singular values coincide)
+    const float is2 = s2 > 0.f ? 1.f / s2 : 0.f, q = 1.f / (4.f * smax);
+    const float ma = q * (2.f * a + (t * 2.f * a + 4.f * u * c) * is2);
+    const float mb = q * (2.f * b + (t * 2.f * b + 4.f * u * d) * is2);
+    const float mc = q * (2.f * c + (-t * 2.f * c + 4.f * u * a) * is2);
+    const float md = q * (2.f * d + (-t * 2.f * d + 4.f * u * b) * is2);
+    const float r = sg / smax, ism = sgn / smax;
+    const float da = ism * d - r * ma, db = -ism * c - r * mb, dc = -ism * b - r * mc, dd = ism * a - r * md;
     const float f = mx / sg;
     *reinterpret_cast<float4*>(dvar + i * 4) =
-        make_float4(fmaf(g.x, f, k * da), fmaf(g.y, f, k * db), fmaf(g.z, f, k * dc), fmaf(g.w, f, k * dd));
+        make_float4(fmaf(g.x, f, g_sg * da), fmaf(g.y, f, g_sg * db), fmaf(g.z, f, g_sg * dc), fmaf(g.w, f, g_sg * dd));
 }
 
 

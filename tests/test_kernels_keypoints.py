@@ -165,3 +165,37 @@ def test_clip_variance(be):
     be.sync()
     assert relerr(O.cpu(), ref.detach()) < 4 * spread_f + 1e-6
     assert relerr(DV.cpu(), vd.grad) < 4 * spread_b + 1e-5
+
+
+def test_clip_variance_of_nearly_singular_covariances(be):
+    """Heat-maps stretched along a line give covariances with sigma_min ~ 1e-6 at entries ~ 0.4 (measured in training: det
+    2e-6, off-diagonal 0.45).  The reference's closed form takes sigma_min^2 from s1 - s2, which is far below the rounding of
+    s1 there: evaluated in fp32 it is rounding noise (zero or negative for a good part of such matrices -> inf / NaN after the
+    clip).  The kernels take sigma_min = |det| / sigma_max: finite, and equal to the fp64 evaluation of the reference's formula."""
+    g = torch.Generator().manual_seed(12)
+    m = 64
+    ang = torch.rand(m, generator=g, dtype=torch.float64) * 3.14159
+    r = torch.stack([torch.stack([ang.cos(), -ang.sin()], -1), torch.stack([ang.sin(), ang.cos()], -1)], -2)
+    big = 0.2 + 0.7 * torch.rand(m, generator=g, dtype=torch.float64)
+    small = 10.0 ** (-7.0 + 3.0 * torch.rand(m, generator=g, dtype=torch.float64))        # 1e-7 .. 1e-4
+    var = (r @ torch.diag_embed(torch.stack([big, small], -1)) @ r.transpose(1, 2)).float()     # what the kernel is given
+    clip = 0.001
+    vd = var.double().requires_grad_(True)
+    sg = restate.smallest_singular(vd).unsqueeze(-1)
+    ref = torch.max(torch.full((), clip, dtype=torch.float64), sg) * vd / sg
+    dout = torch.randn(m, 2, 2, generator=g, dtype=torch.float64)
+    ref.backward(dout)
+    # the fp32 evaluation of the reference's formula on the same matrices: how often is it unusable?
+    sg32 = restate.smallest_singular(var)
+    broken = int((~torch.isfinite(sg32) | (sg32 <= 0)).sum())
+    V, O, DV = be.t(var), be.empty(m, 2, 2), be.empty(m, 2, 2)
+    be.call("mnk_kp_clip_variance_fwd", V, clip, m, O)
+    be.call("mnk_kp_clip_variance_bwd", V, clip, m, be.t(dout.float()), DV)
+    be.sync()
+    assert torch.isfinite(O.cpu()).all() and torch.isfinite(DV.cpu()).all()
+    # fp32 inputs carry ~6e-8 absolute rounding: sigma_min = det / sigma_max is known to ~1e-7 / sigma_min relative
+    per = ((O.cpu().double() - ref.detach()).abs().amax(dim=(1, 2)) / ref.detach().abs().amax(dim=(1, 2)))
+    assert float(per.max()) < 1e-3, float(per.max())
+    gper = ((DV.cpu().double() - vd.grad).abs().amax(dim=(1, 2)) / vd.grad.abs().amax(dim=(1, 2)))
+    assert float(gper.max()) < 5e-3, float(gper.max())
+    print("fp32 evaluation of the reference's closed form: %d of %d matrices give a zero / non-finite sigma_min" % (broken, m))
