@@ -15,6 +15,15 @@ constexpr int MAXK = 16;   // key-points per block-row handled in registers
 // align_corners=True grid of modules/util.py:26-42:  x_j = 2*(j/(w-1)) - 1
 __device__ __forceinline__ float grid_coord(int j, int n) { return 2.f * ((float)j / (float)(n - 1)) - 1.f; }
 
+// a * d - b * c without the cancellation of the naive form (Kahan): the covariances this file inverts are clipped to
+// sigma_min >= 1e-3 at sigma_max up to a few hundred, i.e. det ~ 0.5 from products ~ 3e4
+__device__ __forceinline__ float det_2x2(float a, float b, float c, float d) {
+    const float w = b * c;
+    const float e = fmaf(-b, c, w);        // rounding error of w
+    const float f = fmaf(a, d, -w);
+    return f + e;
+}
+
 // Block-wide sums of small per-thread register arrays.  Loops are fully unrolled with compile-time indices so
 // the arrays stay in VGPRs (runtime-indexed arrays would be demoted to scratch).
 struct BlockRed {
@@ -203,7 +212,7 @@ struct Gauss {
         my = mean[idx * 2 + 1];
         if (var) {
             const float a = var[idx * 4], b = var[idx * 4 + 1], c = var[idx * 4 + 2], d = var[idx * 4 + 3];
-            const float det = a * d - b * c;
+            const float det = det_2x2(a, b, c, d);
             a00 = d / det;
             a01 = -b / det;
             a10 = -c / det;
@@ -490,13 +499,6 @@ static int fill_embed_args(EmbedArgs& a, const float* img, int ld_img, int Cimg,
 // non-finite within four iterations).  Here sigma_max comes from the SUM (no cancellation) and sigma_min = |det| / sigma_max
 // (the product of the singular values is |det|; det by Kahan's fma scheme): identical in exact arithmetic, equal to rounding
 // where the reference's form is accurate, and equal to the fp64 reference where it is not.
-__device__ __forceinline__ float det_2x2(float a, float b, float c, float d) {
-    const float w = b * c;
-    const float e = fmaf(-b, c, w);        // rounding error of w
-    const float f = fmaf(a, d, -w);
-    return f + e;
-}
-
 __device__ __forceinline__ void sigma_2x2(float a, float b, float c, float d, float& s2, float& smax, float& sg) {
     const float s1 = a * a + b * b + c * c + d * d;
     const float t = a * a + b * b - c * c - d * d;
@@ -624,7 +626,7 @@ __global__ void __launch_bounds__(256) kp_normalize_kernel(const float* __restri
     float v00 = var_v[4 * i], v01 = var_v[4 * i + 1], v10 = var_v[4 * i + 2], v11 = var_v[4 * i + 3];
     if (adapt_variance) {
         const float f00 = var_v[4 * first], f01 = var_v[4 * first + 1], f10 = var_v[4 * first + 2], f11 = var_v[4 * first + 3];
-        const float det = f00 * f11 - f01 * f10;
+        const float det = det_2x2(f00, f01, f10, f11);
         const float i00 = f11 / det, i01 = -f01 / det, i10 = -f10 / det, i11 = f00 / det;     // matrix_inverse, eps = 0
         const float t00 = v00 * i00 + v01 * i10, t01 = v00 * i01 + v01 * i11;
         const float t10 = v10 * i00 + v11 * i10, t11 = v10 * i01 + v11 * i11;
