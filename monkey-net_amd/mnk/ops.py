@@ -373,7 +373,9 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
     y = torch.empty(n, h, w, ceil4(cout), dtype=torch.float32, device=x0.device)
     # a small layer whose BatchNorm follows at once (want_stats): that one-launch kernel makes its own statistics and,
     # when this convolution is split along K, also sums the partials -- no separate reduction, no epilogue statistics
-    small = want_stats and residual is None and small_bn(n * h * w)
+    # (even sizes only: a pooling BatchNorm on an odd map -- 96 x 96 frames reach 3 x 3 -- takes the general kernels, and this
+    # function does not know whether the BatchNorm that follows pools)
+    small = want_stats and residual is None and small_bn(n * h * w) and h % 2 == 0 and w % 2 == 0
     if _SPLIT_PENDING:
         raise RuntimeError("a split-K convolution is still waiting for the BatchNorm that sums its partials")
     if up:

@@ -423,3 +423,40 @@ def test_discriminate_pair_batched_equals_two_calls(be, impl, monkeypatch):
         if k.endswith("conv.bias") and "down_blocks.0" not in k and k != "conv.bias":
             continue      # bias in front of an InstanceNorm: rounding noise around an analytically zero gradient
         assert float((one[3][k] - two[3][k]).norm() / (two[3][k].norm() + 1e-12)) < 1e-3, k
+
+
+@pytest.mark.parametrize("hw", [(4, 4), (3, 3), (5, 6), (1, 1)])
+def test_down_block_on_small_and_odd_maps(be, hw):
+    """A small layer whose convolution is split along K (136 input channels): even maps take the one-launch BatchNorm that
+    sums the partials; odd maps are refused with the pooling kernel's own message (H % 2 == 0 && W % 2 == 0) -- the
+    reference's hourglass cannot pool an odd map either (the decoder's torch.cat with the skip then fails, modules/util.py:185)
+    -- and not, as before, with "split-K partials were deferred to a BatchNorm that does not take the small-layer path"."""
+    from modules.util import DownBlock3D
+    from oracle import restate
+    from mnk import _lib
+    h, w = hw
+    torch.manual_seed(5)
+    blk = DownBlock3D(136, 24, kernel_size=(1, 3, 3), padding=(0, 1, 1))
+    sd = {("blk." + k): v.detach().clone().double() for k, v in blk.state_dict().items()}
+    x = torch.rand(4, 136, 1, h, w)
+    for t in sd.values():
+        if t.is_floating_point():
+            t.requires_grad_(True)
+    ctx = restate.Ctx(sd, True)
+    blk.to(be.device).train()
+    if h % 2 or w % 2:
+        with pytest.raises(_lib.MnkError, match="H % 2 == 0"):
+            blk(be.t(x))
+        from mnk import ops
+        assert not ops._SPLIT_PENDING
+        return
+    ref = restate.down_block(ctx, restate.fold(x.double()), "blk")
+    g = torch.randn(ref.shape, dtype=torch.float64)
+    (ref * g).sum().backward()
+    out = blk(be.t(x))
+    (out * be.t(restate.unfold(g.float(), 4))).sum().backward()
+    be.sync()
+    assert float((out.detach().cpu()[:, :, 0].double() - ref).abs().max()) < 2e-5
+    for k in ("conv.weight", "norm.weight", "norm.bias"):
+        a, b = dict(blk.named_parameters())[k].grad.cpu().double(), sd["blk." + k].grad
+        assert float((a - b).norm() / b.norm()) < 1e-4, k

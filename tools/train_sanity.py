@@ -22,16 +22,19 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--every", type=int, default=50)
+    ap.add_argument("--config", default="moving-gif")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--watch", type=int, default=0, help="1: check every parameter and the key points after every iteration")
     args = ap.parse_args()
-    cfg = configs.get("moving-gif")
+    cfg = configs.get(args.config)
     torch.manual_seed(args.seed)
     mp = cfg["model_params"]
     gen = MotionTransferGenerator(**mp["generator_params"], **mp["common_params"]).cuda()
     disc = Discriminator(**mp["discriminator_params"], **mp["common_params"]).cuda()
     kpd = KPDetector(**mp["kp_detector_params"], **mp["common_params"]).cuda()
-    src, drv = workload.synthetic_pair(32, 64, 64)
+    src, drv = workload.synthetic_pair(args.batch, args.size, args.size)
     # smooth frames (the uniform-noise bench input has nothing to learn): blur the noise
     blur = torch.nn.AvgPool2d(9, stride=1, padding=4)
     src = blur(src[:, :, 0]).unsqueeze(2).contiguous()
@@ -67,6 +70,13 @@ def main():
     rec_first, rec_last = sum(first[:-2]), sum(last[:-2])
     print("reconstruction terms %.4f -> %.4f" % (rec_first, rec_last))
     assert rec_last < rec_first, "the reconstruction terms did not fall on a fixed batch"
+    # evaluation-mode forward with the trained weights (running statistics): reconstruction of the batch
+    rec = engine.Reconstructor(kpd, gen, use_graph=False)
+    with torch.no_grad():
+        out = rec(x["source"], x["video"])
+    pred = out["video_prediction"] if isinstance(out, dict) else out
+    assert torch.isfinite(pred).all(), "non-finite evaluation forward"
+    print("evaluation forward: L1 to the driving frames %.4f" % float((pred - x["video"]).abs().mean()))
     print("ok")
 
 
