@@ -35,3 +35,70 @@ def test_fixed_batch_training_stays_finite_and_learns(seed, use_graph):
     for m in (gen, disc, kpd):
         assert all(torch.isfinite(p).all() for p in m.parameters())
     assert sum(last[:len(first) - 1]) < 0.6 * sum(first[:-1]), (first, last)      # reconstruction terms (all but the GAN term)
+
+
+def _models(seed):
+    from mnk import configs
+    from modules.generator import MotionTransferGenerator
+    from modules.discriminator import Discriminator
+    from modules.keypoint_detector import KPDetector
+    cfg = configs.get("moving-gif")
+    mp = cfg["model_params"]
+    torch.manual_seed(seed)
+    gen = MotionTransferGenerator(**mp["generator_params"], **mp["common_params"]).cuda()
+    disc = Discriminator(**mp["discriminator_params"], **mp["common_params"]).cuda()
+    kpd = KPDetector(**mp["kp_detector_params"], **mp["common_params"]).cuda()
+    return cfg, gen, disc, kpd
+
+
+def _batches(n, count):
+    from mnk import workload
+    blur = torch.nn.AvgPool2d(9, stride=1, padding=4)
+    out = []
+    for i in range(count):
+        src, drv = workload.synthetic_pair(n, 64, 64, seed=100 + i)
+        out.append({"source": blur(src[:, :, 0]).unsqueeze(2).contiguous().cuda(),
+                    "video": blur(drv[:, :, 0]).unsqueeze(2).contiguous().cuda()})
+    return out
+
+
+def test_graph_replay_follows_new_batches_and_a_new_learning_rate():
+    """The captured iteration reads its inputs from static buffers and its learning rate from device scalars: a replay
+    must see the batch it is handed (same losses as the eager iteration on the same sequence of batches, different
+    from a replay on the first batch again) and a learning rate set through param_groups (0: the parameters stand still)."""
+    from mnk import engine
+    batches = _batches(16, 3)
+
+    def run(use_graph, order):
+        cfg, gen, disc, kpd = _models(7)
+        step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
+        hist = []
+        for i in order:
+            g_l, d_l, _ = step.step(batches[i])
+            hist.append([float(v) for v in g_l] + [float(v) for v in d_l])
+        return hist, step, (gen, disc, kpd)
+
+    def dev(p, q):
+        return max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(p, q))
+
+    eager, _, _ = run(False, [0, 1, 2])
+    graph, step, mods = run(True, [0, 1, 2])
+    same, _, _ = run(True, [0, 0, 0])
+    for k in range(3):                       # trajectories of two fp32 runs separate by ~1e-2 within three iterations
+        assert dev(graph[k], eager[k]) < 3e-2, (k, graph[k], eager[k])
+    assert dev(graph[1], same[1]) > 10 * dev(graph[1], eager[1]) + 1e-3, "the replay did not see the second batch"
+    # learning rate 0 through param_groups (the reference's MultiStepLR writes there, train.py:88-93)
+    for opt in (step.opt_g, step.opt_d, step.opt_k):
+        for grp in opt.param_groups:
+            grp["lr"] = 0.0
+    before = [p.detach().clone() for m in mods for p in m.parameters()]
+    step.step(batches[0])
+    torch.cuda.synchronize()
+    after = [p.detach() for m in mods for p in m.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(before, after)), "a replay ignored the learning rate set after capture"
+    for opt in (step.opt_g, step.opt_d, step.opt_k):
+        for grp in opt.param_groups:
+            grp["lr"] = 2e-4
+    step.step(batches[1])
+    torch.cuda.synchronize()
+    assert any(not torch.equal(a, b) for a, b in zip(before, [p.detach() for m in mods for p in m.parameters()]))
