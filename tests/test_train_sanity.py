@@ -102,3 +102,35 @@ def test_graph_replay_follows_new_batches_and_a_new_learning_rate():
     step.step(batches[1])
     torch.cuda.synchronize()
     assert any(not torch.equal(a, b) for a, b in zip(before, [p.detach() for m in mods for p in m.parameters()]))
+
+
+def test_resume_from_a_checkpoint_continues_the_run():
+    """train.py resumes from Logger.load_cpk (logger.py:43-66): model and optimiser state dicts into freshly built objects.
+    Iteration 2 after such a resume (captured graph: the capture's warm-up must hand back exactly the loaded state) gives the
+    losses of the uninterrupted run's iteration 2, and the resumed optimiser carries on at step 3."""
+    from mnk import engine
+    batches = _batches(16, 3)
+    cfg, gen, disc, kpd = _models(9)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=True)
+    for i in (0, 1):
+        step.step(batches[i])
+    torch.cuda.synchronize()
+    ckpt = {"generator": {k: v.clone() for k, v in gen.state_dict().items()},
+            "discriminator": {k: v.clone() for k, v in disc.state_dict().items()},
+            "kp_detector": {k: v.clone() for k, v in kpd.state_dict().items()},
+            "opt_g": step.opt_g.state_dict(), "opt_d": step.opt_d.state_dict(), "opt_k": step.opt_k.state_dict()}
+    g_l, d_l, _ = step.step(batches[2])
+    straight = [float(v) for v in g_l] + [float(v) for v in d_l]
+    cfg, gen2, disc2, kpd2 = _models(123)                      # different initial weights: everything must come from the file
+    step2 = engine.TrainStep(gen2, disc2, kpd2, cfg["train_params"], use_graph=True)
+    gen2.load_state_dict(ckpt["generator"]), disc2.load_state_dict(ckpt["discriminator"]), kpd2.load_state_dict(ckpt["kp_detector"])
+    step2.opt_g.load_state_dict(ckpt["opt_g"]), step2.opt_d.load_state_dict(ckpt["opt_d"]), step2.opt_k.load_state_dict(ckpt["opt_k"])
+    g_l, d_l, _ = step2.step(batches[2])
+    resumed = [float(v) for v in g_l] + [float(v) for v in d_l]
+    torch.cuda.synchronize()
+    err = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(resumed, straight))
+    assert err < 2e-3, (resumed, straight)                     # same weights, same batch: only the atomics' rounding differs
+    assert float(step2.opt_g.hyper[7]) == 3.0 and float(step.opt_g.hyper[7]) == 3.0
+    pa = torch.cat([p.detach().flatten() for p in gen.parameters()])
+    pb = torch.cat([p.detach().flatten() for p in gen2.parameters()])
+    assert float((pa - pb).abs().max()) < 3 * cfg["train_params"]["lr"]
