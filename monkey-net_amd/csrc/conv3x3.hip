@@ -803,6 +803,136 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_kernel(const float*
     }
 }
 
+// The same reduction for a layer whose BatchNorm follows (sync_batchnorm/batchnorm.py:60-62 wants sum and sum of squares of
+// what is written here): a block owns `rows_per_block` output rows x tx_n channel quads, every thread sums the splits of its
+// float4 in the order of the kernel above (four interleaved groups, (g0 + g1) + (g2 + g3): the same bits), writes it and
+// keeps the two column sums; stats[row_block][2][ld_y] are the per-block partials that the conv epilogue leaves for an
+// unsplit launch (finished by bn_final_finalize / mnk_bn_stats_finish).  One launch instead of reduction + statistics pass.
+struct RSMap {
+    int tx, ty, col_tiles, row_blocks;
+    long rows_per_block;
+};
+static RSMap make_rsmap(long rows, int ld) {
+    RSMap m;
+    const int nv = ld / 4;
+    int tx = 1;
+    while (tx < nv && tx < 64) tx <<= 1;
+    m.tx = tx;
+    m.ty = 256 / tx;
+    m.col_tiles = (nv + tx - 1) / tx;
+    long want = 1024 / m.col_tiles;
+    if (want < 1) want = 1;
+    const long min_rows = (long)m.ty * 4;
+    long rb = (rows + min_rows - 1) / min_rows;
+    if (rb > want) rb = want;
+    if (rb < 1) rb = 1;
+    m.row_blocks = (int)rb;
+    m.rows_per_block = (rows + rb - 1) / rb;
+    return m;
+}
+
+__global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const float* __restrict__ ws, int splits, long M,
+                                                                          int ldw, const float* __restrict__ bias,
+                                                                          const float* __restrict__ residual, int ld_res,
+                                                                          float* __restrict__ y, int ld_y, int Cout,
+                                                                          int phases, int H, int W, int tx_n, int ty_n,
+                                                                          long rows_per_block, float* __restrict__ stats) {
+    __shared__ float4 red[2][256];
+    const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
+    const int q = blockIdx.x * tx_n + tx, nv = ld_y / 4, c = q * 4;
+    const long rows = M * phases;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    if (q < nv) {
+        const bool k0 = c < Cout, k1 = c + 1 < Cout, k2 = c + 2 < Cout, k3 = c + 3 < Cout;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = make_float4(k0 ? bias[c] : 0.f, k1 ? bias[c + 1] : 0.f, k2 ? bias[c + 2] : 0.f, k3 ? bias[c + 3] : 0.f);
+        const long sstride = rows * ldw;
+        for (long m = r0 + ty; m < r1; m += ty_n) {
+            const float* p = ws + m * ldw + c;
+            float4 g[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s = 0;
+            for (; s + 4 <= splits; s += 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (long)(s + e) * sstride);
+                    g[e].x += v.x;
+                    g[e].y += v.y;
+                    g[e].z += v.z;
+                    g[e].w += v.w;
+                }
+            }
+            for (int e = 0; s < splits; ++s, ++e) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (long)s * sstride);
+                g[e].x += v.x;
+                g[e].y += v.y;
+                g[e].z += v.z;
+                g[e].w += v.w;
+            }
+            long orow = m;
+            if (phases > 1) {
+                const long ph = m / M, mm = m - ph * M;
+                const long tt = mm / W, fr = tt / H;
+                const long jj = mm - tt * W, ii = tt - fr * H;
+                orow = ((fr * H + ii) * 2 + (ph >> 1)) * (2L * W) + 2 * jj + (ph & 1);
+            }
+            float4 r;
+            r.x = (g[0].x + g[1].x) + (g[2].x + g[3].x);
+            r.y = (g[0].y + g[1].y) + (g[2].y + g[3].y);
+            r.z = (g[0].z + g[1].z) + (g[2].z + g[3].z);
+            r.w = (g[0].w + g[1].w) + (g[2].w + g[3].w);
+            if (bias) {
+                r.x += bv.x;
+                r.y += bv.y;
+                r.z += bv.z;
+                r.w += bv.w;
+            }
+            if (residual) {
+                const float* rp = residual + orow * ld_res + c;
+                if (k0) r.x += rp[0];
+                if (k1) r.y += rp[1];
+                if (k2) r.z += rp[2];
+                if (k3) r.w += rp[3];
+            }
+            r.x = k0 ? r.x : 0.f;
+            r.y = k1 ? r.y : 0.f;
+            r.z = k2 ? r.z : 0.f;
+            r.w = k3 ? r.w : 0.f;
+            *reinterpret_cast<float4*>(y + orow * ld_y + c) = r;
+            s1.x += r.x;
+            s1.y += r.y;
+            s1.z += r.z;
+            s1.w += r.w;
+            s2.x = fmaf(r.x, r.x, s2.x);
+            s2.y = fmaf(r.y, r.y, s2.y);
+            s2.z = fmaf(r.z, r.z, s2.z);
+            s2.w = fmaf(r.w, r.w, s2.w);
+        }
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int s = ty_n >> 1; s > 0; s >>= 1) {
+        if (ty < s) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float4 a = red[k][threadIdx.x], b = red[k][threadIdx.x + s * tx_n];
+                red[k][threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+            }
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && q < nv) {
+        float* o = stats + (long)blockIdx.y * 2 * ld_y;
+        *reinterpret_cast<float4*>(o + c) = red[0][tx];
+        *reinterpret_cast<float4*>(o + ld_y + c) = red[1][tx];
+    }
+}
+
 // ---- weight packing: Wp[row][chunk][tap][16] --------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout,
                                                        int C0, int C1, int C0p, int C1p, int ntaps) {
@@ -2005,6 +2135,9 @@ static int g_split_tiles = env_int("MNK_SPLIT_TILES", 192), g_split_target = env
 // the zeroed gradient (no partial buffer / reduce launch).  Measured equal on the MI355X (21.74 ms per training
 // iteration either way: the atomics cost the wgrad kernel what the reduce kernel saves), so determinism wins.
 static int g_wgrad_atomic = env_int("MNK_WGRAD_ATOMIC", 0);
+// 1 (default): a split-K forward launch that was asked for BatchNorm statistics sums its partials with
+// conv3x3_splitk_reduce_stats_kernel (one launch for reduction + statistics pass); 0: no statistics from split launches
+static int g_splitk_stats = env_int("MNK_SPLITK_STATS", 1);
 static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = env_int("MNK_WSPLIT_TARGET", 1024),
            g_wsplit_minsteps = env_int("MNK_WSPLIT_MINSTEPS", 8);
 
@@ -2422,7 +2555,9 @@ size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, 
     if (N <= 0 || Ho <= 0 || Wo <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0 || ntaps <= 0) return 0;
     const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
     Plan p = make_plan((long)N * Ho * Wo, Cout, chunks, ntaps);
-    return p.splits > 1 ? 0 : (size_t)p.gm * 2 * round_up(Cout, 4);
+    if (p.splits > 1)
+        return g_splitk_stats ? (size_t)make_rsmap((long)N * Ho * Wo, round_up(Cout, 4)).row_blocks * 2 * round_up(Cout, 4) : 0;
+    return (size_t)p.gm * 2 * round_up(Cout, 4);
 }
 
 }  // extern "C"
@@ -2497,7 +2632,7 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
     a.ldw = p.ldw;
     a.stats = stats_partial;
     a.xcd = g_xcd_remap;
-    MNK_REQUIRE(!stats_partial || (p.splits == 1 && ld_y == round_up(Cout, 4)));
+    MNK_REQUIRE(!stats_partial || (ld_y == round_up(Cout, 4) && (p.splits == 1 || (g_splitk_stats && !defer_splitk))));
     if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * phases * a.M * p.ldw)) {
         set_error("mnk_conv2d_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * phases * a.M * p.ldw);
         return MNK_EWORKSPACE;
@@ -2560,8 +2695,14 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
     }
     if (p.splits > 1 && !defer_splitk) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
-        hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * phases * ld_y * 4, 8192)), dim3(256), 0, s, ws,
-                           p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W);
+        if (stats_partial) {
+            const RSMap m = make_rsmap(a.M * phases, ld_y);
+            hipLaunchKernelGGL(conv3x3_splitk_reduce_stats_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, ws, p.splits,
+                               a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W, m.tx, m.ty, m.rows_per_block,
+                               stats_partial);
+        } else
+            hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * phases * ld_y * 4, 8192)), dim3(256), 0, s, ws,
+                               p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W);
     }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
@@ -3177,7 +3318,8 @@ int mnk_set_tuning(const char* name, int value) {
                                                   {"MNK_PLAN_TABLE", &g_plan_table}, {"MNK_FORCE_BM", &g_force_bm},
                                                   {"MNK_FORCE_BN", &g_force_bn}, {"MNK_FORCE_SPLITS", &g_force_splits},
                                                   {"MNK_WN16_GROUP_TARGET", &g_wn16_group_target},
-                                                  {"MNK_WN16_GROUP_FEW", &g_wn16_group_target_few}};
+                                                  {"MNK_WN16_GROUP_FEW", &g_wn16_group_target_few},
+                                                  {"MNK_SPLITK_STATS", &g_splitk_stats}};
     for (auto& k : knobs)
         if (strcmp(k.n, name) == 0) {
             *k.v = value;
@@ -3250,7 +3392,9 @@ size_t mnk_conv3x3_up_stats_floats(int N, int H, int W, int C0, int C1, int Cout
     if (N <= 0 || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
     const int chunks = (round_up(C0, 16) + (C1 > 0 ? round_up(C1, 16) : 0)) / 16;
     Plan p = make_plan((long)N * H * W, Cout, chunks, 4, 4);
-    return p.splits > 1 ? 0 : (size_t)4 * p.gm * 2 * round_up(Cout, 4);
+    if (p.splits > 1)
+        return g_splitk_stats ? (size_t)make_rsmap(4L * N * H * W, round_up(Cout, 4)).row_blocks * 2 * round_up(Cout, 4) : 0;
+    return (size_t)4 * p.gm * 2 * round_up(Cout, 4);
 }
 int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp_up,
                        const float* bias, float* y, int ld_y, int N, int H, int W, int Cout, float* ws, size_t ws_floats,

@@ -288,12 +288,17 @@ def test_sumpool2x2(be):
 
 # large enough (>= 192 output tiles) that the forward is not split along K -- only then are the statistics fused
 STAT_CASES = [(6, 64, 64, 5, 0, 20, 0, True, False), (6, 64, 64, 4, 3, 40, 1, True, True)]
+# few output tiles, deep K: split along K -- the reduction of the partials leaves the statistics (one launch for both)
+SPLIT_STAT_CASES = [(2, 8, 8, 64, 0, 22, 0, True, False), (3, 6, 10, 40, 24, 70, 0, False, True), (2, 8, 8, 48, 0, 33, 1, True, False)]
 
 
-@pytest.mark.parametrize("case", STAT_CASES)
+@pytest.mark.parametrize("case", STAT_CASES + SPLIT_STAT_CASES)
 def test_conv3x3_fused_bn_statistics(be, case):
-    """The conv epilogue's per-block column sums + mnk_bn_stats_finish == sums over the written output."""
+    """The conv epilogue's per-block column sums (unsplit launches) or the split-K reduction's (split launches)
+    + mnk_bn_stats_finish == sums over the written output; the output does not depend on the statistics being asked for."""
     n, h, w, c0, c1, cout, ups, _, _ = case
+    split = be.query("mnk_conv3x3_splits", n, h, w, c0, c1, cout) > 1
+    assert split == (case in SPLIT_STAT_CASES)
     x0, x1, wt, b, r = _inputs(case, seed=3)
     wp = be.empty(be.query("mnk_conv3x3_packed_floats", cout, c0, c1))
     be.call("mnk_conv3x3_pack_fwd", be.t(wt), wp, cout, c0, c1)
@@ -304,13 +309,22 @@ def test_conv3x3_fused_bn_statistics(be, case):
     Y = be.empty(n, h, w, ldy)
     nst = be.query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout)
     assert nst > 0 and nst % (2 * ldy) == 0
-    st = be.empty(nst)
-    be.call("mnk_conv3x3_fwd", X0, X0.shape[-1], c0, X1, X1.shape[-1] if x1 is not None else 0, c1, ups, wp,
-            be.t(b) if b is not None else None, R, R.shape[-1] if r is not None else 0, Y, ldy, n, h, w, cout,
-            None, 0, st)
+    st = be.empty(nst).fill_(float("nan"))
+    nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, c0, c1, cout)
+    assert (nws > 0) == split
+    ws = be.empty(nws) if nws else None
+    Y.fill_(float("nan"))
+    args = (X0, X0.shape[-1], c0, X1, X1.shape[-1] if x1 is not None else 0, c1, ups, wp,
+            be.t(b) if b is not None else None, R, R.shape[-1] if r is not None else 0)
+    be.call("mnk_conv3x3_fwd", *args, Y, ldy, n, h, w, cout, ws, nws, st)
     sums = be.empty(2 * cout)
     be.call("mnk_bn_stats_finish", st, nst // (2 * ldy), ldy, cout, sums)
+    Y2 = be.empty(n, h, w, ldy)
+    be.call("mnk_conv3x3_fwd", *args, Y2, ldy, n, h, w, cout, ws, nws, None)
     be.sync()
+    assert torch.equal(Y.cpu(), Y2.cpu())
+    assert relerr(from_nhwc(Y.cpu(), cout), _ref_fwd(case, x0, x1, wt, b, r)) < 2e-6
+    assert torch.all(Y.cpu()[..., cout:] == 0)
     y = from_nhwc(Y.cpu(), cout).double()
     ref = torch.cat([y.sum(dim=(0, 2, 3)), (y * y).sum(dim=(0, 2, 3))])
     assert relerr(sums.cpu(), ref) < 1e-5
