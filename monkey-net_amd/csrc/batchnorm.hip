@@ -108,12 +108,9 @@ __device__ __forceinline__ void colsum2_tail(const Tail& t, const float* partial
     if (t.base < 0) return;
     __shared__ double dsm[256 * 4];
     __shared__ int s_last;
-    __syncthreads();                       // the block's stores have left its waves (workgroup-scope release)
+    __threadfence();                       // this block's partial is visible device-wide before its ticket is
+    __syncthreads();
     if (threadIdx.x == 0) {
-        // one device-scope release per block, by the thread that takes the ticket: the block's partial is written back before
-        // the ticket is visible.  (A __threadfence() by every thread also invalidates the XCD's L2 once per wave -- under the
-        // other blocks' streaming reads: +3.2 ms per training iteration.)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         unsigned* cnt = g_tail_counters + t.base + blockIdx.z * gridDim.x + blockIdx.x;
         const int last = atomicAdd(cnt, 1u) + 1u == gridDim.y;
         if (last) atomicExch(cnt, 0u);
@@ -121,7 +118,7 @@ __device__ __forceinline__ void colsum2_tail(const Tail& t, const float* partial
     }
     __syncthreads();
     if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the other blocks' partials are read after their tickets were seen
+    __threadfence();                       // the other blocks' partials are read after their tickets were seen
     const int RB = gridDim.y;
     const float* pb = partial + (long)blockIdx.z * RB * 2 * ld + q * 4;
     double a[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};

@@ -114,7 +114,6 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline unsigned atomicExch(unsigned* p, unsigned v) { unsigned o = *p; *p = v; return o; }
 static inline void __threadfence() {}       // blocks run one after another here: every store is visible to the next block
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
 
 #define __expf(x) expf(x)
 static inline float __fdividef(float a, float b) { return a / b; }
