@@ -4,17 +4,10 @@
 // HBM-bound: float4 along channels, a 2-D thread map (channel-quad x row) so that every thread keeps its
 // channel quad in registers while it walks rows; column sums are finished in LDS and by a tiny second pass.
 #include <stdlib.h>
-#include <string.h>
-
-#include <mutex>
-#include <unordered_map>
 
 #include "mnk_common.h"
 
 using namespace mnk;
-
-// A/B on the MI355X: profiles/README.md (round 2, last-block second stage)
-int mnk::g_bn_tail = getenv("MNK_BN_TAIL") ? atoi(getenv("MNK_BN_TAIL")) : 3;
 
 namespace {
 
@@ -63,138 +56,10 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int q, int C) {
     return v;
 }
 
-// ---- second stage inside the first: the last block of a column tile finishes the sums ------------------------------------
-// The two-stage column sums above end in a tiny second launch (one per BatchNorm layer and direction: ~85 launches of
-// ~6 us per training iteration).  With a Tail the block that finishes last (a counter per column tile, bumped after a
-// device-scope fence) sums the row-block partials of its column tile itself -- every thread its channel quad over every
-// ty_n-th row block in fp64, combined over the rows of the thread map through LDS, a fixed order whichever block comes
-// last -- and writes the sums (kind 1) or, for a single-process BatchNorm forward, mean / inv-std / scale and the running
-// statistics as well (kind 2).  The counter is left at zero for the next launch.  Counters live in a __device__ pool cut
-// into regions, one per stream the library has seen (kernels of one stream do not overlap; a captured graph keeps the
-// region of its capture stream, like the scratch buffers of mnk/ops.py it is not to be replayed concurrently with
-// another graph captured on the same stream); a launch that needs more counters than a region holds, or the 65th
-// stream, takes the two-launch form.
-constexpr int TAIL_REGION = 256, TAIL_REGIONS = 64;
-__device__ unsigned g_tail_counters[TAIL_REGION * TAIL_REGIONS];
-
-struct Tail {
-    int base;        // index of this launch's counters in g_tail_counters; < 0: no tail (the caller launches the second stage)
-    int kind;        // 1: sums[which][frame][c] for which < nwhich; 2: sums (optional) + BatchNorm finalisation (one frame)
-    int nwhich, C;
-    float* sums;
-    double count;
-    const float* gamma;
-    float* running_mean;
-    float* running_var;
-    float momentum, eps;
-    int update_running;
-    float* mean;
-    float* invstd;
-    float* scale;
-};
-
-static Tail no_tail() {
-    Tail t;
-    memset(&t, 0, sizeof(t));
-    t.base = -1;
-    return t;
-}
-
-// called by every thread of the block after its partial has been stored (block-uniform control flow); KIND = Tail::kind,
-// a compile-time constant so that kernels which only want sums do not carry the finalisation's arguments in registers
-template <int KIND>
-__device__ __forceinline__ void colsum2_tail(const Tail& t, const float* partial, int ld, int nv, int tx_n, int ty_n, int tx,
-                                             int ty, int q) {
-    if (t.base < 0) return;
-    __shared__ double dsm[256 * 4];
-    __shared__ int s_last;
-    __threadfence();                       // this block's partial is visible device-wide before its ticket is
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned* cnt = g_tail_counters + t.base + blockIdx.z * gridDim.x + blockIdx.x;
-        const int last = atomicAdd(cnt, 1u) + 1u == gridDim.y;
-        if (last) atomicExch(cnt, 0u);
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                       // the other blocks' partials are read after their tickets were seen
-    const int RB = gridDim.y;
-    const float* pb = partial + (long)blockIdx.z * RB * 2 * ld + q * 4;
-    double a[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    if (q < nv) {
-#pragma unroll 4
-        for (int rb = ty; rb < RB; rb += ty_n) {
-            const float4 u = *reinterpret_cast<const float4*>(pb + (long)rb * 2 * ld);
-            a[0][0] += (double)u.x;
-            a[0][1] += (double)u.y;
-            a[0][2] += (double)u.z;
-            a[0][3] += (double)u.w;
-            if (t.nwhich > 1) {
-                const float4 v = *reinterpret_cast<const float4*>(pb + ((long)rb * 2 + 1) * ld);
-                a[1][0] += (double)v.x;
-                a[1][1] += (double)v.y;
-                a[1][2] += (double)v.z;
-                a[1][3] += (double)v.w;
-            }
-        }
-    }
-    double r[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k >= t.nwhich) break;          // block-uniform
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dsm[threadIdx.x * 4 + e] = a[k][e];
-        __syncthreads();
-        for (int s = ty_n >> 1; s > 0; s >>= 1) {
-            if (ty < s) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dsm[threadIdx.x * 4 + e] += dsm[(threadIdx.x + s * tx_n) * 4 + e];
-            }
-            __syncthreads();
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[k][e] = dsm[tx * 4 + e];
-        __syncthreads();
-    }
-    if (ty != 0 || q >= nv) return;
-    const int frames = gridDim.z, f = blockIdx.z;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = q * 4 + e;
-        if (c >= t.C) break;
-        const float s1 = (float)r[0][e];
-        if (KIND == 1) {
-            t.sums[(long)f * t.C + c] = s1;
-            if (t.nwhich > 1) t.sums[((long)frames + f) * t.C + c] = (float)r[1][e];
-            continue;
-        }
-        // kind 2: the arithmetic of bn_final_finalize_kernel (sums round-trip through fp32)
-        const float s2 = (float)r[1][e];
-        if (t.sums) {
-            t.sums[c] = s1;
-            t.sums[t.C + c] = s2;
-        }
-        const double m = (double)s1 / t.count;
-        double v = (double)s2 / t.count - m * m;
-        if (v < 0.0) v = 0.0;
-        const float mf = (float)m, vf = (float)v;
-        const float is = 1.0f / sqrtf(vf + t.eps);
-        t.mean[c] = mf;
-        t.invstd[c] = is;
-        t.scale[c] = t.gamma[c] * is;
-        if (t.update_running) {
-            const float unbiased = (float)(v * t.count / (t.count - 1.0));
-            t.running_mean[c] = (1.f - t.momentum) * t.running_mean[c] + t.momentum * mf;
-            t.running_var[c] = (1.f - t.momentum) * t.running_var[c] + t.momentum * unbiased;
-        }
-    }
-}
-
 // partial[rb][which][ld]
-template <class F, int KIND>
+template <class F>
 __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, int nv, int ld, int tx_n, int ty_n,
-                                                              long rows_per_block, float* partial, Tail tail) {
+                                                              long rows_per_block, float* __restrict__ partial) {
     __shared__ float4 red[2][256];
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx;
@@ -230,7 +95,6 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
         *reinterpret_cast<float4*>(o + q * 4) = red[0][tx];
         *reinterpret_cast<float4*>(o + ld + q * 4) = red[1][tx];
     }
-    colsum2_tail<KIND>(tail, partial, ld, nv, tx_n, ty_n, tx, ty, q);
 }
 
 // one wavefront per output column: lanes stride over the row-block partials (fp64 accumulation), the 64 lane sums are
@@ -513,7 +377,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
                                                                double count, int training, int FC,
                                                                float* __restrict__ dy, int ld_dy, long rows, int C,
                                                                int nv, int tx_n, int ty_n, long rows_per_block,
-                                                               float* dy_partial, Tail tail) {
+                                                               float* __restrict__ dy_partial) {
     // dy_partial (optional): [gridDim.y][2][4 * nv] with the column sums of the written dy in slot 0 -- the bias
     // gradient of the convolution in front of this norm layer (Conv3x3Fn.backward), saving its pass over dy
     __shared__ float4 red[256];
@@ -568,7 +432,6 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
         }
         if (ty == 0 && q < nv)
             *reinterpret_cast<float4*>(dy_partial + (long)blockIdx.y * 2 * (4 * nv) + q * 4) = red[tx];
-        colsum2_tail<1>(tail, dy_partial, 4 * nv, nv, tx_n, ty_n, tx, ty, q);
     }
 }
 
@@ -771,20 +634,6 @@ __global__ void __launch_bounds__(256) bn_small_bwd_kernel(BwdLoader L, double c
 
 static inline int small_txn(int nv) { return g_small_txn ? g_small_txn : (nv >= 128 ? 4 : (nv >= 64 ? 2 : 1)); }
 
-// this launch's counters: the region of its stream, or -1 (no region left / more column tiles than a region holds)
-static int tail_base(hipStream_t s, int bit, long need) {
-    if (!(g_bn_tail & bit) || need > TAIL_REGION) return -1;
-    static std::mutex mu;
-    static std::unordered_map<void*, int> regions;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = regions.find((void*)s);
-    if (it != regions.end()) return it->second * TAIL_REGION;
-    if ((int)regions.size() >= TAIL_REGIONS) return -1;
-    const int r = (int)regions.size();
-    regions.emplace((void*)s, r);
-    return r * TAIL_REGION;
-}
-
 static inline int grid_for(long total, int cap = 2048) {
     long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -813,17 +662,10 @@ int mnk_norm_stats(const float* x, int ld, long rows_per_frame, int frames, int 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_STATS, s, (double)rows_per_frame * frames * C * 4);
     StatsLoader L{x, ld};
-    Tail t = no_tail();
-    t.base = tail_base(s, 1, (long)m.col_tiles * frames);
-    t.kind = 1;
-    t.nwhich = 2;
-    t.C = C;
-    t.sums = sums;
-    hipLaunchKernelGGL((colsum2_partial_kernel<StatsLoader, 1>), dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L,
-                       rows_per_frame, ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws, t);
-    if (t.base < 0)
-        hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ld, C,
-                           frames, sums, 2);
+    hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L,
+                       rows_per_frame, ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ld, C,
+                       frames, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -880,17 +722,10 @@ int mnk_norm_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz,
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_BWD, s, (double)N * H * W * C * 4 * (pool ? 1.25 : 2.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, per_frame ? C : 0, slope};
-    Tail t = no_tail();
-    t.base = tail_base(s, 1, (long)m.col_tiles * frames);
-    t.kind = 1;
-    t.nwhich = 2;
-    t.C = C;
-    t.sums = sums;
-    hipLaunchKernelGGL((colsum2_partial_kernel<BwdLoader, 1>), dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L, rows,
-                       ldc / 4, ldc, m.tx, m.ty, m.rows_per_block, ws, t);
-    if (t.base < 0)
-        hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C,
-                           frames, sums, 2);
+    hipLaunchKernelGGL(colsum2_partial_kernel<BwdLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L, rows,
+                       ldc / 4, ldc, m.tx, m.ty, m.rows_per_block, ws);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C,
+                       frames, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -911,8 +746,7 @@ int mnk_norm_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz,
     ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, per_frame ? C : 0, slope};
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
-                       (per_frame ? N : 1) * C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, (float*)nullptr,
-                       no_tail());
+                       (per_frame ? N : 1) * C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, (float*)nullptr);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -936,16 +770,9 @@ int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int l
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, 0, relu ? 0.f : -1.f};
-    Tail t = no_tail();
-    t.base = tail_base(s, 2, m.col_tiles);
-    t.kind = 1;
-    t.nwhich = 1;
-    t.C = C;
-    t.sums = dy_sums;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
-                       C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, ws, t);
-    if (t.base < 0)
-        hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, 1, dy_sums, 1);
+                       C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, ws);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, 1, dy_sums, 1);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -968,28 +795,8 @@ int mnk_bn_stats_finalize(const float* x, int ld, long rows, int C, const float*
             return MNK_EWORKSPACE;
         }
         StatsLoader L{x, ld};
-        Tail t = no_tail();
-        t.base = tail_base(s, 1, m.col_tiles);
-        t.kind = 2;
-        t.nwhich = 2;
-        t.C = C;
-        t.sums = sums;
-        t.count = count;
-        t.gamma = gamma;
-        t.running_mean = running_mean;
-        t.running_var = running_var;
-        t.momentum = momentum;
-        t.eps = eps;
-        t.update_running = update_running;
-        t.mean = mean;
-        t.invstd = invstd;
-        t.scale = scale;
-        hipLaunchKernelGGL((colsum2_partial_kernel<StatsLoader, 2>), dim3(m.col_tiles, m.row_blocks, 1), dim3(256), 0, s, L, rows,
-                           ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws, t);
-        if (t.base >= 0) {
-            MNK_LAUNCH_CHECK();
-            return MNK_OK;
-        }
+        hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, 1), dim3(256), 0, s, L, rows,
+                           ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
         partial = ws;
         row_blocks = m.row_blocks;
     }

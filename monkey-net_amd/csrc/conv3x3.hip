@@ -3319,7 +3319,7 @@ int mnk_set_tuning(const char* name, int value) {
                                                   {"MNK_FORCE_BN", &g_force_bn}, {"MNK_FORCE_SPLITS", &g_force_splits},
                                                   {"MNK_WN16_GROUP_TARGET", &g_wn16_group_target},
                                                   {"MNK_WN16_GROUP_FEW", &g_wn16_group_target_few},
-                                                  {"MNK_SPLITK_STATS", &g_splitk_stats}, {"MNK_BN_TAIL", &g_bn_tail}};
+                                                  {"MNK_SPLITK_STATS", &g_splitk_stats}};
     for (auto& k : knobs)
         if (strcmp(k.n, name) == 0) {
             *k.v = value;

@@ -60,10 +60,6 @@ struct ProfScope {
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-// batchnorm.hip: which two-stage column sums finish in their first launch (bit 0: statistics kernels, bit 1: the dy pass that
-// also sums dy); set from MNK_BN_TAIL at load time, by mnk_set_tuning afterwards
-extern int g_bn_tail;
-
 }  // namespace mnk
 
 #define MNK_REQUIRE(cond)                                                        \

@@ -112,8 +112,6 @@ static inline T __shfl_down(T v, unsigned delta, int width = 64) {
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
-static inline unsigned atomicExch(unsigned* p, unsigned v) { unsigned o = *p; *p = v; return o; }
-static inline void __threadfence() {}       // blocks run one after another here: every store is visible to the next block
 
 #define __expf(x) expf(x)
 static inline float __fdividef(float a, float b) { return a / b; }

@@ -6,17 +6,9 @@ import torch.nn.functional as F
 from _util import to_nhwc, from_nhwc, ceil4, relerr, maxerr
 
 
-@pytest.fixture(params=[3, 0], ids=["one-launch-sums", "two-launch-sums"])
-def tail(be, request):
-    """MNK_BN_TAIL: the last block of a column tile finishes the column sums (3, the default) / a second launch does (0)."""
-    be.lib.call("mnk_set_tuning", b"MNK_BN_TAIL", request.param)
-    yield request.param
-    be.lib.call("mnk_set_tuning", b"MNK_BN_TAIL", 3)
-
-
-@pytest.mark.parametrize("shape", [(2, 5, 6, 4), (3, 45, 4, 6), (2, 300, 2, 2), (1, 64, 16, 16), (4, 20, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 5, 6, 4), (3, 45, 4, 6), (2, 300, 2, 2), (1, 64, 16, 16)])
 @pytest.mark.parametrize("pool", [0, 1])
-def test_bn_train_forward_backward(be, shape, pool, tail):
+def test_bn_train_forward_backward(be, shape, pool):
     n, c, h, w = shape
     g = torch.Generator().manual_seed(3)
     x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
@@ -181,7 +173,7 @@ def test_resize_bilinear(be):
 
 @pytest.mark.parametrize("shape", [(3, 12, 13, 13), (2, 70, 6, 5)])
 @pytest.mark.parametrize("pool", [0, 1])
-def test_instance_norm_leaky_pool(be, shape, pool, tail):
+def test_instance_norm_leaky_pool(be, shape, pool):
     """Per-frame statistics + LeakyReLU(0.2) + avg-pool with odd sizes (the discriminator's DownBlock3D,
     modules/discriminator.py:26-33) through the mnk_norm_* entry points."""
     n, c, h, w = shape
