@@ -97,6 +97,52 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
     }
 }
 
+// A lane's share of one column of the row-block partials: every 64th entry from `lane` on, fp64.  Four entries in flight
+// (a load -> add chain per entry made the second stage of a 1024 ... 2048-partial layer a 16 ... 32-deep latency chain); the
+// order is fixed: four interleaved sub-sums, (s0 + s1) + (s2 + s3).  `stride` = floats between consecutive row blocks.
+__device__ __forceinline__ double lane_colsum(const float* __restrict__ p, int lane, int row_blocks, long stride) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int rb = lane;
+    for (; rb + 192 < row_blocks; rb += 256) {
+        const float v0 = p[(long)rb * stride], v1 = p[(long)(rb + 64) * stride], v2 = p[(long)(rb + 128) * stride],
+                    v3 = p[(long)(rb + 192) * stride];
+        s0 += (double)v0;
+        s1 += (double)v1;
+        s2 += (double)v2;
+        s3 += (double)v3;
+    }
+    for (; rb < row_blocks; rb += 64) s0 += (double)p[(long)rb * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
+// the same for the two sums of one channel at once (eight entries in flight); `q` = p + ld
+__device__ __forceinline__ void lane_colsum_pair(const float* __restrict__ p, int ld, int lane, int row_blocks, long stride,
+                                                 double& a1, double& a2) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    const float* q = p + ld;
+    int rb = lane;
+    for (; rb + 192 < row_blocks; rb += 256) {
+        const float v0 = p[(long)rb * stride], v1 = p[(long)(rb + 64) * stride], v2 = p[(long)(rb + 128) * stride],
+                    v3 = p[(long)(rb + 192) * stride];
+        const float w0 = q[(long)rb * stride], w1 = q[(long)(rb + 64) * stride], w2 = q[(long)(rb + 128) * stride],
+                    w3 = q[(long)(rb + 192) * stride];
+        s0 += (double)v0;
+        s1 += (double)v1;
+        s2 += (double)v2;
+        s3 += (double)v3;
+        t0 += (double)w0;
+        t1 += (double)w1;
+        t2 += (double)w2;
+        t3 += (double)w3;
+    }
+    for (; rb < row_blocks; rb += 64) {
+        s0 += (double)p[(long)rb * stride];
+        t0 += (double)q[(long)rb * stride];
+    }
+    a1 = (s0 + s1) + (s2 + s3);
+    a2 = (t0 + t1) + (t2 + t3);
+}
+
 // one wavefront per output column: lanes stride over the row-block partials (fp64 accumulation), the 64 lane sums are
 // combined through LDS.  (A serial loop per column was 44 % of the step time in the first MI355X profile.)
 __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restrict__ partial, int row_blocks, int ld,
@@ -111,7 +157,7 @@ __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restr
         const int which = i / FC, rem = i - which * FC;
         const int f = rem / C, c = rem - f * C;
         const float* pb = partial + (long)f * row_blocks * 2 * ld;
-        for (int rb = lane; rb < row_blocks; rb += 64) acc += (double)pb[((long)rb * 2 + which) * ld + c];
+        acc = lane_colsum(pb + (long)which * ld + c, lane, row_blocks, 2L * ld);
     }
     sm[threadIdx.x] = acc;
     __syncthreads();
@@ -236,11 +282,9 @@ __global__ void __launch_bounds__(256) bn_final_finalize_kernel(const float* __r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wave;
     double a1 = 0.0, a2 = 0.0;
-    if (c < C)
-        for (int rb = lane; rb < row_blocks; rb += 64) {
-            a1 += (double)partial[((long)rb * 2 + 0) * ld + c];
-            a2 += (double)partial[((long)rb * 2 + 1) * ld + c];
-        }
+    if (c < C) {
+        lane_colsum_pair(partial + c, ld, lane, row_blocks, 2L * ld, a1, a2);      // the bits of lane_colsum per sum
+    }
     sm[0][threadIdx.x] = a1;
     sm[1][threadIdx.x] = a2;
     __syncthreads();

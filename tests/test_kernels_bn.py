@@ -71,6 +71,37 @@ def test_bn_train_forward_backward(be, shape, pool):
     assert maxerr(dys.cpu(), ref_sum) <= 1e-5 * float(DY.cpu().abs().double().reshape(-1, ld).sum(0).max()) + 1e-6
 
 
+@pytest.mark.parametrize("row_blocks", [1, 63, 257, 700, 2048])
+def test_second_stage_over_many_row_block_partials(be, row_blocks):
+    """The second stage alone (mnk_bn_stats_finish, and fused with the finalisation: mnk_bn_stats_finalize on partials a conv
+    epilogue left) over as many row blocks as the 64 x 64-tile launches of the 64^2 layers leave: fp64-exact column sums, and
+    the two forms agree to the bit."""
+    c, ld = 13, 16
+    g = torch.Generator().manual_seed(8)
+    part = torch.randn(row_blocks, 2, ld, generator=g) * 3
+    part[:, 1] = part[:, 1].abs() * 40 + 50            # sums of squares: large against the sums, so that variances are positive
+    ref = part.double().sum(0)[:, :c]
+    count = 64.0 * row_blocks
+    P = be.t(part)
+    sums = be.empty(2 * c)
+    be.call("mnk_bn_stats_finish", P, row_blocks, ld, c, sums)
+    gamma = torch.rand(c, generator=g) + 0.5
+    mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+    RM, RV = be.zeros(c), be.zeros(c) + 1
+    be.call("mnk_bn_finalize", sums, count, be.t(gamma), RM, RV, 0.1, 1e-5, c, 1, mean, invstd, scale)
+    m2, i2, s2, sums2 = be.empty(c), be.empty(c), be.empty(c), be.empty(2 * c)
+    RM2, RV2 = be.zeros(c), be.zeros(c) + 1
+    be.call("mnk_bn_stats_finalize", None, ld, 0, c, P, row_blocks, count, be.t(gamma), RM2, RV2, 0.1, 1e-5, 1, sums2, m2, i2,
+            s2, None, 0)
+    be.sync()
+    assert torch.equal(sums.cpu(), ref.float().reshape(-1))          # fp64 accumulation, one rounding
+    for a, b in ((m2, mean), (i2, invstd), (s2, scale), (sums2, sums), (RM2, RM), (RV2, RV)):
+        assert torch.equal(a.cpu(), b.cpu())
+    m = ref[0] / count
+    assert maxerr(mean.cpu(), m) < 1e-6 * (1 + float(m.abs().max()))
+    assert relerr(invstd.cpu(), 1 / torch.sqrt(ref[1] / count - m * m + 1e-5)) < 1e-5
+
+
 def test_bn_eval(be):
     n, c, h, w = 2, 13, 4, 4
     g = torch.Generator().manual_seed(4)
