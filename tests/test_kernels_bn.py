@@ -284,6 +284,33 @@ def test_bn_small_layer_one_launch_forms(be, shape, pool):
     assert torch.all(DY.cpu()[..., c:] == 0)
 
 
+@pytest.mark.parametrize("splits", [1, 3, 4, 7, 8, 13, 21])
+def test_bn_small_adds_any_number_of_split_partials_in_order(be, splits):
+    """mnk_bn_small_fwd on synthetic [split][M][ldw] partials: y == bias + the partials added one after another in fp32 (the
+    kernel fetches eight / four of them ahead of the adds; the order of the adds is the plain loop's), then BatchNorm + ReLU."""
+    n, h, w, c = 2, 4, 6, 22
+    ld, rows = ceil4(c), 2 * 4 * 6
+    g = torch.Generator().manual_seed(splits)
+    part = torch.randn(splits, rows, ld, generator=g)
+    b = torch.randn(c, generator=g)
+    y = torch.zeros(rows, ld)
+    y[:, :c] = b
+    for sp in range(splits):
+        y = y + part[sp]                                  # fp32, in order
+    y[:, c:] = 0
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    yd = y[:, :c].double().reshape(n, h, w, c).permute(0, 3, 1, 2)
+    zref = F.relu(F.batch_norm(yd, torch.zeros(c).double(), torch.ones(c).double(), gamma.double(), beta.double(), True, 0.1, 1e-5))
+    Y, Z = be.empty(n, h, w, ld), be.empty(n, h, w, ld)
+    mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+    RM, RV = be.zeros(c), be.zeros(c) + 1
+    be.call("mnk_bn_small_fwd", be.t(part), splits, ld, 1, be.t(b), Y, ld, n, h, w, c, be.t(gamma), be.t(beta), RM, RV,
+            0.1, 1e-5, mean, invstd, scale, Z, ld, 1, 0)
+    be.sync()
+    assert torch.equal(Y.cpu().reshape(rows, ld), y)
+    assert maxerr(from_nhwc(Z.cpu(), c), zref) < 2e-5
+
+
 @pytest.mark.parametrize("up", [0, 1], ids=["3x3", "sub-pixel-up"])
 def test_bn_small_sums_the_split_k_partials_of_the_convolution_in_front(be, up):
     """a split-K convolution (few output tiles) run with MNK_CONV_DEFER_SPLITK leaves [split][phase][M][ldw] partials; the

@@ -1,5 +1,5 @@
 #!/bin/bash
-# visit 40: second-stage column sums with four / eight partials in flight: BN kernel tests, the step, per-kernel times
+# visit 40 / 41: second-stage column sums with four / eight partials in flight; split partials fetched ahead in bn_small_fwd: BN kernel tests, the step, per-kernel times
 OUT=gpurun_out/v40; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_kernels_bn.py tests/test_kernels_conv.py -m gpu -x -q 2>&1 | tail -2
 for i in 1 2; do timeout 200 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-profile 2>/dev/null | grep -o '"ms_per_step": [0-9.]*'; done
