@@ -498,6 +498,10 @@ static int small_env(const char* name, int dflt) {
 // blocks walking 32+ rows each is slower than four well-filled launches
 static int g_small_rows = small_env("MNK_BN_SMALL_ROWS", 512);
 static int g_small_txn = small_env("MNK_BN_SMALL_TXN", 1);           // channel quads per block: 0 = by channel count
+// forward kernel only: threads per block (256 / 512 / 1024) and channel quads per block when a convolution's split-K
+// partials are summed (the strided 16-byte reads of one quad per block use an eighth of every 128-byte line they touch)
+static int g_small_fwd_threads = small_env("MNK_BN_SMALL_FWD_THREADS", 256);
+static int g_small_fwd_txn = small_env("MNK_BN_SMALL_FWD_TXN", 0);   // 0: as MNK_BN_SMALL_TXN
 
 __device__ __forceinline__ void small_tree_sum2(float4* red0, float4* red1, float4& a, float4& b, int tx_n, int ty_n, int tx,
                                                 int ty) {
@@ -529,9 +533,9 @@ struct SmallFwdArgs {
     int ld_z, relu, pool, tx_n;
 };
 
-__global__ void __launch_bounds__(256) bn_small_fwd_kernel(SmallFwdArgs a) {
-    __shared__ float4 red0[256], red1[256];
-    const int tx_n = a.tx_n, ty_n = 256 / tx_n;
+__global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) {
+    __shared__ float4 red0[1024], red1[1024];
+    const int tx_n = a.tx_n, ty_n = blockDim.x / tx_n;
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int nv = a.ld_y / 4, q = blockIdx.x * tx_n + tx;
     const bool qok = q < nv;
@@ -938,7 +942,9 @@ int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const flo
     ProfScope prof(K_BN_APPLY, s, (double)N * H * W * C * 4 * 3.0);
     SmallFwdArgs a{ws, splits, ldw, phases, bias, y, ld_y, N, H, W, C, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, z, ld_z, relu, pool, small_txn(ld_y / 4)};
-    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(ld_y / 4, a.tx_n)), dim3(256), 0, s, a);
+    if (g_small_fwd_txn > 0) a.tx_n = g_small_fwd_txn;
+    const int threads = (g_small_fwd_threads == 512 || g_small_fwd_threads == 1024) ? g_small_fwd_threads : 256;
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(ld_y / 4, a.tx_n)), dim3(threads), 0, s, a);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
