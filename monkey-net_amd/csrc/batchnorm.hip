@@ -498,10 +498,13 @@ static int small_env(const char* name, int dflt) {
 // blocks walking 32+ rows each is slower than four well-filled launches
 static int g_small_rows = small_env("MNK_BN_SMALL_ROWS", 512);
 static int g_small_txn = small_env("MNK_BN_SMALL_TXN", 1);           // channel quads per block: 0 = by channel count
-// forward kernel only: threads per block (256 / 512 / 1024) and channel quads per block when a convolution's split-K
-// partials are summed (the strided 16-byte reads of one quad per block use an eighth of every 128-byte line they touch)
-static int g_small_fwd_threads = small_env("MNK_BN_SMALL_FWD_THREADS", 256);
-static int g_small_fwd_txn = small_env("MNK_BN_SMALL_FWD_TXN", 0);   // 0: as MNK_BN_SMALL_TXN
+// forward kernel: threads per block (256 / 512 / 1024) and channel quads per block.  It sums the split-K partials of the
+// convolution in front (8 ... 32 x rows x C floats): with one quad per block every lane reads 16 of the 128 bytes of its
+// line and a block of 256 threads is one wave per SIMD.  1024 threads over up to 8 quads (a full line per row, at least
+// 32 blocks) is the measured setting: 11.25 -> 11.19 ms per iteration (profiles/r02_knob_ab_log.txt, visit 42);
+// MNK_BN_SMALL_FWD_TXN = 0: by channel count, -1: as MNK_BN_SMALL_TXN
+static int g_small_fwd_threads = small_env("MNK_BN_SMALL_FWD_THREADS", 1024);
+static int g_small_fwd_txn = small_env("MNK_BN_SMALL_FWD_TXN", 0);
 
 __device__ __forceinline__ void small_tree_sum2(float4* red0, float4* red1, float4& a, float4& b, int tx_n, int ty_n, int tx,
                                                 int ty) {
@@ -942,7 +945,11 @@ int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const flo
     ProfScope prof(K_BN_APPLY, s, (double)N * H * W * C * 4 * 3.0);
     SmallFwdArgs a{ws, splits, ldw, phases, bias, y, ld_y, N, H, W, C, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, z, ld_z, relu, pool, small_txn(ld_y / 4)};
-    if (g_small_fwd_txn > 0) a.tx_n = g_small_fwd_txn;
+    if (g_small_fwd_txn > 0)
+        a.tx_n = g_small_fwd_txn;
+    else if (g_small_fwd_txn == 0)
+        for (a.tx_n = 8; a.tx_n > 1 && (ld_y / 4) / a.tx_n < 32; a.tx_n >>= 1) {}
+    MNK_REQUIRE(a.tx_n >= 1 && a.tx_n <= 64 && (a.tx_n & (a.tx_n - 1)) == 0);
     const int threads = (g_small_fwd_threads == 512 || g_small_fwd_threads == 1024) ? g_small_fwd_threads : 256;
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(ld_y / 4, a.tx_n)), dim3(threads), 0, s, a);
     MNK_LAUNCH_CHECK();
