@@ -505,6 +505,7 @@ static int g_small_txn = small_env("MNK_BN_SMALL_TXN", 1);           // channel 
 // MNK_BN_SMALL_FWD_TXN = 0: by channel count, -1: as MNK_BN_SMALL_TXN
 static int g_small_fwd_threads = small_env("MNK_BN_SMALL_FWD_THREADS", 1024);
 static int g_small_fwd_txn = small_env("MNK_BN_SMALL_FWD_TXN", 0);
+static int g_small_bwd_shape = small_env("MNK_BN_SMALL_BWD_SHAPE", 1);   // 1: the backward kernel takes the same shape; 0: 256 x MNK_BN_SMALL_TXN
 
 __device__ __forceinline__ void small_tree_sum2(float4* red0, float4* red1, float4& a, float4& b, int tx_n, int ty_n, int tx,
                                                 int ty) {
@@ -654,10 +655,10 @@ __global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(256) bn_small_bwd_kernel(BwdLoader L, double count, int rows, int nv, int tx_n,
-                                                           float* __restrict__ sums, float* __restrict__ dy, int ld_dy) {
-    __shared__ float4 red0[256], red1[256];
-    const int ty_n = 256 / tx_n;
+__global__ void __launch_bounds__(1024) bn_small_bwd_kernel(BwdLoader L, double count, int rows, int nv, int tx_n,
+                                                            float* __restrict__ sums, float* __restrict__ dy, int ld_dy) {
+    __shared__ float4 red0[1024], red1[1024];
+    const int ty_n = blockDim.x / tx_n;
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx;
     const bool qok = q < nv;
@@ -704,6 +705,16 @@ __global__ void __launch_bounds__(256) bn_small_bwd_kernel(BwdLoader L, double c
 }
 
 static inline int small_txn(int nv) { return g_small_txn ? g_small_txn : (nv >= 128 ? 4 : (nv >= 64 ? 2 : 1)); }
+
+// launch shape of the two one-launch kernels: threads per block and channel quads per block (see g_small_fwd_threads)
+static inline void small_shape(int nv, int* threads, int* tx_n) {
+    *tx_n = small_txn(nv);
+    if (g_small_fwd_txn > 0)
+        *tx_n = g_small_fwd_txn;
+    else if (g_small_fwd_txn == 0)
+        for (*tx_n = 8; *tx_n > 1 && nv / *tx_n < 32; *tx_n >>= 1) {}
+    *threads = (g_small_fwd_threads == 512 || g_small_fwd_threads == 1024) ? g_small_fwd_threads : 256;
+}
 
 static inline int grid_for(long total, int cap = 2048) {
     long b = (total + 255) / 256;
@@ -945,12 +956,9 @@ int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const flo
     ProfScope prof(K_BN_APPLY, s, (double)N * H * W * C * 4 * 3.0);
     SmallFwdArgs a{ws, splits, ldw, phases, bias, y, ld_y, N, H, W, C, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, z, ld_z, relu, pool, small_txn(ld_y / 4)};
-    if (g_small_fwd_txn > 0)
-        a.tx_n = g_small_fwd_txn;
-    else if (g_small_fwd_txn == 0)
-        for (a.tx_n = 8; a.tx_n > 1 && (ld_y / 4) / a.tx_n < 32; a.tx_n >>= 1) {}
+    int threads;
+    small_shape(ld_y / 4, &threads, &a.tx_n);
     MNK_REQUIRE(a.tx_n >= 1 && a.tx_n <= 64 && (a.tx_n & (a.tx_n - 1)) == 0);
-    const int threads = (g_small_fwd_threads == 512 || g_small_fwd_threads == 1024) ? g_small_fwd_threads : 256;
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(ld_y / 4, a.tx_n)), dim3(threads), 0, s, a);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
@@ -964,9 +972,12 @@ int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const
     MNK_REQUIRE((long)N * H * W <= 4096 && (!pool || (H % 2 == 0 && W % 2 == 0)));
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_BWD, s, (double)N * H * W * C * 4 * 5.0);
-    const int nv = round_up(C, 4) / 4, txn = small_txn(nv);
+    const int nv = round_up(C, 4) / 4;
+    int threads = 256, txn = small_txn(nv);
+    if (g_small_bwd_shape) small_shape(nv, &threads, &txn);
+    MNK_REQUIRE(txn >= 1 && txn <= 64 && (txn & (txn - 1)) == 0);
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, 0, H, W, C, pool, 0, relu ? 0.f : -1.f};
-    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(ceil_div(nv, txn)), dim3(256), 0, s, L, count, N * H * W, nv, txn, sums, dy, ld_dy);
+    hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(ceil_div(nv, txn)), dim3(threads), 0, s, L, count, N * H * W, nv, txn, sums, dy, ld_dy);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

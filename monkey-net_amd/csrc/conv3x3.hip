@@ -812,6 +812,7 @@ struct RSMap {
     int tx, ty, col_tiles, row_blocks;
     long rows_per_block;
 };
+static int g_rs_rpt = getenv("MNK_RS_RPT") ? atoi(getenv("MNK_RS_RPT")) : 4;      // rows per thread before a layer is cut into more row blocks
 static RSMap make_rsmap(long rows, int ld) {
     RSMap m;
     const int nv = ld / 4;
@@ -822,7 +823,7 @@ static RSMap make_rsmap(long rows, int ld) {
     m.col_tiles = (nv + tx - 1) / tx;
     long want = 1024 / m.col_tiles;
     if (want < 1) want = 1;
-    const long min_rows = (long)m.ty * 4;
+    const long min_rows = (long)m.ty * (g_rs_rpt > 0 ? g_rs_rpt : 4);
     long rb = (rows + min_rows - 1) / min_rows;
     if (rb > want) rb = want;
     if (rb < 1) rb = 1;
