@@ -812,7 +812,8 @@ struct RSMap {
     int tx, ty, col_tiles, row_blocks;
     long rows_per_block;
 };
-static int g_rs_rpt = getenv("MNK_RS_RPT") ? atoi(getenv("MNK_RS_RPT")) : 4;      // rows per thread before a layer is cut into more row blocks
+// rows per thread before a layer is cut into more row blocks (A/B, visit 43: 1 / 2 / 4 / 8 -> 11.18 / 11.16 / 11.18 / 11.26 ms)
+static int g_rs_rpt = getenv("MNK_RS_RPT") ? atoi(getenv("MNK_RS_RPT")) : 2;
 static RSMap make_rsmap(long rows, int ld) {
     RSMap m;
     const int nv = ld / 4;
@@ -823,7 +824,7 @@ static RSMap make_rsmap(long rows, int ld) {
     m.col_tiles = (nv + tx - 1) / tx;
     long want = 1024 / m.col_tiles;
     if (want < 1) want = 1;
-    const long min_rows = (long)m.ty * (g_rs_rpt > 0 ? g_rs_rpt : 4);
+    const long min_rows = (long)m.ty * (g_rs_rpt > 0 ? g_rs_rpt : 2);
     long rb = (rows + min_rows - 1) / min_rows;
     if (rb > want) rb = want;
     if (rb < 1) rb = 1;
