@@ -783,6 +783,68 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict
     }
 }
 
+// The same with one lane per CHANNEL (lanes cl, cl + CL, ... of a pixel walk channels c = cl, cl + CL, ...): an atomic
+// instruction of the kernel above carries one float of every 16 bytes (four instructions per line of dinp), here the CL
+// lanes of a pixel add to CL consecutive floats -- a quarter of the atomic requests per line of the scattered gradient.
+__global__ void __launch_bounds__(256) deform_bwd_chan_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                              const float* __restrict__ field, int hf, int wf, int mode,
+                                                              const float* __restrict__ dout, int ld_out, int out_off,
+                                                              float* __restrict__ dinp, float* __restrict__ dfield, int N,
+                                                              int CL) {
+    const long P = (long)h * w;
+    const long npix = (long)N * P;
+    const int ppb = 256 / CL;   // pixels per block iteration
+    const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
+    const long iters = (npix + ppb - 1) / ppb;
+    for (long it = blockIdx.x; it < iters; it += gridDim.x) {
+        const long np = it * ppb + pl;
+        const bool live = np < npix;
+        float gix = 0.f, giy = 0.f;
+        FieldAt fa;
+        fa.n = 0;
+        long n = 0;
+        if (live) {
+            const int p = (int)(np % P);
+            n = np / P;
+            fa.eval(field, n, hf, wf, p / w, p % w, h, w, mode);
+            Bilin bl;
+            bl.setup(fa.x, fa.y, w, h);
+            const float* ib = inp + n * P * ld_in;
+            float* db = dinp ? dinp + n * P * ld_in : nullptr;
+            const long o_nw = ((long)bl.y0 * w + bl.x0) * ld_in, o_ne = o_nw + ld_in;
+            const long o_sw = o_nw + (long)w * ld_in, o_se = o_sw + ld_in;
+            const bool k_nw = bl.y0ok && bl.x0ok, k_ne = bl.y0ok && bl.x1ok, k_sw = bl.y1ok && bl.x0ok, k_se = bl.y1ok && bl.x1ok;
+            const float* gp = dout + np * ld_out + out_off;
+            for (int c = cl; c < C; c += CL) {
+                const float go = gp[c];
+                const float vnw = k_nw ? ib[o_nw + c] : 0.f, vne = k_ne ? ib[o_ne + c] : 0.f;
+                const float vsw = k_sw ? ib[o_sw + c] : 0.f, vse = k_se ? ib[o_se + c] : 0.f;
+                gix += go * ((vne - vnw) * (1.f - bl.ty) + (vse - vsw) * bl.ty);
+                giy += go * ((vsw - vnw) * (1.f - bl.tx) + (vse - vne) * bl.tx);
+                if (db) {
+                    if (k_nw) atomicAdd(db + o_nw + c, go * bl.wnw);
+                    if (k_ne) atomicAdd(db + o_ne + c, go * bl.wne);
+                    if (k_sw) atomicAdd(db + o_sw + c, go * bl.wsw);
+                    if (k_se) atomicAdd(db + o_se + c, go * bl.wse);
+                }
+            }
+        }
+        for (int o = CL >> 1; o > 0; o >>= 1) {
+            gix += __shfl_xor(gix, o);
+            giy += __shfl_xor(giy, o);
+        }
+        if (live && cl == 0 && dfield) {
+            gix *= (float)(w - 1) * 0.5f;
+            giy *= (float)(h - 1) * 0.5f;
+            float* fb = dfield + n * hf * wf * 2;
+            for (int j = 0; j < fa.n; ++j) {
+                atomicAdd(fb + fa.idx[j] * 2, gix * fa.wgt[j]);
+                atomicAdd(fb + fa.idx[j] * 2 + 1, giy * fa.wgt[j]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -847,6 +909,7 @@ int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy
 
 // the row-tile forms apply (see conv1x1_rows_fwd_kernel); MNK_CONV1X1_ROWS=0: the thread-per-pixel kernels (A/B runs)
 static int g_c11_rows = getenv("MNK_CONV1X1_ROWS") ? atoi(getenv("MNK_CONV1X1_ROWS")) : 1;
+static int g_deform_bwd_chan = getenv("MNK_DEFORM_BWD_CHAN") ? atoi(getenv("MNK_DEFORM_BWD_CHAN")) : 1;   // deform_bwd_chan_kernel
 static bool c11_rows_form(const float* x, int ld_x, int Cin) {
     return g_c11_rows && ld_x % 4 == 0 && ld_x <= C11_MAXLD && Cin + 1 <= 128 && (size_t)x % 16 == 0;
 }
@@ -980,13 +1043,19 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
     MNK_REQUIRE(ld_in % 4 == 0 && ld_in >= round_up(C, 4) && out_off >= 0 && out_off + C <= ld_out);
     MNK_REQUIRE(dinp || dfield);
     hipStream_t s = (hipStream_t)stream;
-    const int nq = (C + 3) / 4;
+    const int nq = (C + 3) / 4, lanes_of = g_deform_bwd_chan ? C : nq;
     int CL = 1;
-    while (CL < nq && CL < 64) CL <<= 1;
+    while (CL < lanes_of && CL < 64) CL <<= 1;
     const long iters = ((long)N * h * w + (256 / CL) - 1) / (256 / CL);
     ProfScope prof(K_DEFORM, s, (double)N * h * w * C * 12);
-    hipLaunchKernelGGL(deform_bwd_kernel, dim3((int)(iters < 4096 ? iters : 4096)), dim3(256), 0, s, inp, ld_in, C, h, w,
-                       field, hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL);
+    const int cap = g_deform_bwd_chan ? 16384 : 4096;
+    const dim3 grid((int)(iters < cap ? iters : cap));
+    if (g_deform_bwd_chan)
+        hipLaunchKernelGGL(deform_bwd_chan_kernel, grid, dim3(256), 0, s, inp, ld_in, C, h, w, field, hf, wf, mode, dout, ld_out,
+                           out_off, dinp, dfield, N, CL);
+    else
+        hipLaunchKernelGGL(deform_bwd_kernel, grid, dim3(256), 0, s, inp, ld_in, C, h, w, field, hf, wf, mode, dout, ld_out,
+                           out_off, dinp, dfield, N, CL);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
