@@ -711,82 +711,12 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(const float* __restrict
     }
 }
 
-// CL lanes (power of two <= 64) cooperate on one pixel: each walks channel quads q = cl, cl+CL, ...; the
-// per-pixel sums over channels (d out / d grid) are finished with wavefront shuffles.
+// CL lanes (power of two <= 64) cooperate on one pixel: each walks channels c = cl, cl + CL, ...; the per-pixel sums over
+// channels (d out / d grid) are finished with wavefront shuffles.  One lane per CHANNEL, not per channel quad: the CL lanes
+// of a pixel then add to CL consecutive floats of the scattered gradient -- a quarter of the atomic requests per line that
+// float4-wide lanes make (four instructions, each carrying one float of every 16 bytes): 11.11 -> 11.00 ms per training
+// iteration against that form (profiles/r02_knob_ab_log.txt, visit 44).
 __global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
-                                                         const float* __restrict__ field, int hf, int wf, int mode,
-                                                         const float* __restrict__ dout, int ld_out, int out_off,
-                                                         float* __restrict__ dinp, float* __restrict__ dfield, int N,
-                                                         int CL) {
-    const int nq = (C + 3) / 4;
-    const long P = (long)h * w;
-    const long npix = (long)N * P;
-    const int ppb = 256 / CL;   // pixels per block iteration
-    const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
-    const long iters = (npix + ppb - 1) / ppb;
-    for (long it = blockIdx.x; it < iters; it += gridDim.x) {
-        const long np = it * ppb + pl;
-        const bool live = np < npix;
-        float gix = 0.f, giy = 0.f;
-        FieldAt fa;
-        fa.n = 0;
-        long n = 0;
-        if (live) {
-            const int p = (int)(np % P);
-            n = np / P;
-            fa.eval(field, n, hf, wf, p / w, p % w, h, w, mode);
-            Bilin bl;
-            bl.setup(fa.x, fa.y, w, h);
-            const float* ib = inp + n * P * ld_in;
-            float* db = dinp ? dinp + n * P * ld_in : nullptr;
-            for (int q = cl; q < nq; q += CL) {
-                const float* gp = dout + np * ld_out + out_off + q * 4;
-                const int rem = C - q * 4;
-                float go[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) go[j] = j < rem ? gp[j] : 0.f;
-                float4 nw = make_float4(0.f, 0.f, 0.f, 0.f), ne = nw, sw = nw, se = nw;
-                const long o_nw = ((long)bl.y0 * w + bl.x0) * ld_in + q * 4, o_ne = o_nw + ld_in;
-                const long o_sw = o_nw + (long)w * ld_in, o_se = o_sw + ld_in;
-                if (bl.y0ok && bl.x0ok) nw = *reinterpret_cast<const float4*>(ib + o_nw);
-                if (bl.y0ok && bl.x1ok) ne = *reinterpret_cast<const float4*>(ib + o_ne);
-                if (bl.y1ok && bl.x0ok) sw = *reinterpret_cast<const float4*>(ib + o_sw);
-                if (bl.y1ok && bl.x1ok) se = *reinterpret_cast<const float4*>(ib + o_se);
-                const float vnw[4] = {nw.x, nw.y, nw.z, nw.w}, vne[4] = {ne.x, ne.y, ne.z, ne.w};
-                const float vsw[4] = {sw.x, sw.y, sw.z, sw.w}, vse[4] = {se.x, se.y, se.z, se.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    gix += go[j] * ((vne[j] - vnw[j]) * (1.f - bl.ty) + (vse[j] - vsw[j]) * bl.ty);
-                    giy += go[j] * ((vsw[j] - vnw[j]) * (1.f - bl.tx) + (vse[j] - vne[j]) * bl.tx);
-                    if (db && j < rem) {
-                        if (bl.y0ok && bl.x0ok) atomicAdd(db + o_nw + j, go[j] * bl.wnw);
-                        if (bl.y0ok && bl.x1ok) atomicAdd(db + o_ne + j, go[j] * bl.wne);
-                        if (bl.y1ok && bl.x0ok) atomicAdd(db + o_sw + j, go[j] * bl.wsw);
-                        if (bl.y1ok && bl.x1ok) atomicAdd(db + o_se + j, go[j] * bl.wse);
-                    }
-                }
-            }
-        }
-        for (int o = CL >> 1; o > 0; o >>= 1) {
-            gix += __shfl_xor(gix, o);
-            giy += __shfl_xor(giy, o);
-        }
-        if (live && cl == 0 && dfield) {
-            gix *= (float)(w - 1) * 0.5f;
-            giy *= (float)(h - 1) * 0.5f;
-            float* fb = dfield + n * hf * wf * 2;
-            for (int j = 0; j < fa.n; ++j) {
-                atomicAdd(fb + fa.idx[j] * 2, gix * fa.wgt[j]);
-                atomicAdd(fb + fa.idx[j] * 2 + 1, giy * fa.wgt[j]);
-            }
-        }
-    }
-}
-
-// The same with one lane per CHANNEL (lanes cl, cl + CL, ... of a pixel walk channels c = cl, cl + CL, ...): an atomic
-// instruction of the kernel above carries one float of every 16 bytes (four instructions per line of dinp), here the CL
-// lanes of a pixel add to CL consecutive floats -- a quarter of the atomic requests per line of the scattered gradient.
-__global__ void __launch_bounds__(256) deform_bwd_chan_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
                                                               const float* __restrict__ field, int hf, int wf, int mode,
                                                               const float* __restrict__ dout, int ld_out, int out_off,
                                                               float* __restrict__ dinp, float* __restrict__ dfield, int N,
@@ -909,7 +839,6 @@ int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy
 
 // the row-tile forms apply (see conv1x1_rows_fwd_kernel); MNK_CONV1X1_ROWS=0: the thread-per-pixel kernels (A/B runs)
 static int g_c11_rows = getenv("MNK_CONV1X1_ROWS") ? atoi(getenv("MNK_CONV1X1_ROWS")) : 1;
-static int g_deform_bwd_chan = getenv("MNK_DEFORM_BWD_CHAN") ? atoi(getenv("MNK_DEFORM_BWD_CHAN")) : 1;   // deform_bwd_chan_kernel
 static bool c11_rows_form(const float* x, int ld_x, int Cin) {
     return g_c11_rows && ld_x % 4 == 0 && ld_x <= C11_MAXLD && Cin + 1 <= 128 && (size_t)x % 16 == 0;
 }
@@ -1043,19 +972,12 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
     MNK_REQUIRE(ld_in % 4 == 0 && ld_in >= round_up(C, 4) && out_off >= 0 && out_off + C <= ld_out);
     MNK_REQUIRE(dinp || dfield);
     hipStream_t s = (hipStream_t)stream;
-    const int nq = (C + 3) / 4, lanes_of = g_deform_bwd_chan ? C : nq;
     int CL = 1;
-    while (CL < lanes_of && CL < 64) CL <<= 1;
+    while (CL < C && CL < 64) CL <<= 1;
     const long iters = ((long)N * h * w + (256 / CL) - 1) / (256 / CL);
     ProfScope prof(K_DEFORM, s, (double)N * h * w * C * 12);
-    const int cap = g_deform_bwd_chan ? 16384 : 4096;
-    const dim3 grid((int)(iters < cap ? iters : cap));
-    if (g_deform_bwd_chan)
-        hipLaunchKernelGGL(deform_bwd_chan_kernel, grid, dim3(256), 0, s, inp, ld_in, C, h, w, field, hf, wf, mode, dout, ld_out,
-                           out_off, dinp, dfield, N, CL);
-    else
-        hipLaunchKernelGGL(deform_bwd_kernel, grid, dim3(256), 0, s, inp, ld_in, C, h, w, field, hf, wf, mode, dout, ld_out,
-                           out_off, dinp, dfield, N, CL);
+    hipLaunchKernelGGL(deform_bwd_kernel, dim3((int)(iters < 16384 ? iters : 16384)), dim3(256), 0, s, inp, ld_in, C, h, w, field,
+                       hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
