@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
     if (q < nv) {
         typename F::State st;         // per-thread channel constants (the column quad q is fixed per thread)
         f.init(st);
-#pragma unroll 4
+#pragma unroll 2
         for (long r = r0 + ty; r < r1; r += ty_n) {
             float4 va, vb;
             f(r, q, st, va, vb);
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
     float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), k1 = sc, k2 = sc;
     BwdLoader::State st;
     L.init(st);
-#pragma unroll 4
+#pragma unroll 2
     for (long r = r0 + ty; r < r1; r += ty_n) {
         const long po = L.poff(r);
         if (po != cur) {            // (re)load the per-channel constants: once for BatchNorm, once per frame otherwise
