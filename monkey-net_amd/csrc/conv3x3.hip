@@ -868,13 +868,15 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const 
                     g[e].w += v.w;
                 }
             }
-            for (int e = 0; s < splits; ++s, ++e) {
-                const float4 v = *reinterpret_cast<const float4*>(p + (long)s * sstride);
-                g[e].x += v.x;
-                g[e].y += v.y;
-                g[e].z += v.z;
-                g[e].w += v.w;
-            }
+#pragma unroll
+            for (int e = 0; e < 3; ++e)          // up to three left over: compile-time indices keep g[] in registers
+                if (s + e < splits) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (long)(s + e) * sstride);
+                    g[e].x += v.x;
+                    g[e].y += v.y;
+                    g[e].z += v.z;
+                    g[e].w += v.w;
+                }
             long orow = m;
             if (phases > 1) {
                 const long ph = m / M, mm = m - ph * M;
