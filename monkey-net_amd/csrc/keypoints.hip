@@ -4,6 +4,8 @@
 //   mnk_movement_embedding_*: MovementEmbeddingModule.forward (movement_embedding.py:42-92) incl. kp2gaussian
 //                             (keypoint_detector.py:7-40) and the translation grid_sample (:76-87)
 // All HBM/L2-bound; spatial reductions use wavefront shuffles + one LDS hop across the 4 waves of a block.
+#include <stdlib.h>
+
 #include "mnk_common.h"
 
 using namespace mnk;
@@ -62,13 +64,16 @@ struct BlockRed {
 
 // one block per frame; all K channels of a pixel are contiguous (NHWC), so a pixel is one 16..64 B read
 __global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __restrict__ heat, int ld, int H, int W,
-                                                             int K, float temperature, float* __restrict__ mean,
-                                                             float* __restrict__ var, float* __restrict__ stat) {
+                                                             int Kall, int kg, float temperature,
+                                                             float* __restrict__ mean, float* __restrict__ var,
+                                                             float* __restrict__ stat) {
     __shared__ float red_mem[4 * MAXK];
     BlockRed br{red_mem};
-    const int n = blockIdx.x, t = threadIdx.x;
+    // blockIdx.y = group of kg key-point channels (all of them: one block per frame): K = channels of this block
+    const int n = blockIdx.x, t = threadIdx.x, k0 = blockIdx.y * kg;
+    const int K = Kall - k0 < kg ? Kall - k0 : kg;
     const int P = H * W;
-    const float* hp = heat + (long)n * P * ld;
+    const float* hp = heat + (long)n * P * ld + k0;
     float mx[MAXK];
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) mx[k] = -INFINITY;
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < MAXK; ++k) {
             if (k >= K) continue;
-            const long o = (long)n * K + k;
+            const long o = (long)n * Kall + k0 + k;
             mean[o * 2 + 0] = mux[k];
             mean[o * 2 + 1] = muy[k];
             var[o * 4 + 0] = vxx[k];
@@ -145,21 +150,23 @@ __global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __rest
 }
 
 __global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __restrict__ heat, int ld, int H, int W,
-                                                             int K, float temperature, const float* __restrict__ mean,
+                                                             int Kall, int kg, float temperature,
+                                                             const float* __restrict__ mean,
                                                              const float* __restrict__ stat,
                                                              const float* __restrict__ dmean,
                                                              const float* __restrict__ dvar, float* __restrict__ dheat,
                                                              int ld_d) {
     __shared__ float red_mem[4 * MAXK];
     BlockRed br{red_mem};
-    const int n = blockIdx.x, t = threadIdx.x;
+    const int n = blockIdx.x, t = threadIdx.x, k0 = blockIdx.y * kg;
+    const int K = Kall - k0 < kg ? Kall - k0 : kg;
     const int P = H * W;
-    const float* hp = heat + (long)n * P * ld;
+    const float* hp = heat + (long)n * P * ld + k0;
     float mux[MAXK], muy[MAXK], mx[MAXK], invS[MAXK], gmx[MAXK], gmy[MAXK], v00[MAXK], v01[MAXK], v11[MAXK];
 #pragma unroll
     for (int k = 0; k < MAXK; ++k)
         if (k < K) {
-            const long o = (long)n * K + k;
+            const long o = (long)n * Kall + k0 + k;
             mux[k] = mean[o * 2];
             muy[k] = mean[o * 2 + 1];
             mx[k] = stat[o * 2];
@@ -189,7 +196,8 @@ __global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __rest
             }
     }
     br.reduce(A, K);
-    float* dp = dheat + (long)n * P * ld_d;
+    float* dp = dheat + (long)n * P * ld_d + k0;
+    const bool last_group = k0 + K == Kall;     // the block of the last channels also zeroes the pad channels
     for (int p = t; p < P; p += 256) {
         const float gx = grid_coord(p % W, W), gy = grid_coord(p / W, H);
 #pragma unroll
@@ -200,7 +208,8 @@ __global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __rest
                 const float ai = gmx[k] * gx + gmy[k] * gy + v00[k] * dx * dx + v01[k] * dx * dy + v11[k] * dy * dy;
                 dp[(long)p * ld_d + k] = s * (ai - A[k]) / temperature;
             }
-        for (int k = K; k < ld_d; ++k) dp[(long)p * ld_d + k] = 0.f;
+        if (last_group)
+            for (int k = K; k < ld_d - k0; ++k) dp[(long)p * ld_d + k] = 0.f;
     }
 }
 
@@ -657,6 +666,13 @@ __global__ void __launch_bounds__(256) kp_normalize_kernel(const float* __restri
     var_out[4 * i + 3] = v11;
 }
 
+// key-point channels per block of the soft-argmax kernels (MNK_KP_GROUP; 16 = all channels of a frame in one block)
+static int g_kp_group = getenv("MNK_KP_GROUP") ? atoi(getenv("MNK_KP_GROUP")) : 16;
+static int kp_group(int K) {
+    int kg = g_kp_group < 1 ? 1 : g_kp_group;
+    return kg > K ? K : kg;
+}
+
 }  // namespace
 
 extern "C" {
@@ -667,7 +683,9 @@ int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, fl
     MNK_REQUIRE(temperature > 0.f);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4 * 3);
-    hipLaunchKernelGGL(softmax_kp_fwd_kernel, dim3(N), dim3(256), 0, s, heat, ld, H, W, K, temperature, mean, var, stat);
+    const int kg = kp_group(K);
+    hipLaunchKernelGGL(softmax_kp_fwd_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg, temperature, mean,
+                       var, stat);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -678,8 +696,9 @@ int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, fl
     MNK_REQUIRE(ld >= K && ld_d >= K && temperature > 0.f);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4 * 3);
-    hipLaunchKernelGGL(softmax_kp_bwd_kernel, dim3(N), dim3(256), 0, s, heat, ld, H, W, K, temperature, mean, stat,
-                       dmean, dvar, dheat, ld_d);
+    const int kg = kp_group(K);
+    hipLaunchKernelGGL(softmax_kp_bwd_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg, temperature, mean,
+                       stat, dmean, dvar, dheat, ld_d);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
