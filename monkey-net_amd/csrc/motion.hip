@@ -720,7 +720,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict
                                                               const float* __restrict__ field, int hf, int wf, int mode,
                                                               const float* __restrict__ dout, int ld_out, int out_off,
                                                               float* __restrict__ dinp, float* __restrict__ dfield, int N,
-                                                              int CL) {
+                                                              int CL, int cslice) {
     const long P = (long)h * w;
     const long npix = (long)N * P;
     const int ppb = 256 / CL;   // pixels per block iteration
@@ -745,7 +745,10 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict
             const long o_sw = o_nw + (long)w * ld_in, o_se = o_sw + ld_in;
             const bool k_nw = bl.y0ok && bl.x0ok, k_ne = bl.y0ok && bl.x1ok, k_sw = bl.y1ok && bl.x0ok, k_se = bl.y1ok && bl.x1ok;
             const float* gp = dout + np * ld_out + out_off;
-            for (int c = cl; c < C; c += CL) {
+            // blockIdx.y = channel slice [c_begin, c_end): few-pixel maps with many channels (2 x 2 ... 8 x 8 with 512 ... 1024)
+            // would otherwise be a few dozen blocks whose lanes walk 16 channels one after another
+            const int c_begin = blockIdx.y * cslice, c_end = c_begin + cslice < C ? c_begin + cslice : C;
+            for (int c = c_begin + cl; c < c_end; c += CL) {
                 const float go = gp[c];
                 const float vnw = k_nw ? ib[o_nw + c] : 0.f, vne = k_ne ? ib[o_ne + c] : 0.f;
                 const float vsw = k_sw ? ib[o_sw + c] : 0.f, vse = k_se ? ib[o_se + c] : 0.f;
@@ -839,6 +842,7 @@ int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy
 
 // the row-tile forms apply (see conv1x1_rows_fwd_kernel); MNK_CONV1X1_ROWS=0: the thread-per-pixel kernels (A/B runs)
 static int g_c11_rows = getenv("MNK_CONV1X1_ROWS") ? atoi(getenv("MNK_CONV1X1_ROWS")) : 1;
+static int g_deform_bwd_blocks = getenv("MNK_DEFORM_BWD_BLOCKS") ? atoi(getenv("MNK_DEFORM_BWD_BLOCKS")) : 512;   // 0: no channel slices
 static bool c11_rows_form(const float* x, int ld_x, int Cin) {
     return g_c11_rows && ld_x % 4 == 0 && ld_x <= C11_MAXLD && Cin + 1 <= 128 && (size_t)x % 16 == 0;
 }
@@ -976,8 +980,16 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
     while (CL < C && CL < 64) CL <<= 1;
     const long iters = ((long)N * h * w + (256 / CL) - 1) / (256 / CL);
     ProfScope prof(K_DEFORM, s, (double)N * h * w * C * 12);
-    hipLaunchKernelGGL(deform_bwd_kernel, dim3((int)(iters < 16384 ? iters : 16384)), dim3(256), 0, s, inp, ld_in, C, h, w, field,
-                       hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL);
+    // channel slices (multiples of CL) until the launch has ~512 blocks; every slice adds its share of the field gradient
+    // atomically, like the pixels that share a field texel do
+    int slices = 1;
+    const int max_slices = (C + CL - 1) / CL;
+    while (slices < max_slices && iters * slices < g_deform_bwd_blocks) slices <<= 1;
+    if (slices > max_slices) slices = max_slices;
+    const int cslice = ((C + slices - 1) / slices + CL - 1) / CL * CL;
+    slices = (C + cslice - 1) / cslice;
+    hipLaunchKernelGGL(deform_bwd_kernel, dim3((int)(iters < 16384 ? iters : 16384), slices), dim3(256), 0, s, inp, ld_in, C, h, w,
+                       field, hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL, cslice);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
