@@ -833,6 +833,7 @@ static RSMap make_rsmap(long rows, int ld) {
     return m;
 }
 
+template <bool STATS>
 __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const float* __restrict__ ws, int splits, long M,
                                                                           int ldw, const float* __restrict__ bias,
                                                                           const float* __restrict__ residual, int ld_res,
@@ -857,7 +858,7 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const 
             float4 g[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            int s = 0;
+            int s = c < ldw ? 0 : splits;        // quads beyond the partial rows (ld_y > ldw): zero columns, nothing to read
             for (; s + 4 <= splits; s += 4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -907,6 +908,7 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const 
             r.z = k2 ? r.z : 0.f;
             r.w = k3 ? r.w : 0.f;
             *reinterpret_cast<float4*>(y + orow * ld_y + c) = r;
+            if (!STATS) continue;
             s1.x += r.x;
             s1.y += r.y;
             s1.z += r.z;
@@ -917,6 +919,7 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const 
             s2.w = fmaf(r.w, r.w, s2.w);
         }
     }
+    if (!STATS) return;          // STATS = false: the plain reduction as float4 rows (no LDS hop, every thread busy for any split count)
     red[0][threadIdx.x] = s1;
     red[1][threadIdx.x] = s2;
     __syncthreads();
@@ -2142,6 +2145,9 @@ static int g_wgrad_atomic = env_int("MNK_WGRAD_ATOMIC", 0);
 // 1 (default): a split-K forward launch that was asked for BatchNorm statistics sums its partials with
 // conv3x3_splitk_reduce_stats_kernel (one launch for reduction + statistics pass); 0: no statistics from split launches
 static int g_splitk_stats = env_int("MNK_SPLITK_STATS", 1);
+// 1: every split-K reduction runs the float4-row kernel (the statistics kernel without its statistics; the same bits);
+// 0: conv3x3_splitk_reduce_kernel (64 outputs x 4 split groups per block, combined through LDS)
+static int g_reduce_v4 = env_int("MNK_REDUCE_V4", 1);
 static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = env_int("MNK_WSPLIT_TARGET", 1024),
            g_wsplit_minsteps = env_int("MNK_WSPLIT_MINSTEPS", 8);
 
@@ -2701,9 +2707,14 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
         if (stats_partial) {
             const RSMap m = make_rsmap(a.M * phases, ld_y);
-            hipLaunchKernelGGL(conv3x3_splitk_reduce_stats_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, ws, p.splits,
-                               a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W, m.tx, m.ty, m.rows_per_block,
-                               stats_partial);
+            hipLaunchKernelGGL(conv3x3_splitk_reduce_stats_kernel<true>, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, ws,
+                               p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W, m.tx, m.ty,
+                               m.rows_per_block, stats_partial);
+        } else if (g_reduce_v4 && (size_t)y % 16 == 0 && (size_t)ws % 16 == 0) {
+            const RSMap m = make_rsmap(a.M * phases, ld_y);
+            hipLaunchKernelGGL(conv3x3_splitk_reduce_stats_kernel<false>, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, ws,
+                               p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W, m.tx, m.ty,
+                               m.rows_per_block, (float*)nullptr);
         } else
             hipLaunchKernelGGL(conv3x3_splitk_reduce_kernel, dim3(grid_for(a.M * phases * ld_y * 4, 8192)), dim3(256), 0, s, ws,
                                p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W);
@@ -3323,7 +3334,7 @@ int mnk_set_tuning(const char* name, int value) {
                                                   {"MNK_FORCE_BN", &g_force_bn}, {"MNK_FORCE_SPLITS", &g_force_splits},
                                                   {"MNK_WN16_GROUP_TARGET", &g_wn16_group_target},
                                                   {"MNK_WN16_GROUP_FEW", &g_wn16_group_target_few},
-                                                  {"MNK_SPLITK_STATS", &g_splitk_stats}};
+                                                  {"MNK_SPLITK_STATS", &g_splitk_stats}, {"MNK_REDUCE_V4", &g_reduce_v4}};
     for (auto& k : knobs)
         if (strcmp(k.n, name) == 0) {
             *k.v = value;

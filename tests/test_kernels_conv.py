@@ -323,6 +323,15 @@ def test_conv3x3_fused_bn_statistics(be, case):
     be.call("mnk_conv3x3_fwd", *args, Y2, ldy, n, h, w, cout, ws, nws, None)
     be.sync()
     assert torch.equal(Y.cpu(), Y2.cpu())
+    if split:           # the 64-outputs x 4-split-groups reduction (MNK_REDUCE_V4=0) adds the splits in the same order
+        Y3 = be.empty(n, h, w, ldy)
+        be.lib.call("mnk_set_tuning", b"MNK_REDUCE_V4", 0)
+        try:
+            be.call("mnk_conv3x3_fwd", *args, Y3, ldy, n, h, w, cout, ws, nws, None)
+            be.sync()
+        finally:
+            be.lib.call("mnk_set_tuning", b"MNK_REDUCE_V4", 1)
+        assert torch.equal(Y.cpu(), Y3.cpu())
     assert relerr(from_nhwc(Y.cpu(), cout), _ref_fwd(case, x0, x1, wt, b, r)) < 2e-6
     assert torch.all(Y.cpu()[..., cout:] == 0)
     y = from_nhwc(Y.cpu(), cout).double()
