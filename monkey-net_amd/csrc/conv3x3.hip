@@ -812,8 +812,9 @@ struct RSMap {
     int tx, ty, col_tiles, row_blocks;
     long rows_per_block;
 };
-// rows per thread before a layer is cut into more row blocks (A/B, visit 43: 1 / 2 / 4 / 8 -> 11.18 / 11.16 / 11.18 / 11.26 ms)
-static int g_rs_rpt = getenv("MNK_RS_RPT") ? atoi(getenv("MNK_RS_RPT")) : 2;
+// rows per thread before a layer is cut into more row blocks (A/B with every split-K reduction on this kernel, visit 48:
+// 1 / 2 / 4 -> 10.92 / 10.97 / 11.10 ms; the 64 x 4-group kernel: 10.95)
+static int g_rs_rpt = getenv("MNK_RS_RPT") ? atoi(getenv("MNK_RS_RPT")) : 1;
 static RSMap make_rsmap(long rows, int ld) {
     RSMap m;
     const int nv = ld / 4;
@@ -824,7 +825,7 @@ static RSMap make_rsmap(long rows, int ld) {
     m.col_tiles = (nv + tx - 1) / tx;
     long want = 1024 / m.col_tiles;
     if (want < 1) want = 1;
-    const long min_rows = (long)m.ty * (g_rs_rpt > 0 ? g_rs_rpt : 2);
+    const long min_rows = (long)m.ty * (g_rs_rpt > 0 ? g_rs_rpt : 1);
     long rb = (rows + min_rows - 1) / min_rows;
     if (rb > want) rb = want;
     if (rb < 1) rb = 1;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit that collects everything profiles/ cites for the final build of a round.  Usage: gpu_evidence.sh TAG
-#   tests + smoke, the two bench lines (default = BASELINE configs[1] with roofline / cpu_baseline / hot_path_only), rocprofv3
+#   tests + smoke, the bench lines (default = BASELINE configs[1] with roofline / cpu_baseline / hot_path_only), rocprofv3
 #   kernel stats (+ steady-state window), FETCH_SIZE / WRITE_SIZE PMC passes (separate runs), an SQ pass over the per-layer
 #   conv bench (MFMA busy, GRBM clock), per-layer conv bench of both configs, batched inference (bair B=512), the
 #   single-rank RCCL exercise of the distributed path.
@@ -29,6 +29,7 @@ cp "$OUT/pmc_traffic_moving-gif_b32.json" "profiles/${R}_pmc_traffic_moving-gif_
 echo "== bench (default: moving-gif, roofline + cpu_baseline + hot_path_only)" | tee -a "$S"
 timeout 900 python bench.py > "$OUT/bench_moving-gif_b32.json" 2> "$OUT/bench.err"; echo "rc=$?" | tee -a "$S"; cut -c1-900 "$OUT/bench_moving-gif_b32.json" | tee -a "$S"
 timeout 400 python bench.py --config taichi --no-cpu-baseline > "$OUT/bench_taichi_b32.json" 2> "$OUT/bench_taichi.err"; echo "taichi rc=$?" | tee -a "$S"; cut -c1-300 "$OUT/bench_taichi_b32.json" | tee -a "$S"
+timeout 300 python bench.py --config vox --size 256 --batch 8 --no-cpu-baseline > "$OUT/bench_vox256_b8.json" 2> "$OUT/bench_vox.err"; echo "vox 256 rc=$?" | tee -a "$S"; cut -c1-300 "$OUT/bench_vox256_b8.json" | tee -a "$S"
 echo "== rocprofv3 kernel stats (eager iteration)" | tee -a "$S"
 CMD="python $PWD/bench.py --steps 5 --warmup 2 --graph 0 --no-cpu-baseline --no-profile"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- $CMD > "$OLDPWD/$OUT/rocprof.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
@@ -50,7 +51,7 @@ echo "== single-rank RCCL exercise (MNK_DIST_FORCE=1, torch.distributed.run)" | 
 MNK_DIST_FORCE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > "$OUT/bench_dist1.json" 2> "$OUT/bench_dist1.err"; echo "rc=$?" | tee -a "$S"
 cut -c1-330 "$OUT/bench_dist1.json" | tee -a "$S"; grep -h "mnk.dist\|capture failed" "$OUT/bench_dist1.err" | head -3 | cut -c1-200 | tee -a "$S"
 # what profiles/ keeps (small files only)
-for f in bench_moving-gif_b32.json bench_taichi_b32.json moving-gif_b32_eager_kernel_stats.csv moving-gif_b32_steady_kernel_stats.csv moving-gif_b32_steady_groups.txt pmc_traffic_moving-gif_b32.json sq_counters_conv_bench_moving-gif.txt conv_bench_moving-gif_b32.txt conv_bench_taichi_b32.txt infer_bair_b512.json; do
+for f in bench_moving-gif_b32.json bench_taichi_b32.json bench_vox256_b8.json moving-gif_b32_eager_kernel_stats.csv moving-gif_b32_steady_kernel_stats.csv moving-gif_b32_steady_groups.txt pmc_traffic_moving-gif_b32.json sq_counters_conv_bench_moving-gif.txt conv_bench_moving-gif_b32.txt conv_bench_taichi_b32.txt infer_bair_b512.json; do
   [ -s "$OUT/$f" ] && cp "$OUT/$f" "$OUT/${R}_$f"
 done
 cp "$OUT/bench_dist1.json" "$OUT/${R}_bench_moving-gif_b32_rccl_1rank.json" 2>/dev/null
