@@ -12,13 +12,12 @@ using namespace mnk;
 namespace {
 
 struct Map2D {
-    int tx, ty, col_tiles, row_blocks;     // tx * ty threads per block (256, or fewer when tx is not a power of two)
+    int tx, ty, col_tiles, row_blocks;
     long rows_per_block;
 };
 
 static int g_bn_rpt = getenv("MNK_BN_RPT") ? atoi(getenv("MNK_BN_RPT")) : 4;            // rows per thread before a layer is cut (A/B: 8 -> 4: 11.51 -> 11.44 ms per step)
 static int g_bn_blocks = getenv("MNK_BN_BLOCKS") ? atoi(getenv("MNK_BN_BLOCKS")) : 1024;   // into more row blocks; block cap
-static int g_bn_exact_tx = getenv("MNK_BN_EXACT_TX") ? atoi(getenv("MNK_BN_EXACT_TX")) : 1;  // see make_map
 
 static Map2D make_map(long rows, int ld, int rows_per_thread = 0, int want_blocks = 0) {
     if (rows_per_thread <= 0) rows_per_thread = g_bn_rpt;
@@ -27,13 +26,8 @@ static Map2D make_map(long rows, int ld, int rows_per_thread = 0, int want_block
     int nv = ld / 4;
     int tx = 1;
     while (tx < nv && tx < 64) tx <<= 1;
-    // a layer narrower than 64 quads whose quad count is not a power of two (45 channels = 12 quads: the refinement stack)
-    // gets exactly nv lanes per row -- with 16 a quarter of every wave would idle -- and a block of tx * ty <= 256 threads
-    if (g_bn_exact_tx && nv < tx) tx = nv;
     m.tx = tx;
-    int ty = 1;
-    while (ty * 2 * tx <= 256) ty <<= 1;
-    m.ty = ty;
+    m.ty = 256 / tx;
     m.col_tiles = (nv + tx - 1) / tx;
     long want = want_blocks / m.col_tiles;   // default ~4 blocks per CU in total
     if (want < 1) want = 1;
@@ -752,7 +746,7 @@ int mnk_norm_stats(const float* x, int ld, long rows_per_frame, int frames, int 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_STATS, s, (double)rows_per_frame * frames * C * 4);
     StatsLoader L{x, ld};
-    hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(m.tx * m.ty), 0, s, L,
+    hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L,
                        rows_per_frame, ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ld, C,
                        frames, sums, 2);
@@ -785,10 +779,10 @@ int mnk_norm_act_fwd(const float* y, int ld_y, const float* mean, const float* s
     Map2D m = make_map(rows, round_up(C, 4), 2, 2048);     // no reduction here: small layers want blocks, not rows per thread
     const dim3 grid(m.col_tiles, m.row_blocks);
     if (pool)
-        hipLaunchKernelGGL(bn_act_fwd_kernel<1>, grid, dim3(m.tx * m.ty), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
+        hipLaunchKernelGGL(bn_act_fwd_kernel<1>, grid, dim3(256), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
                            N, H, W, C, slope, m.tx, m.ty, m.rows_per_block);
     else
-        hipLaunchKernelGGL(bn_act_fwd_kernel<0>, grid, dim3(m.tx * m.ty), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
+        hipLaunchKernelGGL(bn_act_fwd_kernel<0>, grid, dim3(256), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
                            N, H, W, C, slope, m.tx, m.ty, m.rows_per_block);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
@@ -812,7 +806,7 @@ int mnk_norm_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz,
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_BWD, s, (double)N * H * W * C * 4 * (pool ? 1.25 : 2.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, per_frame ? C : 0, slope};
-    hipLaunchKernelGGL(colsum2_partial_kernel<BwdLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(m.tx * m.ty), 0, s, L, rows,
+    hipLaunchKernelGGL(colsum2_partial_kernel<BwdLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L, rows,
                        ldc / 4, ldc, m.tx, m.ty, m.rows_per_block, ws);
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C,
                        frames, sums, 2);
@@ -835,7 +829,7 @@ int mnk_norm_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz,
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, per_frame ? C : 0, slope};
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(m.tx * m.ty), 0, s, L, sums, count, training,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
                        (per_frame ? N : 1) * C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, (float*)nullptr);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
@@ -860,7 +854,7 @@ int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int l
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, 0, relu ? 0.f : -1.f};
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(m.tx * m.ty), 0, s, L, sums, count, training,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
                        C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, ws);
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, 1, dy_sums, 1);
     MNK_LAUNCH_CHECK();
@@ -885,7 +879,7 @@ int mnk_bn_stats_finalize(const float* x, int ld, long rows, int C, const float*
             return MNK_EWORKSPACE;
         }
         StatsLoader L{x, ld};
-        hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, 1), dim3(m.tx * m.ty), 0, s, L, rows,
+        hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, 1), dim3(256), 0, s, L, rows,
                            ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
         partial = ws;
         row_blocks = m.row_blocks;
