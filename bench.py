@@ -26,7 +26,9 @@ One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one 
   hot_path_only_ms -- SURVEY section 8a alone (KPDetector + generator forward and backward with every weight gradient
                    materialised; no discriminator, losses or optimiser) as a hipGraph replay, next to the whole step;
   cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
-                   host's cores on a bounded sample of the same workload (rank 0, N == 1 only).
+                   host's cores on a bounded sample of the same workload (rank 0, N == 1 only); its `recon_l1` = the
+                   second half of BASELINE's metric: reconstruction L1 (reconstruction.py:74) of the eval forward on the
+                   HIP path and on the oracle from the same weights and frames, and their difference (bound: 1e-4).
 """
 import argparse
 import json
@@ -126,6 +128,39 @@ def build_models(cfg, device):
     disc = Discriminator(**mp["discriminator_params"], **mp["common_params"])
     kpd = KPDetector(**mp["kp_detector_params"], **mp["common_params"])
     return gen.to(device), disc.to(device), kpd.to(device)
+
+
+def recon_l1_vs_cpu(cfg, size, device, batch=8):
+    """"recon L1 vs CPU ref" (BASELINE.json's metric): the reconstruction criterion of reconstruction.py:74 -- mean
+    |prediction - driving frame| of the eval-mode forward (key points of source and driving frame, generator) -- on the HIP
+    path and on the CPU oracle (oracle/restate.py, fp32) from the same weights and frames.  The checker leg of the bench:
+    nothing here is timed.  north_star's bound on |difference| is 1e-4."""
+    from oracle import restate, cases
+    from mnk import engine
+    mp = cfg["model_params"]
+    common = mp["common_params"]
+    torch.manual_seed(1)
+    gen, _, kpd = build_models(cfg, "cpu")
+    for i, m in enumerate((gen, kpd)):       # non-trivial running statistics and affine parameters
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 11 + i)
+        m.load_state_dict(sd)
+    sds = {"generator": {k: v.clone() for k, v in gen.state_dict().items()},
+           "kp_detector": {k: v.clone() for k, v in kpd.state_dict().items()}}
+    src, drv = cases.smooth_pair(batch, size, size)
+    with torch.no_grad():
+        kp_params = dict(mp["kp_detector_params"], **common)
+        kp_s = restate.kp_detector_forward(sds["kp_detector"], kp_params, src, training=False)
+        kp_d = restate.kp_detector_forward(sds["kp_detector"], kp_params, drv, training=False)
+        ref = restate.generator_forward(sds["generator"], mp["generator_params"], common, src, kp_d, kp_s, training=False)
+    out = engine.Reconstructor(kpd.to(device), gen.to(device))(src.to(device), drv.to(device))
+    pred = out["video_prediction"].detach().cpu()
+    l1_hip = float((pred.double() - drv.double()).abs().mean())
+    l1_cpu = float((ref["video_prediction"].double() - drv.double()).abs().mean())
+    return {"hip": l1_hip, "cpu_ref": l1_cpu, "abs_diff": abs(l1_hip - l1_cpu),
+            "max_abs_frame_diff": float((pred - ref["video_prediction"]).abs().max()),
+            "sample": "eval forward (kp detector x2 + generator), batch %d @ %dx%d, random-init weights with perturbed "
+                      "BatchNorm statistics, smooth synthetic frames" % (batch, size, size)}
 
 
 def cpu_baseline(cfg, batch, size, steps):
@@ -433,6 +468,10 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, args.cpu_batch, args.size, args.cpu_steps)
+        try:        # the second half of BASELINE's metric; never lose the bench line to it
+            cpu["recon_l1"] = recon_l1_vs_cpu(cfg, args.size, device)
+        except Exception as e:
+            cpu["recon_l1"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         flops = workload.conv_flops_hot_path(cfg, args.size, args.size)

@@ -100,3 +100,18 @@ def test_print_launch_is_the_drivers_command():
     cmd = out.stdout.strip()
     assert "-m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1" in cmd
     assert cmd.endswith("bench.py --gpus 4 --steps 3 --launcher-selftest --print-launch")
+
+
+def test_recon_l1_leg_of_the_bench_line(be):
+    """bench.py's "recon L1 vs CPU ref" leg (the second half of BASELINE's metric) on the kernels' CPU emulation with the tiny
+    configuration: the HIP-path eval forward and the oracle's give the same reconstruction L1 (north_star: within 1e-4)."""
+    import importlib.util
+    import torch
+    from oracle import cases
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = bench.recon_l1_vs_cpu(cases.TINY, 32, be.device, batch=2)
+    be.sync()
+    assert set(rec) >= {"hip", "cpu_ref", "abs_diff", "max_abs_frame_diff", "sample"}
+    assert 0.0 < rec["cpu_ref"] < 1.0 and rec["abs_diff"] < 1e-4 and rec["max_abs_frame_diff"] < 1e-3
