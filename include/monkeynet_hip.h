@@ -184,9 +184,10 @@ typedef struct MnkPackDesc {
 } MnkPackDesc;
 int mnk_conv3x3_pack_multi(const MnkPackDesc* descs_device, int n, int total_tiles, void* stream);
 size_t mnk_conv3x3_workspace_floats(int N, int H, int W, int C0, int C1, int Cout);
-/* `stats_partial` (optional, mnk_conv3x3_stats_floats floats; only when that query is > 0, i.e. no split-K): the kernel
- * epilogue also emits per-block column sums / sums of squares of y -- the BatchNorm statistics of the following
- * norm layer -- to be finished by mnk_bn_stats_finish(stats_partial, stats_floats / (2*ld_y), ld_y, Cout, sums). */
+/* `stats_partial` (optional, mnk_conv3x3_stats_floats floats; only when that query is > 0): per-block column sums / sums
+ * of squares of y -- the BatchNorm statistics of the following norm layer -- from the kernel epilogue of an unsplit launch or
+ * from the reduction of a split-K launch's partials (not with MNK_CONV_DEFER_SPLITK), to be finished by
+ * mnk_bn_stats_finish(stats_partial, stats_floats / (2*ld_y), ld_y, Cout, sums); needs ld_y == round_up(Cout, 4). */
 size_t mnk_conv3x3_stats_floats(int N, int H, int W, int C0, int C1, int Cout);
 /* `flags`: MNK_CONV_UPSAMPLED (= 1, the former `ups` argument: both sources are read through the nearest x2 up-sampling)
  * | MNK_CONV_CLEAN_PADS (= 2): the caller vouches that the pad channels [C, ld) of the sources hold zeros (every
