@@ -117,6 +117,14 @@ int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int l
                                 const float* invstd, const float* scale, const float* beta, const float* sums,
                                 double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu,
                                 int pool, float* dy_sums, float* ws, size_t ws_floats, void* stream);
+/* the same with a second gradient of the normalised tensor added in the pass (`addend`, (N,H,W,ld_add) or NULL): dy = BatchNorm
+ * backward + addend, dy_sums over the sum.  A residual block's first norm layer (util.py:58-67: `out += x`) receives the
+ * gradient of the skip path this way instead of through a separate accumulation pass over both gradients. */
+int mnk_bn_act_bwd_apply_add_colsum(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                                    const float* invstd, const float* scale, const float* beta, const float* sums,
+                                    double count, int training, const float* addend, int ld_add, float* dy, int ld_dy, int N,
+                                    int H, int W, int C, int relu, int pool, float* dy_sums, float* ws, size_t ws_floats,
+                                    void* stream);
 
 /* ---- small layers (N*H*W <= mnk_bn_small_rows() pixel rows, 512 by default: the 2x2 / 4x4 levels of the hourglasses): the whole
  * training-mode BatchNorm (+ReLU, +2x2 pool) of one rank in ONE launch per direction instead of four -- a block owns a tile of

@@ -421,9 +421,12 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
                                                                double count, int training, int FC,
                                                                float* __restrict__ dy, int ld_dy, long rows, int C,
                                                                int nv, int tx_n, int ty_n, long rows_per_block,
-                                                               float* __restrict__ dy_partial) {
+                                                               float* __restrict__ dy_partial,
+                                                               const float* __restrict__ addend, int ld_add) {
     // dy_partial (optional): [gridDim.y][2][4 * nv] with the column sums of the written dy in slot 0 -- the bias
     // gradient of the convolution in front of this norm layer (Conv3x3Fn.backward), saving its pass over dy
+    // addend (optional): a second gradient of the same tensor, added here -- the skip path of a residual block whose
+    // first norm layer this is (util.py:58-67: out += x); saves autograd's accumulation pass over both gradients
     __shared__ float4 red[256];
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx;
@@ -457,6 +460,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
         o.y = sc.y * (g.y - k1.y - xh.y * k2.y);
         o.z = sc.z * (g.z - k1.z - xh.z * k2.z);
         o.w = sc.w * (g.w - k1.w - xh.w * k2.w);
+        if (addend) o = f4_add(o, *reinterpret_cast<const float4*>(addend + r * ld_add + q * 4));
         const int rem = C - q * 4;
         if (rem < 4) {  // keep pad channels of dy at zero
             if (rem < 2) o.y = 0.f;
@@ -830,16 +834,19 @@ int mnk_norm_act_bwd_apply(const float* y, int ld_y, const float* dz, int ld_dz,
     ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, per_frame ? C : 0, slope};
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
-                       (per_frame ? N : 1) * C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, (float*)nullptr);
+                       (per_frame ? N : 1) * C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, (float*)nullptr,
+                       (const float*)nullptr, 0);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
 
-int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
-                                const float* invstd, const float* scale, const float* beta, const float* sums,
-                                double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu,
-                                int pool, float* dy_sums, float* ws, size_t ws_floats, void* stream) {
+int mnk_bn_act_bwd_apply_add_colsum(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                                    const float* invstd, const float* scale, const float* beta, const float* sums,
+                                    double count, int training, const float* addend, int ld_add, float* dy, int ld_dy, int N,
+                                    int H, int W, int C, int relu, int pool, float* dy_sums, float* ws, size_t ws_floats,
+                                    void* stream) {
     MNK_REQUIRE(y && dz && mean && invstd && scale && beta && dy && dy_sums && ws && N > 0 && H > 0 && W > 0 && C > 0);
+    MNK_REQUIRE(!addend || (ld_add % 4 == 0 && ld_add >= round_up(C, 4) && (size_t)addend % 16 == 0));
     MNK_REQUIRE(!training || (sums && count > 0));
     MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && ld_dy % 4 == 0 && ld_dy >= round_up(C, 4));
     MNK_REQUIRE(dz_off >= 0 && dz_off + C <= ld_dz && (!pool || (H >= 2 && W >= 2)));
@@ -855,10 +862,18 @@ int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int l
     ProfScope prof(K_BN_BWD, s, (double)rows * C * 4 * (pool ? 2.25 : 3.0));
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, 0, relu ? 0.f : -1.f};
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
-                       C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, ws);
+                       C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, ws, addend, ld_add);
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, 1, dy_sums, 1);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_bn_act_bwd_apply_colsum(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                                const float* invstd, const float* scale, const float* beta, const float* sums,
+                                double count, int training, float* dy, int ld_dy, int N, int H, int W, int C, int relu,
+                                int pool, float* dy_sums, float* ws, size_t ws_floats, void* stream) {
+    return mnk_bn_act_bwd_apply_add_colsum(y, ld_y, dz, ld_dz, dz_off, mean, invstd, scale, beta, sums, count, training, nullptr,
+                                           0, dy, ld_dy, N, H, W, C, relu, pool, dy_sums, ws, ws_floats, stream);
 }
 
 int mnk_bn_stats_finalize(const float* x, int ld, long rows, int C, const float* pre_partial, int pre_row_blocks,

@@ -610,17 +610,29 @@ class BNActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz):
+        return BNActFn._backward(ctx, dz, None)
+
+    @staticmethod
+    def _backward(ctx, dz, dskip):
+        """dskip: a second gradient of y (BNActSkipFn: the skip path of a residual block), added inside the dy pass."""
         y, mean, invstd, scale, beta = ctx.saved_tensors
         c, training, relu, pool, count = ctx.meta
         dz = dz.contiguous()
         n, h, w, ld = y.shape
         rows = n * h * w
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            assert dskip.shape == y.shape, "the skip gradient of a residual block has the shape of the block's input"
         if ctx.small and knobs.on("MNK_BN_ZERO_BIAS_GRAD"):
             sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
             dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
             _call("mnk_bn_small_bwd", y, _p(y), ld, _p(dz), dz.shape[-1], _p(mean), _p(invstd), _p(scale), _p(beta), count, n, h,
                   w, c, int(relu), int(pool), _p(sums), _p(dy), ld)
-            _DY_SUMS[0] = (dy, None)
+            if dskip is not None:
+                dy = dy + dskip                # few-pixel layers: the one-launch kernel has no addend operand
+                _DY_SUMS[0] = None             # ... and the sum's column sums are not zero: the convolution in front makes them
+            else:
+                _DY_SUMS[0] = (dy, None)
             return dy, sums[c:], sums[:c], None, None, None, None, None, None, None, None, None
         nws = _query("mnk_bn_workspace_floats", rows, ceil4(c))
         ws = SCRATCH.get("ws", nws, y)
@@ -631,7 +643,15 @@ class BNActFn(torch.autograd.Function):
         if training and mdist.active():
             sums = mdist.all_reduce_sum_(sums.clone())
         dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
-        if training and knobs.on("MNK_BN_ZERO_BIAS_GRAD"):
+        if dskip is not None:
+            # dy = BatchNorm backward + skip gradient in one pass, with the column sums of the SUM: the bias gradient of the
+            # convolution that produced y (the previous residual block's second convolution) -- not zero here
+            dy_sums = torch.empty(c, dtype=torch.float32, device=y.device)
+            _call("mnk_bn_act_bwd_apply_add_colsum", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale),
+                  _p(beta), _p(sums), count, int(training), _p(dskip), dskip.shape[-1], _p(dy), ld, n, h, w, c, int(relu),
+                  int(pool), _p(dy_sums), _p(ws), nws)
+            _DY_SUMS[0] = (dy, dy_sums)
+        elif training and knobs.on("MNK_BN_ZERO_BIAS_GRAD"):
             # training-mode statistics: sum over pixels of dy = scale * (sum g - N * mean(g) - k2 * sum xhat) == 0 exactly, so
             # the bias gradient of the convolution in front (util.py:54-56,80-81,99-100) is analytically zero; the reference
             # computes its rounding noise.  No reduction is spent on it: that bias simply receives no gradient (an optimiser
@@ -648,11 +668,31 @@ class BNActFn(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def bn_act(y, c, norm, relu=True, pool=False, sums=None):
+class BNActSkipFn(torch.autograd.Function):
+    """BNActFn for the first norm layer of a residual block (util.py:58-67): returns (z, y) -- y handed through for the
+    block's `out += x`.  Both consumers of the block's input are then this one node, and its backward adds the gradient of
+    the skip path inside the BatchNorm dy pass (mnk_bn_act_bwd_apply_add_colsum) instead of leaving a separate accumulation
+    pass over both gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, pre_sums, c, training, relu, pool, momentum, eps):
+        z = BNActFn.forward(ctx, y, gamma, beta, running_mean, running_var, pre_sums, c, training, relu, pool, momentum, eps)
+        return z, y
+
+    @staticmethod
+    def backward(ctx, dz, dskip):
+        if dz is None:          # only the skip path was used
+            return (dskip,) + (None,) * 11
+        return BNActFn._backward(ctx, dz, dskip)
+
+
+def bn_act(y, c, norm, relu=True, pool=False, sums=None, skip=False):
     """`norm` is a sync_batchnorm.SynchronizedBatchNorm3d parameter holder; `sums` = statistics of y that a conv
-    epilogue already produced (training mode)."""
-    return BNActFn.apply(y, norm.weight, norm.bias, norm.running_mean, norm.running_var,
-                         sums if norm.training else None, c, norm.training, relu, pool, norm.momentum, norm.eps)
+    epilogue already produced (training mode).  skip: -> (z, y handed through for a residual add), see BNActSkipFn."""
+    fn = BNActSkipFn if skip and knobs.on("MNK_RES_SKIP_FUSED") else BNActFn
+    out = fn.apply(y, norm.weight, norm.bias, norm.running_mean, norm.running_var,
+                   sums if norm.training else None, c, norm.training, relu, pool, norm.momentum, norm.eps)
+    return (out, y) if skip and fn is BNActFn else out
 
 
 # ----------------------------------------------------------------------------------------------------------------

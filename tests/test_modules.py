@@ -460,3 +460,62 @@ def test_down_block_on_small_and_odd_maps(be, hw):
     for k in ("conv.weight", "norm.weight", "norm.bias"):
         a, b = dict(blk.named_parameters())[k].grad.cpu().double(), sd["blk." + k].grad
         assert float((a - b).norm() / b.norm()) < 1e-4, k
+
+
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["skip-gradient-in-the-norm-pass", "autograd-accumulates"])
+@pytest.mark.parametrize("hw", [24, 8], ids=["general-kernels", "one-launch-norm"])
+def test_residual_blocks_and_the_gradient_of_their_skip_path(be, monkeypatch, fused, hw):
+    """conv (with bias) -> ResBlock3D -> ResBlock3D in training mode (modules/util.py:45-68) against the oracle in fp64: the
+    output, the gradient of the input and of EVERY parameter -- among them the biases of the convolutions that produce a
+    block's input, whose gradient is the column sum of (BatchNorm backward + skip gradient) and comes out of the next
+    block's norm pass when the skip gradient is added there (MNK_RES_SKIP_FUSED, ops.BNActSkipFn)."""
+    from torch import nn
+    from modules.util import ResBlock3D
+    from mnk import ops
+    from oracle import restate
+    monkeypatch.setenv("MNK_RES_SKIP_FUSED", fused)
+    torch.manual_seed(5)
+    cin, c, n = 3, 5, 2
+    front = nn.Conv3d(cin, c, kernel_size=(1, 3, 3), padding=(0, 1, 1))
+    blocks = [ResBlock3D(c, kernel_size=(1, 3, 3), padding=(0, 1, 1)) for _ in range(2)]
+    with torch.no_grad():
+        for b in blocks:
+            for norm in (b.norm1, b.norm2):
+                norm.weight.add_(0.3 * torch.randn(c))
+                norm.bias.add_(0.3 * torch.randn(c))
+    sd = {"front." + k: v.detach().clone().double() for k, v in front.state_dict().items()}
+    for i, b in enumerate(blocks):
+        sd.update({"r%d.%s" % (i, k): v.detach().clone().double() for k, v in b.state_dict().items()})
+    for t in sd.values():
+        if t.is_floating_point():
+            t.requires_grad_(True)
+    x = torch.rand(n, cin, 1, hw, hw)
+    xd = restate.fold(x.double()).requires_grad_(True)
+    ctx = restate.Ctx(sd, True)
+    ref = restate.conv(ctx, xd, "front")
+    for i in range(2):
+        ref = restate.res_block(ctx, ref, "r%d" % i)
+    g = torch.randn(ref.shape, dtype=torch.float64)
+    (ref * g).sum().backward()
+
+    front.to(be.device)
+    for b in blocks:
+        b.to(be.device).train()
+    X = be.t(x).requires_grad_(True)
+    act, s = ops.conv3x3(ops.to_act(X), cin, front.weight, front.bias, want_stats=True)
+    act, _, s = blocks[0].forward_act(act, c, x_sums=s, want_stats=True)
+    act, _ = blocks[1].forward_act(act, c, x_sums=s)
+    out = ops.from_act(act, c, n)
+    (out * be.t(restate.unfold(g.float(), n))).sum().backward()
+    be.sync()
+    assert float((out.detach().cpu()[:, :, 0].double() - ref).abs().max()) < 2e-5
+    assert float((X.grad.cpu()[:, :, 0].double() - xd.grad).norm() / xd.grad.norm()) < 1e-4
+    named = [("front." + k, p) for k, p in front.named_parameters()]
+    for i, b in enumerate(blocks):
+        named += [("r%d.%s" % (i, k), p) for k, p in b.named_parameters()]
+    for k, p in named:
+        if k in ("r0.conv1.bias", "r1.conv1.bias"):      # in front of a training BatchNorm: exactly zero (no pass is spent)
+            assert p.grad is None or float(p.grad.abs().max()) < 1e-3 * float(sd[k].grad.abs().max() + 1)
+            continue
+        a, b = p.grad.cpu().double().reshape(-1), sd[k].grad.reshape(-1)
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-4, k
