@@ -33,6 +33,8 @@ KNOBS = {
     "MNK_TWO_STREAMS": ("0", "generator forward: the appearance encoder on a second stream next to the dense-motion network "
                              "(its backward follows on that stream); experiment, measured no gain -> off"),
     "MNK_GRAD_OVERLAP": ("1", "launch a gradient bucket's all-reduce as soon as its last gradient is written"),
+    "MNK_SKIP_GRAD_FUSED": ("1", "hourglass levels: the next down block's data-gradient GEMM adds the gradient of the level's other "
+                                 "consumer (decoder skip / warp) in its epilogue (0: autograd accumulates the two gradients)"),
     "MNK_RES_SKIP_FUSED": ("1", "residual blocks: the first norm layer's backward adds the skip gradient in its dy pass (0: autograd "
                                 "accumulates the two gradients of the block's input in a pass of its own)"),
 }

@@ -466,10 +466,17 @@ class Conv3x3Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dsums):
+        return Conv3x3Fn._backward(ctx, dy, None)
+
+    @staticmethod
+    def _backward(ctx, dy, dskip):
+        """dskip: a second gradient of x0 (Conv3x3SkipFn: x0's other consumer), added in the data gradient's epilogue."""
         x0, x1, weight = ctx.saved_tensors
         c0, c1, ups, cout, n, h, w, has_bias, has_res = ctx.meta
         if dy is None:                       # (materialize_grads is off) nothing flows into y
-            return (None,) * 10
+            return (dskip if ctx.needs_input_grad[0] else None,) + (None,) * 9
+        if dskip is not None and not ctx.needs_input_grad[0]:
+            dskip = None
         dy_in = dy
         dy = dy.contiguous()
         ld_dy = dy.shape[-1]
@@ -489,7 +496,12 @@ class Conv3x3Fn(torch.autograd.Function):
                       _p(ws), nws)
                 grads[i] = dx
                 continue
-            dx, _ = _conv_launch(dy, cout, None, 0, 0, wp, None, None, n, h, w, cc)
+            # x0's second gradient rides as the residual operand of the data-gradient GEMM (its epilogue / split reduction)
+            res = None
+            if i == 0 and dskip is not None and not ups:
+                res, dskip = dskip.contiguous(), None
+                assert res.shape == (n, h, w, ceil4(cc))
+            dx, _ = _conv_launch(dy, cout, None, 0, 0, wp, None, res, n, h, w, cc)
             if ups:
                 dxs = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
                 _call("mnk_sumpool2x2", dy, _p(dx), dx.shape[-1], _p(dxs), dxs.shape[-1], n, h, w, cc)
@@ -529,15 +541,37 @@ class Conv3x3Fn(torch.autograd.Function):
             else:
                 db = channel_sums(dy, cout)[:cout]
         dres = dy if has_res and ctx.needs_input_grad[4] else None
+        if dskip is not None:                # forms without a residual operand (up-sampled sources): one add
+            grads[0] = grads[0] + dskip if grads[0] is not None else dskip
         return grads[0], grads[1], dw, db, dres, None, None, None, None, None
 
 
-def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False):
-    """-> (y, sums): sums = fused BatchNorm statistics [sum, sum of squares] of y when want_stats, else None."""
+class Conv3x3SkipFn(torch.autograd.Function):
+    """Conv3x3Fn that also hands x0 through: -> (y, sums, x0).  For a tensor with a second consumer (an hourglass level:
+    the next down block's convolution AND the decoder's skip / a warp, util.py:142-152,184-188) the second consumer takes
+    the handed-through tensor; this node is then the only consumer of the original and its backward adds the other
+    gradient in the epilogue of its data-gradient GEMM (the `residual` operand) -- no accumulation pass by autograd."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, residual, c0, c1, ups, want_stats, track):
+        y, sums = Conv3x3Fn.forward(ctx, x0, x1, weight, bias, residual, c0, c1, ups, want_stats, track)
+        return y, sums, x0
+
+    @staticmethod
+    def backward(ctx, dy, _dsums, dskip):
+        return Conv3x3Fn._backward(ctx, dy, dskip)
+
+
+def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False, skip=False):
+    """-> (y, sums): sums = fused BatchNorm statistics [sum, sum of squares] of y when want_stats, else None.
+    skip: -> (y, sums, x0 handed through for x0's other consumer), see Conv3x3SkipFn."""
     track = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x0, x1, weight, bias, residual))
+    if skip and track and x0.requires_grad and knobs.on("MNK_SKIP_GRAD_FUSED"):
+        y, sums, through = Conv3x3SkipFn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
+        return y, (sums if want_stats else None), through
     y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
-    return y, (sums if want_stats else None)
+    return (y, (sums if want_stats else None), x0) if skip else (y, (sums if want_stats else None))
 
 
 # ----------------------------------------------------------------------------------------------------------------

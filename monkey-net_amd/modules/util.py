@@ -142,7 +142,11 @@ class DownBlock3D(nn.Module):
         self.in_features, self.out_features = in_features, out_features
         _require_plain_3x3(self.conv.kernel_size, self.conv.padding)
 
-    def forward_act(self, x, c):
+    def forward_act(self, x, c, skip=False):
+        """skip: -> ((out, channels), x handed through) for an input that has a second consumer (Encoder.forward_act)."""
+        if skip:
+            out, s, x = ops.conv3x3(x, c, self.conv.weight, self.conv.bias, want_stats=self.norm.training, skip=True)
+            return (ops.bn_act(out, self.out_features, self.norm, relu=True, pool=True, sums=s), self.out_features), x
         out, s = ops.conv3x3(x, c, self.conv.weight, self.conv.bias, want_stats=self.norm.training)
         return ops.bn_act(out, self.out_features, self.norm, relu=True, pool=True, sums=s), self.out_features
 
@@ -184,9 +188,16 @@ class Encoder(nn.Module):
         self.in_features = in_features
 
     def forward_act(self, x, c):
-        outs = [(x, c)]
+        # every level but the deepest has two consumers: the next down block and whoever takes the returned list (the decoder's
+        # skip connections, the generator's warps).  The down block hands its input through and the list holds THAT tensor, so
+        # the block's convolution is the level's only consumer in the autograd graph and adds the other gradient in its own
+        # data-gradient launch (ops.Conv3x3SkipFn)
+        outs, cur = [], (x, c)
         for down_block in self.down_blocks:
-            outs.append(down_block.forward_act(*outs[-1]))
+            nxt, through = down_block.forward_act(*cur, skip=True)
+            outs.append((through, cur[1]))
+            cur = nxt
+        outs.append(cur)
         return outs
 
     def forward(self, x):

@@ -519,3 +519,41 @@ def test_residual_blocks_and_the_gradient_of_their_skip_path(be, monkeypatch, fu
             continue
         a, b = p.grad.cpu().double().reshape(-1), sd[k].grad.reshape(-1)
         assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-4, k
+
+
+@pytest.mark.parametrize("fused", ["1", "0"], ids=["skip-gradient-in-the-dgrad-epilogue", "autograd-accumulates"])
+def test_hourglass_levels_with_two_consumers(be, monkeypatch, fused):
+    """Hourglass (modules/util.py:129-203) on an input that needs a gradient, against the oracle in fp64: output, input gradient
+    and every parameter gradient.  Every encoder level feeds the next down block AND the decoder; with MNK_SKIP_GRAD_FUSED the
+    down block's convolution hands its input through (ops.Conv3x3SkipFn) and its data-gradient launch adds the decoder's
+    gradient as its residual operand."""
+    from modules.util import Hourglass
+    from oracle import restate
+    monkeypatch.setenv("MNK_SKIP_GRAD_FUSED", fused)
+    torch.manual_seed(9)
+    hg = Hourglass(block_expansion=8, in_features=6, out_features=5, num_blocks=3, max_features=32)
+    sd = {"hg." + k: v.detach().clone().double() for k, v in hg.state_dict().items()}
+    for t in sd.values():
+        if t.is_floating_point():
+            t.requires_grad_(True)
+    n, hw = 3, 32
+    x = torch.rand(n, 6, 1, hw, hw)
+    xd = restate.fold(x.double()).requires_grad_(True)
+    ctx = restate.Ctx(sd, True)
+    ref = restate.hourglass(ctx, xd, "hg", 3)
+    g = torch.randn(ref.shape, dtype=torch.float64)
+    (ref * g).sum().backward()
+    hg.to(be.device).train()
+    X = be.t(x).requires_grad_(True)
+    out = hg(X)
+    (out * be.t(restate.unfold(g.float(), n))).sum().backward()
+    be.sync()
+    assert float((out.detach().cpu()[:, :, 0].double() - ref).abs().max()) < 5e-5
+    assert float((X.grad.cpu()[:, :, 0].double() - xd.grad).norm() / xd.grad.norm()) < 2e-4
+    for k, p in hg.named_parameters():
+        r = sd["hg." + k].grad
+        if p.grad is None:          # a convolution bias in front of a training BatchNorm: exactly zero, no pass is spent
+            assert k.endswith("conv.bias") and float(r.abs().max()) < 1e-6 * float(g.abs().sum())
+            continue
+        a = p.grad.cpu().double().reshape(-1)
+        assert float((a - r.reshape(-1)).norm() / (r.norm() + 1e-12)) < 5e-4, k
