@@ -1252,7 +1252,15 @@ class WarpAllFn(torch.autograd.Function):
         inps = ctx.saved_tensors[2:]
         mode, specs = ctx.meta
         _, hf, wf, _ = field.shape
-        dfield = torch.zeros_like(field) if ctx.needs_input_grad[0] and any(d is not None for d in douts) else None
+        # the scatter-add targets of all warps (d input of every level, d field) are slices of ONE zeroed buffer: one fill launch
+        # instead of one per level.  The acts come first (their sizes are multiples of 4 floats: every slice stays 16-byte
+        # aligned for the float4 readers downstream), the field last.
+        want_field = ctx.needs_input_grad[0] and any(d is not None for d in douts)
+        want = [ctx.needs_input_grad[4 + i] and douts[i] is not None for i in range(len(inps))]
+        sizes = [inp.numel() if wnt else 0 for inp, wnt in zip(inps, want)] + [field.numel() if want_field else 0]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=field.device) if sum(sizes) else None
+        offs = [sum(sizes[:k]) for k in range(len(sizes))]
+        dfield = flat[offs[-1]:offs[-1] + sizes[-1]].view_as(field) if want_field else None
         demb = None
         dinps = []
         for i, (inp, (c, ke), dout) in enumerate(zip(inps, specs, douts)):
@@ -1261,7 +1269,7 @@ class WarpAllFn(torch.autograd.Function):
                 continue
             dout = dout.contiguous()
             n, h, w, ld_in = inp.shape
-            dinp = torch.zeros_like(inp) if ctx.needs_input_grad[4 + i] else None
+            dinp = flat[offs[i]:offs[i] + sizes[i]].view_as(inp) if want[i] else None
             if dinp is not None or dfield is not None:
                 _call("mnk_deform_bwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(dout), dout.shape[-1], 0,
                       _p(dinp), _p(dfield), n)
