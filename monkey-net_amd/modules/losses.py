@@ -1,16 +1,32 @@
-"""Training losses (modules/losses.py): L1 feature matching over discriminator maps + LSGAN terms.  Tiny
-element-wise reductions on stock PyTorch ops (out of the hot path); same function names,
-argument order and return conventions as the reference so train.py runs unchanged."""
+"""Training losses (modules/losses.py): L1 feature matching over discriminator maps + LSGAN terms; same function names,
+argument order and return conventions as the reference so train.py runs unchanged.  The L1 terms of fp32 tensors on the
+library's device run the one-launch kernels of csrc/losses.hip (forward: |a - b| reduced per sample, backward: the sign
+pass for whichever side asks for a gradient); anything else (the fp64 checks of the tests, the few-element LSGAN terms)
+is stock PyTorch arithmetic.  mnk.engine.TrainStep goes further and takes the feature-matching terms straight from the
+NHWC activations of the batched discriminator pass (ops.PairL1Fn, ops.GanTermsFn)."""
 import torch
+
+from mnk import _lib, ops
 
 
 def mean_batch(val):
     return val.reshape(val.shape[0], -1).mean(-1)
 
 
+def _on_library_device(*tensors):
+    """fp32 tensors of one shape, where the kernels run (cuda for the gfx950 build)."""
+    first = tensors[0]
+    if not all(torch.is_tensor(t) and t.dtype == torch.float32 and t.shape == first.shape and t.dim() >= 2 and
+               t.numel() > 0 for t in tensors):
+        return False
+    return all(t.is_cuda for t in tensors) if _lib.lib().is_device_build else not any(t.is_cuda for t in tensors)
+
+
 def reconstruction_loss(prediction, target, weight):
     if weight == 0:
         return 0
+    if _on_library_device(prediction, target):
+        return ops.L1MeanFn.apply(prediction, target, weight)
     return weight * mean_batch((prediction - target).abs())
 
 

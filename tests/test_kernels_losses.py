@@ -106,3 +106,25 @@ def test_gan_terms_match_the_loss_module(be, shape):
         ref.backward(retain_graph=True)
         be.sync()
         assert maxerr(S.grad.cpu(), s64.grad) < 1e-6 * (1 + float(s64.grad.abs().max()))
+
+
+def test_loss_module_runs_the_l1_kernels_on_the_library_device(be):
+    """modules.losses.reconstruction_loss (the function the reference's train.py calls, losses.py:8-12) on fp32 tensors of the
+    library's device is the one-launch kernel pair (an L1MeanFn node), equal to the stock arithmetic it replaces; fp64 / CPU
+    checks keep the stock arithmetic."""
+    from modules import losses
+    g = torch.Generator().manual_seed(7)
+    a, b = torch.randn(3, 4, 1, 6, 5, generator=g), torch.randn(3, 4, 1, 6, 5, generator=g)
+    A, B = be.t(a).requires_grad_(True), be.t(b).requires_grad_(True)
+    out = losses.reconstruction_loss(A, B, 10)
+    assert "L1MeanFn" in type(out.grad_fn).__name__
+    gout = torch.randn(3, generator=g)
+    (out * be.t(gout)).sum().backward()
+    be.sync()
+    a64, b64 = a.double().detach().requires_grad_(True), b.double().detach().requires_grad_(True)
+    ref = losses.reconstruction_loss(a64, b64, 10)
+    assert "L1MeanFn" not in type(ref.grad_fn).__name__
+    (ref * gout.double()).sum().backward()
+    assert relerr(out.detach().cpu(), ref.detach()) < 2e-6
+    assert maxerr(A.grad.cpu(), a64.grad) < 1e-6 and maxerr(B.grad.cpu(), b64.grad) < 1e-6
+    assert losses.reconstruction_loss(A, B, 0) == 0
