@@ -120,7 +120,7 @@ def launcher_selftest():
 
 def build_models(cfg, device):
     from modules.generator import MotionTransferGenerator
-    from modules.discriminator import Discriminator     # the gfx950-kernel one (MNK_NATIVE_DISC=0: stock PyTorch ops)
+    from modules.discriminator import Discriminator
     from modules.keypoint_detector import KPDetector
     mp = cfg["model_params"]
     torch.manual_seed(0)

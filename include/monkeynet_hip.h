@@ -294,12 +294,13 @@ typedef struct MnkWgradReduceDesc {
     int reserved;
 } MnkWgradReduceDesc;
 int mnk_wgrad_reduce_blocks(int splits, int Cout, int C);
-/* launch-plan switches (MNK_UP_SUBPIXEL, MNK_WGROUP_CHUNK, MNK_WTAP_TARGET, MNK_WN16_TARGET, MNK_SPLIT_TARGET, MNK_SPLIT_TILES,
- * MNK_BM64_TILES, MNK_XCD_REMAP) are read from the environment when the library is loaded; this changes one afterwards */
+/* the measured defaults of the launch plans (tile counts, split targets, rows per thread: `tuning_knob("name", ...)` in the
+ * kernel sources, e.g. "split_tiles", "wgroup_chunk", "wtap_target", "bn_rpt") are not environment switches: a tuning script
+ * sets one by name here; an A/B visit may pass them all in ONE environment variable, MNK_TUNING="name=value,name=value" */
 int mnk_set_tuning(const char* name, int value);
 /* the forward / data-gradient GEMM's launch plan is a rule (tile by channel count, 64-row tiles and split-K for few-tile
  * layers) overridden, for the benchmark configurations' layer shapes, by plans measured on the MI355X (csrc/plan_table.h;
- * MNK_PLAN_TABLE=0 ignores it).  MNK_FORCE_BM / MNK_FORCE_BN / MNK_FORCE_SPLITS (mnk_set_tuning, 0 = off) force a plan for the
+ * "plan_table" = 0 ignores it).  "force_bm" / "force_bn" / "force_splits" (mnk_set_tuning, 0 = off) force a plan for the
  * sweep that makes the table (tools/plan_tune.py); mnk_last_plan reports the plan of the last such launch or size query:
  * {M, Cout, chunks, taps, phases, bm, bn, splits}. */
 int mnk_last_plan(long* out8);
@@ -411,6 +412,14 @@ int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, fl
 int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, float temperature,
                        const float* mean, const float* stat, const float* dmean, const float* dvar, float* dheat,
                        int ld_d, void* stream);
+/* The integers of the key-point path (north star "bit-exact keypoint indices"; the reference forms integers from key points in
+ * exactly one place, the Visualizer):
+ *   mnk_heatmap_argmax: index[n][k] = h * W + w of the largest heat-map logit, first occurrence -- the integer form of the
+ *     spatial soft-argmax of keypoint_detector.py:103-104 (soft-max and 1/temperature are monotone);
+ *   mnk_kp_pixel_index: pixel[i][2] = floor(size * (mean + 1) / 2), size = (W, H) -- logger.py:99-100
+ *     (`spatial_size * (kp_array + 1) / 2`, then rasterised by skimage.draw.circle, :104), n = number of key points. */
+int mnk_heatmap_argmax(const float* heat, int ld, int N, int H, int W, int K, int* index, void* stream);
+int mnk_kp_pixel_index(const float* mean, long n, int W, int H, int* pixel, void* stream);
 /* clip_variance (keypoint_detector.py:62-65): out = var * max(clip, sigma_min(var)) / sigma_min(var) over M 2x2
  * matrices, sigma_min by the closed form of modules/util.py:244-255; backward through both factors. */
 int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, void* stream);

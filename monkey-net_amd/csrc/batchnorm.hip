@@ -16,8 +16,8 @@ struct Map2D {
     long rows_per_block;
 };
 
-static int g_bn_rpt = getenv("MNK_BN_RPT") ? atoi(getenv("MNK_BN_RPT")) : 4;            // rows per thread before a layer is cut (A/B: 8 -> 4: 11.51 -> 11.44 ms per step)
-static int g_bn_blocks = getenv("MNK_BN_BLOCKS") ? atoi(getenv("MNK_BN_BLOCKS")) : 1024;   // into more row blocks; block cap
+static int g_bn_rpt = tuning_knob("bn_rpt", &g_bn_rpt, 4);            // rows per thread before a layer is cut (A/B: 8 -> 4: 11.51 -> 11.44 ms per step)
+static int g_bn_blocks = tuning_knob("bn_blocks", &g_bn_blocks, 1024);   // into more row blocks; block cap
 
 static Map2D make_map(long rows, int ld, int rows_per_thread = 0, int want_blocks = 0) {
     if (rows_per_thread <= 0) rows_per_thread = g_bn_rpt;
@@ -493,25 +493,21 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
 //             running statistics -> z = [pool] relu((y - mean) * scale + beta)
 //   backward: sum g, sum g*xhat (= dbeta, dgamma) -> dy = scale * (g - sum_g / n - xhat * sum_gx / n)
 // Single rank only (SyncBN has an all-reduce between the two halves).  rows <= mnk_bn_small_rows().
-static int small_env(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 // defaults from the MI355X A/B (profiles/README.md): 512 rows with one channel quad per block is the only setting that beats
 // the general four-launch path (12.39 vs 12.42 ms per iteration); 2048 rows / 4 quads per block LOSES 0.3 ms -- a handful of
 // blocks walking 32+ rows each is slower than four well-filled launches
-static int g_small_rows = small_env("MNK_BN_SMALL_ROWS", 512);
-static int g_small_txn = small_env("MNK_BN_SMALL_TXN", 1);           // channel quads per block: 0 = by channel count
+static int g_small_rows = tuning_knob("bn_small_rows", &g_small_rows, 512);
+static int g_small_txn = tuning_knob("bn_small_txn", &g_small_txn, 1);           // channel quads per block: 0 = by channel count
 // forward kernel: threads per block (256 / 512 / 1024) and channel quads per block.  It sums the split-K partials of the
 // convolution in front (8 ... 32 x rows x C floats): with one quad per block every lane reads 16 of the 128 bytes of its
 // line and a block of 256 threads is one wave per SIMD.  1024 threads over up to 8 quads (a full line per row, at least
 // 32 blocks) is the measured setting: 11.25 -> 11.19 ms per iteration (profiles/r02_knob_ab_log.txt, visit 42);
 // MNK_BN_SMALL_FWD_TXN = 0: by channel count, -1: as MNK_BN_SMALL_TXN
-static int g_small_fwd_threads = small_env("MNK_BN_SMALL_FWD_THREADS", 1024);
-static int g_small_fwd_txn = small_env("MNK_BN_SMALL_FWD_TXN", 0);
+static int g_small_fwd_threads = tuning_knob("bn_small_fwd_threads", &g_small_fwd_threads, 1024);
+static int g_small_fwd_txn = tuning_knob("bn_small_fwd_txn", &g_small_fwd_txn, 0);
 // 1: the backward kernel takes the same shape; 0 (default): 256 threads x MNK_BN_SMALL_TXN quads -- it reads y and dz once,
 // no split partials, and was 0.03 ms per iteration faster that way (visit 43)
-static int g_small_bwd_shape = small_env("MNK_BN_SMALL_BWD_SHAPE", 0);
+static int g_small_bwd_shape = tuning_knob("bn_small_bwd_shape", &g_small_bwd_shape, 0);
 
 __device__ __forceinline__ void small_tree_sum2(float4* red0, float4* red1, float4& a, float4& b, int tx_n, int ty_n, int tx,
                                                 int ty) {

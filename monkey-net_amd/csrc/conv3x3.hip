@@ -24,6 +24,7 @@
 // with a deterministic second-pass reduction (no atomics), which also applies bias and the residual add.
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #include "mnk_common.h"
 #include "pack_tile.h"
@@ -119,12 +120,12 @@ __device__ __forceinline__ void xcd_tile(int enable, int& bx, int& by) {
 // and columns); the per-step gather is branch-free: a tap outside the image reads the clamped pixel and is zeroed on
 // its way to LDS, rows beyond M are clamped to the last pixel (their results are never stored).  K-step cursor
 // (step = chunk * ntaps + ky * kw + kx) advances without divisions or branches.
-template <int RA>
+template <int RA, int NST = 1>      // NST: register stages (K steps in flight between their global loads and their LDS stores)
 struct ActLoader {
     int prow[RA], ph[RA], pw[RA];
     unsigned pmask[RA];            // bits 0..7: kernel rows inside the image, bits 8..15: kernel columns
-    float4 ra[RA];
-    int tail[RA];                  // real channels in ra[j] (<= 0: tap outside the image / chunk beyond C)
+    float4 ra[NST][RA];
+    int tail[NST][RA];             // real channels in ra[st][j] (<= 0: tap outside the image / chunk beyond C)
     int chunk, ky, kx, khh, Hs, Ws, hmax, wmax, lq;
 
     __device__ __forceinline__ void setup(const ConvArgs& a, long m0, int lrow, int lq_, int s_begin, int, int) {
@@ -152,13 +153,15 @@ struct ActLoader {
                 if (ww >= 0 && ww < a.Wi) mk |= 256u << x;
             }
             pmask[j] = mk;
-            tail[j] = 0;
+#pragma unroll
+            for (int st = 0; st < NST; ++st) tail[st][j] = 0;
         }
         chunk = s_begin / a.ntaps;
         ky = (s_begin - chunk * a.ntaps) / a.kw;
         kx = (s_begin - chunk * a.ntaps) - ky * a.kw;
     }
-    // issue the global loads of the cursor's K step, then advance the cursor
+    // issue the global loads of the cursor's K step into register stage ST, then advance the cursor
+    template <int ST = 0>
     __device__ __forceinline__ void load(const ConvArgs& a) {
         const int c0 = chunk * BK;
         const bool second = c0 >= a.C0p;
@@ -176,8 +179,8 @@ struct ActLoader {
             hh = hh < 0 ? 0 : (hh > hmax ? hmax : hh);
             ww = ww < 0 ? 0 : (ww > wmax ? wmax : ww);
             const unsigned off = (unsigned)(prow[j] + (hh >> a.ups) * Ws + (ww >> a.ups)) * (unsigned)ld + (unsigned)che;
-            ra[j] = *reinterpret_cast<const float4*>(src + off);
-            tail[j] = ok ? tl : 0;
+            ra[ST][j] = *reinterpret_cast<const float4*>(src + off);
+            tail[ST][j] = ok ? tl : 0;
         }
         const int kx1 = kx + 1;
         const bool wx = kx1 == a.kw;
@@ -188,12 +191,13 @@ struct ActLoader {
         chunk += wy ? 1 : 0;
     }
     // row j on its way to LDS: pad channels of the producer may hold anything, taps outside the image are zero
+    template <int ST = 0>
     __device__ __forceinline__ float4 masked(int j) const {
-        float4 v = ra[j];
-        v.x = tail[j] < 1 ? 0.f : v.x;
-        v.y = tail[j] < 2 ? 0.f : v.y;
-        v.z = tail[j] < 3 ? 0.f : v.z;
-        v.w = tail[j] < 4 ? 0.f : v.w;
+        float4 v = ra[ST][j];
+        v.x = tail[ST][j] < 1 ? 0.f : v.x;
+        v.y = tail[ST][j] < 2 ? 0.f : v.y;
+        v.z = tail[ST][j] < 3 ? 0.f : v.z;
+        v.w = tail[ST][j] < 4 ? 0.f : v.w;
         return v;
     }
 };
@@ -204,12 +208,12 @@ struct ActLoader {
 // (offsets stay far below 2^30; num_records = 2^30): an out-of-image tap or a chunk beyond the channel count gets bit
 // 30 added to its offset and the hardware returns zeros -- no clamping, no data masks, no branches.  Per row and step:
 // one add, one bit-field extract, one and-or (+ five for the parity shifts of the nearest x2 up-sampling view).
-template <int RA, bool UPS>
+template <int RA, bool UPS, int NST = 1>
 struct ActLoader3 {
     unsigned b0[RA], b1[RA];       // byte offset of the row's centre pixel in source 0 / 1 (relative to the block base)
     unsigned inv[RA];              // bit t: tap t lies outside the image
     unsigned par[RA];              // up-sampling: bit 0 h even, 1 h odd, 2 w even, 3 w odd (bit 4 stays 0)
-    float4 ra[RA];
+    float4 ra[NST][RA];
     __amdgpu_buffer_rsrc_t r0, r1;
     int chunk, ky, kx, Ws, lq4;
 
@@ -247,6 +251,7 @@ struct ActLoader3 {
         ky = (s_begin - chunk * 9) / 3;
         kx = (s_begin - chunk * 9) - ky * 3;
     }
+    template <int ST = 0>
     __device__ __forceinline__ void load(const ConvArgs& a) {
         const int c0 = chunk * BK;
         const bool second = c0 >= a.C0p;
@@ -275,7 +280,7 @@ struct ActLoader3 {
             }
             const int bad = __builtin_amdgcn_sbfe(inv[j], tap, 1);            // 0 or -1
             off = ((unsigned)bad & 0x40000000u) | off;
-            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            ra[ST][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         }
         const int kx1 = kx + 1;
         const bool wx = kx1 == 3;
@@ -285,18 +290,19 @@ struct ActLoader3 {
         ky = wy ? 0 : ky1;
         chunk += wy ? 1 : 0;
     }
-    __device__ __forceinline__ float4 masked(int j) const { return ra[j]; }
+    template <int ST = 0>
+    __device__ __forceinline__ float4 masked(int j) const { return ra[ST][j]; }
 };
 
 // ---- the same idea for any K x K kernel with stride 1 and padding `pad` (the discriminator's 4x4 / pad 0 forward and its
 // pad 3 data gradient), sources with clean pad channels, no up-sampled view: per-row base offset + one validity bit per
 // tap (K*K <= 32); an out-of-image tap or a channel chunk beyond C reads zeros through the buffer range check.
-template <int RA>
+template <int RA, int NST = 1>
 struct ActLoaderK {
     unsigned b0[RA], b1[RA];       // byte offset of input pixel (h * stride, w * stride) -- tap (pad_y, pad_x) -- relative to the
                                    // block base; may lie outside the image (pad > 0): it is only a base for the tap arithmetic
     unsigned inv[RA];              // bit ky * kw + kx: the tap lies outside the image
-    float4 ra[RA];
+    float4 ra[NST][RA];
     __amdgpu_buffer_rsrc_t r0, r1;
     int chunk, ky, kx, khh, lq4, pady, padx;
 
@@ -338,6 +344,7 @@ struct ActLoaderK {
         ky = (s_begin - chunk * a.ntaps) / a.kw;
         kx = (s_begin - chunk * a.ntaps) - ky * a.kw;
     }
+    template <int ST = 0>
     __device__ __forceinline__ void load(const ConvArgs& a) {
         const int c0 = chunk * BK;
         const bool second = c0 >= a.C0p;
@@ -353,7 +360,7 @@ struct ActLoaderK {
             unsigned off = (second ? b1[j] : b0[j]) + st;
             const int bad = __builtin_amdgcn_sbfe(inv[j], tap, 1);            // 0 or -1
             off = ((unsigned)bad & 0x40000000u) | off;
-            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            ra[ST][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
         }
         const int kx1 = kx + 1;
         const bool wx = kx1 == a.kw;
@@ -363,23 +370,38 @@ struct ActLoaderK {
         ky = wy ? 0 : ky1;
         chunk += wy ? 1 : 0;
     }
-    __device__ __forceinline__ float4 masked(int j) const { return ra[j]; }
+    template <int ST = 0>
+    __device__ __forceinline__ float4 masked(int j) const { return ra[ST][j]; }
 };
 
-template <int RA, int MODE> struct LoaderSel { typedef ActLoader<RA> type; };
-template <int RA> struct LoaderSel<RA, 3> { typedef ActLoaderK<RA> type; };
-template <int RA> struct LoaderSel<RA, 1> { typedef ActLoader3<RA, false> type; };
-template <int RA> struct LoaderSel<RA, 2> { typedef ActLoader3<RA, true> type; };
+template <int RA, int MODE, int NST = 1> struct LoaderSel { typedef ActLoader<RA, NST> type; };
+template <int RA, int NST> struct LoaderSel<RA, 3, NST> { typedef ActLoaderK<RA, NST> type; };
+template <int RA, int NST> struct LoaderSel<RA, 1, NST> { typedef ActLoader3<RA, false, NST> type; };
+template <int RA, int NST> struct LoaderSel<RA, 2, NST> { typedef ActLoader3<RA, true, NST> type; };
 
 #ifndef MNK_IGEMM_OCC
 #define MNK_IGEMM_OCC 3                       // waves per SIMD = blocks per CU the register budget is held to
+#endif
+#ifndef MNK_IGEMM_NACC
+#define MNK_IGEMM_NACC 2                      // accumulator sets of a one-tile wave (64x64 / 128x32 block tiles)
+#endif
+#ifndef MNK_IGEMM_NST
+#define MNK_IGEMM_NST 2                       // register stages: K steps between a step's global loads and its LDS stores
 #endif
 
 template <int BM, int BN, int WM, int WN, int MODE>     // MODE: 0 generic loader, 1 / 2 the 3x3 fast loader (plain / x2 up-sampled)
 __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvArgs a) {
     constexpr int RA = BM / 64;               // A rows per thread per K step
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    // A wave that owns ONE 32x32 tile would run all its MFMAs as one dependent chain on one accumulator: an MFMA that follows
+    // its predecessor on the same accumulator with other instructions in between waits for the write-back (the back-to-back
+    // forwarding path only serves adjacent issues), and the loop has loads, LDS traffic and address arithmetic between every
+    // pair.  Two accumulator sets fed by alternating K elements make neighbours independent; they are added once at the end
+    // (which also halves the length of the fp32 summation chain: K = 9 * Cin <= 18 522 terms).
+    constexpr int NACC = (TM * TN == 1) ? MNK_IGEMM_NACC : 1;
+    constexpr int NST = (BM * BN <= 64 * 128) ? MNK_IGEMM_NST : 1;     // 8 (16) registers per stage; the 128x128 tile has none to spare
     static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(NST == 1 || NST == 2, "one or two register stages");
     __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_K];
 
@@ -402,7 +424,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
 
     // ---- per-thread global->LDS assignment: row inside a 64-row slab, float4 column (4 channels) --------------
     const int lrow = t >> 2, lq = t & 3;
-    typename LoaderSel<RA, MODE>::type L;
+    typename LoaderSel<RA, MODE, NST>::type L;
     L.setup(a, m0, lrow, lq, s_begin, a.pad - pa, (a.pad_x < 0 ? a.pad : a.pad_x) - pb);
     constexpr int RB = (BN + 63) / 64;        // B rows per thread per K step
     const long KT = (long)a.ksteps * BK;     // packed row length
@@ -410,28 +432,39 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     const int wco0 = n0 + lrow, wco1 = n0 + lrow + 64;    // rows beyond Cout: clamped, never stored
     const unsigned woff0 = (unsigned)((wco0 < a.Cout ? wco0 : a.Cout - 1) * KT) + lq * 4;
     const unsigned woff1 = (unsigned)((wco1 < a.Cout ? wco1 : a.Cout - 1) * KT) + lq * 4;
-    float4 rb0, rb1;
+    float4 rb0a, rb0b, rb1a, rb1b;            // weight rows of register stage 0 (a) / 1 (b): scalars, not arrays -- an array
+                                              // captured by the lambdas below ends up in scratch memory
 
-    auto load_step = [&](int s) __attribute__((always_inline)) {
-        L.load(a);
+    // global loads of K step s into register stage ST (the activation loader keeps its own cursor: steps in order)
+    auto load_step = [&](int s, auto st_tag) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_tag)::value;
+        L.template load<ST>(a);
         const float* wsrc_ptr = wpb + (long)s * BK;
-        rb0 = *reinterpret_cast<const float4*>(wsrc_ptr + woff0);
-        if constexpr (RB > 1) rb1 = *reinterpret_cast<const float4*>(wsrc_ptr + woff1);
+        if constexpr (ST == 0) {
+            rb0a = *reinterpret_cast<const float4*>(wsrc_ptr + woff0);
+            if constexpr (RB > 1) rb1a = *reinterpret_cast<const float4*>(wsrc_ptr + woff1);
+        } else {
+            rb0b = *reinterpret_cast<const float4*>(wsrc_ptr + woff0);
+            if constexpr (RB > 1) rb1b = *reinterpret_cast<const float4*>(wsrc_ptr + woff1);
+        }
     };
-    auto store_step = [&](int buf) __attribute__((always_inline)) {
+    auto store_step = [&](int buf, auto st_tag) __attribute__((always_inline)) {
+        constexpr int ST = decltype(st_tag)::value;
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = L.masked(j);
-        if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = rb0;
-        if constexpr (RB > 1) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64][lq * 4]) = rb1;
+        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = L.template masked<ST>(j);
+        if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = ST == 0 ? rb0a : rb0b;
+        if constexpr (RB > 1) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64][lq * 4]) = ST == 0 ? rb1a : rb1b;
     };
 
-    f32x16 acc[TM][TN];
+    f32x16 acc[NACC][TM][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < NACC; ++q)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
 
     const int fi = lane & 31, fk = lane >> 5;
     const int a_row0 = wm * (BM / WM) + fi, b_row0 = wn * (BN / WN) + fi;
@@ -450,51 +483,80 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                    constexpr int Q = NACC - 1;
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[0][i][j], 0, 0, 0);
+                    acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[Q][i][j], 0, 0, 0);
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[0][i][j], 0, 0, 0);
+                    acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[Q][i][j], 0, 0, 0);
                 }
         }
     };
+    using St0 = std::integral_constant<int, 0>;
+    using St1 = std::integral_constant<int, NST - 1>;
 
-    // Pipeline: the registers always hold the step after the one in LDS.  In step s the wave first parks step s+1
-    // in the other LDS buffer (loaded a whole step ago: no wait), issues the global loads of step s+2 and then runs
-    // the MFMAs of step s, so loads, address arithmetic and LDS writes sit in the MFMA shadow; one barrier per step.
-    // The steady-state loop body is branch-free (one basic block); the last two steps are peeled.
-    if (s_begin < s_end) {
-        load_step(s_begin);
-        store_step(0);
-        if (s_begin + 1 < s_end) load_step(s_begin + 1);
+    // Pipeline.  K step t (relative to s_begin) travels in register stage t % NST and lands in LDS buffer t & 1.
+    //   NST = 1: the registers always hold the step after the one in LDS.  In step s the wave parks step s+1 in the other
+    //            LDS buffer (loaded a whole step ago), issues the global loads of step s+2 and then runs the MFMAs of step s.
+    //   NST = 2: two steps are in flight in registers: step s parks step s+1, issues the loads of step s+3 into the stage
+    //            that store just freed, runs the MFMAs of step s -- a load has two whole steps to arrive (one step of eight
+    //            MFMAs does not cover an HBM miss when few waves share the SIMD).
+    // Loads, address arithmetic and LDS writes sit in the MFMA shadow; one barrier per step; the steady-state loop body is
+    // branch-free (two steps per trip: LDS buffer and register stage are compile-time constants); the tail is peeled.
+    const int n = s_end - s_begin;
+    if (n > 0) {
+        load_step(s_begin, St0{});
+        store_step(0, St0{});
+        if (n > 1) load_step(s_begin + 1, St1{});
+        if (NST == 2 && n > 2) load_step(s_begin + 2, St0{});
     }
+    if (NST == 2) MNK_WAIT_VMEM();            // exact wait counts inside the loop (see the macro)
     __syncthreads();
-    int s = s_begin;
-    for (; s + 3 < s_end; s += 2) {           // two steps per trip: the LDS buffer index is a compile-time constant
-        store_step(1);
-        load_step(s + 2);
-        mfma_step(0);
-        __syncthreads();
-        store_step(0);
-        load_step(s + 3);
-        mfma_step(1);
-        __syncthreads();
+    int s = 0;
+    if constexpr (NST == 2) {
+        for (; s + 4 < n; s += 2) {
+            store_step(1, St1{});
+            load_step(s_begin + s + 3, St1{});
+            mfma_step(0);
+            __syncthreads();
+            store_step(0, St0{});
+            load_step(s_begin + s + 4, St0{});
+            mfma_step(1);
+            __syncthreads();
+        }
+        for (; s < n; ++s) {                  // at most four steps (s is even here)
+            if ((s & 1) == 0) {
+                if (s + 1 < n) store_step(1, St1{});
+                if (s + 3 < n) load_step(s_begin + s + 3, St1{});
+                mfma_step(0);
+            } else {
+                if (s + 1 < n) store_step(0, St0{});
+                if (s + 3 < n) load_step(s_begin + s + 3, St0{});
+                mfma_step(1);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (; s + 3 < n; s += 2) {
+            store_step(1, St0{});
+            load_step(s_begin + s + 2, St0{});
+            mfma_step(0);
+            __syncthreads();
+            store_step(0, St0{});
+            load_step(s_begin + s + 3, St0{});
+            mfma_step(1);
+            __syncthreads();
+        }
+        for (; s < n; ++s) {
+            if (s + 1 < n) store_step((s & 1) ^ 1, St0{});
+            if (s + 2 < n) load_step(s_begin + s + 2, St0{});
+            mfma_step(s & 1);
+            __syncthreads();                  // (the last one: the epilogue reuses As for the column sums)
+        }
     }
-    for (; s + 2 < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
-        store_step(buf ^ 1);
-        load_step(s + 2);
-        mfma_step(buf);
-        __syncthreads();
+    if constexpr (NACC == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[1][0][0][r];
     }
-    if (s + 1 < s_end) {
-        const int buf = (s - s_begin) & 1;
-        store_step(buf ^ 1);
-        mfma_step(buf);
-        __syncthreads();
-        ++s;
-    }
-    if (s < s_end) mfma_step((s - s_begin) & 1);
-    __syncthreads();                          // the epilogue reuses As for the column sums
 
     // ---- epilogue: D[row][col], col = lane&31 (-> co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (-> pixel) ------
     // bias is fetched once per column, residual values are fetched as a batch before the stores (no per-element
@@ -546,7 +608,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned ro = (r & 3) + 8 * (r >> 2);
-                        float v = acc[i][j][r];
+                        float v = acc[0][i][j][r];
                         if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
                         if (FULL || mb + ro < Mu) {
                             if (scatter)
@@ -814,7 +876,7 @@ struct RSMap {
 };
 // rows per thread before a layer is cut into more row blocks (A/B with every split-K reduction on this kernel, visit 48:
 // 1 / 2 / 4 -> 10.92 / 10.97 / 11.10 ms; the 64 x 4-group kernel: 10.95)
-static int g_rs_rpt = getenv("MNK_RS_RPT") ? atoi(getenv("MNK_RS_RPT")) : 1;
+static int g_rs_rpt = tuning_knob("rs_rpt", &g_rs_rpt, 1);
 static RSMap make_rsmap(long rows, int ld) {
     RSMap m;
     const int nv = ld / 4;
@@ -2132,36 +2194,33 @@ struct Plan {
     int bm, bn, gm, gn, splits, ksteps, ksteps_per_split, ldw;
 };
 
-// split-K knobs (defaults from the MI355X sweep in profiles/README.md; env overrides are for tuning runs only)
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
-static int g_split_tiles = env_int("MNK_SPLIT_TILES", 192), g_split_target = env_int("MNK_SPLIT_TARGET", 512),
-           g_split_minsteps = env_int("MNK_SPLIT_MINSTEPS", 6);
+// split-K plan values (defaults from the MI355X sweeps in profiles/README.md; tuning_knob: settable by name through
+// mnk_set_tuning / MNK_TUNING for tuning runs, no environment switch of their own)
+static int g_split_tiles = tuning_knob("split_tiles", &g_split_tiles, 192), g_split_target = tuning_knob("split_target", &g_split_target, 512),
+           g_split_minsteps = tuning_knob("split_minsteps", &g_split_minsteps, 6);
 // 0 (default): deterministic split-K partials + reduce kernel; 1: accumulate the partial tiles with fp32 atomics into
 // the zeroed gradient (no partial buffer / reduce launch).  Measured equal on the MI355X (21.74 ms per training
 // iteration either way: the atomics cost the wgrad kernel what the reduce kernel saves), so determinism wins.
-static int g_wgrad_atomic = env_int("MNK_WGRAD_ATOMIC", 0);
+static int g_wgrad_atomic = tuning_knob("wgrad_atomic", &g_wgrad_atomic, 0);
 // 1 (default): a split-K forward launch that was asked for BatchNorm statistics sums its partials with
 // conv3x3_splitk_reduce_stats_kernel (one launch for reduction + statistics pass); 0: no statistics from split launches
-static int g_splitk_stats = env_int("MNK_SPLITK_STATS", 1);
+static int g_splitk_stats = tuning_knob("splitk_stats", &g_splitk_stats, 1);
 // 1: every split-K reduction runs the float4-row kernel (the statistics kernel without its statistics; the same bits);
 // 0: conv3x3_splitk_reduce_kernel (64 outputs x 4 split groups per block, combined through LDS)
-static int g_reduce_v4 = env_int("MNK_REDUCE_V4", 1);
-static int g_wsplit_tiles = env_int("MNK_WSPLIT_TILES", 512), g_wsplit_target = env_int("MNK_WSPLIT_TARGET", 1024),
-           g_wsplit_minsteps = env_int("MNK_WSPLIT_MINSTEPS", 8);
+static int g_reduce_v4 = tuning_knob("reduce_v4", &g_reduce_v4, 1);
+static int g_wsplit_tiles = tuning_knob("wsplit_tiles", &g_wsplit_tiles, 512), g_wsplit_target = tuning_knob("wsplit_target", &g_wsplit_target, 1024),
+           g_wsplit_minsteps = tuning_knob("wsplit_minsteps", &g_wsplit_minsteps, 8);
 
 // mid-size layers (fewer than ~2 blocks per CU with 128-row tiles) use 64-row tiles: twice the blocks, so every SIMD
 // has a second wave to overlap loads with MFMA, and less (or no) split-K
-static int g_bm64_tiles = env_int("MNK_BM64_TILES", 512);
-static int g_split64_tiles = env_int("MNK_SPLIT64_TILES", 384), g_split64_target = env_int("MNK_SPLIT64_TARGET", 1024),
-           g_split64_deep = env_int("MNK_SPLIT64_DEEP", 32), g_split64_minsteps = env_int("MNK_SPLIT64_MINSTEPS", 16);
-static double g_bn128_work = (double)env_int("MNK_BN128_KWORK", 8388) * 1000.0;   // pixels x channels from which 128-wide tiles are used
-static int g_xcd_remap = env_int("MNK_XCD_REMAP", 1);
-static int g_fast_loader = env_int("MNK_FAST_LOADER", 1);
-static int g_kxk_fast = env_int("MNK_KXK_FAST", 1);     // buffer-load loader for K x K / any pad (MODE 3)
-static int g_mfma16 = env_int("MNK_MFMA16", 1);
+static int g_bm64_tiles = tuning_knob("bm64_tiles", &g_bm64_tiles, 512);
+static int g_split64_tiles = tuning_knob("split64_tiles", &g_split64_tiles, 384), g_split64_target = tuning_knob("split64_target", &g_split64_target, 1024),
+           g_split64_deep = tuning_knob("split64_deep", &g_split64_deep, 32), g_split64_minsteps = tuning_knob("split64_minsteps", &g_split64_minsteps, 16);
+static int g_bn128_kwork = tuning_knob("bn128_kwork", &g_bn128_kwork, 8388);   // 1000 pixels x channels from which 128-wide tiles are used
+static int g_xcd_remap = tuning_knob("xcd_remap", &g_xcd_remap, 1);
+static int g_fast_loader = tuning_knob("fast_loader", &g_fast_loader, 1);
+static int g_kxk_fast = tuning_knob("kxk_fast", &g_kxk_fast, 1);     // buffer-load loader for K x K / any pad (MODE 3)
+static int g_mfma16 = tuning_knob("mfma16", &g_mfma16, 1);
 
 struct PlanRow {
     long M;
@@ -2170,7 +2229,8 @@ struct PlanRow {
 static const PlanRow g_tuned_rows[] = {
 #include "plan_table.h"
     {0, 0, 0, 0, 0, 0, 0, 0}};
-static int g_plan_table = env_int("MNK_PLAN_TABLE", 1), g_force_bm = 0, g_force_bn = 0, g_force_splits = 0;
+static int g_plan_table = tuning_knob("plan_table", &g_plan_table, 1), g_force_bm = tuning_knob("force_bm", &g_force_bm, 0),
+           g_force_bn = tuning_knob("force_bn", &g_force_bn, 0), g_force_splits = tuning_knob("force_splits", &g_force_splits, 0);
 static long g_last_plan[8];
 
 // block tiles the GEMM kernels are instantiated for (conv2d_fwd_impl's dispatch)
@@ -2192,9 +2252,9 @@ static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 
     // the 64x64 tile (56 registers, 20 KB of LDS: 8 blocks per CU) is the fastest instantiation for every layer wider than
     // 48 channels -- by 5..40 % where 128-wide tiles left CUs idle or forced a split-K the 64x64 plan does not need -- except
     // large layers whose width is a multiple of 128 (>= 65536 pixels x 128 channels: level with the 128x128 tile)
-    // (MNK_BN128_KWORK < 0: the previous rule -- 128-wide tiles for every layer wider than 64 channels -- for A/B runs)
-    const bool small_tiles = g_bn128_work >= 0.0;
-    if (small_tiles && p.bn == 128 && (Cout % 128 != 0 || (double)M * phases * Cout < g_bn128_work)) p.bn = 64;
+    // (bn128_kwork < 0: the previous rule -- 128-wide tiles for every layer wider than 64 channels -- for A/B runs)
+    const bool small_tiles = g_bn128_kwork >= 0;
+    if (small_tiles && p.bn == 128 && (Cout % 128 != 0 || (double)M * phases * Cout < (double)g_bn128_kwork * 1000.0)) p.bn = 64;
     p.gn = ceil_div(Cout, p.bn);
     p.bm = 128;
     if ((small_tiles && p.bn == 64) || (p.bn >= 64 && (long)ceil_div(M, 128) * p.gn * phases < g_bm64_tiles)) p.bm = 64;
@@ -2259,8 +2319,8 @@ struct HPlan {
     int TR, TC, tiles_w, tiles_per_img, gm, gn, splits;
     long total_tiles, tiles_per_split;
 };
-static int g_wgrad_halo = env_int("MNK_WGRAD_HALO", 1), g_whalo_target = env_int("MNK_WHALO_TARGET", 768),
-           g_whalo_mintiles = env_int("MNK_WHALO_MINTILES", 8);
+static int g_wgrad_halo = tuning_knob("wgrad_halo", &g_wgrad_halo, 1), g_whalo_target = tuning_knob("whalo_target", &g_whalo_target, 768),
+           g_whalo_mintiles = tuning_knob("whalo_mintiles", &g_whalo_mintiles, 8);
 
 static HPlan make_hplan(int N, int H, int W, int Cout, int C) {
     HPlan p;
@@ -2315,12 +2375,12 @@ struct NPlan {
     int gm, gn, tiles_w, tiles_per_img, splits;
     long total_tiles, tiles_per_split;
 };
-static int g_wgrad_n16 = env_int("MNK_WGRAD_N16", 1), g_wn16_target = env_int("MNK_WN16_TARGET", 512),
-           g_wn16_mintiles = env_int("MNK_WN16_MINTILES", 2), g_wn16_minc = env_int("MNK_WN16_MINC", 1);
+static int g_wgrad_n16 = tuning_knob("wgrad_n16", &g_wgrad_n16, 1), g_wn16_target = tuning_knob("wn16_target", &g_wn16_target, 512),
+           g_wn16_mintiles = tuning_knob("wn16_mintiles", &g_wn16_mintiles, 2), g_wn16_minc = tuning_knob("wn16_minc", &g_wn16_minc, 1);
 
 // blocks per layer of a grouped nine-tap launch: layers with all 3 x 3 channel tiles in use come in numbers (the eight
 // 45 -> 45 convolutions of the refinement stack), the narrower ones are one or two per launch and need more blocks each
-static int g_wn16_group_target = env_int("MNK_WN16_GROUP_TARGET", 128), g_wn16_group_target_few = env_int("MNK_WN16_GROUP_FEW", 256);
+static int g_wn16_group_target = tuning_knob("wn16_group_target", &g_wn16_group_target, 128), g_wn16_group_target_few = tuning_knob("wn16_group_few", &g_wn16_group_target_few, 256);
 static int n16_group_target(int Cout, int C) { return (Cout > 32 && C > 32) ? g_wn16_group_target : g_wn16_group_target_few; }
 
 static NPlan make_nplan(int N, int H, int W, int Cout, int C, int ld_x, int target = 0) {
@@ -2349,9 +2409,9 @@ struct TPlan {
     int groups, per_group;       // two-stage split reduction when splits > 12 (groups of ~8 splits), else groups = 0
     long pix_per_split;
 };
-static int g_wgrad_tap = env_int("MNK_WGRAD_TAP", 1), g_wtap_target = env_int("MNK_WTAP_TARGET", 768),
-           g_wtap_minsteps = env_int("MNK_WTAP_MINSTEPS", 8), g_wtap_minc = env_int("MNK_WTAP_MINC", 16),
-           g_wtap_bm_max = env_int("MNK_WTAP_BM_MAX", 128);       // 64: no 128-row tiles (A/B runs)
+static int g_wgrad_tap = tuning_knob("wgrad_tap", &g_wgrad_tap, 1), g_wtap_target = tuning_knob("wtap_target", &g_wtap_target, 768),
+           g_wtap_minsteps = tuning_knob("wtap_minsteps", &g_wtap_minsteps, 8), g_wtap_minc = tuning_knob("wtap_minc", &g_wtap_minc, 16),
+           g_wtap_bm_max = tuning_knob("wtap_bm_max", &g_wtap_bm_max, 128);       // 64: no 128-row tiles (A/B runs)
 
 static TPlan make_tplan(long M, int Cout, int C, int ntaps, int ld_x) {
     TPlan p;
@@ -2421,9 +2481,9 @@ static void launch_wgrad_reduce(float* ws, int splits, int Cout, int NT, float* 
 }
 
 // ---- grouped tap-major weight gradients: plan / build / launch --------------------------------------------------------
-static int g_wgroup_chunk = env_int("MNK_WGROUP_CHUNK", 256);
-static int g_wgroup_long = env_int("MNK_WGROUP_LONG", 1), g_wgroup_long_from = env_int("MNK_WGROUP_LONG_FROM", 128);
-static int g_up_subpixel = env_int("MNK_UP_SUBPIXEL", 1);     // weight gradients of up-sampled convolutions: sub-pixel form
+static int g_wgroup_chunk = tuning_knob("wgroup_chunk", &g_wgroup_chunk, 256);
+static int g_wgroup_long = tuning_knob("wgroup_long", &g_wgroup_long, 1), g_wgroup_long_from = tuning_knob("wgroup_long_from", &g_wgroup_long_from, 128);
+static int g_up_subpixel = tuning_knob("up_subpixel", &g_up_subpixel, 1);     // weight gradients of up-sampled convolutions: sub-pixel form
 
 // the sub-pixel tap-major plan of an up-sampled 3x3 layer (flags: UPSAMPLED | CLEAN_PADS), or use = false
 static TPlan make_up_tplan(int N, int Ho, int Wo, int Cout, int C, int kh, int kw, int pad, int ld_x, int flags) {
@@ -3325,26 +3385,6 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
 }
 
 // launch-plan switches are read from the environment when the library is loaded; this sets one afterwards (A/B runs, tests)
-int mnk_set_tuning(const char* name, int value) {
-    MNK_REQUIRE(name);
-    struct { const char* n; int* v; } knobs[] = {{"MNK_UP_SUBPIXEL", &g_up_subpixel}, {"MNK_WGROUP_CHUNK", &g_wgroup_chunk},
-                                                  {"MNK_WTAP_TARGET", &g_wtap_target}, {"MNK_WN16_TARGET", &g_wn16_target},
-                                                  {"MNK_SPLIT_TARGET", &g_split_target}, {"MNK_SPLIT_TILES", &g_split_tiles},
-                                                  {"MNK_BM64_TILES", &g_bm64_tiles}, {"MNK_XCD_REMAP", &g_xcd_remap},
-                                                  {"MNK_PLAN_TABLE", &g_plan_table}, {"MNK_FORCE_BM", &g_force_bm},
-                                                  {"MNK_FORCE_BN", &g_force_bn}, {"MNK_FORCE_SPLITS", &g_force_splits},
-                                                  {"MNK_WN16_GROUP_TARGET", &g_wn16_group_target},
-                                                  {"MNK_WN16_GROUP_FEW", &g_wn16_group_target_few},
-                                                  {"MNK_SPLITK_STATS", &g_splitk_stats}, {"MNK_REDUCE_V4", &g_reduce_v4}};
-    for (auto& k : knobs)
-        if (strcmp(k.n, name) == 0) {
-            *k.v = value;
-            return MNK_OK;
-        }
-    set_error("mnk_set_tuning: unknown switch %s", name);
-    return MNK_EINVAL;
-}
-
 // the last forward / data-gradient launch plan that was made: {M, Cout, chunks, taps, phases, bm, bn, splits}
 int mnk_last_plan(long* out8) {
     MNK_REQUIRE(out8);

@@ -669,10 +669,84 @@ __global__ void __launch_bounds__(256) kp_normalize_kernel(const float* __restri
 // key-point channels per block of the soft-argmax kernels (MNK_KP_GROUP).  16 = all channels of a frame in one block: 64
 // blocks of one wave per SIMD for the 64 frames of an iteration, each doing 3 passes x 10 expf / divisions per pixel; 5 / 2 / 1
 // channels per block measured -0.05 / -0.04 / -0.05 ms per iteration against that (visit 45) -> 5
-static int g_kp_group = getenv("MNK_KP_GROUP") ? atoi(getenv("MNK_KP_GROUP")) : 5;
+static int g_kp_group = tuning_knob("kp_group", &g_kp_group, 5);
 static int kp_group(int K) {
     int kg = g_kp_group < 1 ? 1 : g_kp_group;
     return kg > K ? K : kg;
+}
+
+
+// ---- the integers of the key-point path (north star: "bit-exact keypoint indices") --------------------------------------
+// heatmap_argmax: linear pixel index h * W + w of the largest heat-map logit per (frame, key point), first occurrence --
+// the integer form of the soft-argmax of keypoint_detector.py:103-104 (soft-max and the division by the temperature are
+// monotone, so this is the arg-max of the soft-max heat-map too).  One block per frame, key points in registers.
+__global__ void __launch_bounds__(256) heatmap_argmax_kernel(const float* __restrict__ heat, int ld, int H, int W, int K,
+                                                             int* __restrict__ index) {
+    __shared__ float rv[4][MAXK];
+    __shared__ int ri[4][MAXK];
+    const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int P = H * W;
+    const float* hp = heat + (long)n * P * ld;
+    float bv[MAXK];
+    int bi[MAXK];
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+        bv[k] = -INFINITY;
+        bi[k] = 0x7fffffff;
+    }
+    for (int p = t; p < P; p += 256) {            // ascending p per thread: `>` keeps the first occurrence
+#pragma unroll
+        for (int k = 0; k < MAXK; ++k)
+            if (k < K) {
+                const float v = hp[(long)p * ld + k];
+                if (v > bv[k]) {
+                    bv[k] = v;
+                    bi[k] = p;
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+        if (k < K) {
+            float v = bv[k];
+            int i = bi[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o);
+                const int oi = __shfl_xor(i, o);
+                if (ov > v || (ov == v && oi < i)) {
+                    v = ov;
+                    i = oi;
+                }
+            }
+            if (lane == 0) {
+                rv[wave][k] = v;
+                ri[wave][k] = i;
+            }
+        }
+    __syncthreads();
+    if (t < K) {
+        float v = rv[0][t];
+        int i = ri[0][t];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (rv[w][t] > v || (rv[w][t] == v && ri[w][t] < i)) {
+                v = rv[w][t];
+                i = ri[w][t];
+            }
+        index[(long)n * K + t] = i;
+    }
+}
+
+// kp_pixel_index: the pixel a key point is drawn at -- floor(size * (mean + 1) / 2) per axis, the mapping of
+// Visualizer.draw_video_with_kp (logger.py:99-100: `spatial_size * (kp_array + 1) / 2`, then rasterised), evaluated in the
+// reference's operation order in fp32
+__global__ void __launch_bounds__(256) kp_pixel_index_kernel(const float* __restrict__ mean, long n, int W, int H,
+                                                             int* __restrict__ pixel) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * n) return;
+    const float size = (i & 1) ? (float)H : (float)W;
+    pixel[i] = (int)floorf(size * (mean[i] + 1.f) / 2.f);
 }
 
 }  // namespace
@@ -688,6 +762,24 @@ int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, fl
     const int kg = kp_group(K);
     hipLaunchKernelGGL(softmax_kp_fwd_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg, temperature, mean,
                        var, stat);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_heatmap_argmax(const float* heat, int ld, int N, int H, int W, int K, int* index, void* stream) {
+    MNK_REQUIRE(heat && index && N > 0 && H > 0 && W > 0 && K > 0 && K <= MAXK && ld >= K);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4);
+    hipLaunchKernelGGL(heatmap_argmax_kernel, dim3(N), dim3(256), 0, s, heat, ld, H, W, K, index);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_kp_pixel_index(const float* mean, long n, int W, int H, int* pixel, void* stream) {
+    MNK_REQUIRE(mean && pixel && n > 0 && W > 0 && H > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_KEYPOINT, s, (double)n * 16);
+    hipLaunchKernelGGL(kp_pixel_index_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, s, mean, n, W, H, pixel);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

@@ -20,9 +20,21 @@
 #define MNK_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #endif
 
+// wait until every vector-memory load of this wave has returned (s_waitcnt vmcnt(0); no-op on the emulator).  Used in front of
+// a software-pipelined loop: with nothing pending at the loop entry the compiler's wait-count bookkeeping at the loop header
+// is the back edge's alone, so the waits inside the loop are exact (merged with a prologue that issued its loads in another
+// order they come out pessimistic: `vmcnt(1)` where `vmcnt(3)` would do -- the loop then waits for loads it just issued)
+#ifdef HIPEMU
+#define MNK_WAIT_VMEM() ((void)0)
+#else
+#define MNK_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+#endif
+
 namespace mnk {
 
 void set_error(const char* fmt, ...);
+// a named tuning value with its measured default (runtime.hip): settable through mnk_set_tuning / MNK_TUNING, no env switch of its own
+int tuning_knob(const char* name, int* slot, int dflt);
 
 // kernel ids of the profiling recorder (mnk_prof_*)
 enum KernelId {

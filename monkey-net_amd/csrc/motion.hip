@@ -841,8 +841,8 @@ int mnk_gconv1x1_bwd_weight(const float* x, int ld_x, const float* dy, int ld_dy
 }
 
 // the row-tile forms apply (see conv1x1_rows_fwd_kernel); MNK_CONV1X1_ROWS=0: the thread-per-pixel kernels (A/B runs)
-static int g_c11_rows = getenv("MNK_CONV1X1_ROWS") ? atoi(getenv("MNK_CONV1X1_ROWS")) : 1;
-static int g_deform_bwd_blocks = getenv("MNK_DEFORM_BWD_BLOCKS") ? atoi(getenv("MNK_DEFORM_BWD_BLOCKS")) : 2048;   // 0: no channel slices; 0 / 512 / 2048: 11.03 / 10.99 / 10.95 ms (visit 46)
+static int g_c11_rows = tuning_knob("conv1x1_rows", &g_c11_rows, 1);
+static int g_deform_bwd_blocks = tuning_knob("deform_bwd_blocks", &g_deform_bwd_blocks, 2048);   // 0: no channel slices; 0 / 512 / 2048: 11.03 / 10.99 / 10.95 ms (visit 46)
 static bool c11_rows_form(const float* x, int ld_x, int Cin) {
     return g_c11_rows && ld_x % 4 == 0 && ld_x <= C11_MAXLD && Cin + 1 <= 128 && (size_t)x % 16 == 0;
 }

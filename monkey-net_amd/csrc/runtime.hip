@@ -1,6 +1,7 @@
 // Error reporting + per-kernel event timing for libmonkeynet_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -16,6 +17,31 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- tuning values of the launch plans ------------------------------------------------------------------------------------
+// Every measured default (tile counts, split targets, rows per thread ...) is a `static int g_x = tuning_knob("x", &g_x, d)`
+// in the file that uses it.  They are NOT environment switches: tuning scripts set them by name through the C-ABI
+// (mnk_set_tuning; tools/plan_tune.py), and A/B visits pass ONE environment variable, MNK_TUNING="name=value,name=value",
+// that is read here when a knob registers itself.
+struct Knob {
+    const char* name;
+    int* slot;
+};
+static std::vector<Knob>& knob_registry() {
+    static std::vector<Knob> v;
+    return v;
+}
+int tuning_knob(const char* name, int* slot, int dflt) {
+    knob_registry().push_back({name, slot});
+    const char* env = getenv("MNK_TUNING");
+    const size_t len = strlen(name);
+    for (const char* p = env; p && *p;) {
+        if (strncmp(p, name, len) == 0 && p[len] == '=') return atoi(p + len + 1);
+        p = strchr(p, ',');
+        if (p) ++p;
+    }
+    return dflt;
 }
 
 static const char* kNames[K_NUM] = {"conv3x3_igemm", "conv3x3_wgrad", "conv3x3_reduce_pack", "bn_stats",
@@ -109,6 +135,17 @@ int mnk_table_upload(const void* host, void* device, size_t bytes, void* stream)
     }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_set_tuning(const char* name, int value) {
+    MNK_REQUIRE(name);
+    for (const mnk::Knob& k : mnk::knob_registry())
+        if (strcmp(k.name, name) == 0) {
+            *k.slot = value;
+            return MNK_OK;
+        }
+    mnk::set_error("mnk_set_tuning: unknown tuning value %s", name);
+    return MNK_EINVAL;
 }
 
 int mnk_version(void) { return 100; }

@@ -217,7 +217,12 @@ class TrainStep:
                 if self.mnk_adam:
                     o.flat_m.copy_(saved[0])
                     o.flat_v.copy_(saved[1])
-                    o.hyper.copy_(saved[2])
+                    # only what the warm-up's steps advanced: bias corrections [4:6] and the step counter [7].  The learning
+                    # rate [0] and the gradient scale [6] = 1 / world size were put there by sync_scalars() during the
+                    # warm-up and their host mirrors say so: a captured step never re-syncs them, so restoring the
+                    # snapshot's 1.0 would make every replay SUM the ranks' gradients (exp_avg ws x, exp_avg_sq ws^2 x)
+                    o.hyper[4:6].copy_(saved[2][4:6])
+                    o.hyper[7:8].copy_(saved[2][7:8])
                     continue
                 for p, st in o.state.items():           # state created by the warm-up: back to its initial zeros
                     for k, v in st.items():

@@ -2,16 +2,15 @@
 setting exists so that an A/B can be repeated (tools/gpu_knob_ab.sh) or the reference's own structure restored.
 Values are read from the environment at call time (tests flip them with monkeypatch.setenv).
 
-The kernel launch plans have their own tuning switches, read once when the library is loaded
-(monkey-net_amd/csrc/conv3x3.hip: MNK_SPLIT_*, MNK_WSPLIT_*, MNK_WTAP_*, MNK_WN16_*, MNK_WHALO_*, MNK_BM64_TILES,
-MNK_MFMA16, MNK_XCD_REMAP, MNK_FAST_LOADER, MNK_KXK_FAST, MNK_WGRAD_ATOMIC) -- defaults from sweeps on the MI355X,
-profiles/README.md."""
+The measured defaults of the kernel launch plans are NOT environment switches: they are named tuning values inside the
+library (`tuning_knob` in monkey-net_amd/csrc/*.hip), set by tuning scripts through the C-ABI (mnk_set_tuning) or, for an
+A/B visit, all at once through the single variable MNK_TUNING="name=value,...".  This file is the complete list of the
+package's environment switches (+ MNK_TUNING, and MNK_BUILD_TAG / MNK_EXTRA_FLAGS of csrc/build.sh)."""
 import os
 
 KNOBS = {
     # name: (default, meaning)
     "MNK_LIBRARY": ("", "path of libmonkeynet_hip.so to load instead of the in-tree build (variant builds, A/B)"),
-    "MNK_NATIVE_DISC": ("1", "modules.discriminator.Discriminator = gfx950-kernel network (0: stock PyTorch-ROCm ops)"),
     "MNK_DISC_BATCHED": ("1", "D(generated) and D(real) of a pass as one call on the batch [generated; real]"),
     "MNK_DISC_SHARED": ("1", "one discriminator forward per training iteration (0: the reference's two passes)"),
     "MNK_FUSED_FM_LOSS": ("1", "feature-matching L1 terms reduced on the device from the NHWC activations (14.59 -> 14.26 ms/step)"),
@@ -30,8 +29,10 @@ KNOBS = {
     "MNK_DIST_FORCE": ("", "1: run the collective code paths even with a single rank (tests, single-GPU RCCL exercise)"),
     "MNK_RCCL_DIRECT": ("1", "nccl backend: SyncBN sums and flat gradient buffers are all-reduced by the library's own RCCL "
                              "communicator on the kernels' stream (0: through torch.distributed)"),
-    "MNK_TWO_STREAMS": ("0", "generator forward: the appearance encoder on a second stream next to the dense-motion network "
-                             "(its backward follows on that stream); experiment, measured no gain -> off"),
+    "MNK_DP_SCATTER": ("broadcast", "DataParallelWithCallback under a process group: rank 0's batch is broadcast and every rank "
+                                     "takes its slice (DataParallel's scatter); slice: trust identical batches; off: no scatter"),
+    "MNK_GRAPH_DEADLINE_S": ("", "bench.py under a process group: seconds the hipGraph capture may take before the eager time stands"),
+    "MNK_TUNING": ("", "name=value,... for the library's tuning values (read by the library itself; A/B visits)"),
     "MNK_GRAD_OVERLAP": ("1", "launch a gradient bucket's all-reduce as soon as its last gradient is written"),
     "MNK_SKIP_GRAD_FUSED": ("1", "hourglass levels: the next down block's data-gradient GEMM adds the gradient of the level's other "
                                  "consumer (decoder skip / warp) in its epilogue (0: autograd accumulates the two gradients)"),

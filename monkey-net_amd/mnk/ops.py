@@ -226,10 +226,18 @@ def pack_entry_of(p):
     return None
 
 
+_SUBPIXEL_TOLD = [None, None]       # (library object, value) the library's own "up_subpixel" tuning value was last set to
+
+
 def subpixel(ups):
     """UpBlock3D convolutions run in their sub-pixel forms (mnk_conv3x3_up_*): MNK_UP_SUBPIXEL=0 restores the 3x3
-    convolution over the up-sampled view."""
-    return bool(ups) and knobs.on("MNK_UP_SUBPIXEL")
+    convolution over the up-sampled view (the library's weight-gradient plans follow: its "up_subpixel" tuning value)."""
+    on = knobs.on("MNK_UP_SUBPIXEL")
+    lib = _lib.lib()
+    if _SUBPIXEL_TOLD[0] is not lib or _SUBPIXEL_TOLD[1] != on:
+        lib.call("mnk_set_tuning", b"up_subpixel", int(on))
+        _SUBPIXEL_TOLD[0], _SUBPIXEL_TOLD[1] = lib, on
+    return bool(ups) and on
 
 
 def _packed_fwd_weight(weight, cout, c0, c1, up=False):
@@ -1061,6 +1069,26 @@ class SoftmaxKPFn(torch.autograd.Function):
         _call("mnk_softmax_kp_bwd", heat, _p(heat), ld, n, h, w, k, temperature, _p(mean), _p(stat), _p(dmean), _p(dvar),
               _p(dheat), ld)
         return dheat, None, None
+
+
+def heatmap_argmax(heat, k):
+    """(frames, K) int32: linear pixel index h * W + w of the largest heat-map logit per key point, first occurrence -- the
+    integer form of the soft-argmax (keypoint_detector.py:103-104); `heat` is the key-point detector's logit act."""
+    _check_device(heat)
+    n, h, w, ld = heat.shape
+    idx = torch.empty(n, k, dtype=torch.int32, device=heat.device)
+    _call("mnk_heatmap_argmax", heat, _p(heat), ld, n, h, w, k, _p(idx))
+    return idx
+
+
+def kp_pixel_index(mean, size):
+    """floor(size * (mean + 1) / 2) per axis, size = (W, H): the pixel the reference's Visualizer draws a key point at
+    (logger.py:99-100).  mean (..., 2) fp32 -> (..., 2) int32."""
+    _check_device(mean)
+    m = mean.detach().contiguous().float()
+    out = torch.empty(m.shape, dtype=torch.int32, device=m.device)
+    _call("mnk_kp_pixel_index", m, _p(m), m.numel() // 2, int(size[0]), int(size[1]), _p(out))
+    return out
 
 
 class ClipVarianceFn(torch.autograd.Function):

@@ -299,7 +299,7 @@ class MnkAdam(torch.optim.Optimizer):
         if not active:
             return None
         ws = mdist.world_size() if mdist.grads_active() else 1
-        if ws > 1 or mdist._FORCE:
+        if mdist.grads_active():
             mdist.all_reduce_flat_(self.flat_grad)          # sum over ranks; the mean is folded into the update
         if not _capturing(self.device):
             self.sync_scalars(1.0 / ws)
@@ -337,9 +337,11 @@ class MnkAdam(torch.optim.Optimizer):
         step = 0.0
         for p in self._params:
             st = self.state.get(p)
-            if not st:
-                continue
             m, v = self._views(p)
+            if not st:          # no entry in the checkpoint (a parameter that never received a gradient): fresh state
+                m.zero_()
+                v.zero_()
+                continue
             m.copy_(st["exp_avg"])
             v.copy_(st["exp_avg_sq"])
             step = max(step, float(st["step"]))

@@ -67,10 +67,22 @@ class KPDetector(nn.Module):
         self.clip_variance = clip_variance
         self.num_kp = num_kp
         self.num_channels = num_channels
+        self._last_heat = None
 
     def forward(self, x):
         b, _, d = x.shape[:3]
         act = ops.to_act(x, ops.step_from_scale(self.scale_factor))
         heat, k = self.predictor.forward_act(act, self.num_channels)
         mean, var = ops.SoftmaxKPFn.apply(heat, k, self.temperature)
+        self._last_heat = (heat.detach(), k, b, d)          # for keypoint_indices(): no copy, no extra launch
         return _finish_kp(mean.view(b, d, k, 2), var.view(b, d, k, 2, 2), self.kp_variance, self.clip_variance)
+
+    def keypoint_indices(self, kp, frame_size=None):
+        """The integer key-point positions of the LAST forward call (not part of the reference's API; the north star's
+        "bit-exact keypoint indices"): {'pixel': (B,D,K,2) int32 = floor(size * (mean + 1) / 2), the pixel the reference's
+        Visualizer draws the key point at (logger.py:99-100), for frames of `frame_size` = (W, H) (default: the heat-map's
+        own size); 'argmax': (B,D,K) int32, h * W + w of the largest heat-map value (keypoint_detector.py:103-104)}."""
+        heat, k, b, d = self._last_heat
+        n, h, w, _ = heat.shape
+        size = (w, h) if frame_size is None else frame_size
+        return {'pixel': ops.kp_pixel_index(kp['mean'], size), 'argmax': ops.heatmap_argmax(heat, k).view(b, d, k)}

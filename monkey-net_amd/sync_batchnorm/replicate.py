@@ -1,12 +1,19 @@
 """`DataParallelWithCallback` / `patch_replication_callback` (sync_batchnorm/replicate.py:50-94) for the
 one-process-per-GPU design.
 
-The reference wraps its full models in a single-process `DataParallel` that scatters the batch, re-broadcasts all
-parameters on every forward and runs one thread per GPU (train.py:104-105).  Here every rank already owns a resident
-replica and its shard of the batch, so the wrapper only (a) moves the inputs to this rank's device and (b) calls the
-wrapped module; statistics and gradients are exchanged by `mnk.dist` (RCCL).  The class keeps the reference's name,
-constructor and call signature so train.py / reconstruction.py / transfer.py / demo.py run unchanged."""
+The reference wraps its full models in a single-process `DataParallel` that scatters ONE DataLoader batch over the GPUs,
+re-broadcasts all parameters on every forward and runs one thread per GPU (train.py:99,104-105, replicate.py:64-67).
+Here every rank owns a resident replica, so the wrapper (a) reproduces the scatter -- under a process group rank 0's batch
+is the batch (broadcast) and every rank takes its equal slice of it, so the reference's unmodified train.py needs no
+DistributedSampler: N ranks x B/N samples of the same DataLoader batch, exactly what DataParallel computes --, (b) moves
+the inputs to this rank's device and (c) calls the wrapped module; statistics and gradients are exchanged by `mnk.dist`
+(RCCL).  The class keeps the reference's name, constructor and call signature so train.py / reconstruction.py /
+transfer.py / demo.py run unchanged.
+
+Outputs stay this rank's shard (DataParallel gathers them on device 0): the loop's `loss.mean()` is the shard mean, whose
+gradient averaged over the ranks is the gradient of the global mean (equal shards)."""
 import warnings
+import weakref
 
 import torch
 from torch import nn
@@ -22,6 +29,17 @@ def _to_device(obj, device):
     return obj
 
 
+def _walk(obj, fn):
+    """apply fn to every tensor of a nested dict / list / tuple structure (DataParallel's scatter walks the same containers)"""
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, dict):
+        return {k: _walk(v, fn) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_walk(v, fn) for v in obj)
+    return obj
+
+
 class DataParallelWithCallback(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, dim=0):
         super(DataParallelWithCallback, self).__init__()
@@ -29,6 +47,7 @@ class DataParallelWithCallback(nn.Module):
         self.dim = dim
         self.device_ids = list(device_ids) if device_ids is not None else None
         self.output_device = output_device
+        self._scattered = {}          # id(full tensor) -> (weakref, version, this rank's slice): one exchange per batch tensor
         from mnk import dist as mdist
         if mdist.initialized() and mdist.world_size() > 1:
             # one process per GPU under torch.distributed.run: SyncBN statistics are exchanged inside the BN wrappers
@@ -45,8 +64,56 @@ class DataParallelWithCallback(nn.Module):
             return p.device
         return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
+    # ---- DataParallel's scatter, one process per GPU ------------------------------------------------------------------
+    def _scatter_mode(self):
+        """MNK_DP_SCATTER: "broadcast" (default) -- rank 0's batch is THE batch, every rank takes its slice (correct whatever
+        the ranks' DataLoader seeds are); "slice" -- every rank is trusted to hold the same batch (same seeds): slice
+        without communication; "off" -- every rank's batch already is its own shard (a DistributedSampler loop)."""
+        from mnk import knobs
+        return knobs.get("MNK_DP_SCATTER")
+
+    def _scatter(self, inputs, kwargs, dev):
+        from mnk import dist as mdist
+        ws = mdist.world_size()
+        mode = self._scatter_mode()
+        if ws == 1 or mode == "off" or not self.module.training:
+            return inputs, kwargs          # evaluation wrappers (reconstruction.py:45-49) see batch 1: replicas only
+        sizes = []
+        _walk((inputs, kwargs), lambda t: sizes.append(t.shape[self.dim]) if t.dim() > self.dim else None)
+        if not sizes:
+            return inputs, kwargs
+        n = max(sizes)                     # the DataLoader batch; tensors that an earlier wrapped call returned are n / ws long
+        if n % ws != 0:
+            raise ValueError("DataParallelWithCallback: the batch (%d) is not divisible by the %d ranks it is scattered over"
+                             % (n, ws))
+        import torch.distributed as tdist
+
+        def one(t):
+            if t.dim() <= self.dim or t.shape[self.dim] != n:
+                return t                   # already this rank's shard (outputs of an earlier call in this iteration)
+            hit = self._scattered.get(id(t))
+            if hit is not None and hit[0]() is t and hit[1] == t._version:
+                return hit[2]
+            full = t.to(dev, non_blocking=True)
+            if mode == "broadcast":
+                full = full.contiguous() if full is not t else full.contiguous().clone()
+                if tdist.get_backend() == "gloo" and full.is_cuda:
+                    host = full.cpu()
+                    tdist.broadcast(host, 0)
+                    full = host.to(dev)
+                else:
+                    tdist.broadcast(full, 0)
+            local = mdist.shard_batch(full, self.dim).contiguous()
+            if len(self._scattered) > 16:
+                self._scattered = {k: v for k, v in self._scattered.items() if v[0]() is not None}
+            self._scattered[id(t)] = (weakref.ref(t), t._version, local)
+            return local
+
+        return _walk(inputs, one), _walk(kwargs, one)
+
     def forward(self, *inputs, **kwargs):
         dev = self._device()
+        inputs, kwargs = self._scatter(inputs, kwargs, dev)
         return self.module(*_to_device(inputs, dev), **_to_device(kwargs, dev))
 
     def replicate(self, module, device_ids):  # kept for API compatibility; replicas are separate processes here

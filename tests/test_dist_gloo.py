@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: world_size 2 over gloo (127.0.0.1).  The *host* code under test is the product's
+"""Multi-rank path on CPU: world_size 2 (and 4) over gloo (127.0.0.1).  The *host* code under test is the product's
 (mnk.dist all-reduces inside BNActFn, GradAverager, shard_batch, TrainStep); the kernels run on the CPU emulator
 build so no GPU is needed.  Property: 2 ranks x B/2 samples (SyncBN + gradient averaging) == 1 rank x B samples."""
 import os
@@ -50,9 +50,10 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
     # plain collectives of mnk.dist
     t = torch.full((3,), float(rank + 1))
     mdist.all_reduce_sum_(t)
-    assert torch.equal(t, torch.full((3,), 3.0))
+    tri = world * (world + 1) / 2.0
+    assert torch.equal(t, torch.full((3,), tri))
     sums, count = mdist.combine_bn_stats(torch.tensor([1.0 * (rank + 1), 2.0]), 10)
-    assert count == 20 and torch.equal(sums, torch.tensor([3.0, 4.0]))
+    assert count == 10 * world and torch.equal(sums, torch.tensor([tri, 2.0 * world]))
     dist.destroy_process_group()
 
 
@@ -77,15 +78,16 @@ def _single(emu_path, mnk_adam=False):
     return out
 
 
-@pytest.mark.parametrize("mnk_adam", [False, True], ids=["torch-adam+GradAverager", "mnk-adam-flat-buffer"])
-def test_two_ranks_equal_one_rank_big_batch(mnk_adam):
+@pytest.mark.parametrize("mnk_adam,world", [(False, 2), (True, 2), (True, 4)],
+                         ids=["torch-adam+GradAverager", "mnk-adam-flat-buffer", "mnk-adam-flat-buffer-4-ranks"])
+def test_ranks_equal_one_rank_big_batch(mnk_adam, world):
     from conftest import emu_library_path
     from oracle import cases
     emu = emu_library_path()
     ref = _single(emu, mnk_adam)
     with tempfile.TemporaryDirectory() as tmp:
-        port = 29500 + (os.getpid() % 2000) + (1 if mnk_adam else 0)
-        mp.spawn(_worker, args=(2, port, emu, tmp, mnk_adam), nprocs=2, join=True)
+        port = 29500 + (os.getpid() % 2000) + (1 if mnk_adam else 0) + world
+        mp.spawn(_worker, args=(world, port, emu, tmp, mnk_adam), nprocs=world, join=True)
         r0 = torch.load(os.path.join(tmp, "rank0.pt"), weights_only=False)
         r1 = torch.load(os.path.join(tmp, "rank1.pt"), weights_only=False)
     # ranks stay bit-identical replicas after the step (same averaged gradients, same all-reduced BN statistics)
@@ -154,36 +156,60 @@ def test_bucketed_overlapped_gradient_averaging():
 
 
 def _auto_worker(rank, world, port, out_dir):
-    """the reference's unmodified loop shape: loss.backward(); optimizer.step() -- averaging installed by the wrapper"""
+    """the reference's unmodified loop shape: loss.backward(); optimizer.step() on ONE DataLoader batch that the wrapper
+    scatters (replicate.py:64-67) -- averaging installed by the wrapper, the batch is rank 0's (broadcast), every rank
+    computes its slice: `world` ranks == one rank on the same batch"""
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sync_batchnorm import DataParallelWithCallback
+
+    class Full(torch.nn.Module):          # a "full model" in train.py's sense: dict batch in, per-sample losses out
+        def __init__(self):
+            super().__init__()
+            self.net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
+
+        def forward(self, x, extra=None):
+            out = self.net(x["source"]) + self.net(x["video"])
+            return out if extra is None else out + extra
+
     torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
-    ref = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
-    ref.load_state_dict(net.state_dict())
-    par = DataParallelWithCallback(net, device_ids=[0, 1])        # a process group exists: installs the pre-step averaging
-    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    full_model, ref = Full(), Full()
+    ref.load_state_dict(full_model.state_dict())
+    par = DataParallelWithCallback(full_model, device_ids=list(range(world)))   # a process group exists: installs the averaging
+    opt = torch.optim.SGD(full_model.parameters(), lr=0.1)
     g = torch.Generator().manual_seed(3)
-    full = torch.randn(8, 6, generator=g)
+    batch = {"source": torch.randn(8, 6, generator=g), "video": torch.randn(8, 6, generator=g), "name": ["v%d" % i for i in range(8)]}
+    # ranks > 0 hold a DIFFERENT batch (an unseeded DataLoader per process): rank 0's batch is the batch, as under DataParallel
+    mine = batch if rank == 0 else {"source": torch.full((8, 6), 7.0), "video": torch.zeros(8, 6), "name": batch["name"]}
+    before = {k: v.clone() for k, v in mine.items() if torch.is_tensor(v)}
     for _ in range(2):
         opt.zero_grad()
-        par(full[rank * 4:(rank + 1) * 4]).mean().backward()
+        out = par(mine)
+        assert out.shape[0] == 8 // world                      # outputs stay this rank's shard
+        out2 = par(mine, extra=out.detach())                   # a second wrapped call with a tensor that already is a shard
+        assert out2.shape[0] == 8 // world
+        (out.mean() + 0.0 * out2.mean()).backward()
         opt.step()
+    for k, v in before.items():
+        assert torch.equal(mine[k], v), "the wrapper must not write into its inputs"
     ropt = torch.optim.SGD(ref.parameters(), lr=0.1)
-    for _ in range(2):      # the whole batch on one rank (its gradients are the same on both ranks: averaging is a no-op)
+    for _ in range(2):      # the whole batch on one rank
         ropt.zero_grad()
-        ref(full).mean().backward()
+        ref(batch).mean().backward()
         ropt.step()
-    for a, b in zip(net.parameters(), ref.parameters()):
+    for a, b in zip(full_model.parameters(), ref.parameters()):
         assert torch.allclose(a, b, atol=1e-6), (a, b)
+    # evaluation wrappers (reconstruction.py:45-49) are replicas only: batch 1 is not scattered
+    par.eval()
+    assert par({"source": batch["source"][:1], "video": batch["video"][:1]}).shape[0] == 1
     dist.destroy_process_group()
 
 
-def test_unmodified_loop_gets_gradient_averaging_from_the_wrapper():
-    port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_auto_worker, args=(2, port, None), nprocs=2, join=True)
+@pytest.mark.parametrize("world", [2, 4])
+def test_unmodified_loop_gets_scatter_and_gradient_averaging_from_the_wrapper(world):
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_auto_worker, args=(world, port, None), nprocs=world, join=True)
 
 
 def test_wrapper_warns_about_device_ids_without_a_process_group():

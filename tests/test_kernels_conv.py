@@ -325,12 +325,12 @@ def test_conv3x3_fused_bn_statistics(be, case):
     assert torch.equal(Y.cpu(), Y2.cpu())
     if split:           # the 64-outputs x 4-split-groups reduction (MNK_REDUCE_V4=0) adds the splits in the same order
         Y3 = be.empty(n, h, w, ldy)
-        be.lib.call("mnk_set_tuning", b"MNK_REDUCE_V4", 0)
+        be.lib.call("mnk_set_tuning", b"reduce_v4", 0)
         try:
             be.call("mnk_conv3x3_fwd", *args, Y3, ldy, n, h, w, cout, ws, nws, None)
             be.sync()
         finally:
-            be.lib.call("mnk_set_tuning", b"MNK_REDUCE_V4", 1)
+            be.lib.call("mnk_set_tuning", b"reduce_v4", 1)
         assert torch.equal(Y.cpu(), Y3.cpu())
     assert relerr(from_nhwc(Y.cpu(), cout), _ref_fwd(case, x0, x1, wt, b, r)) < 2e-6
     assert torch.all(Y.cpu()[..., cout:] == 0)
@@ -465,7 +465,7 @@ def test_forced_launch_plans_compute_the_same_convolution(be, case):
     try:
         for bm, bn, splits in [(0, 0, 0), (64, 128, 1), (128, 128, 2), (64, 64, 3), (128, 64, 1), (128, 32, 4), (128, 48, 1),
                                (128, 16, 2), (64, 32, 1), (64, 16, 1), (0, 0, 7)]:
-            for name, v in (("MNK_FORCE_BM", bm), ("MNK_FORCE_BN", bn), ("MNK_FORCE_SPLITS", splits)):
+            for name, v in (("force_bm", bm), ("force_bn", bn), ("force_splits", splits)):
                 be.lib.call("mnk_set_tuning", name.encode(), v)
             Y = _run_fwd(be, case, x0, x1, wt, b, r, clean=True)
             plan = _last_plan(be)
@@ -477,6 +477,6 @@ def test_forced_launch_plans_compute_the_same_convolution(be, case):
             seen.add(plan[5:])
             assert relerr(from_nhwc(Y, cout), ref) < 2e-6, plan
     finally:
-        for name in ("MNK_FORCE_BM", "MNK_FORCE_BN", "MNK_FORCE_SPLITS"):
+        for name in ("force_bm", "force_bn", "force_splits"):
             be.lib.call("mnk_set_tuning", name.encode(), 0)
     assert len(seen) >= 6

@@ -206,10 +206,10 @@ JOB = np.dtype([("x", "<u8"), ("dy", "<u8"), ("part", "<u8"), ("part_floats", "<
 @pytest.mark.parametrize("subpixel", [1, 0], ids=["up-layers-subpixel", "up-layers-upsampled-view"])
 def test_grouped_weight_gradients_of_many_layers(be, subpixel):
     try:
-        be.lib.call("mnk_set_tuning", b"MNK_UP_SUBPIXEL", subpixel)
+        be.lib.call("mnk_set_tuning", b"up_subpixel", subpixel)
         _grouped_weight_gradients(be, subpixel)
     finally:
-        be.lib.call("mnk_set_tuning", b"MNK_UP_SUBPIXEL", 1)
+        be.lib.call("mnk_set_tuning", b"up_subpixel", 1)
 
 
 def _grouped_weight_gradients(be, subpixel):

@@ -323,16 +323,15 @@ def test_down_block_with_fused_statistics(be):
     assert float((blk.norm.running_var.cpu().double() - ctx.new_stats["blk.norm.running_var"]).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("impl", ["hip", "stock"])
 @pytest.mark.parametrize("cfg_name,size", [("tiny", 32), pytest.param("taichi", 64, marks=pytest.mark.gpu)])
-def test_discriminator_matches_oracle(be, cfg_name, size, impl):
+def test_discriminator_matches_oracle(be, cfg_name, size):
     """modules.discriminator: the gfx950-kernel Discriminator (4x4 no-pad convs, InstanceNorm, LeakyReLU, avg-pool, 1x1
-    head; the default) and its stock-op twin (MNK_NATIVE_DISC=0) against oracle/restate.py::discriminator_forward in
-    fp64: every returned feature map and all gradients (parameters, input frame, key-points)."""
+    head) against oracle/restate.py::discriminator_forward in fp64: every returned feature map and all gradients
+    (parameters, input frame, key-points)."""
     import modules.discriminator as md
-    Discriminator = md.HipDiscriminator if impl == "hip" else md.StockDiscriminator
-    if impl == "hip":
-        assert md.Discriminator is md.HipDiscriminator, "the drop-in name must resolve to the gfx950-kernel class"
+    from mnk import discriminator_hip
+    Discriminator = md.Discriminator
+    assert md.Discriminator is discriminator_hip.Discriminator, "the drop-in name must resolve to the gfx950-kernel class"
     from oracle import restate
     if be.kind == "emu" and cfg_name != "tiny":
         pytest.skip("too slow on the emulator")
@@ -378,8 +377,7 @@ def test_discriminator_matches_oracle(be, cfg_name, size, impl):
     assert float((kdh["mean"].grad.cpu().double() - kd64["mean"].grad).norm() / kd64["mean"].grad.norm()) < 2e-3
 
 
-@pytest.mark.parametrize("impl", ["hip", "stock"])
-def test_discriminate_pair_batched_equals_two_calls(be, impl, monkeypatch):
+def test_discriminate_pair_batched_equals_two_calls(be, monkeypatch):
     """mnk.engine.discriminate_pair: D(fake) and D(real) as one pass over [fake; real] (every layer of the
     discriminator is per sample) == the reference's two calls (train.py:43-45): feature maps and every gradient."""
     import modules.discriminator as md
@@ -388,7 +386,7 @@ def test_discriminate_pair_batched_equals_two_calls(be, impl, monkeypatch):
     mp = cfg["model_params"]
     common = mp["common_params"]
     torch.manual_seed(8)
-    disc = (md.HipDiscriminator if impl == "hip" else md.StockDiscriminator)(**mp["discriminator_params"], **common)
+    disc = md.Discriminator(**mp["discriminator_params"], **common)
     sd = {k: v.detach().clone() for k, v in disc.state_dict().items()}
     cases.perturb_state_dict(sd, 13)
     disc.load_state_dict(sd)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Sweep of the forward / data-gradient GEMM launch plans (block tile x split-K) over the 3x3 layer shapes of a config, on the
-GPU box.  For every distinct layer shape and direction each candidate plan is forced (mnk_set_tuning MNK_FORCE_*), the launch is
+GPU box.  For every distinct layer shape and direction each candidate plan is forced (mnk_set_tuning force_*), the launch is
 timed cold (a cache-sized buffer is rewritten before every timed launch) together with what the plan costs downstream -- the
 split-K reduction, and for a layer in front of a BatchNorm the statistics pass a split plan needs because its epilogue cannot
 produce the sums -- and the best plan is compared with make_plan's rule.  Rows that beat the rule by more than --gain go to
@@ -24,9 +24,9 @@ FLUSH = None
 
 def force(bm, bn, splits):
     lib = _lib.lib()
-    lib.call("mnk_set_tuning", b"MNK_FORCE_BM", bm)
-    lib.call("mnk_set_tuning", b"MNK_FORCE_BN", bn)
-    lib.call("mnk_set_tuning", b"MNK_FORCE_SPLITS", splits)
+    lib.call("mnk_set_tuning", b"force_bm", bm)
+    lib.call("mnk_set_tuning", b"force_bn", bn)
+    lib.call("mnk_set_tuning", b"force_splits", splits)
 
 
 def last_plan():
@@ -130,7 +130,7 @@ def main():
             if direction == "fwd" and small:
                 continue                      # the one-launch BatchNorm sums these layers' split partials itself
             force(0, 0, 0)
-            _lib.lib().call("mnk_set_tuning", b"MNK_PLAN_TABLE", 0)
+            _lib.lib().call("mnk_set_tuning", b"plan_table", 0)
             t_rule = time_cold(fn, args.iters)
             rule = last_plan()
             m, co, chunks, taps, phases = rule[:5]
