@@ -503,6 +503,27 @@ int mnk_gan_terms_fwd(const float* score, int n, int B, float w_gen, float w_dis
 int mnk_gan_terms_bwd(const float* score, int n, int B, float w_gen, float w_disc, const float* ggen, const float* gdisc,
                       float* dscore, void* stream);
 
+/* ---- device-side input path ------------------------------------------------------------------
+ * Replaces, for the integer-exact transforms, what the reference does on the host per sample inside 4 DataLoader workers
+ * (train.py:99): read_video's strip -> frames split, gray -> RGB, RGBA -> RGB and img_as_float32 (frames_dataset.py:14-29),
+ * RandomFlip (augmentation.py:91-104), RandomCrop = pad_clip(mode='edge') + crop (:135-171), SelectRandomFrames and
+ * SplitSourceDriving / VideoToTensor (:324-366).  The decoded uint8 strips of the whole dataset stay resident in `pool`
+ * (HBM); one job = one output frame:
+ *   out[out_offset + ch * chan_stride + h * W + w] = float32(strip[r][frame * in_w + c][ch]) * float32(1 / 255)
+ *   with (r, c) = clamp((h + y1 - pad_top, w + x1 - pad_left)) into the in_h x in_w frame, c mirrored when hflip.
+ * `channels` of the strip: 1 / 2 (gray [+ alpha]: replicated), 3 / 4 (RGB [+ alpha: dropped]).  Cout <= 3 planes are written.
+ * For a (B, C, D, H, W) batch tensor: out_offset = (b * C * D + d) * H * W, chan_stride = D * H * W. */
+typedef struct MnkFrameJob {
+    unsigned long long strip_offset;     /* byte offset of the strip (in_h rows of strip_w pixels of `channels` bytes) in pool */
+    unsigned long long out_offset;       /* float offset of this frame's channel-0 plane in `out` */
+    unsigned long long chan_stride;      /* floats between channel planes */
+    int strip_w, in_h, in_w, channels;
+    int frame, hflip, x1, y1;
+    int pad_top, pad_left, reserved0, reserved1;
+} MnkFrameJob;
+int mnk_frames_gather(const unsigned char* pool, const MnkFrameJob* jobs_device, int njobs, int H, int W, int Cout, float* out,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

