@@ -44,6 +44,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PMC_ROUND = "r03"               # profiles/<round>_pmc_traffic_<config>_b<batch>.json: the PMC passes `roofline.traffic` is read from
+
+
+def kernel_source_stamp():
+    """what a PMC traffic file must have been measured on to be quoted next to this run: the sources of the GEMM kernels"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("conv3x3.hip", "mnk_common.h", "pack_tile.h", "plan_table.h"):
+        with open(os.path.join(ROOT, "monkey-net_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -212,7 +223,9 @@ def cpu_baseline(cfg, batch, size, steps):
     steps = max(done, 1)
     return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d training iterations of the same config at batch %d (oracle/restate.py, torch CPU fp32, "
-                      "%d threads), %.2f s/iteration" % (steps, batch, cores, dt)}
+                      "%d threads), %.2f s/iteration.  A PORT: Conv2d on frames folded into the batch, not the reference's "
+                      "own Conv3d((1,3,3)) modules (the reference tree cannot travel to the GPU box; BASELINE.md's number "
+                      "for the reference itself is taichi batch 32 = 12.8 pairs/s on 8 cores)" % (steps, batch, cores, dt)}
 
 
 def hot_path_only(step, x, iters, device):
@@ -292,6 +305,9 @@ def graph_phase(args, rank, fallback, run, device):
     def expire():
         sys.stderr.write("rank %d: hipGraph phase exceeded its deadline; reporting the eager measurement\n" % rank)
         if rank == 0:
+            if fallback is not None:
+                fallback["capture_failed"] = True
+                fallback["config"]["launch"] = "eager (the hipGraph phase exceeded MNK_GRAPH_DEADLINE_S)"
             emit(fallback)
         os._exit(0)
 
@@ -365,6 +381,7 @@ def main():
             dt = float(t.item())
         return dt
 
+    capture_failed = False       # a requested hipGraph capture that did not happen: loud in the JSON line, not only on stderr
     if not dist_mode:
         step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=use_graph)
         if use_graph:
@@ -374,6 +391,7 @@ def main():
             except Exception as e:   # capture is an optimisation, never a requirement
                 sys.stderr.write("hipGraph capture failed (%s: %s); running eager launches\n" % (type(e).__name__, e))
                 use_graph = False
+                capture_failed = True
                 torch.cuda.synchronize(device)
                 gen, disc, kpd = build_models(cfg, device)
                 step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
@@ -430,12 +448,18 @@ def main():
         lib.cdll.mnk_prof_reset()
         conv = kernels.get("conv3x3_igemm")
         traffic, traffic_src = None, None
-        pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_traffic_%s_b%d.json" % (args.config, args.batch))
+        pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s_b%d.json" % (PMC_ROUND, args.config, args.batch))
         if os.path.exists(pmc_file) and args.size == 64:
             # HBM-side bytes per launch of the same kernel on the same workload, from separate rocprofv3 --pmc passes
             # (FETCH_SIZE, WRITE_SIZE; tools/gpu_evidence.sh + tools/pmc_summarize.py), gfx950 correction: 2 x FETCH_SIZE.
-            # A number from a profile run, not from this run: `traffic_source` says which commit it was taken on.
+            # A number from a profile run, not from this run: it is quoted ONLY when that run was made on the GEMM kernel
+            # sources of this run (`_kernel_source_stamp`); otherwise traffic stays null and `traffic_source` says why.
             pm = json.load(open(pmc_file))
+            if pm.get("_kernel_source_stamp") != kernel_source_stamp():
+                traffic_src = "%s was measured on other kernel sources (%s, stamp %s; this run: %s): not quoted" % (
+                    os.path.basename(pmc_file), pm.get("_measured_on", "commit not recorded"),
+                    pm.get("_kernel_source_stamp"), kernel_source_stamp())
+                pm = {}
             n = f = w = 0.0
             for k, v in pm.items():
                 if isinstance(v, dict) and "conv3x3_igemm" in k:
@@ -444,8 +468,8 @@ def main():
                     w += v["write_bytes_per_launch"] * v["launches"]
             if n:
                 traffic = round((2 * f + w) / n)
-                traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (%s)" % (
-                    os.path.basename(pmc_file), pm.get("_measured_on", "commit not recorded"))
+                traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %s (%s, kernel sources %s = this run's)" % (
+                    os.path.basename(pmc_file), pm.get("_measured_on", "commit not recorded"), pm["_kernel_source_stamp"])
         if conv:
             achieved = conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12
             roofline = {"kernel": "conv3x3_igemm_kernel / conv3x3_igemm16_kernel: every forward + data-gradient launch "
@@ -456,6 +480,19 @@ def main():
                         "traffic_source": traffic_src,
                         "launches_per_step": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2),
                         "flop_per_launch": conv["work_per_step"] / conv["launches_per_step"]}
+    # every convolution launch of the iteration, not only the best group: forward + data gradient (conv3x3_igemm), weight
+    # gradient GEMMs (conv3x3_wgrad) and EVERY split reduction / weight re-layout launch that exists because of how those
+    # GEMMs are tiled (conv3x3_reduce_pack: split-K reductions, the weight-gradient partial reduction, packs)
+    roofline_all = None
+    if kernels.get("conv3x3_igemm") and kernels.get("conv3x3_wgrad"):
+        groups = [kernels[k] for k in ("conv3x3_igemm", "conv3x3_wgrad", "conv3x3_reduce_pack") if k in kernels]
+        work = kernels["conv3x3_igemm"]["work_per_step"] + kernels["conv3x3_wgrad"]["work_per_step"]
+        ms = sum(g["ms_per_step"] for g in groups)
+        roofline_all = {"what": "forward + data-gradient + weight-gradient GEMMs and every split reduction / pack launch",
+                        "bound": "mfma", "achieved": round(work / (ms * 1e-3) / 1e12, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(work / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "gflop_per_step": round(work / 1e9, 1), "ms_per_step": round(ms, 3),
+                        "launches_per_step": sum(g["launches_per_step"] for g in groups)}
     hot_ms, hot_launch = None, None
     if not args.no_profile and not dist_mode:
         try:
@@ -493,7 +530,8 @@ def main():
                 "conv_tflops": round(3 * flops["total"] * args.batch / (hot_ms * 1e-3) / 1e12, 2),
                 "frac_of_fp32_mfma_peak": round(3 * flops["total"] * args.batch / (hot_ms * 1e-3) / 1e12
                                                 / FP32_MFMA_PEAK_TFLOPS, 4)},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "roofline_all_conv": roofline_all, "cpu_baseline": cpu, "kernels": kernels,
+            "capture_failed": bool(capture_failed),
         }
         if pcie is not None:
             out["pcie_inclusive"] = pcie
@@ -502,7 +540,10 @@ def main():
     if dist_mode and use_graph:
         g_elapsed = graph_phase(args, rank, out, lambda: timed(
             engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=True)), device)
-        if g_elapsed is not None and g_elapsed < elapsed and rank == 0:
+        if g_elapsed is None and rank == 0:
+            out["capture_failed"] = True       # the line below is the EAGER iteration (typically ~30 % slower than a replay)
+            out["config"]["launch"] = "eager (hipGraph capture with RCCL collectives FAILED on some rank)"
+        elif g_elapsed is not None and g_elapsed < elapsed and rank == 0:
             out.update(value=round(global_batch * args.steps / g_elapsed, 2),
                        ms_per_step=round(g_elapsed / args.steps * 1e3, 3))
             out["config"]["launch"] = "hipGraph replay (RCCL collectives captured); eager: %.3f ms/step" % ms_per_step

@@ -49,11 +49,15 @@ def active():
 # kernels run on: in order with producer and consumer, no event hand-over to torch.distributed's communication stream
 # (two event waits per collective, 84 small SyncBN collectives per iteration), capturable as they are.  torch.distributed
 # stays the rendezvous (it carries the 128-byte id) and the transport of everything else (gloo in the CPU tests).
-_COMM = {"tried": False, "handle": None}
+_COMMS = {}
 
 
-def direct_comm():
-    """The communicator handle (an int) or None: gloo / CPU builds / RCCL not loadable / MNK_RCCL_DIRECT=0."""
+def direct_comm(kind="main"):
+    """The communicator handle (an int) or None: gloo / CPU builds / RCCL not loadable / MNK_RCCL_DIRECT=0.
+    kind "main": the communicator of the kernels' stream (SyncBN sums, in-order gradient exchange); "grads": a second
+    communicator for the gradient exchange that runs on its own stream next to the discriminator's backward pass -- one
+    communicator must not have operations in flight on two streams."""
+    _COMM = _COMMS.setdefault(kind, {"tried": False, "handle": None})
     if _COMM["tried"]:
         return _COMM["handle"]
     _COMM["tried"] = True
@@ -116,6 +120,38 @@ def all_reduce_flat_(flat, chunk_mb=64.0):
     for w in works:
         w.wait()
     return flat
+
+
+_COMM_STREAMS = {}
+
+
+def all_reduce_flat_begin(flat, chunk_mb=64.0):
+    """Start the sum of a flat fp32 buffer over the ranks WITHOUT making the kernels' stream wait: the exchange of the
+    generator's (and key-point detector's) 265-379 MB of gradients runs next to the discriminator-loss backward pass, which
+    depends on neither (what DataParallel's backward hides inside itself, train.py:116-118).  -> handle for
+    all_reduce_flat_end.  RCCL: on a communication stream of its own, with a communicator of its own; torch.distributed
+    (gloo in the CPU tests): asynchronous works."""
+    step = max(int(chunk_mb * 1024 * 1024 / 4), 1)
+    h = direct_comm("grads") if flat.is_cuda else None
+    if h is not None and flat.dtype == torch.float32 and flat.is_contiguous():
+        from . import _lib
+        side = _COMM_STREAMS.get(flat.device)
+        if side is None:
+            side = _COMM_STREAMS[flat.device] = torch.cuda.Stream(flat.device)
+        side.wait_stream(torch.cuda.current_stream(flat.device))         # the gradients are complete
+        _lib.lib().call("mnk_allreduce_grads", h, flat.data_ptr(), flat.numel(), 0, step, side.cuda_stream)
+        return ("stream", side, flat.device)
+    return ("works", [tdist.all_reduce(flat[i:i + step], op=tdist.ReduceOp.SUM, async_op=True)
+                      for i in range(0, flat.numel(), step)])
+
+
+def all_reduce_flat_end(handle):
+    """the consumer (the optimiser step) waits for an exchange started by all_reduce_flat_begin"""
+    if handle[0] == "stream":
+        torch.cuda.current_stream(handle[2]).wait_stream(handle[1])
+    else:
+        for w in handle[1]:
+            w.wait()
 
 
 def average_grads_(params, bucket_mb=64.0):

@@ -297,12 +297,28 @@ class TrainStep:
         torch.autograd.backward(roots, root_grads, inputs=g_params + k_params,
                                 retain_graph=not tp['detach_kp_discriminator'])
         self.avg_gk.average()
-        self.opt_g.step()
-        self.opt_g.zero_grad()
+        # Several ranks, MnkAdam: the exchange of the generator's (and key-point detector's) flat gradient buffers starts here
+        # on the communication stream, and the optimiser steps that consume them move BEHIND the discriminator-loss backward
+        # (step 3 runs on the retained discriminator graph with the generated frames as leaves: it reads neither the
+        # generator's weights nor its update) -- 265-379 MB per iteration leave the critical path.  Same arithmetic, same
+        # order of the three updates' inputs; MNK_GRAD_OVERLAP=0 keeps the in-order exchange.
+        overlap = self.mnk_adam and mdist.grads_active() and knobs.on("MNK_GRAD_OVERLAP")
+        step_k_now = tp['detach_kp_discriminator']
+
+        def step_generator_side():
+            self.opt_g.step()
+            self.opt_g.zero_grad()
+            if step_k_now:
+                self.opt_k.step()
+                self.opt_k.zero_grad()
+
+        if overlap:
+            self.opt_g.begin_exchange()
+            if step_k_now:
+                self.opt_k.begin_exchange()
+        else:
+            step_generator_side()
         self.opt_d.zero_grad()
-        if tp['detach_kp_discriminator']:
-            self.opt_k.step()
-            self.opt_k.zero_grad()
         # 3. the discriminator loss through the retained discriminator graph
         self.avg_d.arm()
         d_total = d_total_fused if d_total_fused is not None else sum(d_values)
@@ -318,6 +334,8 @@ class TrainStep:
             back = [(kp_joined[k], kp_leaf[k].grad) for k in kp_names if kp_leaf[k].grad is not None]
             if back:
                 torch.autograd.backward([t for t, _ in back], [g for _, g in back], inputs=k_params)
+        if overlap:
+            step_generator_side()
         self.avg_d.average()
         self.opt_d.step()
         self.opt_d.zero_grad()

@@ -214,6 +214,7 @@ class MnkAdam(torch.optim.Optimizer):
         self._table = None               # (key, device table, n, blocks, entries)
         self._keep = []
         self._mnk_fresh_entries = ()
+        self._exchange = None            # a gradient exchange started by begin_exchange(), finished by step()
         for p in ps:
             mops.register_grad_sink(p, self)
         weakref.finalize(self, mops.unregister_grad_sinks, [id(p) for p in ps], id(self))
@@ -254,6 +255,9 @@ class MnkAdam(torch.optim.Optimizer):
             torch._foreach_copy_(dsts, srcs)
 
     def zero_grad(self, set_to_none=True):
+        if self._exchange is not None:       # (never in TrainStep: an exchange is always consumed by the step)
+            mdist.all_reduce_flat_end(self._exchange)
+            self._exchange = None
         for p in self._params:
             p.grad = None
         self.reducer.drop()
@@ -291,6 +295,15 @@ class MnkAdam(torch.optim.Optimizer):
         return _device_table(rec, self.device, self._keep), len(rows), blocks, tuple(entries)
 
     @torch.no_grad()
+    def begin_exchange(self):
+        """After backward: put every gradient in place and START the sum over the ranks without blocking the kernels' stream;
+        step() waits for it.  Work that does not depend on this optimiser's update (the discriminator-loss backward of
+        mnk.engine.TrainStep) runs in between and hides the exchange."""
+        self.materialize_grads()
+        if self._exchange is None and mdist.grads_active() and any(p.grad is not None for p in self._params):
+            self._exchange = mdist.all_reduce_flat_begin(self.flat_grad)
+
+    @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closures are not used by train.py")
@@ -299,7 +312,10 @@ class MnkAdam(torch.optim.Optimizer):
         if not active:
             return None
         ws = mdist.world_size() if mdist.grads_active() else 1
-        if mdist.grads_active():
+        if self._exchange is not None:
+            mdist.all_reduce_flat_end(self._exchange)
+            self._exchange = None
+        elif mdist.grads_active():
             mdist.all_reduce_flat_(self.flat_grad)          # sum over ranks; the mean is folded into the update
         if not _capturing(self.device):
             self.sync_scalars(1.0 / ws)

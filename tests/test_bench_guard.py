@@ -74,7 +74,9 @@ def test_graph_phase_deadline_prints_the_eager_line():
     rcs, outs = _run("hang", 3)
     assert rcs == [0, 0], outs
     lines = outs[0][0].splitlines()
-    assert len(lines) == 1 and json.loads(lines[0]) == {"value": 1.0, "config": {"launch": "eager"}}, outs[0]
+    got = json.loads(lines[0])       # the eager measurement, and LOUDLY so: capture_failed in the line itself
+    assert len(lines) == 1 and got["value"] == 1.0 and got["capture_failed"] is True, outs[0]
+    assert got["config"]["launch"].startswith("eager (the hipGraph phase exceeded")
     assert outs[1][0] == "" and "deadline" in outs[0][1] and "deadline" in outs[1][1]
 
 

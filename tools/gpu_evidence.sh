@@ -4,7 +4,7 @@
 #   kernel stats (+ steady-state window), FETCH_SIZE / WRITE_SIZE PMC passes (separate runs), an SQ pass over the per-layer
 #   conv bench (MFMA busy, GRBM clock), per-layer conv bench of both configs, batched inference (bair B=512), the
 #   single-rank RCCL exercise of the distributed path.
-TAG="${1:-r02final}"; R="${TAG%%final*}"; R="${R:-r02}"
+TAG="${1:-r03final}"; R="${TAG%%final*}"; R="${R:-r03}"
 OUT=gpurun_out/$TAG; mkdir -p "$OUT" profiles; export TMPDIR=/tmp
 S="$OUT/summary.txt"; : > "$S"
 COMMIT="$(cat .gpurun_commit 2>/dev/null || echo unknown)"
@@ -18,11 +18,16 @@ CMD2="python $PWD/bench.py --steps 2 --warmup 2 --graph 0 --no-cpu-baseline --no
 python tools/pmc_summarize.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic_moving-gif_b32.json" 2>&1 | tee -a "$S"
 python - "$OUT/pmc_traffic_moving-gif_b32.json" "$COMMIT" <<'P'
 import json, sys
+sys.path.insert(0, ".")
 try:
-    d = json.load(open(sys.argv[1])); d["_measured_on"] = "commit " + sys.argv[2]; json.dump(d, open(sys.argv[1], "w"), indent=1)
+    import bench
+    d = json.load(open(sys.argv[1])); d["_measured_on"] = "commit " + sys.argv[2]
+    d["_kernel_source_stamp"] = bench.kernel_source_stamp()      # bench.py quotes the file only on these kernel sources
+    json.dump(d, open(sys.argv[1], "w"), indent=1)
 except Exception as e:
-    print("pmc stamp:", e)
+    print("pmc stamp:", e); sys.exit(1)
 P
+[ $? -eq 0 ] || { echo "EVIDENCE FAILED: the PMC traffic file could not be stamped with the kernel sources" | tee -a "$S"; }
 find "$OUT" -name "*counter_collection*" -size +8M -delete; find "$OUT" -name "*kernel_trace*" -size +4M -delete
 # bench.py reads roofline.traffic from profiles/: the file of THIS build
 cp "$OUT/pmc_traffic_moving-gif_b32.json" "profiles/${R}_pmc_traffic_moving-gif_b32.json" 2>/dev/null
