@@ -421,9 +421,12 @@ int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, fl
 int mnk_heatmap_argmax(const float* heat, int ld, int N, int H, int W, int K, int* index, void* stream);
 int mnk_kp_pixel_index(const float* mean, long n, int W, int H, int* pixel, void* stream);
 /* clip_variance (keypoint_detector.py:62-65): out = var * max(clip, sigma_min(var)) / sigma_min(var) over M 2x2
- * matrices, sigma_min by the closed form of modules/util.py:244-255; backward through both factors. */
-int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, void* stream);
-int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* dout, float* dvar, void* stream);
+ * matrices, sigma_min by the closed form of modules/util.py:244-255; backward through both factors.
+ * reference_mode 0 (default of the host layer): sigma_max from the sum, sigma_min = |det| / sigma_max -- the reference's number
+ * in exact arithmetic, finite where its fp32 form cancels; 1: the reference's own sqrt((s1 - s2) / 2) in fp32, NaNs included. */
+int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, int reference_mode, void* stream);
+int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* dout, float* dvar, int reference_mode,
+                             void* stream);
 
 /* ---- transfer-time key-point normalisation (transfer.py:31-62 normalize_kp) ------------------
  * mnk_kp_hull_area: area of the convex hull of K (3..32) points [K][2] -> *area (device scalar) -- scipy.spatial.ConvexHull

@@ -502,6 +502,8 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     //            MFMAs does not cover an HBM miss when few waves share the SIMD).
     // Loads, address arithmetic and LDS writes sit in the MFMA shadow; one barrier per step; the steady-state loop body is
     // branch-free (two steps per trip: LDS buffer and register stage are compile-time constants); the tail is peeled.
+    // (Two steps per barrier -- four LDS buffers, half the barriers -- was built and measured in round 3: the per-layer
+    // bench unchanged, the whole step 10.90 vs 10.79 ms with 40 KB of LDS per block: removed.  profiles/r03_knob_ab_log.txt)
     const int n = s_end - s_begin;
     if (n > 0) {
         load_step(s_begin, St0{});

@@ -508,22 +508,26 @@ static int fill_embed_args(EmbedArgs& a, const float* img, int ld_img, int Cimg,
 // non-finite within four iterations).  Here sigma_max comes from the SUM (no cancellation) and sigma_min = |det| / sigma_max
 // (the product of the singular values is |det|; det by Kahan's fma scheme): identical in exact arithmetic, equal to rounding
 // where the reference's form is accurate, and equal to the fp64 reference where it is not.
-__device__ __forceinline__ void sigma_2x2(float a, float b, float c, float d, float& s2, float& smax, float& sg) {
+// reference_mode: sigma_min by the reference's own closed form sqrt((s1 - s2) / 2) in its fp32 operation order
+// (modules/util.py:244-255) -- the switch that keeps the reference's exact numbers (its NaNs on nearly singular covariances
+// included) reachable for parity work; the default is the stable form.
+__device__ __forceinline__ void sigma_2x2(float a, float b, float c, float d, float& s2, float& smax, float& sg,
+                                          int reference_mode = 0) {
     const float s1 = a * a + b * b + c * c + d * d;
     const float t = a * a + b * b - c * c - d * d;
     const float u = a * c + b * d;
     s2 = sqrtf(t * t + 4.f * (u * u));
     smax = sqrtf((s1 + s2) * 0.5f);
-    sg = fabsf(det_2x2(a, b, c, d)) / smax;
+    sg = reference_mode ? sqrtf((s1 - s2) / 2.f) : fabsf(det_2x2(a, b, c, d)) / smax;
 }
 
 __global__ void __launch_bounds__(256) kp_clip_var_fwd_kernel(const float* __restrict__ var, float clip, long M,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int reference_mode) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const float4 v = *reinterpret_cast<const float4*>(var + i * 4);
     float s2, smax, sg;
-    sigma_2x2(v.x, v.y, v.z, v.w, s2, smax, sg);
+    sigma_2x2(v.x, v.y, v.z, v.w, s2, smax, sg, reference_mode);
     const float mx = fmaxf(clip, sg);
     *reinterpret_cast<float4*>(out + i * 4) = make_float4((mx * v.x) / sg, (mx * v.y) / sg, (mx * v.z) / sg, (mx * v.w) / sg);
 }
@@ -533,14 +537,15 @@ __global__ void __launch_bounds__(256) kp_clip_var_fwd_kernel(const float* __res
 // d det = (d, -c, -b, a),  sigma_max = sqrt((s1 + s2) / 2): d sigma_max = (d s1 + d s2) / (4 sigma_max),
 // d s2 = (t dt + 4 u du) / s2  -- sums only, no cancellation
 __global__ void __launch_bounds__(256) kp_clip_var_bwd_kernel(const float* __restrict__ var, float clip, long M,
-                                                              const float* __restrict__ dout, float* __restrict__ dvar) {
+                                                              const float* __restrict__ dout, float* __restrict__ dvar,
+                                                              int reference_mode) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const float4 v = *reinterpret_cast<const float4*>(var + i * 4);
     const float4 g = *reinterpret_cast<const float4*>(dout + i * 4);
     const float a = v.x, b = v.y, c = v.z, d = v.w;
     float s2, smax, sg;
-    sigma_2x2(a, b, c, d, s2, smax, sg);
+    sigma_2x2(a, b, c, d, s2, smax, sg, reference_mode);
     const float mx = fmaxf(clip, sg);
     const float dmx = sg > clip ? 1.f : (sg == clip ? 0.5f : 0.f);      // torch.max splits the gradient on ties
     const float gv = g.x * a + g.y * b + g.z * c + g.w * d;
@@ -554,7 +559,16 @@ __global__ void __launch_bounds__(256) kp_clip_var_bwd_kernel(const float* __res
     const float mc = q * (2.f * c + (-t * 2.f * c + 4.f * u * a) * is2);
     const float md = q * (2.f * d + (-t * 2.f * d + 4.f * u * b) * is2);
     const float r = sg / smax, ism = sgn / smax;
-    const float da = ism * d - r * ma, db = -ism * c - r * mb, dc = -ism * b - r * mc, dd = ism * a - r * md;
+    float da = ism * d - r * ma, db = -ism * c - r * mb, dc = -ism * b - r * mc, dd = ism * a - r * md;
+    if (reference_mode) {
+        // what autograd makes of sqrt((s1 - s2) / 2): d sigma_min = (d s1 - d s2) / (4 sigma_min),
+        // d s1 = 2 (a, b, c, d), d s2 = (t dt + 4 u du) / s2
+        const float qq = 1.f / (4.f * sg);
+        da = qq * (2.f * a - (t * 2.f * a + 4.f * u * c) * is2);
+        db = qq * (2.f * b - (t * 2.f * b + 4.f * u * d) * is2);
+        dc = qq * (2.f * c - (-t * 2.f * c + 4.f * u * a) * is2);
+        dd = qq * (2.f * d - (-t * 2.f * d + 4.f * u * b) * is2);
+    }
     const float f = mx / sg;
     *reinterpret_cast<float4*>(dvar + i * 4) =
         make_float4(fmaf(g.x, f, g_sg * da), fmaf(g.y, f, g_sg * db), fmaf(g.z, f, g_sg * dc), fmaf(g.w, f, g_sg * dd));
@@ -850,21 +864,23 @@ int mnk_movement_embedding_bwd(const float* img, int ld_img, int Cimg, const flo
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
-int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, void* stream) {
+int mnk_kp_clip_variance_fwd(const float* var, float clip, long M, float* out, int reference_mode, void* stream) {
     MNK_REQUIRE(var && out && M > 0 && clip > 0.f && ((size_t)var % 16) == 0 && ((size_t)out % 16) == 0);
+    MNK_REQUIRE(reference_mode == 0 || reference_mode == 1);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_KEYPOINT, s, (double)M * 32);
-    hipLaunchKernelGGL(kp_clip_var_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, clip, M, out);
+    hipLaunchKernelGGL(kp_clip_var_fwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, clip, M, out, reference_mode);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
 
-int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* dout, float* dvar, void* stream) {
-    MNK_REQUIRE(var && dout && dvar && M > 0 && clip > 0.f);
+int mnk_kp_clip_variance_bwd(const float* var, float clip, long M, const float* dout, float* dvar, int reference_mode,
+                             void* stream) {
+    MNK_REQUIRE(var && dout && dvar && M > 0 && clip > 0.f && (reference_mode == 0 || reference_mode == 1));
     MNK_REQUIRE(((size_t)var % 16) == 0 && ((size_t)dout % 16) == 0 && ((size_t)dvar % 16) == 0);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_KEYPOINT, s, (double)M * 48);
-    hipLaunchKernelGGL(kp_clip_var_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, clip, M, dout, dvar);
+    hipLaunchKernelGGL(kp_clip_var_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, var, clip, M, dout, dvar, reference_mode);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

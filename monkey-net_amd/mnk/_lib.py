@@ -96,11 +96,3 @@ def lib():
     if _LIB is None:
         _LIB = Library(knobs.get("MNK_LIBRARY") or DEFAULT_LIB)
     return _LIB
-
-
-def _set_library_for_tests(path, strict=True):
-    """tests/ only: bind the C-ABI of another build of the same sources (the CPU emulator build used by the
-    `-m "not gpu"` kernel tests).  Never called by the product."""
-    global _LIB
-    _LIB = Library(path, strict=strict) if path is not None else None
-    return _LIB

@@ -394,6 +394,9 @@ class _Averager:
     def __init__(self, step, opts, params):
         self.opts = opts
         self.legacy = None if step.mnk_adam else mdist.GradAverager(params)
+        if self.legacy is not None:
+            for o in opts:       # mnk.dist's generic pre-step hook (installed by DataParallelWithCallback) must not average these
+                o._mnk_owns_exchange = True      # gradients a second time: GradAverager.average() already has
 
     def arm(self):
         if self.legacy is not None:

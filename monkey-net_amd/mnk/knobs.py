@@ -33,6 +33,8 @@ KNOBS = {
                                      "takes its slice (DataParallel's scatter); slice: trust identical batches; off: no scatter"),
     "MNK_GRAPH_DEADLINE_S": ("", "bench.py under a process group: seconds the hipGraph capture may take before the eager time stands"),
     "MNK_TUNING": ("", "name=value,... for the library's tuning values (read by the library itself; A/B visits)"),
+    "MNK_CLIP_VARIANCE_MODE": ("stable", "sigma_min of clip_variance: stable = |det| / sigma_max (finite on nearly singular "
+                                         "covariances); reference = the reference's own fp32 sqrt((s1 - s2) / 2), NaNs included"),
     "MNK_GRAD_OVERLAP": ("1", "launch a gradient bucket's all-reduce as soon as its last gradient is written"),
     "MNK_SKIP_GRAD_FUSED": ("1", "hourglass levels: the next down block's data-gradient GEMM adds the gradient of the level's other "
                                  "consumer (decoder skip / warp) in its epilogue (0: autograd accumulates the two gradients)"),

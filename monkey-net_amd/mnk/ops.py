@@ -385,7 +385,13 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
     # function does not know whether the BatchNorm that follows pools)
     small = want_stats and residual is None and small_bn(n * h * w) and h % 2 == 0 and w % 2 == 0
     if _SPLIT_PENDING:
-        raise RuntimeError("a split-K convolution is still waiting for the BatchNorm that sums its partials")
+        # the BatchNorm of an earlier deferred split-K convolution never ran: an exception between the two launches (the entry
+        # is popped by that BatchNorm; nothing else may run in between).  The partial sums are gone with the scratch buffer;
+        # drop the entry -- a retry of the forward pass must not be poisoned by the failed one -- and say so
+        import warnings
+        warnings.warn("dropping the deferred split-K partial sums of %d convolution(s) whose BatchNorm never ran (an "
+                      "exception between a convolution and its normalisation layer?)" % len(_SPLIT_PENDING))
+        _SPLIT_PENDING.clear()
     if up:
         assert ups and residual is None
         hl, wl = h // 2, w // 2
@@ -1096,11 +1102,16 @@ class ClipVarianceFn(torch.autograd.Function):
     modules/util.py:244-255) in one kernel instead of ~25 element-wise launches (+ ~60 in the backward)."""
 
     @staticmethod
-    def forward(ctx, var, clip):
+    def forward(ctx, var, clip, mode="stable"):
+        """mode: "stable" (default; sigma_min = |det| / sigma_max) | "reference" (the reference's own fp32 closed form
+        sqrt((s1 - s2) / 2), modules/util.py:244-255 -- for parity work; it returns NaN on nearly singular covariances)"""
         _check_device(var)
+        if mode not in ("stable", "reference"):
+            raise ValueError("clip_variance_mode must be 'stable' or 'reference', got %r" % (mode,))
         var = var.contiguous().float()
         out = torch.empty_like(var)
-        _call("mnk_kp_clip_variance_fwd", var, _p(var), float(clip), var.numel() // 4, _p(out))
+        ctx.ref_mode = int(mode == "reference")
+        _call("mnk_kp_clip_variance_fwd", var, _p(var), float(clip), var.numel() // 4, _p(out), ctx.ref_mode)
         ctx.save_for_backward(var)
         ctx.clip = float(clip)
         return out
@@ -1110,8 +1121,8 @@ class ClipVarianceFn(torch.autograd.Function):
         var, = ctx.saved_tensors
         dout = dout.contiguous()
         dvar = torch.empty_like(var)
-        _call("mnk_kp_clip_variance_bwd", var, _p(var), ctx.clip, var.numel() // 4, _p(dout), _p(dvar))
-        return dvar, None
+        _call("mnk_kp_clip_variance_bwd", var, _p(var), ctx.clip, var.numel() // 4, _p(dout), _p(dvar), ctx.ref_mode)
+        return dvar, None, None
 
 
 class MovementEmbeddingFn(torch.autograd.Function):

@@ -3,7 +3,7 @@ import torch
 from torch import nn
 
 from modules.util import Hourglass, smallest_singular
-from mnk import ops
+from mnk import knobs, ops
 
 
 def _split_variance(kp, kp_variance):
@@ -32,20 +32,26 @@ def kp2gaussian(kp, spatial_size, kp_variance='matrix'):
     return out[..., 0].reshape(lead + (h, w))
 
 
-def gaussian2kp(heatmap, kp_variance='matrix', clip_variance=None):
+def gaussian2kp(heatmap, kp_variance='matrix', clip_variance=None, clip_variance_mode=None):
     """Mean / covariance of a normalised heat-map (B,K,D,H,W) (modules/keypoint_detector.py:43-78).
-    Public helper; KPDetector.forward fuses the soft-max into the same kernel instead of calling this."""
+    Public helper; KPDetector.forward fuses the soft-max into the same kernel instead of calling this.
+    clip_variance_mode (not in the reference): "stable" (default) | "reference", see _finish_kp."""
     b, k, d, h, w = heatmap.shape
     act = ops.to_act(torch.log(heatmap))                               # softmax(log p) == p for a normalised p
     mean, var = ops.SoftmaxKPFn.apply(act, k, 1.0)
-    return _finish_kp(mean.view(b, d, k, 2), var.view(b, d, k, 2, 2), kp_variance, clip_variance)
+    return _finish_kp(mean.view(b, d, k, 2), var.view(b, d, k, 2, 2), kp_variance, clip_variance, clip_variance_mode)
 
 
-def _finish_kp(mean, var, kp_variance, clip_variance):
+def _finish_kp(mean, var, kp_variance, clip_variance, clip_variance_mode=None):
+    """clip_variance_mode: how sigma_min of the covariance is evaluated (keypoint_detector.py:62-65, util.py:244-255):
+    "stable" (default, MNK_CLIP_VARIANCE_MODE) -- |det| / sigma_max, the reference's value in exact arithmetic and the fp64
+    reference's value in fp32; "reference" -- the reference's own fp32 closed form sqrt((s1 - s2) / 2), which cancels to 0 / NaN
+    once sigma_min / sigma_max <~ 2e-4 (line-shaped heat-maps reach that): for bit-level parity work against the reference."""
     kp = {'mean': mean}
     if kp_variance == 'matrix':
         if clip_variance:
-            var = ops.ClipVarianceFn.apply(var, clip_variance)    # var * max(clip, sigma_min) / sigma_min (:62-65)
+            mode = clip_variance_mode or knobs.get("MNK_CLIP_VARIANCE_MODE")
+            var = ops.ClipVarianceFn.apply(var, clip_variance, mode)    # var * max(clip, sigma_min) / sigma_min (:62-65)
         kp['var'] = var
     elif kp_variance == 'single':
         kp['var'] = ((var[..., 0, 0] + var[..., 1, 1]) / 2).unsqueeze(-1).unsqueeze(-1)
@@ -67,6 +73,7 @@ class KPDetector(nn.Module):
         self.clip_variance = clip_variance
         self.num_kp = num_kp
         self.num_channels = num_channels
+        self.clip_variance_mode = None      # None: MNK_CLIP_VARIANCE_MODE ("stable"); "reference": the reference's fp32 sigma_min
         self._last_heat = None
 
     def forward(self, x):
@@ -75,7 +82,8 @@ class KPDetector(nn.Module):
         heat, k = self.predictor.forward_act(act, self.num_channels)
         mean, var = ops.SoftmaxKPFn.apply(heat, k, self.temperature)
         self._last_heat = (heat.detach(), k, b, d)          # for keypoint_indices(): no copy, no extra launch
-        return _finish_kp(mean.view(b, d, k, 2), var.view(b, d, k, 2, 2), self.kp_variance, self.clip_variance)
+        return _finish_kp(mean.view(b, d, k, 2), var.view(b, d, k, 2, 2), self.kp_variance, self.clip_variance,
+                          self.clip_variance_mode)
 
     def keypoint_indices(self, kp, frame_size=None):
         """The integer key-point positions of the LAST forward call (not part of the reference's API; the north star's

@@ -26,3 +26,12 @@ def relerr(a, b):
 
 def maxerr(a, b):
     return float((a.double().cpu() - b.double().cpu()).abs().max())
+
+
+def set_library(path, strict=True):
+    """TEST INFRASTRUCTURE: bind the C-ABI of another build of the same kernel sources (the CPU emulator build used by the
+    `-m "not gpu"` tests) by replacing the product's process-wide library handle; None: back to the in-tree gfx950 build on
+    next use.  The product has no such switch (its only library override is the MNK_LIBRARY path)."""
+    from mnk import _lib
+    _lib._LIB = _lib.Library(path, strict=strict) if path is not None else None
+    return _lib._LIB

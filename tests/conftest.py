@@ -11,6 +11,9 @@ for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
         sys.path.insert(0, p)
 
 
+import _util  # noqa: E402
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -37,12 +40,12 @@ class Backend:
         from mnk import _lib
         self.kind = kind
         if kind == "emu":
-            self.lib = _lib._set_library_for_tests(emu_library_path(), strict=False)
+            self.lib = _util.set_library(emu_library_path(), strict=False)
             self.device = torch.device("cpu")
         else:
             if not torch.cuda.is_available():
                 pytest.skip("no GPU")
-            self.lib = _lib._set_library_for_tests(None) or _lib.lib()
+            self.lib = _util.set_library(None) or _lib.lib()
             assert self.lib.is_device_build
             self.device = torch.device("cuda:0")
 
@@ -80,4 +83,4 @@ def be(request):
     b = Backend(request.param)
     yield b
     from mnk import _lib
-    _lib._set_library_for_tests(None)
+    _util.set_library(None)

@@ -23,7 +23,7 @@ ref_shim.install_torch_pins()      # torch.gesv (transfer.py:51 calls it directl
 from conftest import emu_library_path  # noqa: E402
 from mnk import _lib  # noqa: E402
 
-_lib._set_library_for_tests(emu_library_path(), strict=False)
+__import__('_util').set_library(emu_library_path(), strict=False)
 
 
 def load_gold(name):

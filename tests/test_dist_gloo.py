@@ -26,9 +26,10 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     from mnk import _lib, dist as mdist, engine
+    import _util
     from oracle import cases
     from test_modules import build
-    _lib._set_library_for_tests(emu_path, strict=False)
+    _util.set_library(emu_path, strict=False)
     cfg = cases.TINY2
     gen, disc, kpd = build(cfg)
     for i, m in enumerate((gen, disc, kpd)):
@@ -60,9 +61,10 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
 def _single(emu_path, mnk_adam=False):
     _setup_paths()
     from mnk import _lib, engine
+    import _util
     from oracle import cases
     from test_modules import build
-    _lib._set_library_for_tests(emu_path, strict=False)
+    _util.set_library(emu_path, strict=False)
     cfg = cases.TINY2
     gen, disc, kpd = build(cfg)
     for i, m in enumerate((gen, disc, kpd)):
@@ -74,7 +76,7 @@ def _single(emu_path, mnk_adam=False):
     g_losses, d_losses, _ = step.step({"source": src, "video": drv})
     out = {"losses": torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64),
            "gen": gen.state_dict(), "kp": kpd.state_dict(), "disc": disc.state_dict()}
-    _lib._set_library_for_tests(None)
+    _util.set_library(None)
     return out
 
 

@@ -110,6 +110,7 @@ def test_no_grad_pack_cache_sees_replaced_storage(be):
     assert float((run() - ref()).abs().max()) < 1e-5
     w.data = be.t(torch.randn(5, 4, 1, 3, 3) * 0.3)
     assert float((run() - ref()).abs().max()) < 1e-5, "stale packed weights after p.data = ..."
+    gc.collect()                    # garbage of earlier tests in this process (whole models in reference cycles) goes first
     n0 = len(ops._PACK_CACHE)
     del w
     gc.collect()

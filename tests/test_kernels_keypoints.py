@@ -160,11 +160,48 @@ def test_clip_variance(be):
     ref32.backward(dout.float())
     spread_f, spread_b = relerr(ref32.detach(), ref.detach()), relerr(v32.grad, vd.grad)
     V, O, DV = be.t(var), be.empty(m, 2, 2), be.empty(m, 2, 2)
-    be.call("mnk_kp_clip_variance_fwd", V, clip, m, O)
-    be.call("mnk_kp_clip_variance_bwd", V, clip, m, be.t(dout.float()), DV)
+    be.call("mnk_kp_clip_variance_fwd", V, clip, m, O, 0)
+    be.call("mnk_kp_clip_variance_bwd", V, clip, m, be.t(dout.float()), DV, 0)
     be.sync()
     assert relerr(O.cpu(), ref.detach()) < 4 * spread_f + 1e-6
     assert relerr(DV.cpu(), vd.grad) < 4 * spread_b + 1e-5
+
+
+def test_clip_variance_reference_mode(be):
+    """reference_mode = 1 (ops.ClipVarianceFn mode="reference", MNK_CLIP_VARIANCE_MODE=reference): sigma_min by the reference's own
+    fp32 closed form sqrt((s1 - s2) / 2) in its operation order (modules/util.py:244-255) -- equal to torch's fp32 evaluation
+    of the restated formula to rounding (forward and autograd's backward), and unusable on a nearly singular covariance
+    exactly where the reference's is."""
+    from mnk import ops
+    g = torch.Generator().manual_seed(4)
+    m = 37
+    a = torch.randn(m, 2, 2, generator=g) * 0.1
+    var = a @ a.transpose(1, 2) + 0.002 * torch.eye(2)
+    clip = 0.004
+    v32 = var.clone().requires_grad_(True)
+    sg32 = restate.smallest_singular(v32).unsqueeze(-1)
+    ref32 = torch.max(torch.full((), clip), sg32) * v32 / sg32
+    dout = torch.randn(m, 2, 2, generator=g)
+    ref32.backward(dout)
+    V = be.t(var).requires_grad_(True)
+    out = ops.ClipVarianceFn.apply(V, clip, "reference")
+    out.backward(be.t(dout))
+    be.sync()
+    # same formula, same precision: only the association of a few products differs (fma contraction)
+    assert relerr(out.detach().cpu(), ref32.detach()) < 2e-5
+    assert relerr(V.grad.cpu(), v32.grad) < 2e-4
+    stable = ops.ClipVarianceFn.apply(be.t(var), clip, "stable")
+    assert relerr(stable.cpu(), out.detach().cpu()) < 1e-3            # two evaluations of one number on benign matrices
+    # a line-shaped covariance: sigma_min / sigma_max = 1e-6 -- the reference's form has no digits left
+    bad = torch.tensor([[[0.5, 0.5], [0.5, 0.5 + 1e-6]]])
+    ref_sg = restate.smallest_singular(bad)
+    got = ops.ClipVarianceFn.apply(be.t(bad), 0.001, "reference").cpu()
+    ok = ops.ClipVarianceFn.apply(be.t(bad), 0.001, "stable").cpu()
+    assert torch.isfinite(ok).all()
+    if not bool(torch.isfinite(ref_sg).all()) or float(ref_sg) <= 0:
+        assert not bool(torch.isfinite(got).all())                    # the reference's failure is reproduced, not repaired
+    with pytest.raises(ValueError):
+        ops.ClipVarianceFn.apply(be.t(var), clip, "exact")
 
 
 def test_clip_variance_of_nearly_singular_covariances(be):
@@ -189,8 +226,8 @@ def test_clip_variance_of_nearly_singular_covariances(be):
     sg32 = restate.smallest_singular(var)
     broken = int((~torch.isfinite(sg32) | (sg32 <= 0)).sum())
     V, O, DV = be.t(var), be.empty(m, 2, 2), be.empty(m, 2, 2)
-    be.call("mnk_kp_clip_variance_fwd", V, clip, m, O)
-    be.call("mnk_kp_clip_variance_bwd", V, clip, m, be.t(dout.float()), DV)
+    be.call("mnk_kp_clip_variance_fwd", V, clip, m, O, 0)
+    be.call("mnk_kp_clip_variance_bwd", V, clip, m, be.t(dout.float()), DV, 0)
     be.sync()
     assert torch.isfinite(O.cpu()).all() and torch.isfinite(DV.cpu()).all()
     # fp32 inputs carry ~6e-8 absolute rounding: sigma_min = det / sigma_max is known to ~1e-7 / sigma_min relative

@@ -35,4 +35,6 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))[
     for c in names:
         if c.startswith("SQ_") and c not in ("SQ_WAVE_CYCLES",):
             line += f" {c[3:]}={v.get(c,0)/wc:.3f}"
+        elif not c.startswith("SQ_") and c != "GRBM_GUI_ACTIVE":
+            line += f" {c}/launch={v.get(c,0)/max(n,1):.4g}"
     print(line)
