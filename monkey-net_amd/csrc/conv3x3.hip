@@ -2075,6 +2075,101 @@ __host__ __device__ __forceinline__ void reduce_map(int splits, int* tw, int* ro
     *rows = splits < 4 ? 4 : 1;
 }
 
+// Few-split layers with C % 4 == 0 -- the deep levels (2x2 ... 8x8 maps, 256 ... 2048 channels), whose "partials" ARE the
+// gradient (240 of the 265 MB of BASELINE configs[1]) in tap-major order -- take a flat map instead: a thread owns four
+// consecutive input channels of one output row, reads one float4 per tap and split (1 KB contiguous per 64 lanes; the tile
+// map above reads 256-byte pieces: ~1.8 TB/s measured) and writes its 4 * ntaps consecutive gradient floats from registers:
+// no LDS, no barrier.  blocks = ceil(Cout * C / 4 / 256).
+__host__ __device__ __forceinline__ bool reduce_flat(int splits, int C) { return splits < 4 && (C & 3) == 0; }
+
+// out[e * NT + tp] = v[tp].e for the four channels e of a thread: the (tap, ci) -> (ci, tap) transposition in registers
+template <int NT>
+__device__ __forceinline__ void flat_store(const float4* v, float* __restrict__ dst, bool accumulate) {
+    float o[4 * NT];
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+        o[0 * NT + tp] = v[tp].x;
+        o[1 * NT + tp] = v[tp].y;
+        o[2 * NT + tp] = v[tp].z;
+        o[3 * NT + tp] = v[tp].w;
+    }
+    if (((size_t)dst & 15) == 0) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            float4 w = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            if (accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(dst + 4 * k);
+                w = make_float4(old.x + w.x, old.y + w.y, old.z + w.z, old.w + w.w);
+            }
+            *reinterpret_cast<float4*>(dst + 4 * k) = w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4 * NT; ++k) dst[k] = accumulate ? dst[k] + o[k] : o[k];
+    }
+}
+
+template <int NIN, int NOUT, int LAYOUT>      // taps read / written; LAYOUT 0 tap-major, 2 tap-major sub-pixel (16 -> 9), 1 parameter-major
+__device__ __forceinline__ void reduce_flat_body(const MnkWgradReduceDesc& d, int co, int ci) {
+    float4 acc[NIN];
+#pragma unroll
+    for (int tp = 0; tp < NIN; ++tp) acc[tp] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* dst = d.dw + ((long)co * d.Cin_total + d.c_start + ci) * NOUT;
+    if (LAYOUT == 1) {
+        // part[s][co][ci * NOUT + tap]: the thread's 4 * NOUT floats are contiguous and already in gradient order
+        const long NT = (long)d.C * NOUT, sstride = (long)d.Cout * NT;
+        const float* src = d.part + (long)co * NT + (long)ci * NOUT;
+        for (int sp = 0; sp < d.splits; ++sp) {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(src + (long)sp * sstride + 4 * k);
+                acc[k] = make_float4(acc[k].x + v.x, acc[k].y + v.y, acc[k].z + v.z, acc[k].w + v.w);
+            }
+        }
+        if (((size_t)dst & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                float4 w = acc[k];
+                if (d.accumulate) {
+                    const float4 old = *reinterpret_cast<const float4*>(dst + 4 * k);
+                    w = make_float4(old.x + w.x, old.y + w.y, old.z + w.z, old.w + w.w);
+                }
+                *reinterpret_cast<float4*>(dst + 4 * k) = w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NIN; ++k) {
+                const float e[4] = {acc[k].x, acc[k].y, acc[k].z, acc[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[4 * k + j] = d.accumulate ? dst[4 * k + j] + e[j] : e[j];
+            }
+        }
+        return;
+    }
+    const long plane = (long)d.Cout * d.C, sstride = (long)NIN * plane;
+    const float* src = d.part + (long)co * d.C + ci;
+    for (int sp = 0; sp < d.splits; ++sp) {                      // NIN independent 16-byte loads in flight per split
+#pragma unroll
+        for (int tp = 0; tp < NIN; ++tp) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long)sp * sstride + (long)tp * plane);
+            acc[tp] = make_float4(acc[tp].x + v.x, acc[tp].y + v.y, acc[tp].z + v.z, acc[tp].w + v.w);
+        }
+    }
+    if (LAYOUT == 2) {                                           // fold the 16 pseudo taps into the nine kernel taps, per channel
+        float ax[16], ay[16], az[16], aw[16];
+#pragma unroll
+        for (int tp = 0; tp < 16; ++tp) ax[tp] = acc[tp].x, ay[tp] = acc[tp].y, az[tp] = acc[tp].z, aw[tp] = acc[tp].w;
+        float4 f[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+            f[tp] = make_float4(up_fold(ax, tp / 3, tp % 3, 1), up_fold(ay, tp / 3, tp % 3, 1), up_fold(az, tp / 3, tp % 3, 1),
+                                up_fold(aw, tp / 3, tp % 3, 1));
+        flat_store<9>(f, dst, d.accumulate != 0);
+    } else {
+        flat_store<NOUT>(acc, dst, d.accumulate != 0);
+    }
+}
+
 // parameter-major partials part[s][co][ci * ntaps + tap]: this thread's elements src[0], src[TW], ... (those below `left`)
 // summed over the splits s0, s0 + sstep, ... into out[0], out[TW], ...; TW is a compile-time constant so that the eight
 // elements of a pass share one address register pair (immediate offsets)
@@ -2117,6 +2212,23 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradR
     const int di = find_desc(&descs[0].block_begin, (int)(sizeof(MnkWgradReduceDesc) / sizeof(int)), n, b, &sh_idx);
     const MnkWgradReduceDesc d = descs[di];
     const int local = b - d.block_begin;
+    if (reduce_flat(d.splits, d.C) && (d.ntaps == 9 || d.ntaps == 16)) {      // (block-uniform: no barrier follows on this path)
+        const int q4 = d.C >> 2;
+        const long item = (long)local * 256 + threadIdx.x;
+        if (item >= (long)d.Cout * q4) return;
+        const int co = (int)(item / q4), ci = 4 * (int)(item - (long)co * q4);
+        if (d.layout == 2)
+            reduce_flat_body<16, 9, 2>(d, co, ci);
+        else if (d.layout == 0 && d.ntaps == 9)
+            reduce_flat_body<9, 9, 0>(d, co, ci);
+        else if (d.layout == 0)
+            reduce_flat_body<16, 16, 0>(d, co, ci);
+        else if (d.ntaps == 9)
+            reduce_flat_body<9, 9, 1>(d, co, ci);
+        else
+            reduce_flat_body<16, 16, 1>(d, co, ci);
+        return;
+    }
     int tw, rpb;
     reduce_map(d.splits, &tw, &rpb);
     const int groups = 256 / tw, gstride = tw * 16;
@@ -3396,6 +3508,12 @@ int mnk_last_plan(long* out8) {
 
 int mnk_wgrad_reduce_blocks(int splits, int Cout, int C) {
     if (splits <= 0 || Cout <= 0 || C <= 0) return 0;
+    // (the flat map is taken for 3x3 / 4x4 kernels only; any other tap count still gets enough blocks from it: the tile map
+    // needs ceil(Cout / 4) * ceil(C / 64) <= ceil(Cout * C / 1024))
+    if (reduce_flat(splits, C)) {
+        const long flat = ((long)Cout * (C >> 2) + 255) / 256, tile = (long)ceil_div(Cout, 4) * ceil_div(C, 64);
+        return (int)(flat > tile ? flat : tile);
+    }
     int tw, rows;
     reduce_map(splits, &tw, &rows);
     return ceil_div(Cout, rows) * ceil_div(C, tw);

@@ -82,6 +82,12 @@ def test_deferred_wgrad_of_many_layers_reduced_in_one_launch(be, accumulate):
     rec = np.array(rows, dtype=REDUCE_DESC)
     layouts = set(int(r["layout"]) for r in rec)
     assert layouts == {0, 1, 2} and direct > 0 and len(rec) > 12, (layouts, direct, len(rec))
+    # both thread maps of the reduction are exercised for every layout: the flat float4 map (few splits, C % 4 == 0: the deep
+    # levels) and the tile map
+    flat = {(int(r["layout"]), int(r["ntaps"])) for r in rec if r["splits"] < 4 and r["C"] % 4 == 0}
+    tiled = {int(r["layout"]) for r in rec if not (r["splits"] < 4 and r["C"] % 4 == 0)}
+    assert {l for l, _ in flat} >= {0, 2} and tiled >= {0, 1}, (flat, tiled)
+    print('flat map:', sorted(flat), 'tile map layouts:', sorted(tiled))
     descs = _table(be, rec)
     be.call("mnk_wgrad_reduce_multi", descs, len(rec), blocks)
     be.sync()
@@ -90,6 +96,60 @@ def test_deferred_wgrad_of_many_layers_reduced_in_one_launch(be, accumulate):
             DY, DW, ref, base = item
             want = ref if base is None else ref + base.double()
             assert relerr(DW.cpu(), want) < 2e-6
+
+
+def _fold16(acc):
+    """(16, ...) pseudo-tap sums of the sub-pixel form -> (9, ...) kernel taps (csrc/conv3x3.hip: up_fold)"""
+    def pairs(k):
+        return ((0, 0 if k == 0 else 1), (1, 1 if k == 2 else 0))
+    out = []
+    for ky in range(3):
+        for kx in range(3):
+            v = 0
+            for ya, yu in pairs(ky):
+                for xb, xv in pairs(kx):
+                    v = v + acc[4 * (2 * ya + xb) + 2 * yu + xv]
+            out.append(v)
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_wgrad_reduce_multi_thread_maps_on_synthetic_partials(be, accumulate):
+    """mnk_wgrad_reduce_multi alone, on made-up partials: every layout x tap count through BOTH thread maps -- the flat float4
+    map (splits < 4, C % 4 == 0) with aligned and unaligned gradient slices, and the tile map (many splits / ragged C)."""
+    g = torch.Generator().manual_seed(31)
+    rows, keep, blocks = [], [], 0
+    for layout, nt in ((0, 9), (0, 16), (1, 9), (1, 16), (2, 9)):
+        for splits, cout, c, c_start, cin_total in ((1, 33, 20, 0, 20), (3, 5, 8, 4, 16), (2, 7, 8, 3, 12), (5, 9, 8, 0, 8),
+                                                    (2, 6, 10, 0, 10), (40, 4, 12, 0, 12)):
+            nin = 16 if layout == 2 else nt
+            if layout == 1:
+                part = torch.randn(splits, cout, c * nt, generator=g)
+                want = part.double().sum(0).view(cout, c, nt)
+            else:
+                part = torch.randn(splits, nin, cout, c, generator=g)
+                acc = part.double().sum(0)                               # (nin, cout, c)
+                want = (_fold16(acc) if layout == 2 else acc).permute(1, 2, 0)   # (cout, c, nt)
+            base = torch.randn(cout, cin_total, nt, generator=g)
+            full = base.double().clone() if accumulate else torch.full((cout, cin_total, nt), float("nan"), dtype=torch.float64)
+            full[:, c_start:c_start + c] = (full[:, c_start:c_start + c] if accumulate else 0) + want
+            P, DW = be.t(part), be.t(base.clone() if accumulate else torch.full_like(base, float("nan")))
+            rows.append((P.data_ptr(), DW.data_ptr(), layout, splits, nt, cout, c, cin_total, c_start, accumulate, blocks, 0))
+            blocks += be.query("mnk_wgrad_reduce_blocks", splits, cout, c)
+            keep.append((P, DW, full, c_start, c))
+    rec = np.array(rows, dtype=REDUCE_DESC)
+    be.call("mnk_wgrad_reduce_multi", _table(be, rec), len(rec), blocks)
+    be.sync()
+    for i, (P, DW, full, c_start, c) in enumerate(keep):
+        got = DW.cpu().double()
+        sl = slice(c_start, c_start + c)
+        assert float((got[:, sl] - full[:, sl]).abs().max()) < 1e-5, (i, rows[i][2:10])
+        rest = torch.ones(got.shape[1], dtype=torch.bool)
+        rest[sl] = False
+        if accumulate:       # columns of other sources are not touched
+            assert torch.equal(got[:, rest], full[:, rest]), (i, rows[i][2:10])
+        else:
+            assert bool(torch.isnan(got[:, rest]).all()), (i, rows[i][2:10])
 
 
 def _adam_reference(params, grads_seq, lr):
