@@ -208,6 +208,21 @@ def install_grad_averaging():
     return True
 
 
+def check_equal_shards(n):
+    """SyncBN finalises with count = local count * world size and gradients are averaged with 1 / world size: both assume that
+    every rank holds the same number of samples.  Raises on the ranks' first disagreement (one tiny collective; callers cache
+    the checked value)."""
+    if not initialized() or tdist.get_world_size() == 1:
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if tdist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(n), -float(n)], dtype=torch.float32, device=dev)
+    tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+    hi, lo = int(t[0].item()), -int(t[1].item())
+    if hi != lo:
+        raise ValueError("ranks hold different numbers of samples (%d ... %d; this rank %d): the SyncBN counts and the gradient "
+                         "average of the data-parallel step assume equal shards" % (lo, hi, n))
+
+
 def combine_bn_stats(sums, count):
     """Host-side statement of the SyncBN exchange for tests: returns (global sums, global count)."""
     if active():

@@ -118,6 +118,7 @@ class TrainStep:
         self._static_x = None
         self._static_out = None
         self._weights_touched = True          # packed weights must be (re)made before the next iteration
+        self._shard_checked = None            # batch size the ranks were last found to agree on (mnk.dist.check_equal_shards)
         if self.mnk_adam:
             from . import optim as moptim
             self.opt_g = moptim.MnkAdam(generator.parameters(), lr=lr, betas=(0.5, 0.999))
@@ -231,6 +232,11 @@ class TrainStep:
         self.weights_changed()                          # the packed copies belong to the warm-up's parameters
 
     def _eager_step(self, x, set_to_none=True):
+        b = int(x['source'].shape[0])
+        if b != self._shard_checked and mdist.initialized() and not (
+                x['source'].is_cuda and torch.cuda.is_current_stream_capturing()):
+            mdist.check_equal_shards(b)       # count = local * world (SyncBN) and the 1 / world gradient scale need equal shards
+            self._shard_checked = b
         self._weights_touched = False
         if knobs.on("MNK_DISC_SHARED"):
             return self._eager_step_shared(x)

@@ -53,6 +53,12 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
     mdist.all_reduce_sum_(t)
     tri = world * (world + 1) / 2.0
     assert torch.equal(t, torch.full((3,), tri))
+    mdist.check_equal_shards(5)
+    try:
+        mdist.check_equal_shards(5 + rank)
+        raise AssertionError("unequal shards must be refused")
+    except ValueError as e:
+        assert "different numbers of samples" in str(e)
     sums, count = mdist.combine_bn_stats(torch.tensor([1.0 * (rank + 1), 2.0]), 10)
     assert count == 10 * world and torch.equal(sums, torch.tensor([tri, 2.0 * world]))
     dist.destroy_process_group()
