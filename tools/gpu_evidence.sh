@@ -50,13 +50,34 @@ python tools/sq_summarize.py "$OUT/sq" > "$OUT/sq_counters_conv_bench_moving-gif
 find "$OUT" -name "*counter_collection*" -size +8M -delete; find "$OUT" -name "*kernel_trace*" -size +4M -delete
 echo "== per-layer conv bench" | tee -a "$S"
 for c in moving-gif taichi; do timeout 300 python tools/conv_bench.py --config $c --batch 32 > "$OUT/conv_bench_${c}_b32.txt" 2>&1; grep TOTAL "$OUT/conv_bench_${c}_b32.txt" | tee -a "$S"; done
+timeout 300 python tools/conv_bench.py --config vox --batch 8 --size 256 > "$OUT/conv_bench_vox256_b8.txt" 2>&1; grep TOTAL "$OUT/conv_bench_vox256_b8.txt" | tee -a "$S"
+echo "== fp32 MFMA pipe micro-benchmark (what the peak of the roofline is worth on this chip)" | tee -a "$S"
+hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/microbench/mfma_f32_peak.hip 2>/dev/null && timeout 120 /tmp/mfma_peak > "$OUT/mfma_f32_peak.txt" 2>&1; head -8 "$OUT/mfma_f32_peak.txt" | tee -a "$S"
+# the parity evidence pytest wrote (tests/test_fullsize_oracle.py, tests/test_kp_index.py)
+mkdir -p "$OUT/parity"; cp gpurun_out/parity_*.json gpurun_out/kp_index_*.json "$OUT/parity/" 2>/dev/null
+python - "$OUT" <<'P'
+import glob, json, os, sys
+out = sys.argv[1]
+rows = []
+for f in sorted(glob.glob(os.path.join(out, "parity", "kp_index_*.json"))):
+    d = json.load(open(f))
+    rows.append("%-34s pixel %5d / %-5d argmax %5d / %-5d max |mean - ref64| %.2e  nearest cell boundary %.2e px  listed %d" % (
+        d["case"], d["pixel_equal"], d["pixel_total"], d["argmax_equal"], d["argmax_total"], d["max_abs_mean_error"],
+        d["smallest_boundary_distance_px"], len(d["listed_ill_defined"])))
+for f in sorted(glob.glob(os.path.join(out, "parity", "parity_*.json"))):
+    d = json.load(open(f))
+    rows.append("%-34s %d quantities, error / reference's own fp32 error: %s, worst error / tolerance %.2f" % (
+        os.path.basename(f)[7:-5], d["n"], d.get("error_over_reference_fp32_error"), d["worst"][0]["ratio"]))
+open(os.path.join(out, "parity_summary.txt"), "w").write("\n".join(rows) + "\n")
+print("\n".join(rows[-4:]))
+P
 echo "== batched inference (bair, B=512)" | tee -a "$S"
 timeout 300 python tools/infer_bench.py > "$OUT/infer_bair_b512.json" 2> "$OUT/infer.err"; cat "$OUT/infer_bair_b512.json" | cut -c1-400 | tee -a "$S"
 echo "== single-rank RCCL exercise (MNK_DIST_FORCE=1, torch.distributed.run)" | tee -a "$S"
 MNK_DIST_FORCE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > "$OUT/bench_dist1.json" 2> "$OUT/bench_dist1.err"; echo "rc=$?" | tee -a "$S"
 cut -c1-330 "$OUT/bench_dist1.json" | tee -a "$S"; grep -h "mnk.dist\|capture failed" "$OUT/bench_dist1.err" | head -3 | cut -c1-200 | tee -a "$S"
 # what profiles/ keeps (small files only)
-for f in bench_moving-gif_b32.json bench_taichi_b32.json bench_vox256_b8.json moving-gif_b32_eager_kernel_stats.csv moving-gif_b32_steady_kernel_stats.csv moving-gif_b32_steady_groups.txt pmc_traffic_moving-gif_b32.json sq_counters_conv_bench_moving-gif.txt conv_bench_moving-gif_b32.txt conv_bench_taichi_b32.txt infer_bair_b512.json; do
+for f in bench_moving-gif_b32.json bench_taichi_b32.json bench_vox256_b8.json moving-gif_b32_eager_kernel_stats.csv moving-gif_b32_steady_kernel_stats.csv moving-gif_b32_steady_groups.txt pmc_traffic_moving-gif_b32.json sq_counters_conv_bench_moving-gif.txt conv_bench_moving-gif_b32.txt conv_bench_taichi_b32.txt conv_bench_vox256_b8.txt infer_bair_b512.json mfma_f32_peak.txt parity_summary.txt; do
   [ -s "$OUT/$f" ] && cp "$OUT/$f" "$OUT/${R}_$f"
 done
 cp "$OUT/bench_dist1.json" "$OUT/${R}_bench_moving-gif_b32_rccl_1rank.json" 2>/dev/null
