@@ -8,7 +8,11 @@
 `modules.*` / `sync_batchnorm.*` resolve here, everything else (train.py, logger.py, frames_dataset.py,
 modules.prediction_module) in the reference tree.  Under torch.distributed.run (one process per GPU) it also joins the
 process group before the script starts, so SyncBN statistics and gradients are exchanged over RCCL without editing
-train.py (sync_batchnorm.DataParallelWithCallback installs the gradient averaging, see replicate.py)."""
+train.py (sync_batchnorm.DataParallelWithCallback installs the gradient averaging, see replicate.py).  Batch semantics are
+DataParallel's: the YAML batch_size is the GLOBAL batch -- every rank's DataLoader produces a batch, rank 0's is broadcast and
+each rank computes its slice (replicate.py, MNK_DP_SCATTER) -- so epochs, learning-rate milestones and logged iteration
+counts mean what they mean in the reference; ranks > 0 load data they do not use (seed the loaders equally and set
+MNK_DP_SCATTER=slice to skip the broadcast)."""
 import os
 import runpy
 import sys
