@@ -18,6 +18,8 @@ KNOBS = {
                            "weight-gradient reductions); 0: torch.optim.Adam(fused=True) + per-layer reductions (round 1)"),
     "MNK_WGRAD_GROUPED": ("1", "MnkAdam pipeline: the tap-major weight-gradient GEMMs of all layers in one launch per tile "
                                "shape at the end of backward (0: one launch per layer during backward)"),
+    "MNK_WGRAD_BG": ("10", "eager iterations: giga-MACs of recorded weight-gradient GEMMs after which they are launched on a second "
+                           "stream during backward (0: all of them at the end, as a captured iteration always does)"),
     "MNK_UP_SUBPIXEL": ("1", "UpBlock3D convolutions in their sub-pixel forms (four 2x2 phase convolutions forward, one 4x4 "
                              "stride-2 convolution for the data gradient; 0: 3x3 over the up-sampled view + sum-pool)"),
     "MNK_BN_ZERO_BIAS_GRAD": ("1", "the bias of a convolution in front of a training-mode BatchNorm gets no gradient (it is "

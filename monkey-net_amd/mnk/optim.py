@@ -48,6 +48,16 @@ def _device_table(rec, device, keep):
     return t
 
 
+_BG_STREAMS = {}
+
+
+def _background_stream(device):
+    s = _BG_STREAMS.get(device)
+    if s is None:
+        s = _BG_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _capturing(device):
     return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
 
@@ -68,6 +78,14 @@ class DeferredReducer:
         self.done = set()         # keys launched / recorded since zero_grad
         self.tables = {}          # tuple(pending keys) -> (device table, n, blocks)
         self.keep = []
+        # background launches (MNK_WGRAD_BG = giga-MACs per launch group; 0: everything at flush time) of an EAGER
+        # backward: the recorded GEMMs go to a second stream as soon as enough of them are there, and run under the
+        # launch-bound normalisation / element-wise passes of the layers further down the chain (MI355X: 12.54 -> 11.40 ms
+        # per eager iteration).  Not while capturing: a hipGraph with a second branch replays 0.6 ms SLOWER than the
+        # linear one (11.4-11.6 against 10.78 ms, profiles/r03_knob_ab_log.txt), so captured iterations stay linear
+        self.bg_macs = float(mops.knobs.get("MNK_WGRAD_BG") or 0) * 1e9
+        self.job_macs = 0.0
+        self.inflight = []        # operands / tables of launches on the background stream since the last join
 
     def _record(self, key, weight, sink, shape, flags):
         n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total, hi, wi, ld_dy, c_start = shape
@@ -113,6 +131,9 @@ class DeferredReducer:
             rec = self._record(key, weight, sink, shape, int(flags))
         if rec["grouped"]:
             self.jobs.append((key, x, dy))                 # launched by flush(); the operands stay alive until then
+            self.job_macs += float(n * ho * wo) * c * cout * kh * kw
+            if self.bg_macs > 0 and self.job_macs >= self.bg_macs and x.is_cuda and not _capturing(x.device):
+                self._launch_grouped(background=True)
         else:
             mops._call("mnk_conv2d_wgrad", dy, mops._p(x), ld_x, c, int(flags) | 4, hi, wi, kh, kw, pad, mops._p(dy), ld_dy,
                        cout, mops._p(sink), cin_total, c_start, n, ho, wo, mops._p(rec["part"]), rec["nfloats"])
@@ -122,8 +143,9 @@ class DeferredReducer:
         own._written.add(id(weight))
         return True
 
-    def _launch_grouped(self):
+    def _launch_grouped(self, background=False):
         jobs, self.jobs = self.jobs, []
+        self.job_macs = 0.0
         lib = _lib.lib()
         dev = jobs[0][1].device
         arr = np.zeros(len(jobs), dtype=JOB)
@@ -139,16 +161,31 @@ class DeferredReducer:
         table = torch.empty(host.size, dtype=torch.uint8, device=dev)
         if _capturing(dev):
             self.keep.append(table)
+        if background:
+            main, side = torch.cuda.current_stream(dev), _background_stream(dev)
+            side.wait_stream(main)                       # the operands of the recorded jobs are complete on `main`
+            self.inflight.append((jobs, table))          # ... and stay allocated until `main` has waited for `side`
+            with torch.cuda.stream(side):
+                mops._call("mnk_table_upload", table, host.ctypes.data, mops._p(table), host.size)
+                mops._call("mnk_wgrad_grouped_launch", table, mops._p(table), host.ctypes.data)
+            return
         if dev.type == "cuda":
             mops._call("mnk_table_upload", table, host.ctypes.data, mops._p(table), host.size)
         else:
             table.copy_(torch.from_numpy(host))
         mops._call("mnk_wgrad_grouped_launch", table, mops._p(table), host.ctypes.data)
 
+    def _join(self):
+        if self.inflight:
+            dev = self.inflight[0][1].device
+            torch.cuda.current_stream(dev).wait_stream(_background_stream(dev))
+            self.inflight = []
+
     def flush(self):
         """The recorded GEMMs in a few grouped launches, then one launch reducing every pending layer's partials."""
         if self.jobs:
             self._launch_grouped()
+        self._join()
         if not self.pending:
             return 0
         keys = tuple(self.pending)
@@ -171,8 +208,10 @@ class DeferredReducer:
         return n
 
     def drop(self):
+        self._join()
         self.pending = []
         self.jobs = []
+        self.job_macs = 0.0
         self.done.clear()
 
 
