@@ -85,17 +85,20 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 
 static inline void __syncthreads() { hipemu::sync_block(); }
 
-template <typename T>
-static inline T __shfl(T v, int src, int width = 64) {
-    static_assert(sizeof(T) == 4, "hipemu shuffles are 32-bit");
-    uint32_t u;
-    memcpy(&u, &v, 4);
+static inline uint32_t hipemu_shfl32(uint32_t u, int src, int width) {
     unsigned l = hipemu::lane_id();
     const uint32_t* all = hipemu::wave_publish(u, 0);
     unsigned base = l & ~(unsigned)(width - 1);
-    uint32_t r = all[base + ((unsigned)src & (unsigned)(width - 1))];
+    return all[base + ((unsigned)src & (unsigned)(width - 1))];
+}
+template <typename T>
+static inline T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "hipemu shuffles are 32- or 64-bit (two halves, as the hardware does)");
+    uint32_t u[sizeof(T) / 4], r[sizeof(T) / 4];
+    memcpy(u, &v, sizeof(T));
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) r[i] = hipemu_shfl32(u[i], src, width);
     T out;
-    memcpy(&out, &r, 4);
+    memcpy(&out, r, sizeof(T));
     return out;
 }
 template <typename T>
