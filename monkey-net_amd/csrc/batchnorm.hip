@@ -97,108 +97,81 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
     }
 }
 
-// ---- second stage of the column sums: one channel QUAD per `tpq` threads -----------------------------------------------
-// Thread j of a quad's group adds the float4 of row blocks j, j + tpq, ... in fp64: four interleaved sub-sums per
-// component, so 4 * NW 16-byte loads are in flight and a 1024 ... 2048-partial layer is one or two memory round trips
-// (round 2's wavefront per COLUMN: 16 ... 32 dependent round trips of 4-byte loads, 8-9 us per launch on the MI355X).
-// The order is fixed: (s0 + s1) + (s2 + s3) per thread, an xor butterfly over the group's lanes, then the waves of a
-// 256-thread group in order.  NW = 1: one statistic; NW = 2: both statistics of the same channels (p, p + which_stride).
-__host__ __device__ __forceinline__ int second_stage_tpq(int row_blocks) {
-    return row_blocks <= 64 ? 16 : (row_blocks <= 512 ? 64 : 256);
+// A lane's share of one column of the row-block partials: every 64th entry from `lane` on, fp64.  Four entries in flight
+// (a load -> add chain per entry made the second stage of a 1024 ... 2048-partial layer a 16 ... 32-deep latency chain); the
+// order is fixed: four interleaved sub-sums, (s0 + s1) + (s2 + s3).  `stride` = floats between consecutive row blocks.
+__device__ __forceinline__ double lane_colsum(const float* __restrict__ p, int lane, int row_blocks, long stride) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int rb = lane;
+    for (; rb + 192 < row_blocks; rb += 256) {
+        const float v0 = p[(long)rb * stride], v1 = p[(long)(rb + 64) * stride], v2 = p[(long)(rb + 128) * stride],
+                    v3 = p[(long)(rb + 192) * stride];
+        s0 += (double)v0;
+        s1 += (double)v1;
+        s2 += (double)v2;
+        s3 += (double)v3;
+    }
+    for (; rb < row_blocks; rb += 64) s0 += (double)p[(long)rb * stride];
+    return (s0 + s1) + (s2 + s3);
 }
 
-template <int NW>
-__device__ __forceinline__ void quad_colsum(const float* __restrict__ p, long which_stride, int j, int tpq, int row_blocks,
-                                            long stride, double (&tot)[NW][4], double (*sm)[4][4]) {
-    double acc[NW][4][4];
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[w][u][e] = 0.0;
-    int rb = j;
-    for (; rb + 3 * tpq < row_blocks; rb += 4 * tpq) {
-        float4 v[NW][4];
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                v[w][u] = *reinterpret_cast<const float4*>(p + w * which_stride + (long)(rb + u * tpq) * stride);
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc[w][u][0] += (double)v[w][u].x;
-                acc[w][u][1] += (double)v[w][u].y;
-                acc[w][u][2] += (double)v[w][u].z;
-                acc[w][u][3] += (double)v[w][u].w;
-            }
+// the same for the two sums of one channel at once (eight entries in flight); `q` = p + ld
+__device__ __forceinline__ void lane_colsum_pair(const float* __restrict__ p, int ld, int lane, int row_blocks, long stride,
+                                                 double& a1, double& a2) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    const float* q = p + ld;
+    int rb = lane;
+    for (; rb + 192 < row_blocks; rb += 256) {
+        const float v0 = p[(long)rb * stride], v1 = p[(long)(rb + 64) * stride], v2 = p[(long)(rb + 128) * stride],
+                    v3 = p[(long)(rb + 192) * stride];
+        const float w0 = q[(long)rb * stride], w1 = q[(long)(rb + 64) * stride], w2 = q[(long)(rb + 128) * stride],
+                    w3 = q[(long)(rb + 192) * stride];
+        s0 += (double)v0;
+        s1 += (double)v1;
+        s2 += (double)v2;
+        s3 += (double)v3;
+        t0 += (double)w0;
+        t1 += (double)w1;
+        t2 += (double)w2;
+        t3 += (double)w3;
     }
-    for (; rb < row_blocks; rb += tpq) {
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float4 v = *reinterpret_cast<const float4*>(p + w * which_stride + (long)rb * stride);
-            acc[w][0][0] += (double)v.x;
-            acc[w][0][1] += (double)v.y;
-            acc[w][0][2] += (double)v.z;
-            acc[w][0][3] += (double)v.w;
-        }
+    for (; rb < row_blocks; rb += 64) {
+        s0 += (double)p[(long)rb * stride];
+        t0 += (double)q[(long)rb * stride];
     }
-    const int in_wave = tpq < 64 ? tpq : 64;
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            double t = (acc[w][0][e] + acc[w][1][e]) + (acc[w][2][e] + acc[w][3][e]);
-            for (int m = in_wave >> 1; m > 0; m >>= 1) t += __shfl_xor(t, m);
-            tot[w][e] = t;
-        }
-    if (tpq == 256) {              // one group per block: the four waves' totals through LDS, in wave order
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        if (lane == 0) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sm[w][wave][e] = tot[w][e];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tot[w][e] = (sm[w][0][e] + sm[w][1][e]) + (sm[w][2][e] + sm[w][3][e]);
-    }
+    a1 = (s0 + s1) + (s2 + s3);
+    a2 = (t0 + t1) + (t2 + t3);
 }
 
-// sums[which][frame][c] = sum_rb partial[frame][rb][which][c], which < nwhich (1: first sum only)
+// one wavefront per output column: lanes stride over the row-block partials (fp64 accumulation), the 64 lane sums are
+// combined through LDS.  (A serial loop per column was 44 % of the step time in the first MI355X profile.)
 __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restrict__ partial, int row_blocks, int ld,
-                                                            int C, int frames, float* __restrict__ sums, int nwhich,
-                                                            int tpq) {
-    __shared__ double sm[1][4][4];
-    const int groups = 256 / tpq, g = threadIdx.x / tpq, j = threadIdx.x - g * tpq;
-    const int nq = (C + 3) >> 2, total = nwhich * frames * nq;
-    const int Q = blockIdx.x * groups + g;          // tpq == 256: block-uniform, so the barrier inside is reached by all
-    const bool live = Q < total;
-    const int Qc = live ? Q : 0;
-    const int which = Qc / (frames * nq), rem = Qc - which * frames * nq;
-    const int f = rem / nq, q = rem - f * nq;
-    double tot[1][4];
-    quad_colsum<1>(partial + (long)f * row_blocks * 2 * ld + (long)which * ld + q * 4, 0, j, tpq, live ? row_blocks : 0,
-                   2L * ld, tot, sm);
-    if (live && j == 0) {
-        float* o = sums + (long)which * frames * C + (long)f * C + q * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (q * 4 + e < C) o[e] = (float)tot[0][e];
+                                                            int C, int frames, float* __restrict__ sums, int nwhich) {
+    // sums[which][frame][c] = sum_rb partial[frame][rb][which][c], which < nwhich (1: first sum only)
+    __shared__ double sm[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    const int FC = frames * C;
+    double acc = 0.0;
+    if (i < nwhich * FC) {
+        const int which = i / FC, rem = i - which * FC;
+        const int f = rem / C, c = rem - f * C;
+        const float* pb = partial + (long)f * row_blocks * 2 * ld;
+        acc = lane_colsum(pb + (long)which * ld + c, lane, row_blocks, 2L * ld);
     }
-}
-
-static void launch_colsum2_final(hipStream_t s, const float* partial, int row_blocks, int ld, int C, int frames, float* sums,
-                                 int nwhich) {
-    const int tpq = second_stage_tpq(row_blocks);
-    const int quads = nwhich * frames * ceil_div(C, 4);
-    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(quads, 256 / tpq)), dim3(256), 0, s, partial, row_blocks, ld, C,
-                       frames, sums, nwhich, tpq);
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane < 8) {
+        double t = 0.0;
+        for (int j = 0; j < 8; ++j) t += sm[wave * 64 + lane * 8 + j];
+        sm[wave * 64 + lane * 8] = t;
+    }
+    __syncthreads();
+    if (lane == 0 && i < nwhich * FC) {
+        double t = 0.0;
+        for (int j = 0; j < 8; ++j) t += sm[wave * 64 + j * 8];
+        sums[i] = (float)t;
+    }
 }
 
 struct StatsLoader {
@@ -297,45 +270,58 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     }
 }
 
-// colsum2_final + bn_finalize in one launch (single-process BatchNorm: nothing sits between the two): a group of
-// threads per channel quad sums both statistics over the row-block partials in fp64 (quad_colsum<2>: the bits of
-// colsum2_final_kernel per sum) and its first thread derives mean / invstd / scale and the running-statistics update.
+// colsum2_final + bn_finalize in one launch (single-process BatchNorm: nothing sits between the two): one wavefront
+// per channel sums both statistics over the row-block partials in fp64 and lane 0 derives mean / invstd / scale and
+// the running-statistics update.
 __global__ void __launch_bounds__(256) bn_final_finalize_kernel(const float* __restrict__ partial, int row_blocks, int ld,
                                                                 int C, double count, const float* __restrict__ gamma,
                                                                 float* running_mean, float* running_var, float momentum,
                                                                 float eps, int update_running, float* sums, float* mean,
-                                                                float* invstd, float* scale, int tpq) {
-    __shared__ double sm[2][4][4];
-    const int groups = 256 / tpq, g = threadIdx.x / tpq, j = threadIdx.x - g * tpq;
-    const int nq = (C + 3) >> 2;
-    const int q = blockIdx.x * groups + g;
-    const bool live = q < nq;
-    double tot[2][4];
-    quad_colsum<2>(partial + (live ? q : 0) * 4, ld, j, tpq, live ? row_blocks : 0, 2L * ld, tot, sm);
-    if (live && j == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = q * 4 + e;
-            if (c >= C) break;
-            // the same arithmetic as colsum2_final_kernel -> bn_finalize_kernel (sums round-trip through fp32)
-            const float s1 = (float)tot[0][e], s2 = (float)tot[1][e];
-            if (sums) {
-                sums[c] = s1;
-                sums[C + c] = s2;
-            }
-            const double m = (double)s1 / count;
-            double v = (double)s2 / count - m * m;
-            if (v < 0.0) v = 0.0;
-            const float mf = (float)m, vf = (float)v;
-            const float is = 1.0f / sqrtf(vf + eps);
-            mean[c] = mf;
-            invstd[c] = is;
-            scale[c] = gamma[c] * is;
-            if (update_running) {
-                const float unbiased = (float)(v * count / (count - 1.0));
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-            }
+                                                                float* invstd, float* scale) {
+    __shared__ double sm[2][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wave;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        lane_colsum_pair(partial + c, ld, lane, row_blocks, 2L * ld, a1, a2);      // the bits of lane_colsum per sum
+    }
+    sm[0][threadIdx.x] = a1;
+    sm[1][threadIdx.x] = a2;
+    __syncthreads();
+    if (lane < 8) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int j = 0; j < 8; ++j) {
+            t1 += sm[0][wave * 64 + lane * 8 + j];
+            t2 += sm[1][wave * 64 + lane * 8 + j];
+        }
+        sm[0][wave * 64 + lane * 8] = t1;
+        sm[1][wave * 64 + lane * 8] = t2;
+    }
+    __syncthreads();
+    if (lane == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int j = 0; j < 8; ++j) {
+            t1 += sm[0][wave * 64 + j * 8];
+            t2 += sm[1][wave * 64 + j * 8];
+        }
+        // the same arithmetic as colsum2_final_kernel -> bn_finalize_kernel (sums round-trip through fp32)
+        const float s1 = (float)t1, s2 = (float)t2;
+        if (sums) {
+            sums[c] = s1;
+            sums[C + c] = s2;
+        }
+        const double m = (double)s1 / count;
+        double v = (double)s2 / count - m * m;
+        if (v < 0.0) v = 0.0;
+        const float mf = (float)m, vf = (float)v;
+        const float is = 1.0f / sqrtf(vf + eps);
+        mean[c] = mf;
+        invstd[c] = is;
+        scale[c] = gamma[c] * is;
+        if (update_running) {
+            const float unbiased = (float)(v * count / (count - 1.0));
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
         }
     }
 }
@@ -762,7 +748,8 @@ int mnk_norm_stats(const float* x, int ld, long rows_per_frame, int frames, int 
     StatsLoader L{x, ld};
     hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L,
                        rows_per_frame, ld / 4, ld, m.tx, m.ty, m.rows_per_block, ws);
-    launch_colsum2_final(s, ws, m.row_blocks, ld, C, frames, sums, 2);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ld, C,
+                       frames, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -821,7 +808,8 @@ int mnk_norm_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz,
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, per_frame ? C : 0, slope};
     hipLaunchKernelGGL(colsum2_partial_kernel<BwdLoader>, dim3(m.col_tiles, m.row_blocks, frames), dim3(256), 0, s, L, rows,
                        ldc / 4, ldc, m.tx, m.ty, m.rows_per_block, ws);
-    launch_colsum2_final(s, ws, m.row_blocks, ldc, C, frames, sums, 2);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * frames * C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C,
+                       frames, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -871,7 +859,7 @@ int mnk_bn_act_bwd_apply_add_colsum(const float* y, int ld_y, const float* dz, i
     BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, 0, relu ? 0.f : -1.f};
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, L, sums, count, training,
                        C, dy, ld_dy, rows, C, ldc / 4, m.tx, m.ty, m.rows_per_block, ws, addend, ld_add);
-    launch_colsum2_final(s, ws, m.row_blocks, ldc, C, 1, dy_sums, 1);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, ws, m.row_blocks, ldc, C, 1, dy_sums, 1);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -907,10 +895,8 @@ int mnk_bn_stats_finalize(const float* x, int ld, long rows, int C, const float*
         partial = ws;
         row_blocks = m.row_blocks;
     }
-    const int tpq = second_stage_tpq(row_blocks);
-    hipLaunchKernelGGL(bn_final_finalize_kernel, dim3(ceil_div(ceil_div(C, 4), 256 / tpq)), dim3(256), 0, s, partial, row_blocks,
-                       ld, C, count, gamma, running_mean, running_var, momentum, eps, update_running, sums, mean, invstd, scale,
-                       tpq);
+    hipLaunchKernelGGL(bn_final_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, count, gamma,
+                       running_mean, running_var, momentum, eps, update_running, sums, mean, invstd, scale);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -923,10 +909,10 @@ int mnk_bn_stats(const float* x, int ld, long rows, int C, float* sums, float* w
 }
 
 int mnk_bn_stats_finish(const float* partial, int row_blocks, int ld, int C, float* sums, void* stream) {
-    MNK_REQUIRE(partial && sums && row_blocks > 0 && C > 0 && ld >= C && ld % 4 == 0);
+    MNK_REQUIRE(partial && sums && row_blocks > 0 && C > 0 && ld >= C);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_STATS, s, (double)row_blocks * 2 * C * 4);
-    launch_colsum2_final(s, partial, row_blocks, ld, C, 1, sums, 2);
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, 1, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
