@@ -114,7 +114,9 @@ class TrainStep:
         lr = train_params['lr']
         self.use_graph = bool(use_graph)
         self.mnk_adam = knobs.on("MNK_HAND_ADAM") if fused_adam is None else bool(fused_adam)
-        self._graph = None
+        self._graph = None                    # the captured iteration: a list of hipGraphs and host calls between them
+        self._segment = None                  # (graph being captured, pool) while _capture runs
+        self._replaying = False               # inside step()'s replay of a captured iteration (host calls look at it)
         self._static_x = None
         self._static_out = None
         self._weights_touched = True          # packed weights must be (re)made before the next iteration
@@ -170,7 +172,12 @@ class TrainStep:
         self._weights_touched = False
         for k in self._static_x:
             self._static_x[k].copy_(x[k], non_blocking=True)
-        self._graph.replay()
+        self._replaying = True
+        try:
+            for piece in self._graph:         # one hipGraph, or linear hipGraphs with the gradient exchange's host calls between
+                piece.replay() if isinstance(piece, torch.cuda.CUDAGraph) else piece()
+        finally:
+            self._replaying = False
         mops.invalidate_packed_weights()      # the captured optimiser steps changed the parameters
         return self._static_out
 
@@ -189,12 +196,59 @@ class TrainStep:
             for _ in range(warmup):          # sizes the scratch buffers, warms MIOpen, creates Adam state
                 self._eager_step(self._static_x, set_to_none=True)
         torch.cuda.current_stream().wait_stream(side)
+        # The iteration is captured as LINEAR hipGraphs.  A captured graph with a second branch that holds a kernel replays
+        # 0.85-1.0 ms slower on this runtime, whatever the branch does (profiles/r03_knob_ab_log.txt), so the overlapped
+        # gradient exchange of several ranks is not a branch of one graph: _cut() ends the graph in front of it, the
+        # exchange is started / awaited by ordinary stream calls at replay time, and a new graph continues behind it.
+        import gc
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._static_out = self._eager_step(self._static_x, set_to_none=True)
-        self._graph = graph
+        gc.collect()
+        torch.cuda.empty_cache()
+        program = []
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(cap):
+                self._segment = [None, pool, program]
+                self._segment_begin()
+                self._static_out = self._eager_step(self._static_x, set_to_none=True)
+                if self._segment[0] is not None:
+                    self._segment_end()
+        except BaseException:
+            if self._segment[0] is not None:          # leave the stream out of capture mode, whatever went wrong
+                try:
+                    self._segment[0].capture_end()
+                except Exception:
+                    pass
+            raise
+        finally:
+            self._segment = None
+        torch.cuda.current_stream().wait_stream(cap)
+        self._graph = program
         self._restore(snap)
+
+    def _segment_begin(self):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._segment[1])
+        self._segment[0] = g
+
+    def _segment_end(self):
+        g, self._segment[0] = self._segment[0], None
+        g.capture_end()
+        self._segment[2].append(g)
+
+    def _cut(self, host_call, last=False):
+        """`host_call()` now -- and, when the iteration is being captured, between two hipGraphs at every replay (last: nothing
+        that launches follows in this iteration, no further graph is begun)."""
+        if self._segment is None:
+            host_call()
+            return
+        self._segment_end()
+        self._segment[2].append(host_call)
+        host_call()
+        if not last:
+            self._segment_begin()
 
     def _snapshot(self):
         """Everything the warm-up iterations of the capture change: parameters, buffers (BatchNorm running statistics),
@@ -319,9 +373,10 @@ class TrainStep:
                 self.opt_k.zero_grad()
 
         if overlap:
-            self.opt_g.begin_exchange()
-            if step_k_now:
-                self.opt_k.begin_exchange()
+            ex = [self.opt_g] + ([self.opt_k] if step_k_now else [])
+            for o in ex:
+                o.materialize_grads()                               # (captured) every gradient in its flat buffer
+            self._cut(lambda: [o.exchange_begin() for o in ex])    # (host call) the sums start on the communication stream
         else:
             step_generator_side()
         self.opt_d.zero_grad()
@@ -340,8 +395,6 @@ class TrainStep:
             back = [(kp_joined[k], kp_leaf[k].grad) for k in kp_names if kp_leaf[k].grad is not None]
             if back:
                 torch.autograd.backward([t for t, _ in back], [g for _, g in back], inputs=k_params)
-        if overlap:
-            step_generator_side()
         self.avg_d.average()
         self.opt_d.step()
         self.opt_d.zero_grad()
@@ -349,6 +402,19 @@ class TrainStep:
             self.avg_k.average()
             self.opt_k.step()
             self.opt_k.zero_grad()
+        if overlap:
+            # (host call, the LAST piece of a captured iteration: two hipGraphs, not three -- every further graph launch costs
+            # 0.35 ms) the kernels' stream waits for the sums, then the generator-side updates run as plain launches: at
+            # replay time from the optimisers' cached descriptor tables (tick + one Adam launch each)
+            def finish():
+                for o in ex:
+                    o.exchange_end()
+                if self._replaying:
+                    for o in ex:
+                        o.replay_step()
+                else:
+                    step_generator_side()
+            self._cut(finish, last=True)
         return [v.detach() for v in loss_values], [v.detach() for v in d_values], generated
 
     def _eager_step_two_pass(self, x, set_to_none=True):

@@ -254,6 +254,7 @@ class MnkAdam(torch.optim.Optimizer):
         self._keep = []
         self._mnk_fresh_entries = ()
         self._exchange = None            # a gradient exchange started by begin_exchange(), finished by step()
+        self._exchanged = False          # ... or already finished by exchange_end(): step() must not sum again
         for p in ps:
             mops.register_grad_sink(p, self)
         weakref.finalize(self, mops.unregister_grad_sinks, [id(p) for p in ps], id(self))
@@ -299,6 +300,7 @@ class MnkAdam(torch.optim.Optimizer):
             self._exchange = None
         for p in self._params:
             p.grad = None
+        self._exchanged = False
         self.reducer.drop()
         self._written.clear()
 
@@ -342,6 +344,28 @@ class MnkAdam(torch.optim.Optimizer):
         if self._exchange is None and mdist.grads_active() and any(p.grad is not None for p in self._params):
             self._exchange = mdist.all_reduce_flat_begin(self.flat_grad)
 
+    def exchange_begin(self):
+        """The bare start of the exchange (no look at the parameters: this is also what runs between two captured
+        hipGraphs at replay time, when no Python-side gradient state exists); exchange_end() is its other half."""
+        if mdist.grads_active():
+            self._exchange = mdist.all_reduce_flat_begin(self.flat_grad)
+
+    def exchange_end(self):
+        if self._exchange is not None:
+            mdist.all_reduce_flat_end(self._exchange)
+            self._exchange = None
+            self._exchanged = True            # the next step() finds the sums in place
+
+    def replay_step(self):
+        """The launches of the last step() again, from its descriptor table: the update of a captured iteration whose
+        optimiser step is NOT part of a hipGraph (mnk.engine.TrainStep with an overlapped exchange)."""
+        if self._table is None:
+            raise RuntimeError("replay_step() before any step()")
+        _, tab, n, blocks, entries = self._table
+        mops._call("mnk_adam_tick", self.hyper, mops._p(self.hyper))
+        mops._call("mnk_adam_multi", self.hyper, mops._p(tab), n, blocks, mops._p(self.hyper))
+        self.steps_taken += 1
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
@@ -354,6 +378,8 @@ class MnkAdam(torch.optim.Optimizer):
         if self._exchange is not None:
             mdist.all_reduce_flat_end(self._exchange)
             self._exchange = None
+        elif self._exchanged:
+            pass
         elif mdist.grads_active():
             mdist.all_reduce_flat_(self.flat_grad)          # sum over ranks; the mean is folded into the update
         if not _capturing(self.device):
