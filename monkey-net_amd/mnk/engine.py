@@ -362,7 +362,9 @@ class TrainStep:
         # (step 3 runs on the retained discriminator graph with the generated frames as leaves: it reads neither the
         # generator's weights nor its update) -- 265-379 MB per iteration leave the critical path.  Same arithmetic, same
         # order of the three updates' inputs; MNK_GRAD_OVERLAP=0 keeps the in-order exchange.
-        overlap = self.mnk_adam and mdist.grads_active() and knobs.on("MNK_GRAD_OVERLAP")
+        # (one rank of a forced process group has nothing to hide: in-order unless MNK_GRAD_OVERLAP=force, the GPU test's setting)
+        ov = knobs.get("MNK_GRAD_OVERLAP")
+        overlap = self.mnk_adam and mdist.grads_active() and (ov == "force" or (ov != "0" and mdist.world_size() > 1))
         step_k_now = tp['detach_kp_discriminator']
 
         def step_generator_side():

@@ -37,7 +37,9 @@ KNOBS = {
     "MNK_TUNING": ("", "name=value,... for the library's tuning values (read by the library itself; A/B visits)"),
     "MNK_CLIP_VARIANCE_MODE": ("stable", "sigma_min of clip_variance: stable = |det| / sigma_max (finite on nearly singular "
                                          "covariances); reference = the reference's own fp32 sqrt((s1 - s2) / 2), NaNs included"),
-    "MNK_GRAD_OVERLAP": ("1", "launch a gradient bucket's all-reduce as soon as its last gradient is written"),
+    "MNK_GRAD_OVERLAP": ("1", "MnkAdam: the generator-side gradient exchange runs next to the discriminator backward when there is "
+                              "more than one rank (force: also on one rank); GradAverager: a bucket's all-reduce starts when its "
+                              "last gradient is written; 0: in-order exchanges"),
     "MNK_SKIP_GRAD_FUSED": ("1", "hourglass levels: the next down block's data-gradient GEMM adds the gradient of the level's other "
                                  "consumer (decoder skip / warp) in its epilogue (0: autograd accumulates the two gradients)"),
     "MNK_RES_SKIP_FUSED": ("1", "residual blocks: the first norm layer's backward adds the skip gradient in its dy pass (0: autograd "

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_captured_iteration_with_overlapped_exchange_equals_eager():
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MNK_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MNK_DIST_FORCE="1", MNK_GRAD_OVERLAP="force", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(here, "dist_graph_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
