@@ -505,6 +505,13 @@ int mnk_l1_mean_bwd(const float* a, const float* b, long n, int B, float weight,
 int mnk_gan_terms_fwd(const float* score, int n, int B, float w_gen, float w_disc, float* gen, float* disc, void* stream);
 int mnk_gan_terms_bwd(const float* score, int n, int B, float w_gen, float w_disc, const float* ggen, const float* gdisc,
                       float* dscore, void* stream);
+/* batch means of the per-sample loss vectors and their sum in one launch (train.py:114 `[val.mean() for val in losses]`,
+ * :116 `sum(loss_values)`): `vecs` = HOST array of nvec <= 16 device pointers to `len` floats each;
+ * means[i] = mean_j vecs[i][j] for i < nvec, means[nvec] = means[0] + ... + means[nvec - 1] (added in this order).
+ * backward: gvecs[i][j] = (gmeans[i] + gtotal[0]) / len for the upstream gradients of the means (nvec floats) and of the
+ * sum (one float); either may be NULL = zero. */
+int mnk_vec_means_fwd(const float* const* vecs, int nvec, int len, float* means, void* stream);
+int mnk_vec_means_bwd(const float* gmeans, const float* gtotal, int nvec, int len, float* gvecs, void* stream);
 
 /* ---- device-side input path ------------------------------------------------------------------
  * Replaces, for the integer-exact transforms, what the reference does on the host per sample inside 4 DataLoader workers

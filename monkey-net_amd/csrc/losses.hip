@@ -133,9 +133,69 @@ __global__ void __launch_bounds__(256) gan_terms_bwd_kernel(const float* __restr
     }
 }
 
+// ---- batch means of the loss vectors (train.py:114 `[val.mean() for val in losses]` and their sum) -----------------------
+constexpr int MAX_LOSS_VECS = 16;
+struct LossVecs {
+    const float* v[MAX_LOSS_VECS];
+};
+
+// one wavefront per vector: means[i] = mean_j v[i][j]; thread 0 then adds the means in order -> means[nvec]
+__global__ void __launch_bounds__(64 * MAX_LOSS_VECS) vec_means_fwd_kernel(LossVecs vecs, int nvec, int len,
+                                                                          float* __restrict__ means) {
+    __shared__ float sm[MAX_LOSS_VECS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < nvec) {
+        const float* v = vecs.v[wave];
+        float a = 0.f;
+        for (int j = lane; j < len; j += 64) a += v[j];
+        a = wave_sum(a);
+        if (lane == 0) {
+            const float m = a / (float)len;
+            sm[wave] = m;
+            means[wave] = m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < nvec; ++i) t += sm[i];
+        means[nvec] = t;
+    }
+}
+
+// gvecs[i][j] = (gmeans[i] + gtotal[0]) / len   (either upstream gradient may be NULL = zero)
+__global__ void __launch_bounds__(256) vec_means_bwd_kernel(const float* __restrict__ gmeans, const float* __restrict__ gtotal,
+                                                            int nvec, int len, float* __restrict__ gvecs) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nvec * len) return;
+    const int i = q / len;
+    gvecs[q] = ((gmeans ? gmeans[i] : 0.f) + (gtotal ? gtotal[0] : 0.f)) / (float)len;
+}
+
 }  // namespace
 
 extern "C" {
+
+int mnk_vec_means_fwd(const float* const* vecs, int nvec, int len, float* means, void* stream) {
+    MNK_REQUIRE(vecs && means && nvec > 0 && nvec <= MAX_LOSS_VECS && len > 0);
+    LossVecs lv;
+    for (int i = 0; i < MAX_LOSS_VECS; ++i) lv.v[i] = i < nvec ? vecs[i] : nullptr;
+    for (int i = 0; i < nvec; ++i) MNK_REQUIRE(lv.v[i]);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LOSS, s, (double)nvec * len * 4);
+    hipLaunchKernelGGL(vec_means_fwd_kernel, dim3(1), dim3(64 * nvec), 0, s, lv, nvec, len, means);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_vec_means_bwd(const float* gmeans, const float* gtotal, int nvec, int len, float* gvecs, void* stream) {
+    MNK_REQUIRE((gmeans || gtotal) && gvecs && nvec > 0 && nvec <= MAX_LOSS_VECS && len > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LOSS, s, (double)nvec * len * 4);
+    hipLaunchKernelGGL(vec_means_bwd_kernel, dim3(ceil_div(nvec * len, 256)), dim3(256), 0, s, gmeans, gtotal, nvec, len, gvecs);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
 
 int mnk_pair_l1_fwd(const float* a, int ld, long rows, int C, int B, float weight, float* out, void* stream) {
     MNK_REQUIRE(a && out && ld > 0 && ld % 4 == 0 && rows > 0 && C > 0 && C <= ld && B > 0);

@@ -22,6 +22,21 @@ def split_kp(kp_joined, detach=False):
     return out
 
 
+def joined_kp(kp_detector, x):
+    """The key points of [source frame | driving frames] per video (train.py:27 calls the detector on
+    torch.cat([source, video], dim=2)).  The detector works per frame, so for one driving frame per video -- every training
+    iteration -- it is called on the frames stacked along the BATCH axis instead, and the (2B,1,...) result is viewed as
+    (B,2,...): source and driving key points are then two contiguous halves of one buffer, and the split views that every
+    consumer asks `.contiguous()` of (two embeddings in the generator, one in the discriminator, the motion field) cost no
+    copy launches.  Same frames, same batch statistics (the sums run over the frames in a different order)."""
+    src, vid = x['source'], x['video']
+    if vid.shape[2] != 1 or src.shape[2] != 1:
+        return kp_detector(torch.cat([src, vid], dim=2))
+    b = src.shape[0]
+    kp = kp_detector(torch.cat([src, vid], dim=0))
+    return {k: v.view(2, b, *v.shape[2:]).transpose(0, 1) for k, v in kp.items()}
+
+
 def discriminate_pair(discriminator, fake, real, kp_dict):
     """(D(fake, kp), D(real, kp)) -- train.py:43-45,66-68 call the discriminator twice with the same key-points.
     Every layer of it works per sample (convolutions, InstanceNorm, LeakyReLU, pooling; no batch statistics), so the
@@ -70,7 +85,7 @@ class GeneratorFullModel(torch.nn.Module):
         self.train_params = train_params
 
     def forward(self, x):
-        kp_joined = self.kp_extractor(torch.cat([x['source'], x['video']], dim=2))
+        kp_joined = joined_kp(self.kp_extractor, x)
         generated = self.generator(x['source'], **split_kp(kp_joined, self.train_params['detach_kp_generator']))
         kp_dict = split_kp(kp_joined, False)
         maps_generated, maps_real = discriminate_pair(self.discriminator, generated['video_prediction'], x['video'],
@@ -116,6 +131,7 @@ class TrainStep:
         self.mnk_adam = knobs.on("MNK_HAND_ADAM") if fused_adam is None else bool(fused_adam)
         self._graph = None                    # the captured iteration: a list of hipGraphs and host calls between them
         self._segment = None                  # (graph being captured, pool) while _capture runs
+        self._ones = {}
         self._replaying = False               # inside step()'s replay of a captured iteration (host calls look at it)
         self._static_x = None
         self._static_out = None
@@ -141,6 +157,12 @@ class TrainStep:
                                 list(generator.parameters()) + list(kp_detector.parameters()))
         self.avg_d = _Averager(self, (self.opt_d,), list(discriminator.parameters()))
         self.avg_k = _Averager(self, (self.opt_k,), list(kp_detector.parameters()))
+
+    def _one(self, like):
+        t = self._ones.get(like.device)
+        if t is None:
+            t = self._ones[like.device] = torch.ones((), dtype=torch.float32, device=like.device)
+        return t
 
     def weights_changed(self):
         """Parameters were written from outside (load_state_dict does this by itself): the packed GEMM layouts are
@@ -313,7 +335,7 @@ class TrainStep:
         g_params = list(self.generator.parameters())
         k_params = list(self.kp_detector.parameters())
         d_params = list(self.discriminator.parameters())
-        kp_joined = self.kp_detector(torch.cat([x['source'], x['video']], dim=2))
+        kp_joined = joined_kp(self.kp_detector, x)
         generated = self.generator(x['source'], **split_kp(kp_joined, tp['detach_kp_generator']))
         fake = generated['video_prediction']
         fake_leaf = fake.detach().requires_grad_(True)
@@ -324,10 +346,10 @@ class TrainStep:
             g_vec, d_vec = fused_pair_losses(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False),
                                              generated['video_deformed'], tp['loss_weights'])
             generated.update(split_kp(kp_joined, False))
-            # batch means of all terms in one reduction (the reference: [val.mean() for val in losses], train.py:114)
-            g_means, d_means = torch.stack(g_vec).mean(1), torch.stack(d_vec).mean(1)
+            # batch means of all terms and their sum in one launch (the reference: [val.mean() for val in losses], train.py:114)
+            g_means, g_total_fused = mops.LossMeansFn.apply(*g_vec)
+            d_means, d_total_fused = mops.LossMeansFn.apply(*d_vec)
             loss_values, d_values = list(g_means.unbind(0)), list(d_means.unbind(0))
-            g_total_fused, d_total_fused = g_means.sum(), d_means.sum()
         else:
             g_total_fused = d_total_fused = None
             maps_generated, maps_real = discriminate_pair(self.discriminator, fake_leaf, x['video'],
@@ -342,8 +364,9 @@ class TrainStep:
         g_total = g_total_fused if g_total_fused is not None else sum(loss_values)
         # 1. through the discriminator only
         leaves = [fake_leaf] + [kp_leaf[k] for k in kp_names]
+        one = self._one(g_total)                  # the root gradient, made once (autograd's default: a fill launch per call)
         with mops.no_param_grads():
-            seeds = torch.autograd.grad(g_total, leaves, retain_graph=True, allow_unused=True)
+            seeds = torch.autograd.grad(g_total, leaves, grad_outputs=one, retain_graph=True, allow_unused=True)
         # 2. generator + key-point detector, one traversal
         roots, root_grads = [], []
         for t, g in zip([fake] + [kp_joined[k] for k in kp_names], seeds):
@@ -352,7 +375,7 @@ class TrainStep:
                 root_grads.append(g)
         if tp['loss_weights']['reconstruction_deformed'] != 0:      # the only term of L_G that does not pass the cut
             roots.append(g_total)
-            root_grads.append(None)
+            root_grads.append(one)
         self.avg_gk.arm()
         torch.autograd.backward(roots, root_grads, inputs=g_params + k_params,
                                 retain_graph=not tp['detach_kp_discriminator'])
@@ -387,13 +410,13 @@ class TrainStep:
         d_total = d_total_fused if d_total_fused is not None else sum(d_values)
         if tp['detach_kp_discriminator']:
             with mops.no_leaf_input_grads():     # nothing below the discriminator's first convolution is asked for
-                torch.autograd.backward(d_total, inputs=d_params)
+                torch.autograd.backward(d_total, one, inputs=d_params)
         else:
             self.avg_k.arm()
             kl = [kp_leaf[k] for k in kp_names]
             for t in kl:
                 t.grad = None
-            torch.autograd.backward(d_total, inputs=d_params + kl)
+            torch.autograd.backward(d_total, one, inputs=d_params + kl)
             back = [(kp_joined[k], kp_leaf[k].grad) for k in kp_names if kp_leaf[k].grad is not None]
             if back:
                 torch.autograd.backward([t for t, _ in back], [g for _, g in back], inputs=k_params)

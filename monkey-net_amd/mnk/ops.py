@@ -973,6 +973,37 @@ class GanTermsFn(torch.autograd.Function):
         return ds, None, None, None
 
 
+class LossMeansFn(torch.autograd.Function):
+    """[v.mean() for v in vecs] and the sum of these means (train.py:114,116) for per-sample loss vectors of one length:
+    (means (n,), total ()).  One launch each way instead of stack / mean / sum and their expand / div backward passes."""
+
+    @staticmethod
+    def forward(ctx, *vecs):
+        import numpy as np
+        ref = vecs[0]
+        _check_device(ref)
+        vecs = [v.contiguous().float() for v in vecs]
+        n, ln = len(vecs), vecs[0].numel()
+        assert all(v.numel() == ln for v in vecs)
+        out = torch.empty(n + 1, dtype=torch.float32, device=ref.device)
+        ptrs = np.array([v.data_ptr() for v in vecs], dtype=np.uint64)
+        _call("mnk_vec_means_fwd", ref, ptrs.ctypes.data, n, ln, _p(out))
+        ctx.meta = (n, ln, [v.shape for v in vecs])
+        ctx.set_materialize_grads(False)
+        return out[:n], out[n]
+
+    @staticmethod
+    def backward(ctx, gmeans, gtotal):
+        n, ln, shapes = ctx.meta
+        if gmeans is None and gtotal is None:
+            return (None,) * n
+        ref = gmeans if gmeans is not None else gtotal
+        gv = torch.empty(n, ln, dtype=torch.float32, device=ref.device)
+        _call("mnk_vec_means_bwd", ref, _p(gmeans.contiguous()) if gmeans is not None else None,
+              _p(gtotal.contiguous()) if gtotal is not None else None, n, ln, _p(gv))
+        return tuple(g.view(shp) for g, shp in zip(gv.unbind(0), shapes))
+
+
 class GConv1x1Fn(torch.autograd.Function):
     """nn.Conv3d(kernel (1,1,1), groups=num_kp+1) of SameBlock3D (dense_motion_module.py:24-28)."""
 

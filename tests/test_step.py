@@ -120,7 +120,9 @@ def _compare_step_forms(be, monkeypatch, rec_def, detach_d, detach_g, base, othe
 
     l2, grads2, final2 = run(base, fused[0])
     l1, grads1, final1 = run(other, fused[1])
-    assert max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(l1, l2)) < 1e-6, (l1, l2)
+    # (the shared form stacks source and driving frames along the batch axis for the detector and takes the batch means in
+    # one kernel: the same sums in another order -- an ulp or two of a loss value)
+    assert max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(l1, l2)) < 4e-6, (l1, l2)
     if iters > 1:
         # Adam's first updates are sign-like (|dp| = lr whatever the gradient's size): parameters of the two runs may
         # differ by a few lr where a gradient element is rounding noise -- bounded, not compared bit for bit
