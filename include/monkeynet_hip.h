@@ -473,6 +473,14 @@ int mnk_motion_field_fwd(const float* pred, int ld, const float* delta, int N, i
 int mnk_motion_field_bwd(const float* pred, int ld, const float* delta, const float* dfield, int N, int h, int w,
                          int K, int use_mask, int use_correction, float* dpred, int ld_d, float* ddelta,
                          void* stream);
+/* the same with delta taken from the key points inside the kernels (mask form): mean_s / mean_d [N][K][2] = kp_source.mean /
+ * kp_driving.mean of the frame (dense_motion_module.py:52-54: the difference, the zero background slot and their backward
+ * passes as no launches of their own); dmean_s = +sum_p m_k dfield, dmean_d = -dmean_s */
+int mnk_motion_field_kp_fwd(const float* pred, int ld, const float* mean_s, const float* mean_d, int N, int h, int w, int K,
+                            int use_correction, float* field, void* stream);
+int mnk_motion_field_kp_bwd(const float* pred, int ld, const float* mean_s, const float* mean_d, const float* dfield, int N, int h,
+                            int w, int K, int use_correction, float* dpred, int ld_d, float* dmean_s, float* dmean_d,
+                            void* stream);
 
 /* ---- bilinear warp (MotionTransferGenerator.deform_input, modules/generator.py:51-58) --------------------
  * out[n,y,x,off+c] = bilinear(inp[n], field'[n,y,x]) with zeros padding, align_corners=True (torch 0.4.1),
@@ -493,6 +501,10 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
 int mnk_pair_l1_fwd(const float* a, int ld, long rows, int C, int B, float weight, float* out, void* stream);
 int mnk_pair_l1_bwd(const float* a, int ld, long rows, int C, int B, float weight, const float* g, float* da,
                     void* stream);
+/* ... + addend ([2B][rows][ld], may be NULL): the gradient that reaches the same map through its other consumer (the next
+ * discriminator block), added in this pass instead of by an accumulation pass of its own */
+int mnk_pair_l1_bwd_add(const float* a, int ld, long rows, int C, int B, float weight, const float* g, const float* addend,
+                        float* da, void* stream);
 /* image-level term of the same loss (losses.py:8-12 on NCDHW frames: train.py:39-42 reconstruction_deformed, map 0 of
  * 'reconstruction'): out[i] = weight * mean_j |a[i][j] - b[i][j]| over n contiguous floats per sample; backward:
  * da = g[i] * weight / n * sign(a - b), db = -da (either may be NULL) */

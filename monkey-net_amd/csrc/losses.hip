@@ -46,7 +46,7 @@ __device__ __forceinline__ float sgn(float d) { return d > 0.f ? 1.f : (d < 0.f 
 // da[i] = g[i] * scale * sign(a[i] - a[B + i]) on channels < C (0 on pad channels), da[B + i] = -da[i]
 __global__ void __launch_bounds__(256) pair_l1_bwd_kernel(const float* __restrict__ a, int ld, long rows, int C, int B,
                                                           float scale, const float* __restrict__ g,
-                                                          float* __restrict__ da) {
+                                                          const float* __restrict__ addend, float* __restrict__ da) {
     const int nv = ld / 4;
     const long per = rows * nv, total = per * B;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
@@ -62,8 +62,14 @@ __global__ void __launch_bounds__(256) pair_l1_bwd_kernel(const float* __restric
         d.y = c + 1 < C ? k * sgn(u.y - v.y) : 0.f;
         d.z = c + 2 < C ? k * sgn(u.z - v.z) : 0.f;
         d.w = c + 3 < C ? k * sgn(u.w - v.w) : 0.f;
+        float4 e = make_float4(-d.x, -d.y, -d.z, -d.w);
+        if (addend) {            // the gradient of the map's other consumer (the next block), added here instead of by autograd
+            const float4 p = *reinterpret_cast<const float4*>(addend + oa), q2 = *reinterpret_cast<const float4*>(addend + ob);
+            d = make_float4(d.x + p.x, d.y + p.y, d.z + p.z, d.w + p.w);
+            e = make_float4(e.x + q2.x, e.y + q2.y, e.z + q2.z, e.w + q2.w);
+        }
         *reinterpret_cast<float4*>(da + oa) = d;
-        *reinterpret_cast<float4*>(da + ob) = make_float4(-d.x, -d.y, -d.z, -d.w);
+        *reinterpret_cast<float4*>(da + ob) = e;
     }
 }
 
@@ -208,20 +214,25 @@ int mnk_pair_l1_fwd(const float* a, int ld, long rows, int C, int B, float weigh
     return MNK_OK;
 }
 
-int mnk_pair_l1_bwd(const float* a, int ld, long rows, int C, int B, float weight, const float* g, float* da,
-                    void* stream) {
+int mnk_pair_l1_bwd_add(const float* a, int ld, long rows, int C, int B, float weight, const float* g, const float* addend,
+                        float* da, void* stream) {
     MNK_REQUIRE(a && g && da && ld > 0 && ld % 4 == 0 && rows > 0 && C > 0 && C <= ld && B > 0);
-    MNK_REQUIRE((size_t)a % 16 == 0 && (size_t)da % 16 == 0);
+    MNK_REQUIRE((size_t)a % 16 == 0 && (size_t)da % 16 == 0 && (size_t)addend % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(K_LAYOUT, s, 4.0 * B * rows * ld * 4);
+    ProfScope prof(K_LAYOUT, s, (addend ? 6.0 : 4.0) * B * rows * ld * 4);
     const long total = (long)B * rows * (ld / 4);
     int blocks = ceil_div(total, 256 * 4);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(pair_l1_bwd_kernel, dim3(blocks), dim3(256), 0, s, a, ld, rows, C, B,
-                       weight / (float)((double)rows * C), g, da);
+                       weight / (float)((double)rows * C), g, addend, da);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_pair_l1_bwd(const float* a, int ld, long rows, int C, int B, float weight, const float* g, float* da,
+                    void* stream) {
+    return mnk_pair_l1_bwd_add(a, ld, rows, C, B, weight, g, nullptr, da, stream);
 }
 
 int mnk_l1_mean_fwd(const float* a, const float* b, long n, int B, float weight, float* out, void* stream) {

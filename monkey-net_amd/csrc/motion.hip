@@ -463,8 +463,19 @@ __global__ void __launch_bounds__(256) conv1x1_rows_bwd_kernel(const float* __re
 }
 
 // ---- motion field ------------------------------------------------------------------------------------------------
+// delta[n][k][c] either stored (slot 0 = background = 0) or taken from the key points: kp_s.mean - kp_d.mean ([N][K][2] each)
+struct DeltaSrc {
+    const float *delta, *kp_s, *kp_d;
+    __device__ __forceinline__ float operator()(long n, int S, int k, int c) const {
+        if (delta) return delta[(n * S + k) * 2 + c];
+        if (k == 0) return 0.f;
+        const long o = (n * (S - 1) + (k - 1)) * 2 + c;
+        return kp_s[o] - kp_d[o];
+    }
+};
+
 __global__ void __launch_bounds__(256) motion_field_fwd_kernel(const float* __restrict__ pred, int ld,
-                                                               const float* __restrict__ delta, int N, int h, int w,
+                                                               DeltaSrc delta, int N, int h, int w,
                                                                int K, int use_mask, int use_corr,
                                                                float* __restrict__ field) {
     const long P = (long)h * w;
@@ -482,8 +493,8 @@ __global__ void __launch_bounds__(256) motion_field_fwd_kernel(const float* __re
             for (int k = 0; k < S; ++k) den += expf(pr[k] - mx);
             for (int k = 0; k < S; ++k) {
                 const float m = expf(pr[k] - mx) / den;
-                fx += delta[(n * S + k) * 2] * m;
-                fy += delta[(n * S + k) * 2 + 1] * m;
+                fx += delta(n, S, k, 0) * m;
+                fy += delta(n, S, k, 1) * m;
             }
         }
         if (use_corr) {
@@ -500,11 +511,13 @@ __global__ void __launch_bounds__(256) motion_field_fwd_kernel(const float* __re
 // one block per frame (the mask's delta gradient is a per-frame sum): 1024 threads, because a batch is only 32 blocks and a
 // pixel costs S exponentials (256 threads, three exponentials per slot: 40 us)
 constexpr int MF_THREADS = 1024;
+// (dkp_s / dkp_d given: the gradient goes to the key points instead, [N][K][2] each: +sum and -sum of slots 1..K)
 __global__ void __launch_bounds__(MF_THREADS) motion_field_bwd_kernel(const float* __restrict__ pred, int ld,
-                                                                      const float* __restrict__ delta,
+                                                                      DeltaSrc delta,
                                                                       const float* __restrict__ dfield, int h, int w, int K,
                                                                       int use_mask, int use_corr, float* __restrict__ dpred,
-                                                                      int ld_d, float* __restrict__ ddelta) {
+                                                                      int ld_d, float* __restrict__ ddelta,
+                                                                      float* __restrict__ dkp_s, float* __restrict__ dkp_d) {
     __shared__ float red[(MF_THREADS / 64) * 2 * MAXS];
     const int n = blockIdx.x;
     const int P = h * w, S = K + 1;
@@ -538,13 +551,13 @@ __global__ void __launch_bounds__(MF_THREADS) motion_field_bwd_kernel(const floa
             for (int k = 0; k < MAXS; ++k)
                 if (k < S) {
                     const float m = e[k] / den;
-                    dot += m * (delta[((long)n * S + k) * 2] * gx + delta[((long)n * S + k) * 2 + 1] * gy);
+                    dot += m * (delta(n, S, k, 0) * gx + delta(n, S, k, 1) * gy);
                 }
 #pragma unroll
             for (int k = 0; k < MAXS; ++k)
                 if (k < S) {
                     const float m = e[k] / den;
-                    const float dm = delta[((long)n * S + k) * 2] * gx + delta[((long)n * S + k) * 2 + 1] * gy;
+                    const float dm = delta(n, S, k, 0) * gx + delta(n, S, k, 1) * gy;
                     dp[k] = m * (dm - dot);
                     dd[2 * k] += m * gx;
                     dd[2 * k + 1] += m * gy;
@@ -571,9 +584,13 @@ __global__ void __launch_bounds__(MF_THREADS) motion_field_bwd_kernel(const floa
             const int k = threadIdx.x;
             float s = 0.f;
             for (int wv = 0; wv < MF_THREADS / 64; ++wv) s += red[wv * 2 * MAXS + k];
-            ddelta[(long)n * S * 2 + k] = s;
+            if (ddelta) ddelta[(long)n * S * 2 + k] = s;
+            if (dkp_s && k >= 2) {
+                dkp_s[(long)n * K * 2 + k - 2] = s;
+                dkp_d[(long)n * K * 2 + k - 2] = -s;
+            }
         }
-    } else if (threadIdx.x < 2 * S) {
+    } else if (threadIdx.x < 2 * S && ddelta) {
         ddelta[(long)n * S * 2 + threadIdx.x] = 0.f;
     }
 }
@@ -937,8 +954,21 @@ int mnk_motion_field_fwd(const float* pred, int ld, const float* delta, int N, i
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)N * h * w;
     ProfScope prof(K_FIELD, s, (double)total * (ld + 2) * 4);
-    hipLaunchKernelGGL(motion_field_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, pred, ld, delta, N, h, w, K,
-                       use_mask, use_correction, field);
+    hipLaunchKernelGGL(motion_field_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, pred, ld, DeltaSrc{delta, nullptr, nullptr},
+                       N, h, w, K, use_mask, use_correction, field);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_motion_field_kp_fwd(const float* pred, int ld, const float* mean_s, const float* mean_d, int N, int h, int w, int K,
+                            int use_correction, float* field, void* stream) {
+    MNK_REQUIRE(pred && field && mean_s && mean_d && N > 0 && h > 1 && w > 1 && K >= 1 && K + 1 <= MAXS);
+    MNK_REQUIRE(ld >= K + 1 + 2 * (use_correction ? 1 : 0));
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * h * w;
+    ProfScope prof(K_FIELD, s, (double)total * (ld + 2) * 4);
+    hipLaunchKernelGGL(motion_field_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, pred, ld, DeltaSrc{nullptr, mean_s, mean_d},
+                       N, h, w, K, 1, use_correction, field);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -951,8 +981,22 @@ int mnk_motion_field_bwd(const float* pred, int ld, const float* delta, const fl
     MNK_REQUIRE(ld >= (K + 1) * (use_mask ? 1 : 0) + 2 * (use_correction ? 1 : 0) && ld_d >= ld - 3);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_FIELD, s, (double)N * h * w * (ld + ld_d + 2) * 4);
-    hipLaunchKernelGGL(motion_field_bwd_kernel, dim3(N), dim3(MF_THREADS), 0, s, pred, ld, delta, dfield, h, w, K, use_mask,
-                       use_correction, dpred, ld_d, ddelta);
+    hipLaunchKernelGGL(motion_field_bwd_kernel, dim3(N), dim3(MF_THREADS), 0, s, pred, ld, DeltaSrc{delta, nullptr, nullptr}, dfield,
+                       h, w, K, use_mask, use_correction, dpred, ld_d, ddelta, (float*)nullptr, (float*)nullptr);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_motion_field_kp_bwd(const float* pred, int ld, const float* mean_s, const float* mean_d, const float* dfield, int N, int h,
+                            int w, int K, int use_correction, float* dpred, int ld_d, float* dmean_s, float* dmean_d,
+                            void* stream) {
+    MNK_REQUIRE(pred && dfield && dpred && mean_s && mean_d && dmean_s && dmean_d && N > 0 && h > 1 && w > 1 && K >= 1 &&
+                K + 1 <= MAXS);
+    MNK_REQUIRE(ld >= K + 1 + 2 * (use_correction ? 1 : 0) && ld_d >= ld - 3);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_FIELD, s, (double)N * h * w * (ld + ld_d + 2) * 4);
+    hipLaunchKernelGGL(motion_field_bwd_kernel, dim3(N), dim3(MF_THREADS), 0, s, pred, ld, DeltaSrc{nullptr, mean_s, mean_d}, dfield,
+                       h, w, K, 1, use_correction, dpred, ld_d, (float*)nullptr, dmean_s, dmean_d);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

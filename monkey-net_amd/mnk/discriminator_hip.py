@@ -65,20 +65,27 @@ class Discriminator(nn.Module):
         self.scale_factor = scale_factor
         self.num_channels = num_channels
 
-    def forward_acts(self, x, kp_driving, kp_source):
+    def forward_acts(self, x, kp_driving, kp_source, tap=None):
         """The same pass with the block outputs left in the kernels' NHWC form: ([(act, channels), ...] per down block,
-        score (B,1,1,h,w)) -- for callers that reduce the feature maps on the device (mnk.engine, PairL1Fn)."""
+        score (B,1,1,h,w)) -- for callers that reduce the feature maps on the device (mnk.engine, PairL1Fn).  x may hold
+        twice as many samples as the key points ([generated | real] of the same videos): both halves get the same embedding.
+        tap(i, act, channels) -> act: called on every block output; the next block continues on what it returns."""
         b, _, d = x.shape[:3]
         if d != 1:
             raise NotImplementedError("one frame per sample (train.py:43-44,69-70)")
         step = ops.step_from_scale(self.scale_factor)
         out, c = ops.to_act(x, step), self.num_channels
         if self.kp_embedding:
-            emb, ce = self.kp_embedding.forward_act(x, kp_driving, kp_source, pre_step=step)
-            out, c = ops.Concat2Fn.apply(out, c, emb, ce), c + ce
+            bk = kp_driving['mean'].shape[0]
+            if bk != b and (2 * bk != b or self.kp_embedding.use_deformed_source_image):
+                raise ValueError("key points of %d samples for %d frames" % (bk, b))
+            emb, ce = self.kp_embedding.forward_act(x[:bk], kp_driving, kp_source, pre_step=step)
+            out, c = (ops.Concat2Fn if bk == b else ops.Concat2PairFn).apply(out, c, emb, ce), c + ce
         acts = []
         for i, down_block in enumerate(self.down_blocks):
             out, c = down_block.forward_act(out, c, leaf_input=(i == 0))
+            if tap is not None:
+                out = tap(i, out, c)
             acts.append((out, c))
         return acts, ops.Conv1x1SigmoidFn.apply(out, self.conv.weight, self.conv.bias, c, b, 0)
 

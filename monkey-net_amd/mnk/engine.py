@@ -56,19 +56,26 @@ def fused_pair_losses(discriminator, fake, real, kp_dict, video_deformed, loss_w
     instead of from NCDHW copies of every feature map.  Needs a discriminator with forward_acts (the gfx950-kernel
     one).  Returns (generator loss vectors in generator_loss's order, discriminator loss vectors)."""
     b = fake.shape[0]
-    kp2 = {name: {k: torch.cat([v, v], dim=0) for k, v in kp.items()} for name, kp in kp_dict.items()}
-    acts, score = discriminator.forward_acts(torch.cat([fake, real], dim=0), **kp2)
+    emb = getattr(discriminator, "kp_embedding", None)
+    if emb is not None and getattr(emb, "use_deformed_source_image", False):      # (an embedding that reads the frames)
+        kp_dict = {name: {k: torch.cat([v, v], dim=0) for k, v in kp.items()} for name, kp in kp_dict.items()}
     w = loss_weights
+    rec = w['reconstruction'] if w['reconstruction'] != 0 else []
+    taps = {}
+
+    def tap(i, act, c):          # feature-matching term of block output i (map i + 1): taken where the map is made
+        if i + 1 < len(rec) and rec[i + 1] != 0:
+            act, taps[i + 1] = mops.PairL1TapFn.apply(act, c, b, float(rec[i + 1]))
+        return act
+
+    acts, score = discriminator.forward_acts(torch.cat([fake, real], dim=0), **kp_dict, tap=tap)
     g_values = []
     if w['reconstruction_deformed'] != 0:
         g_values.append(mops.L1MeanFn.apply(real, video_deformed, w['reconstruction_deformed']))
     if w['reconstruction'] != 0:
-        rec = w['reconstruction']
         if rec[0] != 0:                               # map 0 is the frame itself
             g_values.append(mops.L1MeanFn.apply(fake, real, rec[0]))
-        for i, (act, c) in enumerate(acts, start=1):
-            if i < len(rec) and rec[i] != 0:
-                g_values.append(mops.PairL1Fn.apply(act, c, b, float(rec[i])))
+        g_values.extend(taps[i] for i in sorted(taps))
     gen_gan, disc_gan = mops.GanTermsFn.apply(score, b, w['generator_gan'], w['discriminator_gan'])
     g_values.append(gen_gan)
     return g_values, [disc_gan]

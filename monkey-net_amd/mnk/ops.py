@@ -113,6 +113,42 @@ class FromActFn(torch.autograd.Function):
         return out, None, None
 
 
+class Concat2PairFn(torch.autograd.Function):
+    """Concat2Fn for the batched discriminator pass [generated | real] (mnk.engine.fused_pair_losses): `a` holds 2B frames, `b`
+    (the key-point embedding, the same for both halves) B frames: out[n] = [a[n] | b[n mod B]].  The reference's two calls
+    embed the same key points twice (train.py:43-45); here the embedding is made once, and its gradient is the sum of the two
+    halves -- no concatenated key-point tensors, none of their backward additions."""
+
+    @staticmethod
+    def forward(ctx, a, ca, b, cb):
+        n, h, w, _ = a.shape
+        assert b.shape[0] * 2 == n and b.shape[1:3] == a.shape[1:3]
+        whole = ca % 4 == 0 and b.shape[-1] == ceil4(cb)
+        out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)
+        rows = n * h * w
+        _call("mnk_copy_channels", a, _p(a), a.shape[-1], 0, _p(out), out.shape[-1], 0, ca, rows, 0)
+        for half in (out[:n // 2], out[n // 2:]):
+            _call("mnk_copy_channels", a, _p(b), b.shape[-1], 0, _p(half), out.shape[-1], ca, ceil4(cb) if whole else cb,
+                  rows // 2, 0)
+        ctx.meta = (ca, cb, a.shape[-1], b.shape[-1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ca, cb, lda, ldb = ctx.meta
+        g = g.contiguous()
+        n, h, w, ld = g.shape
+        rows = n * h * w
+        whole = ca % 4 == 0 and lda == ca and ldb == ceil4(cb) and ld == ca + ldb
+        alloc = torch.empty if whole else torch.zeros
+        ga = alloc(n, h, w, lda, dtype=torch.float32, device=g.device)
+        gb = alloc(n // 2, h, w, ldb, dtype=torch.float32, device=g.device)
+        _call("mnk_copy_channels", g, _p(g), ld, 0, _p(ga), lda, 0, ca, rows, 0)
+        for i, half in enumerate((g[:n // 2], g[n // 2:])):
+            _call("mnk_copy_channels", g, _p(half), ld, ca, _p(gb), ldb, 0, ldb if whole else cb, rows // 2, i)
+        return ga, None, gb, None
+
+
 class Concat2Fn(torch.autograd.Function):
     """torch.cat([a, b], dim=channel) on acts (modules/util.py:185 for the last decoder stage)."""
 
@@ -853,8 +889,7 @@ class InstNormActFn(torch.autograd.Function):
                   _p(invstd), _p(scale))
             bt = beta
         else:   # first block: no normalisation -> identity affine
-            mean = torch.zeros(c, dtype=torch.float32, device=dev)
-            invstd = torch.ones(c, dtype=torch.float32, device=dev)
+            mean, invstd = _identity_affine(c, dev)          # constants, made once per (channels, device)
             scale, bt = invstd, mean
         ho, wo = (h // 2, w // 2) if pool else (h, w)
         z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
@@ -887,6 +922,17 @@ class InstNormActFn(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None
 
 
+_IDENTITY_AFFINE = {}
+
+
+def _identity_affine(c, dev):
+    t = _IDENTITY_AFFINE.get((c, dev))
+    if t is None:
+        t = _IDENTITY_AFFINE[(c, dev)] = (torch.zeros(c, dtype=torch.float32, device=dev),
+                                          torch.ones(c, dtype=torch.float32, device=dev))
+    return t
+
+
 class PairL1Fn(torch.autograd.Function):
     """weight * mean_batch(|generated - real|) (modules/losses.py:8-12) of one discriminator feature map, read from the
     act of the batched pass [generated | real] (2B frames) -> tensor (B,).  One launch forward, one backward; the
@@ -911,6 +957,37 @@ class PairL1Fn(torch.autograd.Function):
         g = g.contiguous()
         da = torch.empty_like(act)
         _call("mnk_pair_l1_bwd", act, _p(act), ld, h * w, c, b, weight, _p(g), _p(da))
+        return da, None, None, None
+
+
+class PairL1TapFn(torch.autograd.Function):
+    """PairL1Fn as a tap on the discriminator's forward pass: (the map itself for the next block, the loss vector).  The map
+    then has ONE consumer in the autograd graph, and the gradient of the next block is added inside the L1 backward kernel
+    (autograd's own accumulation: one more pass over every feature map of the batched [generated | real] pass)."""
+
+    @staticmethod
+    def forward(ctx, act, c, b, weight):
+        _check_device(act)
+        n, h, w, ld = act.shape
+        assert n == 2 * b and act.is_contiguous()
+        out = torch.empty(b, dtype=torch.float32, device=act.device)
+        _call("mnk_pair_l1_fwd", act, _p(act), ld, h * w, c, b, float(weight), _p(out))
+        ctx.save_for_backward(act)
+        ctx.meta = (c, b, float(weight))
+        ctx.set_materialize_grads(False)
+        return act.view_as(act), out
+
+    @staticmethod
+    def backward(ctx, g_act, g):
+        if g is None:
+            return g_act, None, None, None
+        act, = ctx.saved_tensors
+        c, b, weight = ctx.meta
+        n, h, w, ld = act.shape
+        if g_act is not None:
+            g_act = g_act.contiguous()
+        da = torch.empty_like(act)
+        _call("mnk_pair_l1_bwd_add", act, _p(act), ld, h * w, c, b, weight, _p(g.contiguous()), _p(g_act), _p(da))
         return da, None, None, None
 
 
@@ -1216,6 +1293,36 @@ class MovementEmbeddingFn(torch.autograd.Function):
             if not use_heatmap:
                 g_var_d = g_var_s = None
         return None, g_mean_d, g_var_d, g_mean_s, g_var_s, None
+
+
+class MotionFieldKPFn(torch.autograd.Function):
+    """MotionFieldFn's mask form with kp_source.mean - kp_driving.mean formed inside the kernels (one driving frame per
+    video): no subtraction / concatenation / zero-slot launches, and the two key-point gradients come out of the backward
+    kernel.  mean_s, mean_d: (B,1,K,2)."""
+
+    @staticmethod
+    def forward(ctx, pred, mean_s, mean_d, k, use_corr):
+        _check_device(pred)
+        n, h, w, ld = pred.shape
+        ms, md = mean_s.contiguous().float(), mean_d.contiguous().float()
+        assert ms.numel() == n * k * 2 and md.numel() == n * k * 2
+        field = torch.empty(n, h, w, 2, dtype=torch.float32, device=pred.device)
+        _call("mnk_motion_field_kp_fwd", pred, _p(pred), ld, _p(ms), _p(md), n, h, w, k, int(use_corr), _p(field))
+        ctx.save_for_backward(pred, ms, md)
+        ctx.meta = (k, use_corr, mean_s.shape)
+        return field
+
+    @staticmethod
+    def backward(ctx, dfield):
+        pred, ms, md = ctx.saved_tensors
+        k, use_corr, shape = ctx.meta
+        n, h, w, ld = pred.shape
+        dfield = dfield.contiguous()
+        dpred = torch.empty_like(pred)
+        g = torch.empty(2, *shape, dtype=torch.float32, device=pred.device)
+        _call("mnk_motion_field_kp_bwd", pred, _p(pred), ld, _p(ms), _p(md), _p(dfield), n, h, w, k, int(use_corr), _p(dpred),
+              ld, _p(g[0]), _p(g[1]))
+        return dpred, g[0], g[1], None, None
 
 
 class MotionFieldFn(torch.autograd.Function):

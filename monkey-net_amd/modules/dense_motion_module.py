@@ -48,6 +48,9 @@ class DenseMotionModule(nn.Module):
             pred, c = block.forward_act(pred, c)     # the reference's extra leaky_relu(0.2) after ReLU is the identity
         pred, c = self.hourglass.forward_act(pred, c)
         delta = None
+        if self.use_mask and kp_driving['mean'].shape[1] == 1 and kp_source['mean'].shape == kp_driving['mean'].shape:
+            # one driving frame per video: the key-point difference is formed inside the kernels
+            return ops.MotionFieldKPFn.apply(pred, kp_source['mean'], kp_driving['mean'], self.num_kp, bool(self.use_correction))
         if self.use_mask:
             diff = kp_source['mean'] - kp_driving['mean']                       # (B,d,K,2)
             d = diff.shape[1]

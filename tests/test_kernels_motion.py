@@ -109,6 +109,31 @@ def test_motion_field(be, use_mask, use_corr):
         assert relerr(DD.cpu(), dd.grad) < 1e-5
 
 
+@pytest.mark.parametrize("use_corr", [0, 1])
+def test_motion_field_from_key_points_equals_the_delta_form(be, use_corr):
+    """mnk_motion_field_kp_*: kp_source.mean - kp_driving.mean formed inside the kernels (dense_motion_module.py:52-54) -- the
+    field and d pred of the delta form to the bit, the two key-point gradients +- its d delta."""
+    g = torch.Generator().manual_seed(4)
+    n, h, w, K = 3, 6, 9, 4
+    cpred = K + 1 + 2 * use_corr
+    ld = ceil4(cpred)
+    pred = torch.randn(n, cpred, h, w, generator=g) * 2
+    ms, md = torch.rand(n, K, 2, generator=g) * 2 - 1, torch.rand(n, K, 2, generator=g) * 2 - 1
+    delta = torch.cat([torch.zeros(n, 1, 2), ms - md], dim=1)
+    df = torch.randn(n, h, w, 2, generator=g)
+    PR = be.t(to_nhwc(pred))
+    F1, F2 = be.empty(n, h, w, 2), be.empty(n, h, w, 2)
+    be.call("mnk_motion_field_fwd", PR, ld, be.t(delta), n, h, w, K, 1, use_corr, F1)
+    be.call("mnk_motion_field_kp_fwd", PR, ld, be.t(ms), be.t(md), n, h, w, K, use_corr, F2)
+    DP1, DP2, DD = be.empty(n, h, w, ld), be.empty(n, h, w, ld), be.empty(n, K + 1, 2)
+    GS, GD = be.empty(n, K, 2), be.empty(n, K, 2)
+    be.call("mnk_motion_field_bwd", PR, ld, be.t(delta), be.t(df), n, h, w, K, 1, use_corr, DP1, ld, DD)
+    be.call("mnk_motion_field_kp_bwd", PR, ld, be.t(ms), be.t(md), be.t(df), n, h, w, K, use_corr, DP2, ld, GS, GD)
+    be.sync()
+    assert torch.equal(F1.cpu(), F2.cpu()) and torch.equal(DP1.cpu(), DP2.cpu())
+    assert torch.equal(GS.cpu(), DD.cpu()[:, 1:]) and torch.equal(GD.cpu(), -DD.cpu()[:, 1:])
+
+
 DEFORM_CASES = [("same", (2, 5, 16, 16), 0), ("down", (2, 6, 4, 4), 0), ("up", (2, 3, 32, 32), 0),
                 ("one", (2, 7, 1, 1), 0), ("tri_down", (2, 6, 8, 8), 1), ("tri_up", (2, 3, 32, 32), 1),
                 ("wide", (2, 300, 4, 4), 0)]
