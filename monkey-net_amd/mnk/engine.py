@@ -122,6 +122,9 @@ class DiscriminatorFullModel(torch.nn.Module):
                                   loss_weights=self.train_params['loss_weights'])
 
 
+_BROKEN_CAPTURES = []
+
+
 class TrainStep:
     """One iteration of train.py:110-136 on this rank's shard, with gradients averaged over ranks (RCCL) before
     every optimiser step."""
@@ -219,20 +222,27 @@ class TrainStep:
             "graph capture with torch.distributed active was disabled (MNK_DIST_GRAPH=0)"
         self._static_x = {k: v.clone() for k, v in x.items()}
         snap = self._snapshot()
+        import gc
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):          # sizes the scratch buffers, warms MIOpen, creates Adam state
+            for it in range(warmup + 1):     # sizes the scratch buffers, creates Adam state and the descriptor tables
+                if it == warmup:
+                    # what torch.cuda.graph() does before a capture -- but in front of the LAST warm-up iteration: objects
+                    # of earlier runs that only the cycle collector frees (models, optimisers) take their packed-weight
+                    # registrations with them, and the tables the capture must find unchanged are keyed by that registry
+                    torch.cuda.synchronize()
+                    gc.collect()
+                    torch.cuda.empty_cache()
                 self._eager_step(self._static_x, set_to_none=True)
         torch.cuda.current_stream().wait_stream(side)
         # The iteration is captured as LINEAR hipGraphs.  A captured graph with a second branch that holds a kernel replays
         # 0.85-1.0 ms slower on this runtime, whatever the branch does (profiles/r03_knob_ab_log.txt), so the overlapped
         # gradient exchange of several ranks is not a branch of one graph: _cut() ends the graph in front of it, the
         # exchange is started / awaited by ordinary stream calls at replay time, and a new graph continues behind it.
-        import gc
         torch.cuda.synchronize()
-        gc.collect()
-        torch.cuda.empty_cache()
+        gc_was_on = gc.isenabled()
+        gc.disable()                          # (no collection -- no finaliser -- in the middle of the capture either)
         program = []
         pool = torch.cuda.graph_pool_handle()
         cap = torch.cuda.Stream()
@@ -249,10 +259,12 @@ class TrainStep:
                 try:
                     self._segment[0].capture_end()
                 except Exception:
-                    pass
+                    _BROKEN_CAPTURES.append(self._segment[0])     # (its destructor would abort the process: keep it)
             raise
         finally:
             self._segment = None
+            if gc_was_on:
+                gc.enable()
         torch.cuda.current_stream().wait_stream(cap)
         self._graph = program
         self._restore(snap)
