@@ -492,6 +492,24 @@ int mnk_deform_fwd(const float* inp, int ld_in, int C, int h, int w, const float
  * is ACCUMULATED into (several skips share one field). */
 int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
                    const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, void* stream);
+/* All warps of one generator pass in ONE launch each way (generator.py:60-78: every decoder level's appearance skip is
+ * warped by the same field, nearest-resized (mode 0), and the key-point embedding is resized into the channels behind it):
+ *   out_l[n][y][x][c] = grid_sample(inp_l, resize(field))[c]                    for c < C_l            (mnk_deform_fwd)
+ *   out_l[n][y][x][emb_off_l + c] = emb[n][nearest(y)][nearest(x)][c]         for c < ke_l           (mnk_resize_nearest)
+ * backward: dinp_l (zero-initialised by the caller, may be NULL) and dfield (zero-initialised, may be NULL) receive the
+ * scatter-adds of mnk_deform_bwd; demb[N][He][We][ld_emb] (may be NULL) is WRITTEN: the gathers of mnk_resize_nearest_bwd
+ * summed level after level, pad channels 0.  nlevels <= 8. */
+typedef struct MnkWarpLevel {
+    const float* inp;   /* [N][h][w][ld_in] */
+    float* out;         /* forward: [N][h][w][ld_out] */
+    const float* dout;  /* backward: gradient of out */
+    float* dinp;        /* backward */
+    int ld_in, C, h, w, ld_out, ke, emb_off, reserved;
+} MnkWarpLevel;
+int mnk_warp_levels_fwd(const MnkWarpLevel* levels, int nlevels, const float* field, int hf, int wf, int mode, const float* emb,
+                        int ld_emb, int He, int We, int N, void* stream);
+int mnk_warp_levels_bwd(const MnkWarpLevel* levels, int nlevels, const float* field, int hf, int wf, int mode, float* dfield,
+                        float* demb, int ld_emb, int He, int We, int N, void* stream);
 
 /* ---- feature-matching L1 on the discriminator's activations (modules/losses.py:8-12 reconstruction_loss over
  * discriminator maps; train.py:47-51) ---------------------------------------------------------------------------

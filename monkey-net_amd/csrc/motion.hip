@@ -680,14 +680,16 @@ struct Bilin {
     }
 };
 
-__global__ void __launch_bounds__(256) deform_fwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
-                                                         const float* __restrict__ field, int hf, int wf, int mode,
-                                                         float* __restrict__ out, int ld_out, int out_off, int N) {
+// (vb, vgrid): this block's index / the block count of the work item -- blockIdx.x / gridDim.x of a launch of its own, a
+// sub-range of the blocks of a multi-level launch (warp_levels_*_kernel)
+__device__ __forceinline__ void deform_fwd_body(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                const float* __restrict__ field, int hf, int wf, int mode,
+                                                float* __restrict__ out, int ld_out, int out_off, int N, int vb, int vgrid) {
     const int nq = (C + 3) / 4;
     const long P = (long)h * w;
     const long total = (long)N * P * nq;
     const bool vec_store = ((out_off & 3) == 0) && ((ld_out & 3) == 0);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)vb * blockDim.x + threadIdx.x; i < total; i += (long)vgrid * blockDim.x) {
         const int q = (int)(i % nq);
         const long np = i / nq;
         const int p = (int)(np % P);
@@ -728,22 +730,28 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(const float* __restrict
     }
 }
 
+__global__ void __launch_bounds__(256) deform_fwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                         const float* __restrict__ field, int hf, int wf, int mode,
+                                                         float* __restrict__ out, int ld_out, int out_off, int N) {
+    deform_fwd_body(inp, ld_in, C, h, w, field, hf, wf, mode, out, ld_out, out_off, N, blockIdx.x, gridDim.x);
+}
+
 // CL lanes (power of two <= 64) cooperate on one pixel: each walks channels c = cl, cl + CL, ...; the per-pixel sums over
 // channels (d out / d grid) are finished with wavefront shuffles.  One lane per CHANNEL, not per channel quad: the CL lanes
 // of a pixel then add to CL consecutive floats of the scattered gradient -- a quarter of the atomic requests per line that
 // float4-wide lanes make (four instructions, each carrying one float of every 16 bytes): 11.11 -> 11.00 ms per training
 // iteration against that form (profiles/r02_knob_ab_log.txt, visit 44).
-__global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
-                                                              const float* __restrict__ field, int hf, int wf, int mode,
-                                                              const float* __restrict__ dout, int ld_out, int out_off,
-                                                              float* __restrict__ dinp, float* __restrict__ dfield, int N,
-                                                              int CL, int cslice) {
+__device__ __forceinline__ void deform_bwd_body(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                const float* __restrict__ field, int hf, int wf, int mode,
+                                                const float* __restrict__ dout, int ld_out, int out_off,
+                                                float* __restrict__ dinp, float* __restrict__ dfield, int N, int CL, int cslice,
+                                                int vbx, int vgx, int vby) {
     const long P = (long)h * w;
     const long npix = (long)N * P;
     const int ppb = 256 / CL;   // pixels per block iteration
     const int cl = threadIdx.x % CL, pl = threadIdx.x / CL;
     const long iters = (npix + ppb - 1) / ppb;
-    for (long it = blockIdx.x; it < iters; it += gridDim.x) {
+    for (long it = vbx; it < iters; it += vgx) {
         const long np = it * ppb + pl;
         const bool live = np < npix;
         float gix = 0.f, giy = 0.f;
@@ -764,7 +772,7 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict
             const float* gp = dout + np * ld_out + out_off;
             // blockIdx.y = channel slice [c_begin, c_end): few-pixel maps with many channels (2 x 2 ... 8 x 8 with 512 ... 1024)
             // would otherwise be a few dozen blocks whose lanes walk 16 channels one after another
-            const int c_begin = blockIdx.y * cslice, c_end = c_begin + cslice < C ? c_begin + cslice : C;
+            const int c_begin = vby * cslice, c_end = c_begin + cslice < C ? c_begin + cslice : C;
             for (int c = c_begin + cl; c < c_end; c += CL) {
                 const float go = gp[c];
                 const float vnw = k_nw ? ib[o_nw + c] : 0.f, vne = k_ne ? ib[o_ne + c] : 0.f;
@@ -791,6 +799,114 @@ __global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict
                 atomicAdd(fb + fa.idx[j] * 2, gix * fa.wgt[j]);
                 atomicAdd(fb + fa.idx[j] * 2 + 1, giy * fa.wgt[j]);
             }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                              const float* __restrict__ field, int hf, int wf, int mode,
+                                                              const float* __restrict__ dout, int ld_out, int out_off,
+                                                              float* __restrict__ dinp, float* __restrict__ dfield, int N,
+                                                              int CL, int cslice) {
+    deform_bwd_body(inp, ld_in, C, h, w, field, hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL, cslice, blockIdx.x,
+                    gridDim.x, blockIdx.y);
+}
+
+// ---- all warps of a generator pass in ONE launch (generator.py:60-78: the appearance skips of every decoder level are
+// warped by the same field, and the key-point embedding is resized into each of them) -----------------------------------
+constexpr int MAX_WARP_LEVELS = 8;
+struct WarpSeg {          // one level's share of the launch
+    const float* inp;
+    float* out;           // forward: [N][h][w][ld_out]
+    const float* dout;    // backward: its gradient
+    float* dinp;          // backward: zero-initialised scatter target (or NULL)
+    int ld_in, C, h, w, ld_out, ke, emb_off;
+    int warp_begin, warp_blocks;      // forward: blocks of the warp / of the embedding copy; backward: warp blocks = gx * slices
+    int emb_begin, emb_blocks;
+    int CL, cslice, gx;
+};
+struct WarpSegs {
+    WarpSeg lv[MAX_WARP_LEVELS];
+    int n, N, hf, wf, mode, ld_emb, He, We;
+    const float* field;
+    const float* emb;
+    float* dfield;
+    float* demb;
+    int demb_begin, demb_blocks;
+};
+
+__global__ void __launch_bounds__(256) warp_levels_fwd_kernel(WarpSegs a) {
+    const int b = blockIdx.x;
+    for (int l = 0; l < a.n; ++l) {
+        const WarpSeg& L = a.lv[l];
+        if (b >= L.warp_begin && b < L.warp_begin + L.warp_blocks) {
+            deform_fwd_body(L.inp, L.ld_in, L.C, L.h, L.w, a.field, a.hf, a.wf, a.mode, L.out, L.ld_out, 0, a.N, b - L.warp_begin,
+                            L.warp_blocks);
+            return;
+        }
+        if (b >= L.emb_begin && b < L.emb_begin + L.emb_blocks) {
+            // nearest resize of the embedding into channels [emb_off, emb_off + ke) (resize_nearest_kernel of layout.hip)
+            const long total = (long)a.N * L.h * L.w * L.ke;
+            for (long i = (long)(b - L.emb_begin) * 256 + threadIdx.x; i < total; i += (long)L.emb_blocks * 256) {
+                const int c = (int)(i % L.ke);
+                const long p = i / L.ke;
+                const int x = (int)(p % L.w);
+                const long t = p / L.w;
+                const int y = (int)(t % L.h);
+                const int n = (int)(t / L.h);
+                const int ys = nearest_src(y, a.He, L.h), xs = nearest_src(x, a.We, L.w);
+                L.out[p * L.ld_out + L.emb_off + c] = a.emb[(((long)n * a.He + ys) * a.We + xs) * a.ld_emb + c];
+            }
+            return;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_levels_bwd_kernel(WarpSegs a) {
+    const int b = blockIdx.x;
+    for (int l = 0; l < a.n; ++l) {
+        const WarpSeg& L = a.lv[l];
+        if (b >= L.warp_begin && b < L.warp_begin + L.warp_blocks) {
+            const int vb = b - L.warp_begin;
+            deform_bwd_body(L.inp, L.ld_in, L.C, L.h, L.w, a.field, a.hf, a.wf, a.mode, L.dout, L.ld_out, 0, L.dinp, a.dfield,
+                            a.N, L.CL, L.cslice, vb % L.gx, L.gx, vb / L.gx);
+            return;
+        }
+    }
+    if (b >= a.demb_begin && b < a.demb_begin + a.demb_blocks) {
+        // gradient of the embedding: every element gathers, level after level (the order of the per-level launches), the
+        // pixels whose nearest source it is (resize_nearest_bwd_kernel of layout.hip); pad channels are written 0
+        const long total = (long)a.N * a.He * a.We * a.ld_emb;
+        for (long i = (long)(b - a.demb_begin) * 256 + threadIdx.x; i < total; i += (long)a.demb_blocks * 256) {
+            const int c = (int)(i % a.ld_emb);
+            const long p = i / a.ld_emb;
+            const int xs = (int)(p % a.We);
+            const long t = p / a.We;
+            const int ys = (int)(t % a.He);
+            const int n = (int)(t / a.He);
+            float tot = 0.f;
+            bool first = true;
+            for (int l = 0; l < a.n; ++l) {
+                const WarpSeg& L = a.lv[l];
+                if (L.ke <= 0 || c >= L.ke) continue;
+                int h_lo = (int)((long)ys * L.h / a.He) - 1, h_hi = (int)(((long)ys + 1) * L.h / a.He) + 1;
+                int w_lo = (int)((long)xs * L.w / a.We) - 1, w_hi = (int)(((long)xs + 1) * L.w / a.We) + 1;
+                if (h_lo < 0) h_lo = 0;
+                if (w_lo < 0) w_lo = 0;
+                if (h_hi > L.h - 1) h_hi = L.h - 1;
+                if (w_hi > L.w - 1) w_hi = L.w - 1;
+                float acc = 0.f;
+                for (int y = h_lo; y <= h_hi; ++y) {
+                    if (nearest_src(y, a.He, L.h) != ys) continue;
+                    for (int x = w_lo; x <= w_hi; ++x) {
+                        if (nearest_src(x, a.We, L.w) != xs) continue;
+                        acc += L.dout[(((long)n * L.h + y) * L.w + x) * L.ld_out + L.emb_off + c];
+                    }
+                }
+                tot = first ? acc : tot + acc;
+                first = false;
+            }
+            a.demb[i] = tot;
         }
     }
 }
@@ -1034,6 +1150,95 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
     slices = (C + cslice - 1) / cslice;
     hipLaunchKernelGGL(deform_bwd_kernel, dim3((int)(iters < 16384 ? iters : 16384), slices), dim3(256), 0, s, inp, ld_in, C, h, w,
                        field, hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL, cslice);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+static void warp_bwd_plan(int C, long npix, int& CL, int& cslice, int& gx, int& slices) {
+    CL = 1;
+    while (CL < C && CL < 64) CL <<= 1;
+    const long iters = (npix + (256 / CL) - 1) / (256 / CL);
+    slices = 1;
+    const int max_slices = (C + CL - 1) / CL;
+    while (slices < max_slices && iters * slices < g_deform_bwd_blocks) slices <<= 1;
+    if (slices > max_slices) slices = max_slices;
+    cslice = ((C + slices - 1) / slices + CL - 1) / CL * CL;
+    slices = (C + cslice - 1) / cslice;
+    gx = (int)(iters < 16384 ? iters : 16384);
+}
+
+static int warp_levels_check(const MnkWarpLevel* lv, int n, const float* field, int hf, int wf, int mode, int He, int We,
+                             int ld_emb, int N) {
+    MNK_REQUIRE(lv && n > 0 && n <= MAX_WARP_LEVELS && field && hf > 0 && wf > 0 && mode == 0 && N > 0);
+    for (int l = 0; l < n; ++l) {
+        MNK_REQUIRE(lv[l].inp && lv[l].C > 0 && lv[l].h > 0 && lv[l].w > 0 && lv[l].ld_in % 4 == 0 &&
+                    lv[l].ld_in >= round_up(lv[l].C, 4) && lv[l].C <= lv[l].ld_out && lv[l].ke >= 0);
+        MNK_REQUIRE(lv[l].ke == 0 || (He > 0 && We > 0 && lv[l].ke <= ld_emb && lv[l].emb_off >= lv[l].C &&
+                                      lv[l].emb_off + lv[l].ke <= lv[l].ld_out));
+    }
+    return MNK_OK;
+}
+
+int mnk_warp_levels_fwd(const MnkWarpLevel* levels, int nlevels, const float* field, int hf, int wf, int mode, const float* emb,
+                        int ld_emb, int He, int We, int N, void* stream) {
+    if (int rc = warp_levels_check(levels, nlevels, field, hf, wf, mode, He, We, ld_emb, N)) return rc;
+    WarpSegs a = {};
+    a.n = nlevels, a.N = N, a.hf = hf, a.wf = wf, a.mode = mode, a.ld_emb = ld_emb, a.He = He, a.We = We;
+    a.field = field, a.emb = emb;
+    int blocks = 0;
+    double bytes = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const MnkWarpLevel& m = levels[l];
+        MNK_REQUIRE(m.out && (m.ke == 0 || emb));
+        WarpSeg& L = a.lv[l];
+        L.inp = m.inp, L.out = m.out, L.ld_in = m.ld_in, L.C = m.C, L.h = m.h, L.w = m.w, L.ld_out = m.ld_out, L.ke = m.ke,
+        L.emb_off = m.emb_off;
+        const long px = (long)N * m.h * m.w;
+        L.warp_begin = blocks;
+        L.warp_blocks = grid_for(px * ((m.C + 3) / 4));
+        blocks += L.warp_blocks;
+        L.emb_begin = blocks;
+        L.emb_blocks = m.ke > 0 ? grid_for(px * m.ke) : 0;
+        blocks += L.emb_blocks;
+        bytes += (double)px * (m.C + m.ke) * 8;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_DEFORM, s, bytes);
+    hipLaunchKernelGGL(warp_levels_fwd_kernel, dim3(blocks), dim3(256), 0, s, a);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_warp_levels_bwd(const MnkWarpLevel* levels, int nlevels, const float* field, int hf, int wf, int mode, float* dfield,
+                        float* demb, int ld_emb, int He, int We, int N, void* stream) {
+    if (int rc = warp_levels_check(levels, nlevels, field, hf, wf, mode, He, We, ld_emb, N)) return rc;
+    WarpSegs a = {};
+    a.n = nlevels, a.N = N, a.hf = hf, a.wf = wf, a.mode = mode, a.ld_emb = ld_emb, a.He = He, a.We = We;
+    a.field = field, a.dfield = dfield, a.demb = demb;
+    int blocks = 0;
+    double bytes = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        const MnkWarpLevel& m = levels[l];
+        MNK_REQUIRE(m.dout);
+        WarpSeg& L = a.lv[l];
+        L.inp = m.inp, L.dout = m.dout, L.dinp = m.dinp, L.ld_in = m.ld_in, L.C = m.C, L.h = m.h, L.w = m.w,
+        L.ld_out = m.ld_out, L.ke = m.ke, L.emb_off = m.emb_off;
+        L.warp_begin = blocks;
+        L.warp_blocks = 0;
+        if (m.dinp || dfield) {
+            int slices;
+            warp_bwd_plan(m.C, (long)N * m.h * m.w, L.CL, L.cslice, L.gx, slices);
+            L.warp_blocks = L.gx * slices;
+        }
+        blocks += L.warp_blocks;
+        bytes += (double)N * m.h * m.w * m.C * 12;
+    }
+    a.demb_begin = blocks;
+    a.demb_blocks = demb ? grid_for((long)N * He * We * ld_emb) : 0;
+    blocks += a.demb_blocks;
+    MNK_REQUIRE(blocks > 0);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_DEFORM, s, bytes);
+    hipLaunchKernelGGL(warp_levels_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

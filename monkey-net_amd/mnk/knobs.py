@@ -20,6 +20,8 @@ KNOBS = {
                                "shape at the end of backward (0: one launch per layer during backward)"),
     "MNK_WGRAD_BG": ("10", "eager iterations: giga-MACs of recorded weight-gradient GEMMs after which they are launched on a second "
                            "stream during backward (0: all of them at the end, as a captured iteration always does)"),
+    "MNK_WARP_LEVELS": ("1", "all warps (and key-point embedding copies) of a generator pass in one launch each way (0: one "
+                             "launch per decoder level)"),
     "MNK_UP_SUBPIXEL": ("1", "UpBlock3D convolutions in their sub-pixel forms (four 2x2 phase convolutions forward, one 4x4 "
                              "stride-2 convolution for the data gradient; 0: 3x3 over the up-sampled view + sum-pool)"),
     "MNK_BN_ZERO_BIAS_GRAD": ("1", "the bias of a convolution in front of a training-mode BatchNorm gets no gradient (it is "

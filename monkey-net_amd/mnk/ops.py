@@ -825,7 +825,14 @@ class ConvKxKFn(torch.autograd.Function):
         ho, wo = hi + 2 * pad - kh + 1, wi + 2 * pad - kw + 1
         nt = kh * kw
         wp = SCRATCH.get("pack", _query("mnk_conv2d_packed_floats", cout, cin, 0, nt), x)
-        _call("mnk_conv2d_pack_fwd", x, _p(weight), _p(wp), cout, cin, 0, nt)
+        ctx.wd = None
+        if ctx.needs_input_grad[0] and nt <= 16:
+            # forward and data-gradient layouts in ONE launch; the latter serves every backward pass through this node (the
+            # generator pass and the discriminator pass of one iteration read the same, not yet updated, weights)
+            ctx.wd = torch.empty(_query("mnk_conv2d_packed_floats", cin, cout, 0, nt), dtype=torch.float32, device=x.device)
+            _call("mnk_conv2d_pack_all", x, _p(weight), _p(wp), _p(ctx.wd), None, cout, cin, 0, nt)
+        else:
+            _call("mnk_conv2d_pack_fwd", x, _p(weight), _p(wp), cout, cin, 0, nt)
         y = torch.empty(n, ho, wo, ceil4(cout), dtype=torch.float32, device=x.device)
         nws = _query("mnk_conv2d_workspace_floats", n, ho, wo, cin, 0, cout, nt)
         ws = SCRATCH.get("ws", nws, x) if nws else None
@@ -844,8 +851,10 @@ class ConvKxKFn(torch.autograd.Function):
         nt = kh * kw
         dx = dw = db = None
         if ctx.needs_input_grad[0] and not (ctx.leaf_input and _SKIP_LEAF_INPUT_GRADS[0]):
-            wp = SCRATCH.get("pack", _query("mnk_conv2d_packed_floats", cin, cout, 0, nt), dy)
-            _call("mnk_conv2d_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, 0, cin, nt)
+            wp = ctx.wd
+            if wp is None:
+                wp = SCRATCH.get("pack", _query("mnk_conv2d_packed_floats", cin, cout, 0, nt), dy)
+                _call("mnk_conv2d_pack_dgrad", dy, _p(weight), _p(wp), cout, cin, 0, cin, nt)
             dx = torch.empty(n, hi, wi, ceil4(cin), dtype=torch.float32, device=dy.device)
             nws = _query("mnk_conv2d_workspace_floats", n, hi, wi, cout, 0, cin, nt)
             ws = SCRATCH.get("ws", nws, dy) if nws else None
@@ -1396,6 +1405,10 @@ class WarpSkipFn(torch.autograd.Function):
         return dinp, dfield, demb, None, None, None
 
 
+WARP_LEVEL = np.dtype([("inp", "<u8"), ("out", "<u8"), ("dout", "<u8"), ("dinp", "<u8"), ("ld_in", "<i4"), ("C", "<i4"),
+                       ("h", "<i4"), ("w", "<i4"), ("ld_out", "<i4"), ("ke", "<i4"), ("emb_off", "<i4"), ("reserved", "<i4")])
+
+
 class WarpAllFn(torch.autograd.Function):
     """Every deform_input of one generator forward (generator.py:66-73 the skips, :78 the source frame) as ONE autograd node.
     They all read the same deformation field, so as separate nodes each backward zero-fills its own field gradient and
@@ -1408,6 +1421,24 @@ class WarpAllFn(torch.autograd.Function):
         _check_device(field)
         _, hf, wf, _ = field.shape
         outs = []
+        ctx.multi = mode == 0 and len(inps) <= 8 and knobs.on("MNK_WARP_LEVELS")
+        if ctx.multi:         # one launch for the warps and embedding copies of all levels (mnk_warp_levels_fwd)
+            lv = np.zeros(len(inps), dtype=WARP_LEVEL)
+            for i, (inp, (c, ke)) in enumerate(zip(inps, specs)):
+                n, h, w, ld_in = inp.shape
+                e = emb if ke else None
+                whole = c % 4 == 0 and (e is None or e.shape[-1] == ceil4(ke))
+                out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
+                lv[i] = (inp.data_ptr(), out.data_ptr(), 0, 0, ld_in, c, h, w, out.shape[-1],
+                         (ceil4(ke) if whole else ke) if e is not None else 0, c, 0)
+                outs.append(out)
+            _call("mnk_warp_levels_fwd", field, lv.ctypes.data, len(inps), _p(field), hf, wf, mode, _p(emb),
+                  emb.shape[-1] if emb is not None else 0, emb.shape[1] if emb is not None else 0,
+                  emb.shape[2] if emb is not None else 0, inps[0].shape[0])
+            ctx.save_for_backward(field, emb, *inps)
+            ctx.meta = (mode, tuple(specs))
+            ctx.set_materialize_grads(False)
+            return tuple(outs)
         for inp, (c, ke) in zip(inps, specs):
             n, h, w, ld_in = inp.shape
             e = emb if ke else None
@@ -1440,6 +1471,24 @@ class WarpAllFn(torch.autograd.Function):
         dfield = flat[offs[-1]:offs[-1] + sizes[-1]].view_as(field) if want_field else None
         demb = None
         dinps = []
+        if ctx.multi and all(d is not None for d in douts):
+            lv = np.zeros(len(inps), dtype=WARP_LEVEL)
+            keep = []
+            want_emb = emb is not None and ctx.needs_input_grad[1] and any(ke for _, ke in specs)
+            for i, (inp, (c, ke), dout) in enumerate(zip(inps, specs, douts)):
+                dout = dout.contiguous()
+                keep.append(dout)
+                n, h, w, ld_in = inp.shape
+                dinp = flat[offs[i]:offs[i] + sizes[i]].view_as(inp) if want[i] else None
+                dinps.append(dinp)
+                lv[i] = (inp.data_ptr(), 0, dout.data_ptr(), dinp.data_ptr() if dinp is not None else 0, ld_in, c, h, w,
+                         dout.shape[-1], ke if want_emb else 0, c, 0)
+            if want_emb:
+                demb = torch.empty_like(emb)
+            _call("mnk_warp_levels_bwd", field, lv.ctypes.data, len(inps), _p(field), hf, wf, mode, _p(dfield), _p(demb),
+                  emb.shape[-1] if emb is not None else 0, emb.shape[1] if emb is not None else 0,
+                  emb.shape[2] if emb is not None else 0, inps[0].shape[0])
+            return (dfield, demb, None, None) + tuple(dinps)
         for i, (inp, (c, ke), dout) in enumerate(zip(inps, specs, douts)):
             if dout is None:
                 dinps.append(None)

@@ -181,3 +181,46 @@ def test_deform_matches_reference_golden(be):
                 OUT, ld, 0, n)
         be.sync()
         assert maxerr(from_nhwc(OUT.cpu(), c), ref[:, :, 0]) < 1e-5, tag
+
+
+@pytest.mark.parametrize("emb_ch", [0, 6, 8])
+def test_all_warps_in_one_launch_equal_the_per_level_launches(be, monkeypatch, emb_ch):
+    """ops.WarpAllFn with mnk_warp_levels_fwd / _bwd (MNK_WARP_LEVELS=1: every level's warp and embedding copy in one launch
+    each way) against one launch per level: outputs and the embedding gradient to the bit (same gathers in the same order),
+    the scatter-added gradients (atomics) to rounding."""
+    from mnk import ops
+    g = torch.Generator().manual_seed(6)
+    n = 2
+    field = be.t((torch.rand(n, 16, 16, 2, generator=g) * 2.4 - 1.2))
+    emb = be.t(torch.randn(n, 8, 8, ceil4(emb_ch), generator=g)) if emb_ch else None
+    if emb is not None:
+        emb[..., emb_ch:] = 0
+    shapes = [(8, 4, 4), (5, 8, 8), (4, 16, 16), (3, 32, 32)]
+    specs = tuple((c, emb_ch if i % 2 == 0 else 0) for i, (c, _, _) in enumerate(shapes))
+    inps = [be.t(torch.randn(n, h, w, ceil4(c), generator=g)) for c, h, w in shapes]
+    for t, (c, _, _) in zip(inps, shapes):
+        t[..., c:] = 0
+    douts = [torch.randn(n, h, w, ceil4(c + ke), generator=g) for (c, h, w), (_, ke) in zip(shapes, specs)]
+    for d, (c, _, _), (_, ke) in zip(douts, shapes, specs):
+        d[..., c + ke:] = 0                      # gradients of acts: zero pad channels
+
+    def run(flag):
+        monkeypatch.setenv("MNK_WARP_LEVELS", flag)
+        f = field.clone().requires_grad_(True)
+        e = emb.clone().requires_grad_(True) if emb is not None else None
+        xs = [t.clone().requires_grad_(True) for t in inps]
+        outs = ops.WarpAllFn.apply(f, e, 0, specs, *xs)
+        torch.autograd.backward(list(outs), [be.t(d) for d in douts])
+        be.sync()
+        return ([o.detach().cpu() for o in outs], f.grad.cpu(), e.grad.cpu() if e is not None else None,
+                [x.grad.cpu() for x in xs])
+
+    o0, gf0, ge0, gx0 = run("0")
+    o1, gf1, ge1, gx1 = run("1")
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    if emb is not None:
+        assert torch.equal(ge0, ge1)
+    assert relerr(gf1, gf0) < 1e-5
+    for a, b in zip(gx0, gx1):
+        assert relerr(b, a) < 1e-5
