@@ -1471,21 +1471,23 @@ class WarpAllFn(torch.autograd.Function):
         dfield = flat[offs[-1]:offs[-1] + sizes[-1]].view_as(field) if want_field else None
         demb = None
         dinps = []
-        if ctx.multi and all(d is not None for d in douts):
-            lv = np.zeros(len(inps), dtype=WARP_LEVEL)
+        if ctx.multi and any(d is not None for d in douts):
+            live = [i for i, d in enumerate(douts) if d is not None]        # (a level whose output went nowhere: no gradient)
+            lv = np.zeros(len(live), dtype=WARP_LEVEL)
             keep = []
-            want_emb = emb is not None and ctx.needs_input_grad[1] and any(ke for _, ke in specs)
-            for i, (inp, (c, ke), dout) in enumerate(zip(inps, specs, douts)):
-                dout = dout.contiguous()
+            want_emb = emb is not None and ctx.needs_input_grad[1] and any(specs[i][1] for i in live)
+            dinps = [None] * len(inps)
+            for j, i in enumerate(live):
+                inp, (c, ke) = inps[i], specs[i]
+                dout = douts[i].contiguous()
                 keep.append(dout)
                 n, h, w, ld_in = inp.shape
-                dinp = flat[offs[i]:offs[i] + sizes[i]].view_as(inp) if want[i] else None
-                dinps.append(dinp)
-                lv[i] = (inp.data_ptr(), 0, dout.data_ptr(), dinp.data_ptr() if dinp is not None else 0, ld_in, c, h, w,
+                dinps[i] = flat[offs[i]:offs[i] + sizes[i]].view_as(inp) if want[i] else None
+                lv[j] = (inp.data_ptr(), 0, dout.data_ptr(), dinps[i].data_ptr() if dinps[i] is not None else 0, ld_in, c, h, w,
                          dout.shape[-1], ke if want_emb else 0, c, 0)
             if want_emb:
                 demb = torch.empty_like(emb)
-            _call("mnk_warp_levels_bwd", field, lv.ctypes.data, len(inps), _p(field), hf, wf, mode, _p(dfield), _p(demb),
+            _call("mnk_warp_levels_bwd", field, lv.ctypes.data, len(live), _p(field), hf, wf, mode, _p(dfield), _p(demb),
                   emb.shape[-1] if emb is not None else 0, emb.shape[1] if emb is not None else 0,
                   emb.shape[2] if emb is not None else 0, inps[0].shape[0])
             return (dfield, demb, None, None) + tuple(dinps)
