@@ -47,7 +47,8 @@ t=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
 head -45 "$OUT/moving-gif_b32_steady_groups.txt" | cut -c1-130 | tee -a "$S"
 find "$OUT" -name "*kernel_trace*" -size +4M -delete
 echo "== rocprofv3 kernel trace of hipGraph replays: idle time between kernels (tools/trace_gaps.py)" | tee -a "$S"
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_graph -o g -- python $PWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-profile > "$OLDPWD/$OUT/rocprof_graph.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
+CMDG="python $PWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-profile"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_graph -o g -- $CMDG > "$OLDPWD/$OUT/rocprof_graph.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
 t=$(find /tmp/prof_graph -name "*kernel_trace.csv" | head -1)
 [ -n "$t" ] && python tools/trace_gaps.py "$t" --last 6 > "$OUT/graph_replay_gaps.txt" 2>&1; head -3 "$OUT/graph_replay_gaps.txt" | cut -c1-200 | tee -a "$S"
 echo "== SQ pass over the per-layer conv bench (moving-gif): MFMA busy, clock" | tee -a "$S"
