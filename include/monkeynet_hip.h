@@ -378,6 +378,8 @@ int mnk_comm_unique_id(void* id128);
 int mnk_comm_init(const void* id128, int rank, int world, void** comm_out);
 int mnk_comm_destroy(void* comm);
 int mnk_allreduce_bnstats(void* comm, float* sums, long n, void* stream);
+/* the same into a second buffer (the local sums stay: they are this rank's share of the scale / shift gradients) */
+int mnk_allreduce_bnstats_to(void* comm, const float* sums, float* out, long n, void* stream);
 int mnk_allreduce_grads(void* comm, float* grads, long n, int average, long chunk_floats, void* stream);
 
 /* ---- grouped 1x1 convolution (SameBlock3D, modules/util.py:118, dense_motion_module.py:24-28) ----------- */

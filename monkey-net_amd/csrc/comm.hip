@@ -135,18 +135,20 @@ int mnk_comm_destroy(void* comm) {
 #endif
 }
 
-// sums[0..n) <- sum over ranks, in place, on `stream`
-int mnk_allreduce_bnstats(void* comm, float* sums, long n, void* stream) {
-    MNK_REQUIRE(comm && sums && n > 0);
+// out[0..n) <- sum over ranks of sums[0..n) on `stream` (out == sums: in place)
+int mnk_allreduce_bnstats_to(void* comm, const float* sums, float* out, long n, void* stream) {
+    MNK_REQUIRE(comm && sums && out && n > 0);
 #ifdef HIPEMU
     set_error("mnk_allreduce_bnstats: no RCCL in the CPU emulator build");
     return MNK_ECOMM;
 #else
     Comm* c = (Comm*)comm;
-    ncclResult_t rc = rccl().AllReduce(sums, sums, (size_t)n, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream);
+    ncclResult_t rc = rccl().AllReduce(sums, out, (size_t)n, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream);
     return rc == ncclSuccess ? MNK_OK : fail("ncclAllReduce (BatchNorm statistics)", rc);
 #endif
 }
+
+int mnk_allreduce_bnstats(void* comm, float* sums, long n, void* stream) { return mnk_allreduce_bnstats_to(comm, sums, sums, n, stream); }
 
 // grads[0..n) <- sum (average = 0) or mean (average = 1) over ranks, in place, on `stream`, as ceil(n / chunk) collectives
 // grouped into one RCCL launch (xGMI rings are per-link bound: few large messages); chunk_floats <= 0: one collective

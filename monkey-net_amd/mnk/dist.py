@@ -102,6 +102,17 @@ def all_reduce_sum_(t):
     return t
 
 
+def all_reduce_sum(t):
+    """-> a new tensor: the sum of `t` over the ranks; `t` keeps the local values (no copy launch in front of the collective)."""
+    h = direct_comm() if t.is_cuda else None
+    if h is not None and t.dtype == torch.float32 and t.is_contiguous():
+        from . import _lib
+        out = torch.empty_like(t)
+        _lib.lib().call("mnk_allreduce_bnstats_to", h, t.data_ptr(), out.data_ptr(), t.numel(), _stream_of(t))
+        return out
+    return all_reduce_sum_(t.clone())
+
+
 def grads_active():
     """True when gradients must be exchanged (several ranks, or the forced single-rank exercise)."""
     return initialized() and (tdist.get_world_size() > 1 or _FORCE)

@@ -664,7 +664,7 @@ class BNActFn(torch.autograd.Function):
                                  "(sync_batchnorm/batchnorm.py:116)")
             if mdist.active():
                 sums = pre_sums if pre_sums is not None and pre_sums.numel() == 2 * c else channel_sums(y, c)
-                sums = mdist.all_reduce_sum_(sums.clone() if sums is pre_sums else sums)
+                sums = mdist.all_reduce_sum(sums) if sums is pre_sums else mdist.all_reduce_sum_(sums)
                 count *= mdist.world_size()
                 _call("mnk_bn_finalize", y, _p(sums), count, _p(gamma), _p(running_mean), _p(running_var),
                       float(momentum), float(eps), c, 1, _p(mean), _p(invstd), _p(scale))
@@ -725,7 +725,7 @@ class BNActFn(torch.autograd.Function):
               w, c, int(relu), int(pool), _p(sums), _p(ws), nws)
         dbeta, dgamma = sums[:c], sums[c:]       # local contributions (averaged later together with all gradients)
         if training and mdist.active():
-            sums = mdist.all_reduce_sum_(sums.clone())
+            sums = mdist.all_reduce_sum(sums)
         dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
         if dskip is not None:
             # dy = BatchNorm backward + skip gradient in one pass, with the column sums of the SUM: the bias gradient of the
