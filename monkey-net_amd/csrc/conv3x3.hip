@@ -2205,7 +2205,9 @@ __device__ __forceinline__ void reduce_param_major(const float* __restrict__ src
     }
 }
 
-__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const MnkWgradReduceDesc* __restrict__ descs, int n) {
+// (four waves per SIMD: the kernel needs 132 registers unconstrained, i.e. three waves; capped at 128 it reduces the generator's
+// 692 MB of partials in 311 instead of 361 us; five waves -- 96 registers -- spill: 765 us.  tools/reduce_probe.py)
+__global__ void __launch_bounds__(256, 4) wgrad_reduce_multi_kernel(const MnkWgradReduceDesc* __restrict__ descs, int n) {
     __shared__ float sm[16 * 16 * 16 + 64];        // [group][channel * ntaps + tap], group stride tw * 16
     __shared__ int sh_idx;
     const int b = blockIdx.x;
