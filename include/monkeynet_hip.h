@@ -357,8 +357,15 @@ typedef struct MnkAdamDesc {
     float* wp_d0;
     float* wp_d1;
     int Cout, C0, C1, block_begin;
-    int flags;      /* bit 0: an up-sampled convolution -- emit the packs of its sub-pixel forms (mnk_conv3x3_up_*) */
+    int flags;      /* bit 0: an up-sampled convolution -- emit the packs of its sub-pixel forms (mnk_conv3x3_up_*);
+                       bit 1 / bit 2: gt0 / gt1 hold 16 pseudo taps of the sub-pixel weight-gradient form (folded here) */
     int reserved;
+    /* optional: the gradient of source 0 / source 1 of a convolution weight taken straight from the tap-major partials of the
+     * grouped weight-gradient GEMMs, part[split][tap][Cout][C_source] (mnk_wgrad_grouped_*), summed over gt_splits* <= 3 splits in
+     * order -- the bits mnk_wgrad_reduce_multi would have left in `g`, without its pass over them.  NULL: `g` is read. */
+    const float* gt0;
+    const float* gt1;
+    int gt_splits0, gt_splits1;
 } MnkAdamDesc;
 int mnk_adam_blocks(long n, int Cout, int C0, int C1, int packed);
 int mnk_adam_tick(float* hyper, void* stream);

@@ -1956,25 +1956,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_n16_grouped_kernel(const
 // reads are coalesced along ci with four independent split-sum chains per element (loads in flight), the
 // (tap, ci) -> (ci, tap) transposition goes through LDS, writes are contiguous runs of 64 * ntaps floats.
 // Fixed summation order (deterministic).
-// the pseudo taps of the sub-pixel form that contribute to kernel row (column) k: (a, u) with k in S(a, u) -- two each
-__device__ __forceinline__ void up_fold_pairs(int k, int& a0, int& u0, int& a1, int& u1) {
-    // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
-    a0 = 0, u0 = k == 0 ? 0 : 1;          // k = 0: (0,0); k = 1, 2: (0,1)
-    a1 = 1, u1 = k == 2 ? 1 : 0;          // k = 0, 1: (1,0); k = 2: (1,1)
-}
-// dW[ky][kx] from the 16 pseudo-tap sums acc[4 * (2a + b) + 2u + v]
-__device__ __forceinline__ float up_fold(const float* acc, int ky, int kx, int stride) {
-    int ya[2], yu[2], xb[2], xv[2];
-    up_fold_pairs(ky, ya[0], yu[0], ya[1], yu[1]);
-    up_fold_pairs(kx, xb[0], xv[0], xb[1], xv[1]);
-    float v = 0.f;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) v += acc[(4 * (2 * ya[p] + xb[q]) + 2 * yu[p] + xv[q]) * stride];
-    return v;
-}
-
+// (up_fold / up_fold_pairs: pack_tile.h -- the optimiser kernel folds tap-major partials too)
 __global__ void __launch_bounds__(256) conv3x3_wgrad_tap_reduce_kernel(const float* __restrict__ part, int splits,
                                                                        int ntaps, int Cout, int C,
                                                                        float* __restrict__ dw, long ld_out, int up) {

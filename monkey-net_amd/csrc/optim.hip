@@ -48,7 +48,7 @@ constexpr int PLAIN_PER_BLOCK = 4096;       // floats of a plain range handled b
 
 __global__ void __launch_bounds__(256) adam_multi_kernel(const MnkAdamDesc* __restrict__ descs, int n,
                                                          const float* __restrict__ hyper) {
-    __shared__ float T[16 * (16 * 17 + 1)];
+    __shared__ float T[16 * (16 * 17 + 1)];       // the tile [16 co][16 ci][taps] (padded strides); also the 16-tap staging area
     __shared__ int sh_idx;
     const int b = blockIdx.x;
     // the block's descriptor: one coalesced read of the block_begin column + an LDS count (a binary search over device
@@ -98,8 +98,41 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const MnkAdamDesc* __re
     const int C0p = (d.C0 + 15) & ~15, C1p = d.C1 > 0 ? (d.C1 + 15) & ~15 : 0, tiles_x = (C0p + C1p) / 16;
     const int cot = local / tiles_x, cc = local - cot * tiles_x;
     const PackTileGeom g = pack_tile_geom<9>(d.Cout, d.C0, d.C1, C0p, C1p, 9, cc, cot);
-    constexpr int run = 16 * 9;
-    for (int i = t; i < 16 * run; i += 256) {
+    constexpr int run = 16 * 9, NI = 16 * run / 256;        // nine elements per thread
+    static_assert(16 * run % 256 == 0, "a tile is a whole number of passes of the block");
+    // the gradient of this tile's source straight from the tap-major partials of the grouped weight-gradient GEMMs (few-split
+    // layers: the deep levels, whose partials ARE the gradient): staged through T with 64-byte runs along ci, summed over the
+    // splits in order, the 16 pseudo taps of a sub-pixel form folded -- what mnk_wgrad_reduce_multi would have written to `g`
+    const float* gt = g.second ? d.gt1 : d.gt0;
+    float gv[NI];
+    if (gt) {
+        const int nin = (d.flags & (g.second ? 4 : 2)) ? 16 : 9;
+        const int splits = g.second ? d.gt_splits1 : d.gt_splits0;
+        const long plane = (long)d.Cout * g.Cs, sstride = (long)nin * plane;
+        for (int i = t; i < nin * 256; i += 256) {
+            const int ci = i & 15, r = (i >> 4) & 15, tp = i >> 8;
+            const int co = g.co0 + r, c = g.ci0 + ci;
+            float v = 0.f;
+            if (co < d.Cout && c < g.Cs) {
+                const float* src = gt + ((long)tp * d.Cout + co) * g.Cs + c;
+                for (int sp = 0; sp < splits; ++sp) v += src[(long)sp * sstride];
+            }
+            T[(r * 16 + ci) * 17 + tp] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = t + k * 256;
+            const int r = i / run, o = i - r * run;
+            const int ci = o / 9, tap = o - ci * 9;
+            const float* a = T + (r * 16 + ci) * 17;
+            gv[k] = nin == 16 ? up_fold(a, tap / 3, tap - (tap / 3) * 3, 1) : a[tap];
+        }
+        __syncthreads();          // T is re-used for the updated parameters below
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = t + k * 256;
         const int r = i / run, o = i - r * run;     // row (co), offset inside the row = ci * 9 + tap
         const int ci = o / 9, tap = o - ci * 9;
         const int co = g.co0 + r;
@@ -108,7 +141,7 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const MnkAdamDesc* __re
             const size_t idx = ((size_t)co * g.Cin + g.cstart + g.ci0) * 9 + o;
             p = d.p[idx];
             float m = d.m[idx], v = d.v[idx];
-            adam_update(p, d.g[idx], m, v, h);
+            adam_update(p, gt ? gv[k] : d.g[idx], m, v, h);
             d.p[idx] = p;
             d.m[idx] = m;
             d.v[idx] = v;

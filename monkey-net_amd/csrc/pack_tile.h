@@ -74,6 +74,26 @@ __device__ __forceinline__ void up_dgrad_set(int t, int& lo, int& hi) {
     hi = t == 0 ? 2 : (t == 1 ? 2 : (t == 2 ? 1 : 0));
 }
 
+// ---- the weight gradient of the sub-pixel form (16 pseudo taps) folded into the nine kernel taps ------------------------------
+// the pseudo taps of the sub-pixel form that contribute to kernel row (column) k: (a, u) with k in S(a, u) -- two each
+__device__ __forceinline__ void up_fold_pairs(int k, int& a0, int& u0, int& a1, int& u1) {
+    // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+    a0 = 0, u0 = k == 0 ? 0 : 1;          // k = 0: (0,0); k = 1, 2: (0,1)
+    a1 = 1, u1 = k == 2 ? 1 : 0;          // k = 0, 1: (1,0); k = 2: (1,1)
+}
+// dW[ky][kx] from the 16 pseudo-tap sums acc[4 * (2a + b) + 2u + v]
+__device__ __forceinline__ float up_fold(const float* acc, int ky, int kx, int stride) {
+    int ya[2], yu[2], xb[2], xv[2];
+    up_fold_pairs(ky, ya[0], yu[0], ya[1], yu[1]);
+    up_fold_pairs(kx, xb[0], xv[0], xb[1], xv[1]);
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) v += acc[(4 * (2 * ya[p] + xb[q]) + 2 * yu[p] + xv[q]) * stride];
+    return v;
+}
+
 __device__ __forceinline__ void pack_tile_emit_up(const float* T, const PackTileGeom& g, float* __restrict__ wf,
                                                   float* __restrict__ wd0, float* __restrict__ wd1, int Cout, int cc, int cot) {
     const int t = threadIdx.x;

@@ -228,6 +228,12 @@ class TrainStep:
         with torch.cuda.stream(side):
             for it in range(warmup + 1):     # sizes the scratch buffers, creates Adam state and the descriptor tables
                 if it == warmup:
+                    # the captured iteration of one process: the optimiser kernels read the gradients of the deep levels from
+                    # the tap-major partials themselves (MnkAdam.tap_direct; p.grad is not observable inside a replay)
+                    direct = self.mnk_adam and not mdist.grads_active() and knobs.on("MNK_ADAM_TAP_DIRECT")
+                    for o in (self.opt_g, self.opt_d, self.opt_k):
+                        if hasattr(o, "tap_direct"):
+                            o.tap_direct = bool(direct)
                     # what torch.cuda.graph() does before a capture -- but in front of the LAST warm-up iteration: objects
                     # of earlier runs that only the cycle collector frees (models, optimisers) take their packed-weight
                     # registrations with them, and the tables the capture must find unchanged are keyed by that registry
@@ -265,6 +271,9 @@ class TrainStep:
             self._segment = None
             if gc_was_on:
                 gc.enable()
+            for o in (self.opt_g, self.opt_d, self.opt_k):      # eager iterations keep every p.grad valid
+                if hasattr(o, "tap_direct"):
+                    o.tap_direct = False
         torch.cuda.current_stream().wait_stream(cap)
         self._graph = program
         self._restore(snap)

@@ -20,6 +20,9 @@ KNOBS = {
                                "shape at the end of backward (0: one launch per layer during backward)"),
     "MNK_WGRAD_BG": ("10", "eager iterations: giga-MACs of recorded weight-gradient GEMMs after which they are launched on a second "
                            "stream during backward (0: all of them at the end, as a captured iteration always does)"),
+    "MNK_ADAM_TAP_DIRECT": ("1", "captured iteration of one process: the optimiser kernel reads the gradients of the few-split "
+                                 "tap-major layers from their partials (no reduction pass for them; p.grad of those parameters "
+                                 "is not written)"),
     "MNK_WARP_LEVELS": ("1", "all warps (and key-point embedding copies) of a generator pass in one launch each way (0: one "
                              "launch per decoder level)"),
     "MNK_UP_SUBPIXEL": ("1", "UpBlock3D convolutions in their sub-pixel forms (four 2x2 phase convolutions forward, one 4x4 "

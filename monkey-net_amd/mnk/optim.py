@@ -26,7 +26,8 @@ from . import ops as mops
 
 ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("wp_fwd", "<u8"),
                       ("wp_d0", "<u8"), ("wp_d1", "<u8"), ("Cout", "<i4"), ("C0", "<i4"), ("C1", "<i4"),
-                      ("block_begin", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
+                      ("block_begin", "<i4"), ("flags", "<i4"), ("reserved", "<i4"), ("gt0", "<u8"), ("gt1", "<u8"),
+                      ("gt_splits0", "<i4"), ("gt_splits1", "<i4")])
 REDUCE_DESC = np.dtype([("part", "<u8"), ("dw", "<u8"), ("layout", "<i4"), ("splits", "<i4"), ("ntaps", "<i4"),
                         ("Cout", "<i4"), ("C", "<i4"), ("Cin_total", "<i4"), ("c_start", "<i4"), ("accumulate", "<i4"),
                         ("block_begin", "<i4"), ("reserved", "<i4")])
@@ -86,6 +87,7 @@ class DeferredReducer:
         self.bg_macs = float(mops.knobs.get("MNK_WGRAD_BG") or 0) * 1e9
         self.job_macs = 0.0
         self.inflight = []        # operands / tables of launches on the background stream since the last join
+        self.direct = ()          # keys of the last flush whose partials the optimiser kernel reads itself (MnkAdam.tap_direct)
 
     def _record(self, key, weight, sink, shape, flags):
         n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total, hi, wi, ld_dy, c_start = shape
@@ -110,6 +112,7 @@ class DeferredReducer:
             layout, splits, nfloats = int(plan.layout), int(plan.splits), int(plan.part_floats)
         part = torch.empty(max(nfloats, 1), dtype=torch.float32, device=weight.device)
         rec = {"shape": shape, "part": part, "splits": splits, "nfloats": nfloats, "grouped": grouped, "job": job,
+               "direct_ok": mops.pack_entry_of(weight) is not None and c_start in (0, mops.pack_entry_of(weight).meta[1]),
                "row": (part.data_ptr(), sink.data_ptr(), layout, splits, kh * kw, cout, c, cin_total, c_start, 0),
                "blocks": lib.query("mnk_wgrad_reduce_blocks", splits, cout, c) if splits > 0 else 0}
         self.recs[key] = rec
@@ -142,6 +145,15 @@ class DeferredReducer:
         self.done.add(key)
         own._written.add(id(weight))
         return True
+
+    def is_direct(self, key):
+        """The owner's optimiser kernel reads this layer's gradient straight from its tap-major partials (MnkAdam.tap_direct:
+        few-split layers of a grouped GEMM whose weight the kernel updates tile by tile) -- no reduction for it."""
+        if not self.owner.tap_direct:
+            return False
+        r = self.recs.get(key)
+        return (r is not None and r["grouped"] and 1 <= r["splits"] <= 3 and r["row"][2] in (0, 2) and r["row"][4] == 9
+                and r["direct_ok"])
 
     def _launch_grouped(self, background=False):
         jobs, self.jobs = self.jobs, []
@@ -186,6 +198,11 @@ class DeferredReducer:
         if self.jobs:
             self._launch_grouped()
         self._join()
+        if self.owner.tap_direct:
+            self.direct = tuple(k for k in self.pending if self.is_direct(k))
+            self.pending = [k for k in self.pending if k not in self.direct]
+        else:
+            self.direct = ()
         if not self.pending:
             return 0
         keys = tuple(self.pending)
@@ -254,6 +271,11 @@ class MnkAdam(torch.optim.Optimizer):
         self._keep = []
         self._mnk_fresh_entries = ()
         self._exchange = None            # a gradient exchange started by begin_exchange(), finished by step()
+        # True: the step kernel takes the gradients of the few-split tap-major layers (the deep levels: 330 of the generator's
+        # 690 MB of partials ARE the gradient) straight from the partials, and mnk_wgrad_reduce_multi skips them -- `p.grad` of
+        # those parameters is then NOT valid.  mnk.engine.TrainStep switches it on for a captured iteration of one process
+        # (nobody can look at p.grad between the launches of a replay; several ranks exchange the flat buffer)
+        self.tap_direct = False
         self._exchanged = False          # ... or already finished by exchange_end(): step() must not sum again
         for p in ps:
             mops.register_grad_sink(p, self)
@@ -324,13 +346,22 @@ class MnkAdam(torch.optim.Optimizer):
             if e is not None:
                 cout, c0, c1, up = e.meta
                 nb = _lib.lib().query("mnk_adam_blocks", 0, cout, c0, c1, 1)
+                gt, flags = [(0, 0), (0, 0)], int(up)
+                for si, cs in enumerate((0, c0) if c1 else (0,)):
+                    key = (id(p), cs)
+                    if key in self.reducer.direct:
+                        r = self.reducer.recs[key]
+                        gt[si] = (r["part"].data_ptr(), r["splits"])
+                        flags |= (2 << si) if r["row"][2] == 2 else 0
                 rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), e.wp.data_ptr(),
                              e.wd[0].data_ptr() if e.wd[0] is not None else 0,
-                             e.wd[1].data_ptr() if e.wd[1] is not None else 0, cout, c0, c1, blocks, int(up), 0))
+                             e.wd[1].data_ptr() if e.wd[1] is not None else 0, cout, c0, c1, blocks, flags, 0,
+                             gt[0][0], gt[1][0], gt[0][1], gt[1][1]))
                 entries.append(e)
             else:
                 nb = _lib.lib().query("mnk_adam_blocks", p.numel(), 0, 0, 0, 0)
-                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks, 0, 0))
+                rows.append((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks, 0, 0,
+                             0, 0, 0, 0))
             blocks += nb
         rec = np.array(rows, dtype=ADAM_DESC)
         return _device_table(rec, self.device, self._keep), len(rows), blocks, tuple(entries)
@@ -384,7 +415,8 @@ class MnkAdam(torch.optim.Optimizer):
             mdist.all_reduce_flat_(self.flat_grad)          # sum over ranks; the mean is folded into the update
         if not _capturing(self.device):
             self.sync_scalars(1.0 / ws)
-        key = (tuple(id(p) for p in active), tuple(p.data_ptr() for p in active), mops.pack_registry_version())
+        key = (tuple(id(p) for p in active), tuple(p.data_ptr() for p in active), mops.pack_registry_version(),
+               self.reducer.direct)
         if self._table is None or self._table[0] != key:
             if _capturing(self.device):
                 raise RuntimeError("the optimiser's tensor set changed during hipGraph capture (run one eager iteration first)")

@@ -21,11 +21,12 @@ REDUCE_DESC = np.dtype([("part", "<u8"), ("dw", "<u8"), ("layout", "<i4"), ("spl
                         ("block_begin", "<i4"), ("reserved", "<i4")])
 ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("wp_fwd", "<u8"),
                       ("wp_d0", "<u8"), ("wp_d1", "<u8"), ("Cout", "<i4"), ("C0", "<i4"), ("C1", "<i4"),
-                      ("block_begin", "<i4"), ("flags", "<i4"), ("reserved", "<i4")])
+                      ("block_begin", "<i4"), ("flags", "<i4"), ("reserved", "<i4"), ("gt0", "<u8"), ("gt1", "<u8"),
+                      ("gt_splits0", "<i4"), ("gt_splits1", "<i4")])
 
 
 def test_descriptor_sizes_match_the_header():
-    assert REDUCE_DESC.itemsize == 56 and ADAM_DESC.itemsize == 88
+    assert REDUCE_DESC.itemsize == 56 and ADAM_DESC.itemsize == 112
 
 
 def _table(be, rec):
@@ -192,7 +193,7 @@ def test_adam_multi_matches_torch_adam_and_emits_the_packs(be, lr_drop):
     for k, p in enumerate(params):
         if k < len(plains):
             nb = be.query("mnk_adam_blocks", p.numel(), 0, 0, 0, 0)
-            rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks, 0, 0))
+            rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), 0, 0, 0, 0, 0, 0, blocks, 0, 0, 0, 0, 0, 0))
             packs.append(None)
         else:
             cout, c0, c1, d0, d1 = convs[k - len(plains)]
@@ -208,7 +209,7 @@ def test_adam_multi_matches_torch_adam_and_emits_the_packs(be, lr_drop):
             nb = be.query("mnk_adam_blocks", 0, cout, c0, c1, 1)
             rows.append((P[k].data_ptr(), G[k].data_ptr(), M[k].data_ptr(), V[k].data_ptr(), p.numel(), wf.data_ptr(),
                          w0.data_ptr() if w0 is not None else 0, w1.data_ptr() if w1 is not None else 0, cout, c0, c1, blocks,
-                         up, 0))
+                         up, 0, 0, 0, 0, 0))
             packs.append((wf, w0, w1))
         assert nb > 0
         blocks += nb
@@ -373,3 +374,39 @@ def test_table_upload_through_kernel_arguments(be):
         be.lib.call("mnk_table_upload", host.ctypes.data, dev.data_ptr(), nbytes, be.stream())
         be.sync()
         assert bytes(dev.cpu().numpy()[:nbytes]) == bytes(host)
+
+
+@pytest.mark.parametrize("batch", [2, 8])
+def test_adam_reading_tap_major_partials_equals_reduce_then_adam(be, batch):
+    """MnkAdam.tap_direct (what a captured iteration of one process uses): the step kernel takes the gradients of the few-split
+    tap-major layers -- plain, sub-pixel (16 pseudo taps folded) and second-source ones -- straight from the partials of the
+    grouped weight-gradient GEMMs, and mnk_wgrad_reduce_multi skips them.  Same sums in the same order: the parameters after
+    two steps are the reduce-then-Adam ones to the bit."""
+    from modules.util import Hourglass
+    from mnk import optim as moptim
+
+    def run(direct):
+        torch.manual_seed(3)
+        hg = Hourglass(block_expansion=64, in_features=3, out_features=4, num_blocks=2, max_features=256).to(be.device)
+        hg.train()
+        opt = moptim.MnkAdam(hg.parameters(), lr=1e-3, betas=(0.5, 0.999))
+        opt.tap_direct = direct
+        g = torch.Generator().manual_seed(4)
+        x = be.t(torch.rand(batch, 3, 1, 16, 16, generator=g))
+        ndirect, most = 0, 0
+        for _ in range(2):
+            out = hg(x)
+            (out * out).mean().backward()
+            opt.step()
+            ndirect = max(ndirect, len(opt.reducer.direct))
+            most = max([most] + [opt.reducer.recs[k]["splits"] for k in opt.reducer.direct])
+            opt.zero_grad()
+        be.sync()
+        return [p.detach().cpu().clone() for p in hg.parameters()], ndirect, most
+
+    base, n0, _ = run(False)
+    got, n1, most = run(True)
+    assert n0 == 0 and n1 >= 3, (n0, n1)          # plain, up-sampled and two-source layers took the direct path
+    assert most >= (2 if batch == 8 else 1)       # ... batch 8: with more than one split to add up
+    for a, b in zip(base, got):
+        assert torch.equal(a, b)
