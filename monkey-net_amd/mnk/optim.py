@@ -87,7 +87,8 @@ class DeferredReducer:
         self.bg_macs = float(mops.knobs.get("MNK_WGRAD_BG") or 0) * 1e9
         self.job_macs = 0.0
         self.inflight = []        # operands / tables of launches on the background stream since the last join
-        self.direct = ()          # keys of the last flush whose partials the optimiser kernel reads itself (MnkAdam.tap_direct)
+        self.direct = ()          # keys (since the last drop) whose partials the optimiser kernel reads itself (MnkAdam.tap_direct)
+        self.multi = set()        # keys of weights that were seen to receive two contributions before one step: never direct
 
     def _record(self, key, weight, sink, shape, flags):
         n, ho, wo, c, cout, kh, kw, pad, ld_x, cin_total, hi, wi, ld_dy, c_start = shape
@@ -153,7 +154,7 @@ class DeferredReducer:
             return False
         r = self.recs.get(key)
         return (r is not None and r["grouped"] and 1 <= r["splits"] <= 3 and r["row"][2] in (0, 2) and r["row"][4] == 9
-                and r["direct_ok"])
+                and r["direct_ok"] and key not in self.multi)
 
     def _launch_grouped(self, background=False):
         jobs, self.jobs = self.jobs, []
@@ -198,11 +199,12 @@ class DeferredReducer:
         if self.jobs:
             self._launch_grouped()
         self._join()
-        if self.owner.tap_direct:
-            self.direct = tuple(k for k in self.pending if self.is_direct(k))
-            self.pending = [k for k in self.pending if k not in self.direct]
-        else:
-            self.direct = ()
+        # (a second flush before the step -- TrainStep materialises the gradients, then steps -- finds nothing pending and must
+        # leave the set alone: it lives until drop())
+        if self.owner.tap_direct and self.pending:
+            now = tuple(k for k in self.pending if self.is_direct(k))
+            self.direct = self.direct + now
+            self.pending = [k for k in self.pending if k not in now]
         if not self.pending:
             return 0
         keys = tuple(self.pending)
@@ -224,8 +226,27 @@ class DeferredReducer:
         self.pending = []
         return n
 
+    def undirect(self, weight):
+        """A second contribution to `weight` arrives before the step (MnkAdam.add_to_sink): the first one must be in the sink
+        after all -- reduce the partials the optimiser kernel was going to read itself, now and from now on."""
+        keys = tuple(k for k in self.direct if k[0] == id(weight))
+        self.multi.update(k for k in self.recs if k[0] == id(weight))
+        if not keys:
+            return
+        self.direct = tuple(k for k in self.direct if k not in keys)
+        rec = np.zeros(len(keys), dtype=REDUCE_DESC)
+        blocks = 0
+        for i, k in enumerate(keys):
+            r = self.recs[k]
+            rec[i] = r["row"] + (blocks, 0)
+            blocks += r["blocks"]
+        dev = self.recs[keys[0]]["part"].device
+        tab = _device_table(rec, dev, self.keep)
+        mops._call("mnk_wgrad_reduce_multi", tab, mops._p(tab), len(keys), blocks)
+
     def drop(self):
         self._join()
+        self.direct = ()
         self.pending = []
         self.jobs = []
         self.job_macs = 0.0
@@ -289,6 +310,7 @@ class MnkAdam(torch.optim.Optimizer):
         """slow path: a further contribution to a parameter whose sink already holds one (a parameter used by two
         backward passes before one step, e.g. train_params['detach_kp_discriminator'] = False)."""
         self.materialize_grads()
+        self.reducer.undirect(p)
         self._sinks[id(p)].add_(grad)
         self._written.add(id(p))
 

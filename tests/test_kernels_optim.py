@@ -376,8 +376,8 @@ def test_table_upload_through_kernel_arguments(be):
         assert bytes(dev.cpu().numpy()[:nbytes]) == bytes(host)
 
 
-@pytest.mark.parametrize("batch", [2, 8])
-def test_adam_reading_tap_major_partials_equals_reduce_then_adam(be, batch):
+@pytest.mark.parametrize("batch,twice", [(2, False), (8, False), (2, True)])
+def test_adam_reading_tap_major_partials_equals_reduce_then_adam(be, batch, twice):
     """MnkAdam.tap_direct (what a captured iteration of one process uses): the step kernel takes the gradients of the few-split
     tap-major layers -- plain, sub-pixel (16 pseudo taps folded) and second-source ones -- straight from the partials of the
     grouped weight-gradient GEMMs, and mnk_wgrad_reduce_multi skips them.  Same sums in the same order: the parameters after
@@ -397,9 +397,12 @@ def test_adam_reading_tap_major_partials_equals_reduce_then_adam(be, batch):
         for _ in range(2):
             out = hg(x)
             (out * out).mean().backward()
-            opt.step()
+            opt.materialize_grads()          # (as mnk.engine.TrainStep does before it steps: a second flush finds nothing pending)
             ndirect = max(ndirect, len(opt.reducer.direct))
             most = max([most] + [opt.reducer.recs[k]["splits"] for k in opt.reducer.direct])
+            if twice:                        # a second backward pass before the step: the slow path adds to the sinks, so the
+                (hg(x * 0.5).sum() * 1e-3).backward()        # first contribution must be reduced into them after all
+            opt.step()
             opt.zero_grad()
         be.sync()
         return [p.detach().cpu().clone() for p in hg.parameters()], ndirect, most
