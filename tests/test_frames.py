@@ -229,6 +229,8 @@ def test_reference_checkpoint_layout_restores_models_and_optimisers(be, shapes):
         be.sync()
         assert float((kp_d["mean"].cpu() - gold["tiny_eval_kp_mean_after"]).abs().max()) < 2e-5
         assert float((pred.cpu() - gold["tiny_eval_prediction_after"]).abs().max()) < 2e-4
+        if not mnk_adam:
+            continue          # (the iteration after a restore: once, on the default pipeline -- it is the expensive part on the emulator)
         gen.train(), kpd.train()
         g_losses, _, _ = step.step({"source": x["source"], "video": x["video"]})
         be.sync()

@@ -376,7 +376,7 @@ def test_table_upload_through_kernel_arguments(be):
         assert bytes(dev.cpu().numpy()[:nbytes]) == bytes(host)
 
 
-@pytest.mark.parametrize("batch,twice", [(2, False), (8, False), (2, True)])
+@pytest.mark.parametrize("batch,twice", [(2, False), (5, False), (2, True)])
 def test_adam_reading_tap_major_partials_equals_reduce_then_adam(be, batch, twice):
     """MnkAdam.tap_direct (what a captured iteration of one process uses): the step kernel takes the gradients of the few-split
     tap-major layers -- plain, sub-pixel (16 pseudo taps folded) and second-source ones -- straight from the partials of the
@@ -410,6 +410,6 @@ def test_adam_reading_tap_major_partials_equals_reduce_then_adam(be, batch, twic
     base, n0, _ = run(False)
     got, n1, most = run(True)
     assert n0 == 0 and n1 >= 3, (n0, n1)          # plain, up-sampled and two-source layers took the direct path
-    assert most >= (2 if batch == 8 else 1)       # ... batch 8: with more than one split to add up
+    assert most >= (2 if batch == 5 else 1)       # ... batch 5: with more than one split to add up
     for a, b in zip(base, got):
         assert torch.equal(a, b)
