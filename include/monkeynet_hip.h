@@ -99,6 +99,14 @@ int mnk_bn_eval_coeffs(const float* gamma, const float* running_mean, const floa
 /* z = [avgpool2x2] [relu] ((y-mean)*scale + beta)   (modules/util.py:56-57,62,81,87,100-101,106-107) */
 int mnk_bn_act_fwd(const float* y, int ld_y, const float* mean, const float* scale, const float* beta, float* z,
                    int ld_z, int z_off, int N, int H, int W, int C, int relu, int pool, void* stream);
+/* mnk_bn_finalize + mnk_bn_act_fwd in one launch: `sums` = finished [sum x][sum x^2] of the whole batch (the SyncBN path: they
+ * come out of the cross-rank all-reduce, batchnorm.py:95-111, so the single-process fusion of the second stage does not apply);
+ * every block derives the constants of its channels, the first row block writes mean / invstd / scale for the backward pass
+ * and updates the running statistics (batchnorm.py:113-125).  Same arithmetic as the two-launch form. */
+int mnk_bn_act_fwd_sums(const float* y, int ld_y, const float* sums, double count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, int update_running, float* mean,
+                        float* invstd, float* scale, float* z, int ld_z, int z_off, int N, int H, int W, int C, int relu, int pool,
+                        void* stream);
 /* backward, pass 1: sums[0..C) = sum g, sums[C..2C) = sum g*xhat with g = dL/d(BN output), xhat = (y-mean)*invstd.
  * These are also dbeta and dgamma. */
 int mnk_bn_act_bwd_stats(const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,

@@ -343,14 +343,27 @@ __device__ __forceinline__ float act_apply(float v, float slope) {   // slope < 
 }
 
 // thread (tx = channel quad, ty = output pixel lane): the per-channel constants stay in registers
-template <int POOL>
+// the statistics of the FIN form: finished column sums [sum x][sum x^2] of the whole (cross-rank) batch; every block derives the
+// constants of its channels from them with bn_finalize_kernel's arithmetic, the first row block also leaves mean / inv-std /
+// scale for the backward pass and updates the running statistics -- bn_finalize as no launch of its own (SyncBN path: the sums
+// come out of an all-reduce, so the fused second stage of the single-process path does not apply)
+struct FwdFinalize {
+    const float* sums;
+    const float* gamma;
+    float *running_mean, *running_var, *mean, *invstd, *scale;
+    double count;
+    float momentum, eps;
+    int update_running;
+};
+
+template <int POOL, bool FIN = false>
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict__ y, int ld_y,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ beta, int pstride,
                                                          float* __restrict__ z, int ld_z, int z_off, int N, int H,
                                                          int W, int C, float slope, int tx_n, int ty_n,
-                                                         long rows_per_block) {
+                                                         long rows_per_block, FwdFinalize fin = FwdFinalize()) {
     const int nv = (C + 3) / 4;
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx;
@@ -367,10 +380,38 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
     long cur = -1;
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f), sc = m;
     const float4 be = ld4_guard(beta, q, C);
+    if (FIN) {
+        float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = q * 4 + e;
+            if (c >= C) continue;
+            const double mu = (double)fin.sums[c] / fin.count;
+            double var = (double)fin.sums[C + c] / fin.count - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)mu, vf = (float)var;
+            const float is = 1.0f / sqrtf(vf + fin.eps);
+            mm[e] = mf;
+            ss[e] = fin.gamma[c] * is;
+            if (blockIdx.y == 0 && ty == 0) {
+                fin.mean[c] = mf;
+                fin.invstd[c] = is;
+                fin.scale[c] = ss[e];
+                if (fin.update_running) {
+                    const float unbiased = (float)(var * fin.count / (fin.count - 1.0));
+                    fin.running_mean[c] = (1.f - fin.momentum) * fin.running_mean[c] + fin.momentum * mf;
+                    fin.running_var[c] = (1.f - fin.momentum) * fin.running_var[c] + fin.momentum * unbiased;
+                }
+            }
+        }
+        m = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        sc = make_float4(ss[0], ss[1], ss[2], ss[3]);
+        cur = 0;
+    }
 #pragma unroll 2
     for (long p = r0 + ty; p < r1; p += ty_n) {
         const long po = pstride ? (long)((unsigned)p / HWo) * pstride : 0;     // per-frame statistics (InstanceNorm)
-        if (po != cur) {
+        if (!FIN && po != cur) {
             cur = po;
             m = ld4_guard(mean + po, q, C);
             sc = ld4_guard(scale + po, q, C);
@@ -780,10 +821,10 @@ int mnk_norm_act_fwd(const float* y, int ld_y, const float* mean, const float* s
     const dim3 grid(m.col_tiles, m.row_blocks);
     if (pool)
         hipLaunchKernelGGL(bn_act_fwd_kernel<1>, grid, dim3(256), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
-                           N, H, W, C, slope, m.tx, m.ty, m.rows_per_block);
+                           N, H, W, C, slope, m.tx, m.ty, m.rows_per_block, FwdFinalize());
     else
         hipLaunchKernelGGL(bn_act_fwd_kernel<0>, grid, dim3(256), 0, s, y, ld_y, mean, scale, beta, pstride, z, ld_z, z_off,
-                           N, H, W, C, slope, m.tx, m.ty, m.rows_per_block);
+                           N, H, W, C, slope, m.tx, m.ty, m.rows_per_block, FwdFinalize());
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -922,6 +963,32 @@ int mnk_bn_finalize(const float* sums, double count, const float* gamma, float* 
                     void* stream) {
     return mnk_norm_finalize(sums, count, gamma, running_mean, running_var, momentum, eps, C, 1, update_running, mean,
                              invstd, scale, stream);
+}
+
+int mnk_bn_act_fwd_sums(const float* y, int ld_y, const float* sums, double count, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float eps, int update_running, float* mean,
+                        float* invstd, float* scale, float* z, int ld_z, int z_off, int N, int H, int W, int C, int relu, int pool,
+                        void* stream) {
+    MNK_REQUIRE(y && sums && gamma && beta && mean && invstd && scale && z && N > 0 && H > 0 && W > 0 && C > 0 && count > 0);
+    MNK_REQUIRE(!update_running || (running_mean && running_var && count > 1));
+    MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && z_off >= 0 && z_off + C <= ld_z);
+    MNK_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0));
+    MNK_REQUIRE((long)N * H * W < (1L << 31));
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    ProfScope prof(K_BN_APPLY, s, (double)N * H * W * C * 4 * (pool ? 1.25 : 2.0));
+    Map2D m = make_map(rows, round_up(C, 4), 2, 2048);
+    const dim3 grid(m.col_tiles, m.row_blocks);
+    const FwdFinalize fin{sums, gamma, running_mean, running_var, mean, invstd, scale, count, momentum, eps, update_running};
+    const float slope = relu ? 0.f : -1.f;
+    if (pool)
+        hipLaunchKernelGGL((bn_act_fwd_kernel<1, true>), grid, dim3(256), 0, s, y, ld_y, (const float*)nullptr,
+                           (const float*)nullptr, beta, 0, z, ld_z, z_off, N, H, W, C, slope, m.tx, m.ty, m.rows_per_block, fin);
+    else
+        hipLaunchKernelGGL((bn_act_fwd_kernel<0, true>), grid, dim3(256), 0, s, y, ld_y, (const float*)nullptr,
+                           (const float*)nullptr, beta, 0, z, ld_z, z_off, N, H, W, C, slope, m.tx, m.ty, m.rows_per_block, fin);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
 }
 
 int mnk_bn_eval_coeffs(const float* gamma, const float* running_mean, const float* running_var, float eps, int C,

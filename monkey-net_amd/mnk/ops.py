@@ -666,8 +666,15 @@ class BNActFn(torch.autograd.Function):
                 sums = pre_sums if pre_sums is not None and pre_sums.numel() == 2 * c else channel_sums(y, c)
                 sums = mdist.all_reduce_sum(sums) if sums is pre_sums else mdist.all_reduce_sum_(sums)
                 count *= mdist.world_size()
-                _call("mnk_bn_finalize", y, _p(sums), count, _p(gamma), _p(running_mean), _p(running_var),
-                      float(momentum), float(eps), c, 1, _p(mean), _p(invstd), _p(scale))
+                # finalisation inside the apply pass (mnk_bn_act_fwd_sums): one launch less per norm layer on the SyncBN path
+                ho, wo = (h // 2, w // 2) if pool else (h, w)
+                z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
+                _call("mnk_bn_act_fwd_sums", y, _p(y), ld, _p(sums), count, _p(gamma), _p(beta), _p(running_mean),
+                      _p(running_var), float(momentum), float(eps), 1, _p(mean), _p(invstd), _p(scale), _p(z), z.shape[-1], 0, n, h,
+                      w, c, int(relu), int(pool))
+                ctx.save_for_backward(y, mean, invstd, scale, beta)
+                ctx.meta = (c, training, relu, pool, count)
+                return z
             else:
                 # one launch for second stage + finalisation; partials from the conv epilogue when it produced them
                 part = pre_sums if pre_sums is not None and pre_sums.numel() > 2 * c else None

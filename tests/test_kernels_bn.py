@@ -354,3 +354,37 @@ def test_bn_small_sums_the_split_k_partials_of_the_convolution_in_front(be, up):
     assert relerr(from_nhwc(Y.cpu(), cout), yref) < 2e-6
     assert torch.all(Y.cpu()[..., cout:] == 0)
     assert maxerr(from_nhwc(Z.cpu(), cout), zref) < 2e-5
+
+
+@pytest.mark.parametrize("shape,pool", [((3, 45, 4, 6), 0), ((2, 64, 8, 8), 1), ((2, 5, 6, 4), 1)])
+def test_apply_from_finished_sums_equals_finalize_then_apply(be, shape, pool):
+    """mnk_bn_act_fwd_sums (the SyncBN path: the sums come out of an all-reduce, the finalisation happens inside the apply
+    pass) against mnk_bn_finalize + mnk_bn_act_fwd: outputs, saved statistics and running statistics to the bit."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    ld, rows = ceil4(c), n * h * w
+    X = be.t(to_nhwc(x))
+    nws = be.query("mnk_bn_workspace_floats", rows, ld)
+    ws, sums = be.empty(nws), be.empty(2 * c)
+    be.call("mnk_bn_stats", X, ld, rows, c, sums, ws, nws)
+    count = float(3 * rows)                 # as if three ranks had contributed (the sums are whatever the exchange left)
+    G, Bt = be.t(gamma), be.t(beta)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    out = []
+    for fused in (False, True):
+        mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+        RM, RV = be.t(rm0.clone()), be.t(rv0.clone())
+        Z = be.zeros(n, ho, wo, ld)
+        if fused:
+            be.call("mnk_bn_act_fwd_sums", X, ld, sums, count, G, Bt, RM, RV, 0.1, 1e-5, 1, mean, invstd, scale, Z, ld, 0, n, h, w, c,
+                    1, pool)
+        else:
+            be.call("mnk_bn_finalize", sums, count, G, RM, RV, 0.1, 1e-5, c, 1, mean, invstd, scale)
+            be.call("mnk_bn_act_fwd", X, ld, mean, scale, Bt, Z, ld, 0, n, h, w, c, 1, pool)
+        be.sync()
+        out.append([t.cpu().clone() for t in (Z, mean, invstd, scale, RM, RV)])
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
