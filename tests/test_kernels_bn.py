@@ -388,3 +388,25 @@ def test_apply_from_finished_sums_equals_finalize_then_apply(be, shape, pool):
         out.append([t.cpu().clone() for t in (Z, mean, invstd, scale, RM, RV)])
     for a, b in zip(*out):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("ca,cb", [(3, 11), (8, 12), (4, 6)])
+def test_concat_with_an_embedding_shared_by_both_batch_halves(be, ca, cb):
+    """ops.Concat2PairFn (the batched discriminator pass [generated | real] with ONE key-point embedding):
+    out[n] = [a[n] | b[n mod B]], gradient of b = sum of both halves -- torch.cat / repeat and their autograd."""
+    from mnk import ops
+    g = torch.Generator().manual_seed(12)
+    b2, h, w = 4, 5, 3
+    a = torch.randn(b2, ca, h, w, generator=g)
+    e = torch.randn(b2 // 2, cb, h, w, generator=g)
+    A, E = be.t(to_nhwc(a)).requires_grad_(True), be.t(to_nhwc(e)).requires_grad_(True)
+    out = ops.Concat2PairFn.apply(A, ca, E, cb)
+    ref = torch.cat([a, e.repeat(2, 1, 1, 1)], dim=1)
+    be.sync()
+    assert torch.equal(from_nhwc(out.detach().cpu(), ca + cb), ref)
+    assert torch.all(out.detach().cpu()[..., ca + cb:] == 0)
+    go = torch.randn(b2, ca + cb, h, w, generator=g)
+    out.backward(be.t(to_nhwc(go)))
+    be.sync()
+    assert torch.equal(from_nhwc(A.grad.cpu(), ca), go[:, :ca])
+    assert maxerr(from_nhwc(E.grad.cpu(), cb), go[:b2 // 2, ca:] + go[b2 // 2:, ca:]) < 1e-6

@@ -128,3 +128,67 @@ def test_loss_module_runs_the_l1_kernels_on_the_library_device(be):
     assert relerr(out.detach().cpu(), ref.detach()) < 2e-6
     assert maxerr(A.grad.cpu(), a64.grad) < 1e-6 and maxerr(B.grad.cpu(), b64.grad) < 1e-6
     assert losses.reconstruction_loss(A, B, 0) == 0
+
+
+@pytest.mark.parametrize("nvec,length", [(1, 4), (6, 32), (16, 70)])
+def test_batch_means_of_the_loss_vectors(be, nvec, length):
+    """mnk_vec_means_fwd / _bwd and ops.LossMeansFn against `[v.mean() for v in losses]`, `sum(loss_values)` (train.py:114,116)
+    and autograd's gradients of both outputs."""
+    import numpy as np
+    from mnk import ops
+    g = torch.Generator().manual_seed(5)
+    vecs = [torch.randn(length, generator=g) * (i + 1) for i in range(nvec)]
+    V = [be.t(v) for v in vecs]
+    means = be.empty(nvec + 1)
+    ptrs = np.array([v.data_ptr() for v in V], dtype=np.uint64)
+    be.call("mnk_vec_means_fwd", ptrs.ctypes.data, nvec, length, means)
+    ref = torch.stack([v.double().mean() for v in vecs])
+    gm, gt = torch.randn(nvec, generator=g), torch.randn(1, generator=g)
+    GV = be.empty(nvec, length).fill_(float("nan"))
+    be.call("mnk_vec_means_bwd", be.t(gm), be.t(gt), nvec, length, GV)
+    GV2 = be.empty(nvec, length)
+    be.call("mnk_vec_means_bwd", None, be.t(gt), nvec, length, GV2)
+    be.sync()
+    assert maxerr(means.cpu()[:nvec], ref) < 1e-6 * (1 + float(ref.abs().max()))
+    assert abs(float(means.cpu()[nvec]) - float(ref.sum())) < 1e-5 * (1 + float(ref.abs().sum()))
+    want = ((gm.double() + gt.double()) / length).unsqueeze(1).expand(nvec, length)
+    assert maxerr(GV.cpu(), want) < 1e-6
+    assert maxerr(GV2.cpu(), (gt.double() / length).expand(nvec, length)) < 1e-6
+    # the autograd wrapper: same gradients as the stock formulation
+    leaves = [be.t(v.clone()).requires_grad_(True) for v in vecs]
+    m, tot = ops.LossMeansFn.apply(*leaves)
+    (tot * 2.0 + (m * be.t(gm)).sum()).backward()
+    leaves2 = [v.detach().double().requires_grad_(True) for v in vecs]
+    m2 = torch.stack([v.mean() for v in leaves2])
+    (m2.sum() * 2.0 + (m2 * gm.double()).sum()).backward()
+    be.sync()
+    for a, b in zip(leaves, leaves2):
+        assert maxerr(a.grad.cpu(), b.grad) < 1e-6
+
+
+def test_feature_matching_tap_adds_the_next_blocks_gradient(be):
+    """ops.PairL1TapFn: the map goes on to the next block unchanged, and its backward is the L1 gradient PLUS the gradient the
+    next block sends (mnk_pair_l1_bwd_add) -- what autograd's accumulation of two consumers gives."""
+    from mnk import ops
+    b, c, h, w = 2, 10, 6, 5
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2 * b, c, h, w, generator=g)
+    nxt = torch.randn(2 * b, h, w, ceil4(c), generator=g)
+    nxt[..., c:] = 0
+    gl = torch.randn(b, generator=g)
+    A = be.t(to_nhwc(x)).requires_grad_(True)
+    act, loss = ops.PairL1TapFn.apply(A, c, b, 3.0)
+    assert torch.equal(act.detach().cpu(), A.detach().cpu())
+    ((act * be.t(nxt)).sum() + (loss * be.t(gl)).sum()).backward()
+    A2 = be.t(to_nhwc(x)).requires_grad_(True)
+    loss2 = ops.PairL1Fn.apply(A2, c, b, 3.0)
+    ((A2 * be.t(nxt)).sum() + (loss2 * be.t(gl)).sum()).backward()
+    be.sync()
+    assert torch.equal(loss.detach().cpu(), loss2.detach().cpu())
+    assert maxerr(A.grad.cpu(), A2.grad.cpu()) < 1e-6
+    # only the next block's gradient (the discriminator-loss backward): handed through untouched
+    A3 = be.t(to_nhwc(x)).requires_grad_(True)
+    act3, _ = ops.PairL1TapFn.apply(A3, c, b, 3.0)
+    (act3 * be.t(nxt)).sum().backward()
+    be.sync()
+    assert torch.equal(A3.grad.cpu(), nxt)
