@@ -389,8 +389,22 @@ template <int RA, int NST> struct LoaderSel<RA, 2, NST> { typedef ActLoader3<RA,
 #define MNK_IGEMM_NST 2                       // register stages: K steps between a step's global loads and its LDS stores
 #endif
 
+// -DMNK_PHASE_CLOCKS (an experiment build, tools/phase_probe.py): thread 0 of every block of the 32x32-tile kernel stamps the
+// 100 MHz wall clock at its entry, in front of its K loop, behind it and at its exit
+#ifdef MNK_PHASE_CLOCKS
+__device__ unsigned long long mnk_phase_log[4 * 16384];
+#define MNK_PHASE(i)                                                                                              \
+    do {                                                                                                          \
+        const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                    \
+        if (threadIdx.x == 0 && lin__ < 16384u) mnk_phase_log[4 * lin__ + (i)] = wall_clock64();                  \
+    } while (0)
+#else
+#define MNK_PHASE(i) ((void)0)
+#endif
+
 template <int BM, int BN, int WM, int WN, int MODE>     // MODE: 0 generic loader, 1 / 2 the 3x3 fast loader (plain / x2 up-sampled)
 __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvArgs a) {
+    MNK_PHASE(0);
     constexpr int RA = BM / 64;               // A rows per thread per K step
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     // A wave that owns ONE 32x32 tile would run all its MFMAs as one dependent chain on one accumulator: an MFMA that follows
@@ -513,6 +527,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     }
     if (NST == 2) MNK_WAIT_VMEM();            // exact wait counts inside the loop (see the macro)
     __syncthreads();
+    MNK_PHASE(1);
     int s = 0;
     if constexpr (NST == 2) {
         for (; s + 4 < n; s += 2) {
@@ -555,6 +570,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
             __syncthreads();                  // (the last one: the epilogue reuses As for the column sums)
         }
     }
+    MNK_PHASE(2);
     if constexpr (NACC == 2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[1][0][0][r];
@@ -655,6 +671,10 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
             sp[a.ld_y + n0 + t] = t2;
         }
     }
+#ifdef MNK_PHASE_CLOCKS
+    __builtin_amdgcn_s_waitcnt(0);            // the output stores of this wave have left (vmcnt / lgkmcnt / expcnt = 0)
+#endif
+    MNK_PHASE(3);
 }
 
 // ---- narrow-output variant on v_mfma_f32_16x16x4_f32 -----------------------------------------------------------
@@ -3617,3 +3637,15 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int flags, const float* d
                             stream);
 }
 }
+
+#ifdef MNK_PHASE_CLOCKS
+extern "C" int mnk_phase_log_read(void* host, size_t bytes, int clear) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(mnk_phase_log), bytes) != hipSuccess) return MNK_ELAUNCH;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(mnk_phase_log)) != hipSuccess) return MNK_ELAUNCH;
+        if (hipMemset(p, 0, sizeof(unsigned long long) * 4 * 16384) != hipSuccess) return MNK_ELAUNCH;
+    }
+    return MNK_OK;
+}
+#endif

@@ -20,6 +20,9 @@ KNOBS = {
                                "shape at the end of backward (0: one launch per layer during backward)"),
     "MNK_WGRAD_BG": ("10", "eager iterations: giga-MACs of recorded weight-gradient GEMMs after which they are launched on a second "
                            "stream during backward (0: all of them at the end, as a captured iteration always does)"),
+    "MNK_REPLAY_STREAMS": ("0", "captured iteration of one process: 0 = hipGraphLaunch; n >= 1 = the library's stream executor "
+                                "(csrc/replay.hip) on at most n streams; n >= 2 also keeps the background weight-gradient "
+                                "launches of the backward pass as a branch of the captured graph"),
     "MNK_ADAM_TAP_DIRECT": ("1", "captured iteration of one process: the optimiser kernel reads the gradients of the few-split "
                                  "tap-major layers from their partials (no reduction pass for them; p.grad of those parameters "
                                  "is not written)"),
