@@ -2351,6 +2351,20 @@ static int g_plan_table = tuning_knob("plan_table", &g_plan_table, 1), g_force_b
            g_force_bn = tuning_knob("force_bn", &g_force_bn, 0), g_force_splits = tuning_knob("force_splits", &g_force_splits, 0);
 static long g_last_plan[8];
 
+// ---- occupancy shaping: bytes of (unused) dynamic LDS that make exactly ceil(blocks / CUs) blocks of a launch fit a CU.
+// gfx950: 256 CUs, 160 KB of LDS per CU, 64 KB per workgroup.  0 when the launch is more than one generation anyway (> 7 per
+// CU), when one block per CU would be the target (> 80 KB: over the workgroup limit; the dispatcher spreads those evenly
+// already) or when the kernel's own LDS is at / above the target.
+static int g_occ_shape = tuning_knob("occ_shape", &g_occ_shape, 1);
+static unsigned shaped_dynamic_lds(long blocks, int static_lds) {
+    if (!g_occ_shape) return 0;
+    const long per = (blocks + 255) / 256;
+    if (per < 2 || per > 7) return 0;
+    static const int target[8] = {0, 0, 61440, 53248, 39936, 31744, 26624, 22528};     // floor(160 KB / target) == per
+    const int t = target[per];
+    return t > static_lds ? (unsigned)(t - static_lds) : 0u;
+}
+
 // block tiles the GEMM kernels are instantiated for (conv2d_fwd_impl's dispatch)
 static bool plan_tile_ok(int bm, int bn, int Cout, int phases) {
     if (bn == 16 || bn == 48) return bm == 128 && phases == 1 && g_mfma16 && Cout <= bn;
@@ -2853,10 +2867,18 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
         // the roofline kernel is timed by its own begin / end stamps (bench.py `roofline`, agrees with rocprofv3)
         hipEvent_t ev0, ev1;
         const bool timed = prof.kernel_events(&ev0, &ev1);
-#define MNK_IGEMM_MODE(KERNEL, MODE, ...)                                                                     \
-    do {                                                                                                      \
-        if (timed) hipExtLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), 0, s, ev0, ev1, 0, a); \
-        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), 0, s, a);                       \
+        // occupancy shaping (round 4, tools/phase_probe.py): most layers of this network are ONE generation of blocks -- e.g.
+        // 1024 tiles on 256 CUs -- and a CU holds up to seven 20 KB blocks, so the dispatcher is free to put five or six on one
+        // CU and two on another; the block clocks showed K loops of 28 .. 44 us inside one launch (the launch ends with its most
+        // crowded CU) against 30 .. 31 us where every CU got one block.  Padding a block's LDS request with unused dynamic LDS so
+        // that exactly ceil(blocks / CUs) blocks fit a CU forces the even distribution.
+        const long nblocks = (long)grid.x * grid.y * grid.z;
+        const int static_lds = (p.bn == 16 ? 23040 : p.bn == 48 ? 28160 : (p.bm + p.bn) * 2 * LDS_K * 4);
+        const unsigned dyn = shaped_dynamic_lds(nblocks, static_lds);
+#define MNK_IGEMM_MODE(KERNEL, MODE, ...)                                                                       \
+    do {                                                                                                        \
+        if (timed) hipExtLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, ev0, ev1, 0, a); \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, a);                       \
     } while (0)
 #define MNK_IGEMM(KERNEL, ...)                                      \
     do {                                                            \

@@ -29,6 +29,9 @@ using namespace mnk;
 namespace {
 
 constexpr int MAX_STREAMS = 8;
+// 1: side streams are created with the lowest stream priority (the caller's chain -- the critical path -- gets the free
+// workgroup slots first)
+int g_side_priority = tuning_knob("replay_side_priority", &g_side_priority, 0);
 
 struct RNode {
     hipGraphNodeType type;
@@ -303,7 +306,11 @@ int mnk_replay_create(void* hip_graph, int max_streams, void** handle_out) {
         }
     }
     for (int s = 1; s < P->nstreams; ++s) {
-        if (hipStreamCreateWithFlags(&P->side[s], hipStreamNonBlocking) != hipSuccess) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const hipError_t se = g_side_priority ? hipStreamCreateWithPriority(&P->side[s], hipStreamNonBlocking, least)
+                                              : hipStreamCreateWithFlags(&P->side[s], hipStreamNonBlocking);
+        if (se != hipSuccess) {
             set_error("mnk_replay_create: hipStreamCreate failed");
             delete P;
             return MNK_ELAUNCH;

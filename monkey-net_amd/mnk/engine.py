@@ -33,7 +33,8 @@ def joined_kp(kp_detector, x):
     if vid.shape[2] != 1 or src.shape[2] != 1:
         return kp_detector(torch.cat([src, vid], dim=2))
     b = src.shape[0]
-    kp = kp_detector(torch.cat([src, vid], dim=0))
+    kp = kp_detector(mops.StackedBatch(src, vid) if src.is_contiguous() and vid.is_contiguous()
+                     else torch.cat([src, vid], dim=0))
     return {k: v.view(2, b, *v.shape[2:]).transpose(0, 1) for k, v in kp.items()}
 
 
@@ -68,7 +69,7 @@ def fused_pair_losses(discriminator, fake, real, kp_dict, video_deformed, loss_w
             act, taps[i + 1] = mops.PairL1TapFn.apply(act, c, b, float(rec[i + 1]))
         return act
 
-    acts, score = discriminator.forward_acts(torch.cat([fake, real], dim=0), **kp_dict, tap=tap)
+    acts, score = discriminator.forward_acts(mops.StackedBatch(fake, real), **kp_dict, tap=tap)
     g_values = []
     if w['reconstruction_deformed'] != 0:
         g_values.append(mops.L1MeanFn.apply(real, video_deformed, w['reconstruction_deformed']))

@@ -92,6 +92,53 @@ class ToActFn(torch.autograd.Function):
         return out, None
 
 
+class StackedBatch:
+    """[a ; b] along the batch axis of two (B,C,D,H,W) tensors WITHOUT the concatenation: the only consumer of such a stack in
+    the training iteration is the conversion to the kernels' layout (train.py:27 / :43-45 -> to_act), which writes the two
+    halves of one act itself (ToActPairFn) -- torch.cat of contiguous tensors along dim 0 is two device-to-device memcpy
+    launches in front of that conversion."""
+
+    def __init__(self, a, b):
+        assert a.shape == b.shape and a.dim() == 5
+        self.parts = (a, b)
+        self.shape = torch.Size((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]))
+        self.device = a.device
+
+    def __getitem__(self, idx):
+        b = self.parts[0].shape[0]
+        if isinstance(idx, slice) and idx.start in (None, 0) and idx.step is None and idx.stop == b:
+            return self.parts[0]
+        return torch.cat(self.parts, dim=0)[idx]
+
+
+class ToActPairFn(torch.autograd.Function):
+    """ToActFn of StackedBatch(a, b): one act, its two halves written by one conversion launch each."""
+
+    @staticmethod
+    def forward(ctx, a5, b5, step):
+        _check_device(a5)
+        a5, b5 = a5.contiguous().float(), b5.contiguous().float()
+        b, c, d, h, w = a5.shape
+        out = torch.empty(2 * b * d, h // step, w // step, ceil4(c), dtype=torch.float32, device=a5.device)
+        for i, src in enumerate((a5, b5)):
+            _call("mnk_ncdhw_to_nhwc", src, _p(src), _p(out[i * b * d:]), b, c, d, h, w, step, ceil4(c))
+        ctx.meta = (b, c, d, h, w, step)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, c, d, h, w, step = ctx.meta
+        if step != 1:
+            raise NotImplementedError("gradient w.r.t. a down-scaled input image is never consumed by the reference")
+        g = g.contiguous()
+        outs = [None, None]
+        for i in range(2):
+            if ctx.needs_input_grad[i]:
+                outs[i] = torch.empty(b, c, d, h, w, dtype=torch.float32, device=g.device)
+                _call("mnk_nhwc_to_ncdhw", g, _p(g[i * b * d:]), g.shape[-1], _p(outs[i]), b, c, d, h, w)
+        return outs[0], outs[1], None
+
+
 class FromActFn(torch.autograd.Function):
     """act -> (B,C,D,H,W)."""
 
@@ -1525,6 +1572,8 @@ class WarpAllFn(torch.autograd.Function):
 
 # convenience wrappers ---------------------------------------------------------------------------------------------
 def to_act(x5, step=1):
+    if isinstance(x5, StackedBatch):
+        return ToActPairFn.apply(x5.parts[0], x5.parts[1], step)
     return ToActFn.apply(x5, int(step))
 
 
