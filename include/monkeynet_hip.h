@@ -45,6 +45,9 @@ int mnk_prof_num_kernels(void);
 const char* mnk_prof_kernel_name(int kernel_id);
 /* launches, summed milliseconds and summed algorithmic work (FLOP for MFMA kernels, bytes otherwise) */
 int mnk_prof_query(int kernel_id, uint64_t* launches, double* total_ms, double* total_work);
+/* the work the launches of the group actually issued (2 x multiply-adds of the form that ran: a sub-pixel form of an up-sampled
+ * 3x3 convolution issues 4/9 of the algorithmic figure mnk_prof_query reports; equal to it for every other kernel) */
+int mnk_prof_query_executed(int kernel_id, double* executed_work);
 
 /* ---- layout --------------------------------------------------------------------------------------------
  * (B,C,D,H,W) <-> folded NHWC.  `step` > 1 applies the nearest down-scaling F.interpolate(scale_factor=

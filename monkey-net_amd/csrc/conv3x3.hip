@@ -63,6 +63,7 @@ struct ConvArgs {
     int ldw;
     float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
     int xcd;           // re-chunk the launch order per XCD (xcd_tile)
+    int nt;            // write the output with non-temporal stores (tuning value "igemm_nt_store")
     int clean;         // the sources' pad channels [C, ld) hold zeros (finite values): the 3x3 fast loader may be used
     unsigned mulW, shW, mulH, shH;   // division of an output pixel index (< 2^31) by W and H (fast_div)
     // ---- K x K loader generalisations (ActLoaderK) ---------------------------------------------------------------
@@ -629,10 +630,11 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
                         float v = acc[0][i][j][r];
                         if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
                         if (FULL || mb + ro < Mu) {
-                            if (scatter)
-                                obase[out_row(mb + ro) * ldo + (unsigned)co] = v;
+                            float* const dst = scatter ? obase + out_row(mb + ro) * ldo + (unsigned)co : obase + off0 + ro * ldo;
+                            if (a.nt)
+                                MNK_NT_STORE(v, dst);
                             else
-                                obase[off0 + ro * ldo] = v;
+                                *dst = v;
                             s1[j] += v;
                             s2[j] = fmaf(v, v, s2[j]);
                         }
@@ -2339,6 +2341,7 @@ static int g_xcd_remap = tuning_knob("xcd_remap", &g_xcd_remap, 1);
 static int g_fast_loader = tuning_knob("fast_loader", &g_fast_loader, 1);
 static int g_kxk_fast = tuning_knob("kxk_fast", &g_kxk_fast, 1);     // buffer-load loader for K x K / any pad (MODE 3)
 static int g_mfma16 = tuning_knob("mfma16", &g_mfma16, 1);
+static int g_igemm_nt = tuning_knob("igemm_nt_store", &g_igemm_nt, 0);   // non-temporal stores of the 32x32-tile kernel's output
 
 struct PlanRow {
     long M;
@@ -2350,20 +2353,6 @@ static const PlanRow g_tuned_rows[] = {
 static int g_plan_table = tuning_knob("plan_table", &g_plan_table, 1), g_force_bm = tuning_knob("force_bm", &g_force_bm, 0),
            g_force_bn = tuning_knob("force_bn", &g_force_bn, 0), g_force_splits = tuning_knob("force_splits", &g_force_splits, 0);
 static long g_last_plan[8];
-
-// ---- occupancy shaping: bytes of (unused) dynamic LDS that make exactly ceil(blocks / CUs) blocks of a launch fit a CU.
-// gfx950: 256 CUs, 160 KB of LDS per CU, 64 KB per workgroup.  0 when the launch is more than one generation anyway (> 7 per
-// CU), when one block per CU would be the target (> 80 KB: over the workgroup limit; the dispatcher spreads those evenly
-// already) or when the kernel's own LDS is at / above the target.
-static int g_occ_shape = tuning_knob("occ_shape", &g_occ_shape, 1);
-static unsigned shaped_dynamic_lds(long blocks, int static_lds) {
-    if (!g_occ_shape) return 0;
-    const long per = (blocks + 255) / 256;
-    if (per < 2 || per > 7) return 0;
-    static const int target[8] = {0, 0, 61440, 53248, 39936, 31744, 26624, 22528};     // floor(160 KB / target) == per
-    const int t = target[per];
-    return t > static_lds ? (unsigned)(t - static_lds) : 0u;
-}
 
 // block tiles the GEMM kernels are instantiated for (conv2d_fwd_impl's dispatch)
 static bool plan_tile_ok(int bm, int bn, int Cout, int phases) {
@@ -2835,6 +2824,7 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
     a.ldw = p.ldw;
     a.stats = stats_partial;
     a.xcd = g_xcd_remap;
+    a.nt = g_igemm_nt;
     MNK_REQUIRE(!stats_partial || (ld_y == round_up(Cout, 4) && (p.splits == 1 || (g_splitk_stats && !defer_splitk))));
     if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * phases * a.M * p.ldw)) {
         set_error("mnk_conv2d_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * phases * a.M * p.ldw);
@@ -2848,7 +2838,8 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
         const double alg = phases == 4 ? 2.0 * 4.0 * (double)a.M * Cout * 9.0 * (C0 + C1)
                                        : (stride == 2 ? 2.0 * 4.0 * (double)a.M * Cout * 9.0 * (C0 + C1)
                                                       : 2.0 * (double)a.M * Cout * (double)ntaps * (C0 + C1));
-        ProfScope prof(K_CONV_FWD, s, alg);
+        // what the launch issues: the sub-pixel forms run 4 (forward) / 16 at a quarter of the pixels (data gradient) taps
+        ProfScope prof(K_CONV_FWD, s, alg, 2.0 * (double)a.M * phases * Cout * (double)ntaps * (C0 + C1));
         // loader: the 3x3 / pad 1 fast form when the caller vouches for clean pad channels and a block's pixel span
         // fits the 2^30-byte buffer window (always, short of ~2 M-float pixel rows)
         const long span = ((long)BK * 8 + 3L * (ups ? Wi / 2 : Wi) + 8) * (ld0 > ld1 ? ld0 : ld1) * 4;
@@ -2867,14 +2858,10 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
         // the roofline kernel is timed by its own begin / end stamps (bench.py `roofline`, agrees with rocprofv3)
         hipEvent_t ev0, ev1;
         const bool timed = prof.kernel_events(&ev0, &ev1);
-        // occupancy shaping (round 4, tools/phase_probe.py): most layers of this network are ONE generation of blocks -- e.g.
-        // 1024 tiles on 256 CUs -- and a CU holds up to seven 20 KB blocks, so the dispatcher is free to put five or six on one
-        // CU and two on another; the block clocks showed K loops of 28 .. 44 us inside one launch (the launch ends with its most
-        // crowded CU) against 30 .. 31 us where every CU got one block.  Padding a block's LDS request with unused dynamic LDS so
-        // that exactly ceil(blocks / CUs) blocks fit a CU forces the even distribution.
-        const long nblocks = (long)grid.x * grid.y * grid.z;
-        const int static_lds = (p.bn == 16 ? 23040 : p.bn == 48 ? 28160 : (p.bm + p.bn) * 2 * LDS_K * 4);
-        const unsigned dyn = shaped_dynamic_lds(nblocks, static_lds);
+        // (padding a block's LDS request so that exactly ceil(blocks / CUs) blocks fit a CU was built and measured in round 4: the
+        // dispatcher already puts 1024 blocks on 256 CUs four by four -- tools/microbench/launch_gap.hip (e) -- and the step did
+        // not move, 10.33 vs 10.32 ms: removed.  profiles/r04_knob_ab_log.txt)
+        const unsigned dyn = 0;
 #define MNK_IGEMM_MODE(KERNEL, MODE, ...)                                                                       \
     do {                                                                                                        \
         if (timed) hipExtLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, ev0, ev1, 0, a); \
@@ -3007,7 +2994,8 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
             hipStream_t st = (hipStream_t)stream;
             dim3 grid(up.gm, up.gn * 16, up.splits);
             {
-                ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)N * Ho * Wo * Cout * 9.0 * C);
+                ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)N * Ho * Wo * Cout * 9.0 * C,
+                               2.0 * (double)g.M * Cout * 16.0 * C);        // 16 pseudo taps at the low resolution
                 if (up.bm == 128 && up.bn == 128)
                     hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
                 else if (up.bm == 128)
@@ -3478,12 +3466,13 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
     for (int v = 0; v < 16; ++v) {
         const int cnt = hd->count[v], blocks = hd->blocks[v];
         if (!cnt) continue;
-        double flop = 0.0;
+        double flop = 0.0, issued = 0.0;
         for (int i = 0; i < cnt; ++i) {
             const WgradTapArgs& g = hrecs[hd->first[v] + i].a;      // algorithmic: the sub-pixel form stands for 9 taps at 4 M pixels
             flop += v % 4 == 3 ? 2.0 * 4.0 * (double)g.M * g.Cout * 9.0 * g.C : 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
+            issued += 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
         }
-        ProfScope prof(K_CONV_WGRAD, st, flop);
+        ProfScope prof(K_CONV_WGRAD, st, flop, issued);
         const TapJobRec* rv = drecs + hd->first[v];
         const int mode = v % 4;
 #define MNK_WGROUP(...)                                                                                                        \

@@ -753,14 +753,17 @@ __global__ void __launch_bounds__(256) heatmap_argmax_kernel(const float* __rest
 }
 
 // kp_pixel_index: the pixel a key point is drawn at -- floor(size * (mean + 1) / 2) per axis, the mapping of
-// Visualizer.draw_video_with_kp (logger.py:99-100: `spatial_size * (kp_array + 1) / 2`, then rasterised), evaluated in the
-// reference's operation order in fp32
+// Visualizer.draw_video_with_kp (logger.py:99-100: `spatial_size * (kp_array + 1) / 2`, then rasterised), in numpy's
+// arithmetic: `kp_array + 1` stays float32 (a float32 array plus a Python int), the int64 `spatial_size` array times that
+// float32 array is promoted to float64, and so is the division.  (For frame sizes that are powers of two the fp32 product is
+// exact and both orders agree; for e.g. 96 x 80 frames an fp32 product can round across a cell boundary.)
 __global__ void __launch_bounds__(256) kp_pixel_index_kernel(const float* __restrict__ mean, long n, int W, int H,
                                                              int* __restrict__ pixel) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= 2 * n) return;
-    const float size = (i & 1) ? (float)H : (float)W;
-    pixel[i] = (int)floorf(size * (mean[i] + 1.f) / 2.f);
+    const double size = (i & 1) ? (double)H : (double)W;
+    const float t = mean[i] + 1.f;
+    pixel[i] = (int)floor(size * (double)t / 2.0);
 }
 
 }  // namespace

@@ -30,6 +30,13 @@
 #define MNK_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 #endif
 
+// non-temporal store (streams past the caches; a plain store on the emulator)
+#ifdef HIPEMU
+#define MNK_NT_STORE(v, p) (*(p) = (v))
+#else
+#define MNK_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 namespace mnk {
 
 void set_error(const char* fmt, ...);
@@ -57,7 +64,10 @@ enum KernelId {
 
 // RAII scope: when profiling is on, brackets the launches issued inside it with two HIP events on `stream`.
 struct ProfScope {
-    ProfScope(int kid, hipStream_t stream, double work);
+    // work: ALGORITHMIC FLOPs (MFMA kernels: those of the reference's convolution, whatever form computes it) or bytes;
+    // executed: the multiply-adds the launch actually issues x 2 (sub-pixel forms of an up-sampled 3x3 convolution: 4/9 of the
+    // algorithmic figure); < 0: the same as `work`
+    ProfScope(int kid, hipStream_t stream, double work, double executed = -1.0);
     ~ProfScope();
     // For a scope that holds exactly ONE launch: the two events to hand to hipExtLaunchKernelGGL, which stamps them with
     // the kernel's own begin / end (what rocprofv3 reports) instead of the stream positions around the launch, which

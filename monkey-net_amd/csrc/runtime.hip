@@ -51,13 +51,13 @@ static const char* kNames[K_NUM] = {"conv3x3_igemm", "conv3x3_wgrad", "conv3x3_r
 struct ProfRec {
     int kid;
     hipEvent_t a, b;
-    double work;
+    double work, executed;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static uint64_t g_launches[K_NUM];
-static double g_ms[K_NUM], g_work[K_NUM];
+static double g_ms[K_NUM], g_work[K_NUM], g_executed[K_NUM];
 
 static hipEvent_t get_event() {
     if (!g_pool.empty()) {
@@ -70,9 +70,10 @@ static hipEvent_t get_event() {
     return e;
 }
 
-ProfScope::ProfScope(int kid_, hipStream_t stream_, double work) : kid(kid_), stream(stream_), slot(-1), ext(false) {
+ProfScope::ProfScope(int kid_, hipStream_t stream_, double work, double executed)
+    : kid(kid_), stream(stream_), slot(-1), ext(false) {
     if (!g_prof_on) return;
-    ProfRec r{kid, get_event(), get_event(), work};
+    ProfRec r{kid, get_event(), get_event(), work, executed < 0.0 ? work : executed};
     (void)hipEventRecord(r.a, stream);
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
@@ -97,6 +98,7 @@ static void drain() {
         g_launches[r.kid] += 1;
         g_ms[r.kid] += ms;
         g_work[r.kid] += r.work;
+        g_executed[r.kid] += r.executed;
         g_pool.push_back(r.a);
         g_pool.push_back(r.b);
     }
@@ -167,6 +169,7 @@ int mnk_prof_reset(void) {
         mnk::g_launches[i] = 0;
         mnk::g_ms[i] = 0;
         mnk::g_work[i] = 0;
+        mnk::g_executed[i] = 0;
     }
     return MNK_OK;
 }
@@ -178,6 +181,12 @@ int mnk_prof_query(int k, uint64_t* launches, double* total_ms, double* total_wo
     if (launches) *launches = mnk::g_launches[k];
     if (total_ms) *total_ms = mnk::g_ms[k];
     if (total_work) *total_work = mnk::g_work[k];
+    return MNK_OK;
+}
+int mnk_prof_query_executed(int k, double* executed_work) {
+    MNK_REQUIRE(k >= 0 && k < mnk::K_NUM && executed_work);
+    mnk::drain();
+    *executed_work = mnk::g_executed[k];
     return MNK_OK;
 }
 }

@@ -35,6 +35,11 @@ def joined_kp(kp_detector, x):
     b = src.shape[0]
     kp = kp_detector(mops.StackedBatch(src, vid) if src.is_contiguous() and vid.is_contiguous()
                      else torch.cat([src, vid], dim=0))
+    # the detector saw 2B one-frame samples [all sources | all drivings]: keypoint_indices() of this call must hand its
+    # heat-map arg-max out in the (B, 2, K) layout of the key points returned here
+    if getattr(kp_detector, "_last_heat", None) is not None:
+        heat, k, _, _ = kp_detector._last_heat
+        kp_detector._last_heat = (heat, k, b, 2, True)
     return {k: v.view(2, b, *v.shape[2:]).transpose(0, 1) for k, v in kp.items()}
 
 
@@ -393,9 +398,13 @@ class TrainStep:
 
     def _eager_step(self, x, set_to_none=True):
         b = int(x['source'].shape[0])
-        if b != self._shard_checked and mdist.initialized() and not (
-                x['source'].is_cuda and torch.cuda.is_current_stream_capturing()):
-            mdist.check_equal_shards(b)       # count = local * world (SyncBN) and the 1 / world gradient scale need equal shards
+        # count = local * world (SyncBN) and the 1 / world gradient scale need equal shards.  The check is a collective, so the
+        # decision to enter it must not depend on this rank's own history: EVERY eager iteration of a process group checks (a
+        # rank whose batch did not change would otherwise walk into the SyncBN collectives while another rank sits in this
+        # one -- a hang instead of the ValueError).  One 8-byte MAX-reduce per eager iteration; a captured
+        # iteration is checked when it is captured (its batch size is frozen with the graph).
+        if mdist.initialized() and not (x['source'].is_cuda and torch.cuda.is_current_stream_capturing()):
+            mdist.check_equal_shards(b)
             self._shard_checked = b
         self._weights_touched = False
         if knobs.on("MNK_DISC_SHARED"):

@@ -132,7 +132,12 @@ class DeferredReducer:
         return rec
 
     def wgrad(self, weight, x, ld_x, c, flags, hi, wi, kh, kw, pad, dy, ld_dy, cout, cin_total, c_start, n, ho, wo):
-        """d(weight)[:, c_start:c_start+c] towards the owner's sink of `weight`; True when taken."""
+        """d(weight)[:, c_start:c_start+c] towards the owner's sink of `weight`; True when taken.
+        INVARIANT (background launches, MNK_WGRAD_BG): the recorded operands `x` and `dy` are read by GEMMs that may run on a
+        second stream while the backward pass continues on the main one -- nothing later in that backward pass may write
+        these two buffers in place (no kernel of this package does: every epilogue writes a fresh tensor), and they stay
+        referenced until _join() has made the main stream wait for the side stream (flush() / drop()).
+        tests/test_step.py::test_background_weight_gradients_equal_the_in_order_ones pins bit-equality of the two orders."""
         own = self.owner
         sink = own.sink(weight)
         key = (id(weight), c_start)
@@ -165,8 +170,10 @@ class DeferredReducer:
         if not self.owner.tap_direct:
             return False
         r = self.recs.get(key)
+        # C % 4 == 0: only the layers mnk_wgrad_reduce_multi sums with its flat map -- (s0 + s1) + s2 in split order, the order
+        # the optimiser kernel's direct read uses; the tile map of the other layers adds (s0 + s2) + s1, an ulp apart
         return (r is not None and r["grouped"] and 1 <= r["splits"] <= 3 and r["row"][2] in (0, 2) and r["row"][4] == 9
-                and r["direct_ok"] and key not in self.multi)
+                and r["row"][6] % 4 == 0 and r["direct_ok"] and key not in self.multi)
 
     def _launch_grouped(self, background=False):
         jobs, self.jobs = self.jobs, []

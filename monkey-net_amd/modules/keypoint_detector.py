@@ -90,7 +90,14 @@ class KPDetector(nn.Module):
         "bit-exact keypoint indices"): {'pixel': (B,D,K,2) int32 = floor(size * (mean + 1) / 2), the pixel the reference's
         Visualizer draws the key point at (logger.py:99-100), for frames of `frame_size` = (W, H) (default: the heat-map's
         own size); 'argmax': (B,D,K) int32, h * W + w of the largest heat-map value (keypoint_detector.py:103-104)}."""
-        heat, k, b, d = self._last_heat
+        heat, k, b, d = self._last_heat[:4]
         n, h, w, _ = heat.shape
         size = (w, h) if frame_size is None else frame_size
-        return {'pixel': ops.kp_pixel_index(kp['mean'], size), 'argmax': ops.heatmap_argmax(heat, k).view(b, d, k)}
+        am = ops.heatmap_argmax(heat, k)
+        if len(self._last_heat) > 4 and self._last_heat[4]:
+            # mnk.engine.joined_kp ran the detector on [sources | drivings] stacked along the batch axis and returned the key
+            # points as (B, 2, K, .): the same re-layout for the arg-max of that call
+            am = am.view(d, b, k).transpose(0, 1)
+        else:
+            am = am.view(b, d, k)
+        return {'pixel': ops.kp_pixel_index(kp['mean'], size), 'argmax': am}

@@ -9,6 +9,10 @@
 * <config>_allgrads.pt -- the same per-parameter norm / sample / spread records for the batch-2 module cases of
   oracle/make_golden.py (taichi, moving-gif, bair, vox@128), which keep one full gradient per sub-network.
 * vox256.pt -- config/vox.yaml at its native 256x256 (BASELINE configs[3]), batch 2, compact form + per-parameter records.
+* vox256_b8.pt -- the same at batch 8, the per-GPU share of BASELINE configs[3] that bench.py's vox line is quoted on.
+* fullstep_<config>_b32_params.pt -- the full iteration WITH the reference's three Adam steps: a 64-element sample of every
+  parameter after its step (fp32 and fp64 runs) -- what the benchmarked pipeline (deferred weight gradients -> one reduction
+  -> mnk_adam_multi, captured as a hipGraph) is compared with directly.
 * infer_bair_b512.pt -- bair.yaml eval forward at batch 512 (BASELINE configs[4]): reconstruction L1 (reconstruction.py:74),
   key-points, every 16th frame.
 The restatement is re-pinned on the way (fp64, same tolerances as make_golden.py).  TEST INFRASTRUCTURE ONLY."""
@@ -98,6 +102,92 @@ def fullstep(ref, name="fullstep_moving-gif_b32", cfg_name="moving-gif", batch=3
     save(name, out)
 
 
+def fullstep_params(ref, name="fullstep_moving-gif_b32", cfg_name="moving-gif", batch=32, size=64):
+    """<name>_params.pt -- the SAME iteration as fullstep() with the reference's three optimisers in the loop (train.py:81-83:
+    torch.optim.Adam(lr, betas=(0.5, 0.999)); the statement order of train.py:110-136): for every parameter of the three
+    networks a 64-element sample AFTER its Adam step, from the reference's fp32 and fp64 runs, next to the same sample
+    before the step.  Adam's first update is sign-like (-lr * g / (|g| + eps)): an element moves by lr whatever |g| is, and
+    two correct implementations differ by 2 lr exactly where a gradient element's sign is decided by rounding -- the
+    reference's own fp32-vs-fp64 disagreement on the sample is recorded as the yard-stick."""
+    cfg = copy.deepcopy(cases.TINY) if cfg_name == "tiny" else load_cfg(cfg_name)
+    tp = cfg["train_params"]
+    src, drv = cases.synthetic_pair(batch, size, size)
+    res = {}
+    for dtype in (torch.float32, torch.float64):
+        t0 = time.time()
+        gen, disc, kpd, _ = build_reference(ref, cfg)
+        mods = {"generator": gen, "discriminator": disc, "kp_detector": kpd}
+        for m in mods.values():
+            m.to(dtype).train()
+        before = {n: {k: p.detach().double().reshape(-1)[sample_index(p.numel())].clone() for k, p in m.named_parameters()}
+                  for n, m in mods.items()}
+        opts = {n: torch.optim.Adam(m.parameters(), lr=tp["lr"], betas=(0.5, 0.999)) for n, m in mods.items()}
+        x = {"source": src.to(dtype), "video": drv.to(dtype)}
+        gfull = ref.GeneratorFullModel(kpd, gen, disc, tp)
+        dfull = ref.DiscriminatorFullModel(kpd, gen, disc, tp)
+        outs = gfull(x)                                                          # train.py:110
+        lv = [v.mean() for v in outs[:-2]]
+        generated, kp_joined = outs[-2], outs[-1]
+        sum(lv).backward(retain_graph=not tp["detach_kp_discriminator"])         # :117
+        opts["generator"].step(), opts["generator"].zero_grad(), opts["discriminator"].zero_grad()     # :118-120
+        if tp["detach_kp_discriminator"]:
+            opts["kp_detector"].step(), opts["kp_detector"].zero_grad()          # :121-123
+        dl = [v.mean() for v in dfull(x, kp_joined, generated)]                  # :127
+        sum(dl).backward()
+        opts["discriminator"].step(), opts["discriminator"].zero_grad()          # :131-133
+        if not tp["detach_kp_discriminator"]:
+            opts["kp_detector"].step(), opts["kp_detector"].zero_grad()          # :134-136
+        after = {n: {k: p.detach().double().reshape(-1)[sample_index(p.numel())].clone() for k, p in m.named_parameters()}
+                 for n, m in mods.items()}
+        numels = {n: {k: p.numel() for k, p in m.named_parameters()} for n, m in mods.items()}
+        res[dtype] = (before, after, [float(v) for v in lv + dl])
+        print("fullstep_params %s %s: %.1f s" % (name, dtype, time.time() - t0), flush=True)
+    (b32, a32, l32), (b64, a64, l64) = res[torch.float32], res[torch.float64]
+    out = {"cfg": cfg, "batch": batch, "size": size, "lr": tp["lr"], "losses32": l32, "losses64": l64, "params": {}}
+    for n in a64:
+        out["params"][n] = {}
+        for k in a64[n]:
+            out["params"][n][k] = {"before": b64[n][k].float(), "after32": a32[n][k].float(), "after64": a64[n][k].float(),
+                                   "numel": int(numels[n][k])}
+    flat32 = torch.cat([v["after32"].double() - v["after64"].double() for d in out["params"].values() for v in d.values()])
+    out["ref32_vs_ref64_mean_abs"] = float(flat32.abs().mean())
+    out["ref32_vs_ref64_frac_differs"] = float((flat32.abs() > 1e-7).double().mean())
+    print("fullstep_params %s: reference fp32 vs fp64 after one Adam step: mean |diff| %.3e, %.2f %% of the sampled elements "
+          "differ by more than 1e-7" % (name, out["ref32_vs_ref64_mean_abs"], 100 * out["ref32_vs_ref64_frac_differs"]),
+          flush=True)
+    save(name + "_params", out)
+
+
+def slim_vox256_b8(gold, stride=2):
+    """38 MB -> 7 MB: the loss weights are re-made from their seed by the test (oracle/make_golden.py::module_case draws them
+    from torch.Generator().manual_seed(99)); the frames are kept at every `stride`-th pixel (the fp32-vs-fp64 spreads were taken
+    over the whole frames before)."""
+    if "loss_weights" in gold:
+        del gold["loss_weights"]
+        gold["loss_weights_seed"] = 99
+    if gold.get("frame_stride", 1) == 1:
+        for mode in ("train64", "eval64"):
+            for k in ("video_prediction", "video_deformed"):
+                gold[mode][k] = gold[mode][k][..., ::stride, ::stride].contiguous()
+        gold["frame_stride"] = stride
+
+
+def vox256_b8(ref):
+    """vox256_b8.pt -- config/vox.yaml at 256x256, batch 8: the per-GPU share of BASELINE configs[3] (batch 64 over 8 GPUs),
+    the size bench.py --config vox --size 256 --batch 8 is quoted on.  Same compact form as vox256.pt (batch 2)."""
+    from oracle.make_golden import module_case
+    cfg = load_cfg("vox")
+    t0 = time.time()
+    module_case(ref, "vox256_b8", cfg, batch=8, size=256, store_weights=False,
+                grad_keys=("encoder.down_blocks.0.conv.weight",), compact=True)
+    rec, _ = allgrads(ref, "vox", batch=8, size=256)
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "vox256_b8.pt"), weights_only=False)
+    gold["grad_records"] = rec
+    slim_vox256_b8(gold)
+    save("vox256_b8", gold)
+    print("vox256_b8: %.1f s" % (time.time() - t0), flush=True)
+
+
 def allgrads(ref, name, batch=2, size=64):
     """per-parameter records of the module case `name` of make_golden.py (same seeds, weights, inputs, loss)."""
     cfg = load_cfg(name)
@@ -160,7 +250,7 @@ def infer(ref, name="infer_bair_b512", batch=512, size=64, keep_every=16):
 def main():
     assert ref_shim.available(), "run this in the authoring container (needs /root/reference)"
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
-    what = set(sys.argv[1:]) or {"fullstep", "allgrads", "vox256", "infer"}
+    what = set(sys.argv[1:]) or {"fullstep", "allgrads", "vox256", "infer", "vox256_b8", "fullstep_params"}
     ref = ref_shim.load()
     if "fullstep" in what:
         fullstep(ref)
@@ -177,6 +267,12 @@ def main():
                   flush=True)
     if "vox256" in what:
         vox256(ref)
+    if "vox256_b8" in what:
+        vox256_b8(ref)
+    if "fullstep_params" in what:
+        fullstep_params(ref)
+        fullstep_params(ref, "fullstep_taichi_b32", "taichi", batch=32, size=64)
+        fullstep_params(ref, "fullstep_tiny_b4", "tiny", batch=4, size=32)
     if "infer" in what:
         infer(ref)
     with open(os.path.join(ROOT, "tests", "golden", "RESTATEMENT_REPORT_FULL.txt"), "a") as f:

@@ -29,10 +29,35 @@ from oracle import ref_shim, cases  # noqa: E402
 from oracle.make_golden import build_reference, load_cfg, save  # noqa: E402
 
 
+ALT_FRAME = (96, 80)     # a frame size that is not a power of two: the product size * (mean + 1) is not exact in fp32 there
+
+
 def pixel_index(mean, frame):
-    """logger.py:99-100 in the arithmetic of `mean`'s dtype: floor(spatial_size * (mean + 1) / 2), spatial_size = (W, H)."""
-    size = torch.tensor([frame[0], frame[1]], dtype=mean.dtype)
-    return torch.floor(size * (mean + 1) / 2).to(torch.int64)
+    """logger.py:99-100 `spatial_size * (kp_array + 1) / 2` in numpy's arithmetic: `kp_array + 1` stays in the key points'
+    dtype (an array plus a Python int), the int64 `spatial_size` array times a float32 array is promoted to float64, and so
+    is the division; then floor.  spatial_size = (W, H).  A pure function of the recorded means: `--patch` recomputes the
+    integer records of an existing tests/golden/kp_index.pt without running the reference again."""
+    size = torch.tensor([frame[0], frame[1]], dtype=torch.float64)
+    t = mean + 1
+    return torch.floor(size * t.double() / 2).to(torch.int64)
+
+
+def patch():
+    """re-derive pixel32 / pixel64 (numpy promotion) and add the ALT_FRAME records to the existing golden"""
+    path = os.path.join(ROOT, "tests", "golden", "kp_index.pt")
+    gold = torch.load(path, weights_only=False)
+    changed = 0
+    for name, g in gold.items():
+        if name.startswith("_"):
+            continue
+        for tag in ("32", "64"):
+            new = pixel_index(g["mean" + tag], g["frame"])
+            changed += int((new != g["pixel" + tag]).sum())
+            g["pixel" + tag] = new
+            g["pixel%s_alt" % tag] = pixel_index(g["mean" + tag], ALT_FRAME)
+        g["frame_alt"] = ALT_FRAME
+    print("patched %s: %d integer(s) changed by the float64 promotion; alt frame %s added" % (path, changed, ALT_FRAME))
+    save("kp_index", gold)
 
 
 def run_kp(kpd, frames, dtype, train):
@@ -60,9 +85,11 @@ def case(ref, cfg, frames, train, frame_size):
         out["mean" + tag] = mean
         out["argmax" + tag] = am
         out["pixel" + tag] = pixel_index(mean, frame_size)
+        out["pixel%s_alt" % tag] = pixel_index(mean, ALT_FRAME)
         if tag == "64":
             out["top2_gap64"] = gap
     out["frame"] = tuple(frame_size)
+    out["frame_alt"] = ALT_FRAME
     out["heat_hw"] = heat_hw
     return out
 
@@ -105,4 +132,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    patch() if "--patch" in sys.argv else main()

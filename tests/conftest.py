@@ -84,3 +84,11 @@ def be(request):
     yield b
     from mnk import _lib
     _util.set_library(None)
+
+
+@pytest.fixture
+def make_backend():
+    """Backend(kind) for tests that name their backends themselves (so that no gpu-marked instance of a test builds the CPU
+    emulator); the product's library handle is put back afterwards like `be` does."""
+    yield Backend
+    _util.set_library(None)

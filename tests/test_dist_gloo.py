@@ -59,6 +59,15 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
         raise AssertionError("unequal shards must be refused")
     except ValueError as e:
         assert "different numbers of samples" in str(e)
+    # the shard of ONE rank changes (a last partial batch): rank 0 keeps the batch size it was checked with, the
+    # others get one sample less.  The check must be entered by every rank -- all of them raise; before, rank 0 skipped the
+    # collective (its size was cached) and walked into the SyncBN all-reduces while the others sat in the check: a hang
+    xs = {k: (v if rank == 0 else v[:-1]).contiguous() for k, v in x.items()}
+    try:
+        step.step(xs)
+        raise AssertionError("a shard that changed on some ranks only must be refused on every rank")
+    except ValueError as e:
+        assert "different numbers of samples" in str(e)
     sums, count = mdist.combine_bn_stats(torch.tensor([1.0 * (rank + 1), 2.0]), 10)
     assert count == 10 * world and torch.equal(sums, torch.tensor([tri, 2.0 * world]))
     dist.destroy_process_group()

@@ -50,9 +50,42 @@ def test_heatmap_argmax_kernel(be, n, h, w, k, ld):
         assert int(idx[0, 1]) == 0
 
 
+def _numpy_pixel_index(mean, W, H):
+    """logger.py:99-100 as numpy evaluates it: float32 `kp_array + 1`, then int64 spatial_size * float32 -> float64, / 2"""
+    import numpy as np
+    kp = mean.numpy().astype(np.float32)
+    return torch.from_numpy(np.floor(np.array([W, H], dtype=np.int64)[np.newaxis] * (kp + 1) / 2).astype(np.int32))
+
+
+def test_kp_pixel_index_kernel_at_a_frame_size_that_is_not_a_power_of_two(be):
+    """96 x 80 frames: `size * (mean + 1)` is not exact in fp32 there, numpy's int64 * float32 -> float64 promotion
+    decides the cell; the kernel must follow numpy, not an all-fp32 evaluation"""
+    W, H = 96, 80
+    g = torch.Generator().manual_seed(5)
+    # positions a hair around every cell boundary + random ones
+    j = torch.arange(0, W, dtype=torch.float64)
+    on = torch.stack([-1 + 2 * j / W, -1 + 2 * (j % H) / H], dim=-1).float()
+    pts = [on]
+    for k in range(1, 4):
+        pts.append(torch.nextafter(pts[-1], torch.full_like(on, 2.0)))
+    low = on
+    for k in range(3):
+        low = torch.nextafter(low, torch.full_like(on, -2.0))
+        pts.append(low)
+    pts.append(torch.rand(4000, 2, generator=g) * 2.2 - 1.1)
+    mean = torch.cat(pts)
+    out = torch.empty(mean.shape, dtype=torch.int32, device=be.device)
+    be.call("mnk_kp_pixel_index", be.t(mean), mean.shape[0], W, H, out)
+    be.sync()
+    want = _numpy_pixel_index(mean, W, H)
+    assert torch.equal(out.cpu(), want)
+    fp32 = torch.floor(torch.tensor([W, H], dtype=torch.float32) * (mean + 1) / 2).to(torch.int32)
+    print("all-fp32 evaluation differs from numpy's on %d of %d positions" % (int((fp32 != want).sum()), want.numel()))
+
+
 def test_kp_pixel_index_kernel(be):
     """cell boundaries are exactly representable means (-1 + 2 j / W for W a power of two): index j there, j - 1 a little below;
-    one ulp below the boundary is whatever the reference's fp32 formula makes of it (`mean + 1` may round the ulp away)"""
+    one ulp below the boundary is whatever the reference's formula makes of it (`mean + 1` is float32 and may round the ulp away)"""
     W, H = 64, 32
     js = torch.arange(0, W, dtype=torch.float32)
     on = torch.stack([-1 + 2 * js / W, -1 + 2 * (js % H) / H], dim=-1)                   # exactly on a boundary
@@ -64,8 +97,7 @@ def test_kp_pixel_index_kernel(be):
     out = torch.empty(mean.shape, dtype=torch.int32, device=be.device)
     be.call("mnk_kp_pixel_index", be.t(mean), mean.shape[0], W, H, out)
     be.sync()
-    size = torch.tensor([W, H], dtype=torch.float32)
-    want = torch.floor(size * (mean + 1) / 2).to(torch.int32)                            # logger.py:99-100 in fp32
+    want = _numpy_pixel_index(mean, W, H)                                                # logger.py:99-100 as numpy evaluates it
     assert torch.equal(out.cpu(), want)
     assert torch.equal(out.cpu()[:W, 0], js.to(torch.int32))
     assert torch.equal(out.cpu()[2 * W:3 * W, 0], js.to(torch.int32) - 1)
@@ -127,6 +159,17 @@ def _check_case(be, name):
         name, int(bad.sum()), [(i, int(pixel[tuple(i)]), int(rec["pixel64"][tuple(i)]), float(dist[tuple(i)]))
                                for i in torch.nonzero(bad).tolist()[:4]])
     assert int((pixel - rec["pixel64"]).abs().max()) <= 1
+    # the same key points drawn on a frame whose size is not a power of two (96 x 80: the fp32 product is inexact there)
+    if "frame_alt" in rec:
+        alt = kpd.keypoint_indices(kp, frame_size=rec["frame_alt"])["pixel"].cpu().long()
+        fa = torch.tensor(rec["frame_alt"], dtype=torch.float64)
+        pa = fa * (rec["mean64"].double() + 1) / 2
+        near_a = (pa - torch.round(pa)).abs() < BOUNDARY_PX
+        bad_a = (alt != rec["pixel64_alt"]) & ~near_a
+        assert not bool(bad_a.any()), "%s: %d pixel indices on the %s frame differ from the reference away from a boundary" % (
+            name, int(bad_a.sum()), rec["frame_alt"])
+        assert int((alt - rec["pixel64_alt"]).abs().max()) <= 1
+        assert torch.equal(rec["pixel32_alt"], rec["pixel64_alt"]) or int((rec["pixel32_alt"] != rec["pixel64_alt"]).sum()) <= 4
     # ---- heat-map arg-max -----------------------------------------------------------------------------------------
     tie = rec["top2_gap64"] < TIE_LOGIT
     adiff = argmax != rec["argmax64"]

@@ -323,8 +323,9 @@ def test_down_block_with_fused_statistics(be):
     assert float((blk.norm.running_var.cpu().double() - ctx.new_stats["blk.norm.running_var"]).abs().max()) < 1e-5
 
 
-@pytest.mark.parametrize("cfg_name,size", [("tiny", 32), pytest.param("taichi", 64, marks=pytest.mark.gpu)])
-def test_discriminator_matches_oracle(be, cfg_name, size):
+@pytest.mark.parametrize("kind,cfg_name,size", [("emu", "tiny", 32), pytest.param("hip", "tiny", 32, marks=pytest.mark.gpu),
+                                                pytest.param("hip", "taichi", 64, marks=pytest.mark.gpu)])
+def test_discriminator_matches_oracle(make_backend, kind, cfg_name, size):
     """modules.discriminator: the gfx950-kernel Discriminator (4x4 no-pad convs, InstanceNorm, LeakyReLU, avg-pool, 1x1
     head) against oracle/restate.py::discriminator_forward in fp64: every returned feature map and all gradients
     (parameters, input frame, key-points)."""
@@ -333,8 +334,8 @@ def test_discriminator_matches_oracle(be, cfg_name, size):
     Discriminator = md.Discriminator
     assert md.Discriminator is discriminator_hip.Discriminator, "the drop-in name must resolve to the gfx950-kernel class"
     from oracle import restate
-    if be.kind == "emu" and cfg_name != "tiny":
-        pytest.skip("too slow on the emulator")
+    # (explicit backend list: no gpu-marked instance touches the CPU emulator, so a GPU-box run maps libmonkeynet_hip.so only)
+    be = make_backend(kind)
     cfg = load(cfg_name)["cfg"]
     mp = cfg["model_params"]
     common = mp["common_params"]
