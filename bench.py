@@ -72,6 +72,11 @@ def parse():
     ap.add_argument("--host-inputs", action="store_true",
                     help="additionally time K iterations whose inputs start in pinned host memory (PCIe-inclusive "
                          "rate, reported as `pcie_inclusive`; never `value`)")
+    ap.add_argument("--dropin", type=int, default=1,
+                    help="1 (default, one GPU): also time the reference's OWN loop on the drop-in modules -- train.py:78-153's "
+                         "statement sequence (three torch.optim.Adam, host dict batches through DataParallelWithCallback("
+                         "device_ids=[0]), two discriminator passes, per-iteration .cpu() of the losses) -- reported as "
+                         "`dropin`, never as `value`; 0: skip")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the iteration as one captured hipGraph, 0: eager launches, -1: graph on 1 GPU")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -174,7 +179,20 @@ def recon_l1_vs_cpu(cfg, size, device, batch=8):
                       "BatchNorm statistics, smooth synthetic frames" % (batch, size, size)}
 
 
-def cpu_baseline(cfg, batch, size, steps):
+def reference_cpu_row(cfg_name, batch, size):
+    """BASELINE.md section 2's row for this workload: the unmodified reference on the authoring container's host CPU"""
+    try:
+        rows = json.load(open(os.path.join(ROOT, "profiles", "r04_reference_cpu_timing.json")))["rows"]
+        for r in rows:
+            if r["config"] == cfg_name and r["batch"] == batch and r["size"] == size:
+                return "%.2f frames/s (%.3f s/iteration, %d threads of %s)" % (r["frames_per_s"], r["s_per_step_mean"],
+                                                                               r["threads"], r["cpu"])
+    except Exception:
+        pass
+    return "no row for this workload (taichi batch 32: 12.8 pairs/s on 8 cores)"
+
+
+def cpu_baseline(cfg, batch, size, steps, cfg_name=""):
     """The oracle restatement (torch CPU, fp32) doing the same training iteration: forward through
     restate.generator_full_forward / discriminator_full_forward, backward, 3x Adam."""
     from oracle import restate, cases
@@ -224,8 +242,9 @@ def cpu_baseline(cfg, batch, size, steps):
     return {"value": batch / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d training iterations of the same config at batch %d (oracle/restate.py, torch CPU fp32, "
                       "%d threads), %.2f s/iteration.  A PORT: Conv2d on frames folded into the batch, not the reference's "
-                      "own Conv3d((1,3,3)) modules (the reference tree cannot travel to the GPU box; BASELINE.md's number "
-                      "for the reference itself is taichi batch 32 = 12.8 pairs/s on 8 cores)" % (steps, batch, cores, dt)}
+                      "own Conv3d((1,3,3)) modules (the reference tree cannot travel to the GPU box).  The UNMODIFIED reference "
+                      "itself, timed in the authoring container by oracle/time_reference.py (BASELINE.md section 2, "
+                      "profiles/r04_reference_cpu_timing.json): %s" % (steps, batch, cores, dt, reference_cpu_row(cfg_name, batch, size))}
 
 
 def hot_path_only(step, x, iters, device):
@@ -273,6 +292,58 @@ def hot_path_only(step, x, iters, device):
     e1.record()
     torch.cuda.synchronize(device)
     return e0.elapsed_time(e1) / iters, launch
+
+
+def dropin_loop(cfg, x, device, steps, warmup):
+    """What a user of the reference gets by putting monkey-net_amd/ in front of the reference root and running the reference's
+    unmodified train.py: its loop (train.py:78-153), statement for statement as tests/test_dropin_replay.py restates it --
+    three torch.optim.Adam(betas=(0.5, 0.999)), the two full models (train.py:24-75 = mnk.engine.GeneratorFullModel /
+    DiscriminatorFullModel) behind DataParallelWithCallback(device_ids=[0]), HOST dict batches as a DataLoader hands them
+    over (pinned; the wrapper moves them), generator pass -> backward -> steps, discriminator pass (a second discriminator
+    forward) -> backward -> step, and the per-iteration host copies of the loss values (train.py:125,138).  No hipGraph, no
+    MnkAdam, no shared discriminator forward: every launch is issued by the Python loop."""
+    from mnk.engine import GeneratorFullModel, DiscriminatorFullModel
+    from sync_batchnorm import DataParallelWithCallback
+    tp = cfg["train_params"]
+    generator, discriminator, kp_detector = build_models(cfg, device)
+    opt_g = torch.optim.Adam(generator.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
+    opt_d = torch.optim.Adam(discriminator.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
+    opt_k = torch.optim.Adam(kp_detector.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
+    gpar = DataParallelWithCallback(GeneratorFullModel(kp_detector, generator, discriminator, tp), device_ids=[0])
+    dpar = DataParallelWithCallback(DiscriminatorFullModel(kp_detector, generator, discriminator, tp), device_ids=[0])
+    host = {k: v.cpu().pin_memory() for k, v in x.items()}
+
+    def iteration():
+        xb = dict(host)
+        out = gpar(xb)
+        loss_values = [val.mean() for val in out[:-2]]
+        generated, kp_joined = out[-2], out[-1]
+        sum(loss_values).backward(retain_graph=not tp["detach_kp_discriminator"])
+        opt_g.step(), opt_g.zero_grad(), opt_d.zero_grad()
+        if tp["detach_kp_discriminator"]:
+            opt_k.step(), opt_k.zero_grad()
+        g_host = [val.detach().cpu().numpy() for val in loss_values]
+        loss_values = [val.mean() for val in dpar(xb, kp_joined, generated)]
+        sum(loss_values).backward()
+        opt_d.step(), opt_d.zero_grad()
+        if not tp["detach_kp_discriminator"]:
+            opt_k.step(), opt_k.zero_grad()
+        return g_host + [val.detach().cpu().numpy() for val in loss_values]
+
+    for _ in range(warmup):
+        iteration()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = iteration()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    b = int(x["source"].shape[0])
+    return {"value": round(b / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
+            "finite": bool(all(float(v) == float(v) for v in last)),
+            "what": "the reference's own loop on the drop-in modules: train.py:78-153 statement sequence (3x torch.optim.Adam, "
+                    "host batches through DataParallelWithCallback(device_ids=[0]), two discriminator passes, host copies of "
+                    "the losses every iteration), eager launches -- tests/test_dropin_replay.py is its parity test"}
 
 
 _JSON_FD = [None]
@@ -514,6 +585,12 @@ def main():
                         "gflop_per_step": round(work / 1e9, 1), "executed_gflop_per_step": round(issued / 1e9, 1),
                         "ms_per_step": round(ms, 3),
                         "launches_per_step": sum(g["launches_per_step"] for g in groups)}
+    dropin = None
+    if args.dropin and not dist_mode and rank == 0:
+        try:
+            dropin = dropin_loop(cfg, x, device, max(5, min(args.steps, 20)), 3)
+        except Exception as e:   # never lose the bench line to the extra measurement
+            dropin = {"error": "%s: %s" % (type(e).__name__, e)}
     hot_ms, hot_launch = None, None
     if not args.no_profile and not dist_mode:
         try:
@@ -525,7 +602,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, args.cpu_batch, args.size, args.cpu_steps)
+        cpu = cpu_baseline(cfg, args.cpu_batch, args.size, args.cpu_steps, args.config)
         try:        # the second half of BASELINE's metric; never lose the bench line to it
             cpu["recon_l1"] = recon_l1_vs_cpu(cfg, args.size, device)
         except Exception as e:
@@ -554,6 +631,7 @@ def main():
                                                 / FP32_MFMA_PEAK_TFLOPS, 4)},
             "roofline": roofline, "roofline_all_conv": roofline_all, "cpu_baseline": cpu, "kernels": kernels,
             "capture_failed": bool(capture_failed),
+            "dropin": dropin,
         }
         if pcie is not None:
             out["pcie_inclusive"] = pcie

@@ -47,8 +47,8 @@ def discriminate_pair(discriminator, fake, real, kp_dict):
     """(D(fake, kp), D(real, kp)) -- train.py:43-45,66-68 call the discriminator twice with the same key-points.
     Every layer of it works per sample (convolutions, InstanceNorm, LeakyReLU, pooling; no batch statistics), so the
     two calls are ONE pass over the batch [fake; real]: half the launches on layers this small (64x64 and below at
-    batch 32 are launch / latency bound).  MNK_DISC_BATCHED=0 keeps the two separate calls."""
-    if not knobs.on("MNK_DISC_BATCHED"):
+    batch 32 are launch / latency bound).  (knobs.FORMS["DISC_BATCHED"] = False: the two separate calls, for the test.)"""
+    if not knobs.form("DISC_BATCHED"):
         return discriminator(fake, **kp_dict), discriminator(real, **kp_dict)
     b = fake.shape[0]
     kp2 = {name: {k: torch.cat([v, v], dim=0) for k, v in kp.items()} for name, kp in kp_dict.items()}
@@ -175,7 +175,7 @@ class TrainStep:
         self.tp = train_params
         lr = train_params['lr']
         self.use_graph = bool(use_graph)
-        self.mnk_adam = knobs.on("MNK_HAND_ADAM") if fused_adam is None else bool(fused_adam)
+        self.mnk_adam = True if fused_adam is None else bool(fused_adam)
         self._graph = None                    # the captured iteration: a list of hipGraphs and host calls between them
         self._segment = None                  # (graph being captured, pool) while _capture runs
         self._ones = {}
@@ -194,8 +194,6 @@ class TrainStep:
                 m.register_load_state_dict_post_hook(lambda *a, **k: self.weights_changed())
         else:
             kw = {'capturable': True} if self.use_graph else {}
-            if fused_adam is None and next(generator.parameters()).is_cuda:
-                kw['fused'] = True           # MNK_HAND_ADAM=0: round 1's default optimiser
             self.opt_g = torch.optim.Adam(generator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
             self.opt_d = torch.optim.Adam(discriminator.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
             self.opt_k = torch.optim.Adam(kp_detector.parameters(), lr=lr, betas=(0.5, 0.999), **kw)
@@ -269,7 +267,7 @@ class TrainStep:
                 if it == warmup:
                     # the captured iteration of one process: the optimiser kernels read the gradients of the deep levels from
                     # the tap-major partials themselves (MnkAdam.tap_direct; p.grad is not observable inside a replay)
-                    direct = self.mnk_adam and not mdist.grads_active() and knobs.on("MNK_ADAM_TAP_DIRECT")
+                    direct = self.mnk_adam and not mdist.grads_active()
                     for o in (self.opt_g, self.opt_d, self.opt_k):
                         if hasattr(o, "tap_direct"):
                             o.tap_direct = bool(direct)
@@ -407,7 +405,7 @@ class TrainStep:
             mdist.check_equal_shards(b)
             self._shard_checked = b
         self._weights_touched = False
-        if knobs.on("MNK_DISC_SHARED"):
+        if knobs.form("DISC_SHARED"):
             return self._eager_step_shared(x)
         return self._eager_step_two_pass(x)
 
@@ -434,7 +432,7 @@ class TrainStep:
         fake_leaf = fake.detach().requires_grad_(True)
         kp_names = list(kp_joined.keys())
         kp_leaf = {k: kp_joined[k].detach().requires_grad_(True) for k in kp_names}
-        if knobs.on("MNK_FUSED_FM_LOSS") and hasattr(self.discriminator, "forward_acts"):
+        if knobs.form("FUSED_FM_LOSS") and hasattr(self.discriminator, "forward_acts"):
             # feature-matching terms straight from the NHWC activations (profiles/README.md: 14.59 -> 14.26 ms per step)
             g_vec, d_vec = fused_pair_losses(self.discriminator, fake_leaf, x['video'], split_kp(kp_leaf, False),
                                              generated['video_deformed'], tp['loss_weights'])
@@ -537,7 +535,7 @@ class TrainStep:
 
     def _eager_step_two_pass(self, x, set_to_none=True):
         """The reference's structure: generator pass and discriminator pass each run the discriminator
-        (MNK_DISC_SHARED=0)."""
+        (knobs.FORMS["DISC_SHARED"] = False: the comparison form of tests/test_step.py)."""
         tp = self.tp
         # The generator pass back-propagates THROUGH the discriminator but the reference throws the discriminator's own
         # weight gradients of this pass away (optimizer_discriminator.zero_grad(), train.py:120): do not compute them.

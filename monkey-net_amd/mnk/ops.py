@@ -313,14 +313,13 @@ _SUBPIXEL_TOLD = [None, None]       # (library object, value) the library's own 
 
 
 def subpixel(ups):
-    """UpBlock3D convolutions run in their sub-pixel forms (mnk_conv3x3_up_*): MNK_UP_SUBPIXEL=0 restores the 3x3
-    convolution over the up-sampled view (the library's weight-gradient plans follow: its "up_subpixel" tuning value)."""
-    on = knobs.on("MNK_UP_SUBPIXEL")
+    """UpBlock3D convolutions run in their sub-pixel forms (mnk_conv3x3_up_*) -- 13.87 -> 12.62 ms per step in round 2; the 3x3
+    convolution over the up-sampled view stays for the operands the sub-pixel kernels do not take (a residual input) and, for
+    A/B runs, behind the library's "up_subpixel" tuning value (MNK_TUNING=up_subpixel=0), which this function follows."""
     lib = _lib.lib()
-    if _SUBPIXEL_TOLD[0] is not lib or _SUBPIXEL_TOLD[1] != on:
-        lib.call("mnk_set_tuning", b"up_subpixel", int(on))
-        _SUBPIXEL_TOLD[0], _SUBPIXEL_TOLD[1] = lib, on
-    return bool(ups) and on
+    if _SUBPIXEL_TOLD[0] is not lib:
+        _SUBPIXEL_TOLD[0], _SUBPIXEL_TOLD[1] = lib, "up_subpixel=0" not in knobs.get("MNK_TUNING").replace(" ", "")
+    return bool(ups) and _SUBPIXEL_TOLD[1]
 
 
 def _packed_fwd_weight(weight, cout, c0, c1, up=False):
@@ -408,8 +407,6 @@ def repack_registered(only_if_stale=False):
     iteration (and everything, when called under stream capture before the table exists) fall back to per-layer packs.
     only_if_stale: nothing to do when every entry is still fresh (the optimiser kernel of mnk.optim wrote the packs)."""
     t = _PACK_TABLE
-    if not knobs.on("MNK_PACK_MULTI"):
-        return False
     if only_if_stale and _PACK_REG:
         stale = False
         for e in _PACK_REG.values():
@@ -454,7 +451,7 @@ _SPLIT_PENDING = {}
 
 def small_bn(rows, training=True):
     """the one-launch BatchNorm forms of small layers apply: single rank, training statistics, few pixel rows"""
-    return (training and knobs.on("MNK_BN_SMALL") and not mdist.active() and 1 < rows <= _query("mnk_bn_small_rows"))
+    return (training and not mdist.active() and 1 < rows <= _query("mnk_bn_small_rows"))
 
 
 def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats=False, up=False):
@@ -664,7 +661,7 @@ def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, 
     skip: -> (y, sums, x0 handed through for x0's other consumer), see Conv3x3SkipFn."""
     track = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x0, x1, weight, bias, residual))
-    if skip and track and x0.requires_grad and knobs.on("MNK_SKIP_GRAD_FUSED"):
+    if skip and track and x0.requires_grad and knobs.form("SKIP_GRAD_FUSED"):
         y, sums, through = Conv3x3SkipFn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
         return y, (sums if want_stats else None), through
     y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
@@ -761,7 +758,7 @@ class BNActFn(torch.autograd.Function):
         if dskip is not None:
             dskip = dskip.contiguous()
             assert dskip.shape == y.shape, "the skip gradient of a residual block has the shape of the block's input"
-        if ctx.small and knobs.on("MNK_BN_ZERO_BIAS_GRAD"):
+        if ctx.small:
             sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
             dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
             _call("mnk_bn_small_bwd", y, _p(y), ld, _p(dz), dz.shape[-1], _p(mean), _p(invstd), _p(scale), _p(beta), count, n, h,
@@ -789,7 +786,7 @@ class BNActFn(torch.autograd.Function):
                   _p(beta), _p(sums), count, int(training), _p(dskip), dskip.shape[-1], _p(dy), ld, n, h, w, c, int(relu),
                   int(pool), _p(dy_sums), _p(ws), nws)
             _DY_SUMS[0] = (dy, dy_sums)
-        elif training and knobs.on("MNK_BN_ZERO_BIAS_GRAD"):
+        elif training:
             # training-mode statistics: sum over pixels of dy = scale * (sum g - N * mean(g) - k2 * sum xhat) == 0 exactly, so
             # the bias gradient of the convolution in front (util.py:54-56,80-81,99-100) is analytically zero; the reference
             # computes its rounding noise.  No reduction is spent on it: that bias simply receives no gradient (an optimiser
@@ -827,7 +824,7 @@ class BNActSkipFn(torch.autograd.Function):
 def bn_act(y, c, norm, relu=True, pool=False, sums=None, skip=False):
     """`norm` is a sync_batchnorm.SynchronizedBatchNorm3d parameter holder; `sums` = statistics of y that a conv
     epilogue already produced (training mode).  skip: -> (z, y handed through for a residual add), see BNActSkipFn."""
-    fn = BNActSkipFn if skip and knobs.on("MNK_RES_SKIP_FUSED") else BNActFn
+    fn = BNActSkipFn if skip and knobs.form("RES_SKIP_FUSED") else BNActFn
     out = fn.apply(y, norm.weight, norm.bias, norm.running_mean, norm.running_var,
                    sums if norm.training else None, c, norm.training, relu, pool, norm.momentum, norm.eps)
     return (out, y) if skip and fn is BNActFn else out
@@ -1475,7 +1472,7 @@ class WarpAllFn(torch.autograd.Function):
         _check_device(field)
         _, hf, wf, _ = field.shape
         outs = []
-        ctx.multi = mode == 0 and len(inps) <= 8 and knobs.on("MNK_WARP_LEVELS")
+        ctx.multi = mode == 0 and len(inps) <= 8 and knobs.form("WARP_LEVELS")
         if ctx.multi:         # one launch for the warps and embedding copies of all levels (mnk_warp_levels_fwd)
             lv = np.zeros(len(inps), dtype=WARP_LEVEL)
             for i, (inp, (c, ke)) in enumerate(zip(inps, specs)):

@@ -108,7 +108,7 @@ class DeferredReducer:
         lib = _lib.lib()
         job = np.zeros(1, dtype=JOB)
         job[0] = (0, 0, 0, 0, ld_x, c, flags, ld_dy, cout, n, ho, wo, hi, wi, kh, kw, pad, 0, 0, 0)
-        grouped = mops.knobs.on("MNK_WGRAD_GROUPED")
+        grouped = True
         if grouped:
             if lib.query("mnk_wgrad_grouped_plan", job.ctypes.data, 1) != 0:
                 raise _lib.MnkError("mnk_wgrad_grouped_plan failed: %s" % lib.cdll.mnk_last_error().decode())

@@ -3,6 +3,8 @@ import os
 
 import pytest
 import torch
+
+from mnk import knobs
 import torch.nn.functional as F
 
 from _util import to_nhwc, from_nhwc, ceil4, relerr, maxerr
@@ -205,7 +207,7 @@ def test_all_warps_in_one_launch_equal_the_per_level_launches(be, monkeypatch, e
         d[..., c + ke:] = 0                      # gradients of acts: zero pad channels
 
     def run(flag):
-        monkeypatch.setenv("MNK_WARP_LEVELS", flag)
+        monkeypatch.setitem(knobs.FORMS, "WARP_LEVELS", flag == "1")
         f = field.clone().requires_grad_(True)
         e = emb.clone().requires_grad_(True) if emb is not None else None
         xs = [t.clone().requires_grad_(True) for t in inps]

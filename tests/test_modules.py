@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import cases
+from mnk import knobs
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -399,7 +400,7 @@ def test_discriminate_pair_batched_equals_two_calls(be, monkeypatch):
 
     def run(batched):
         nonlocal ws
-        monkeypatch.setenv("MNK_DISC_BATCHED", "1" if batched else "0")
+        monkeypatch.setitem(knobs.FORMS, "DISC_BATCHED", bool(batched))
         fake = be.t(fake0.clone()).requires_grad_(True)         # (be.t is the identity on the emulator backend)
         kp = {"kp_driving": {k: be.t(v.clone()).requires_grad_(True) for k, v in kd.items()},
               "kp_source": {k: be.t(v) for k, v in ks.items()}}
@@ -472,7 +473,7 @@ def test_residual_blocks_and_the_gradient_of_their_skip_path(be, monkeypatch, fu
     from modules.util import ResBlock3D
     from mnk import ops
     from oracle import restate
-    monkeypatch.setenv("MNK_RES_SKIP_FUSED", fused)
+    monkeypatch.setitem(knobs.FORMS, "RES_SKIP_FUSED", fused == "1")
     torch.manual_seed(5)
     cin, c, n = 3, 5, 2
     front = nn.Conv3d(cin, c, kernel_size=(1, 3, 3), padding=(0, 1, 1))
@@ -528,7 +529,7 @@ def test_hourglass_levels_with_two_consumers(be, monkeypatch, fused):
     gradient as its residual operand."""
     from modules.util import Hourglass
     from oracle import restate
-    monkeypatch.setenv("MNK_SKIP_GRAD_FUSED", fused)
+    monkeypatch.setitem(knobs.FORMS, "SKIP_GRAD_FUSED", fused == "1")
     torch.manual_seed(9)
     hg = Hourglass(block_expansion=8, in_features=6, out_features=5, num_blocks=3, max_features=32)
     sd = {"hg." + k: v.detach().clone().double() for k, v in hg.state_dict().items()}

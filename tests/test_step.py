@@ -56,19 +56,19 @@ import pytest
                                                         (1, False, False)])
 def test_shared_discriminator_forward_equals_two_pass_step(be, monkeypatch, rec_def, detach_d, detach_g):
     """mnk.engine.TrainStep with ONE discriminator forward per iteration (graph cut at the discriminator's inputs,
-    the default) against the reference's two-pass structure (MNK_DISC_SHARED=0) -- for the loss / detach variants the
+    the default) against the reference's two-pass structure (knobs.FORMS["DISC_SHARED"] = False) -- for the loss / detach variants the
     configs use (reconstruction_deformed on / off, key-points of the discriminator pass detached or not)."""
     _compare_step_forms(be, monkeypatch, rec_def, detach_d, detach_g,
-                        base={"MNK_DISC_SHARED": "0"}, other={"MNK_DISC_SHARED": "1"})
+                        base={"DISC_SHARED": False}, other={"DISC_SHARED": True})
 
 
 @pytest.mark.parametrize("rec_def,detach_d", [(1, True), (0, False)])
 def test_fused_feature_matching_losses_equal_the_loss_module(be, monkeypatch, rec_def, detach_d):
-    """MNK_FUSED_FM_LOSS=1 (opt-in): the feature-matching terms reduced on the device from the discriminator's NHWC
+    """knobs.FORMS["FUSED_FM_LOSS"] (the default): the feature-matching terms reduced on the device from the discriminator's NHWC
     activations (ops.PairL1Fn, mnk.engine.fused_pair_losses) give the losses and gradients of modules/losses.py on the
     NCDHW feature maps."""
     _compare_step_forms(be, monkeypatch, rec_def, detach_d, False,
-                        base={"MNK_FUSED_FM_LOSS": "0"}, other={"MNK_FUSED_FM_LOSS": "1"})
+                        base={"FUSED_FM_LOSS": False}, other={"FUSED_FM_LOSS": True})
 
 
 @pytest.mark.parametrize("rec_def,detach_d,detach_g", [(1, True, False), (0, False, True), (1, False, False)])
@@ -94,8 +94,9 @@ def _compare_step_forms(be, monkeypatch, rec_def, detach_d, detach_g, base, othe
     x = {"source": be.t(src), "video": be.t(drv)}
 
     def run(env, fused_adam):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+        from mnk import knobs
+        for k, v in env.items():            # comparison forms of mnk.knobs.FORMS (not environment switches)
+            monkeypatch.setitem(knobs.FORMS, k, v)
         gen, disc, kpd = build(cfg)
         gen.load_state_dict(gold["state"]["generator"])
         disc.load_state_dict(gold["state"]["discriminator"])
