@@ -469,13 +469,6 @@ def main():
         eager = step if not use_graph else engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
         elapsed = timed(step)
         launch = "hipGraph replay" if use_graph else "eager"
-        ri = getattr(step, "replay_info", None)
-        if use_graph and ri and "refused" not in ri:
-            launch = ("captured iteration replayed by the library's stream executor (csrc/replay.hip): %d nodes as stream "
-                      "launches on %d stream(s), %d of them on side streams, %d cross-stream waits"
-                      % (ri["nodes"], ri["streams"], ri["side_stream_nodes"], ri["cross_stream_waits"]))
-        elif use_graph and ri:
-            launch = "hipGraph replay (stream executor refused: %s)" % ri["refused"][:300]
     else:
         # several ranks: the eager iteration is measured FIRST (a complete, valid K-step measurement), then the iteration
         # with its RCCL collectives is captured as a hipGraph and measured again under a deadline (below) -- a capture

@@ -348,23 +348,6 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
  * must be 16-byte aligned and hold bytes rounded up to 16. */
 int mnk_table_upload(const void* host, void* device, size_t bytes, void* stream);
 
-/* ---- stream executor of a captured iteration (replaces hipGraphLaunch for the captured
- * train.py:110-136 iteration of mnk.engine.TrainStep).  `hip_graph` is the hipGraph_t of a finished stream capture, which the
- * caller keeps alive (the kernel argument blocks are the graph's).  mnk_replay_create reads its kernel / memset / memcpy nodes
- * and edges back, orders them topologically along the capture order and binds its chains to at most `max_streams` HIP streams
- * (chain 0 = the stream passed to mnk_replay_launch); an edge between two streams becomes an event record + stream wait.
- * mnk_replay_launch issues the nodes as ordinary stream launches (hipLaunchKernel with the captured arguments), so the
- * independent branches of the iteration -- weight-gradient GEMMs, the appearance encoder next to the key-point detector, the
- * discriminator-loss backward next to the generator's optimiser step -- overlap on the device; the caller's stream joins every
- * side stream before the call returns (stream order; nothing blocks the host).  A graph with a node that stream launches
- * cannot reproduce (host / child-graph / external-event nodes, a memcpy whose operands the graph API does not hand out) is
- * refused with MNK_EINVAL and the message names the kernels around it.  info[8] = {nodes, kernels, memsets, memcpys, streams
- * in use, cross-stream waits, edges, nodes on side streams}. */
-int mnk_replay_create(void* hip_graph, int max_streams, void** handle_out);
-int mnk_replay_info(void* handle, long* info8);
-int mnk_replay_launch(void* handle, void* stream);
-int mnk_replay_destroy(void* handle);
-
 /* ---- optimiser: torch.optim.Adam(lr, betas=(0.5, 0.999)) of train.py:81-83,118-136 for EVERY
  * tensor of a model in one launch.  Formula of torch/optim/adam.py::_single_tensor_adam (no amsgrad / weight decay) in
  * fp32.  `hyper` = 10 floats in DEVICE memory [lr, beta1, beta2, eps, lr / (1 - beta1^t), sqrt(1 - beta2^t), grad_scale, t,

@@ -131,37 +131,6 @@ class DiscriminatorFullModel(torch.nn.Module):
 _BROKEN_CAPTURES = []
 
 
-class StreamProgram:
-    """A captured hipGraph replayed by the library's stream executor (csrc/replay.hip, mnk_replay_*) instead of
-    hipGraphLaunch: the nodes are issued as ordinary stream launches, the branches of the captured dependency graph on
-    streams of their own.  Keeps the torch graph object (it owns the hipGraph_t, the kernel argument blocks and the capture's
-    memory pool) alive."""
-
-    def __init__(self, graph, max_streams):
-        import ctypes
-        from . import _lib
-        self.graph = graph
-        self._lib = _lib.lib()
-        self._handle = ctypes.c_void_p()
-        self._lib.call("mnk_replay_create", ctypes.c_void_p(graph.raw_cuda_graph()), int(max_streams),
-                       ctypes.byref(self._handle))
-        info = (ctypes.c_long * 8)()
-        self._lib.call("mnk_replay_info", self._handle, info)
-        self.info = dict(zip(("nodes", "kernels", "memsets", "memcpys", "streams", "cross_stream_waits", "edges",
-                              "side_stream_nodes"), [int(v) for v in info]))
-
-    def replay(self):
-        self._lib.call("mnk_replay_launch", self._handle, torch.cuda.current_stream().cuda_stream)
-
-    def __del__(self):
-        try:
-            if self._handle:
-                torch.cuda.synchronize()
-                self._lib.cdll.mnk_replay_destroy(self._handle)
-        except Exception:
-            pass
-
-
 class TrainStep:
     """One iteration of train.py:110-136 on this rank's shard, with gradients averaged over ranks (RCCL) before
     every optimiser step."""
@@ -184,7 +153,6 @@ class TrainStep:
         self._static_out = None
         self._weights_touched = True          # packed weights must be (re)made before the next iteration
         self._shard_checked = None            # batch size the ranks were last found to agree on (mnk.dist.check_equal_shards)
-        self.replay_info = None               # what the stream executor made of the captured iteration (StreamProgram.info)
         if self.mnk_adam:
             from . import optim as moptim
             self.opt_g = moptim.MnkAdam(generator.parameters(), lr=lr, betas=(0.5, 0.999))
@@ -243,7 +211,7 @@ class TrainStep:
         self._replaying = True
         try:
             for piece in self._graph:         # one hipGraph, or linear hipGraphs with the gradient exchange's host calls between
-                piece.replay() if hasattr(piece, "replay") else piece()
+                piece.replay() if isinstance(piece, torch.cuda.CUDAGraph) else piece()
         finally:
             self._replaying = False
         mops.invalidate_packed_weights()      # the captured optimiser steps changed the parameters
@@ -259,7 +227,6 @@ class TrainStep:
         self._static_x = {k: v.clone() for k, v in x.items()}
         snap = self._snapshot()
         import gc
-        from . import optim as moptim
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -293,8 +260,6 @@ class TrainStep:
         try:
             with torch.cuda.stream(cap):
                 self._segment = [None, pool, program]
-                if self.mnk_adam:
-                    moptim.CAPTURE_BRANCHES[0] = self._replay_streams() >= 2
                 self._segment_begin()
                 self._static_out = self._eager_step(self._static_x, set_to_none=True)
                 if self._segment[0] is not None:
@@ -308,8 +273,6 @@ class TrainStep:
             raise
         finally:
             self._segment = None
-            if self.mnk_adam:
-                moptim.CAPTURE_BRANCHES[0] = False
             if gc_was_on:
                 gc.enable()
             for o in (self.opt_g, self.opt_d, self.opt_k):      # eager iterations keep every p.grad valid
@@ -319,32 +282,14 @@ class TrainStep:
         self._graph = program
         self._restore(snap)
 
-    def _replay_streams(self):
-        """MNK_REPLAY_STREAMS: 0 = hipGraphLaunch of the captured (linear) graph; n >= 1 = the library's stream executor on
-        at most n streams (n >= 2: the capture keeps the branches of the iteration's dependency graph -- background
-        weight-gradient launches, csrc/replay.hip).  One process only: the captured RCCL collectives of several ranks stay
-        with hipGraphLaunch."""
-        n = int(knobs.get("MNK_REPLAY_STREAMS") or 0)
-        return 0 if mdist.active() else n
-
     def _segment_begin(self):
-        g = torch.cuda.CUDAGraph(keep_graph=True) if self._replay_streams() else torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph()
         g.capture_begin(pool=self._segment[1])
         self._segment[0] = g
 
     def _segment_end(self):
         g, self._segment[0] = self._segment[0], None
         g.capture_end()
-        n = self._replay_streams()
-        if n:
-            try:
-                g = StreamProgram(g, n)
-                self.replay_info = g.info
-            except Exception as e:          # a node the executor cannot issue: say so, replay with hipGraphLaunch
-                import warnings
-                warnings.warn("stream executor refused the captured iteration (%s); replaying with hipGraphLaunch" % e)
-                self.replay_info = {"refused": str(e)}
-                g.instantiate()
         self._segment[2].append(g)
 
     def _cut(self, host_call, last=False):

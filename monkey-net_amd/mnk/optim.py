@@ -63,12 +63,6 @@ def _capturing(device):
     return device.type == "cuda" and torch.cuda.is_current_stream_capturing()
 
 
-# True while mnk.engine.TrainStep captures an iteration for the library's stream executor (csrc/replay.hip) with more than one
-# stream: the background launches of the recorded weight-gradient GEMMs then stay a BRANCH of the captured graph (under
-# hipGraphLaunch a branch costs 0.85 ms per replay, so that capture stays linear)
-CAPTURE_BRANCHES = [False]
-
-
 class DeferredReducer:
     """The weight-gradient GEMMs of one optimiser's convolutions, run as late and as together as possible:
     * tap-major shapes (every layer wider than one 64-channel tile) are only RECORDED during backward and launched
@@ -152,8 +146,7 @@ class DeferredReducer:
         if rec["grouped"]:
             self.jobs.append((key, x, dy))                 # launched by flush(); the operands stay alive until then
             self.job_macs += float(n * ho * wo) * c * cout * kh * kw
-            if self.bg_macs > 0 and self.job_macs >= self.bg_macs and x.is_cuda and (
-                    CAPTURE_BRANCHES[0] or not _capturing(x.device)):
+            if self.bg_macs > 0 and self.job_macs >= self.bg_macs and x.is_cuda and not _capturing(x.device):
                 self._launch_grouped(background=True)
         else:
             mops._call("mnk_conv2d_wgrad", dy, mops._p(x), ld_x, c, int(flags) | 4, hi, wi, kh, kw, pad, mops._p(dy), ld_dy,
