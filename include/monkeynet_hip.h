@@ -583,6 +583,28 @@ typedef struct MnkFrameJob {
 } MnkFrameJob;
 int mnk_frames_gather(const unsigned char* pool, const MnkFrameJob* jobs_device, int njobs, int H, int W, int Cout, float* out,
                       void* stream);
+/* The same batch path with the reference's non-integer augmentations in front of the crop (round 4): RandomRotation
+ * (augmentation.py:175-214 = skimage.transform.rotate), RandomResize (:105-133 = skimage.transform.resize, order 1, mode
+ * 'constant', anti_aliasing=True with ratios >= 0.8: a one-tap filter) and ColorJitter's hue term (:217-320 = img_as_ubyte ->
+ * PIL RGB -> HSV -> uint8 hue shift -> RGB -> img_as_float), in the arithmetic of the versions requirements.txt pins
+ * (scikit-image 0.14.0, Pillow 5.2.0, torchvision 0.2.1; restated in oracle/augment_restate.py).  flags: 1 rotate (rot = the
+ * inverse map  col = rot[0] c + rot[1] r + rot[2], row = rot[3] c + rot[4] r + rot[5]), 2 resize to (new_h, new_w) with order 1
+ * (interpolation='bilinear'), 8 the same with order 0 (RandomResize's default 'nearest': what the shipped configs run), 4 hue.
+ * vmin / vmax: min / max of the float32 source frame over its channels (skimage clips a warp's output to its input's range);
+ * rot_range: njobs x 2 doubles of scratch when any job rotates (the range of the rotated frame, which clips the resize). */
+typedef struct MnkAugJob {
+    unsigned long long strip_offset;
+    unsigned long long out_offset;
+    unsigned long long chan_stride;
+    double rot[6];
+    int strip_w, in_h, in_w, channels;
+    int frame, hflip, x1, y1;
+    int pad_top, pad_left, new_h, new_w;
+    int flags, hue_shift;
+    float vmin, vmax;
+} MnkAugJob;
+int mnk_frames_augment(const unsigned char* pool, const MnkAugJob* jobs_device, int njobs, int any_rotation, double* rot_range,
+                       int H, int W, int Cout, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -47,9 +47,234 @@ __global__ void __launch_bounds__(256) frames_gather_kernel(const unsigned char*
     for (int ch = 0; ch < Cout; ++ch) o[(size_t)ch * j.chan_stride] = v[ch < 3 ? ch : 2];
 }
 
+// ---- the non-integer augmentations (round 4): RandomRotation -> RandomResize -> RandomCrop -> ColorJitter(hue) --------------------
+//   augmentation.py:175-214  RandomRotation = skimage.transform.rotate(img, angle, preserve_range=True)
+//   augmentation.py:105-133  RandomResize   = skimage.transform.resize(img, (new_h, new_w), order=1, preserve_range=True,
+//                                             mode='constant', anti_aliasing=True)
+//   augmentation.py:217-320  ColorJitter    = img_as_ubyte -> PIL -> torchvision adjust_hue -> np.array -> img_as_float -> float32
+// in the arithmetic of the versions the reference pins (scikit-image 0.14.0, Pillow 5.2.0, torchvision 0.2.1), restated in
+// oracle/augment_restate.py with the citations; this kernel follows that restatement statement by statement (float64 warps as
+// skimage computes them, Pillow's float / double mix in the colour conversions), so the two agree to the last bit except where
+// a libm call differs.  The two warps are NOT composed into one resampling: a pixel of the resized frame is the bilinear blend
+// of four pixels of the ROTATED frame, each of which is itself a bilinear blend of four source bytes, clipped to the source
+// frame's value range -- 16 byte reads per output value and no intermediate image.  One thread per output pixel.
+#pragma clang fp contract(off)      // (a * b + c must round twice, as numpy does)
+
+struct AugSrc {
+    const unsigned char* base;      // the frame's first byte in the strip
+    int strip_w, in_h, in_w, channels, hflip;
+};
+
+// channel values of the float32 frame img_as_float32(uint8) at (r, c) -- np.fliplr applied -- or cval = 0 outside the image
+__device__ __forceinline__ void aug_src(const AugSrc& s, long r, long c, double v[3]) {
+    if (r < 0 || r >= s.in_h || c < 0 || c >= s.in_w) {
+        v[0] = v[1] = v[2] = 0.0;
+        return;
+    }
+    if (s.hflip) c = s.in_w - 1 - c;
+    const unsigned char* px = s.base + ((size_t)r * s.strip_w + c) * s.channels;
+    const float k = 1.f / 255.f;
+    if (s.channels >= 3) {
+        v[0] = (double)((float)px[0] * k);
+        v[1] = (double)((float)px[1] * k);
+        v[2] = (double)((float)px[2] * k);
+    } else {
+        v[0] = v[1] = v[2] = (double)((float)px[0] * k);
+    }
+}
+
+// _clip_warp_output: clip to the input's range; a pixel that is exactly cval (0) keeps it when 0 lies outside the range
+__device__ __forceinline__ double aug_clip(double x, double lo, double hi) {
+    if (!(lo <= 0.0 && 0.0 <= hi) && x == 0.0) return 0.0;
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
+template <class Tap>
+__device__ __forceinline__ void aug_bilinear(double r, double c, Tap tap, double out[3]) {
+    const double fr = floor(r), fc = floor(c);
+    const long minr = (long)fr, minc = (long)fc, maxr = (long)ceil(r), maxc = (long)ceil(c);
+    const double dr = r - fr, dc = c - fc;
+    double a[3], b[3], cc[3], d[3];
+    tap(minr, minc, a);
+    tap(minr, maxc, b);
+    tap(maxr, minc, cc);
+    tap(maxr, maxc, d);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double top = (1 - dc) * a[i] + dc * b[i];
+        const double bottom = (1 - dc) * cc[i] + dc * d[i];
+        out[i] = (1 - dr) * top + dr * bottom;
+    }
+}
+
+// pixel (r, c) of the rotated frame (or of the source frame when the job has no rotation); 0 outside the frame
+__device__ __forceinline__ void aug_rotated(const MnkAugJob& j, const AugSrc& s, long r, long c, double v[3]) {
+    if (!(j.flags & 1)) {
+        aug_src(s, r, c, v);
+        return;
+    }
+    if (r < 0 || r >= s.in_h || c < 0 || c >= s.in_w) {
+        v[0] = v[1] = v[2] = 0.0;
+        return;
+    }
+    const double cc = j.rot[0] * (double)c + j.rot[1] * (double)r + j.rot[2];
+    const double rr = j.rot[3] * (double)c + j.rot[4] * (double)r + j.rot[5];
+    aug_bilinear(rr, cc, [&](long y, long x, double* o) { aug_src(s, y, x, o); }, v);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = aug_clip(v[i], (double)j.vmin, (double)j.vmax);
+}
+
+// per job: min / max of the rotated frame over its three channels (the clip range of the resize that follows a rotation)
+__global__ void __launch_bounds__(256) frames_rotated_range_kernel(const unsigned char* __restrict__ pool,
+                                                                   const MnkAugJob* __restrict__ jobs,
+                                                                   double* __restrict__ range) {
+    __shared__ double lo_s[256], hi_s[256];
+    const MnkAugJob j = jobs[blockIdx.x];
+    const AugSrc s{pool + j.strip_offset + (size_t)j.frame * j.in_w * j.channels, j.strip_w, j.in_h, j.in_w, j.channels, j.hflip};
+    double lo = 1e300, hi = -1e300;
+    for (int p = threadIdx.x; p < j.in_h * j.in_w; p += 256) {
+        double v[3];
+        aug_rotated(j, s, p / j.in_w, p % j.in_w, v);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lo = v[i] < lo ? v[i] : lo;
+            hi = v[i] > hi ? v[i] : hi;
+        }
+    }
+    lo_s[threadIdx.x] = lo;
+    hi_s[threadIdx.x] = hi;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            lo_s[threadIdx.x] = lo_s[threadIdx.x + k] < lo_s[threadIdx.x] ? lo_s[threadIdx.x + k] : lo_s[threadIdx.x];
+            hi_s[threadIdx.x] = hi_s[threadIdx.x + k] > hi_s[threadIdx.x] ? hi_s[threadIdx.x + k] : hi_s[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        range[2 * blockIdx.x] = lo_s[0];
+        range[2 * blockIdx.x + 1] = hi_s[0];
+    }
+}
+
+// Pillow 5.2.0 libImaging/Convert.c::rgb2hsv / hsv2rgb on one pixel, with torchvision 0.2.1's uint8 hue shift in between
+__device__ __forceinline__ void aug_hue(unsigned char rgb[3], int shift) {
+    const unsigned char r = rgb[0], g = rgb[1], b = rgb[2];
+    const unsigned char maxc = r > g ? (r > b ? r : b) : (g > b ? g : b), minc = r < g ? (r < b ? r : b) : (g < b ? g : b);
+    unsigned char uh = 0, us = 0;
+    const unsigned char uv = maxc;
+    if (minc != maxc) {
+        const float cr = (float)(maxc - minc);
+        const float s = cr / (float)maxc;
+        const float rc = ((float)(maxc - r)) / cr, gc = ((float)(maxc - g)) / cr, bc = ((float)(maxc - b)) / cr;
+        float h;
+        if (r == maxc)
+            h = bc - gc;
+        else if (g == maxc)
+            h = (float)(2.0 + (double)rc - (double)bc);
+        else
+            h = (float)(4.0 + (double)gc - (double)rc);
+        h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+        int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
+        uh = (unsigned char)(ih < 0 ? 0 : (ih > 255 ? 255 : ih));
+        us = (unsigned char)(is < 0 ? 0 : (is > 255 ? 255 : is));
+    }
+    uh = (unsigned char)((uh + shift) & 255);                       // np_h += np.uint8(hue_factor * 255), uint8 wrap-around
+    if (us == 0) {
+        rgb[0] = rgb[1] = rgb[2] = uv;
+        return;
+    }
+    const double hf = (double)(float)uh * 6.0 / 255.0;
+    const int i = (int)floor(hf);
+    const float f = (float)(hf - (double)(float)i);
+    const float fs = (float)((double)(float)us / 255.0);
+    auto cround = [](double x) { return x >= 0.0 ? floor(x + 0.5) : ceil(x - 0.5); };      // C round(): half away from zero
+    auto clip8 = [](double x) { return (unsigned char)(x < 0.0 ? 0 : (x > 255.0 ? 255 : (int)x)); };
+    const unsigned char up = clip8(cround((double)(float)uv * (1.0 - (double)fs)));
+    const unsigned char uq = clip8(cround((double)(float)uv * (1.0 - (double)fs * (double)f)));
+    const unsigned char ut = clip8(cround((double)(float)uv * (1.0 - (double)fs * (1.0 - (double)f))));
+    switch (i % 6) {
+        case 0: rgb[0] = uv, rgb[1] = ut, rgb[2] = up; break;
+        case 1: rgb[0] = uq, rgb[1] = uv, rgb[2] = up; break;
+        case 2: rgb[0] = up, rgb[1] = uv, rgb[2] = ut; break;
+        case 3: rgb[0] = up, rgb[1] = uq, rgb[2] = uv; break;
+        case 4: rgb[0] = ut, rgb[1] = up, rgb[2] = uv; break;
+        default: rgb[0] = uv, rgb[1] = up, rgb[2] = uq; break;
+    }
+}
+
+// one thread per (job, output pixel): grid (ceil(H * W / 256), jobs); (H, W) = the output (crop) size
+__global__ void __launch_bounds__(256) frames_augment_kernel(const unsigned char* __restrict__ pool,
+                                                             const MnkAugJob* __restrict__ jobs,
+                                                             const double* __restrict__ rot_range, int H, int W, int Cout,
+                                                             float* __restrict__ out) {
+    const MnkAugJob j = jobs[blockIdx.y];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int h = p / W, w = p - h * W;
+    const AugSrc s{pool + j.strip_offset + (size_t)j.frame * j.in_w * j.channels, j.strip_w, j.in_h, j.in_w, j.channels, j.hflip};
+    // RandomCrop: position inside the edge-padded (rotated, resized) frame -> clamped position inside that frame
+    int ry = h + j.y1 - j.pad_top, rx = w + j.x1 - j.pad_left;
+    ry = ry < 0 ? 0 : (ry > j.new_h - 1 ? j.new_h - 1 : ry);
+    rx = rx < 0 ? 0 : (rx > j.new_w - 1 ? j.new_w - 1 : rx);
+    double v[3];
+    const bool warped = (j.flags & 11) != 0;         // float64 values from here on (skimage converts to double), else float32
+    if (j.flags & 8) {
+        // order 0 (RandomResize's default interpolation 'nearest' -- what every shipped config runs): the pixel at
+        // (round(r), round(c)), C round(), cval outside, no clipping
+        const double row_scale = (double)j.in_h / (double)j.new_h, col_scale = (double)j.in_w / (double)j.new_w;
+        const double c = col_scale * (double)rx + 0.0 * (double)ry + (col_scale / 2.0 - 0.5);
+        const double r = 0.0 * (double)rx + row_scale * (double)ry + (row_scale / 2.0 - 0.5);
+        const double rr = r >= 0.0 ? floor(r + 0.5) : ceil(r - 0.5), cc = c >= 0.0 ? floor(c + 0.5) : ceil(c - 0.5);
+        aug_rotated(j, s, (long)rr, (long)cc, v);
+    } else if (j.flags & 2) {
+        const double row_scale = (double)j.in_h / (double)j.new_h, col_scale = (double)j.in_w / (double)j.new_w;
+        const double c = col_scale * (double)rx + 0.0 * (double)ry + (col_scale / 2.0 - 0.5);
+        const double r = 0.0 * (double)rx + row_scale * (double)ry + (row_scale / 2.0 - 0.5);
+        aug_bilinear(r, c, [&](long y, long x, double* o) { aug_rotated(j, s, y, x, o); }, v);
+        const double lo = (j.flags & 1) ? rot_range[2 * blockIdx.y] : (double)j.vmin;
+        const double hi = (j.flags & 1) ? rot_range[2 * blockIdx.y + 1] : (double)j.vmax;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = aug_clip(v[i], lo, hi);
+    } else {
+        aug_rotated(j, s, ry, rx, v);
+    }
+    float o3[3];
+    if (j.flags & 4) {
+        unsigned char rgb[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                // img_as_ubyte: clip(rint(x * 255)) in the image's own float type
+            double y = warped ? v[i] * 255.0 : (double)((float)v[i] * 255.f);
+            y = rint(y);
+            rgb[i] = (unsigned char)(y < 0.0 ? 0 : (y > 255.0 ? 255 : (int)y));
+        }
+        aug_hue(rgb, j.hue_shift);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o3[i] = (float)((double)rgb[i] * (1.0 / 255));          // img_as_float, then float32
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o3[i] = (float)v[i];
+    }
+    float* o = out + j.out_offset + p;
+    for (int ch = 0; ch < Cout; ++ch) o[(size_t)ch * j.chan_stride] = o3[ch < 3 ? ch : 2];
+}
+
 }  // namespace
 
 extern "C" {
+
+int mnk_frames_augment(const unsigned char* pool, const MnkAugJob* jobs_device, int njobs, int any_rotation, double* rot_range,
+                       int H, int W, int Cout, float* out, void* stream) {
+    MNK_REQUIRE(pool && jobs_device && out && njobs > 0 && njobs <= 65535 && H > 0 && W > 0 && Cout >= 1 && Cout <= 3);
+    MNK_REQUIRE(!any_rotation || rot_range);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_LAYOUT, s, (double)njobs * H * W * (16.0 * 3 + 4.0 * Cout));
+    if (any_rotation) hipLaunchKernelGGL(frames_rotated_range_kernel, dim3(njobs), dim3(256), 0, s, pool, jobs_device, rot_range);
+    hipLaunchKernelGGL(frames_augment_kernel, dim3((H * W + 255) / 256, njobs), dim3(256), 0, s, pool, jobs_device, rot_range, H, W,
+                       Cout, out);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
 
 int mnk_frames_gather(const unsigned char* pool, const MnkFrameJob* jobs_device, int njobs, int H, int W, int Cout, float* out,
                       void* stream) {

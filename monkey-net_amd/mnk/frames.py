@@ -8,11 +8,17 @@ frames is 39 GB of the 288 GB), and a batch is ONE kernel launch (mnk_frames_gat
 choices of the augmentation are drawn on the host in the reference's own order from the same `random` / `numpy.random`
 generators, so with equal seeds a sample is bit-identical to `FramesDataset.__getitem__`.
 
-Supported (integer-exact, parity-tested against the unmodified reference transforms): frame selection, time flip,
-horizontal flip, edge padding + random crop, gray / RGBA handling, uint8 -> float32, (C, D, H, W) layout.  `resize_param`,
-`rotation_param` and `jitter_param` (skimage / PIL arithmetic: config/actions.yaml, moving-gif.yaml) are NOT implemented and
-raise -- there is no host fallback.  `.gif` / `.mp4` inputs need a decoder this image does not have; PNG strips are read by
-the small decoder below (zlib + the five PNG filters), or by PIL when it is importable."""
+Supported, integer-exact and parity-tested against the unmodified reference transforms: frame selection, time flip,
+horizontal flip, edge padding + random crop, gray / RGBA handling, uint8 -> float32, (C, D, H, W) layout.  Round 4: the
+non-integer augmentations of config/moving-gif.yaml and actions.yaml -- `rotation_param` (skimage.transform.rotate),
+`resize_param` (skimage.transform.resize, bilinear, ratios >= 0.8) and `jitter_param` with `hue` (img_as_ubyte -> PIL HSV ->
+torchvision adjust_hue -> img_as_float) -- in one launch per batch (mnk_frames_augment), in the arithmetic of the package
+versions the reference pins; those packages are not in this image, so that path is checked against a numpy restatement of
+their published algorithms (oracle/augment_restate.py, "parity unpinned"), not against the packages themselves.  brightness /
+contrast / saturation jitter (no shipped config sets them) raise.  `.gif` / `.mp4` inputs need a decoder this image does not
+have; PNG strips are read by the small decoder below (zlib + the five PNG filters), or by PIL when it is importable.
+`DevicePairedDataset` is frames_dataset.py:91-131's PairedDataset over a DeviceFramesDataset."""
+import math
 import os
 import random
 import struct
@@ -26,6 +32,12 @@ from . import ops as mops
 JOB = np.dtype([("strip_offset", "<u8"), ("out_offset", "<u8"), ("chan_stride", "<u8"), ("strip_w", "<i4"), ("in_h", "<i4"),
                 ("in_w", "<i4"), ("channels", "<i4"), ("frame", "<i4"), ("hflip", "<i4"), ("x1", "<i4"), ("y1", "<i4"),
                 ("pad_top", "<i4"), ("pad_left", "<i4"), ("reserved0", "<i4"), ("reserved1", "<i4")])
+
+
+AUGJOB = np.dtype([("strip_offset", "<u8"), ("out_offset", "<u8"), ("chan_stride", "<u8"), ("rot", "<f8", (6,)),
+                   ("strip_w", "<i4"), ("in_h", "<i4"), ("in_w", "<i4"), ("channels", "<i4"), ("frame", "<i4"), ("hflip", "<i4"),
+                   ("x1", "<i4"), ("y1", "<i4"), ("pad_top", "<i4"), ("pad_left", "<i4"), ("new_h", "<i4"), ("new_w", "<i4"),
+                   ("flags", "<i4"), ("hue_shift", "<i4"), ("vmin", "<f4"), ("vmax", "<f4")])
 
 
 # ---- PNG (8 bit, non-interlaced; gray, gray + alpha, RGB, RGBA): what `skimage.io.imread` returns for those files -------
@@ -117,10 +129,6 @@ class DeviceFramesDataset:
         self.root_dir = root_dir
         self.images = list(files)
         p = dict(augmentation_params or {})
-        for k in ("resize_param", "rotation_param", "jitter_param"):
-            if is_train and p.get(k) is not None:
-                raise NotImplementedError("augmentation %s is skimage / PIL arithmetic on the host in the reference and is not "
-                                          "part of the device-side input path" % k)
         self.flip = dict(p["flip_param"]) if is_train and p.get("flip_param") is not None else None
         crop = p.get("crop_param") if is_train else None
         if crop is not None:
@@ -128,16 +136,48 @@ class DeviceFramesDataset:
             self.crop = (int(size), int(size)) if isinstance(size, (int, float)) else (int(size[0]), int(size[1]))
         else:
             self.crop = None
+        # the non-integer augmentations (augmentation.py:105-133,175-214,217-320)
+        self.rotation = self.resize = self.hue = None
+        self.resize_order = 0
+        if is_train and p.get("rotation_param") is not None:
+            deg = p["rotation_param"]["degrees"]
+            if isinstance(deg, (int, float)):
+                if deg < 0:
+                    raise ValueError("If degrees is a single number,must be positive")      # augmentation.py:186-188
+                deg = (-deg, deg)
+            if len(deg) != 2:
+                raise ValueError("If degrees is a sequence,it must be of len 2.")
+            self.rotation = (float(deg[0]), float(deg[1]))
+        if is_train and p.get("resize_param") is not None:
+            rp = dict(p["resize_param"])
+            ratio = tuple(rp.get("ratio", (3. / 4., 4. / 3.)))
+            # resize_clip (augmentation.py:55) runs skimage's resize with order=1 ONLY for interpolation == 'bilinear'; the
+            # default 'nearest' -- every shipped config -- is order 0
+            self.resize_order = 1 if rp.get("interpolation", "nearest") == "bilinear" else 0
+            if min(ratio) < 0.8:
+                raise NotImplementedError("resize ratios below 0.8 need skimage's multi-tap anti-aliasing filter (ratio %s)" % (ratio,))
+            self.resize = (float(ratio[0]), float(ratio[1]))
+        if is_train and p.get("jitter_param") is not None:
+            jp = dict(p["jitter_param"])
+            if any(jp.get(k, 0) for k in ("brightness", "contrast", "saturation")):
+                raise NotImplementedError("ColorJitter brightness / contrast / saturation (no shipped config sets them)")
+            if jp.get("hue", 0) > 0:
+                self.hue = float(jp["hue"])
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         # ---- decode once, keep resident -----------------------------------------------------------------------------
         H, W, C = self.image_shape
         strips, self.meta, off = [], [], 0
+        self.ranges = []
         for name in self.images:
             arr = np.ascontiguousarray(read_strip(os.path.join(root_dir, name)))
             h, wf, ch = arr.shape
             if h != H or wf % W != 0:
                 raise ValueError("%s: a %dx%d strip is not a row of %dx%d frames" % (name, h, wf, H, W))
             self.meta.append((off, wf, ch, wf // W))
+            # value range of every frame (over the colour channels the pipeline keeps): skimage clips a warp's output to it
+            fr = arr[:, :, :3] if ch >= 3 else arr[:, :, :1]
+            fr = fr.reshape(h, wf // W, W, -1)
+            self.ranges.append((fr.min(axis=(0, 2, 3)), fr.max(axis=(0, 2, 3))))
             strips.append(arr.reshape(-1))
             off += (arr.size + 15) // 16 * 16
         pool = np.zeros(max(off, 16), dtype=np.uint8)
@@ -151,10 +191,12 @@ class DeviceFramesDataset:
 
     # ---- the random choices of one sample, in the reference's draw order ------------------------------------------------
     def _draw(self, frame_count):
-        """-> (frames [source, driving...], hflip, x1, y1, pad_top, pad_left, out_h, out_w)"""
+        """-> (frames [source, driving...], hflip, x1, y1, pad_top, pad_left, out_h, out_w, angle, new_hw, hue_factor): the
+        random choices of AllAugmentationTransform (augmentation.py:369-389) in ITS draw order -- select, flip, rotation,
+        resize, crop, jitter"""
         H, W, _ = self.image_shape
         if not self.is_train:                                   # VideoToTensor: every frame, no augmentation
-            return list(range(frame_count)), 0, 0, 0, 0, 0, H, W
+            return list(range(frame_count)), 0, 0, 0, 0, 0, H, W, None, None, None
         # SelectRandomFrames (augmentation.py:324-345): two indices with replacement, sorted
         sel = list(np.sort(np.random.choice(range(frame_count), replace=True, size=2)))
         hflip = 0
@@ -163,35 +205,82 @@ class DeviceFramesDataset:
                 sel = sel[::-1]
             elif random.random() < 0.5 and self.flip.get("horizontal_flip", False):
                 hflip = 1
+        angle = random.uniform(self.rotation[0], self.rotation[1]) if self.rotation is not None else None     # :206
+        new_hw = None
+        rh, rw = H, W                                           # the frame size the crop sees
+        if self.resize is not None:                             # RandomResize (:120-133)
+            scaling_factor = random.uniform(self.resize[0], self.resize[1])
+            rw, rh = int(W * scaling_factor), int(H * scaling_factor)
+            new_hw = (rh, rw)
         x1 = y1 = pt = pl = 0
-        oh, ow = H, W
+        oh, ow = rh, rw
         if self.crop is not None:                               # RandomCrop (:135-171) incl. its pad_clip and its quirks
             oh, ow = self.crop
-            pt = 0 if oh < H else (oh - H) // 2
-            pl = 0 if ow < W else (ow - W) // 2
-            im_h = H if oh < H else H + (oh - H) // 2 + (oh - H + 1) // 2
-            im_w = W if ow < W else W + (ow - W) // 2 + (ow - W + 1) // 2
+            pt = 0 if oh < rh else (oh - rh) // 2
+            pl = 0 if ow < rw else (ow - rw) // 2
+            im_h = rh if oh < rh else rh + (oh - rh) // 2 + (oh - rh + 1) // 2
+            im_w = rw if ow < rw else rw + (ow - rw) // 2 + (ow - rw + 1) // 2
             x1 = 0 if oh == im_h else random.randint(0, im_w - ow)      # (sic: the height decides whether x is drawn)
             y1 = 0 if ow == im_w else random.randint(0, im_h - oh)
-        return sel, hflip, x1, y1, pt, pl, oh, ow
+        # ColorJitter.get_params (:238-262) with only `hue` set; random.shuffle of the one-element transform list draws nothing
+        hue = random.uniform(-self.hue, self.hue) if self.hue is not None else None
+        return sel, hflip, x1, y1, pt, pl, oh, ow, angle, new_hw, hue
 
     def _jobs(self, indices):
         """draw every sample of a batch -> (job rows, per-tensor frame counts, output size)"""
         drawn = [(i,) + tuple(self._draw(self.meta[i][3])) for i in indices]
         sizes = {(d[7], d[8]) for d in drawn}
-        assert len(sizes) == 1
+        assert len(sizes) == 1, "samples of one batch must have one output size (a resize needs a crop_param behind it)"
         return drawn, sizes.pop()
 
     def _launch(self, rows, total_floats, oh, ow):
-        rec = np.zeros(len(rows), dtype=JOB)
-        for k, r in enumerate(rows):
-            rec[k] = r
-        table = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.device, non_blocking=True)
-        out = torch.empty(total_floats, dtype=torch.float32, device=self.device)
+        """rows: (frames_gather fields ..., video index, angle, new_hw, hue_factor) per output frame"""
         C = self.image_shape[2]
+        out = torch.empty(total_floats, dtype=torch.float32, device=self.device)
+        augment = self.rotation is not None or self.resize is not None or self.hue is not None
+        if not augment:
+            rec = np.zeros(len(rows), dtype=JOB)
+            for k, r in enumerate(rows):
+                rec[k] = r[:15]
+            table = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.device, non_blocking=True)
+            for k0 in range(0, len(rows), 65535):
+                n = min(65535, len(rows) - k0)
+                mops._call("mnk_frames_gather", out, mops._p(self.pool), table.data_ptr() + k0 * JOB.itemsize, n, oh, ow, C,
+                           mops._p(out))
+            return out
+        rec = np.zeros(len(rows), dtype=AUGJOB)
+        k32 = np.float32(1.0 / 255)
+        for k, r in enumerate(rows):
+            (off, out_off, cstride, wf, H, W, ch, frame, hflip, x1, y1, pt, pl, _, _, vid, angle, new_hw, hue) = r
+            j = rec[k]
+            j["strip_offset"], j["out_offset"], j["chan_stride"] = off, out_off, cstride
+            j["strip_w"], j["in_h"], j["in_w"], j["channels"] = wf, H, W, ch
+            j["frame"], j["hflip"], j["x1"], j["y1"], j["pad_top"], j["pad_left"] = frame, hflip, x1, y1, pt, pl
+            flags = 0
+            if angle is not None:                     # skimage.transform.rotate: T(centre) R(angle) T(-centre) as the inverse map
+                flags |= 1
+                cx, cy = W / 2.0 - 0.5, H / 2.0 - 0.5
+                a = math.radians(angle)
+                co, si = math.cos(a), math.sin(a)
+                j["rot"] = (co, -si, cx - co * cx + si * cy, si, co, cy - si * cx - co * cy)
+            if new_hw is not None:
+                flags |= 2 if self.resize_order == 1 else 8
+                j["new_h"], j["new_w"] = new_hw
+            else:
+                j["new_h"], j["new_w"] = H, W
+            if hue is not None:
+                flags |= 4
+                j["hue_shift"] = int(math.trunc(hue * 255)) % 256          # np.uint8(hue_factor * 255): truncation, wrap-around
+            j["flags"] = flags
+            lo, hi = self.ranges[vid]
+            j["vmin"], j["vmax"] = np.float32(lo[frame]) * k32, np.float32(hi[frame]) * k32
+        table = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.device, non_blocking=True)
+        any_rot = int(self.rotation is not None)
         for k0 in range(0, len(rows), 65535):
             n = min(65535, len(rows) - k0)
-            mops._call("mnk_frames_gather", out, mops._p(self.pool), table.data_ptr() + k0 * JOB.itemsize, n, oh, ow, C, mops._p(out))
+            rng = torch.empty(2 * n, dtype=torch.float64, device=self.device) if any_rot else None
+            mops._call("mnk_frames_augment", out, mops._p(self.pool), table.data_ptr() + k0 * AUGJOB.itemsize, n, any_rot,
+                       mops._p(rng), oh, ow, C, mops._p(out))
         return out
 
     def batch(self, indices):
@@ -209,19 +298,21 @@ class DeviceFramesDataset:
         if self.is_train:
             d_drv = nf - 1
             src_floats = B * C * plane
-            for b, (i, sel, hflip, x1, y1, pt, pl, _, _) in enumerate(drawn):
+            for b, (i, sel, hflip, x1, y1, pt, pl, _, _, angle, new_hw, hue) in enumerate(drawn):
                 off, wf, ch, _ = self.meta[i]
-                rows.append((off, b * C * plane, plane, wf, H, W, ch, int(sel[0]), hflip, x1, y1, pt, pl, 0, 0))
+                rows.append((off, b * C * plane, plane, wf, H, W, ch, int(sel[0]), hflip, x1, y1, pt, pl, 0, 0, i, angle, new_hw,
+                             hue))
                 for d, f in enumerate(sel[1:]):
                     rows.append((off, src_floats + (b * C * d_drv + d) * plane, d_drv * plane, wf, H, W, ch, int(f), hflip, x1,
-                                 y1, pt, pl, 0, 0))
+                                 y1, pt, pl, 0, 0, i, angle, new_hw, hue))
             out = self._launch(rows, src_floats + B * C * d_drv * plane, oh, ow)
             return {"source": out[:src_floats].view(B, C, 1, oh, ow), "video": out[src_floats:].view(B, C, d_drv, oh, ow),
                     "name": [self.images[i] for i in indices]}
-        for b, (i, sel, hflip, x1, y1, pt, pl, _, _) in enumerate(drawn):
+        for b, (i, sel, hflip, x1, y1, pt, pl, _, _, angle, new_hw, hue) in enumerate(drawn):
             off, wf, ch, _ = self.meta[i]
             for d, f in enumerate(sel):
-                rows.append((off, (b * C * nf + d) * plane, nf * plane, wf, H, W, ch, int(f), hflip, x1, y1, pt, pl, 0, 0))
+                rows.append((off, (b * C * nf + d) * plane, nf * plane, wf, H, W, ch, int(f), hflip, x1, y1, pt, pl, 0, 0, i,
+                             angle, new_hw, hue))
         out = self._launch(rows, B * C * nf * plane, oh, ow)
         return {"video": out.view(B, C, nf, oh, ow), "name": [self.images[i] for i in indices]}
 
@@ -250,3 +341,44 @@ class DeviceLoader:
         order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
         for k in range(len(self)):
             yield self.dataset.batch(order[k * self.batch_size:(k + 1) * self.batch_size])
+
+
+
+class DevicePairedDataset:
+    """PairedDataset (frames_dataset.py:91-131): the (driving, source) video pairs that transfer.py iterates, over a
+    DeviceFramesDataset.  Same constructor, same random choice of the pairs (numpy's global generator seeded with `seed`, the
+    mgrid / choice statements of :103-108) or the pairs of the data set's `pairs_list` csv (:109-121); an item is the reference's
+    dict {'driving_video', 'driving_name', 'source_video', 'source_name'} with device tensors."""
+
+    def __init__(self, initial_dataset, number_of_pairs, seed=0):
+        self.initial_dataset = initial_dataset
+        pairs_list = self.initial_dataset.pairs_list
+        np.random.seed(seed)
+        if pairs_list is None:
+            max_idx = min(number_of_pairs, len(initial_dataset))
+            nx, ny = max_idx, max_idx
+            xy = np.mgrid[:nx, :ny].reshape(2, -1).T
+            number_of_pairs = min(xy.shape[0], number_of_pairs)
+            self.pairs = xy.take(np.random.choice(xy.shape[0], number_of_pairs, replace=False), axis=0)
+        else:
+            import pandas as pd
+            images = self.initial_dataset.images
+            name_to_index = {name: index for index, name in enumerate(images)}
+            pairs = pd.read_csv(pairs_list)
+            pairs = pairs[np.logical_and(pairs['source'].isin(images), pairs['driving'].isin(images))]
+            number_of_pairs = min(pairs.shape[0], number_of_pairs)
+            self.pairs = []
+            self.start_frames = []
+            for ind in range(number_of_pairs):
+                self.pairs.append((name_to_index[pairs['driving'].iloc[ind]], name_to_index[pairs['source'].iloc[ind]]))
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def __getitem__(self, idx):
+        pair = self.pairs[idx]
+        first = self.initial_dataset[int(pair[0])]
+        second = self.initial_dataset[int(pair[1])]
+        first = {'driving_' + key: value for key, value in first.items()}
+        second = {'source_' + key: value for key, value in second.items()}
+        return {**first, **second}

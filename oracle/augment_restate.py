@@ -1,0 +1,210 @@
+"""CPU restatement (numpy) of the reference's non-integer augmentations -- TEST INFRASTRUCTURE ONLY (the checker of
+tests/test_frames.py for csrc/frames.hip::frames_augment_kernel; nothing in monkey-net_amd/ imports it).
+
+The reference's RandomResize / RandomRotation / ColorJitter (augmentation.py:105-133,175-214,217-320) are thin wrappers around
+third-party functions that are NOT in this image and not vendored by the reference (requirements.txt pins scikit-image==0.14.0,
+Pillow==5.2.0, torchvision==0.2.1, numpy==1.15.0), so this file restates the published algorithms of exactly those versions,
+function by function, and says where each statement comes from.  **Parity unpinned**: there is no way to execute skimage /
+PIL here, so nothing checks this restatement against the real packages; what IS checked (tests/test_frames.py) is that the
+device kernel reproduces this file, and that the integer-exact parts of the pipeline around it still reproduce the reference
+(tests/golden/frames_shapes.npz, made by the unmodified reference).
+
+    skimage.transform.resize(img, (rows, cols), order=1, preserve_range=True, mode='constant', anti_aliasing=True)
+        0.14.0 transform/_warps.py::resize: image.astype(double); anti-aliasing = ndi.gaussian_filter with
+        sigma = max(0, (in / out - 1) / 2) per axis (scipy truncates the kernel at int(4 sigma + 0.5) taps each side: ONE tap --
+        the identity -- for every ratio >= 0.8, which covers ratio: [0.9, 1.1] of config/moving-gif.yaml and actions.yaml; wider
+        down-scalings are refused here and by the kernel); then warp() with the affine map  in = scale * (out + 0.5) - 0.5,
+        order 1, mode 'constant', cval 0, clip=True.
+    skimage.transform.rotate(img, angle, preserve_range=True)
+        0.14.0 _warps.py::rotate: centre (cols / 2 - 0.5, rows / 2 - 0.5), inverse map T(c) R(angle) T(-c), warp() as above.
+    skimage.transform.warp, order 1, 3-D image
+        0.14.0 _warps_cy.pyx::_warp_fast per channel -> interpolation.pxd::bilinear_interpolation: minr = floor(r), maxr = ceil(r)
+        (likewise c), out-of-image taps read cval (mode 'C'); then _clip_warp_output: np.clip to [image.min(), image.max()] of
+        the whole (H, W, C) input.
+    skimage.img_as_ubyte / img_as_float
+        0.14.0 util/dtype.py::convert: float -> uint8 = clip(rint(x * 255)) in the input's float type; uint8 -> float64 =
+        x * (1 / 255).
+    torchvision.transforms.functional.adjust_hue (0.2.1): PIL RGB -> HSV, h += uint8(hue_factor * 255) with uint8 wrap-around,
+        HSV -> RGB.
+    PIL Image.convert('HSV') / .convert('RGB') (Pillow 5.2.0 libImaging/Convert.c::rgb2hsv, hsv2rgb): the colorsys formulas in
+        C float / double arithmetic with (int) truncation on the way to HSV and round() on the way back."""
+import math
+
+import numpy as np
+
+
+# ---- skimage 0.14.0: warp, order 1, mode 'constant', cval 0, clip ------------------------------------------------------------
+def _bilinear_constant(img, r, c):
+    """interpolation.pxd::bilinear_interpolation on one channel plane `img` (rows, cols) at float64 coordinate arrays r, c"""
+    rows, cols = img.shape
+    minr, minc = np.floor(r).astype(np.int64), np.floor(c).astype(np.int64)
+    maxr, maxc = np.ceil(r).astype(np.int64), np.ceil(c).astype(np.int64)
+    dr, dc = r - minr, c - minc
+
+    def px(rr, cc):
+        ok = (rr >= 0) & (rr < rows) & (cc >= 0) & (cc < cols)
+        return np.where(ok, img[np.clip(rr, 0, rows - 1), np.clip(cc, 0, cols - 1)], 0.0)
+
+    top = (1 - dc) * px(minr, minc) + dc * px(minr, maxc)
+    bottom = (1 - dc) * px(maxr, minc) + dc * px(maxr, maxc)
+    return (1 - dr) * top + dr * bottom
+
+
+def _warp_affine(image, matrix, out_rows, out_cols):
+    """warp(image (H, W, C) float64, inverse map `matrix` (3x3, acting on (col, row, 1)), order=1, mode='constant', clip=True)"""
+    tfr, tfc = np.meshgrid(np.arange(out_rows, dtype=np.float64), np.arange(out_cols, dtype=np.float64), indexing="ij")
+    c = matrix[0, 0] * tfc + matrix[0, 1] * tfr + matrix[0, 2]
+    r = matrix[1, 0] * tfc + matrix[1, 1] * tfr + matrix[1, 2]
+    out = np.stack([_bilinear_constant(image[..., ch], r, c) for ch in range(image.shape[2])], axis=-1)
+    lo, hi = image.min(), image.max()                 # _clip_warp_output (cval 0 inside [lo, hi] or not: clip wins for order 1
+    preserve = not (lo <= 0.0 <= hi)                  #  unless cval lies outside the range: those pixels keep cval)
+    mask = out == 0.0 if preserve else None
+    out = np.clip(out, lo, hi)
+    if preserve:
+        out[mask] = 0.0
+    return out
+
+
+def _c_round_half_away(x):
+    return np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5))
+
+
+def resize(img, new_rows, new_cols, order):
+    """skimage.transform.resize(img, (new_rows, new_cols), order=order, preserve_range=True, mode='constant',
+    anti_aliasing=True), order 1 (bilinear) or 0 -- resize_clip (augmentation.py:55) passes order=1 ONLY for
+    interpolation == 'bilinear'; RandomResize's default 'nearest', which every shipped config uses, is order 0:
+    interpolation.pxd::nearest_neighbour_interpolation = the pixel at (round(r), round(c)) with C's round(), cval 0 outside, and
+    no clipping (_clip_warp_output acts on order != 0 only)."""
+    if order == 1:
+        return resize_bilinear(img, new_rows, new_cols)
+    image = img.astype(np.float64)
+    rows, cols = image.shape[:2]
+    row_scale, col_scale = float(rows) / new_rows, float(cols) / new_cols
+    for f in (row_scale, col_scale):
+        if int(4.0 * max(0.0, (f - 1.0) / 2.0) + 0.5) > 0:
+            raise NotImplementedError("down-scaling by more than 1.25 (ratio < 0.8) needs the multi-tap anti-aliasing filter")
+    tfr, tfc = np.meshgrid(np.arange(new_rows, dtype=np.float64), np.arange(new_cols, dtype=np.float64), indexing="ij")
+    c = col_scale * tfc + 0.0 * tfr + (col_scale / 2.0 - 0.5)
+    r = 0.0 * tfc + row_scale * tfr + (row_scale / 2.0 - 0.5)
+    rr, cc = _c_round_half_away(r).astype(np.int64), _c_round_half_away(c).astype(np.int64)
+    ok = (rr >= 0) & (rr < rows) & (cc >= 0) & (cc < cols)
+    out = image[np.clip(rr, 0, rows - 1), np.clip(cc, 0, cols - 1)]
+    return np.where(ok[..., None], out, 0.0)
+
+
+def resize_bilinear(img, new_rows, new_cols):
+    """skimage.transform.resize(img, (new_rows, new_cols), order=1, preserve_range=True, mode='constant', anti_aliasing=True)"""
+    image = img.astype(np.float64)
+    rows, cols = image.shape[:2]
+    row_scale, col_scale = float(rows) / new_rows, float(cols) / new_cols
+    for f in (row_scale, col_scale):                   # anti-aliasing: scipy's gaussian_filter1d truncates at int(4 sigma + .5)
+        if int(4.0 * max(0.0, (f - 1.0) / 2.0) + 0.5) > 0:
+            raise NotImplementedError("down-scaling by more than 1.25 (ratio < 0.8) needs the multi-tap anti-aliasing filter")
+    m = np.array([[col_scale, 0.0, col_scale / 2.0 - 0.5], [0.0, row_scale, row_scale / 2.0 - 0.5], [0.0, 0.0, 1.0]])
+    return _warp_affine(image, m, new_rows, new_cols)
+
+
+def rotate_bilinear(img, angle_deg):
+    """skimage.transform.rotate(image=img, angle=angle_deg, preserve_range=True)"""
+    image = img.astype(np.float64)
+    rows, cols = image.shape[:2]
+    cx, cy = cols / 2.0 - 0.5, rows / 2.0 - 0.5
+    a = math.radians(angle_deg)
+    co, si = math.cos(a), math.sin(a)
+    # tform3 + tform2 + tform1 = T(center) @ R(a) @ T(-center)   (SimilarityTransform: [[cos, -sin, tx], [sin, cos, ty]])
+    m = np.array([[co, -si, cx - co * cx + si * cy], [si, co, cy - si * cx - co * cy], [0.0, 0.0, 1.0]])
+    return _warp_affine(image, m, rows, cols)
+
+
+# ---- skimage 0.14.0 dtype conversions ---------------------------------------------------------------------------------------
+def img_as_ubyte(x):
+    y = x * x.dtype.type(255)                          # (the input's own float type: float64 after resize / rotate, else float32)
+    return np.clip(np.rint(y), 0, 255).astype(np.uint8)
+
+
+def img_as_float(u8):
+    return np.multiply(u8, 1.0 / 255, dtype=np.float64)
+
+
+# ---- Pillow 5.2.0 libImaging/Convert.c -----------------------------------------------------------------------------------------
+def rgb2hsv_u8(rgb):
+    r, g, b = (rgb[..., i].astype(np.int32) for i in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    gray = maxc == minc
+    cr = np.where(gray, 1, maxc - minc).astype(np.float32)
+    mx = np.where(maxc == 0, 1, maxc).astype(np.float32)
+    s = cr / mx                                                                   # float
+    rc, gc, bc = ((maxc - r).astype(np.float32) / cr, (maxc - g).astype(np.float32) / cr, (maxc - b).astype(np.float32) / cr)
+    # 2.0 + rc - bc: the C expression promotes to double
+    h = np.where(r == maxc, (bc - gc).astype(np.float32),
+                 np.where(g == maxc, (2.0 + rc.astype(np.float64) - bc.astype(np.float64)).astype(np.float32),
+                          (4.0 + gc.astype(np.float64) - rc.astype(np.float64)).astype(np.float32)))
+    h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)         # h = fmod((h/6.0 + 1.0), 1.0), stored as float
+    uh = np.clip((h.astype(np.float64) * 255.0).astype(np.int64), 0, 255)         # (int) truncation, CLIP8
+    us = np.clip((s.astype(np.float64) * 255.0).astype(np.int64), 0, 255)
+    return np.stack([np.where(gray, 0, uh), np.where(gray, 0, us), maxc], axis=-1).astype(np.uint8)
+
+
+def _c_round(x):
+    """C round(): half away from zero"""
+    return np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5)).astype(np.int64)
+
+
+def hsv2rgb_u8(hsv):
+    h, s, v = (hsv[..., i].astype(np.int64) for i in range(3))
+    hf = h.astype(np.float32).astype(np.float64) * 6.0 / 255.0
+    i = np.floor(hf).astype(np.int64)
+    f = (hf - i.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)     # float f
+    fs = (s.astype(np.float32).astype(np.float64) / 255.0).astype(np.float32).astype(np.float64)   # float fs
+    vf = v.astype(np.float32).astype(np.float64)
+    p = np.clip(_c_round(vf * (1.0 - fs)), 0, 255)
+    q = np.clip(_c_round(vf * (1.0 - fs * f)), 0, 255)
+    t = np.clip(_c_round(vf * (1.0 - fs * (1.0 - f))), 0, 255)
+    k = i % 6
+    r = np.choose(k, [v, q, p, p, t, v])
+    g = np.choose(k, [t, v, v, q, p, p])
+    b = np.choose(k, [p, p, t, v, v, q])
+    gray = s == 0
+    return np.stack([np.where(gray, v, r), np.where(gray, v, g), np.where(gray, v, b)], axis=-1).astype(np.uint8)
+
+
+def hue_shift_u8(hue_factor):
+    """np.uint8(hue_factor * 255): the C cast of a double -- truncation toward zero, then wrap-around modulo 256"""
+    return int(math.trunc(hue_factor * 255)) % 256
+
+
+def adjust_hue(img_float, hue_factor):
+    """ColorJitter.__call__ for one image with only `hue` set (augmentation.py:269-300): img_as_ubyte -> ToPILImage ->
+    torchvision adjust_hue -> np.array -> img_as_float -> astype('float32')"""
+    u8 = img_as_ubyte(img_float)
+    hsv = rgb2hsv_u8(u8)
+    hsv[..., 0] = (hsv[..., 0].astype(np.int64) + hue_shift_u8(hue_factor)) % 256
+    return img_as_float(hsv2rgb_u8(hsv)).astype(np.float32)
+
+
+# ---- the reference's pipeline on one sample (augmentation.py:369-389) with the random choices handed in ----------------------
+def pad_clip_edge(clip, h, w):
+    """augmentation.py:33-39 (skimage.util.pad = numpy.pad, mode='edge')"""
+    im_h, im_w = clip[0].shape[:2]
+    pad_h = (0, 0) if h < im_h else ((h - im_h) // 2, (h - im_h + 1) // 2)
+    pad_w = (0, 0) if w < im_w else ((w - im_w) // 2, (w - im_w + 1) // 2)
+    return np.pad(np.asarray(clip), ((0, 0), pad_h, pad_w, (0, 0)), mode="edge")
+
+
+def pipeline(frames_u8, sel, hflip, angle, new_hw, crop, x1, y1, hue_factor, resize_order=0):
+    """frames_u8 (F, H, W, 3) uint8 of one video; the draws of mnk.frames.DeviceFramesDataset._draw -> (C, D, h, w) float32 in
+    SplitSourceDriving's layout (source first).  angle / new_hw / crop / hue_factor: None = that transform is not configured."""
+    clip = [np.multiply(frames_u8[f], 1.0 / 255, dtype=np.float32) for f in sel]          # img_as_float32, selection (+ time flip)
+    if hflip:
+        clip = [np.fliplr(img) for img in clip]
+    if angle is not None:
+        clip = [rotate_bilinear(img, angle) for img in clip]
+    if new_hw is not None:
+        clip = [resize(img, new_hw[0], new_hw[1], resize_order) for img in clip]
+    if crop is not None:
+        h, w = crop
+        clip = pad_clip_edge(clip, h, w)
+        clip = [img[y1:y1 + h, x1:x1 + w, :] for img in clip]
+    if hue_factor is not None:
+        clip = [adjust_hue(np.asarray(img), hue_factor) for img in clip]
+    return np.array(clip, dtype="float32").transpose((3, 0, 1, 2))

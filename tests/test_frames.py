@@ -127,12 +127,119 @@ def test_a_batch_is_one_launch_of_the_same_samples(be, shapes):
     assert vb["video"].shape == (2, 3, 32, 64, 64) and "source" not in vb
 
 
-def test_transforms_without_an_exact_device_form_raise(shapes):
+def test_transforms_without_a_device_form_raise(shapes):
     from mnk import frames
     fx, root, names = shapes
-    for bad in ({"resize_param": {"ratio": [0.9, 1.1]}}, {"rotation_param": {"degrees": 10}}, {"jitter_param": {"hue": 0.5}}):
+    for bad in ({"resize_param": {"ratio": [0.5, 1.1]}}, {"jitter_param": {"brightness": 0.2}},
+                {"jitter_param": {"hue": 0.1, "contrast": 0.3}}):
         with pytest.raises(NotImplementedError):
             frames.DeviceFramesDataset(root, bad, device="cpu", files=names)
+
+
+AUG = {   # config/moving-gif.yaml:5-14 (at the 64x64 frames of the fixture), config/actions.yaml:5-16, and the order-1 resize
+    "moving-gif": {"flip_param": {"horizontal_flip": True, "time_flip": True}, "crop_param": {"size": [64, 64]},
+                   "resize_param": {"ratio": [0.9, 1.1]}, "jitter_param": {"hue": 0.5}},
+    "actions": {"flip_param": {"time_flip": True, "horizontal_flip": True}, "crop_param": {"size": [64, 64]},
+                "resize_param": {"ratio": [0.9, 1.1]}, "jitter_param": {"hue": 0.5}, "rotation_param": {"degrees": [-10, 10]}},
+    "bilinear": {"crop_param": {"size": [56, 72]}, "resize_param": {"ratio": [0.85, 1.2], "interpolation": "bilinear"},
+                 "rotation_param": {"degrees": 25}},
+    "hue-only": {"jitter_param": {"hue": 0.3}},
+}
+
+
+@pytest.mark.parametrize("tag", sorted(AUG))
+def test_resize_rotation_and_hue_jitter_equal_the_restated_library_arithmetic(be, shapes, tag):
+    """the augmentation_params of config/moving-gif.yaml / actions.yaml through DeviceFramesDataset (mnk_frames_augment) against
+    oracle/augment_restate.py -- skimage 0.14.0's resize / rotate, Pillow 5.2.0's HSV conversions, torchvision 0.2.1's
+    adjust_hue restated in numpy; those packages are absent here, so the restatement itself is unpinned -- with the SAME random
+    draws.  Tolerance: the warps run in float64 on both sides and differ only by libm (cos / sin / fmod): |diff| <= 1e-6 without
+    the jitter; with it the values are uint8 levels / 255 and a level can flip where x * 255 lands within ~1e-9 of a rounding
+    boundary: at most 0.01 % of the values may differ, by one hue step's worth of colour at most."""
+    from mnk import frames
+    from oracle import augment_restate as ar
+    fx, root, names = shapes
+    params = AUG[tag]
+    ds = frames.DeviceFramesDataset(root, params, image_shape=(64, 64, 3), is_train=True, device=be.device, files=names)
+    strips = [fx["strip%d" % i] for i in range(len(names))]
+    total = differ = 0
+    worst = 0.0
+    for seed in (0, 1, 2):
+        for idx in range(len(names)):
+            random.seed(100 * seed + idx), np.random.seed(100 * seed + idx)
+            item = ds[idx]
+            random.seed(100 * seed + idx), np.random.seed(100 * seed + idx)
+            sel, hflip, x1, y1, pt, pl, oh, ow, angle, new_hw, hue = ds._draw(ds.meta[idx][3])
+            strip = strips[idx][:, :, :3]
+            frames_u8 = np.moveaxis(strip.reshape(64, -1, 64, 3), 1, 0)          # read_video: (F, H, W, 3)
+            ref = ar.pipeline(frames_u8, sel, hflip, angle, new_hw, ds.crop, x1, y1, hue, resize_order=ds.resize_order)
+            got = torch.cat([item["source"], item["video"]], dim=1).cpu().numpy()
+            assert got.shape == ref.shape, (got.shape, ref.shape)
+            d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+            total += d.size
+            differ += int((d > 1e-6).sum())
+            worst = max(worst, float(d.max()))
+    if "jitter_param" in params:
+        assert differ <= 1e-4 * total, (tag, differ, total, worst)
+    else:
+        assert worst <= 1e-6, (tag, worst)
+    print("%s: %d values, %d differ by more than 1e-6, largest difference %.3e" % (tag, total, differ, worst))
+
+
+def test_the_draw_order_of_the_full_augmentation_matches_the_reference_statement_order():
+    """AllAugmentationTransform (augmentation.py:369-389) runs select -> flip -> rotation -> resize -> crop -> jitter; a replay of
+    exactly those `random` / `numpy.random` calls must leave both generators where DeviceFramesDataset._draw leaves them"""
+    from mnk import frames
+    ds = frames.DeviceFramesDataset.__new__(frames.DeviceFramesDataset)
+    ds.image_shape, ds.is_train = (64, 64, 3), True
+    ds.flip, ds.crop = {"time_flip": True, "horizontal_flip": True}, (64, 64)
+    ds.rotation, ds.resize, ds.hue, ds.resize_order = (-10.0, 10.0), (0.9, 1.1), 0.5, 0
+    for seed in range(20):
+        random.seed(seed), np.random.seed(seed)
+        got = ds._draw(32)
+        after = (random.random(), np.random.rand())
+        random.seed(seed), np.random.seed(seed)
+        sel = list(np.sort(np.random.choice(range(32), replace=True, size=2)))         # SelectRandomFrames
+        hflip = 0
+        if random.random() < 0.5:                                                       # RandomFlip (both flags set)
+            sel = sel[::-1]
+        elif random.random() < 0.5:
+            hflip = 1
+        angle = random.uniform(-10.0, 10.0)                                             # RandomRotation
+        sf = random.uniform(0.9, 1.1)                                                   # RandomResize
+        nw, nh = int(64 * sf), int(64 * sf)
+        im_h = nh if 64 < nh else nh + (64 - nh) // 2 + (64 - nh + 1) // 2              # pad_clip
+        im_w = nw if 64 < nw else nw + (64 - nw) // 2 + (64 - nw + 1) // 2
+        x1 = 0 if 64 == im_h else random.randint(0, im_w - 64)                          # RandomCrop
+        y1 = 0 if 64 == im_w else random.randint(0, im_h - 64)
+        hue = random.uniform(-0.5, 0.5)                                                 # ColorJitter.get_params (hue only)
+        random.shuffle([None])                                                          # one transform: no draw
+        assert (random.random(), np.random.rand()) == after
+        assert got[0] == sel and got[1] == hflip and got[2:4] == (x1, y1) and got[8] == angle and got[9] == (nh, nw) and got[10] == hue
+
+
+def test_paired_dataset_pairs_and_items(be, shapes):
+    """DevicePairedDataset = frames_dataset.py:91-131: the same pairs as the reference's statements draw, items with the
+    reference's keys"""
+    from mnk import frames
+    fx, root, names = shapes
+    ds = frames.DeviceFramesDataset(root, None, image_shape=(64, 64, 3), is_train=False, device=be.device, files=names)
+    pd_ = frames.DevicePairedDataset(ds, number_of_pairs=5, seed=3)
+    np.random.seed(3)                                     # frames_dataset.py:100-108, restated
+    xy = np.mgrid[:5, :5].reshape(2, -1).T
+    want = xy.take(np.random.choice(xy.shape[0], 5, replace=False), axis=0)
+    assert np.array_equal(np.asarray(pd_.pairs), want) and len(pd_) == 5
+    item = pd_[1]
+    assert set(item) == {"driving_video", "driving_name", "source_video", "source_name"}
+    assert item["driving_name"] == names[want[1][0]] and item["source_name"] == names[want[1][1]]
+    assert torch.equal(item["driving_video"].cpu(), ds[int(want[1][0])]["video"].cpu())
+    # pairs_list csv (frames_dataset.py:109-121)
+    csv = os.path.join(root, "pairs.csv")
+    with open(csv, "w") as f:
+        f.write("source,driving\n%s,%s\n%s,%s\nmissing.png,%s\n" % (names[0], names[1], names[2], names[0], names[1]))
+    ds2 = frames.DeviceFramesDataset(root, None, image_shape=(64, 64, 3), is_train=False, device=be.device, files=names,
+                                     pairs_list=csv)
+    pd2 = frames.DevicePairedDataset(ds2, number_of_pairs=10)
+    assert pd2.pairs == [(1, 0), (0, 2)]                  # (driving, source); the row with a missing file is dropped
 
 
 def _history_check(step, x, history, history64, be):
