@@ -400,6 +400,23 @@ int mnk_allreduce_bnstats(void* comm, float* sums, long n, void* stream);
 int mnk_allreduce_bnstats_to(void* comm, const float* sums, float* out, long n, void* stream);
 int mnk_allreduce_grads(void* comm, float* grads, long n, int average, long chunk_floats, void* stream);
 
+/* ---- SyncBN exchange of one node without a collective library (round 4; SURVEY.md section 5, section 7 hard part 6) -------------
+ * Replaces sync_batchnorm/batchnorm.py:95-111 + comm.py:102-133 (reduce to the master replica + broadcast through queues) for
+ * the <= 8 KB [sum, sum of squares] / [sum g, sum g xhat] vectors of a norm layer: every rank owns a mailbox in its HBM
+ * (mnk_p2p_create), exports it as a 64-byte IPC handle (mnk_p2p_export; the host layer gathers the handles of all ranks of the
+ * node, in rank order) and maps the others' (mnk_p2p_connect).  mnk_p2p_allreduce is ONE 256-thread kernel on `stream`: push
+ * the rank's n <= mnk_p2p_max_floats() floats into its row of every mailbox over xGMI, flag it with the exchange's sequence
+ * number (kept in device memory and advanced by the kernel: capturable), wait for every rank's flag in the own mailbox, add
+ * the rows in rank order -> out (in == out allowed): every rank gets the same bits.  The wait gives up after timeout_ms
+ * (a dead peer must not hang the GPU) and raises the handle's error word, read with mnk_p2p_error (0 = none; it synchronises). */
+int mnk_p2p_max_floats(void);
+int mnk_p2p_create(int rank, int world, void** handle_out);
+int mnk_p2p_export(void* handle, void* ipc_handle64);
+int mnk_p2p_connect(void* handle, const void* all_handles);
+int mnk_p2p_allreduce(void* handle, const float* in, float* out, int n, int timeout_ms, void* stream);
+int mnk_p2p_error(void* handle, int* flag_out);
+int mnk_p2p_destroy(void* handle);
+
 /* ---- grouped 1x1 convolution (SameBlock3D, modules/util.py:118, dense_motion_module.py:24-28) ----------- */
 int mnk_gconv1x1_fwd(const float* x, int ld_x, const float* w, const float* bias, float* y, int ld_y, long rows,
                      int groups, int gsize, void* stream);

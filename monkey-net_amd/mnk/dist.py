@@ -87,12 +87,100 @@ def direct_comm(kind="main"):
     return _COMM["handle"]
 
 
+# ---- the SyncBN exchange of one node as the library's own peer-to-peer kernel (csrc/p2p.hip, mnk_p2p_*) -----------------
+# One 256-thread kernel per norm layer and direction instead of one RCCL all-reduce: every rank pushes its <= 8 KB vector into
+# every rank's IPC-mapped mailbox and adds the rows in rank order (bit-identical sums on all ranks).  torch.distributed only
+# carries the 64-byte IPC handles once.  Used when every rank of the group runs on this host (one process per GPU of one node:
+# the deployment BASELINE.json names); otherwise -- or with MNK_SYNCBN_P2P=0 -- the RCCL path below.
+_P2P = {"tried": False, "handle": None, "max": 0}
+P2P_TIMEOUT_MS = 20000
+
+
+def p2p_comm(force=False):
+    """The peer-to-peer exchange handle (an int) or None.  force: also with a gloo group (the GPU test runs several processes
+    on ONE device, which RCCL does not allow)."""
+    if _P2P["tried"]:
+        return _P2P["handle"]
+    _P2P["tried"] = True
+    try:
+        if not (knobs.on("MNK_SYNCBN_P2P") and initialized() and (force or tdist.get_backend() == "nccl")):
+            return None
+        import ctypes
+        import socket
+        from . import _lib
+        lib = _lib.lib()
+        if not lib.is_device_build or not torch.cuda.is_available():
+            return None
+        world, me = tdist.get_world_size(), tdist.get_rank()
+        handle = ctypes.c_void_p()
+        mine = (ctypes.c_ubyte * 64)()
+        ok = True
+        try:
+            lib.call("mnk_p2p_create", me, world, ctypes.byref(handle))
+            lib.call("mnk_p2p_export", handle, mine)
+        except Exception as e:
+            ok = False
+            why = str(e)
+        # every rank takes part in the gather whatever happened locally: the decision must be the same on all ranks
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, (socket.gethostname(), bytes(mine) if ok else None))
+        if not all(g[1] is not None for g in gathered) or len({g[0] for g in gathered}) != 1:
+            if handle:
+                lib.cdll.mnk_p2p_destroy(handle)
+            return None
+        blob = b"".join(g[1] for g in gathered)
+        ok2 = True
+        try:
+            lib.call("mnk_p2p_connect", handle, ctypes.c_char_p(blob))
+        except Exception as e:
+            ok2 = False
+            why = str(e)
+        flags = [None] * world
+        tdist.all_gather_object(flags, ok2)
+        if not all(flags):
+            lib.cdll.mnk_p2p_destroy(handle)
+            if not ok2:
+                raise RuntimeError(why)
+            return None
+        _P2P["handle"] = handle.value
+        _P2P["max"] = int(lib.query("mnk_p2p_max_floats"))
+    except Exception as e:      # the RCCL / torch.distributed path below is always there
+        import sys
+        sys.stderr.write("mnk.dist: peer-to-peer SyncBN exchange not available (%s: %s); using the collective path\n"
+                         % (type(e).__name__, e))
+        _P2P["handle"] = None
+    return _P2P["handle"]
+
+
+def p2p_error():
+    """0, or 1 + the rank whose contribution an exchange gave up waiting for (synchronises the device)"""
+    if _P2P["handle"] is None:
+        return 0
+    import ctypes
+    from . import _lib
+    flag = ctypes.c_int(0)
+    _lib.lib().call("mnk_p2p_error", ctypes.c_void_p(_P2P["handle"]), ctypes.byref(flag))
+    return int(flag.value)
+
+
+def _p2p_sum(t, out):
+    h = p2p_comm() if t.is_cuda else None
+    if h is None or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() > _P2P["max"]:
+        return False
+    from . import _lib
+    import ctypes
+    _lib.lib().call("mnk_p2p_allreduce", ctypes.c_void_p(h), t.data_ptr(), out.data_ptr(), t.numel(), P2P_TIMEOUT_MS, _stream_of(t))
+    return True
+
+
 def _stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def all_reduce_sum_(t):
     """SyncBN exchange: sum a small fp32 vector over the ranks in place."""
+    if _p2p_sum(t, t):
+        return t
     h = direct_comm() if t.is_cuda else None
     if h is not None and t.dtype == torch.float32 and t.is_contiguous():
         from . import _lib
@@ -104,6 +192,10 @@ def all_reduce_sum_(t):
 
 def all_reduce_sum(t):
     """-> a new tensor: the sum of `t` over the ranks; `t` keeps the local values (no copy launch in front of the collective)."""
+    if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+        out = torch.empty_like(t)
+        if _p2p_sum(t, out):
+            return out
     h = direct_comm() if t.is_cuda else None
     if h is not None and t.dtype == torch.float32 and t.is_contiguous():
         from . import _lib

@@ -1,0 +1,131 @@
+"""The SyncBN exchange of one node as the library's own peer-to-peer kernel (csrc/p2p.hip, mnk_p2p_*; replaces
+sync_batchnorm/batchnorm.py:95-111 + comm.py:102-133) WITHOUT an 8-GPU box: 2 and 4 processes share the one MI355X of the test
+box -- IPC handles work between processes on the same device; RCCL does not allow that, a hand-written exchange does -- and
+every rank's result must be, bit for bit, the rank-ordered sum of all ranks' vectors: eager launches with message sizes from
+one float to the largest BatchNorm of the configurations (2 x 1024 channels), and exchanges captured in a hipGraph and
+replayed (the sequence number lives in device memory).  A dead peer must not hang the GPU: the kernel's wait is bounded
+(mnk.dist.P2P_TIMEOUT_MS), and every process of this test runs under a deadline."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(rank, it, n):
+    g = torch.Generator().manual_seed(1000 * it + rank)
+    return torch.randn(n, generator=g) * (1.0 + rank)
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "monkey-net_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import threading
+    threading.Timer(150.0, lambda: os._exit(17)).start()          # the whole process under a deadline, whatever happens
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from mnk import dist as mdist
+    mdist.P2P_TIMEOUT_MS = 4000
+    h = mdist.p2p_comm(force=True)
+    assert h is not None, "the peer-to-peer exchange did not come up"
+    nmax = mdist._P2P["max"]
+    sizes = [1, 2, 3, 64, 90, 256, 1000, 2048, nmax] + [int(torch.randint(1, nmax + 1, (1,), generator=torch.Generator().manual_seed(k)))
+                                                       for k in range(60)]
+    bad = 0
+    for it, n in enumerate(sizes):
+        mine = _vec(rank, it, n).to(dev)
+        out = mdist.all_reduce_sum(mine) if it % 2 else mdist.all_reduce_sum_(mine.clone())
+        want = torch.zeros(n)
+        for q in range(world):                      # the kernel adds the rows in rank order, starting from 0.f
+            want = want + _vec(q, it, n)
+        torch.cuda.synchronize()
+        if not torch.equal(out.cpu(), want):
+            bad += 1
+    assert bad == 0, "%d of %d exchanges differ from the rank-ordered sum" % (bad, len(sizes))
+    assert mdist._P2P["handle"] is not None and mdist.p2p_error() == 0
+    # ---- captured: three exchanges in a hipGraph, replayed with new inputs (the sequence counter advances on the device)
+    n = 530
+    a, b = torch.zeros(n, device=dev), torch.zeros(2 * n, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        mdist.all_reduce_sum(a), mdist.all_reduce_sum(b)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ra = mdist.all_reduce_sum(a)
+        rb = mdist.all_reduce_sum(b)
+        rc = mdist.all_reduce_sum(ra * 0.5)          # an exchange that depends on the first one's result
+    for rep in range(6):
+        a.copy_(_vec(rank, 500 + rep, n).to(dev))
+        b.copy_(_vec(rank, 600 + rep, 2 * n).to(dev))
+        g.replay()
+        torch.cuda.synchronize()
+        wa, wb = torch.zeros(n), torch.zeros(2 * n)
+        for q in range(world):
+            wa, wb = wa + _vec(q, 500 + rep, n), wb + _vec(q, 600 + rep, 2 * n)
+        wc = torch.zeros(n)
+        for q in range(world):
+            wc = wc + wa * 0.5
+        assert torch.equal(ra.cpu(), wa) and torch.equal(rb.cpu(), wb) and torch.equal(rc.cpu(), wc), rep
+    assert mdist.p2p_error() == 0
+    # ---- what an exchange costs with `world` processes on this one device (event timing on rank 0's stream)
+    x = torch.randn(256, device=dev)
+    for _ in range(5):
+        mdist.all_reduce_sum(x)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        mdist.all_reduce_sum(x)
+    e1.record()
+    torch.cuda.synchronize()
+    if rank == 0:
+        with open(os.path.join(out_dir, "timing.txt"), "w") as f:
+            f.write("world %d on one device: %.1f us per exchange of 256 floats (100 back-to-back, events)\n"
+                    % (world, e0.elapsed_time(e1) * 10.0))
+    dist.barrier()
+    dist.destroy_process_group()
+    os._exit(0)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_to_peer_syncbn_exchange_between_processes_on_one_device(world, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert codes == [0] * world, "worker exit codes %s (17 = the worker's own deadline)" % codes
+    t = open(os.path.join(tmp_path, "timing.txt")).read().strip()
+    print(t)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "p2p_timing_world%d.txt" % world), "w") as f:
+            f.write(t + "\n")
