@@ -250,6 +250,24 @@ int mnk_conv3x3_up_fwd(const float* x0, int ld0, int C0, const float* x1, int ld
 size_t mnk_conv3x3_up_dgrad_workspace_floats(int N, int H, int W, int Cout, int C);
 int mnk_conv3x3_up_dgrad(const float* dy, int ld_dy, int Cout, const float* wp_up_dgrad, float* dx, int ld_dx, int N, int H,
                          int W, int C, float* ws, size_t ws_floats, void* stream);
+/* Data-gradient launches that ALSO leave the backward statistics of the BatchNorm (+ activation) layer whose output they
+ * differentiate (round 4; sync_batchnorm/batchnorm.py:48-78 backward through modules/util.py:56-62,81-87): dx of the
+ * convolution IS dz of the norm layer in front when that layer's output has no other consumer, and the GEMM epilogue holds the
+ * dz tile in registers, so stats_partial receives per-block column sums of
+ *     g = act'((bn_y - mean) * scale + beta) * dz      and      g * (bn_y - mean) * invstd
+ * ([blocks][2][ld_dx], blocks * 2 * ld_dx = mnk_conv3x3_stats_floats(N, H, W, Cout, 0, C) resp.
+ * mnk_conv3x3_up_dgrad_stats_floats; 0: this shape's launch plan has no statistics form) -- what mnk_bn_act_bwd_stats makes
+ * in a pass of its own over bn_y and dz; mnk_bn_stats_finish sums them.  slope: < 0 none, 0 ReLU, > 0 LeakyReLU.  The norm
+ * layer must not pool (dz and bn_y have one geometry). */
+int mnk_conv3x3_dgrad_bnstats(const float* dy, int ld_dy, int Cout, const float* wp_dgrad, const float* residual, int ld_res,
+                              float* dx, int ld_dx, int N, int H, int W, int C, float* ws, size_t ws_floats, float* stats_partial,
+                              const float* bn_y, int ld_bny, const float* bn_mean, const float* bn_invstd, const float* bn_scale,
+                              const float* bn_beta, float slope, void* stream);
+size_t mnk_conv3x3_up_dgrad_stats_floats(int N, int H, int W, int Cout, int C);
+int mnk_conv3x3_up_dgrad_bnstats(const float* dy, int ld_dy, int Cout, const float* wp_up_dgrad, float* dx, int ld_dx, int N, int H,
+                                 int W, int C, float* ws, size_t ws_floats, float* stats_partial, const float* bn_y, int ld_bny,
+                                 const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_beta,
+                                 float slope, void* stream);
 
 /* ---- general K x K form of the same kernels (stride 1).  Used for the discriminator's nn.Conv3d((1,4,4)) without
  * padding (modules/discriminator.py:17-18; SURVEY.md section 8f row 1, the first "next" component): forward

@@ -40,6 +40,19 @@ __device__ __forceinline__ int round_up16(int v) { return (v + 15) & ~15; }
 constexpr int BK = 16;        // K step (floats)
 constexpr int LDS_K = 20;     // padded LDS row (floats)
 
+// The BatchNorm (+ activation) layer whose OUTPUT this launch's output is the gradient of (a data-gradient launch: dz of the
+// layer in front).  With it the fused column sums of the epilogue are that layer's backward statistics
+//     sum g,  sum g * xhat      g = act'((y - mean) * scale + beta) * dz,   xhat = (y - mean) * invstd
+// (sync_batchnorm/batchnorm.py's backward through F.batch_norm; what colsum2_partial_kernel<BwdLoader> makes in a pass of its
+// own over y and dz) instead of sum v, sum v^2 -- the tile of dz is in registers here, only y is read.  slope: < 0 no
+// activation, 0 ReLU, > 0 LeakyReLU.  y == nullptr: plain statistics.
+struct BnBwdSrc {
+    const float* y;
+    const float *mean, *invstd, *scale, *beta;
+    int ld;
+    float slope;
+};
+
 struct ConvArgs {
     const float* x0;
     const float* x1;
@@ -63,7 +76,6 @@ struct ConvArgs {
     int ldw;
     float* stats;      // optional [gridDim.x][2][ld_y]: per-block column sums / sums of squares of the written output
     int xcd;           // re-chunk the launch order per XCD (xcd_tile)
-    int nt;            // write the output with non-temporal stores (tuning value "igemm_nt_store")
     int clean;         // the sources' pad channels [C, ld) hold zeros (finite values): the 3x3 fast loader may be used
     unsigned mulW, shW, mulH, shH;   // division of an output pixel index (< 2^31) by W and H (fast_div)
     // ---- K x K loader generalisations (ActLoaderK) ---------------------------------------------------------------
@@ -79,6 +91,7 @@ struct ConvArgs {
     // (2i + a, 2j + b) of the (N, 2H, 2W) tensor.
     int phases, tiles_per_phase;
     long phase_wstride;
+    BnBwdSrc bnb;
 };
 
 // buffer resource from values the compiler cannot prove wave-uniform (e.g. derived from a 64-bit division): pin the
@@ -597,11 +610,18 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     };
     int cov[TN];
     float bv[TN], s1[TN], s2[TN];
+    const bool bnb = a.bnb.y != nullptr && a.stats && !split_out;     // the column sums are a BatchNorm layer's backward statistics
+    float bm[TN], bis[TN], bsc[TN], bbe[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         cov[j] = n0 + wn * (BN / WN) + 32 * j + fi;
         bv[j] = (!split_out && a.bias && cov[j] < a.Cout) ? a.bias[cov[j]] : 0.f;
         s1[j] = s2[j] = 0.f;
+        const bool real = bnb && cov[j] < a.Cout;
+        bm[j] = real ? a.bnb.mean[cov[j]] : 0.f;
+        bis[j] = real ? a.bnb.invstd[cov[j]] : 0.f;
+        bsc[j] = real ? a.bnb.scale[cov[j]] : 0.f;
+        bbe[j] = real ? a.bnb.beta[cov[j]] : 0.f;
     }
     auto emit = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -624,19 +644,35 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
                             if (FULL || mb + ro < Mu) rv[r] = a.residual[roff0 + ro * (unsigned)a.ld_res];
                         }
                     }
+                    float yv[16];
+                    if (bnb) {
+                        const unsigned yoff0 = mb * (unsigned)a.bnb.ld + (unsigned)co;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const unsigned ro = (r & 3) + 8 * (r >> 2);
+                            yv[r] = (c_real && (FULL || mb + ro < Mu)) ? a.bnb.y[yoff0 + ro * (unsigned)a.bnb.ld] : 0.f;
+                        }
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const unsigned ro = (r & 3) + 8 * (r >> 2);
                         float v = acc[0][i][j][r];
                         if (!split_out) v = c_real ? (v + bv[j]) + rv[r] : 0.f;
                         if (FULL || mb + ro < Mu) {
-                            float* const dst = scatter ? obase + out_row(mb + ro) * ldo + (unsigned)co : obase + off0 + ro * ldo;
-                            if (a.nt)
-                                MNK_NT_STORE(v, dst);
+                            if (scatter)
+                                obase[out_row(mb + ro) * ldo + (unsigned)co] = v;
                             else
-                                *dst = v;
-                            s1[j] += v;
-                            s2[j] = fmaf(v, v, s2[j]);
+                                obase[off0 + ro * ldo] = v;
+                            if (bnb) {
+                                const float d = yv[r] - bm[j];
+                                float g = v;
+                                if (a.bnb.slope >= 0.f && !(fmaf(d, bsc[j], bbe[j]) > 0.f)) g *= a.bnb.slope;
+                                s1[j] += g;
+                                s2[j] = fmaf(g, d * bis[j], s2[j]);
+                            } else {
+                                s1[j] += v;
+                                s2[j] = fmaf(v, v, s2[j]);
+                            }
                         }
                     }
                 }
@@ -780,6 +816,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     float s1[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) s1[j] = s2[j] = 0.f;
+    const bool bnb = a.bnb.y != nullptr && a.stats && !split_out;     // (see BnBwdSrc)
     auto emit = [&](auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -787,16 +824,25 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
             const int co = n0 + 16 * j + fi;
             const bool c_real = co < a.Cout, c_store = co < co_lim;
             const float bv = (!split_out && a.bias && c_real) ? a.bias[co] : 0.f;
+            const bool breal = bnb && c_real;
+            const float bm = breal ? a.bnb.mean[co] : 0.f, bis = breal ? a.bnb.invstd[co] : 0.f,
+                        bsc = breal ? a.bnb.scale[co] : 0.f, bbe = breal ? a.bnb.beta[co] : 0.f;
             if (c_store) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const unsigned mb = mrow0 + 16 * i;
                     const unsigned off0 = mb * ldo + (unsigned)co, roff0 = mb * (unsigned)a.ld_res + (unsigned)co;
-                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f}, yv[4] = {0.f, 0.f, 0.f, 0.f};
                     if (use_res && c_real) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (FULL || mb + r < Mu) rv[r] = a.residual[roff0 + r * (unsigned)a.ld_res];
+                    }
+                    if (breal) {
+                        const unsigned yoff0 = mb * (unsigned)a.bnb.ld + (unsigned)co;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (FULL || mb + r < Mu) yv[r] = a.bnb.y[yoff0 + r * (unsigned)a.bnb.ld];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -804,8 +850,16 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
                         if (!split_out) v = c_real ? (v + bv) + rv[r] : 0.f;
                         if (FULL || mb + r < Mu) {
                             obase[off0 + r * ldo] = v;
-                            s1[j] += v;
-                            s2[j] = fmaf(v, v, s2[j]);
+                            if (bnb) {
+                                const float d = yv[r] - bm;
+                                float g = v;
+                                if (a.bnb.slope >= 0.f && !(fmaf(d, bsc, bbe) > 0.f)) g *= a.bnb.slope;
+                                s1[j] += g;
+                                s2[j] = fmaf(g, d * bis, s2[j]);
+                            } else {
+                                s1[j] += v;
+                                s2[j] = fmaf(v, v, s2[j]);
+                            }
                         }
                     }
                 }
@@ -926,7 +980,8 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const 
                                                                           const float* __restrict__ residual, int ld_res,
                                                                           float* __restrict__ y, int ld_y, int Cout,
                                                                           int phases, int H, int W, int tx_n, int ty_n,
-                                                                          long rows_per_block, float* __restrict__ stats) {
+                                                                          long rows_per_block, float* __restrict__ stats,
+                                                                          BnBwdSrc bnb = BnBwdSrc{}) {
     __shared__ float4 red[2][256];
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx, nv = ld_y / 4, c = q * 4;
@@ -996,6 +1051,25 @@ __global__ void __launch_bounds__(256) conv3x3_splitk_reduce_stats_kernel(const 
             r.w = k3 ? r.w : 0.f;
             *reinterpret_cast<float4*>(y + orow * ld_y + c) = r;
             if (!STATS) continue;
+            if (bnb.y) {         // the sums are a BatchNorm layer's backward statistics (see BnBwdSrc)
+                const float* yp = bnb.y + orow * bnb.ld + c;
+                const float rr[4] = {r.x, r.y, r.z, r.w};
+                float a1[4], a2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a1[e] = a2[e] = 0.f;
+                    if (c + e < Cout) {
+                        const float d = yp[e] - bnb.mean[c + e];
+                        float g = rr[e];
+                        if (bnb.slope >= 0.f && !(fmaf(d, bnb.scale[c + e], bnb.beta[c + e]) > 0.f)) g *= bnb.slope;
+                        a1[e] = g;
+                        a2[e] = g * (d * bnb.invstd[c + e]);
+                    }
+                }
+                s1.x += a1[0], s1.y += a1[1], s1.z += a1[2], s1.w += a1[3];
+                s2.x += a2[0], s2.y += a2[1], s2.z += a2[2], s2.w += a2[3];
+                continue;
+            }
             s1.x += r.x;
             s1.y += r.y;
             s1.z += r.z;
@@ -2341,7 +2415,6 @@ static int g_xcd_remap = tuning_knob("xcd_remap", &g_xcd_remap, 1);
 static int g_fast_loader = tuning_knob("fast_loader", &g_fast_loader, 1);
 static int g_kxk_fast = tuning_knob("kxk_fast", &g_kxk_fast, 1);     // buffer-load loader for K x K / any pad (MODE 3)
 static int g_mfma16 = tuning_knob("mfma16", &g_mfma16, 1);
-static int g_igemm_nt = tuning_knob("igemm_nt_store", &g_igemm_nt, 0);   // non-temporal stores of the 32x32-tile kernel's output
 
 struct PlanRow {
     long M;
@@ -2761,7 +2834,7 @@ size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, 
 static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, int Hi, int Wi, int kh,
                            int kw, int pad, int stride, int phases, const float* wp, const float* bias, const float* residual,
                            int ld_res, float* y, int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats,
-                           float* stats_partial, void* stream) {
+                           float* stats_partial, void* stream, const BnBwdSrc* bnb = nullptr) {
     MNK_REQUIRE(flags >= 0 && flags <= 7);
     const int ups = flags & MNK_CONV_UPSAMPLED, clean = (flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
     // MNK_CONV_DEFER_SPLITK: a split-K launch leaves its partials in `ws` ([split][phase][M][ldw], bias not added) and the
@@ -2823,8 +2896,10 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
     a.ws = ws;
     a.ldw = p.ldw;
     a.stats = stats_partial;
+    a.bnb = bnb ? *bnb : BnBwdSrc{};
+    MNK_REQUIRE(!bnb || (stats_partial && bnb->y && bnb->mean && bnb->invstd && bnb->scale && bnb->beta && bnb->ld >= Cout &&
+                         phases == 1 && !defer_splitk));
     a.xcd = g_xcd_remap;
-    a.nt = g_igemm_nt;
     MNK_REQUIRE(!stats_partial || (ld_y == round_up(Cout, 4) && (p.splits == 1 || (g_splitk_stats && !defer_splitk))));
     if (p.splits > 1 && (!ws || ws_floats < (size_t)p.splits * phases * a.M * p.ldw)) {
         set_error("mnk_conv2d_fwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)p.splits * phases * a.M * p.ldw);
@@ -2897,7 +2972,7 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
             const RSMap m = make_rsmap(a.M * phases, ld_y);
             hipLaunchKernelGGL(conv3x3_splitk_reduce_stats_kernel<true>, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, ws,
                                p.splits, a.M, p.ldw, bias, residual, ld_res, y, ld_y, Cout, phases, a.H, a.W, m.tx, m.ty,
-                               m.rows_per_block, stats_partial);
+                               m.rows_per_block, stats_partial, a.bnb);
         } else if (g_reduce_v4 && (size_t)y % 16 == 0 && (size_t)ws % 16 == 0) {
             const RSMap m = make_rsmap(a.M * phases, ld_y);
             hipLaunchKernelGGL(conv3x3_splitk_reduce_stats_kernel<false>, dim3(m.col_tiles, m.row_blocks), dim3(256), 0, s, ws,
@@ -3613,6 +3688,33 @@ int mnk_conv3x3_up_dgrad(const float* dy, int ld_dy, int Cout, const float* wp_u
                          int W, int C, float* ws, size_t ws_floats, void* stream) {
     return conv2d_fwd_impl(dy, ld_dy, Cout, nullptr, 0, 0, MNK_CONV_CLEAN_PADS, 2 * H, 2 * W, 4, 4, 1, 2, 1, wp_up_dgrad, nullptr,
                            nullptr, 0, dx, ld_dx, N, H, W, C, ws, ws_floats, nullptr, stream);
+}
+
+// ---- data-gradient launches that also leave the backward statistics of the BatchNorm layer in front (round 4) ------------------
+static BnBwdSrc bnb_of(const float* bn_y, int ld_bny, const float* mean, const float* invstd, const float* scale, const float* beta,
+                       float slope) {
+    BnBwdSrc b;
+    b.y = bn_y, b.ld = ld_bny, b.mean = mean, b.invstd = invstd, b.scale = scale, b.beta = beta, b.slope = slope;
+    return b;
+}
+int mnk_conv3x3_dgrad_bnstats(const float* dy, int ld_dy, int Cout, const float* wp_dgrad, const float* residual, int ld_res,
+                              float* dx, int ld_dx, int N, int H, int W, int C, float* ws, size_t ws_floats, float* stats_partial,
+                              const float* bn_y, int ld_bny, const float* bn_mean, const float* bn_invstd, const float* bn_scale,
+                              const float* bn_beta, float slope, void* stream) {
+    const BnBwdSrc b = bnb_of(bn_y, ld_bny, bn_mean, bn_invstd, bn_scale, bn_beta, slope);
+    return conv2d_fwd_impl(dy, ld_dy, Cout, nullptr, 0, 0, MNK_CONV_CLEAN_PADS, H, W, 3, 3, 1, 1, 1, wp_dgrad, nullptr, residual,
+                           ld_res, dx, ld_dx, N, H, W, C, ws, ws_floats, stats_partial, stream, &b);
+}
+size_t mnk_conv3x3_up_dgrad_stats_floats(int N, int H, int W, int Cout, int C) {
+    return mnk_conv2d_stats_floats(N, H, W, Cout, 0, C, 16);
+}
+int mnk_conv3x3_up_dgrad_bnstats(const float* dy, int ld_dy, int Cout, const float* wp_up_dgrad, float* dx, int ld_dx, int N, int H,
+                                 int W, int C, float* ws, size_t ws_floats, float* stats_partial, const float* bn_y, int ld_bny,
+                                 const float* bn_mean, const float* bn_invstd, const float* bn_scale, const float* bn_beta,
+                                 float slope, void* stream) {
+    const BnBwdSrc b = bnb_of(bn_y, ld_bny, bn_mean, bn_invstd, bn_scale, bn_beta, slope);
+    return conv2d_fwd_impl(dy, ld_dy, Cout, nullptr, 0, 0, MNK_CONV_CLEAN_PADS, 2 * H, 2 * W, 4, 4, 1, 2, 1, wp_up_dgrad, nullptr,
+                           nullptr, 0, dx, ld_dx, N, H, W, C, ws, ws_floats, stats_partial, stream, &b);
 }
 
 // ---- 3x3 / pad 1 forms (the hot path's nn.Conv3d (1,3,3)) ------------------------------------------------------------

@@ -30,13 +30,6 @@
 #define MNK_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 #endif
 
-// non-temporal store (streams past the caches; a plain store on the emulator)
-#ifdef HIPEMU
-#define MNK_NT_STORE(v, p) (*(p) = (v))
-#else
-#define MNK_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
-
 namespace mnk {
 
 void set_error(const char* fmt, ...);

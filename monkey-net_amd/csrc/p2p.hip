@@ -5,18 +5,23 @@
 //
 // Every rank owns a mailbox in its own HBM, exported with hipIpcGetMemHandle and mapped by every peer of the node
 // (hipIpcOpenMemHandle; one process per GPU, the handles travel through torch.distributed's rendezvous):
-//     mailbox = SLOTS x world x { flag word | MAXF floats }
+//     mailbox = SLOTS x world x MAXF words of 8 bytes, a word = { sequence number | one float }
 // An exchange with sequence number q (a DEVICE-resident counter that the kernel advances itself, so a captured hipGraph
 // replays it without a host value) uses slot q mod SLOTS:
-//   push   rank r stores its n floats into row r of slot s of EVERY rank's mailbox -- its own included; peers are written
-//          over xGMI with system-scope stores -- then, behind a system-scope release fence, stores q into that row's flag;
-//   wait   spins (system-scope acquire loads) until the `world` flags of ITS OWN mailbox's slot s hold q;
-//   sum    adds the `world` rows in rank order -- every rank forms the same sum in the same order: bit-identical statistics
-//          on all ranks, no broadcast.
+//   push   rank r stores its n floats, each PACKED WITH q into one 8-byte word, into row r of slot s of EVERY rank's mailbox --
+//          its own included; peers are written over xGMI -- with system-scope relaxed atomic stores (write-through, single
+//          copy atomic: a reader sees the old word or the new one, never half);
+//   sum    every thread polls, for its elements, the `world` rows of ITS OWN mailbox's slot s (system-scope relaxed atomic
+//          loads: they bypass the caches) until a word carries q, and adds the floats in rank order -- every rank forms the same
+//          sum in the same order: bit-identical statistics on all ranks, no broadcast.
+// Flag and data travel in ONE word, so there is no ordering to enforce between them: no release / acquire fence -- on this chip
+// a system-scope fence writes back and invalidates the XCD's whole L2, which holds the 16+ MB of the convolution output in front
+// of the norm layer (the first form of this kernel, data rows + a flag per row behind __threadfence_system(), cost 7.6 us per
+// exchange on one rank against 3.8 for RCCL's one-rank copy: profiles/r04_knob_ab_log.txt).
 // One block of 256 threads on the kernels' stream: in order with the producing and the consuming kernel, capturable.
 // Slot reuse: a rank finishes exchange q + 1 only after every peer pushed q + 1, which a peer does only after it finished
 // READING q -- so when a rank pushes q + 2 nobody reads slot q any more: two slots suffice, four are used.
-// A peer that never arrives would hang the GPU: the wait gives up after `timeout_ms` (wall clock), raises the handle's
+// A peer that never arrives would hang the GPU: the polling gives up after `timeout_ms` (wall clock), raises the handle's
 // device error word (mnk_p2p_error) and lets the kernel finish with whatever it has.
 #include <string.h>
 
@@ -31,72 +36,73 @@ namespace {
 
 constexpr int P2P_SLOTS = 4;
 constexpr int P2P_MAXF = 2048 + 64;       // floats per message: [sum, sum of squares] of <= 1024 channels (+ slack)
-constexpr int P2P_ROW = P2P_MAXF + 16;    // a row: 16 words of header (word 0 = flag), then the payload
 constexpr int P2P_MAX_WORLD = 16;
 
 struct PeerTable {
-    unsigned* box[P2P_MAX_WORLD];         // every rank's mailbox as mapped into THIS process (box[rank] = the local allocation)
+    unsigned long long* box[P2P_MAX_WORLD];      // every rank's mailbox as mapped into THIS process (box[rank] = the local one)
 };
 
 struct P2P {
     int rank, world;
-    unsigned* local;                      // this rank's mailbox
+    unsigned long long* local;            // this rank's mailbox
     unsigned* state;                      // device words: [0] sequence counter, [1] error flag
     PeerTable peers;
     bool opened[P2P_MAX_WORLD];
     size_t bytes;
 };
 
-__device__ __forceinline__ unsigned* row_of(unsigned* box, int world, int slot, int r) {
-    return box + ((size_t)slot * world + r) * P2P_ROW;
+__device__ __forceinline__ unsigned long long* row_of(unsigned long long* box, int world, int slot, int r) {
+    return box + ((size_t)slot * world + r) * P2P_MAXF;
 }
 
 __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int rank, int world, unsigned* __restrict__ state,
                                                             const float* __restrict__ in, float* __restrict__ out, int n,
                                                             unsigned long long timeout_ticks) {
-    __shared__ unsigned seq_s;
-    __shared__ int ok_s;
     const int t = threadIdx.x;
-    if (t == 0) {
-        seq_s = state[0] + 1;             // this exchange's number (the first one is 1: a zeroed mailbox never matches)
-        ok_s = 1;
-    }
-    __syncthreads();
-    const unsigned seq = seq_s;
+    const unsigned seq = state[0] + 1;    // this exchange's number (the first one is 1: a zeroed mailbox never matches)
     const int slot = (int)(seq % P2P_SLOTS);
-    // ---- push: this rank's row of the slot in every mailbox (system scope: the peers' kernels are running)
-    for (int q = 0; q < world; ++q) {
-        unsigned* row = row_of(peers.box[q], world, slot, rank);
-        for (int i = t; i < n; i += 256)
-            __hip_atomic_store(reinterpret_cast<float*>(row + 16) + i, in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- push: this rank's row of the slot in every mailbox, {seq | value} words
+    float mine[(P2P_MAXF + 255) / 256];
+#pragma unroll
+    for (int k = 0; k < (P2P_MAXF + 255) / 256; ++k) {
+        const int i = t + 256 * k;
+        mine[k] = i < n ? in[i] : 0.f;
     }
-    __threadfence_system();
-    __syncthreads();
-    if (t < world) __hip_atomic_store(row_of(peers.box[t], world, slot, rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // ---- wait: every rank's row of the slot in THIS rank's mailbox
-    if (t < world) {
-        const unsigned* flag = row_of(peers.box[rank], world, slot, t);
-        const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
-                ok_s = 0;
-                __hip_atomic_store(state + 1, 1u + (unsigned)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
+    for (int q = 0; q < world; ++q) {
+        unsigned long long* row = row_of(peers.box[q], world, slot, rank);
+#pragma unroll
+        for (int k = 0; k < (P2P_MAXF + 255) / 256; ++k) {
+            const int i = t + 256 * k;
+            if (i < n)
+                __hip_atomic_store(row + i, ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(mine[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    __syncthreads();
-    __threadfence_system();
-    // ---- sum in rank order (every rank: the same order, the same bits)
-    for (int i = t; i < n; i += 256) {
+    // ---- poll + sum in rank order (every rank: the same order, the same bits)
+    const unsigned long long t0 = wall_clock64();
+    bool gave_up = false;
+#pragma unroll
+    for (int k = 0; k < (P2P_MAXF + 255) / 256; ++k) {
+        const int i = t + 256 * k;
+        if (i >= n) break;
         float s = 0.f;
-        for (int q = 0; q < world; ++q)
-            s += __hip_atomic_load(reinterpret_cast<const float*>(row_of(peers.box[rank], world, slot, q) + 16) + i,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int q = 0; q < world; ++q) {
+            const unsigned long long* w = row_of(peers.box[rank], world, slot, q) + i;
+            unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            while ((unsigned)(v >> 32) != seq && !gave_up) {
+                if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+                    gave_up = true;
+                    __hip_atomic_store(state + 1, 1u + (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            s += __uint_as_float((unsigned)v);
+        }
         out[i] = s;
     }
-    __syncthreads();
+    __syncthreads();                      // (every thread has read state[0] long before this)
     if (t == 0) state[0] = seq;
 }
 
@@ -124,7 +130,7 @@ int mnk_p2p_create(int rank, int world, void** handle_out) {
     memset(p, 0, sizeof(*p));
     p->rank = rank;
     p->world = world;
-    p->bytes = (size_t)P2P_SLOTS * world * P2P_ROW * sizeof(unsigned);
+    p->bytes = (size_t)P2P_SLOTS * world * P2P_MAXF * sizeof(unsigned long long);
     // (plain device memory: the kernel's own accesses are system-scope atomics, which go to memory on every access)
     if (hipMalloc((void**)&p->local, p->bytes) != hipSuccess || hipMalloc((void**)&p->state, 64) != hipSuccess) {
         set_error("mnk_p2p_create: hipMalloc failed");
@@ -176,7 +182,7 @@ int mnk_p2p_connect(void* handle, const void* all_handles) {
             set_error("mnk_p2p_connect: hipIpcOpenMemHandle of rank %d's mailbox failed: %s", q, hipGetErrorString(e));
             return MNK_ECOMM;
         }
-        p->peers.box[q] = (unsigned*)ptr;
+        p->peers.box[q] = (unsigned long long*)ptr;
         p->opened[q] = true;
     }
     return MNK_OK;

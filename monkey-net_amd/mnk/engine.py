@@ -188,6 +188,7 @@ class TrainStep:
         # every conv parameter seen so far packed in one launch -- unless the optimiser kernel of the previous iteration
         # already wrote the layouts (mnk.optim.MnkAdam)
         mops.repack_registered(only_if_stale=self.mnk_adam)
+        mops.clear_dz_stats()
 
     def step(self, x):
         """Eager iteration, or -- with use_graph -- a replay of the whole iteration captured once as a hipGraph

@@ -43,6 +43,7 @@ FORMS = {
     "WARP_LEVELS": True,        # all warps of a generator pass in one launch each way (False: one launch per decoder level)
     "SKIP_GRAD_FUSED": True,    # hourglass levels: the skip gradient rides in the next data-gradient GEMM's epilogue
     "RES_SKIP_FUSED": True,     # residual blocks: the skip gradient is added inside the first norm layer's dy pass
+    "DGRAD_BN_STATS": True,     # the data-gradient GEMM behind a (non-pooling) norm layer leaves that layer's backward statistics
 }
 
 

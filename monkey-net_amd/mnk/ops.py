@@ -527,6 +527,46 @@ def channel_sums(a, c):
 # (dy tensor, its column sums) handed from BNActFn.backward to the Conv3x3Fn.backward that receives this very tensor
 _DY_SUMS = [None]
 
+# ---- backward statistics of a norm layer from the data-gradient GEMM behind it (round 4) ---------------------------------------
+# bn_act() remembers, per OUTPUT tensor z of a training-mode BatchNorm that does not pool, what its backward statistics need
+# (y, mean, inv-std, scale, beta, activation).  A convolution that consumes z keeps that record; its data-gradient launch --
+# whose output IS dz when z has no other consumer -- then also leaves the column sums of g and g * xhat (mnk_conv3x3_dgrad_bnstats:
+# the dz tile is in the GEMM's registers, only y is read), and hands them to the norm layer's backward under the dx tensor it
+# returns.  The norm layer's backward looks its incoming gradient up: the very tensor -> one second-stage launch instead of a
+# pass over y and dz + second stage; anything else (a second consumer made autograd add two gradients) -> the ordinary pass.
+import weakref  # noqa: E402
+
+_BN_OF = {}                               # id(z) -> (weak reference to z, _BnRecord); z = the tensor object callers hold
+#                                           (a WeakKeyDictionary would compare tensors with ==)
+
+
+def _bn_of(t):
+    e = _BN_OF.get(id(t)) if t is not None else None
+    return e[1] if e is not None and e[0]() is t else None
+
+
+def _bind_bn(z, rec):
+    key = id(z)
+    _BN_OF[key] = (weakref.ref(z, lambda _r, key=key: _BN_OF.pop(key, None)), rec)
+_LAST_BN = [None]                         # BNActFn.forward -> bn_act(): the record of the launch that just ran
+_DZ_STATS = {}                            # dx.data_ptr() -> (dx, partials, rows, y.data_ptr()); dx is held, so the key is unique
+DZ_STATS_COUNT = [0, 0]                   # norm-layer backward passes that took the hand-over / that made their own pass (tests)
+
+
+class _BnRecord:
+    __slots__ = ("y", "mean", "invstd", "scale", "beta", "c", "slope")
+
+    def __init__(self, y, mean, invstd, scale, beta, c, slope):
+        self.y, self.mean, self.invstd, self.scale, self.beta, self.c, self.slope = y, mean, invstd, scale, beta, c, slope
+
+
+def clear_dz_stats():
+    """drop hand-overs that no norm layer picked up (their gradient was summed with another one first): start of an iteration"""
+    _DZ_STATS.clear()
+
+
+_SRC_BN = [None]                          # conv3x3() -> Conv3x3Fn.forward: (record of x0's norm layer or None, of x1's)
+
 
 class Conv3x3Fn(torch.autograd.Function):
     """nn.Conv3d((1,3,3), padding (0,1,1)) over the channel concatenation [x0 | x1], optionally read through the
@@ -550,6 +590,7 @@ class Conv3x3Fn(torch.autograd.Function):
             wp = _packed_fwd_weight(weight, cout, c0, c1, up)
         y, sums = _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats, up)
         ctx.up = up
+        ctx.src_bn, _SRC_BN[0] = (_SRC_BN[0] if track and _SRC_BN[0] is not None else (None, None)), None
         ctx.save_for_backward(x0, x1, weight)
         ctx.meta = (c0, c1, ups, cout, n, h, w, bias is not None, residual is not None)
         if sums is None:
@@ -580,14 +621,28 @@ class Conv3x3Fn(torch.autograd.Function):
             if src is None or not ctx.needs_input_grad[i]:
                 continue
             wp = ctx.wd[i]                       # packed in the forward (mnk_conv3x3_pack_all)
+            # the source is the output of a norm layer (no pooling) and (presumably) has no other consumer: this launch also
+            # leaves that layer's backward statistics (see _BN_OF); rows = the geometry both tensors share
+            rec = ctx.src_bn[i]
+            if rec is not None and (rec.c != cc or rec.y.shape[-1] != ceil4(cc) or small_bn(rec.y.numel() // rec.y.shape[-1])):
+                rec = None
             if ctx.up:
                 # data gradient w.r.t. the low-resolution source: one 4x4 / stride 2 convolution over dy (no gradient of
                 # the up-sampled view, no 2x2 sum-pool pass)
                 dx = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
                 nws = _query("mnk_conv3x3_up_dgrad_workspace_floats", n, h // 2, w // 2, cout, cc)
                 ws = SCRATCH.get("ws", nws, dy) if nws else None
-                _call("mnk_conv3x3_up_dgrad", dy, _p(dy), ld_dy, cout, _p(wp), _p(dx), dx.shape[-1], n, h // 2, w // 2, cc,
-                      _p(ws), nws)
+                nst = _query("mnk_conv3x3_up_dgrad_stats_floats", n, h // 2, w // 2, cout, cc) if (
+                    rec is not None and tuple(rec.y.shape) == tuple(dx.shape)) else 0
+                if nst:
+                    st = torch.empty(nst, dtype=torch.float32, device=dy.device)
+                    _call("mnk_conv3x3_up_dgrad_bnstats", dy, _p(dy), ld_dy, cout, _p(wp), _p(dx), dx.shape[-1], n, h // 2,
+                          w // 2, cc, _p(ws), nws, _p(st), _p(rec.y), rec.y.shape[-1], _p(rec.mean), _p(rec.invstd),
+                          _p(rec.scale), _p(rec.beta), float(rec.slope))
+                    _DZ_STATS[dx.data_ptr()] = (dx, st, nst // (2 * dx.shape[-1]), rec.y.data_ptr())
+                else:
+                    _call("mnk_conv3x3_up_dgrad", dy, _p(dy), ld_dy, cout, _p(wp), _p(dx), dx.shape[-1], n, h // 2, w // 2, cc,
+                          _p(ws), nws)
                 grads[i] = dx
                 continue
             # x0's second gradient rides as the residual operand of the data-gradient GEMM (its epilogue / split reduction)
@@ -595,6 +650,19 @@ class Conv3x3Fn(torch.autograd.Function):
             if i == 0 and dskip is not None and not ups:
                 res, dskip = dskip.contiguous(), None
                 assert res.shape == (n, h, w, ceil4(cc))
+            nst = _query("mnk_conv3x3_stats_floats", n, h, w, cout, 0, cc) if (
+                rec is not None and not ups and tuple(rec.y.shape) == (n, h, w, ceil4(cc))) else 0
+            if nst:
+                dx = torch.empty(n, h, w, ceil4(cc), dtype=torch.float32, device=dy.device)
+                nws = _query("mnk_conv3x3_workspace_floats", n, h, w, cout, 0, cc)
+                ws = SCRATCH.get("ws", nws, dy) if nws else None
+                st = torch.empty(nst, dtype=torch.float32, device=dy.device)
+                _call("mnk_conv3x3_dgrad_bnstats", dy, _p(dy), ld_dy, cout, _p(wp), _p(res),
+                      res.shape[-1] if res is not None else 0, _p(dx), dx.shape[-1], n, h, w, cc, _p(ws), nws, _p(st), _p(rec.y),
+                      rec.y.shape[-1], _p(rec.mean), _p(rec.invstd), _p(rec.scale), _p(rec.beta), float(rec.slope))
+                _DZ_STATS[dx.data_ptr()] = (dx, st, nst // (2 * dx.shape[-1]), rec.y.data_ptr())
+                grads[i] = dx
+                continue
             dx, _ = _conv_launch(dy, cout, None, 0, 0, wp, None, res, n, h, w, cc)
             if ups:
                 dxs = torch.empty(n, h // 2, w // 2, ceil4(cc), dtype=torch.float32, device=dy.device)
@@ -661,6 +729,8 @@ def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, 
     skip: -> (y, sums, x0 handed through for x0's other consumer), see Conv3x3SkipFn."""
     track = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x0, x1, weight, bias, residual))
+    if track:       # the norm layers whose outputs the sources are (see _BN_OF): picked up by Conv3x3Fn.forward
+        _SRC_BN[0] = (_bn_of(x0), _bn_of(x1))
     if skip and track and x0.requires_grad and knobs.form("SKIP_GRAD_FUSED"):
         y, sums, through = Conv3x3SkipFn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
         return y, (sums if want_stats else None), through
@@ -718,6 +788,8 @@ class BNActFn(torch.autograd.Function):
                       w, c, int(relu), int(pool))
                 ctx.save_for_backward(y, mean, invstd, scale, beta)
                 ctx.meta = (c, training, relu, pool, count)
+                if not pool and ld == z.shape[-1] and knobs.form("DGRAD_BN_STATS"):
+                    _LAST_BN[0] = _BnRecord(y, mean, invstd, scale, beta, c, 0.0 if relu else -1.0)
                 return z
             else:
                 # one launch for second stage + finalisation; partials from the conv epilogue when it produced them
@@ -741,6 +813,8 @@ class BNActFn(torch.autograd.Function):
               int(pool))
         ctx.save_for_backward(y, mean, invstd, scale, beta)
         ctx.meta = (c, training, relu, pool, count)
+        if training and not pool and ld == z.shape[-1] and knobs.form("DGRAD_BN_STATS"):
+            _LAST_BN[0] = _BnRecord(y, mean, invstd, scale, beta, c, 0.0 if relu else -1.0)
         return z
 
     @staticmethod
@@ -772,8 +846,15 @@ class BNActFn(torch.autograd.Function):
         nws = _query("mnk_bn_workspace_floats", rows, ceil4(c))
         ws = SCRATCH.get("ws", nws, y)
         sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
-        _call("mnk_bn_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta), n, h,
-              w, c, int(relu), int(pool), _p(sums), _p(ws), nws)
+        pre = _DZ_STATS.pop(dz.data_ptr(), None)
+        if pre is not None and pre[0].shape == dz.shape and pre[3] == y.data_ptr() and not pool:
+            # this gradient is the data-gradient GEMM's own output: its epilogue left the statistics' first stage
+            _call("mnk_bn_stats_finish", y, _p(pre[1]), pre[2], ld, c, _p(sums))
+            DZ_STATS_COUNT[0] += 1
+        else:
+            DZ_STATS_COUNT[1] += 1
+            _call("mnk_bn_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta), n,
+                  h, w, c, int(relu), int(pool), _p(sums), _p(ws), nws)
         dbeta, dgamma = sums[:c], sums[c:]       # local contributions (averaged later together with all gradients)
         if training and mdist.active():
             sums = mdist.all_reduce_sum(sums)
@@ -825,8 +906,14 @@ def bn_act(y, c, norm, relu=True, pool=False, sums=None, skip=False):
     """`norm` is a sync_batchnorm.SynchronizedBatchNorm3d parameter holder; `sums` = statistics of y that a conv
     epilogue already produced (training mode).  skip: -> (z, y handed through for a residual add), see BNActSkipFn."""
     fn = BNActSkipFn if skip and knobs.form("RES_SKIP_FUSED") else BNActFn
+    _LAST_BN[0] = None
     out = fn.apply(y, norm.weight, norm.bias, norm.running_mean, norm.running_var,
                    sums if norm.training else None, c, norm.training, relu, pool, norm.momentum, norm.eps)
+    rec, _LAST_BN[0] = _LAST_BN[0], None
+    if rec is not None and torch.is_grad_enabled():
+        z = out[0] if isinstance(out, tuple) else out
+        if z.requires_grad:
+            _bind_bn(z, rec)
     return (out, y) if skip and fn is BNActFn else out
 
 

@@ -480,3 +480,80 @@ def test_forced_launch_plans_compute_the_same_convolution(be, case):
         for name in ("force_bm", "force_bn", "force_splits"):
             be.lib.call("mnk_set_tuning", name.encode(), 0)
     assert len(seen) >= 6
+
+
+# ---- data-gradient launches that also leave the backward statistics of the norm layer in front (round 4) -----------------------
+BNSTATS_CASES = [
+    # N, H, W, Cout of the forward conv (= channels of dy), C (= channels of dx = of the norm layer), up, residual, slope
+    (4, 16, 16, 24, 64, False, False, 0.0),      # 64x64 tiles, ReLU
+    (2, 16, 16, 40, 45, False, True, 0.0),       # 16x16-MFMA kernel (BN = 48), a residual (skip gradient) in the epilogue
+    (3, 8, 8, 20, 70, False, False, -1.0),       # 128-wide plan / two N tiles, no activation
+    (2, 8, 12, 33, 30, False, False, 0.2),       # 128x32 tile, LeakyReLU, ragged M
+    (2, 4, 4, 136, 24, False, False, 0.0),       # split-K launch: the statistics come out of the split reduction
+    (2, 8, 8, 24, 40, True, False, 0.0),         # sub-pixel data gradient of an up-sampled convolution (4x4 / stride 2)
+]
+
+
+@pytest.mark.parametrize("case", BNSTATS_CASES)
+def test_data_gradient_leaves_the_backward_statistics_of_the_norm_layer_in_front(be, case):
+    """mnk_conv3x3_dgrad_bnstats / mnk_conv3x3_up_dgrad_bnstats: dx equals the plain data-gradient launch's, and the finished
+    column sums equal mnk_bn_act_bwd_stats's pass over (y, dz = dx) -- and an fp64 evaluation of sum g, sum g * xhat."""
+    n, h, w, cout, c, up, use_res, slope = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    ho, wo = (2 * h, 2 * w) if up else (h, w)                       # geometry of dy; (h, w) = geometry of dx and of the norm layer
+    dy = torch.randn(n, cout, ho, wo, generator=g)
+    wt = torch.randn(cout, c, 3, 3, generator=g) * 0.2
+    res = torch.randn(n, c, h, w, generator=g) if use_res else None
+    y = torch.randn(n, c, h, w, generator=g)                        # the norm layer's input
+    mean, var = y.mean(dim=(0, 2, 3)), y.var(dim=(0, 2, 3), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    scale = gamma * invstd
+    DY, Y = be.t(to_nhwc(dy)), be.t(to_nhwc(y))
+    ldx = ceil4(c)
+    dx_a, dx_b = be.empty(n, h, w, ldx), be.empty(n, h, w, ldx)
+    if up:
+        wp = be.empty(be.query("mnk_conv3x3_up_dgrad_packed_floats", cout, c))
+        be.call("mnk_conv3x3_up_pack_dgrad", be.t(wt), wp, cout, c, 0, c)
+        nws = be.query("mnk_conv3x3_up_dgrad_workspace_floats", n, h, w, cout, c)
+        nst = be.query("mnk_conv3x3_up_dgrad_stats_floats", n, h, w, cout, c)
+    else:
+        wp = be.empty(be.query("mnk_conv3x3_packed_floats", c, cout, 0))
+        be.call("mnk_conv3x3_pack_dgrad", be.t(wt), wp, cout, c, 0, c)
+        nws = be.query("mnk_conv3x3_workspace_floats", n, h, w, cout, 0, c)
+        nst = be.query("mnk_conv3x3_stats_floats", n, h, w, cout, 0, c)
+    assert nst > 0 and nst % (2 * ldx) == 0
+    ws = be.empty(max(nws, 1))
+    st = be.empty(nst)
+    R = be.t(to_nhwc(res)) if use_res else None
+    bn = (Y, ldx, be.t(mean), be.t(invstd), be.t(scale), be.t(beta), float(slope))
+    if up:
+        be.call("mnk_conv3x3_up_dgrad", DY, DY.shape[-1], cout, wp, dx_a, ldx, n, h, w, c, ws, nws)
+        be.call("mnk_conv3x3_up_dgrad_bnstats", DY, DY.shape[-1], cout, wp, dx_b, ldx, n, h, w, c, ws, nws, st, *bn)
+    else:
+        be.call("mnk_conv3x3_fwd", DY, DY.shape[-1], cout, None, 0, 0, 2, wp, None, R, ldx if use_res else 0, dx_a, ldx, n, h, w,
+                c, ws, nws, None)
+        be.call("mnk_conv3x3_dgrad_bnstats", DY, DY.shape[-1], cout, wp, R, ldx if use_res else 0, dx_b, ldx, n, h, w, c, ws, nws,
+                st, *bn)
+    sums = be.empty(2 * c)
+    be.call("mnk_bn_stats_finish", st, nst // (2 * ldx), ldx, c, sums)
+    # the separate pass the hand-over replaces
+    ref_sums = be.empty(2 * c)
+    nwb = be.query("mnk_bn_workspace_floats", n * h * w, ldx)
+    wsb = be.empty(max(nwb, 1))
+    relu = 1 if slope == 0.0 else 0
+    if slope in (0.0, -1.0):
+        be.call("mnk_bn_act_bwd_stats", Y, ldx, dx_a, ldx, 0, be.t(mean), be.t(invstd), be.t(scale), be.t(beta), n, h, w, c, relu, 0,
+                ref_sums, wsb, nwb)
+    be.sync()
+    assert torch.equal(dx_a.cpu(), dx_b.cpu()), "the data gradient itself must not change"
+    dz = from_nhwc(dx_a.cpu(), c).double()
+    d = y.double() - mean.double()[None, :, None, None]
+    pre = d * scale.double()[None, :, None, None] + beta.double()[None, :, None, None]
+    gg = dz if slope < 0 else torch.where(pre > 0, dz, dz * slope)
+    want = torch.cat([gg.sum(dim=(0, 2, 3)), (gg * d * invstd.double()[None, :, None, None]).sum(dim=(0, 2, 3))])
+    got = sums.cpu().double()
+    tol = 2e-5 * (float(want.abs().max()) + float(gg.abs().sum(dim=(0, 2, 3)).max()) * 1e-2)
+    assert float((got - want).abs().max()) <= tol, (float((got - want).abs().max()), tol)
+    if slope in (0.0, -1.0):
+        assert float((got - ref_sums.cpu().double()).abs().max()) <= tol

@@ -557,3 +557,43 @@ def test_hourglass_levels_with_two_consumers(be, monkeypatch, fused):
             continue
         a = p.grad.cpu().double().reshape(-1)
         assert float((a - r.reshape(-1)).norm() / (r.norm() + 1e-12)) < 5e-4, k
+
+
+def test_norm_layers_take_their_backward_statistics_from_the_data_gradient_launch(be, monkeypatch):
+    """round 4 (verdict r3 item 6a): a non-pooling BatchNorm whose output feeds ONE convolution gets sum g, sum g * xhat from
+    that convolution's data-gradient epilogue (ops._DZ_STATS) instead of a pass of its own over (y, dz).  Same gradients as
+    with the form switched off, and the hand-over is really used (decoder up-blocks, residual blocks)."""
+    from mnk import ops
+    from modules.util import Hourglass, ResBlock3D
+    torch.manual_seed(11)
+    hg = Hourglass(block_expansion=16, in_features=3, out_features=5, max_features=64, num_blocks=2)
+    r1, r2 = ResBlock3D(21, kernel_size=(1, 3, 3), padding=(0, 1, 1)), ResBlock3D(21, kernel_size=(1, 3, 3), padding=(0, 1, 1))
+    x = torch.rand(24, 3, 1, 32, 32)                     # 24 576 pixel rows at full resolution: not the small-layer path
+    xr = torch.rand(24, 21, 1, 32, 32)
+    w1, w2 = torch.randn(24, 5, 1, 32, 32), torch.randn(24, 21, 1, 32, 32)
+    for m in (hg, r1, r2):
+        m.to(be.device).train()
+
+    def run(on):
+        monkeypatch.setitem(knobs.FORMS, "DGRAD_BN_STATS", on)
+        ops.DZ_STATS_COUNT[0] = ops.DZ_STATS_COUNT[1] = 0
+        for m in (hg, r1, r2):
+            m.zero_grad()
+        xin = be.t(xr.clone()).requires_grad_(True)        # (be.t is the identity on the emulator: a fresh leaf per run)
+        out = hg(be.t(x))
+        res = r2(r1(xin))
+        ((out * be.t(w1)).sum() + (res * be.t(w2)).sum()).backward()
+        be.sync()
+        grads = {"%d.%s" % (i, k): p.grad.detach().cpu().clone() for i, m in enumerate((hg, r1, r2)) for k, p in m.named_parameters()
+                 if p.grad is not None}
+        grads["x"] = xin.grad.cpu().clone()
+        return grads, tuple(ops.DZ_STATS_COUNT)
+
+    g_on, used = run(True)
+    g_off, unused = run(False)
+    assert used[0] >= 4, used                       # the hourglass decoder's up-block in front of the last one + the residual blocks' norms
+    assert unused[0] == 0
+    assert set(g_on) == set(g_off)
+    for k in g_on:
+        err = float((g_on[k] - g_off[k]).norm() / (g_off[k].norm() + 1e-12))
+        assert err < 2e-5, (k, err)

@@ -30,7 +30,8 @@ def main():
                     return int(m.group(1)) if m else -1
                 rows.append((blk.group(1), g("next_free_vgpr"), g("accum_offset"), g("next_free_sgpr"),
                              g("private_segment_fixed_size"), g("group_segment_fixed_size")))
-            names = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True).stdout.splitlines()
+            names = subprocess.run(["c++filt"] + [r[0] for r in rows], capture_output=True, text=True,
+                                   stdin=subprocess.DEVNULL).stdout.splitlines() if rows else []
             lines.append("== " + os.path.basename(f))
             for r, dn in zip(rows, names):
                 dn = re.sub(r"\(anonymous namespace\)::", "", dn)
