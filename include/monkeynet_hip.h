@@ -427,6 +427,20 @@ int mnk_allreduce_grads(void* comm, float* grads, long n, int average, long chun
  * number (kept in device memory and advanced by the kernel: capturable), wait for every rank's flag in the own mailbox, add
  * the rows in rank order -> out (in == out allowed): every rank gets the same bits.  The wait gives up after timeout_ms
  * (a dead peer must not hang the GPU) and raises the handle's error word, read with mnk_p2p_error (0 = none; it synchronises). */
+/* BatchNorm statistics with that exchange INSIDE their second stage (csrc/batchnorm.hip colsum2_final_sync_kernel): the wavefront
+ * that finishes a column sum pushes it to every rank and adds the contributions in rank order -- second stage + all-reduce in one
+ * launch, so a norm layer costs a data-parallel rank as many launches as a single GPU.  p2p: a connected mnk_p2p handle;
+ * sums_local (optional, 2C): this rank's own sums; sums_global (2C): the sums over the ranks, the same bits on every rank.
+ * _finish_sync: from per-block partials ([row_blocks][2][ld], a convolution's epilogue); _stats_sync: a pass over x + second stage;
+ * _bwd_stats_sync: mnk_bn_act_bwd_stats's pass over (y, dz) + second stage. */
+int mnk_bn_stats_finish_sync(void* p2p, const float* partial, int row_blocks, int ld, int C, float* sums_local, float* sums_global,
+                             int timeout_ms, void* stream);
+int mnk_bn_stats_sync(void* p2p, const float* x, int ld, long rows, int C, float* sums_local, float* sums_global, float* ws,
+                      size_t ws_floats, int timeout_ms, void* stream);
+int mnk_bn_act_bwd_stats_sync(void* p2p, const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                              const float* invstd, const float* scale, const float* beta, int N, int H, int W, int C, int relu,
+                              int pool, float* sums_local, float* sums_global, float* ws, size_t ws_floats, int timeout_ms,
+                              void* stream);
 int mnk_p2p_max_floats(void);
 int mnk_p2p_create(int rank, int world, void** handle_out);
 int mnk_p2p_export(void* handle, void* ipc_handle64);

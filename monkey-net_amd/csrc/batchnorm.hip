@@ -6,6 +6,12 @@
 #include <stdlib.h>
 
 #include "mnk_common.h"
+#ifndef HIPEMU
+#include "p2p.h"
+namespace mnk {
+bool p2p_launch_info(void* handle, PeerTable* peers, int* rank, int* world, unsigned** state);      // p2p.hip
+}
+#endif
 
 using namespace mnk;
 
@@ -173,6 +179,63 @@ __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restr
         sums[i] = (float)t;
     }
 }
+
+#ifndef HIPEMU
+// colsum2_final_kernel with the SyncBN exchange of one node inside (csrc/p2p.hip's protocol): the wavefront that finishes the
+// sum of column i pushes it into every rank's mailbox and adds the `world` contributions in rank order -- the second stage of
+// the statistics and their all-reduce are ONE launch, so a norm layer of a data-parallel run costs as many launches as on one
+// GPU (it was: second stage, then a collective: 84 extra launches per iteration).  local (optional): this rank's own sums (the
+// scale / shift gradients of the backward pass are local sums; they are averaged with all other gradients later).
+__global__ void __launch_bounds__(256) colsum2_final_sync_kernel(const float* __restrict__ partial, int row_blocks, int ld, int C,
+                                                                 float* __restrict__ local, float* __restrict__ global_sums,
+                                                                 PeerTable peers, int rank, int world, unsigned* state,
+                                                                 unsigned long long timeout_ticks) {
+    __shared__ double sm[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    const unsigned seq = state[0] + 1;
+    const int slot = (int)(seq % P2P_SLOTS);
+    double acc = 0.0;
+    if (i < 2 * C) {
+        const int which = i / C, c = i - which * C;
+        acc = lane_colsum(partial + (long)which * ld + c, lane, row_blocks, 2L * ld);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane < 8) {
+        double t = 0.0;
+        for (int j = 0; j < 8; ++j) t += sm[wave * 64 + lane * 8 + j];
+        sm[wave * 64 + lane * 8] = t;
+    }
+    __syncthreads();
+    if (i < 2 * C) {                       // (wave-uniform)
+        double t = 0.0;
+        for (int j = 0; j < 8; ++j) t += sm[wave * 64 + j * 8];       // every lane: the bits colsum2_final_kernel's lane 0 makes
+        const float mine = (float)t;
+        const float all = p2p_exchange_value(peers, rank, world, slot, seq, i, mine, state, timeout_ticks);
+        if (lane == 0) {
+            if (local) local[i] = mine;
+            global_sums[i] = all;
+        }
+    }
+    p2p_finish_launch(state, seq);
+}
+
+static int launch_final_sync(void* p2p, const float* partial, int row_blocks, int ld, int C, float* local, float* global_sums,
+                             int timeout_ms, hipStream_t s) {
+    PeerTable peers;
+    int rank = 0, world = 0;
+    unsigned* state = nullptr;
+    if (!p2p_launch_info(p2p, &peers, &rank, &world, &state) || 2 * C > P2P_MAXF || timeout_ms <= 0) {
+        set_error("synchronised BatchNorm statistics: the peer-to-peer exchange is not connected, or more than %d channels",
+                  P2P_MAXF / 2);
+        return MNK_ECOMM;
+    }
+    hipLaunchKernelGGL(colsum2_final_sync_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, local,
+                       global_sums, peers, rank, world, state, (unsigned long long)timeout_ms * 100000ull);
+    return MNK_OK;
+}
+#endif
 
 struct StatsLoader {
     const float* x;
@@ -956,6 +1019,72 @@ int mnk_bn_stats_finish(const float* partial, int row_blocks, int ld, int C, flo
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(ceil_div(2 * C, 4)), dim3(256), 0, s, partial, row_blocks, ld, C, 1, sums, 2);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+// ---- the same statistics with the SyncBN exchange of one node inside their second stage (colsum2_final_sync_kernel) -----------
+int mnk_bn_stats_finish_sync(void* p2p, const float* partial, int row_blocks, int ld, int C, float* sums_local, float* sums_global,
+                             int timeout_ms, void* stream) {
+    MNK_REQUIRE(p2p && partial && sums_global && row_blocks > 0 && C > 0 && ld >= C);
+#ifdef HIPEMU
+    return MNK_ECOMM;
+#else
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_STATS, s, (double)row_blocks * 2 * C * 4);
+    const int rc = launch_final_sync(p2p, partial, row_blocks, ld, C, sums_local, sums_global, timeout_ms, s);
+    if (rc != MNK_OK) return rc;
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+#endif
+}
+int mnk_bn_stats_sync(void* p2p, const float* x, int ld, long rows, int C, float* sums_local, float* sums_global, float* ws,
+                      size_t ws_floats, int timeout_ms, void* stream) {
+    MNK_REQUIRE(p2p && x && sums_global && ws && rows > 0 && C > 0 && ld % 4 == 0 && ld >= C);
+#ifdef HIPEMU
+    return MNK_ECOMM;
+#else
+    Map2D m = make_map(rows, ld);
+    if (ws_floats < (size_t)m.row_blocks * 2 * ld) {
+        set_error("mnk_bn_stats_sync: workspace too small");
+        return MNK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_STATS, s, (double)rows * C * 4);
+    StatsLoader L{x, ld};
+    hipLaunchKernelGGL(colsum2_partial_kernel<StatsLoader>, dim3(m.col_tiles, m.row_blocks, 1), dim3(256), 0, s, L, rows, ld / 4, ld,
+                       m.tx, m.ty, m.rows_per_block, ws);
+    const int rc = launch_final_sync(p2p, ws, m.row_blocks, ld, C, sums_local, sums_global, timeout_ms, s);
+    if (rc != MNK_OK) return rc;
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+#endif
+}
+int mnk_bn_act_bwd_stats_sync(void* p2p, const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
+                              const float* invstd, const float* scale, const float* beta, int N, int H, int W, int C, int relu,
+                              int pool, float* sums_local, float* sums_global, float* ws, size_t ws_floats, int timeout_ms,
+                              void* stream) {
+    MNK_REQUIRE(p2p && y && dz && mean && invstd && scale && beta && sums_global && ws && N > 0 && H > 0 && W > 0 && C > 0);
+    MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && dz_off >= 0 && dz_off + C <= ld_dz);
+    MNK_REQUIRE((!pool || (H >= 2 && W >= 2)) && (long)N * H * W < (1L << 31));
+#ifdef HIPEMU
+    return MNK_ECOMM;
+#else
+    const long rows = (long)N * H * W;
+    const int ldc = round_up(C, 4);
+    Map2D m = make_map(rows, ldc);
+    if (ws_floats < (size_t)m.row_blocks * 2 * ldc) {
+        set_error("mnk_bn_act_bwd_stats_sync: workspace too small");
+        return MNK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_BWD, s, (double)N * H * W * C * 4 * (pool ? 1.25 : 2.0));
+    BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, dz_off, H, W, C, pool, 0, relu ? 0.f : -1.f};
+    hipLaunchKernelGGL(colsum2_partial_kernel<BwdLoader>, dim3(m.col_tiles, m.row_blocks, 1), dim3(256), 0, s, L, rows, ldc / 4, ldc,
+                       m.tx, m.ty, m.rows_per_block, ws);
+    const int rc = launch_final_sync(p2p, ws, m.row_blocks, ldc, C, sums_local, sums_global, timeout_ms, s);
+    if (rc != MNK_OK) return rc;
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+#endif
 }
 
 int mnk_bn_finalize(const float* sums, double count, const float* gamma, float* running_mean, float* running_var,

@@ -1,0 +1,72 @@
+// Shared definitions of the peer-to-peer SyncBN exchange (csrc/p2p.hip): the mailbox layout and the per-word protocol, for the
+// kernels that carry an exchange inside them (p2p.hip: the stand-alone all-reduce; batchnorm.hip: the second stage of the
+// BatchNorm statistics, which pushes each column sum as it finishes it).
+#pragma once
+#include "mnk_common.h"
+
+namespace mnk {
+
+constexpr int P2P_SLOTS = 4;
+constexpr int P2P_MAXF = 2048 + 64;       // floats per message: [sum, sum of squares] of <= 1024 channels (+ slack)
+constexpr int P2P_MAX_WORLD = 16;
+
+struct PeerTable {
+    unsigned long long* box[P2P_MAX_WORLD];      // every rank's mailbox as mapped into THIS process (box[rank] = the local one)
+};
+
+struct P2P {
+    int rank, world;
+    unsigned long long* local;            // this rank's mailbox
+    unsigned* state;                      // device words: [0] sequence counter, [1] error flag
+    PeerTable peers;
+    bool opened[P2P_MAX_WORLD];
+    size_t bytes;
+};
+__device__ __forceinline__ unsigned long long* row_of(unsigned long long* box, int world, int slot, int r) {
+    return box + ((size_t)slot * world + r) * P2P_MAXF;
+}
+
+
+// one value of exchange `seq`: push it into row `rank` of every mailbox (lane q of the calling wave serves peer q), then poll the
+// own mailbox's row q (lane q) and add the `world` values in rank order.  Called by one whole wavefront; returns the sum in every
+// lane.  `gave_up` is raised (and state[1] set) when a peer's word did not arrive within timeout_ticks of the 100 MHz wall clock.
+__device__ __forceinline__ float p2p_exchange_value(const PeerTable& peers, int rank, int world, int slot, unsigned seq, int index,
+                                                    float value, unsigned* state, unsigned long long timeout_ticks) {
+    const int lane = threadIdx.x & 63;
+    float got = 0.f;
+    if (lane < world) {
+        __hip_atomic_store(row_of(peers.box[lane], world, slot, rank) + index,
+                           ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(value), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long* w = row_of(peers.box[rank], world, slot, lane) + index;
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while ((unsigned)(v >> 32) != seq) {
+            if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+                __hip_atomic_store(state + 1, 1u + (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        got = __uint_as_float((unsigned)v);
+    }
+    float s = 0.f;
+    for (int q = 0; q < world; ++q) s += __shfl(got, q);
+    return s;
+}
+
+// the exchange's sequence number: every block reads state[0] + 1 when it starts; the LAST block to finish (ticket in state[2])
+// advances state[0] -- no block of the launch can still be waiting to read it then
+__device__ __forceinline__ void p2p_finish_launch(unsigned* state, unsigned seq) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(state + 2, 1u);
+        if (done == gridDim.x * gridDim.y * gridDim.z - 1) {
+            state[2] = 0;
+            state[0] = seq;
+        }
+    }
+}
+
+}  // namespace mnk

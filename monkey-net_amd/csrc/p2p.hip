@@ -28,32 +28,14 @@
 #include <vector>
 
 #include "mnk_common.h"
+#ifndef HIPEMU
+#include "p2p.h"
+#endif
 
 using namespace mnk;
 
 #ifndef HIPEMU
 namespace {
-
-constexpr int P2P_SLOTS = 4;
-constexpr int P2P_MAXF = 2048 + 64;       // floats per message: [sum, sum of squares] of <= 1024 channels (+ slack)
-constexpr int P2P_MAX_WORLD = 16;
-
-struct PeerTable {
-    unsigned long long* box[P2P_MAX_WORLD];      // every rank's mailbox as mapped into THIS process (box[rank] = the local one)
-};
-
-struct P2P {
-    int rank, world;
-    unsigned long long* local;            // this rank's mailbox
-    unsigned* state;                      // device words: [0] sequence counter, [1] error flag
-    PeerTable peers;
-    bool opened[P2P_MAX_WORLD];
-    size_t bytes;
-};
-
-__device__ __forceinline__ unsigned long long* row_of(unsigned long long* box, int world, int slot, int r) {
-    return box + ((size_t)slot * world + r) * P2P_MAXF;
-}
 
 __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int rank, int world, unsigned* __restrict__ state,
                                                             const float* __restrict__ in, float* __restrict__ out, int n,
@@ -107,6 +89,20 @@ __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int
 }
 
 }  // namespace
+#endif
+
+#ifndef HIPEMU
+namespace mnk {
+// what a kernel of another file needs to carry an exchange (batchnorm.hip's synchronised second stage)
+bool p2p_launch_info(void* handle, PeerTable* peers, int* rank, int* world, unsigned** state) {
+    if (!handle) return false;
+    P2P* p = (P2P*)handle;
+    for (int q = 0; q < p->world; ++q)
+        if (!p->peers.box[q]) return false;
+    *peers = p->peers, *rank = p->rank, *world = p->world, *state = p->state;
+    return true;
+}
+}  // namespace mnk
 #endif
 
 extern "C" {

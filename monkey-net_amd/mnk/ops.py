@@ -505,21 +505,48 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
             sums = st                          # per-block partials: finished together with the finalisation (bn_act)
         elif nst:
             sums = torch.empty(2 * cout, dtype=torch.float32, device=x0.device)
-            _call("mnk_bn_stats_finish", x0, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, _p(sums))
+            h = _sync_handle()
+            if h is not None:                  # second stage + exchange over the ranks in one launch
+                _call("mnk_bn_stats_finish_sync", x0, h, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, None, _p(sums),
+                      mdist.P2P_TIMEOUT_MS)
+                _REDUCED.add(sums.data_ptr())
+            else:
+                _call("mnk_bn_stats_finish", x0, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, _p(sums))
         elif mdist.active():
-            sums = channel_sums(y, cout)       # split-K layers: statistics by a pass over y
+            sums = channel_sums(y, cout, sync=True)       # split-K layers: statistics by a pass over y
         else:
             sums = y.new_empty(0)              # split-K layers, single process: bn_act makes its own pass over y
     return y, sums
 
 
-def channel_sums(a, c):
-    """[sum over pixels of a[..., :c], sum of squares] -> tensor (2c,)."""
+_REDUCED = set()       # data pointers of statistics vectors that already hold the sums over the ranks (see _sync_handle)
+
+
+def _sync_handle():
+    """The connected peer-to-peer exchange (csrc/p2p.hip) when the BatchNorm statistics of this process are exchanged by it: the
+    statistics' second stage then carries the exchange itself (mnk_bn_*_sync: one launch instead of second stage + collective)."""
+    if not mdist.active():
+        return None
+    h = mdist.p2p_comm()
+    if h is None:
+        return None
+    import ctypes
+    return ctypes.c_void_p(h)
+
+
+def channel_sums(a, c, sync=False):
+    """[sum over pixels of a[..., :c], sum of squares] -> tensor (2c,).  sync: over the ranks, when the peer-to-peer exchange is
+    up (the result is then registered in _REDUCED: no all-reduce behind it)."""
     rows = a.numel() // a.shape[-1]
     ld = a.shape[-1]
     nws = _query("mnk_bn_workspace_floats", rows, ld)
     ws = SCRATCH.get("ws", nws, a)
     sums = torch.empty(2 * c, dtype=torch.float32, device=a.device)
+    h = _sync_handle() if sync else None
+    if h is not None:
+        _call("mnk_bn_stats_sync", a, h, _p(a), ld, rows, c, None, _p(sums), _p(ws), nws, mdist.P2P_TIMEOUT_MS)
+        _REDUCED.add(sums.data_ptr())
+        return sums
     _call("mnk_bn_stats", a, _p(a), ld, rows, c, _p(sums), _p(ws), nws)
     return sums
 
@@ -563,6 +590,7 @@ class _BnRecord:
 def clear_dz_stats():
     """drop hand-overs that no norm layer picked up (their gradient was summed with another one first): start of an iteration"""
     _DZ_STATS.clear()
+    _REDUCED.clear()
 
 
 _SRC_BN = [None]                          # conv3x3() -> Conv3x3Fn.forward: (record of x0's norm layer or None, of x1's)
@@ -777,8 +805,11 @@ class BNActFn(torch.autograd.Function):
                 raise ValueError("BatchNorm needs more than one value per channel in training mode "
                                  "(sync_batchnorm/batchnorm.py:116)")
             if mdist.active():
-                sums = pre_sums if pre_sums is not None and pre_sums.numel() == 2 * c else channel_sums(y, c)
-                sums = mdist.all_reduce_sum(sums) if sums is pre_sums else mdist.all_reduce_sum_(sums)
+                sums = pre_sums if pre_sums is not None and pre_sums.numel() == 2 * c else channel_sums(y, c, sync=True)
+                if sums.data_ptr() in _REDUCED:          # the statistics' second stage carried the exchange
+                    _REDUCED.discard(sums.data_ptr())
+                else:
+                    sums = mdist.all_reduce_sum(sums) if sums is pre_sums else mdist.all_reduce_sum_(sums)
                 count *= mdist.world_size()
                 # finalisation inside the apply pass (mnk_bn_act_fwd_sums): one launch less per norm layer on the SyncBN path
                 ho, wo = (h // 2, w // 2) if pool else (h, w)
@@ -847,16 +878,25 @@ class BNActFn(torch.autograd.Function):
         ws = SCRATCH.get("ws", nws, y)
         sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
         pre = _DZ_STATS.pop(dz.data_ptr(), None)
+        sync = _sync_handle() if training else None      # several ranks: the second stage carries the exchange of the sums
+        local = torch.empty(2 * c, dtype=torch.float32, device=y.device) if sync is not None else sums
         if pre is not None and pre[0].shape == dz.shape and pre[3] == y.data_ptr() and not pool:
             # this gradient is the data-gradient GEMM's own output: its epilogue left the statistics' first stage
-            _call("mnk_bn_stats_finish", y, _p(pre[1]), pre[2], ld, c, _p(sums))
+            if sync is not None:
+                _call("mnk_bn_stats_finish_sync", y, sync, _p(pre[1]), pre[2], ld, c, _p(local), _p(sums), mdist.P2P_TIMEOUT_MS)
+            else:
+                _call("mnk_bn_stats_finish", y, _p(pre[1]), pre[2], ld, c, _p(sums))
             DZ_STATS_COUNT[0] += 1
         else:
             DZ_STATS_COUNT[1] += 1
-            _call("mnk_bn_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta), n,
-                  h, w, c, int(relu), int(pool), _p(sums), _p(ws), nws)
-        dbeta, dgamma = sums[:c], sums[c:]       # local contributions (averaged later together with all gradients)
-        if training and mdist.active():
+            if sync is not None:
+                _call("mnk_bn_act_bwd_stats_sync", y, sync, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale),
+                      _p(beta), n, h, w, c, int(relu), int(pool), _p(local), _p(sums), _p(ws), nws, mdist.P2P_TIMEOUT_MS)
+            else:
+                _call("mnk_bn_act_bwd_stats", y, _p(y), ld, _p(dz), dz.shape[-1], 0, _p(mean), _p(invstd), _p(scale), _p(beta), n,
+                      h, w, c, int(relu), int(pool), _p(sums), _p(ws), nws)
+        dbeta, dgamma = local[:c], local[c:]     # local contributions (averaged later together with all gradients)
+        if training and mdist.active() and sync is None:
             sums = mdist.all_reduce_sum(sums)
         dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
         if dskip is not None:

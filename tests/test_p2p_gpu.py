@@ -53,6 +53,30 @@ def _worker(rank, world, port, out_dir):
             bad += 1
     assert bad == 0, "%d of %d exchanges differ from the rank-ordered sum" % (bad, len(sizes))
     assert mdist._P2P["handle"] is not None and mdist.p2p_error() == 0
+    # ---- the exchange inside the statistics' second stage (mnk_bn_stats_finish_sync): global = the rank-ordered sum of every
+    # rank's own second-stage result (mnk_bn_stats_finish), local = this rank's
+    import ctypes
+    from mnk import _lib, ops as mops
+    lib = _lib.lib()
+    hp = ctypes.c_void_p(h)
+    st = torch.cuda.current_stream().cuda_stream
+    for it, (rows, c) in enumerate(((64, 10), (512, 64), (2048, 45), (33, 1024))):
+        ld = (c + 3) // 4 * 4
+        parts = [(torch.randn(rows, 2, ld, generator=torch.Generator().manual_seed(7000 + 10 * it + q)) * (1 + q)).to(dev)
+                 for q in range(world)]
+        loc, glo = torch.empty(2 * c, device=dev), torch.empty(2 * c, device=dev)
+        lib.call("mnk_bn_stats_finish_sync", hp, parts[rank].data_ptr(), rows, ld, c, loc.data_ptr(), glo.data_ptr(), 4000, st)
+        want = torch.zeros(2 * c)
+        for q in range(world):
+            one = torch.empty(2 * c, device=dev)
+            lib.call("mnk_bn_stats_finish", parts[q].data_ptr(), rows, ld, c, one.data_ptr(), st)
+            torch.cuda.synchronize()
+            if q == rank:
+                assert torch.equal(one.cpu(), loc.cpu()), "local sums of the synchronised second stage"
+            want = want + one.cpu()
+        torch.cuda.synchronize()
+        assert torch.equal(glo.cpu(), want), ("synchronised second stage", it, float((glo.cpu() - want).abs().max()))
+    assert mdist.p2p_error() == 0
     # ---- captured: three exchanges in a hipGraph, replayed with new inputs (the sequence counter advances on the device)
     n = 530
     a, b = torch.zeros(n, device=dev), torch.zeros(2 * n, device=dev)
