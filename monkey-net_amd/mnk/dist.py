@@ -142,6 +142,30 @@ def p2p_comm(force=False):
             if not ok2:
                 raise RuntimeError(why)
             return None
+        # self-test before the exchange carries any statistics: one all-reduce of rank-dependent values over the mapped
+        # mailboxes, bounded by a short timeout; every rank must see the right sums and no give-up flag, or ALL ranks stay on
+        # the collective path (the decision is gathered, so it is the same everywhere)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        probe = torch.arange(1, 65, dtype=torch.float32, device=dev) * float(me + 1)
+        got = torch.empty_like(probe)
+        fine = True
+        try:
+            lib.call("mnk_p2p_allreduce", handle, probe.data_ptr(), got.data_ptr(), 64, 3000,
+                     torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize(dev)
+            flag = ctypes.c_int(0)
+            lib.call("mnk_p2p_error", handle, ctypes.byref(flag))
+            want = torch.arange(1, 65, dtype=torch.float32) * float(world * (world + 1) // 2)
+            fine = flag.value == 0 and torch.equal(got.cpu(), want)
+        except Exception:
+            fine = False
+        verdicts = [None] * world
+        tdist.all_gather_object(verdicts, bool(fine))
+        if not all(verdicts):
+            import sys
+            sys.stderr.write("mnk.dist: the peer-to-peer exchange failed its self-test on rank(s) %s; using the collective path\n"
+                             % [i for i, v in enumerate(verdicts) if not v])
+            return None               # (the mailboxes stay mapped: a rank may still be inside the probe kernel of a slow peer)
         _P2P["handle"] = handle.value
         _P2P["max"] = int(lib.query("mnk_p2p_max_floats"))
     except Exception as e:      # the RCCL / torch.distributed path below is always there
