@@ -407,10 +407,14 @@ template <int RA, int NST> struct LoaderSel<RA, 2, NST> { typedef ActLoader3<RA,
 // 100 MHz wall clock at its entry, in front of its K loop, behind it and at its exit
 #ifdef MNK_PHASE_CLOCKS
 __device__ unsigned long long mnk_phase_log[4 * 16384];
+__device__ unsigned long long mnk_phase_sclk[2 * 16384];      // the shader clock (s_memtime) in front of / behind the K loop
 #define MNK_PHASE(i)                                                                                              \
     do {                                                                                                          \
         const unsigned lin__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                    \
-        if (threadIdx.x == 0 && lin__ < 16384u) mnk_phase_log[4 * lin__ + (i)] = wall_clock64();                  \
+        if (threadIdx.x == 0 && lin__ < 16384u) {                                                                 \
+            mnk_phase_log[4 * lin__ + (i)] = wall_clock64();                                                      \
+            if ((i) == 1 || (i) == 2) mnk_phase_sclk[2 * lin__ + (i) - 1] = clock64();                            \
+        }                                                                                                         \
     } while (0)
 #else
 #define MNK_PHASE(i) ((void)0)
@@ -3752,6 +3756,9 @@ int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int flags, const float* d
 }
 
 #ifdef MNK_PHASE_CLOCKS
+extern "C" int mnk_phase_sclk_read(void* host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(mnk_phase_sclk), bytes) == hipSuccess ? MNK_OK : MNK_ELAUNCH;
+}
 extern "C" int mnk_phase_log_read(void* host, size_t bytes, int clear) {
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(mnk_phase_log), bytes) != hipSuccess) return MNK_ELAUNCH;
     if (clear) {

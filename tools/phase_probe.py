@@ -45,6 +45,7 @@ def main():
     layers = workload.conv_flops_hot_path(cfg, args.size, args.size)["layers"]
     dev = torch.device("cuda:0")
     log = np.zeros(4 * 16384, dtype=np.uint64)
+    sclk = np.zeros(2 * 16384, dtype=np.uint64)
     print("%-14s %5s %5s %3s | %6s blocks | event us | start p50 / max | prologue p50 | loop p50 (min..max) | epilogue p50 | "
           "last end | first end" % ("layer", "cin", "cout", "hw", ""))
     seen = set()
@@ -66,7 +67,9 @@ def main():
         lib.cdll.mnk_phase_log_read(log.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(log.nbytes), 1)
         fn()
         torch.cuda.synchronize()
+        lib.cdll.mnk_phase_sclk_read(sclk.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(sclk.nbytes))
         lib.cdll.mnk_phase_log_read(log.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(log.nbytes), 1)
+        sc = sclk.reshape(-1, 2)[log.reshape(-1, 4)[:, 0] > 0].astype(np.int64)
         st = log.reshape(-1, 4)
         st = st[st[:, 0] > 0].astype(np.int64)
         if not len(st):
@@ -79,9 +82,13 @@ def main():
         loop = us(st[:, 2] - st[:, 1])
         epi = us(st[:, 3] - st[:, 2])
         end = us(st[:, 3] - t0)
-        print("%-14s %5d %5d %3d | %6d blocks | %8.1f | %6.1f / %6.1f | %8.1f | %6.1f (%5.1f..%5.1f) | %8.1f | %7.1f | %7.1f"
+        # shader clock during the K loop: s_memtime ticks per 100 MHz wall-clock tick
+        ghz = np.median((sc[:, 1] - sc[:, 0]) / np.maximum(st[:, 2] - st[:, 1], 1)) * 0.1
+        ksteps = 9 * ((cin + 15) // 16)
+        print("%-14s %5d %5d %3d | %6d blocks | %8.1f | %6.1f / %6.1f | %8.1f | %6.1f (%5.1f..%5.1f) | %8.1f | %7.1f | %7.1f | "
+              "s_memtime/wall in the loop: %.3f GHz-equivalent, %d K steps"
               % (name, cin, cout, h, len(st), t, np.median(start), start.max(), np.median(pro), np.median(loop), loop.min(),
-                 loop.max(), np.median(epi), end.max(), end.min()))
+                 loop.max(), np.median(epi), end.max(), end.min(), ghz, ksteps))
 
 
 if __name__ == "__main__":
