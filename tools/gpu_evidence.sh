@@ -4,8 +4,8 @@
 #   kernel stats (+ steady-state window), FETCH_SIZE / WRITE_SIZE PMC passes (separate runs), an SQ pass over the per-layer
 #   conv bench (MFMA busy, GRBM clock), per-layer conv bench of both configs, batched inference (bair B=512), the
 #   single-rank RCCL exercise of the distributed path.
-TAG="${1:-r03final}"; R="${TAG%%final*}"; R="${R:-r03}"
-OUT=gpurun_out/$TAG; mkdir -p "$OUT" profiles; export TMPDIR=/tmp
+TAG="${1:-r04final}"; R="${TAG%%final*}"; R="${R:-r04}"
+OUT=gpurun_out/$TAG; mkdir -p "$OUT" profiles; export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 # (profiled EAGER iterations launch their weight-gradient GEMMs at the end, as a captured iteration does: with the background
 # launches of an eager backward, MNK_WGRAD_BG, kernels overlap and their durations are not comparable)
 EAGER_ENV="MNK_WGRAD_BG=0"
@@ -84,6 +84,9 @@ timeout 300 python tools/infer_bench.py > "$OUT/infer_bair_b512.json" 2> "$OUT/i
 echo "== single-rank RCCL exercise (MNK_DIST_FORCE=1, torch.distributed.run)" | tee -a "$S"
 MNK_DIST_FORCE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > "$OUT/bench_dist1.json" 2> "$OUT/bench_dist1.err"; echo "rc=$?" | tee -a "$S"
 cut -c1-330 "$OUT/bench_dist1.json" | tee -a "$S"; grep -h "mnk.dist\|capture failed" "$OUT/bench_dist1.err" | head -3 | cut -c1-200 | tee -a "$S"
+echo "== the same with the SyncBN sums through RCCL instead of the peer-to-peer exchange (MNK_SYNCBN_P2P=0)" | tee -a "$S"
+MNK_SYNCBN_P2P=0 MNK_DIST_FORCE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > "$OUT/bench_dist1_rccl.json" 2> "$OUT/bench_dist1_rccl.err"; echo "rc=$?" | tee -a "$S"
+cut -c1-200 "$OUT/bench_dist1_rccl.json" | tee -a "$S"
 echo "== the same with the overlapped gradient exchange of several ranks forced on (two linear hipGraphs + host calls)" | tee -a "$S"
 MNK_DIST_FORCE=1 MNK_GRAD_OVERLAP=force timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-profile > "$OUT/bench_dist1_overlap.json" 2> "$OUT/bench_dist1_overlap.err"; echo "rc=$?" | tee -a "$S"
 cut -c1-200 "$OUT/bench_dist1_overlap.json" | tee -a "$S"
@@ -93,5 +96,7 @@ for f in bench_moving-gif_b32.json bench_taichi_b32.json bench_vox256_b8.json mo
 done
 cp "$OUT/bench_dist1.json" "$OUT/${R}_bench_moving-gif_b32_rccl_1rank.json" 2>/dev/null
 cp "$OUT/bench_dist1_overlap.json" "$OUT/${R}_bench_moving-gif_b32_rccl_1rank_overlap.json" 2>/dev/null
+cp "$OUT/bench_dist1_rccl.json" "$OUT/${R}_bench_moving-gif_b32_rccl_1rank_syncbn_rccl.json" 2>/dev/null
+cp gpurun_out/p2p_timing_world2.txt gpurun_out/p2p_timing_world4.txt "$OUT/" 2>/dev/null
 cp "$OUT/graph_replay_gaps.txt" "$OUT/${R}_graph_replay_gaps.txt" 2>/dev/null
 tail -3 "$OUT/pytest_gpu.log" > "$OUT/${R}_pytest_gpu_tail.txt"
