@@ -640,6 +640,18 @@ def main():
             out.update(value=round(global_batch * args.steps / g_elapsed, 2),
                        ms_per_step=round(g_elapsed / args.steps * 1e3, 3))
             out["config"]["launch"] = "hipGraph replay (RCCL collectives captured); eager: %.3f ms/step" % ms_per_step
+    if dist_mode:
+        # a peer-to-peer SyncBN exchange that gave up waiting for a rank leaves wrong statistics behind: say so, on every rank
+        from mnk import dist as mdist
+        code = torch.tensor([mdist.p2p_error()], dtype=torch.int32, device=device)
+        dist.all_reduce(code, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            out["syncbn_exchange"] = ("peer-to-peer (csrc/p2p.hip)" if mdist._P2P["handle"] is not None else
+                                      "collective (RCCL / torch.distributed)")
+            out["p2p_error"] = int(code.item())
+            if out["p2p_error"]:
+                out["capture_failed"] = True
+                out["config"]["launch"] += " -- INVALID: a peer-to-peer exchange timed out (rank %d)" % (out["p2p_error"] - 1)
     if rank == 0:
         emit(out)
     if dist_mode:

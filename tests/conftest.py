@@ -24,7 +24,15 @@ _EMU = {}
 def emu_library_path():
     """Build (once per session) the CPU emulation of the kernels -- tests/hipemu, test infrastructure only."""
     if "path" not in _EMU:
-        out = subprocess.run([os.path.join(ROOT, "tests", "hipemu", "build.sh")], capture_output=True, text=True)
+        import fcntl
+        os.makedirs(os.path.join(ROOT, "tests", "hipemu", "build"), exist_ok=True)
+        # one build at a time: the workers of `pytest -n N` all get here, and a worker must not dlopen the library while another
+        # one's link step is rewriting it
+        with open(os.path.join(ROOT, "tests", "hipemu", "build", ".lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            out = subprocess.run([os.path.join(ROOT, "tests", "hipemu", "build.sh")], capture_output=True, text=True,
+                                 stdin=subprocess.DEVNULL)
+            fcntl.flock(lock, fcntl.LOCK_UN)
         if out.returncode != 0:
             raise RuntimeError("hipemu build failed:\n" + out.stdout + out.stderr)
         _EMU["path"] = out.stdout.strip().splitlines()[-1]

@@ -16,5 +16,11 @@ for f in "$SRC"/*.hip "$HERE/hipemu.cpp"; do
   OBJS="$OBJS $o"
 done
 wait
-g++ -shared -o "$OUT/libmnk_emu.so" $OBJS -ldl
+# relink only when an object is newer than the library (and atomically: a process may have the old file mapped)
+NEED=0
+[ -f "$OUT/libmnk_emu.so" ] || NEED=1
+for o in $OBJS; do [ "$o" -nt "$OUT/libmnk_emu.so" ] && NEED=1; done
+if [ "$NEED" = 1 ]; then
+  g++ -shared -o "$OUT/libmnk_emu.so.tmp.$$" $OBJS -ldl && mv -f "$OUT/libmnk_emu.so.tmp.$$" "$OUT/libmnk_emu.so"
+fi
 echo "$OUT/libmnk_emu.so"

@@ -15,7 +15,7 @@ echo "== pytest -m gpu + smoke" | tee -a "$S"
 timeout 900 python -m pytest tests -q -m gpu > "$OUT/pytest_gpu.log" 2>&1; echo "rc=$?" | tee -a "$S"; tail -3 "$OUT/pytest_gpu.log" | cut -c1-200 | tee -a "$S"
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-200 | tee -a "$S"
 echo "== pmc FETCH_SIZE / WRITE_SIZE (separate passes)" | tee -a "$S"
-CMD2="env $EAGER_ENV python $PWD/bench.py --steps 2 --warmup 2 --graph 0 --no-cpu-baseline --no-profile"
+CMD2="env $EAGER_ENV python $PWD/bench.py --steps 2 --warmup 2 --graph 0 --no-cpu-baseline --no-profile --dropin 0"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OLDPWD/$OUT/pmc_fetch" -o f -- $CMD2 > "$OLDPWD/$OUT/pmc_fetch.log" 2>&1 ); echo "fetch rc=$?" | tee -a "$S"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OLDPWD/$OUT/pmc_write" -o w -- $CMD2 > "$OLDPWD/$OUT/pmc_write.log" 2>&1 ); echo "write rc=$?" | tee -a "$S"
 python tools/pmc_summarize.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic_moving-gif_b32.json" 2>&1 | tee -a "$S"
@@ -39,7 +39,7 @@ timeout 900 python bench.py > "$OUT/bench_moving-gif_b32.json" 2> "$OUT/bench.er
 timeout 400 python bench.py --config taichi --no-cpu-baseline > "$OUT/bench_taichi_b32.json" 2> "$OUT/bench_taichi.err"; echo "taichi rc=$?" | tee -a "$S"; cut -c1-300 "$OUT/bench_taichi_b32.json" | tee -a "$S"
 timeout 300 python bench.py --config vox --size 256 --batch 8 --no-cpu-baseline > "$OUT/bench_vox256_b8.json" 2> "$OUT/bench_vox.err"; echo "vox 256 rc=$?" | tee -a "$S"; cut -c1-300 "$OUT/bench_vox256_b8.json" | tee -a "$S"
 echo "== rocprofv3 kernel stats (eager iteration)" | tee -a "$S"
-CMD="env $EAGER_ENV python $PWD/bench.py --steps 5 --warmup 2 --graph 0 --no-cpu-baseline --no-profile"
+CMD="env $EAGER_ENV python $PWD/bench.py --steps 5 --warmup 2 --graph 0 --no-cpu-baseline --no-profile --dropin 0"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- $CMD > "$OLDPWD/$OUT/rocprof.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
 f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/moving-gif_b32_eager_kernel_stats.csv"
 t=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
@@ -47,7 +47,7 @@ t=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)
 head -45 "$OUT/moving-gif_b32_steady_groups.txt" | cut -c1-130 | tee -a "$S"
 find "$OUT" -name "*kernel_trace*" -size +4M -delete
 echo "== rocprofv3 kernel trace of hipGraph replays: idle time between kernels (tools/trace_gaps.py)" | tee -a "$S"
-CMDG="python $PWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-profile"
+CMDG="python $PWD/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-profile --dropin 0"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_graph -o g -- $CMDG > "$OLDPWD/$OUT/rocprof_graph.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
 t=$(find /tmp/prof_graph -name "*kernel_trace.csv" | head -1)
 [ -n "$t" ] && python tools/trace_gaps.py "$t" --last 6 > "$OUT/graph_replay_gaps.txt" 2>&1; head -3 "$OUT/graph_replay_gaps.txt" | cut -c1-200 | tee -a "$S"

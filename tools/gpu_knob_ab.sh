@@ -8,7 +8,7 @@ for rep in $(seq 1 ${REPS:-2}); do
   for v in "$@"; do
     envs="$(echo "$v" | tr ',' ' ')"
     f="$OUT/bench_$(echo "${v:-default}" | tr '=,' '__')_$rep.json"
-    env $envs timeout 200 python bench.py --steps ${STEPS:-40} --warmup 5 --no-cpu-baseline --no-profile ${BENCH_ARGS:-} > "$f" 2> "$f.err"
+    env $envs timeout 200 python bench.py --steps ${STEPS:-40} --warmup 5 --no-cpu-baseline --no-profile --dropin 0 ${BENCH_ARGS:-} > "$f" 2> "$f.err"
     echo "rep=$rep ${v:-default}: $(grep -o '"ms_per_step": [0-9.]*' "$f" | head -1)" | tee -a "$OUT/summary.txt"
   done
 done

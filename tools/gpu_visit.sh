@@ -35,7 +35,7 @@ if [ -n "$BENCH" ]; then
 fi
 if [ "${TRACE:-0}" = 1 ]; then
   echo "== rocprofv3 kernel trace (eager iteration${TRACE_ARGS:+, $TRACE_ARGS})" | tee -a "$S"
-  CMDT="python $PWD/bench.py --steps 5 --warmup 2 --graph 0 --no-cpu-baseline --no-profile ${TRACE_ARGS:-}"
+  CMDT="python $PWD/bench.py --steps 5 --warmup 2 --graph 0 --no-cpu-baseline --no-profile --dropin 0 ${TRACE_ARGS:-}"
   ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- $CMDT > "$OLDPWD/$OUT/rocprof.log" 2>&1 ); echo "rocprof rc=$?" | tee -a "$S"
   f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/eager_kernel_stats.csv"
   t=$(find "$OUT/prof" -name "*kernel_trace.csv" | head -1)

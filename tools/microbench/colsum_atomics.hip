@@ -1,6 +1,8 @@
 // Column sums of a [rows][C] fp32 matrix, two ways: (a) per-block partial rows + a second-stage launch (what the BatchNorm
 // statistics do today), (b) one launch whose blocks add their partial sums to per-column fp64 accumulators with device-scope
-// atomics (no second launch; the consumer reads 2 * C doubles).  Measures a dependent chain of the two forms back to back,
+// atomics (no second launch; the consumer reads 2 * C doubles); (c) (round 4) the same with one accumulator row PER XCD and
+// workgroup-scope atomics -- a block adds to the row of the XCD it runs on (s_getreg XCC_ID), so the read-modify-writes stay in
+// that XCD's L2 and never meet another XCD's; the kernel boundary publishes them, the consumer adds 8 rows.  Measures a dependent chain of the two forms back to back,
 // the way they sit in a training iteration: (a) = 2 launches per layer, (b) = 1.
 //   hipcc --offload-arch=gfx950 -O3 -o /tmp/colsum tools/microbench/colsum_atomics.hip && /tmp/colsum
 #include <hip/hip_runtime.h>
@@ -8,7 +10,7 @@
 #include <vector>
 
 __global__ void __launch_bounds__(256) partial_kernel(const float* __restrict__ x, long rows, int C, long rows_per_block,
-                                                      float* __restrict__ partial, double* __restrict__ acc) {
+                                                      float* __restrict__ partial, double* __restrict__ acc, int per_xcd = 0) {
     __shared__ float4 red[2][256];
     const int nv = C / 4, tx_n = nv < 16 ? nv : 16, ty_n = 256 / tx_n;
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -37,7 +39,17 @@ __global__ void __launch_bounds__(256) partial_kernel(const float* __restrict__ 
         __syncthreads();
     }
     if (ty == 0 && q < nv) {
-        if (acc) {
+        if (acc && per_xcd) {
+            unsigned xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const float4 s1 = red[0][tx], s2 = red[1][tx];
+            double* o = acc + (size_t)(xcc & 7) * 2 * C + q * 4;
+            const double v[8] = {s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w};
+            for (int e = 0; e < 4; ++e) {
+                __hip_atomic_fetch_add(o + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(o + C + e, v[4 + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else if (acc) {
             const float4 s1 = red[0][tx], s2 = red[1][tx];
             double* o = acc + q * 4;
             atomicAdd(o, (double)s1.x), atomicAdd(o + 1, (double)s1.y), atomicAdd(o + 2, (double)s1.z), atomicAdd(o + 3, (double)s1.w);
@@ -69,14 +81,16 @@ __global__ void __launch_bounds__(256) final_kernel(const float* __restrict__ pa
 
 // the consumer: y = (x - mean) * invstd; statistics from `sums` (float) or from the fp64 accumulators
 __global__ void __launch_bounds__(256) apply_kernel(const float* __restrict__ x, long rows, int C, const float* __restrict__ sums,
-                                                    const double* __restrict__ acc, float* __restrict__ y) {
+                                                    const double* __restrict__ acc, float* __restrict__ y, int per_xcd = 0) {
     const long total = rows * (C / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int q = (int)(i % (C / 4));
         float m[4], is[4];
         for (int e = 0; e < 4; ++e) {
             const int c = q * 4 + e;
-            const double s1 = acc ? acc[c] : (double)sums[c], s2 = acc ? acc[C + c] : (double)sums[C + c];
+            double s1 = acc ? acc[c] : (double)sums[c], s2 = acc ? acc[C + c] : (double)sums[C + c];
+            if (per_xcd)
+                for (int x8 = 1; x8 < 8; ++x8) s1 += acc[(size_t)x8 * 2 * C + c], s2 += acc[(size_t)x8 * 2 * C + C + c];
             const double mean = s1 / (double)rows;
             double var = s2 / (double)rows - mean * mean;
             m[e] = (float)mean;
@@ -98,16 +112,16 @@ int main() {
         float *x, *y, *partial, *sums;
         double* acc;
         hipMalloc(&x, rows * C * 4), hipMalloc(&y, rows * C * 4), hipMalloc(&partial, (size_t)row_blocks * 2 * C * 4);
-        hipMalloc(&sums, 2 * C * 4), hipMalloc(&acc, 2 * C * 8 * 64);
+        hipMalloc(&sums, 2 * C * 4), hipMalloc(&acc, (size_t)2 * C * 8 * 64 * 8);
         std::vector<float> h(rows * C);
         for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.f - 0.5f;
         hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-        hipMemset(acc, 0, 2 * C * 8 * 64);
+        hipMemset(acc, 0, (size_t)2 * C * 8 * 64 * 8);
         hipEvent_t e0, e1;
         hipEventCreate(&e0), hipEventCreate(&e1);
         const int reps = 50, ablocks = 2048;
-        float ms[2];
-        for (int form = 0; form < 2; ++form) {
+        float ms[3];
+        for (int form = 0; form < 3; ++form) {
             for (int warm = 0; warm < 2; ++warm) {
                 hipEventRecord(e0, 0);
                 for (int r = 0; r < reps; ++r) {
@@ -118,6 +132,10 @@ int main() {
                         hipLaunchKernelGGL(partial_kernel, dim3(col_tiles, row_blocks), dim3(256), 0, 0, src, rows, C, rpb, partial, (double*)nullptr);
                         hipLaunchKernelGGL(final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, 0, partial, row_blocks, C, sums);
                         hipLaunchKernelGGL(apply_kernel, dim3(ablocks), dim3(256), 0, 0, src, rows, C, sums, (const double*)nullptr, dst);
+                    } else if (form == 2) {
+                        double* a = acc + (size_t)(r % 64) * 2 * C * 8;      // eight rows (one per XCD) per layer
+                        hipLaunchKernelGGL(partial_kernel, dim3(col_tiles, row_blocks), dim3(256), 0, 0, src, rows, C, rpb, (float*)nullptr, a, 1);
+                        hipLaunchKernelGGL(apply_kernel, dim3(ablocks), dim3(256), 0, 0, src, rows, C, (const float*)nullptr, a, dst, 1);
                     } else {
                         double* a = acc + (size_t)(r % 64) * 2 * C;          // a fresh (zeroed) accumulator per layer
                         hipLaunchKernelGGL(partial_kernel, dim3(col_tiles, row_blocks), dim3(256), 0, 0, src, rows, C, rpb, (float*)nullptr, a);
@@ -127,12 +145,12 @@ int main() {
                 hipEventRecord(e1, 0);
                 hipEventSynchronize(e1);
                 hipEventElapsedTime(&ms[form], e0, e1);
-                hipMemset(acc, 0, 2 * C * 8 * 64);
+                hipMemset(acc, 0, (size_t)2 * C * 8 * 64 * 8);
                 hipDeviceSynchronize();
             }
         }
-        printf("rows %7ld C %4d row_blocks %5d: partial+final+apply %.2f us per layer | atomics+apply %.2f us per layer\n", rows, C,
-               row_blocks, ms[0] * 1e3 / reps, ms[1] * 1e3 / reps);
+        printf("rows %7ld C %4d row_blocks %5d: partial+final+apply %.2f us per layer | device-scope atomics+apply %.2f | per-XCD rows, "
+               "workgroup-scope atomics+apply %.2f\n", rows, C, row_blocks, ms[0] * 1e3 / reps, ms[1] * 1e3 / reps, ms[2] * 1e3 / reps);
         hipFree(x), hipFree(y), hipFree(partial), hipFree(sums), hipFree(acc);
     }
     return 0;
