@@ -219,7 +219,10 @@ class DeferredReducer:
             self.pending = [k for k in self.pending if k not in now]
         if not self.pending:
             return 0
-        keys = tuple(self.pending)
+        # the layers with the longest per-block chains (most splits) first: the blocks of a launch start in table order, and a
+        # 497-split layer placed last (the discriminator's first convolution: 64 blocks of 31 sequential partial sums) was the
+        # tail of the whole launch.  Every layer's sum is its own: the order of the table changes no result
+        keys = tuple(sorted(self.pending, key=lambda k: -self.recs[k]["splits"]))
         tab = self.tables.get(keys)
         dev = self.recs[keys[0]]["part"].device
         if tab is None:

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--config", default="moving-gif")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--opt", default="g", choices=["g", "d", "kp"], help="whose optimiser: generator / discriminator / key points")
     a = ap.parse_args()
     cfg = configs.get(a.config)
     mp = cfg["model_params"]
@@ -36,8 +37,8 @@ def main():
     for _ in range(2):
         step.step(x)
     torch.cuda.synchronize()
-    red = step.opt_g.reducer
-    names = {id(p): n for n, p in gen.named_parameters()}
+    red = {"g": step.opt_g, "d": step.opt_d, "kp": step.opt_k}[a.opt].reducer
+    names = {id(p): n for n, p in {"g": gen, "d": disc, "kp": kpd}[a.opt].named_parameters()}
     recs = [(k, r) for k, r in red.recs.items() if r["splits"] > 0]
 
     def table(sel):
@@ -79,8 +80,12 @@ def main():
     for k, r in sorted(recs, key=lambda kr: -kr[1]["nfloats"]):
         us, blocks = timeit([(k, r)], iters=10)
         row = r["row"]
-        print("%-46s splits %4d layout %d partial %7.2f MB blocks %5d %7.1f us" % (
-            names.get(k[0], "?")[:46], r["splits"], row[2], r["nfloats"] * 4 / 1e6, blocks, us))
+        td, red.owner.tap_direct = red.owner.tap_direct, True
+        direct = red.is_direct(k)
+        red.owner.tap_direct = td
+        print("%-46s splits %4d layout %d partial %7.2f MB blocks %5d %7.1f us  C %4d Cout %4d%s" % (
+            names.get(k[0], "?")[:46], r["splits"], row[2], r["nfloats"] * 4 / 1e6, blocks, us, row[6], row[5],
+            "  direct (read by the optimiser kernel in a captured iteration)" if direct else ""))
 
 
 if __name__ == "__main__":
