@@ -294,21 +294,25 @@ def hot_path_only(step, x, iters, device):
     return e0.elapsed_time(e1) / iters, launch
 
 
-def dropin_loop(cfg, x, device, steps, warmup):
+def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):
     """What a user of the reference gets by putting monkey-net_amd/ in front of the reference root and running the reference's
     unmodified train.py: its loop (train.py:78-153), statement for statement as tests/test_dropin_replay.py restates it --
     three torch.optim.Adam(betas=(0.5, 0.999)), the two full models (train.py:24-75 = mnk.engine.GeneratorFullModel /
     DiscriminatorFullModel) behind DataParallelWithCallback(device_ids=[0]), HOST dict batches as a DataLoader hands them
     over (pinned; the wrapper moves them), generator pass -> backward -> steps, discriminator pass (a second discriminator
     forward) -> backward -> step, and the per-iteration host copies of the loss values (train.py:125,138).  No hipGraph, no
-    MnkAdam, no shared discriminator forward: every launch is issued by the Python loop."""
+    MnkAdam, no shared discriminator forward: every launch is issued by the Python loop.
+    mnk_adam: the same loop with train.py:81-83's three `torch.optim.Adam(...)` replaced by `mnk.optim.MnkAdam(...)` -- the one
+    edit of the reference's loop INTEGRATION.md section 1.5 offers (both variants: tests/test_dropin_replay.py)."""
     from mnk.engine import GeneratorFullModel, DiscriminatorFullModel
+    from mnk.optim import MnkAdam
     from sync_batchnorm import DataParallelWithCallback
     tp = cfg["train_params"]
     generator, discriminator, kp_detector = build_models(cfg, device)
-    opt_g = torch.optim.Adam(generator.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
-    opt_d = torch.optim.Adam(discriminator.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
-    opt_k = torch.optim.Adam(kp_detector.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
+    Adam = MnkAdam if mnk_adam else torch.optim.Adam
+    opt_g = Adam(generator.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
+    opt_d = Adam(discriminator.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
+    opt_k = Adam(kp_detector.parameters(), lr=tp["lr"], betas=(0.5, 0.999))
     gpar = DataParallelWithCallback(GeneratorFullModel(kp_detector, generator, discriminator, tp), device_ids=[0])
     dpar = DataParallelWithCallback(DiscriminatorFullModel(kp_detector, generator, discriminator, tp), device_ids=[0])
     host = {k: v.cpu().pin_memory() for k, v in x.items()}
@@ -582,6 +586,10 @@ def main():
     if args.dropin and not dist_mode and rank == 0:
         try:
             dropin = dropin_loop(cfg, x, device, max(5, min(args.steps, 20)), 3)
+            m = dropin_loop(cfg, x, device, max(5, min(args.steps, 20)), 3, mnk_adam=True)
+            dropin["with_mnk_adam"] = {"value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"], "finite": m["finite"],
+                                       "what": "the same loop with train.py:81-83's three torch.optim.Adam replaced by "
+                                               "mnk.optim.MnkAdam (INTEGRATION.md section 1.5)"}
         except Exception as e:   # never lose the bench line to the extra measurement
             dropin = {"error": "%s: %s" % (type(e).__name__, e)}
     hot_ms, hot_launch = None, None

@@ -27,8 +27,17 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# (the raw handle of the current stream without a torch.cuda.Stream object: 0.3 instead of 5 us per kernel launch -- the
+# reference's own loop on these modules is bound by the host, not by the GPU: tools/dropin_profile.py)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+    if not t.is_cuda:
+        return 0
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(t.device.index)
+    return torch.cuda.current_stream(t.device).cuda_stream
 
 
 def _check_device(t):
@@ -367,6 +376,13 @@ def _pack_entry(weight, cout, c0, c1, need, up=False):
     e = _PACK_REG.get(id(weight))
     if e is not None and e.fresh(weight, meta, need):
         return e
+    if (e is not None and e.wref() is weight and e.wptr == weight.data_ptr() and e.meta == meta
+            and all(e.wd[i] is not None for i in (0, 1) if need[i])):
+        # a known layer gone stale (an optimiser stepped): the first such layer of an iteration re-packs EVERY registered
+        # parameter in one launch -- a user-owned loop (the reference's train.py) then pays one pack launch per iteration
+        # instead of one (to three) per convolution, as mnk.engine.TrainStep does at the start of its iterations
+        if repack_registered() and e.fresh(weight, meta, need):
+            return e
     if e is None or e.wref() is not weight or e.wptr != weight.data_ptr() or e.meta != meta:
         e = _PackEntry()
         e.wref, e.wptr, e.meta, e.wd, e.stamp = weakref.ref(weight), weight.data_ptr(), meta, [None, None], None

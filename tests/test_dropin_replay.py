@@ -18,9 +18,18 @@ from oracle import cases
 from test_modules import build, load
 
 
-def test_train_py_caller_sequence_replayed_on_the_drop_in_modules(be, tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("adam", ["torch", "mnk"])
+def test_train_py_caller_sequence_replayed_on_the_drop_in_modules(be, tmp_path, adam):
+    """adam = "mnk": the same loop with train.py:81-83's three constructors replaced by mnk.optim.MnkAdam (INTEGRATION.md
+    section 1.5: the one change to the reference's loop that is worth making -- weight-gradient GEMMs of a backward pass launched
+    together into the optimiser's flat buffer, one Adam launch per optimiser that also writes the packed weights)."""
     from mnk.engine import GeneratorFullModel, DiscriminatorFullModel          # train.py:24-75 restated (mnk/engine.py)
+    from mnk.optim import MnkAdam
     from sync_batchnorm import DataParallelWithCallback
+    Adam = torch.optim.Adam if adam == "torch" else MnkAdam
     gold = load("step_tiny")
     config = copy.deepcopy(gold["cfg"])
     train_params = config["train_params"]
@@ -41,9 +50,9 @@ def test_train_py_caller_sequence_replayed_on_the_drop_in_modules(be, tmp_path):
             return {"source": src[i], "video": drv[i]}
 
     # train.py:81-99
-    optimizer_generator = torch.optim.Adam(generator.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
-    optimizer_discriminator = torch.optim.Adam(discriminator.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
-    optimizer_kp_detector = torch.optim.Adam(kp_detector.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
+    optimizer_generator = Adam(generator.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
+    optimizer_discriminator = Adam(discriminator.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
+    optimizer_kp_detector = Adam(kp_detector.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
     schedulers = [MultiStepLR(o, train_params['epoch_milestones'], gamma=0.1, last_epoch=-1)
                   for o in (optimizer_generator, optimizer_discriminator, optimizer_kp_detector)]
     dataloader = DataLoader(Pairs(), batch_size=train_params['batch_size'], shuffle=False, num_workers=0, drop_last=True)
@@ -102,7 +111,7 @@ def test_train_py_caller_sequence_replayed_on_the_drop_in_modules(be, tmp_path):
     g2, d2, k2 = build(config)
     for m in (g2, d2, k2):
         m.to(be.device)
-    og2 = torch.optim.Adam(g2.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
+    og2 = Adam(g2.parameters(), lr=train_params['lr'], betas=(0.5, 0.999))
     checkpoint = torch.load(path, weights_only=False)
     g2.load_state_dict(checkpoint['generator'])
     k2.load_state_dict(checkpoint['kp_detector'])
