@@ -23,3 +23,13 @@ done
 for p in $pids; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$HERE/../libmonkeynet_hip$TAG.so" $OBJS -ldl
 echo "$HERE/../libmonkeynet_hip$TAG.so"
+# the CPython binding of the C-ABI, generated from the header (mnk/_lib.py binds it to whichever library it loads; without it
+# every call goes through ctypes)
+PYINC="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')"
+PYEXT="$(python3 -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))')"
+FAST="$HERE/../_mnkfast$PYEXT"
+if [ ! -f "$FAST" ] || [ "$ROOT/include/monkeynet_hip.h" -nt "$FAST" ] || [ "$HERE/gen_fastcall.py" -nt "$FAST" ]; then
+  python3 "$HERE/gen_fastcall.py" "$ROOT/include/monkeynet_hip.h" "$OUT/_mnkfast.c" > /dev/null
+  gcc -O2 -shared -fPIC -Wall -I"$PYINC" -o "$FAST.tmp.$$" "$OUT/_mnkfast.c" && mv -f "$FAST.tmp.$$" "$FAST"
+fi
+echo "$FAST"

@@ -74,10 +74,41 @@ def _query(name, *args):
     return _lib.lib().query(name, *args)
 
 
+class _EvalCtx:
+    """What a Function.forward of this module sees as `ctx` when it runs OUTSIDE autograd (grad mode off): nothing is saved,
+    no input needs a gradient; attributes a forward sets (ctx.meta = ...) land on this throw-away object."""
+    __slots__ = ("__dict__", "needs_input_grad")
+
+    def __init__(self, n):
+        self.needs_input_grad = (False,) * n
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
+class _Fn(torch.autograd.Function):
+    """torch.autograd.Function whose apply() calls forward() directly when grad mode is off: the evaluation loops of the
+    reference (reconstruction.py:52-62, transfer.py:65-79, demo.py) run the networks frame by frame at batch 1 under
+    torch.no_grad(), ~95 Function calls per frame, and are bound by the host (tools/frame_loop_probe.py) -- the autograd
+    machinery of apply() (argument scan, node construction, output wrapping) has nothing to record there."""
+
+    @classmethod
+    def apply(cls, *args):
+        if torch.is_grad_enabled():
+            return super().apply(*args)
+        return cls.forward(_EvalCtx(len(args)), *args)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # layout
 # ----------------------------------------------------------------------------------------------------------------
-class ToActFn(torch.autograd.Function):
+class ToActFn(_Fn):
     """(B,C,D,H,W) -> act, with the nearest down-scaling by an integer `step` (keypoint_detector.py:98-99)."""
 
     @staticmethod
@@ -120,7 +151,7 @@ class StackedBatch:
         return torch.cat(self.parts, dim=0)[idx]
 
 
-class ToActPairFn(torch.autograd.Function):
+class ToActPairFn(_Fn):
     """ToActFn of StackedBatch(a, b): one act, its two halves written by one conversion launch each."""
 
     @staticmethod
@@ -148,7 +179,7 @@ class ToActPairFn(torch.autograd.Function):
         return outs[0], outs[1], None
 
 
-class FromActFn(torch.autograd.Function):
+class FromActFn(_Fn):
     """act -> (B,C,D,H,W)."""
 
     @staticmethod
@@ -169,7 +200,7 @@ class FromActFn(torch.autograd.Function):
         return out, None, None
 
 
-class Concat2PairFn(torch.autograd.Function):
+class Concat2PairFn(_Fn):
     """Concat2Fn for the batched discriminator pass [generated | real] (mnk.engine.fused_pair_losses): `a` holds 2B frames, `b`
     (the key-point embedding, the same for both halves) B frames: out[n] = [a[n] | b[n mod B]].  The reference's two calls
     embed the same key points twice (train.py:43-45); here the embedding is made once, and its gradient is the sum of the two
@@ -205,7 +236,7 @@ class Concat2PairFn(torch.autograd.Function):
         return ga, None, gb, None
 
 
-class Concat2Fn(torch.autograd.Function):
+class Concat2Fn(_Fn):
     """torch.cat([a, b], dim=channel) on acts (modules/util.py:185 for the last decoder stage)."""
 
     @staticmethod
@@ -612,7 +643,7 @@ def clear_dz_stats():
 _SRC_BN = [None]                          # conv3x3() -> Conv3x3Fn.forward: (record of x0's norm layer or None, of x1's)
 
 
-class Conv3x3Fn(torch.autograd.Function):
+class Conv3x3Fn(_Fn):
     """nn.Conv3d((1,3,3), padding (0,1,1)) over the channel concatenation [x0 | x1], optionally read through the
     nearest x2 up-sampling (UpBlock3D, modules/util.py:83-85), plus bias and residual add (ResBlock3D :66-67)."""
 
@@ -752,7 +783,7 @@ class Conv3x3Fn(torch.autograd.Function):
         return grads[0], grads[1], dw, db, dres, None, None, None, None, None
 
 
-class Conv3x3SkipFn(torch.autograd.Function):
+class Conv3x3SkipFn(_Fn):
     """Conv3x3Fn that also hands x0 through: -> (y, sums, x0).  For a tensor with a second consumer (an hourglass level:
     the next down block's convolution AND the decoder's skip / a warp, util.py:142-152,184-188) the second consumer takes
     the handed-through tensor; this node is then the only consumer of the original and its backward adds the other
@@ -785,7 +816,7 @@ def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, 
 # ----------------------------------------------------------------------------------------------------------------
 # BatchNorm (+ReLU, +2x2 average pool)
 # ----------------------------------------------------------------------------------------------------------------
-class BNActFn(torch.autograd.Function):
+class BNActFn(_Fn):
     """SynchronizedBatchNorm3d (sync_batchnorm/batchnorm.py:48-78) fused with the ReLU and the AvgPool3d((1,2,2))
     that follow it in DownBlock3D / UpBlock3D / SameBlock3D / ResBlock3D (modules/util.py).  In training mode under
     torch.distributed the sufficient statistics are all-reduced over the ranks (SyncBN over RCCL)."""
@@ -940,7 +971,7 @@ class BNActFn(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-class BNActSkipFn(torch.autograd.Function):
+class BNActSkipFn(_Fn):
     """BNActFn for the first norm layer of a residual block (util.py:58-67): returns (z, y) -- y handed through for the
     block's `out += x`.  Both consumers of the block's input are then this one node, and its backward adds the gradient of
     the skip path inside the BatchNorm dy pass (mnk_bn_act_bwd_apply_add_colsum) instead of leaving a separate accumulation
@@ -1005,7 +1036,7 @@ class no_leaf_input_grads:
         _SKIP_LEAF_INPUT_GRADS[0] = self.prev
 
 
-class ConvKxKFn(torch.autograd.Function):
+class ConvKxKFn(_Fn):
     """nn.Conv3d((1,k,k)), stride 1, zero padding `pad`, single source -- the discriminator's 4x4 convolutions without
     padding (modules/discriminator.py:17-18,28) on the same implicit-GEMM kernels; the data gradient is the same
     kernel on dy with pad k-1-pad and the flipped / transposed pack."""
@@ -1071,7 +1102,7 @@ class ConvKxKFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
-class InstNormActFn(torch.autograd.Function):
+class InstNormActFn(_Fn):
     """[InstanceNorm3d (affine)] -> LeakyReLU(slope) -> avg_pool (1,2,2) of the discriminator's DownBlock3D
     (modules/discriminator.py:26-33): per-frame statistics (the time axis is 1 on every call path), one fused pass."""
 
@@ -1136,7 +1167,7 @@ def _identity_affine(c, dev):
     return t
 
 
-class PairL1Fn(torch.autograd.Function):
+class PairL1Fn(_Fn):
     """weight * mean_batch(|generated - real|) (modules/losses.py:8-12) of one discriminator feature map, read from the
     act of the batched pass [generated | real] (2B frames) -> tensor (B,).  One launch forward, one backward; the
     feature maps never take their NCDHW form."""
@@ -1163,7 +1194,7 @@ class PairL1Fn(torch.autograd.Function):
         return da, None, None, None
 
 
-class PairL1TapFn(torch.autograd.Function):
+class PairL1TapFn(_Fn):
     """PairL1Fn as a tap on the discriminator's forward pass: (the map itself for the next block, the loss vector).  The map
     then has ONE consumer in the autograd graph, and the gradient of the next block is added inside the L1 backward kernel
     (autograd's own accumulation: one more pass over every feature map of the batched [generated | real] pass)."""
@@ -1194,7 +1225,7 @@ class PairL1TapFn(torch.autograd.Function):
         return da, None, None, None
 
 
-class L1MeanFn(torch.autograd.Function):
+class L1MeanFn(_Fn):
     """weight * mean_batch(|prediction - target|) (modules/losses.py:8-12) of two equally shaped contiguous tensors
     (the frames themselves: reconstruction_deformed, map 0 of 'reconstruction') -> tensor (B,).  One launch each way
     instead of sub / abs / mean / mul and their four backward nodes."""
@@ -1223,7 +1254,7 @@ class L1MeanFn(torch.autograd.Function):
         return da, db, None
 
 
-class GanTermsFn(torch.autograd.Function):
+class GanTermsFn(_Fn):
     """(generator_gan_loss, discriminator_gan_loss) of modules/losses.py:15-21 from the score maps of the batched
     discriminator pass [generated | real] (2B samples) -> two tensors (B,).  One launch each way; the score tensor is
     not sliced (a slice's backward is a zero fill and a copy)."""
@@ -1253,7 +1284,7 @@ class GanTermsFn(torch.autograd.Function):
         return ds, None, None, None
 
 
-class LossMeansFn(torch.autograd.Function):
+class LossMeansFn(_Fn):
     """[v.mean() for v in vecs] and the sum of these means (train.py:114,116) for per-sample loss vectors of one length:
     (means (n,), total ()).  One launch each way instead of stack / mean / sum and their expand / div backward passes."""
 
@@ -1284,7 +1315,7 @@ class LossMeansFn(torch.autograd.Function):
         return tuple(g.view(shp) for g, shp in zip(gv.unbind(0), shapes))
 
 
-class GConv1x1Fn(torch.autograd.Function):
+class GConv1x1Fn(_Fn):
     """nn.Conv3d(kernel (1,1,1), groups=num_kp+1) of SameBlock3D (dense_motion_module.py:24-28)."""
 
     @staticmethod
@@ -1319,7 +1350,7 @@ class GConv1x1Fn(torch.autograd.Function):
         return dx, dw, db if has_bias else None, None
 
 
-class Conv1x1SigmoidFn(torch.autograd.Function):
+class Conv1x1SigmoidFn(_Fn):
     """1x1 conv writing (B,C,D,H,W) directly: refinement_module['conv-last'] + torch.sigmoid (generator.py:48,79-80;
     act=1) or the discriminator's linear score head (discriminator.py:59,77; act=0)."""
 
@@ -1358,7 +1389,7 @@ class Conv1x1SigmoidFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------
 # key-points
 # ----------------------------------------------------------------------------------------------------------------
-class SoftmaxKPFn(torch.autograd.Function):
+class SoftmaxKPFn(_Fn):
     """F.softmax(heatmap / T over H*W) + gaussian2kp 'matrix' (keypoint_detector.py:43-60,103-107)."""
 
     @staticmethod
@@ -1408,7 +1439,7 @@ def kp_pixel_index(mean, size):
     return out
 
 
-class ClipVarianceFn(torch.autograd.Function):
+class ClipVarianceFn(_Fn):
     """var * max(clip, sigma_min(var)) / sigma_min(var) on (..., 2, 2) covariances (keypoint_detector.py:62-65,
     modules/util.py:244-255) in one kernel instead of ~25 element-wise launches (+ ~60 in the backward)."""
 
@@ -1436,7 +1467,7 @@ class ClipVarianceFn(torch.autograd.Function):
         return dvar, None, None
 
 
-class MovementEmbeddingFn(torch.autograd.Function):
+class MovementEmbeddingFn(_Fn):
     """MovementEmbeddingModule.forward (movement_embedding.py:42-92) -> act with kp-major channel order."""
 
     @staticmethod
@@ -1498,7 +1529,7 @@ class MovementEmbeddingFn(torch.autograd.Function):
         return None, g_mean_d, g_var_d, g_mean_s, g_var_s, None
 
 
-class MotionFieldKPFn(torch.autograd.Function):
+class MotionFieldKPFn(_Fn):
     """MotionFieldFn's mask form with kp_source.mean - kp_driving.mean formed inside the kernels (one driving frame per
     video): no subtraction / concatenation / zero-slot launches, and the two key-point gradients come out of the backward
     kernel.  mean_s, mean_d: (B,1,K,2)."""
@@ -1528,7 +1559,7 @@ class MotionFieldKPFn(torch.autograd.Function):
         return dpred, g[0], g[1], None, None
 
 
-class MotionFieldFn(torch.autograd.Function):
+class MotionFieldFn(_Fn):
     """mask softmax, sum_k m_k * delta_k + correction + identity grid (dense_motion_module.py:52-73) -> (N,h,w,2)."""
 
     @staticmethod
@@ -1555,7 +1586,7 @@ class MotionFieldFn(torch.autograd.Function):
         return dpred, (ddelta if delta is not None else None), None, None, None
 
 
-class WarpSkipFn(torch.autograd.Function):
+class WarpSkipFn(_Fn):
     """deform_input (generator.py:51-58) of one skip tensor, with the nearest-resized key-point embedding written
     behind it in the same buffer (generator.py:72-73): out = [warp(inp, field) | resize(emb)]."""
 
@@ -1603,7 +1634,7 @@ WARP_LEVEL = np.dtype([("inp", "<u8"), ("out", "<u8"), ("dout", "<u8"), ("dinp",
                        ("h", "<i4"), ("w", "<i4"), ("ld_out", "<i4"), ("ke", "<i4"), ("emb_off", "<i4"), ("reserved", "<i4")])
 
 
-class WarpAllFn(torch.autograd.Function):
+class WarpAllFn(_Fn):
     """Every deform_input of one generator forward (generator.py:66-73 the skips, :78 the source frame) as ONE autograd node.
     They all read the same deformation field, so as separate nodes each backward zero-fills its own field gradient and
     autograd adds the eight of them up; here the warp backward kernels accumulate into one zeroed buffer (they add

@@ -39,6 +39,31 @@ def test_invalid_arguments_are_rejected_before_launch(real_lib):
     assert real_lib.query("mnk_conv3x3_workspace_floats", 32, 4, 4, 1024, 0, 1024) > 0     # deep level: split-K
 
 
+def test_generated_cpython_binding_is_the_same_abi(real_lib):
+    """monkey-net_amd/_mnkfast (csrc/gen_fastcall.py, generated from the header): every entry point without a char* in its
+    prototype has a wrapper bound to THIS library's address; the wrapper returns what the ctypes call returns, reports a
+    wrong argument count, passes status codes on, and hands an argument it does not take (a ctypes object) back to ctypes."""
+    import ctypes
+    import _mnkfast
+    from mnk import _lib
+    names = set(_mnkfast.names())
+    assert len(names) >= len(real_lib.protos) - 8 and names <= set(real_lib.protos)
+    assert set(real_lib.fast) == names
+    for args in ((64, 3, 0), (128, 64, 32), (45, 45, 0)):
+        assert real_lib.fast["mnk_conv3x3_packed_floats"](*args) == real_lib.cdll.mnk_conv3x3_packed_floats(*args)
+    assert real_lib.fast["mnk_version"]() == real_lib.cdll.mnk_version()
+    with pytest.raises(TypeError):
+        real_lib.fast["mnk_conv3x3_packed_floats"](64, 3)
+    assert real_lib.fast["mnk_bn_stats"](None, 4, 10, 3, None, None, 0, None) == -1            # MNK_EINVAL, nothing launched
+    assert real_lib.fast["mnk_conv3x3_packed_floats"](64.5, 3, 0) is NotImplemented              # not an int: ctypes' turn
+    plan = (ctypes.c_int * 8)()
+    assert real_lib.fast["mnk_conv2d_wgrad_plan2"](32, 8, 8, 64, 64, 3, 3, 1, 64, 0, ctypes.byref(plan)) is NotImplemented
+    assert real_lib.query("mnk_conv2d_wgrad_plan2", 32, 8, 8, 64, 64, 3, 3, 1, 64, 0, ctypes.byref(plan)) == 0
+    # a second library (here: the same file under a second handle) binds its own addresses
+    other = _lib.Library(_lib.DEFAULT_LIB, strict=True)
+    assert other.query("mnk_conv3x3_packed_floats", 64, 3, 0) == 64 * 9 * 16
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from mnk import _lib
     with pytest.raises(_lib.MnkError):
