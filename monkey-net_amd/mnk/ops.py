@@ -816,6 +816,35 @@ def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, 
 # ----------------------------------------------------------------------------------------------------------------
 # BatchNorm (+ReLU, +2x2 average pool)
 # ----------------------------------------------------------------------------------------------------------------
+# Evaluation-mode coefficients (mean, 1/sqrt(var + eps), gamma / sqrt(var + eps)) of a norm layer, kept between calls: the
+# reference's evaluation loops run the networks frame by frame with constant weights, and the coefficient launch was 40 of
+# the 135 launches per frame (tools/frame_loop_probe.py).  Valid while nothing wrote the layer's tensors: tensor versions
+# (load_state_dict, in-place ops), storage addresses, the optimiser-step / replay epoch (_PACK_EPOCH: fused optimisers and
+# captured iterations do not bump versions) and the training-forward epoch (kernels update running statistics through raw
+# pointers) are all part of the key; never used under stream capture (a replay must read the live buffers).
+_BN_EVAL = {}
+_BN_EVAL_EPOCH = [0]
+
+
+def _bn_eval_coeffs(y, gamma, running_mean, running_var, eps, c):
+    capturing = y.is_cuda and torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        key = (0 if gamma is None else gamma.data_ptr(), 0 if gamma is None else gamma._version, running_mean.data_ptr(),
+               running_mean._version, running_var.data_ptr(), running_var._version, float(eps), c, _stream(y),
+               _PACK_EPOCH[0], _BN_EVAL_EPOCH[0])
+        hit = _BN_EVAL.get(id(running_mean))
+        if hit is not None and hit[0] == key and hit[2]() is running_mean:
+            return hit[1]
+    mean = torch.empty(c, dtype=torch.float32, device=y.device)
+    invstd, scale = torch.empty_like(mean), torch.empty_like(mean)
+    _call("mnk_bn_eval_coeffs", y, _p(gamma), _p(running_mean), _p(running_var), float(eps), c, _p(mean), _p(invstd), _p(scale))
+    if not capturing:
+        if id(running_mean) not in _BN_EVAL:
+            weakref.finalize(running_mean, _BN_EVAL.pop, id(running_mean), None)
+        _BN_EVAL[id(running_mean)] = (key, (mean, invstd, scale), weakref.ref(running_mean))
+    return mean, invstd, scale
+
+
 class BNActFn(_Fn):
     """SynchronizedBatchNorm3d (sync_batchnorm/batchnorm.py:48-78) fused with the ReLU and the AvgPool3d((1,2,2))
     that follow it in DownBlock3D / UpBlock3D / SameBlock3D / ResBlock3D (modules/util.py).  In training mode under
@@ -827,9 +856,12 @@ class BNActFn(_Fn):
         n, h, w, ld = y.shape
         rows = n * h * w
         dev = y.device
-        mean = torch.empty(c, dtype=torch.float32, device=dev)
-        invstd = torch.empty_like(mean)
-        scale = torch.empty_like(mean)
+        if training:
+            _BN_EVAL_EPOCH[0] += 1          # kernels are about to write running statistics through raw pointers
+        if training:
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            invstd = torch.empty_like(mean)
+            scale = torch.empty_like(mean)
         count = float(rows)
         pending = _SPLIT_PENDING.pop(y.data_ptr(), None)
         ctx.small = False
@@ -883,8 +915,7 @@ class BNActFn(_Fn):
                           _p(running_var), float(momentum), float(eps), 1, None, _p(mean), _p(invstd), _p(scale),
                           _p(ws), nws)
         else:
-            _call("mnk_bn_eval_coeffs", y, _p(gamma), _p(running_mean), _p(running_var), float(eps), c, _p(mean),
-                  _p(invstd), _p(scale))
+            mean, invstd, scale = _bn_eval_coeffs(y, gamma, running_mean, running_var, eps, c)
         ho, wo = (h // 2, w // 2) if pool else (h, w)
         z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)     # the kernel zeroes the pad channels
         _call("mnk_bn_act_fwd", y, _p(y), ld, _p(mean), _p(scale), _p(beta), _p(z), z.shape[-1], 0, n, h, w, c, int(relu),

@@ -259,6 +259,63 @@ def test_repack_registered_serves_training_forwards(be):
         ops._call = real
 
 
+def test_evaluation_coefficients_of_a_norm_layer_are_kept_until_something_writes_it(be):
+    """The reference's evaluation loops call the networks frame by frame with constant weights (reconstruction.py:52-62): the
+    (mean, invstd, scale) launch of an eval-mode norm layer runs once, not per call -- and again after ANY write to the layer:
+    an in-place change of a buffer, load_state_dict, an optimiser step (fused steps do not bump tensor versions: the global
+    post-step hook does it), a training-mode forward (kernels update the running statistics through raw pointers)."""
+    from mnk import ops
+    from modules.util import SameBlock3D
+    torch.manual_seed(3)
+    blk = SameBlock3D(6, 6, groups=1, kernel_size=(1, 1, 1), padding=(0, 0, 0)).to(be.device)
+    blk.norm.running_mean.uniform_(-0.5, 0.5), blk.norm.running_var.uniform_(0.5, 2.0)
+    x = be.t(torch.rand(2, 6, 1, 8, 8))
+    launches = []
+    real = ops._call
+
+    def counting(name, *a, **k):
+        launches.append(name)
+        return real(name, *a, **k)
+
+    def ref():
+        bn = blk.norm
+        y = torch.nn.functional.conv3d(x.cpu().double(), blk.conv.weight.detach().cpu().double(), blk.conv.bias.detach().cpu().double())
+        y = (y - bn.running_mean.cpu().double().view(1, -1, 1, 1, 1)) / torch.sqrt(bn.running_var.cpu().double().view(1, -1, 1, 1, 1) + bn.eps)
+        return torch.relu(y * bn.weight.detach().cpu().double().view(1, -1, 1, 1, 1) + bn.bias.detach().cpu().double().view(1, -1, 1, 1, 1))
+
+    def run(expect):
+        del launches[:]
+        with torch.no_grad():
+            out = blk(x)
+        be.sync()
+        assert launches.count("mnk_bn_eval_coeffs") == expect, (expect, launches)
+        assert float((out.cpu().double() - ref()).abs().max()) < 1e-5
+
+    ops._call = counting
+    try:
+        blk.eval()
+        run(1)
+        run(0), run(0)
+        blk.norm.running_mean.add_(0.25)                       # an in-place write: the tensor's version moves
+        run(1), run(0)
+        sd = {k: v.clone() for k, v in blk.state_dict().items()}
+        sd["norm.running_var"] *= 1.5
+        blk.load_state_dict(sd)
+        run(1), run(0)
+        opt = torch.optim.SGD(blk.parameters(), lr=0.1)
+        for p in blk.parameters():
+            p.grad = torch.ones_like(p)
+        opt.step()                                             # the norm layer's gamma changed
+        run(1), run(0)
+        blk.train()
+        with torch.no_grad():
+            blk(x)                                             # updates the running statistics on the device
+        blk.eval()
+        run(1), run(0)
+    finally:
+        ops._call = real
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny2"])
 def test_pad_channels_are_written(be, name, monkeypatch):
     """The 3x3 fast loader (MNK_CONV_CLEAN_PADS) relies on every activation this package produces having ZERO pad
