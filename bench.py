@@ -12,9 +12,11 @@ discriminator forward serving both).  KPDetector / DenseMotionModule / generator
 and backward on the hand-written gfx950 kernels (libmonkeynet_hip.so), and so do the loss terms and the three Adam
 steps (mnk.optim.MnkAdam: one launch per optimiser that also emits the packed weights of the next forward); what
 is left on stock PyTorch-ROCm ops is autograd's own gradient accumulation and the batch means of the loss vectors
-(SURVEY.md section 8f).  With several ranks the SyncBN statistics and the flat gradient buffer are all-reduced by the
-library's own RCCL communicator inside the timed step.  Data: synthetic U[0,1) frame pairs (BASELINE.md section 2
-protocol), random-init weights of the named configuration; inputs are resident in HBM before the timed region.
+(SURVEY.md section 8f).  With several ranks the flat gradient buffer is all-reduced by the library's own RCCL
+communicator and the SyncBN statistics travel through the peer-to-peer exchange inside the statistics kernels (csrc/p2p.hip;
+RCCL when the mailboxes cannot be mapped: `syncbn_exchange` in the JSON line says which), inside the timed step.
+Data: synthetic U[0,1) frame pairs (BASELINE.md section 2 protocol), random-init weights of the named configuration;
+inputs are resident in HBM before the timed region.
 
 One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one generated driving frame = one
 (source, driving) pair), whole-job aggregate over all ranks (weak scaling: fixed per-GPU batch), plus
@@ -23,6 +25,12 @@ One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one 
                    begin and end on the launch stream (hipExtLaunchKernelGGL) in two profiled eager iterations after
                    the timed region, against the 157.3 TFLOP/s fp32-MFMA peak of MI355X_MICROARCH.md; `traffic` =
                    HBM bytes per launch from the committed PMC passes of the same build (profiles/, `traffic_source`);
+                   `executed` / `executed_frac`: the multiply-adds the launches actually issue (the sub-pixel forms of the
+                   up-sampled convolutions run 4/9 of the algorithmic ones) / time / peak;
+  dropin        -- the reference's OWN loop on the drop-in modules (train.py:78-153's statement sequence: three
+                   torch.optim.Adam, host batches through DataParallelWithCallback, two discriminator passes, per-iteration
+                   host copies of the losses; eager launches) and `with_mnk_adam`: the same loop with mnk.optim.MnkAdam in
+                   place of the three optimisers -- reported beside `value`, never as it;
   hot_path_only_ms -- SURVEY section 8a alone (KPDetector + generator forward and backward with every weight gradient
                    materialised; no discriminator, losses or optimiser) as a hipGraph replay, next to the whole step;
   cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
