@@ -662,8 +662,14 @@ def main():
         code = torch.tensor([mdist.p2p_error()], dtype=torch.int32, device=device)
         dist.all_reduce(code, op=dist.ReduceOp.MAX)
         if rank == 0:
-            out["syncbn_exchange"] = ("peer-to-peer (csrc/p2p.hip)" if mdist._P2P["handle"] is not None else
-                                      "collective (RCCL / torch.distributed)")
+            if mdist._P2P["handle"] is not None:
+                import ctypes
+                from mnk import _lib
+                kind = _lib.lib().query("mnk_p2p_memory_kind", ctypes.c_void_p(mdist._P2P["handle"]))
+                out["syncbn_exchange"] = "peer-to-peer (csrc/p2p.hip), mailboxes in %s device memory" % (
+                    {3: "uncached", 1: "fine-grained", 0: "ordinary"}.get(kind, "?"))
+            else:
+                out["syncbn_exchange"] = "collective (RCCL / torch.distributed)"
             out["p2p_error"] = int(code.item())
             if out["p2p_error"]:
                 out["capture_failed"] = True

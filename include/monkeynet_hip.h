@@ -447,6 +447,10 @@ int mnk_p2p_export(void* handle, void* ipc_handle64);
 int mnk_p2p_connect(void* handle, const void* all_handles);
 int mnk_p2p_allreduce(void* handle, const float* in, float* out, int n, int timeout_ms, void* stream);
 int mnk_p2p_error(void* handle, int* flag_out);
+/* what the mailbox was allocated as: 3 = uncached device memory (hipDeviceMallocUncached: remote writes over xGMI do not pass
+ * through the owning device's L2, so the polling side must not cache the words either -- what RCCL uses for its own flags),
+ * 1 = fine-grained, 0 = ordinary device memory (enough between processes of ONE device); negative: invalid handle */
+int mnk_p2p_memory_kind(void* handle);
 int mnk_p2p_destroy(void* handle);
 
 /* ---- grouped 1x1 convolution (SameBlock3D, modules/util.py:118, dense_motion_module.py:24-28) ----------- */

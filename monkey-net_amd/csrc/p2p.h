@@ -21,6 +21,7 @@ struct P2P {
     PeerTable peers;
     bool opened[P2P_MAX_WORLD];
     size_t bytes;
+    int memory_kind;                      // 3 uncached, 1 fine-grained, 0 ordinary device memory
 };
 __device__ __forceinline__ unsigned long long* row_of(unsigned long long* box, int world, int slot, int r) {
     return box + ((size_t)slot * world + r) * P2P_MAXF;

@@ -127,9 +127,27 @@ int mnk_p2p_create(int rank, int world, void** handle_out) {
     p->rank = rank;
     p->world = world;
     p->bytes = (size_t)P2P_SLOTS * world * P2P_MAXF * sizeof(unsigned long long);
-    // (plain device memory: the kernel's own accesses are system-scope atomics, which go to memory on every access)
-    if (hipMalloc((void**)&p->local, p->bytes) != hipSuccess || hipMalloc((void**)&p->state, 64) != hipSuccess) {
-        set_error("mnk_p2p_create: hipMalloc failed");
+    // The mailbox is written by OTHER devices over xGMI: such writes reach this device's memory without passing through its
+    // L2, and ordinary (coarse-grained) device memory may be held in that L2 -- a polling load could then hit a stale line for
+    // ever.  Uncached device memory (MTYPE UC: what RCCL allocates for its own flags on this architecture) takes the L2 out of
+    // the picture for every accessor; fine-grained memory is the second choice, plain memory the last one (enough for
+    // processes that share one device and therefore one L2: tests/test_p2p_gpu.py).  The start-up self-test of
+    // mnk.dist.p2p_comm() decides whether what came out is used at all.
+    p->memory_kind = 3;
+    hipError_t e = hipExtMallocWithFlags((void**)&p->local, p->bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        p->memory_kind = 1;
+        e = hipExtMallocWithFlags((void**)&p->local, p->bytes, hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        p->memory_kind = 0;
+        e = hipMalloc((void**)&p->local, p->bytes);
+    }
+    if (e != hipSuccess || hipMalloc((void**)&p->state, 64) != hipSuccess) {
+        set_error("mnk_p2p_create: device allocation failed: %s", hipGetErrorString(e));
+        if (p->local) (void)hipFree(p->local);
         delete p;
         return MNK_ECOMM;
     }
@@ -211,6 +229,14 @@ int mnk_p2p_error(void* handle, int* flag_out) {
     if (hipMemcpy(st, p->state, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return MNK_ELAUNCH;
     *flag_out = (int)st[1];
     return MNK_OK;
+#endif
+}
+
+int mnk_p2p_memory_kind(void* handle) {
+#ifdef HIPEMU
+    return -1;
+#else
+    return handle ? ((P2P*)handle)->memory_kind : -1;
 #endif
 }
 
