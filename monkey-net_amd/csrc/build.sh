@@ -29,7 +29,10 @@ PYINC="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')
 PYEXT="$(python3 -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))')"
 FAST="$HERE/../_mnkfast$PYEXT"
 if [ ! -f "$FAST" ] || [ "$ROOT/include/monkeynet_hip.h" -nt "$FAST" ] || [ "$HERE/gen_fastcall.py" -nt "$FAST" ]; then
-  python3 "$HERE/gen_fastcall.py" "$ROOT/include/monkeynet_hip.h" "$OUT/_mnkfast.c" > /dev/null
-  gcc -O2 -shared -fPIC -Wall -I"$PYINC" -o "$FAST.tmp.$$" "$OUT/_mnkfast.c" && mv -f "$FAST.tmp.$$" "$FAST"
+  # (not fatal: without the module every call goes through ctypes -- slower on the host, same results)
+  ( python3 "$HERE/gen_fastcall.py" "$ROOT/include/monkeynet_hip.h" "$OUT/_mnkfast.c" > /dev/null &&
+    gcc -O2 -shared -fPIC -Wall -Wno-unused-function -I"$PYINC" -o "$FAST.tmp.$$" "$OUT/_mnkfast.c" && mv -f "$FAST.tmp.$$" "$FAST" ) ||
+    { rm -f "$FAST.tmp.$$"; echo "warning: the _mnkfast binding was not built (python3 headers / gcc?): calls will go through ctypes" >&2; }
 fi
-echo "$FAST"
+[ -f "$FAST" ] && echo "$FAST"
+exit 0
