@@ -15,8 +15,9 @@ non-integer augmentations of config/moving-gif.yaml and actions.yaml -- `rotatio
 torchvision adjust_hue -> img_as_float) -- in one launch per batch (mnk_frames_augment), in the arithmetic of the package
 versions the reference pins; those packages are not in this image, so that path is checked against a numpy restatement of
 their published algorithms (oracle/augment_restate.py, "parity unpinned"), not against the packages themselves.  brightness /
-contrast / saturation jitter (no shipped config sets them) raise.  `.gif` / `.mp4` inputs need a decoder this image does not
-have; PNG strips are read by the small decoder below (zlib + the five PNG filters), or by PIL when it is importable.
+contrast / saturation jitter (no shipped config sets them) raise.  `.gif` files (the moving-gif data set) are decoded with
+Pillow (read_gif); `.mp4` / `.mov` need a decoder this image does not have; PNG strips are read by the small decoder below
+(zlib + the five PNG filters), or by PIL when it is importable.
 `DevicePairedDataset` is frames_dataset.py:91-131's PairedDataset over a DeviceFramesDataset."""
 import math
 import os
@@ -92,10 +93,38 @@ def decode_png(path):
     return out.reshape(h, w) if chans == 1 else out.reshape(h, w, chans)
 
 
+def read_gif(path):
+    """frames_dataset.py:30-36 for a .gif: `np.array(imageio.mimread(name))` -- every frame composited on the canvas (disposal
+    methods, transparency) and converted from its palette to RGB (RGBA when the file declares a transparent index; the
+    reference then drops the alpha channel, :34-35; gray frames become three equal channels, :32-33) -- laid out as the strip
+    of frames (H, W * F, channels) the rest of this module works on.  Decoded with Pillow, the library imageio's GIF reader
+    itself sits on (imageio 2.3.0 `GIF-PIL`); imageio is not part of this image, so this branch is checked on GIFs written
+    from known frames (tests/test_frames.py), not against imageio: "parity unpinned" for files whose frames depend on how a
+    decoder composites partial frames."""
+    try:
+        from PIL import Image, ImageSequence
+    except ImportError:
+        raise NotImplementedError("%s: reading .gif files needs Pillow" % path)
+    frames = []
+    with Image.open(path) as im:
+        alpha = "transparency" in im.info
+        for fr in ImageSequence.Iterator(im):
+            a = np.array(fr.convert("RGBA" if alpha else "RGB"))
+            frames.append(a[:, :, :3])
+    if not frames:
+        raise ValueError("%s: no frames" % path)
+    if any(f.shape != frames[0].shape for f in frames):
+        raise ValueError("%s: frames of different sizes" % path)
+    return np.concatenate(frames, axis=1)
+
+
 def read_strip(path):
-    """the decoded image of a stacked-frame file as uint8 (H, W * F, channels)"""
+    """the decoded frames of a file as uint8 (H, W * F, channels): a stacked-frame .png (frames_dataset.py:15-29) as it is, the
+    frames of a .gif side by side"""
+    if path.lower().endswith(".gif"):
+        return read_gif(path)
     if not path.lower().endswith(".png"):
-        raise NotImplementedError("%s: only stacked-frame .png files (frames_dataset.py:15-29); .jpg / .gif / .mp4 need a "
+        raise NotImplementedError("%s: stacked-frame .png and .gif files only (frames_dataset.py:15-36); .jpg / .mp4 / .mov need a "
                                   "decoder that is not part of this image" % path)
     try:
         from PIL import Image

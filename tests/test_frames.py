@@ -127,6 +127,53 @@ def test_a_batch_is_one_launch_of_the_same_samples(be, shapes):
     assert vb["video"].shape == (2, 3, 32, 64, 64) and "source" not in vb
 
 
+def test_gif_videos_give_the_samples_of_the_same_frames_stacked_as_a_png_strip(be, shapes, tmp_path):
+    """frames_dataset.py:30-36: a .gif video (the moving-gif data set's format) is its frames, composited and converted from the
+    palette to RGB.  The fixture's strips (few colours: lossless in a GIF palette) are written as animated GIFs -- once with a
+    global palette and full frames, once with a transparent index and partial-frame optimisation, which a decoder has to
+    composite -- and every sample must equal, bit for bit, the sample of the PNG strip of the same frames."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    from mnk import frames
+    fx, root, names = shapes
+    params, _ = VARIANTS["crop48"]
+    for variant in ("plain", "optimised"):
+        gdir = os.path.join(tmp_path, variant, "train")
+        os.makedirs(gdir), os.makedirs(os.path.join(tmp_path, variant, "test"))
+        pdir = os.path.join(tmp_path, variant + "_png", "train")
+        os.makedirs(pdir), os.makedirs(os.path.join(tmp_path, variant + "_png", "test"))
+        gnames = []
+        for i, n in enumerate(names[:4]):
+            strip = fx["strip%d" % i][:, :, :3]
+            fr = [np.ascontiguousarray(strip[:, k * 64:(k + 1) * 64]) for k in range(strip.shape[1] // 64)]
+            # (Pillow's GIF writer folds a frame that equals its predecessor into the predecessor's duration: compare on
+            # frame lists without such repeats)
+            fr = [f for k, f in enumerate(fr) if k == 0 or not np.array_equal(f, fr[k - 1])]
+            strip = np.concatenate(fr, axis=1)
+            _write_png(os.path.join(pdir, n), strip)
+            assert len(np.unique(strip.reshape(-1, 3), axis=0)) <= 255
+            ims = [Image.fromarray(f, "RGB") for f in fr]
+            g = os.path.join(gdir, n.replace(".png", ".gif"))
+            if variant == "plain":
+                ims[0].save(g, save_all=True, append_images=ims[1:], loop=0, duration=40, optimize=False, disposal=1)
+            else:
+                ims[0].save(g, save_all=True, append_images=ims[1:], loop=0, duration=40, optimize=True, disposal=1)
+            gnames.append(os.path.basename(g))
+            assert np.array_equal(frames.read_strip(g), strip), (variant, n)
+        dg = frames.DeviceFramesDataset(os.path.join(tmp_path, variant), params, image_shape=(64, 64, 3), is_train=True,
+                                        device=be.device, files=gnames)
+        dp = frames.DeviceFramesDataset(os.path.join(tmp_path, variant + "_png"), params, image_shape=(64, 64, 3), is_train=True,
+                                        device=be.device, files=names[:4])
+        random.seed(9), np.random.seed(9)
+        a = dg.batch([0, 1, 2, 3, 1])
+        random.seed(9), np.random.seed(9)
+        b = dp.batch([0, 1, 2, 3, 1])
+        for k in ("source", "video"):
+            assert torch.equal(a[k].cpu(), b[k].cpu()), (variant, k)
+    with pytest.raises(NotImplementedError):
+        frames.read_strip(os.path.join(tmp_path, "clip.mp4"))
+
+
 def test_transforms_without_a_device_form_raise(shapes):
     from mnk import frames
     fx, root, names = shapes
