@@ -4,7 +4,10 @@ box -- IPC handles work between processes on the same device; RCCL does not allo
 every rank's result must be, bit for bit, the rank-ordered sum of all ranks' vectors: eager launches with message sizes from
 one float to the largest BatchNorm of the configurations (2 x 1024 channels), and exchanges captured in a hipGraph and
 replayed (the sequence number lives in device memory).  A dead peer must not hang the GPU: the kernel's wait is bounded
-(mnk.dist.P2P_TIMEOUT_MS), and every process of this test runs under a deadline."""
+(mnk.dist.P2P_TIMEOUT_MS), and every process of this test runs under a deadline.
+(Eight processes on ONE device do not work as a stand-in for eight GPUs: an exchange needs the kernels of all ranks resident at
+the same time, and the hardware scheduler time-slices more than a few processes' queues on one device -- every polling kernel
+then waits for peers that are not running, up to its timeout; measured: all eight workers hit the 150 s deadline.)"""
 import os
 import sys
 
