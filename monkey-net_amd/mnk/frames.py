@@ -137,6 +137,14 @@ def read_strip(path):
     return arr[:, :, None] if arr.ndim == 2 else arr
 
 
+def split_train_test(images, random_seed=0, test_size=0.2):
+    """scikit-learn 0.19.2's train_test_split(images, random_state=random_seed, test_size=test_size) for a list"""
+    n = len(images)
+    n_test = int(math.ceil(test_size * n))
+    perm = np.random.RandomState(random_seed).permutation(n)
+    return [images[i] for i in perm[n_test:]], [images[i] for i in perm[:n_test]]
+
+
 class DeviceFramesDataset:
     """`FramesDataset(root_dir, augmentation_params, image_shape, is_train, random_seed, pairs_list)` with the decoded
     strips resident on `device`.  `dataset[i]` returns what the reference's returns (device tensors instead of numpy
@@ -151,8 +159,11 @@ class DeviceFramesDataset:
             assert os.path.exists(os.path.join(root_dir, "test"))
             root_dir = os.path.join(root_dir, "train" if is_train else "test")
         elif files is None:
-            raise NotImplementedError("random train-test split (sklearn's train_test_split, frames_dataset.py:63) -- give a "
-                                      "directory with train/ and test/, or pass `files`")
+            # frames_dataset.py:61-63: sklearn.model_selection.train_test_split(images, random_state=random_seed, test_size=0.2),
+            # restated: ceil(0.2 n) test items from the front of RandomState(seed).permutation(n), the rest train
+            # (ShuffleSplit._iter_indices; tests/test_frames.py compares with scikit-learn itself where it is installed)
+            train, test = split_train_test(os.listdir(root_dir), random_seed)
+            files = train if is_train else test
         if files is None:
             files = os.listdir(root_dir)                          # the reference's order: the directory listing, not sorted
         self.root_dir = root_dir

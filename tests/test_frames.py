@@ -174,6 +174,29 @@ def test_gif_videos_give_the_samples_of_the_same_frames_stacked_as_a_png_strip(b
         frames.read_strip(os.path.join(tmp_path, "clip.mp4"))
 
 
+def test_random_train_test_split_is_scikit_learns(be, shapes, tmp_path):
+    """frames_dataset.py:61-63: a data directory without train/ and test/ is split by sklearn's train_test_split(images,
+    random_state=random_seed, test_size=0.2) -- restated in mnk.frames.split_train_test and compared with scikit-learn itself."""
+    sk = pytest.importorskip("sklearn.model_selection")
+    from mnk import frames
+    for n in (1, 2, 5, 8, 10, 33, 101):
+        items = ["v%03d.png" % i for i in range(n)]
+        for seed in (0, 1, 7):
+            if n == 1:
+                continue                                   # (sklearn refuses an empty train set)
+            tr, te = sk.train_test_split(items, random_state=seed, test_size=0.2)
+            assert frames.split_train_test(items, seed) == (tr, te), (n, seed)
+    fx, root, names = shapes
+    flat = os.path.join(tmp_path, "flat")
+    os.makedirs(flat)
+    for i, n in enumerate(names):
+        _write_png(os.path.join(flat, n), fx["strip%d" % i])
+    listing = os.listdir(flat)
+    tr, te = sk.train_test_split(listing, random_state=3, test_size=0.2)
+    assert frames.DeviceFramesDataset(flat, None, is_train=True, random_seed=3, device=be.device).images == tr
+    assert frames.DeviceFramesDataset(flat, None, is_train=False, random_seed=3, device=be.device).images == te
+
+
 def test_transforms_without_a_device_form_raise(shapes):
     from mnk import frames
     fx, root, names = shapes
