@@ -123,8 +123,16 @@ def read_strip(path):
     frames of a .gif side by side"""
     if path.lower().endswith(".gif"):
         return read_gif(path)
+    if path.lower().endswith(".jpg"):
+        try:
+            from PIL import Image
+        except ImportError:
+            raise NotImplementedError("%s: reading .jpg files needs Pillow" % path)
+        with Image.open(path) as im:          # (what skimage.io.imread's default plugin does for a .jpg: PIL's decoder)
+            arr = np.array(im if im.mode in ("L", "RGB") else im.convert("RGB"))
+        return arr[:, :, None] if arr.ndim == 2 else arr
     if not path.lower().endswith(".png"):
-        raise NotImplementedError("%s: stacked-frame .png and .gif files only (frames_dataset.py:15-36); .jpg / .mp4 / .mov need a "
+        raise NotImplementedError("%s: stacked-frame .png / .jpg and .gif files only (frames_dataset.py:15-36); .mp4 / .mov need a "
                                   "decoder that is not part of this image" % path)
     try:
         from PIL import Image
