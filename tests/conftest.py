@@ -18,6 +18,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """`pytest tests -m "not gpu"` (the CPU suite: kernels on the fiber emulator, ~10 min in one process) runs on four worker
+    processes when pytest-xdist is installed and no -n / -p no:xdist was given -- about 3 min.  The GPU suite (-m gpu) and any
+    other selection are left alone: its tests share one device (and some spawn processes of their own).  MNK_TESTS_SERIAL=1
+    keeps one process."""
+    opt = config.option
+    if (os.environ.get("MNK_TESTS_SERIAL") == "1" or os.environ.get("PYTEST_XDIST_WORKER")
+            or not config.pluginmanager.hasplugin("xdist") or getattr(opt, "numprocesses", None) is not None
+            or (getattr(opt, "markexpr", "") or "").strip() != "not gpu" or getattr(opt, "collectonly", False)
+            or getattr(opt, "usepdb", False) or (os.cpu_count() or 1) < 4):
+        return None
+    opt.numprocesses = 4
+    return None
+
+
 _EMU = {}
 
 

@@ -625,9 +625,13 @@ def test_norm_layers_take_their_backward_statistics_from_the_data_gradient_launc
     torch.manual_seed(11)
     hg = Hourglass(block_expansion=16, in_features=3, out_features=5, max_features=64, num_blocks=2)
     r1, r2 = ResBlock3D(21, kernel_size=(1, 3, 3), padding=(0, 1, 1)), ResBlock3D(21, kernel_size=(1, 3, 3), padding=(0, 1, 1))
-    x = torch.rand(24, 3, 1, 32, 32)                     # 24 576 pixel rows at full resolution: not the small-layer path
-    xr = torch.rand(24, 21, 1, 32, 32)
-    w1, w2 = torch.randn(24, 5, 1, 32, 32), torch.randn(24, 21, 1, 32, 32)
+    # every level above the one-launch small-layer path (<= 512 pixel rows): 8 x 8 maps x 9 frames = 576 rows at the bottom of
+    # the hourglass on the emulator, 24 frames on the GPU
+    nb = 24 if be.kind == "hip" else 9
+    x = torch.rand(nb, 3, 1, 32, 32)
+    rs = 32 if be.kind == "hip" else 16                  # (the residual blocks: 16 x 16 x 9 = 2 304 rows on the emulator)
+    xr = torch.rand(nb, 21, 1, rs, rs)
+    w1, w2 = torch.randn(nb, 5, 1, 32, 32), torch.randn(nb, 21, 1, rs, rs)
     for m in (hg, r1, r2):
         m.to(be.device).train()
 
