@@ -30,7 +30,8 @@ One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one 
   dropin        -- the reference's OWN loop on the drop-in modules (train.py:78-153's statement sequence: three
                    torch.optim.Adam, host batches through DataParallelWithCallback, two discriminator passes, per-iteration
                    host copies of the losses; eager launches) and `with_mnk_adam`: the same loop with mnk.optim.MnkAdam in
-                   place of the three optimisers -- reported beside `value`, never as it;
+                   place of the three optimisers; `eval_frame_loop`: reconstruction.py:45-62's per-frame loop at batch 1 --
+                   reported beside `value`, never as it;
   hot_path_only_ms -- SURVEY section 8a alone (KPDetector + generator forward and backward with every weight gradient
                    materialised; no discriminator, losses or optimiser) as a hipGraph replay, next to the whole step;
   cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
@@ -358,6 +359,35 @@ def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):
                     "the losses every iteration), eager launches -- tests/test_dropin_replay.py is its parity test"}
 
 
+def frame_loop(cfg, size, device, frames=40):
+    """The reference's per-frame evaluation loop on the drop-in modules (reconstruction.py:45-62: for every frame of a video,
+    kp_detector(frame) and generator(source, kp_driving, kp_source) at batch 1 under no_grad, behind DataParallelWithCallback),
+    eager launches: milliseconds per frame.  (mnk.engine.Reconstructor is the batched / hipGraph form of the same work.)"""
+    from sync_batchnorm import DataParallelWithCallback
+    gen, _, kpd = build_models(cfg, device)
+    generator, kp_detector = DataParallelWithCallback(gen), DataParallelWithCallback(kpd)
+    generator.eval(), kp_detector.eval()
+    video = torch.rand(1, 3, frames, size, size)
+
+    def loop():
+        with torch.no_grad():
+            kp_source = kp_detector(video[:, :, :1])
+            for i in range(frames):
+                kp_driving = kp_detector(video[:, :, i:i + 1])
+                out = generator(source_image=video[:, :, :1], kp_driving=kp_driving, kp_source=kp_source)
+        return out["video_prediction"]
+
+    loop()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    last = loop()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / frames
+    return {"ms_per_frame": round(dt * 1e3, 3), "frames_per_s": round(1.0 / dt, 1), "finite": bool(torch.isfinite(last).all()),
+            "what": "reconstruction.py:45-62's loop on the drop-in modules: kp_detector + generator per frame at batch 1, "
+                    "no_grad, eager launches (host frames through DataParallelWithCallback)"}
+
+
 _JSON_FD = [None]
 
 
@@ -600,6 +630,11 @@ def main():
                                                "mnk.optim.MnkAdam (INTEGRATION.md section 1.5)"}
         except Exception as e:   # never lose the bench line to the extra measurement
             dropin = {"error": "%s: %s" % (type(e).__name__, e)}
+        if isinstance(dropin, dict) and "error" not in dropin:
+            try:
+                dropin["eval_frame_loop"] = frame_loop(cfg, args.size, device)
+            except Exception as e:
+                dropin["eval_frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
     hot_ms, hot_launch = None, None
     if not args.no_profile and not dist_mode:
         try:
