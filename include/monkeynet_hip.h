@@ -441,6 +441,13 @@ int mnk_bn_act_bwd_stats_sync(void* p2p, const float* y, int ld_y, const float* 
                               const float* invstd, const float* scale, const float* beta, int N, int H, int W, int C, int relu,
                               int pool, float* sums_local, float* sums_global, float* ws, size_t ws_floats, int timeout_ms,
                               void* stream);
+/* mnk_bn_small_bwd for one rank of a data-parallel run: the one-launch backward of a small norm layer (<= mnk_bn_small_rows()
+ * pixel rows per rank) with the exchange of its eight sums per channel quad inside -- statistics, exchange and apply in one
+ * launch, as on a single GPU.  count_all_ranks = pixel rows of ALL ranks; sums_local (2C) = this rank's own [sum g, sum g xhat]
+ * (its dbeta / dgamma contributions, averaged later with all other gradients: batchnorm.py:48-78 under DataParallel). */
+int mnk_bn_small_bwd_sync(void* p2p, const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,
+                          const float* scale, const float* beta, double count_all_ranks, int N, int H, int W, int C, int relu,
+                          int pool, float* sums_local, float* dy, int ld_dy, int timeout_ms, void* stream);
 int mnk_p2p_max_floats(void);
 int mnk_p2p_create(int rank, int world, void** handle_out);
 int mnk_p2p_export(void* handle, void* ipc_handle64);

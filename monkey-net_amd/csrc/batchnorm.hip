@@ -810,6 +810,76 @@ __global__ void __launch_bounds__(1024) bn_small_bwd_kernel(BwdLoader L, double 
     }
 }
 
+#ifndef HIPEMU
+// bn_small_bwd_kernel of one rank of a data-parallel run: ONE channel quad per block (256 threads over the rows); after the
+// block's own sums (= this rank's dbeta / dgamma contributions, written to `sums`) wave 0 exchanges the eight of them with every
+// rank of the node in one round trip (p2p_exchange_values) and the apply pass runs with the sums over all ranks -- statistics,
+// exchange and apply of a small layer in one launch, as on a single GPU (count = rows of ALL ranks).
+__global__ void __launch_bounds__(256) bn_small_bwd_sync_kernel(BwdLoader L, double count, int rows, int nv, float* __restrict__ sums,
+                                                                float* __restrict__ dy, int ld_dy, PeerTable peers, int rank,
+                                                                int world, unsigned* state, unsigned long long timeout_ticks) {
+    __shared__ float4 red0[256], red1[256];
+    __shared__ float glob[8];
+    const int ty = threadIdx.x, q = blockIdx.x;          // (tx_n = 1: q < nv for every block)
+    const unsigned seq = state[0] + 1;
+    const int slot = (int)(seq % P2P_SLOTS);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    BwdLoader::State st;
+    L.init(st);
+    for (int r = ty; r < rows; r += 256) {
+        float4 g, xh;
+        L.load(r, q, st, g, xh);
+        a = f4_add(a, g);
+        b = f4_fma(g, xh, b);
+    }
+    small_tree_sum2(red0, red1, a, b, 1, 256, 0, ty);
+    const int C = L.C, rem = C - q * 4;
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    if (ty == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (q * 4 + e < C) {
+                sums[q * 4 + e] = av[e];
+                sums[C + q * 4 + e] = bv[e];
+            }
+    }
+    if (ty < 64) {                                         // wave 0: value j = lane / W of {a.xyzw, b.xyzw}
+        const int W = world <= 8 ? 8 : 16, per = 64 / W;
+        for (int j0 = 0; j0 < 8; j0 += per) {
+            const int j = j0 + ty / W, e = j & 3, c = q * 4 + e;
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (e == k) v = j < 4 ? av[k] : bv[k];
+            const int index = (j < 8 && c < C) ? (j < 4 ? c : C + c) : -1;
+            const float all = p2p_exchange_values(peers, rank, world, slot, seq, index, v, state, timeout_ticks);
+            if ((ty & (W - 1)) == 0 && j < 8) glob[j] = all;
+        }
+    }
+    __syncthreads();
+    const float inv = (float)(1.0 / count);
+    const float4 k1 = make_float4(glob[0] * inv, glob[1] * inv, glob[2] * inv, glob[3] * inv),
+                 k2 = make_float4(glob[4] * inv, glob[5] * inv, glob[6] * inv, glob[7] * inv);
+    const float4 sc = ld4_guard(L.scale, q, C);
+    for (int r = ty; r < rows; r += 256) {
+        float4 g, xh;
+        L.load(r, q, st, g, xh);
+        float4 o;
+        o.x = sc.x * (g.x - k1.x - xh.x * k2.x);
+        o.y = sc.y * (g.y - k1.y - xh.y * k2.y);
+        o.z = sc.z * (g.z - k1.z - xh.z * k2.z);
+        o.w = sc.w * (g.w - k1.w - xh.w * k2.w);
+        if (rem < 4) {  // keep pad channels of dy at zero
+            if (rem < 2) o.y = 0.f;
+            if (rem < 3) o.z = 0.f;
+            o.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(dy + (long)r * ld_dy + q * 4) = o;
+    }
+    p2p_finish_launch(state, seq);
+}
+#endif
+
 static inline int small_txn(int nv) { return g_small_txn ? g_small_txn : (nv >= 128 ? 4 : (nv >= 64 ? 2 : 1)); }
 
 // launch shape of the two one-launch kernels: threads per block and channel quads per block (see g_small_fwd_threads)
@@ -1189,5 +1259,33 @@ int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const
     hipLaunchKernelGGL(bn_small_bwd_kernel, dim3(ceil_div(nv, txn)), dim3(threads), 0, s, L, count, N * H * W, nv, txn, sums, dy, ld_dy);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_bn_small_bwd_sync(void* p2p, const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,
+                          const float* scale, const float* beta, double count_all_ranks, int N, int H, int W, int C, int relu,
+                          int pool, float* sums_local, float* dy, int ld_dy, int timeout_ms, void* stream) {
+    MNK_REQUIRE(p2p && y && dz && mean && invstd && scale && beta && sums_local && dy && N > 0 && H > 0 && W > 0 && C > 0);
+    MNK_REQUIRE(count_all_ranks > 1 && timeout_ms > 0);
+    MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && ld_dy % 4 == 0 && ld_dy >= round_up(C, 4) && ld_dz >= C);
+    MNK_REQUIRE((long)N * H * W <= 4096 && (!pool || (H % 2 == 0 && W % 2 == 0)));
+#ifdef HIPEMU
+    return MNK_ECOMM;
+#else
+    PeerTable peers;
+    int rank = 0, world = 0;
+    unsigned* state = nullptr;
+    if (!p2p_launch_info(p2p, &peers, &rank, &world, &state) || 2 * C > P2P_MAXF) {
+        set_error("mnk_bn_small_bwd_sync: the peer-to-peer exchange is not connected, or more than %d channels", P2P_MAXF / 2);
+        return MNK_ECOMM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_BWD, s, (double)N * H * W * C * 4 * 5.0);
+    const int nv = round_up(C, 4) / 4;
+    BwdLoader L{y, dz, mean, invstd, scale, beta, ld_y, ld_dz, 0, H, W, C, pool, 0, relu ? 0.f : -1.f};
+    hipLaunchKernelGGL(bn_small_bwd_sync_kernel, dim3(nv), dim3(256), 0, s, L, count_all_ranks, N * H * W, nv, sums_local, dy, ld_dy,
+                       peers, rank, world, state, (unsigned long long)timeout_ms * 100000ull);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+#endif
 }
 }

@@ -57,6 +57,38 @@ __device__ __forceinline__ float p2p_exchange_value(const PeerTable& peers, int 
     return s;
 }
 
+// up to 64 / W values of exchange `seq` at once (W = 8 for up to eight ranks, else 16): lane l of the calling wave serves value
+// l / W and peer l % W -- one round trip for all of them (a kernel that owns a handful of columns, e.g. the one-launch small-layer
+// BatchNorm backward: 4 channels x 2 sums per block).  value / index: this lane's value j = l / W and its position in the
+// mailbox row (negative: nothing to exchange for this lane).  Returns, in every lane, the rank-ordered sum of ITS value j.
+__device__ __forceinline__ float p2p_exchange_values(const PeerTable& peers, int rank, int world, int slot, unsigned seq, int index,
+                                                     float value, unsigned* state, unsigned long long timeout_ticks) {
+    const int lane = threadIdx.x & 63;
+    const int W = world <= 8 ? 8 : 16, q = lane & (W - 1);
+    float got = 0.f;
+    if (q < world && index >= 0) {
+        __hip_atomic_store(row_of(peers.box[q], world, slot, rank) + index,
+                           ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(value), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long* w = row_of(peers.box[rank], world, slot, q) + index;
+        const unsigned long long t0 = wall_clock64();
+        unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        while ((unsigned)(v >> 32) != seq) {
+            if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+                __hip_atomic_store(state + 1, 1u + (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        got = __uint_as_float((unsigned)v);
+    }
+    float s = 0.f;
+    const int base = lane & ~(W - 1);
+    for (int r = 0; r < world; ++r) s += __shfl(got, base + r);
+    return s;
+}
+
 // the exchange's sequence number: every block reads state[0] + 1 when it starts; the LAST block to finish (ticket in state[2])
 // advances state[0] -- no block of the launch can still be waiting to read it then
 __device__ __forceinline__ void p2p_finish_launch(unsigned* state, unsigned seq) {

@@ -496,6 +496,11 @@ def repack_registered(only_if_stale=False):
 _SPLIT_PENDING = {}
 
 
+def _small_sync(rows):
+    """several ranks with the peer-to-peer exchange up: a small layer's backward is mnk_bn_small_bwd_sync (one launch)"""
+    return mdist.active() and 1 < rows <= _query("mnk_bn_small_rows") and _sync_handle() is not None
+
+
 def small_bn(rows, training=True):
     """the one-launch BatchNorm forms of small layers apply: single rank, training statistics, few pixel rows"""
     return (training and not mdist.active() and 1 < rows <= _query("mnk_bn_small_rows"))
@@ -699,8 +704,9 @@ class Conv3x3Fn(_Fn):
             # the source is the output of a norm layer (no pooling) and (presumably) has no other consumer: this launch also
             # leaves that layer's backward statistics (see _BN_OF); rows = the geometry both tensors share
             rec = ctx.src_bn[i]
-            if rec is not None and (rec.c != cc or rec.y.shape[-1] != ceil4(cc) or small_bn(rec.y.numel() // rec.y.shape[-1])):
-                rec = None
+            if rec is not None and (rec.c != cc or rec.y.shape[-1] != ceil4(cc) or small_bn(rec.y.numel() // rec.y.shape[-1])
+                                    or _small_sync(rec.y.numel() // rec.y.shape[-1])):
+                rec = None               # (small layers make their backward statistics inside their own one-launch kernel)
             if ctx.up:
                 # data gradient w.r.t. the low-resolution source: one 4x4 / stride 2 convolution over dy (no gradient of
                 # the up-sampled view, no 2x2 sum-pool pass)
@@ -952,11 +958,26 @@ class BNActFn(_Fn):
             else:
                 _DY_SUMS[0] = (dy, None)
             return dy, sums[c:], sums[:c], None, None, None, None, None, None, None, None, None
+        sync = _sync_handle() if training else None      # several ranks: the second stage carries the exchange of the sums
+        if (sync is not None and _small_sync(rows) and ld == ceil4(c) and 2 * c <= mdist._P2P["max"]
+                and (not pool or (h % 2 == 0 and w % 2 == 0))):
+            # a small layer on one rank of several: statistics, their exchange and the apply pass in ONE launch, as the
+            # single-process path does it (mnk_bn_small_bwd) -- the general path spends three to four launches here
+            _DZ_STATS.pop(dz.data_ptr(), None)
+            local = torch.empty(2 * c, dtype=torch.float32, device=y.device)
+            dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
+            _call("mnk_bn_small_bwd_sync", y, sync, _p(y), ld, _p(dz), dz.shape[-1], _p(mean), _p(invstd), _p(scale), _p(beta),
+                  count, n, h, w, c, int(relu), int(pool), _p(local), _p(dy), ld, mdist.P2P_TIMEOUT_MS)
+            if dskip is not None:
+                dy = dy + dskip
+                _DY_SUMS[0] = None
+            else:
+                _DY_SUMS[0] = (dy, None)
+            return dy, local[c:], local[:c], None, None, None, None, None, None, None, None, None
         nws = _query("mnk_bn_workspace_floats", rows, ceil4(c))
         ws = SCRATCH.get("ws", nws, y)
         sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
         pre = _DZ_STATS.pop(dz.data_ptr(), None)
-        sync = _sync_handle() if training else None      # several ranks: the second stage carries the exchange of the sums
         local = torch.empty(2 * c, dtype=torch.float32, device=y.device) if sync is not None else sums
         if pre is not None and pre[0].shape == dz.shape and pre[3] == y.data_ptr() and not pool:
             # this gradient is the data-gradient GEMM's own output: its epilogue left the statistics' first stage

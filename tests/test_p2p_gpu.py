@@ -80,6 +80,43 @@ def _worker(rank, world, port, out_dir):
         torch.cuda.synchronize()
         assert torch.equal(glo.cpu(), want), ("synchronised second stage", it, float((glo.cpu() - want).abs().max()))
     assert mdist.p2p_error() == 0
+    # ---- the one-launch backward of a small norm layer with the exchange inside (mnk_bn_small_bwd_sync): this rank's sums are
+    # mnk_bn_small_bwd's of its shard, bit for bit; dy is the apply pass with the rank-ordered sum of all ranks' sums
+    for it, (nn, hh, ww, c, relu, pool) in enumerate(((8, 4, 4, 256, 1, 0), (4, 8, 8, 45, 1, 0), (16, 2, 2, 1024, 1, 1), (6, 4, 4, 10, 0, 0))):
+        ld = (c + 3) // 4 * 4
+        gen = torch.Generator().manual_seed(9000 + it)
+        meanv, invs = torch.randn(c, generator=gen).to(dev), (torch.rand(c, generator=gen) + 0.5).to(dev)
+        scl, bet = (torch.randn(c, generator=gen) * invs.cpu()).to(dev), torch.randn(c, generator=gen).to(dev)
+        ys, dzs = [], []
+        for q in range(world):
+            g2 = torch.Generator().manual_seed(9100 + 10 * it + q)
+            yq = torch.zeros(nn, hh, ww, ld)
+            yq[..., :c] = torch.randn(nn, hh, ww, c, generator=g2)
+            ho, wo = (hh // 2, ww // 2) if pool else (hh, ww)
+            dq = torch.zeros(nn, ho, wo, ld)
+            dq[..., :c] = torch.randn(nn, ho, wo, c, generator=g2)
+            ys.append(yq.to(dev)), dzs.append(dq.to(dev))
+        rows = nn * hh * ww
+        count = float(rows * world)
+        loc, dyv = torch.empty(2 * c, device=dev), torch.empty(nn, hh, ww, ld, device=dev)
+        lib.call("mnk_bn_small_bwd_sync", hp, ys[rank].data_ptr(), ld, dzs[rank].data_ptr(), ld, meanv.data_ptr(), invs.data_ptr(),
+                 scl.data_ptr(), bet.data_ptr(), count, nn, hh, ww, c, relu, pool, loc.data_ptr(), dyv.data_ptr(), ld, 4000, st)
+        tot = torch.zeros(2 * c)
+        for q in range(world):
+            one, tmp = torch.empty(2 * c, device=dev), torch.empty(nn, hh, ww, ld, device=dev)
+            lib.call("mnk_bn_small_bwd", ys[q].data_ptr(), ld, dzs[q].data_ptr(), ld, meanv.data_ptr(), invs.data_ptr(),
+                     scl.data_ptr(), bet.data_ptr(), float(rows), nn, hh, ww, c, relu, pool, one.data_ptr(), tmp.data_ptr(), ld, st)
+            torch.cuda.synchronize()
+            if q == rank:
+                assert torch.equal(one.cpu(), loc.cpu()), "local sums of the synchronised small-layer backward"
+            tot = tot + one.cpu()
+        want, totd = torch.empty(nn, hh, ww, ld, device=dev), tot.to(dev)
+        lib.call("mnk_bn_act_bwd_apply", ys[rank].data_ptr(), ld, dzs[rank].data_ptr(), ld, 0, meanv.data_ptr(), invs.data_ptr(),
+                 scl.data_ptr(), bet.data_ptr(), totd.data_ptr(), count, 1, want.data_ptr(), ld, nn, hh, ww, c, relu, pool, st)
+        torch.cuda.synchronize()
+        err = float((dyv - want).abs().max() / (want.abs().max() + 1e-30))
+        assert err < 1e-6, ("synchronised small-layer backward", it, err)
+    assert mdist.p2p_error() == 0
     # ---- captured: three exchanges in a hipGraph, replayed with new inputs (the sequence counter advances on the device)
     n = 530
     a, b = torch.zeros(n, device=dev), torch.zeros(2 * n, device=dev)
