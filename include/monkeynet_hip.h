@@ -224,23 +224,6 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
                     const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W,
                     int Cout, float* ws, size_t ws_floats, float* stats_partial, void* stream);
 /* dw[co][c_start+ci][ky][kx] = sum_pixels dy[p][co] * x[p+tap][ci]; x is one source (C channels) */
-/* mnk_conv3x3_fwd with the training-mode BatchNorm + ReLU behind it INSIDE the launch (util.py:52-66,79-87: conv -> norm ->
- * relu): the GEMM's epilogue publishes its column partials, one block per channel finishes the statistics (mean, inverse standard
- * deviation, scale, running statistics: batchnorm.py:113-125) and every block applies them to the tile it still holds -- y (the
- * convolution's output, kept for the backward pass) AND act = relu((y - mean) * scale + beta) come out of one launch instead of
- * three.  Fence-free in-kernel reduction over {generation | float} words in fn_ws (mnk_fused_norm_workspace_bytes(), zeroed ONCE
- * by the caller and kept: the generations live in it); needs every block of the launch resident, which the library checks per
- * launch: *fused_out = 1 when the fused form ran, 0 when the shape does not allow it -- then y and stats_partial are what
- * mnk_conv3x3_fwd leaves and the caller runs the norm layer's own launches.  A wait that gives up after timeout_ms raises the
- * workspace's error word (mnk_fused_norm_error; it synchronises). */
-size_t mnk_fused_norm_workspace_bytes(void);
-int mnk_conv3x3_fwd_norm(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp,
-                         const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W, int Cout,
-                         float* ws, size_t ws_floats, float* stats_partial, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float momentum, float eps, int relu, float* mean, float* invstd,
-                         float* scale, float* act, int ld_act, void* fn_ws, size_t fn_ws_bytes, int timeout_ms, int* fused_out,
-                         void* stream);
-int mnk_fused_norm_error(const void* fn_ws, int* flag_out);
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout);
 int mnk_conv3x3_wgrad(const float* x, int ld_x, int C, int flags, const float* dy, int ld_dy, int Cout, float* dw,
                       int Cin_total, int c_start, int N, int H, int W, float* ws, size_t ws_floats, void* stream);

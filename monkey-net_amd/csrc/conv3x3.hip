@@ -53,31 +53,6 @@ struct BnBwdSrc {
     float slope;
 };
 
-// conv -> training-mode BatchNorm -> activation in ONE launch (forward; the producing GEMM's epilogue finishes the statistics and
-// applies them): every block publishes its column partials as {generation | float} words (device-scope relaxed atomic stores),
-// the block whose linear tile index equals a channel number reduces that channel (both columns, all row tiles, fixed order),
-// finalises it and publishes {generation | mean}, {generation | scale}; every block polls the words of its columns and applies
-// them to the tile it still holds in registers.  No fence, no atomic counter, no grid barrier -- but every block of the launch
-// must be RESIDENT (a block waits for blocks that must be running): the host checks the grid against the occupancy of the
-// kernel.  The generation of a column is whatever its total word carries when the launch starts, plus one (read by every block
-// before it publishes anything: no reducer can have advanced it yet), so a captured launch replays without host values.
-// tools/microbench/grid_reduce.hip: +5 ... 7 us per 1 024-block launch, against the two launches (10 - 21 us) it replaces.
-// phase: -1 = the whole protocol (device); the block-sequential test emulator runs it as three launches (0: publish,
-// 1: reducers only, 2: apply -- the tile is recomputed).
-struct FusedNorm {
-    unsigned long long* part;        // [row tiles][2][ldc] words
-    unsigned long long* tot;         // [2][cmax] words: {gen | mean}, {gen | scale}
-    int ldc, cmax, phase, dbg, nap;  // nap: pauses of 512 cycles between two polling rounds of a reducer;       // dbg: timing experiments only (1: no act store, 2: no wait for totals, 4: no reducers)
-    const float *gamma, *beta;
-    float *running_mean, *running_var, *mean, *invstd, *scale;
-    double count;
-    float momentum, eps, slope;
-    float* act;                      // the activated output (same geometry as y)
-    int ld_act;
-    unsigned* err;                   // device word: set when a wait gave up
-    unsigned long long timeout_ticks;
-};
-
 struct ConvArgs {
     const float* x0;
     const float* x1;
@@ -117,113 +92,7 @@ struct ConvArgs {
     int phases, tiles_per_phase;
     long phase_wstride;
     BnBwdSrc bnb;
-    FusedNorm fn;
 };
-
-__device__ __forceinline__ unsigned long long fn_wait(const unsigned long long* w, unsigned gen, const FusedNorm& f) {
-    unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifndef HIPEMU
-    const unsigned long long t0 = wall_clock64();
-    while ((unsigned)(v >> 32) != gen) {
-        if ((unsigned long long)wall_clock64() - t0 > f.timeout_ticks) {
-            __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-        for (int k = 0; k < f.nap; ++k) __builtin_amdgcn_s_sleep(8);
-        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#else
-    if ((unsigned)(v >> 32) != gen) *f.err = 2u;          // the emulator's phases run in order: the word must be there
-#endif
-    return v;
-}
-
-// the reducer of channel c (one block, 256 threads): sums of both columns over the row tiles in a fixed order, the layer's
-// mean / inverse standard deviation / scale and running statistics (bn_finalize_kernel's arithmetic), the two total words
-__device__ __forceinline__ void fn_reduce_channel(const FusedNorm& f, int c, int row_tiles, unsigned gen, double* sm /* [2][256] */) {
-    const int t = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r0 = 0; r0 < row_tiles; r0 += 256 * 4) {
-        // this thread's (up to) eight words of the trip: ALL of them are (re)loaded together until the last one carries the
-        // generation -- a device-scope load is a round trip to memory (1 - 2 us), and polling the words one after the other made
-        // the reducer's tail eight round trips long (13 us per launch, tools/fn_time.py)
-        unsigned long long v[2][4];
-        const unsigned long long ready = (unsigned long long)gen << 32;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            v[0][u] = v[1][u] = ready + 1;                 // (rows beyond the grid: "ready", value bits irrelevant -> masked below)
-        bool all = false;
-#ifndef HIPEMU
-        const unsigned long long t0 = wall_clock64();
-#endif
-        while (!all) {
-            all = true;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * 256 + t;
-                if (r < row_tiles) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        v[h][u] = __hip_atomic_load(f.part + ((size_t)r * 2 + h) * f.ldc + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    if ((unsigned)(v[h][u] >> 32) != gen) all = false;
-#ifndef HIPEMU
-            if (!all) {
-                if ((unsigned long long)wall_clock64() - t0 > f.timeout_ticks) {
-                    __hip_atomic_store(f.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                for (int k = 0; k < f.nap; ++k) __builtin_amdgcn_s_sleep(8);
-            }
-#else
-            if (!all) {
-                *f.err = 2u;
-                break;
-            }
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + u * 256 + t;
-            if (r < row_tiles) {
-                s1 += (double)__uint_as_float((unsigned)v[0][u]);
-                s2 += (double)__uint_as_float((unsigned)v[1][u]);
-            }
-        }
-    }
-    sm[t] = s1;
-    sm[256 + t] = s2;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (t < k) {
-            sm[t] += sm[t + k];
-            sm[256 + t] += sm[256 + t + k];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const float s1f = (float)sm[0], s2f = (float)sm[256];       // (the unfused path's sums round-trip through fp32 too)
-        const double m = (double)s1f / f.count;
-        double var = (double)s2f / f.count - m * m;
-        if (var < 0.0) var = 0.0;
-        const float mf = (float)m, is = 1.0f / sqrtf((float)var + f.eps), sc = f.gamma[c] * is;
-        f.mean[c] = mf;
-        f.invstd[c] = is;
-        f.scale[c] = sc;
-        const float unbiased = (float)(var * f.count / (f.count - 1.0));
-        f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mf;
-        f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
-        __hip_atomic_store(f.tot + c, ((unsigned long long)gen << 32) | __float_as_uint(mf), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(f.tot + f.cmax + c, ((unsigned long long)gen << 32) | __float_as_uint(sc), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-}
 
 // buffer resource from values the compiler cannot prove wave-uniform (e.g. derived from a 64-bit division): pin the
 // pointer into scalar registers, otherwise every buffer load becomes a readfirstlane "waterfall" loop
@@ -874,27 +743,6 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     const int s_begin = split * a.ksteps_per_split;
     int s_end = s_begin + a.ksteps_per_split;
     if (s_end > a.ksteps) s_end = a.ksteps;
-    // ---- conv -> BatchNorm -> activation in this launch (FusedNorm): the generation of this block's columns, and of the channel
-    // this block reduces (linear tile index = channel number), read before anything of this launch can have been published
-    __shared__ unsigned fn_gen[BN];
-    __shared__ float fn_mean[BN], fn_scale[BN];
-    const bool fused = a.fn.part != nullptr;
-    const int fph = fused ? a.fn.phase : -1;
-    const int tile_lin = by * (int)gridDim.x + bx;
-    unsigned fn_gen_red = 0;
-    if (fused) {
-        const unsigned step = fph == 2 ? 0u : 1u;
-        if (t < BN) {
-            const int col = n0 + t < a.fn.cmax ? n0 + t : a.fn.cmax - 1;
-            fn_gen[t] = (unsigned)(__hip_atomic_load(a.fn.tot + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + step;
-        }
-        if (tile_lin < a.Cout)
-            fn_gen_red = (unsigned)(__hip_atomic_load(a.fn.tot + tile_lin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) + step;
-        if (fph == 1) {                      // (emulator) reducers only
-            if (tile_lin < a.Cout) fn_reduce_channel(a.fn, tile_lin, (int)gridDim.x, fn_gen_red, reinterpret_cast<double*>(&As[0][0][0]));
-            return;
-        }
-    }
     const int lrow = t >> 2, lq = t & 3;
     typename LoaderSel<RA, MODE>::type L;
     L.setup(a, m0, lrow, lq, s_begin, a.pad, a.pad_x < 0 ? a.pad : a.pad_x);
@@ -1004,7 +852,6 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[i][j][r];
                         if (!split_out) v = c_real ? (v + bv) + rv[r] : 0.f;
-                        acc[i][j][r] = v;                     // (kept: the fused norm layer applies its constants to it below)
                         if (FULL || mb + r < Mu) {
                             obase[off0 + r * ldo] = v;
                             if (bnb) {
@@ -1027,7 +874,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
         emit(TrueTag{});
     else
         emit(FalseTag{});
-    if ((a.stats || fused) && !split_out) {
+    if (a.stats && !split_out) {
         float* red = &As[0][0][0];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1048,57 +895,9 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
                 t1 += red[(w * 2 + 0) * BN + t];
                 t2 += red[(w * 2 + 1) * BN + t];
             }
-            if (a.stats) {
-                float* sp = a.stats + (long)bx * 2 * a.ld_y;
-                sp[n0 + t] = t1;
-                sp[a.ld_y + n0 + t] = t2;
-            }
-            if (fused && fph != 2 && n0 + t < a.fn.ldc) {        // publish this row tile's partials of column n0 + t
-                unsigned long long* w = a.fn.part + (size_t)bx * 2 * a.fn.ldc + n0 + t;
-                const unsigned long long g = (unsigned long long)fn_gen[t] << 32;
-                __hip_atomic_store(w, g | __float_as_uint(t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(w + a.fn.ldc, g | __float_as_uint(t2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    if (fused && fph != 0) {
-        __syncthreads();                      // (the statistics' LDS region is free again)
-        if (fph == -1 && tile_lin < a.Cout && !(a.fn.dbg & 4))
-            fn_reduce_channel(a.fn, tile_lin, (int)gridDim.x, fn_gen_red, reinterpret_cast<double*>(&As[0][0][0]));
-        if (t < BN) {
-            const int col = n0 + t;
-            float mv = 0.f, sv = 0.f;
-            if (col < a.Cout && !(a.fn.dbg & 2)) {
-                mv = __uint_as_float((unsigned)fn_wait(a.fn.tot + col, fn_gen[t], a.fn));
-                sv = __uint_as_float((unsigned)fn_wait(a.fn.tot + a.fn.cmax + col, fn_gen[t], a.fn));
-            }
-            fn_mean[t] = mv;
-            fn_scale[t] = sv;
-        }
-        __syncthreads();
-        // act = activation((v - mean) * scale + beta): bn_act_fwd_kernel's arithmetic on the tile still in registers
-        const unsigned lda = (unsigned)a.fn.ld_act;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + 16 * j + fi;
-            const bool c_real = co < a.Cout;
-            if (co < a.fn.ld_act) {
-                const float mv = fn_mean[16 * j + fi], sv = fn_scale[16 * j + fi], be = c_real ? a.fn.beta[co] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const unsigned mb = mrow0 + 16 * i;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (full || mb + r < Mu) {
-                            float o = 0.f;
-                            if (c_real) {
-                                o = fmaf(acc[i][j][r] - mv, sv, be);
-                                if (a.fn.slope >= 0.f && !(o > 0.f)) o *= a.fn.slope;
-                            }
-                            if (!(a.fn.dbg & 1)) a.fn.act[(mb + r) * lda + (unsigned)co] = o;
-                        }
-                }
-            }
+            float* sp = a.stats + (long)bx * 2 * a.ld_y;
+            sp[n0 + t] = t1;
+            sp[a.ld_y + n0 + t] = t2;
         }
     }
 }
@@ -3036,43 +2835,11 @@ size_t mnk_conv2d_stats_floats(int N, int Ho, int Wo, int C0, int C1, int Cout, 
 //   phases == 1: Ho x Wo outputs, input pixel of output (h, w), tap (ky, kx) = (h * stride + ky - pad, w * stride + kx - pad)
 //   phases == 4: the sub-pixel form of [nearest x2 -> 3x3 / pad 1] (ConvArgs): kh = kw = 2, pad = 1, (Hi, Wi) = (Ho, Wo) =
 //                the LOW resolution; y is the (N, 2 Ho, 2 Wo) tensor; wp = four per-phase packs
-// ---- FusedNorm host side -----------------------------------------------------------------------------------------------------
-constexpr int FN_CMAX = 256, FN_ROWS = 2048;     // channels / row tiles the caller's persistent workspace is laid out for
-static int g_fused_norm = tuning_knob("fused_norm", &g_fused_norm, 1), g_fused_norm_dbg = tuning_knob("fused_norm_dbg", &g_fused_norm_dbg, 0),
-           g_fused_norm_nap = tuning_knob("fused_norm_nap", &g_fused_norm_nap, 4);
-// workspace (caller-owned, zero-initialised ONCE, persistent: the columns' generations live in it):
-//   [2 * FN_CMAX total words][8 bytes: error word][FN_ROWS * 2 * FN_CMAX partial words]
-static size_t fused_norm_ws_bytes() { return ((size_t)2 * FN_CMAX + 1 + (size_t)FN_ROWS * 2 * FN_CMAX) * 8; }
-// every block of `grid` resident at once for this kernel?  (a block of a FusedNorm launch waits for other blocks)
-static bool fn_resident(const void* kernel, dim3 grid) {
-#ifdef HIPEMU
-    return true;
-#else
-    static std::vector<std::pair<const void*, long>> cache;
-    long cap = -1;
-    for (auto& e : cache)
-        if (e.first == kernel) cap = e.second;
-    if (cap < 0) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess)
-            cap = 0;
-        else
-            cap = (long)per_cu * prop.multiProcessorCount;
-        cache.push_back({kernel, cap});
-    }
-    return (long)grid.x * grid.y * grid.z <= cap;
-#endif
-}
-
 static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, int Hi, int Wi, int kh,
                            int kw, int pad, int stride, int phases, const float* wp, const float* bias, const float* residual,
                            int ld_res, float* y, int ld_y, int N, int Ho, int Wo, int Cout, float* ws, size_t ws_floats,
-                           float* stats_partial, void* stream, const BnBwdSrc* bnb = nullptr, const FusedNorm* fn = nullptr,
-                           int* fused_out = nullptr) {
+                           float* stats_partial, void* stream, const BnBwdSrc* bnb = nullptr) {
     MNK_REQUIRE(flags >= 0 && flags <= 7);
-    if (fused_out) *fused_out = 0;
     const int ups = flags & MNK_CONV_UPSAMPLED, clean = (flags & MNK_CONV_CLEAN_PADS) ? 1 : 0;
     // MNK_CONV_DEFER_SPLITK: a split-K launch leaves its partials in `ws` ([split][phase][M][ldw], bias not added) and the
     // caller sums them (mnk_bn_small_fwd does, together with the normalisation that follows)
@@ -3134,12 +2901,6 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
     a.ldw = p.ldw;
     a.stats = stats_partial;
     a.bnb = bnb ? *bnb : BnBwdSrc{};
-    a.fn = FusedNorm{};
-    // the norm layer behind this convolution inside the launch (FusedNorm): the 16x16-tile kernels, no split, no sub-pixel
-    // form, at most FN_ROWS row tiles and FN_CMAX channels -- and (checked per kernel below) every block resident
-    if (fn && g_fused_norm && p.splits == 1 && phases == 1 && (p.bn == 16 || p.bn == 48) && p.gn == 1 && p.gm <= FN_ROWS &&
-        Cout <= FN_CMAX && Cout <= p.gm && fn->count > 1.0 && ld_y == round_up(Cout, 4) && fn->ld_act == ld_y)
-        a.fn = *fn, a.fn.dbg = g_fused_norm_dbg, a.fn.nap = g_fused_norm_nap;
     MNK_REQUIRE(!bnb || (stats_partial && bnb->y && bnb->mean && bnb->invstd && bnb->scale && bnb->beta && bnb->ld >= Cout &&
                          phases == 1 && !defer_splitk));
     a.xcd = g_xcd_remap;
@@ -3180,23 +2941,8 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
         // dispatcher already puts 1024 blocks on 256 CUs four by four -- tools/microbench/launch_gap.hip (e) -- and the step did
         // not move, 10.33 vs 10.32 ms: removed.  profiles/r04_knob_ab_log.txt)
         const unsigned dyn = 0;
-#ifdef HIPEMU
-#define MNK_FN_PHASES(KERNEL, MODE, ...)                                                                         \
-    if (a.fn.part) {                       /* the block-sequential emulator: publish, reduce, apply as three launches */ \
-        for (int ph = 0; ph < 3; ++ph) {                                                                         \
-            a.fn.phase = ph;                                                                                     \
-            hipLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, a);                         \
-        }                                                                                                        \
-        break;                                                                                                   \
-    }
-#else
-#define MNK_FN_PHASES(KERNEL, MODE, ...)
-#endif
 #define MNK_IGEMM_MODE(KERNEL, MODE, ...)                                                                       \
     do {                                                                                                        \
-        if (a.fn.part && !fn_resident((const void*)(KERNEL<__VA_ARGS__, MODE>), grid)) a.fn = FusedNorm{};      \
-        if (a.fn.part && fused_out) *fused_out = 1;                                                             \
-        MNK_FN_PHASES(KERNEL, MODE, __VA_ARGS__)                                                                \
         if (timed) hipExtLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, ev0, ev1, 0, a); \
         else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, a);                       \
     } while (0)
@@ -3223,7 +2969,6 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
             MNK_IGEMM(conv3x3_igemm_kernel, 128, 32, 4, 1);
 #undef MNK_IGEMM
 #undef MNK_IGEMM_MODE
-#undef MNK_FN_PHASES
     }
     if (p.splits > 1 && !defer_splitk) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);
@@ -4000,46 +3745,6 @@ int mnk_conv3x3_fwd(const float* x0, int ld0, int C0, const float* x1, int ld1, 
     return mnk_conv2d_fwd(x0, ld0, C0, x1, ld1, C1, flags, H, W, 3, 3, 1, wp, bias, residual, ld_res, y, ld_y, N, H, W, Cout,
                           ws, ws_floats, stats_partial, stream);
 }
-size_t mnk_fused_norm_workspace_bytes(void) { return fused_norm_ws_bytes(); }
-
-int mnk_conv3x3_fwd_norm(const float* x0, int ld0, int C0, const float* x1, int ld1, int C1, int flags, const float* wp,
-                         const float* bias, const float* residual, int ld_res, float* y, int ld_y, int N, int H, int W, int Cout,
-                         float* ws, size_t ws_floats, float* stats_partial, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float momentum, float eps, int relu, float* mean, float* invstd,
-                         float* scale, float* act, int ld_act, void* fn_ws, size_t fn_ws_bytes, int timeout_ms, int* fused_out,
-                         void* stream) {
-    MNK_REQUIRE(gamma && beta && running_mean && running_var && mean && invstd && scale && act && fn_ws && fused_out);
-    MNK_REQUIRE(fn_ws_bytes >= fused_norm_ws_bytes() && ((size_t)fn_ws % 8) == 0 && timeout_ms > 0 && stats_partial);
-    FusedNorm f{};
-    unsigned long long* w = (unsigned long long*)fn_ws;
-    f.tot = w;
-    f.err = (unsigned*)(w + 2 * FN_CMAX);
-    f.part = w + 2 * FN_CMAX + 1;
-    f.ldc = FN_CMAX;
-    f.cmax = FN_CMAX;
-    f.phase = -1;
-    f.gamma = gamma, f.beta = beta, f.running_mean = running_mean, f.running_var = running_var;
-    f.mean = mean, f.invstd = invstd, f.scale = scale;
-    f.count = (double)N * H * W;
-    f.momentum = momentum, f.eps = eps, f.slope = relu ? 0.f : -1.f;
-    f.act = act, f.ld_act = ld_act;
-    f.timeout_ticks = (unsigned long long)timeout_ms * 100000ull;
-    return conv2d_fwd_impl(x0, ld0, C0, x1, ld1, C1, flags, H, W, 3, 3, 1, 1, 1, wp, bias, residual, ld_res, y, ld_y, N, H, W, Cout,
-                           ws, ws_floats, stats_partial, stream, nullptr, &f, fused_out);
-}
-
-int mnk_fused_norm_error(const void* fn_ws, int* flag_out) {
-    MNK_REQUIRE(fn_ws && flag_out);
-    unsigned v = 0;
-#ifdef HIPEMU
-    v = *(const unsigned*)((const unsigned long long*)fn_ws + 2 * FN_CMAX);
-#else
-    if (hipMemcpy(&v, (const unsigned long long*)fn_ws + 2 * FN_CMAX, 4, hipMemcpyDeviceToHost) != hipSuccess) return MNK_ELAUNCH;
-#endif
-    *flag_out = (int)v;
-    return MNK_OK;
-}
-
 size_t mnk_conv3x3_wgrad_workspace_floats(int N, int H, int W, int C, int Cout) {
     return mnk_conv2d_wgrad_workspace_floats(N, H, W, C, Cout, 3, 3, 1);
 }

@@ -495,33 +495,6 @@ def repack_registered(only_if_stale=False):
 # a split-K convolution whose partials a small-layer BatchNorm will sum: y.data_ptr() -> (ws, splits, phases, bias)
 _SPLIT_PENDING = {}
 
-# conv -> norm -> ReLU in one launch (mnk_conv3x3_fwd_norm): conv3x3(norm=...) leaves the layer here for _conv_launch, which
-# leaves the layer's result for the bn_act() that follows: y.data_ptr() -> (y, act, mean, invstd, scale, id(norm.running_mean))
-_FUSE_NORM = [None]
-_FUSED_NORM = {}
-_FN_WS = {}                   # device -> the persistent workspace of the in-kernel reductions (their generations live in it)
-FUSED_NORM_COUNT = [0, 0]     # launches that took the fused form / that were offered a layer and declined (tests)
-
-
-def _fn_workspace(dev):
-    ws = _FN_WS.get(dev)
-    if ws is None:
-        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            return None                     # (first use inside a capture: the eager warm-up iterations come first in TrainStep)
-        ws = _FN_WS[dev] = torch.zeros((_query("mnk_fused_norm_workspace_bytes") + 7) // 8, dtype=torch.int64, device=dev)
-    return ws
-
-
-def fused_norm_error():
-    """non-zero: an in-kernel reduction of a fused conv + norm launch gave up waiting (synchronises)"""
-    import numpy as _np
-    worst = 0
-    for ws in _FN_WS.values():
-        flag = _np.zeros(1, dtype=_np.int32)
-        _lib.lib().call("mnk_fused_norm_error", ws.data_ptr(), flag.ctypes.data)
-        worst = max(worst, int(flag[0]))
-    return worst
-
 
 def _small_sync(rows):
     """several ranks with the peer-to-peer exchange up: a small layer's backward is mnk_bn_small_bwd_sync (one launch)"""
@@ -569,34 +542,11 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
         nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats and not small else 0
         st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None   # lives until the norm layer reads it
         defer = 4 if small and nws else 0
-        norm, _FUSE_NORM[0] = _FUSE_NORM[0], None
-        fnws = _fn_workspace(x0.device) if (norm is not None and nst and not defer and not mdist.active()) else None
-        done = False
-        if fnws is not None:
-            # the norm layer (+ ReLU) behind this convolution inside its launch; the library declines shapes it cannot run
-            # that way (*fused = 0: y and st are then what mnk_conv3x3_fwd leaves)
-            import numpy as _np
-            act = torch.empty_like(y)
-            mean = torch.empty(cout, dtype=torch.float32, device=x0.device)
-            invstd, scale = torch.empty_like(mean), torch.empty_like(mean)
-            fused = _np.zeros(1, dtype=_np.int32)
-            _call("mnk_conv3x3_fwd_norm", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
-                  int(ups) | 2, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
-                  y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st), _p(norm.weight), _p(norm.bias), _p(norm.running_mean),
-                  _p(norm.running_var), float(norm.momentum), float(norm.eps), 1, _p(mean), _p(invstd), _p(scale), _p(act),
-                  act.shape[-1], fnws.data_ptr(), fnws.numel() * 8, 2000, fused.ctypes.data)
-            done = True
-            if int(fused[0]):
-                _FUSED_NORM[y.data_ptr()] = (y, act, mean, invstd, scale, id(norm.running_mean))
-                FUSED_NORM_COUNT[0] += 1
-            else:
-                FUSED_NORM_COUNT[1] += 1
         # flags: bit 0 = nearest x2 up-sampled view, bit 1 = MNK_CONV_CLEAN_PADS -- every act this module produces has zero
         # pad channels (tests/test_modules.py::test_pad_channels_are_written pins that), so the fast 3x3 loader applies
-        if not done:
-            _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
-                  int(ups) | 2 | defer, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
-                  y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
+        _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
+              int(ups) | 2 | defer, _p(wp), _p(bias), _p(residual), residual.shape[-1] if residual is not None else 0, _p(y),
+              y.shape[-1], n, h, w, cout, _p(ws), nws, _p(st))
         if defer:
             _SPLIT_PENDING[y.data_ptr()] = (ws, _query("mnk_conv3x3_splits", n, h, w, c0, c1, cout), 1, bias)
     if small:
@@ -855,22 +805,17 @@ class Conv3x3SkipFn(_Fn):
         return Conv3x3Fn._backward(ctx, dy, dskip)
 
 
-def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False, skip=False, norm=None):
+def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False, skip=False):
     """-> (y, sums): sums = fused BatchNorm statistics [sum, sum of squares] of y when want_stats, else None.
-    skip: -> (y, sums, x0 handed through for x0's other consumer), see Conv3x3SkipFn.
-    norm: the training-mode norm layer (+ ReLU, no pooling) that the caller applies to y next (bn_act): where the launch
-    allows it, that layer runs INSIDE the convolution's launch (mnk_conv3x3_fwd_norm) and bn_act() finds its result."""
+    skip: -> (y, sums, x0 handed through for x0's other consumer), see Conv3x3SkipFn."""
     track = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x0, x1, weight, bias, residual))
-    _FUSE_NORM[0] = norm if (norm is not None and want_stats and norm.training and knobs.form("FUSED_NORM")) else None
     if track:       # the norm layers whose outputs the sources are (see _BN_OF): picked up by Conv3x3Fn.forward
         _SRC_BN[0] = (_bn_of(x0), _bn_of(x1))
     if skip and track and x0.requires_grad and knobs.form("SKIP_GRAD_FUSED"):
         y, sums, through = Conv3x3SkipFn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
-        _FUSE_NORM[0] = None
         return y, (sums if want_stats else None), through
     y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
-    _FUSE_NORM[0] = None
     return (y, (sums if want_stats else None), x0) if skip else (y, (sums if want_stats else None))
 
 
@@ -926,16 +871,6 @@ class BNActFn(_Fn):
         count = float(rows)
         pending = _SPLIT_PENDING.pop(y.data_ptr(), None)
         ctx.small = False
-        fz = _FUSED_NORM.pop(y.data_ptr(), None)
-        if fz is not None and fz[0] is y and training and relu and not pool and fz[5] == id(running_mean):
-            # this layer already ran inside the convolution's launch (mnk_conv3x3_fwd_norm): statistics, running statistics,
-            # mean / inv-std / scale and the activated output are all there
-            _, z, mean, invstd, scale, _ = fz
-            ctx.save_for_backward(y, mean, invstd, scale, beta)
-            ctx.meta = (c, training, relu, pool, count)
-            if ld == z.shape[-1] and knobs.form("DGRAD_BN_STATS"):
-                _LAST_BN[0] = _BnRecord(y, mean, invstd, scale, beta, c, 0.0)
-            return z
         if small_bn(rows, training) and ld == ceil4(c) and h % (2 if pool else 1) == 0 and w % (2 if pool else 1) == 0:
             # the whole layer in one launch (csrc/batchnorm.hip: bn_small_fwd_kernel)
             ho, wo = (h // 2, w // 2) if pool else (h, w)

@@ -89,8 +89,7 @@ class MotionTransferGenerator(nn.Module):
                 last = block
             else:     # hand the output statistics of each block to the next block's norm1 (fused in the conv epilogue)
                 more = idx + 1 < len(blocks) and blocks[idx + 1][0] != 'conv-last' and block.training
-                res = block.forward_act(out, c, x_sums=sums, want_stats=more,
-                                        next_norm=blocks[idx + 1][1].norm1 if more else None)
+                res = block.forward_act(out, c, x_sums=sums, want_stats=more)
                 out, c = res[0], res[1]
                 sums = res[2] if more else None
         video_prediction = ops.Conv1x1SigmoidFn.apply(out, last.weight, last.bias, c, b)

@@ -95,16 +95,15 @@ class ResBlock3D(nn.Module):
         self.norm2 = BatchNorm3d(in_features, affine=True)
         self.in_features = in_features
 
-    def forward_act(self, x, c, x_sums=None, want_stats=False, next_norm=None):
+    def forward_act(self, x, c, x_sums=None, want_stats=False):
         """x_sums: BatchNorm statistics of x from the producing conv epilogue; want_stats: also return those of the
         output (the next block's norm1 consumes them).  Returns (out, c[, out_sums])."""
         # skip=True: x comes back from the norm node, so that node alone consumes the block's input and adds the gradient of
         # `out += x` inside its own backward pass (ops.BNActSkipFn)
         out, x = ops.bn_act(x, c, self.norm1, relu=True, sums=x_sums, skip=True)
-        # (norm=: the layer that follows runs inside the convolution's launch where the launch allows it, ops.conv3x3)
-        out, s = ops.conv3x3(out, c, self.conv1.weight, self.conv1.bias, want_stats=self.norm2.training, norm=self.norm2)
+        out, s = ops.conv3x3(out, c, self.conv1.weight, self.conv1.bias, want_stats=self.norm2.training)
         out = ops.bn_act(out, c, self.norm2, relu=True, sums=s)
-        out, s = ops.conv3x3(out, c, self.conv2.weight, self.conv2.bias, residual=x, want_stats=want_stats, norm=next_norm)
+        out, s = ops.conv3x3(out, c, self.conv2.weight, self.conv2.bias, residual=x, want_stats=want_stats)
         return (out, c, s) if want_stats else (out, c)
 
     def forward(self, x):

@@ -195,28 +195,3 @@ static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b
     }
     return c;
 }
-
-// ---- device-scope atomics and bit casts used by the in-kernel reductions (conv3x3.hip FusedNorm): on the block-sequential
-// emulator a relaxed atomic load / store is a plain access
-#ifndef __HIP_MEMORY_SCOPE_AGENT
-#define __HIP_MEMORY_SCOPE_AGENT 4
-#define __HIP_MEMORY_SCOPE_SYSTEM 5
-#endif
-template <class T, class V>
-static inline void __hip_atomic_store(T* p, V v, int, int) {
-    *p = (T)v;
-}
-template <class T>
-static inline T __hip_atomic_load(const T* p, int, int) {
-    return *p;
-}
-static inline float __uint_as_float(unsigned u) {
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-static inline unsigned __float_as_uint(float f) {
-    unsigned u;
-    memcpy(&u, &f, 4);
-    return u;
-}

@@ -259,60 +259,6 @@ def test_repack_registered_serves_training_forwards(be):
         ops._call = real
 
 
-def test_conv_norm_relu_in_one_launch_equals_the_three_launch_form(be, monkeypatch):
-    """knobs.FORMS["FUSED_NORM"]: a residual stack's conv -> training-mode norm -> ReLU pairs run as ONE launch each
-    (mnk_conv3x3_fwd_norm: in-kernel, fence-free reduction of the statistics; the emulator runs its three phases as launches):
-    same outputs, gradients and running statistics as conv launch + second stage + apply launch, the fused form is really
-    taken, and no wait of the in-kernel reductions gave up."""
-    from mnk import ops
-    from modules.util import ResBlock3D
-    torch.manual_seed(21)
-    # 33 ... 48 channels: the 16x16-tile kernel with a 48-column block tile (the product's refinement stack has 45), and at
-    # least as many row tiles (128 pixels each) as channels: every channel needs a block to reduce it
-    ch, nb = (45, 8) if be.kind == "hip" else (36, 5)
-    blocks = [ResBlock3D(ch, kernel_size=(1, 3, 3), padding=(0, 1, 1)).to(be.device).train() for _ in range(2)]
-    x = torch.rand(nb, ch, 1, 32, 32)
-    wgt = torch.randn(nb, ch, 1, 32, 32)
-    state = [{k: v.clone() for k, v in b.state_dict().items()} for b in blocks]
-
-    def run(on):
-        monkeypatch.setitem(knobs.FORMS, "FUSED_NORM", on)
-        ops.FUSED_NORM_COUNT[0] = ops.FUSED_NORM_COUNT[1] = 0
-        for b, sd in zip(blocks, state):
-            b.load_state_dict(sd)
-            b.zero_grad()
-        xin = be.t(x.clone()).requires_grad_(True)
-        a = ops.to_act(xin)
-        out, c, sums = blocks[0].forward_act(a, ch, want_stats=True, next_norm=blocks[1].norm1)
-        out, c = blocks[1].forward_act(out, c, x_sums=sums)
-        y = ops.from_act(out, c, 1)
-        (y * be.t(wgt)).sum().backward()
-        be.sync()
-        grads = {"%d.%s" % (i, k): p.grad.detach().cpu().clone() for i, b in enumerate(blocks) for k, p in b.named_parameters()
-                 if p.grad is not None}
-        grads["x"] = xin.grad.cpu().clone()
-        bufs = {"%d.%s" % (i, k): v.detach().cpu().clone() for i, b in enumerate(blocks) for k, v in b.named_buffers()
-                if v.dtype.is_floating_point}
-        return y.detach().cpu().clone(), grads, bufs, tuple(ops.FUSED_NORM_COUNT)
-
-    # (the stack runs at batch 32 x 64 x 64 in the product: 1 024 row tiles, no split along K; at this test's size the launch
-    # plan would split -- hold it to one split, the case the fused form is for)
-    be.lib.call("mnk_set_tuning", b"force_splits", 1)
-    try:
-        y_on, g_on, b_on, used = run(True)
-        y_off, g_off, b_off, unused = run(False)
-    finally:
-        be.lib.call("mnk_set_tuning", b"force_splits", 0)
-    assert used[0] == 3 and unused[0] == 0, (used, unused)       # conv1 -> norm2 twice, block 0's conv2 -> block 1's norm1
-    assert ops.fused_norm_error() == 0
-    assert float((y_on - y_off).abs().max() / y_off.abs().max()) < 2e-6
-    assert set(g_on) == set(g_off)
-    for k in g_on:
-        assert float((g_on[k] - g_off[k]).norm() / (g_off[k].norm() + 1e-12)) < 2e-5, k
-    for k in b_on:
-        assert float((b_on[k] - b_off[k]).abs().max()) < 1e-6, k
-
-
 def test_evaluation_coefficients_of_a_norm_layer_are_kept_until_something_writes_it(be):
     """The reference's evaluation loops call the networks frame by frame with constant weights (reconstruction.py:52-62): the
     (mean, invstd, scale) launch of an eval-mode norm layer runs once, not per call -- and again after ANY write to the layer:
