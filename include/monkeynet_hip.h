@@ -71,7 +71,8 @@ int mnk_resize_nearest_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, i
 int mnk_resize_nearest_bwd_accumulate(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
                                       int Hs, int Ws, int N, int C, void* stream);
 /* the same with bilinear, align_corners=False weights (interpolation_mode='trilinear' with unchanged depth, vox configs);
- * the adjoint ACCUMULATES into dsrc (zero it first) */
+ * the adjoint is ADDED to dsrc (zero it first, or let several resized copies of one tensor add up) by a gather per source
+ * texel in destination-pixel order: deterministic, no atomics */
 int mnk_resize_bilinear(const float* src, int ld_src, int Hs, int Ws, float* dst, int ld_dst, int dst_off, int Hd,
                         int Wd, int N, int C, void* stream);
 int mnk_resize_bilinear_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, int Wd, float* dsrc, int ld_src,
@@ -568,17 +569,22 @@ int mnk_motion_field_kp_bwd(const float* pred, int ld, const float* mean_s, cons
  * ('trilinear' with unchanged depth). */
 int mnk_deform_fwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
                    float* out, int ld_out, int out_off, int N, void* stream);
-/* dinp (same layout as inp) must be zero-initialised by the caller when d_inp != NULL; dfield [N][hf][wf][2]
- * is ACCUMULATED into (several skips share one field). */
+/* Backward, DETERMINISTIC (no floating-point atomics; the reference's CPU grid_sample backward is a fixed-order sum per
+ * source texel, a loop over output pixels): pass A stores every output pixel's sampling point and its share of the field
+ * gradient in the workspace, pass B gathers per source texel -- the pixels that touch it in pixel order -- and per field
+ * texel.  dinp (same layout as inp, may be NULL) is WRITTEN, pad channels 0; dfield [N][hf][wf][2] (may be NULL) is ADDED
+ * to (several skips share one field: zero it before the first level).  ws: mnk_deform_bwd_workspace_floats floats. */
+size_t mnk_deform_bwd_workspace_floats(int C, int h, int w, int N);
 int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
-                   const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, void* stream);
+                   const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, float* ws, size_t ws_floats,
+                   void* stream);
 /* All warps of one generator pass in ONE launch each way (generator.py:60-78: every decoder level's appearance skip is
  * warped by the same field, nearest-resized (mode 0), and the key-point embedding is resized into the channels behind it):
  *   out_l[n][y][x][c] = grid_sample(inp_l, resize(field))[c]                    for c < C_l            (mnk_deform_fwd)
  *   out_l[n][y][x][emb_off_l + c] = emb[n][nearest(y)][nearest(x)][c]         for c < ke_l           (mnk_resize_nearest)
- * backward: dinp_l (zero-initialised by the caller, may be NULL) and dfield (zero-initialised, may be NULL) receive the
- * scatter-adds of mnk_deform_bwd; demb[N][He][We][ld_emb] (may be NULL) is WRITTEN: the gathers of mnk_resize_nearest_bwd
- * summed level after level, pad channels 0.  nlevels <= 8. */
+ * backward (two launches, deterministic -- see mnk_deform_bwd): dinp_l (may be NULL), dfield (may be NULL: the sum over the
+ * levels in order) and demb[N][He][We][ld_emb] (may be NULL: the gathers of mnk_resize_nearest_bwd summed level after level,
+ * pad channels 0) are all WRITTEN, nothing needs a zero fill.  ws: mnk_warp_levels_bwd_workspace_floats floats.  nlevels <= 8. */
 typedef struct MnkWarpLevel {
     const float* inp;   /* [N][h][w][ld_in] */
     float* out;         /* forward: [N][h][w][ld_out] */
@@ -588,8 +594,9 @@ typedef struct MnkWarpLevel {
 } MnkWarpLevel;
 int mnk_warp_levels_fwd(const MnkWarpLevel* levels, int nlevels, const float* field, int hf, int wf, int mode, const float* emb,
                         int ld_emb, int He, int We, int N, void* stream);
+size_t mnk_warp_levels_bwd_workspace_floats(const MnkWarpLevel* levels, int nlevels, int N);
 int mnk_warp_levels_bwd(const MnkWarpLevel* levels, int nlevels, const float* field, int hf, int wf, int mode, float* dfield,
-                        float* demb, int ld_emb, int He, int We, int N, void* stream);
+                        float* demb, int ld_emb, int He, int We, int N, float* ws, size_t ws_floats, void* stream);
 
 /* ---- feature-matching L1 on the discriminator's activations (modules/losses.py:8-12 reconstruction_loss over
  * discriminator maps; train.py:47-51) ---------------------------------------------------------------------------

@@ -178,28 +178,49 @@ __global__ void __launch_bounds__(256) resize_bilinear_kernel(const float* __res
     }
 }
 
-// adjoint: scatter with fp32 atomics into the zero-initialised source gradient
+// adjoint, written as a gather over source texels (deterministic, no atomics): a source texel walks the destination
+// pixels of a small window in order, forms each pixel's four (index, weight) pairs exactly as the forward does and adds
+// the pairs that name it, in the forward's order; the result is ADDED to dsrc by the one thread that owns the texel.
+__device__ __forceinline__ void lin1d_window(int s, int in_size, int out_size, int& lo, int& hi) {
+    // dst with i0 in {s-1, s} (or clamped onto s): scale*(dst+0.5)-0.5 in [s-1, s+1); one pixel of slack either side
+    lo = (int)(((long)s - 1) * out_size / in_size) - 2;
+    hi = (int)((((long)s + 2) * out_size + in_size - 1) / in_size) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
+}
+
 __global__ void __launch_bounds__(256) resize_bilinear_bwd_kernel(const float* __restrict__ ddst, int ld_dst,
                                                                   int dst_off, int Hd, int Wd,
                                                                   float* __restrict__ dsrc, int ld_src, int Hs, int Ws,
                                                                   int N, int C) {
-    const long total = (long)N * Hd * Wd * C;
+    const long total = (long)N * Hs * Ws * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long p = i / C;
-        int w = (int)(p % Wd);
-        long t = p / Wd;
-        int h = (int)(t % Hd);
-        int n = (int)(t / Hd);
-        Lin1D ly, lx;
-        ly.setup(h, Hs, Hd);
-        lx.setup(w, Ws, Wd);
-        const float g = ddst[p * ld_dst + dst_off + c];
-        float* sb = dsrc + (long)n * Hs * Ws * ld_src + c;
-        atomicAdd(sb + ((long)ly.i0 * Ws + lx.i0) * ld_src, g * ly.l0 * lx.l0);
-        atomicAdd(sb + ((long)ly.i0 * Ws + lx.i1) * ld_src, g * ly.l0 * lx.l1);
-        atomicAdd(sb + ((long)ly.i1 * Ws + lx.i0) * ld_src, g * ly.l1 * lx.l0);
-        atomicAdd(sb + ((long)ly.i1 * Ws + lx.i1) * ld_src, g * ly.l1 * lx.l1);
+        const int c = (int)(i % C);
+        const long p = i / C;
+        const int ws = (int)(p % Ws);
+        const long t = p / Ws;
+        const int hs = (int)(t % Hs);
+        const int n = (int)(t / Hs);
+        int h_lo, h_hi, w_lo, w_hi;
+        lin1d_window(hs, Hs, Hd, h_lo, h_hi);
+        lin1d_window(ws, Ws, Wd, w_lo, w_hi);
+        float acc = 0.f;
+        for (int h = h_lo; h <= h_hi; ++h) {
+            Lin1D ly;
+            ly.setup(h, Hs, Hd);
+            if (ly.i0 != hs && ly.i1 != hs) continue;
+            for (int w = w_lo; w <= w_hi; ++w) {
+                Lin1D lx;
+                lx.setup(w, Ws, Wd);
+                if (lx.i0 != ws && lx.i1 != ws) continue;
+                const float g = ddst[(((long)n * Hd + h) * Wd + w) * ld_dst + dst_off + c];
+                if (ly.i0 == hs && lx.i0 == ws) acc += g * ly.l0 * lx.l0;
+                if (ly.i0 == hs && lx.i1 == ws) acc += g * ly.l0 * lx.l1;
+                if (ly.i1 == hs && lx.i0 == ws) acc += g * ly.l1 * lx.l0;
+                if (ly.i1 == hs && lx.i1 == ws) acc += g * ly.l1 * lx.l1;
+            }
+        }
+        dsrc[p * ld_src + c] += acc;
     }
 }
 
@@ -310,8 +331,8 @@ int mnk_resize_bilinear_bwd(const float* ddst, int ld_dst, int dst_off, int Hd, 
     MNK_REQUIRE(ddst && dsrc && N > 0 && C > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && ld_src >= C &&
                 dst_off >= 0 && dst_off + C <= ld_dst);
     hipStream_t s = (hipStream_t)stream;
-    long total = (long)N * Hd * Wd * C;
-    ProfScope prof(K_LAYOUT, s, (double)total * 8);
+    long total = (long)N * Hs * Ws * C;
+    ProfScope prof(K_LAYOUT, s, (double)N * Hd * Wd * C * 8);
     hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, ddst, ld_dst, dst_off, Hd,
                        Wd, dsrc, ld_src, Hs, Ws, N, C);
     MNK_LAUNCH_CHECK();

@@ -624,18 +624,15 @@ struct FieldAt {
     int idx[4];
     float wgt[4];
     int n;
-    __device__ __forceinline__ void eval(const float* __restrict__ field, long nimg, int hf, int wf, int py, int px,
-                                         int h, int w, int mode) {
-        const float* fb = field + nimg * hf * wf * 2;
+    Lin1D ly, lx;
+    // which field texels pixel (py, px) of an (h, w) map reads, and with which weights
+    __device__ __forceinline__ void setup(int hf, int wf, int py, int px, int h, int w, int mode) {
         if (mode == 0) {
             const int ys = nearest_src(py, hf, h), xs = nearest_src(px, wf, w);
             idx[0] = ys * wf + xs;
             wgt[0] = 1.f;
             n = 1;
-            x = fb[idx[0] * 2];
-            y = fb[idx[0] * 2 + 1];
         } else {
-            Lin1D ly, lx;
             ly.setup(py, hf, h);
             lx.setup(px, wf, w);
             idx[0] = ly.i0 * wf + lx.i0;
@@ -647,6 +644,16 @@ struct FieldAt {
             idx[3] = ly.i1 * wf + lx.i1;
             wgt[3] = ly.l1 * lx.l1;
             n = 4;
+        }
+    }
+    __device__ __forceinline__ void eval(const float* __restrict__ field, long nimg, int hf, int wf, int py, int px,
+                                         int h, int w, int mode) {
+        const float* fb = field + nimg * hf * wf * 2;
+        setup(hf, wf, py, px, h, w, mode);
+        if (mode == 0) {
+            x = fb[idx[0] * 2];
+            y = fb[idx[0] * 2 + 1];
+        } else {
             // ATen upsample_bilinear2d: l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11)
             x = ly.l0 * (lx.l0 * fb[idx[0] * 2] + lx.l1 * fb[idx[1] * 2]) +
                 ly.l1 * (lx.l0 * fb[idx[2] * 2] + lx.l1 * fb[idx[3] * 2]);
@@ -658,10 +665,10 @@ struct FieldAt {
 
 struct Bilin {
     int x0, y0;
-    float wnw, wne, wsw, wse, tx, ty;
+    float wnw, wne, wsw, wse, tx, ty, ix, iy;
     bool x0ok, x1ok, y0ok, y1ok;
     __device__ __forceinline__ void setup(float x, float y, int W, int H) {
-        const float ix = ((x + 1.f) / 2.f) * (float)(W - 1), iy = ((y + 1.f) / 2.f) * (float)(H - 1);
+        ix = ((x + 1.f) / 2.f) * (float)(W - 1), iy = ((y + 1.f) / 2.f) * (float)(H - 1);
         const float fx = floorf(ix), fy = floorf(iy);
         // clamp before the int conversion so that far-away / non-finite coordinates stay out of range
         x0 = (fx >= -2.f && fx <= (float)W) ? (int)fx : -2;
@@ -736,16 +743,37 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(const float* __restrict
     deform_fwd_body(inp, ld_in, C, h, w, field, hf, wf, mode, out, ld_out, out_off, N, blockIdx.x, gridDim.x);
 }
 
-// CL lanes (power of two <= 64) cooperate on one pixel: each walks channels c = cl, cl + CL, ...; the per-pixel sums over
-// channels (d out / d grid) are finished with wavefront shuffles.  One lane per CHANNEL, not per channel quad: the CL lanes
-// of a pixel then add to CL consecutive floats of the scattered gradient -- a quarter of the atomic requests per line that
-// float4-wide lanes make (four instructions, each carrying one float of every 16 bytes): 11.11 -> 11.00 ms per training
-// iteration against that form (profiles/r02_knob_ab_log.txt, visit 44).
-__device__ __forceinline__ void deform_bwd_body(const float* __restrict__ inp, int ld_in, int C, int h, int w,
-                                                const float* __restrict__ field, int hf, int wf, int mode,
-                                                const float* __restrict__ dout, int ld_out, int out_off,
-                                                float* __restrict__ dinp, float* __restrict__ dfield, int N, int CL, int cslice,
-                                                int vbx, int vgx, int vby) {
+// ---- backward of the warps: deterministic, no floating-point atomics ---------------------------------------------------
+// grid_sample's adjoint scatters every output pixel's gradient onto the four source texels around its sampling point, and the
+// sampling points are data (the predicted field): any number of pixels may name the same texel.  The reference's CPU
+// backward is a loop over output pixels, i.e. a fixed-order sum per texel (generator.py:51-58 -> F.grid_sample backward);
+// fp32 atomics give a different order -- and different bits -- on every run.  Here the adjoint is two passes:
+//   pass A, per OUTPUT PIXEL (warp_bwd_pixel_body): the sampling point (ix, iy) in texel units is stored (samp), and the
+//     pixel's share of the field gradient -- sum over channels of dout * d(sample)/d(ix, iy), CL lanes per pixel, channel
+//     slices over blockIdx.y, finished with wavefront shuffles -- goes to gpart[slice][pixel][2].  Nothing is added to
+//     anything shared.
+//   pass B, per SOURCE TEXEL (warp_bwd_gather_body): a block owns a T x T tile of one frame's texels.  It scans the frame's
+//     sampling points in pixel order, WG_BATCH at a time, and compacts those whose 2 x 2 footprint touches the tile into an
+//     LDS list IN PIXEL ORDER (wavefront ballots + popcounts of the lower lanes: no atomics either); then every
+//     (texel, channel quad) thread walks the list and accumulates weight * dout[pixel] of the entries that touch its texel.
+//     Per texel that is the reference's own summation order.  d input is WRITTEN (pad channels 0): no zero fill.
+//   The field gradient of a field texel is a gather as well (warp_bwd_field_gather): over the levels in order, the pixels
+//     of each level that read the texel (nearest pick or the bilinear footprint) in pixel order, the channel slices in order.
+constexpr int WG_BATCH = 1024;   // sampling points scanned per round (4 per thread)
+constexpr int WG_MAXACC = 8;     // channel quads a thread accumulates (float4 each)
+
+__device__ __forceinline__ int lane_prefix_count(unsigned long long m) {     // set bits of m below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// CL lanes (power of two <= 64) cooperate on one pixel: each walks channels c = cl, cl + CL, ... of the block's channel
+// slice (blockIdx.y: few-pixel maps with many channels -- 2 x 2 ... 8 x 8 with 512 ... 1024 -- would otherwise be a few
+// dozen blocks whose lanes walk 16 channels one after another); gpart == NULL: only the sampling points are wanted.
+__device__ __forceinline__ void warp_bwd_pixel_body(const float* __restrict__ inp, int ld_in, int C, int h, int w,
+                                                    const float* __restrict__ field, int hf, int wf, int mode,
+                                                    const float* __restrict__ dout, int ld_out, int out_off,
+                                                    float* __restrict__ samp, float* __restrict__ gpart, int N, int CL,
+                                                    int cslice, int vbx, int vgx, int vby) {
     const long P = (long)h * w;
     const long npix = (long)N * P;
     const int ppb = 256 / CL;   // pixels per block iteration
@@ -755,61 +783,165 @@ __device__ __forceinline__ void deform_bwd_body(const float* __restrict__ inp, i
         const long np = it * ppb + pl;
         const bool live = np < npix;
         float gix = 0.f, giy = 0.f;
-        FieldAt fa;
-        fa.n = 0;
-        long n = 0;
         if (live) {
             const int p = (int)(np % P);
-            n = np / P;
+            const long n = np / P;
+            FieldAt fa;
             fa.eval(field, n, hf, wf, p / w, p % w, h, w, mode);
             Bilin bl;
             bl.setup(fa.x, fa.y, w, h);
-            const float* ib = inp + n * P * ld_in;
-            float* db = dinp ? dinp + n * P * ld_in : nullptr;
-            const long o_nw = ((long)bl.y0 * w + bl.x0) * ld_in, o_ne = o_nw + ld_in;
-            const long o_sw = o_nw + (long)w * ld_in, o_se = o_sw + ld_in;
-            const bool k_nw = bl.y0ok && bl.x0ok, k_ne = bl.y0ok && bl.x1ok, k_sw = bl.y1ok && bl.x0ok, k_se = bl.y1ok && bl.x1ok;
-            const float* gp = dout + np * ld_out + out_off;
-            // blockIdx.y = channel slice [c_begin, c_end): few-pixel maps with many channels (2 x 2 ... 8 x 8 with 512 ... 1024)
-            // would otherwise be a few dozen blocks whose lanes walk 16 channels one after another
-            const int c_begin = vby * cslice, c_end = c_begin + cslice < C ? c_begin + cslice : C;
-            for (int c = c_begin + cl; c < c_end; c += CL) {
-                const float go = gp[c];
-                const float vnw = k_nw ? ib[o_nw + c] : 0.f, vne = k_ne ? ib[o_ne + c] : 0.f;
-                const float vsw = k_sw ? ib[o_sw + c] : 0.f, vse = k_se ? ib[o_se + c] : 0.f;
-                gix += go * ((vne - vnw) * (1.f - bl.ty) + (vse - vsw) * bl.ty);
-                giy += go * ((vsw - vnw) * (1.f - bl.tx) + (vse - vne) * bl.tx);
-                if (db) {
-                    if (k_nw) atomicAdd(db + o_nw + c, go * bl.wnw);
-                    if (k_ne) atomicAdd(db + o_ne + c, go * bl.wne);
-                    if (k_sw) atomicAdd(db + o_sw + c, go * bl.wsw);
-                    if (k_se) atomicAdd(db + o_se + c, go * bl.wse);
+            if (vby == 0 && cl == 0) {
+                samp[np * 2] = bl.ix;
+                samp[np * 2 + 1] = bl.iy;
+            }
+            if (gpart) {
+                const float* ib = inp + n * P * ld_in;
+                const long o_nw = ((long)bl.y0 * w + bl.x0) * ld_in, o_ne = o_nw + ld_in;
+                const long o_sw = o_nw + (long)w * ld_in, o_se = o_sw + ld_in;
+                const bool k_nw = bl.y0ok && bl.x0ok, k_ne = bl.y0ok && bl.x1ok, k_sw = bl.y1ok && bl.x0ok, k_se = bl.y1ok && bl.x1ok;
+                const float* gp = dout + np * ld_out + out_off;
+                const int c_begin = vby * cslice, c_end = c_begin + cslice < C ? c_begin + cslice : C;
+                for (int c = c_begin + cl; c < c_end; c += CL) {
+                    const float go = gp[c];
+                    const float vnw = k_nw ? ib[o_nw + c] : 0.f, vne = k_ne ? ib[o_ne + c] : 0.f;
+                    const float vsw = k_sw ? ib[o_sw + c] : 0.f, vse = k_se ? ib[o_se + c] : 0.f;
+                    gix += go * ((vne - vnw) * (1.f - bl.ty) + (vse - vsw) * bl.ty);
+                    giy += go * ((vsw - vnw) * (1.f - bl.tx) + (vse - vne) * bl.tx);
                 }
             }
         }
-        for (int o = CL >> 1; o > 0; o >>= 1) {
-            gix += __shfl_xor(gix, o);
-            giy += __shfl_xor(giy, o);
-        }
-        if (live && cl == 0 && dfield) {
-            gix *= (float)(w - 1) * 0.5f;
-            giy *= (float)(h - 1) * 0.5f;
-            float* fb = dfield + n * hf * wf * 2;
-            for (int j = 0; j < fa.n; ++j) {
-                atomicAdd(fb + fa.idx[j] * 2, gix * fa.wgt[j]);
-                atomicAdd(fb + fa.idx[j] * 2 + 1, giy * fa.wgt[j]);
+        if (gpart) {
+            for (int o = CL >> 1; o > 0; o >>= 1) {
+                gix += __shfl_xor(gix, o);
+                giy += __shfl_xor(giy, o);
+            }
+            if (live && cl == 0) {
+                gpart[((long)vby * npix + np) * 2] = gix * ((float)(w - 1) * 0.5f);
+                gpart[((long)vby * npix + np) * 2 + 1] = giy * ((float)(h - 1) * 0.5f);
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(256) deform_bwd_kernel(const float* __restrict__ inp, int ld_in, int C, int h, int w,
-                                                              const float* __restrict__ field, int hf, int wf, int mode,
-                                                              const float* __restrict__ dout, int ld_out, int out_off,
-                                                              float* __restrict__ dinp, float* __restrict__ dfield, int N,
-                                                              int CL, int cslice) {
-    deform_bwd_body(inp, ld_in, C, h, w, field, hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL, cslice, blockIdx.x,
-                    gridDim.x, blockIdx.y);
+__device__ __forceinline__ float4 load4_channels(const float* __restrict__ row, int c, int C, bool vec) {
+    if (vec && c + 4 <= C) return *reinterpret_cast<const float4*>(row + c);
+    float4 v;
+    v.x = c < C ? row[c] : 0.f;
+    v.y = c + 1 < C ? row[c + 1] : 0.f;
+    v.z = c + 2 < C ? row[c + 2] : 0.f;
+    v.w = c + 3 < C ? row[c + 3] : 0.f;
+    return v;
+}
+
+// vb = ((frame * tiles + tile) * qslices + quad slice); 256 threads = T*T texels x QL = 256 / (T*T) lanes per texel; a thread
+// owns channel quads qbase + a * QL + ql, a < nacc <= WG_MAXACC
+__device__ __forceinline__ void warp_bwd_gather_body(const float* __restrict__ dout, int ld_out, int out_off, int C, int h,
+                                                     int w, const float* __restrict__ samp, float* __restrict__ dinp,
+                                                     int ld_in, int T, int nacc, int qslices, int vb) {
+    __shared__ float s_ix[WG_BATCH], s_iy[WG_BATCH];
+    __shared__ int s_p[WG_BATCH];
+    __shared__ int s_cnt[WG_BATCH / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (w + T - 1) / T, tiles = tiles_x * ((h + T - 1) / T);
+    const int slice = vb % qslices;
+    const int tile = (vb / qslices) % tiles, n = (vb / qslices) / tiles;
+    const int tx0 = (tile % tiles_x) * T, ty0 = (tile / tiles_x) * T;
+    const int QL = 256 / (T * T);
+    const int tex = tid / QL, ql = tid % QL;
+    const int tx = tx0 + tex % T, ty = ty0 + tex / T;
+    const bool active = tx < w && ty < h;
+    const int nq = ld_in >> 2;
+    const int qbase = slice * nacc * QL;
+    const int P = h * w;
+    const float* sb = samp + (long)n * P * 2;
+    const float* db = dout + (long)n * P * ld_out + out_off;
+    const bool vec = ((out_off & 3) == 0) && ((ld_out & 3) == 0);
+    float4 acc[WG_MAXACC];
+#pragma unroll
+    for (int a = 0; a < WG_MAXACC; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < P; base += WG_BATCH) {
+        float ix[4], iy[4];
+        bool hit[4];
+        int pre[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = base + j * 256 + tid;
+            hit[j] = false;
+            ix[j] = iy[j] = 0.f;
+            if (p < P) {
+                const float2 sp = *reinterpret_cast<const float2*>(sb + 2 * (long)p);
+                ix[j] = sp.x, iy[j] = sp.y;
+                const float fx = floorf(sp.x), fy = floorf(sp.y);
+                // (non-finite and far-away points fail the comparisons: Bilin::setup's clamp)
+                hit[j] = fx >= (float)(tx0 - 1) && fx <= (float)(tx0 + T - 1) && fy >= (float)(ty0 - 1) && fy <= (float)(ty0 + T - 1);
+            }
+            const unsigned long long m = __ballot(hit[j]);
+            pre[j] = lane_prefix_count(m);
+            if (lane == 0) s_cnt[j * 4 + wave] = __popcll(m);
+        }
+        __syncthreads();
+        int off[4], total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if ((k & 3) == wave) off[k >> 2] = total;
+            total += s_cnt[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (hit[j]) {
+                const int pos = off[j] + pre[j];
+                s_p[pos] = base + j * 256 + tid;
+                s_ix[pos] = ix[j];
+                s_iy[pos] = iy[j];
+            }
+        __syncthreads();
+        if (active)
+            for (int e = 0; e < total; ++e) {
+                const float eix = s_ix[e], eiy = s_iy[e];
+                const float fx = floorf(eix), fy = floorf(eiy);
+                const int dx = tx - (int)fx, dy = ty - (int)fy;
+                if ((unsigned)dx < 2u && (unsigned)dy < 2u) {
+                    // the forward's corner weights: (ex - ix | ix - fx) * (ey - iy | iy - fy), ex = fx + 1
+                    const float wx = dx ? eix - fx : (fx + 1.f) - eix;
+                    const float wy = dy ? eiy - fy : (fy + 1.f) - eiy;
+                    const float wgt = wx * wy;
+                    const float* gp = db + (long)s_p[e] * ld_out;
+#pragma unroll
+                    for (int a = 0; a < WG_MAXACC; ++a) {
+                        const int q = qbase + a * QL + ql;
+                        if (a < nacc && q < nq) {
+                            const float4 v = load4_channels(gp, q * 4, C, vec);
+                            acc[a].x += v.x * wgt;
+                            acc[a].y += v.y * wgt;
+                            acc[a].z += v.z * wgt;
+                            acc[a].w += v.w * wgt;
+                        }
+                    }
+                }
+            }
+        __syncthreads();
+    }
+    if (active) {
+        float* op = dinp + (((long)n * h + ty) * w + tx) * ld_in;
+#pragma unroll
+        for (int a = 0; a < WG_MAXACC; ++a) {
+            const int q = qbase + a * QL + ql;
+            if (a < nacc && q < nq) *reinterpret_cast<float4*>(op + q * 4) = acc[a];
+        }
+    }
+}
+
+// destination pixels (of a size-`out` axis) that may read field texel s of a size-`in` axis; one pixel of slack either side
+__device__ __forceinline__ void field_window(int s, int in_size, int out_size, int mode, int& lo, int& hi) {
+    if (mode == 0) {
+        lo = (int)((long)s * out_size / in_size) - 1;
+        hi = (int)(((long)s + 1) * out_size / in_size) + 1;
+    } else {     // Lin1D: i0 in {s-1, s} <=> in/out*(dst+0.5)-0.5 in [s-1, s+1)
+        lo = (int)(((long)s - 1) * out_size / in_size) - 2;
+        hi = (int)((((long)s + 2) * out_size + in_size - 1) / in_size) + 1;
+    }
+    if (lo < 0) lo = 0;
+    if (hi > out_size - 1) hi = out_size - 1;
 }
 
 // ---- all warps of a generator pass in ONE launch (generator.py:60-78: the appearance skips of every decoder level are
@@ -819,11 +951,14 @@ struct WarpSeg {          // one level's share of the launch
     const float* inp;
     float* out;           // forward: [N][h][w][ld_out]
     const float* dout;    // backward: its gradient
-    float* dinp;          // backward: zero-initialised scatter target (or NULL)
-    int ld_in, C, h, w, ld_out, ke, emb_off;
-    int warp_begin, warp_blocks;      // forward: blocks of the warp / of the embedding copy; backward: warp blocks = gx * slices
+    float* dinp;          // backward: written by the gather pass (or NULL)
+    float* samp;          // backward workspace: sampling point of every output pixel, texel units [N*h*w][2]
+    float* gpart;         // backward workspace: field-gradient share of every pixel [slices][N*h*w][2]
+    int ld_in, C, h, w, ld_out, out_off, ke, emb_off;
+    int warp_begin, warp_blocks;      // forward: blocks of the warp / of the embedding copy; backward pass A: gx * slices
     int emb_begin, emb_blocks;
-    int CL, cslice, gx;
+    int CL, cslice, gx, slices;
+    int gat_begin, gat_blocks, T, nacc, qslices;       // backward pass B: the texel-tile gathers of d input
 };
 struct WarpSegs {
     WarpSeg lv[MAX_WARP_LEVELS];
@@ -832,6 +967,7 @@ struct WarpSegs {
     const float* emb;
     float* dfield;
     float* demb;
+    int dfield_begin, dfield_blocks, dfield_accumulate;
     int demb_begin, demb_blocks;
 };
 
@@ -862,16 +998,75 @@ __global__ void __launch_bounds__(256) warp_levels_fwd_kernel(WarpSegs a) {
     }
 }
 
-__global__ void __launch_bounds__(256) warp_levels_bwd_kernel(WarpSegs a) {
+// pass A of the backward, every level in one launch
+__global__ void __launch_bounds__(256) warp_levels_bwd_pixel_kernel(WarpSegs a) {
     const int b = blockIdx.x;
     for (int l = 0; l < a.n; ++l) {
         const WarpSeg& L = a.lv[l];
         if (b >= L.warp_begin && b < L.warp_begin + L.warp_blocks) {
             const int vb = b - L.warp_begin;
-            deform_bwd_body(L.inp, L.ld_in, L.C, L.h, L.w, a.field, a.hf, a.wf, a.mode, L.dout, L.ld_out, 0, L.dinp, a.dfield,
-                            a.N, L.CL, L.cslice, vb % L.gx, L.gx, vb / L.gx);
+            warp_bwd_pixel_body(L.inp, L.ld_in, L.C, L.h, L.w, a.field, a.hf, a.wf, a.mode, L.dout, L.ld_out, L.out_off, L.samp,
+                                a.dfield ? L.gpart : nullptr, a.N, L.CL, L.cslice, vb % L.gx, L.gx, vb / L.gx);
             return;
         }
+    }
+}
+
+// pass B: d input of every level (texel tiles), the field gradient (one thread per field texel) and the gradient of the
+// embedding (one thread per element)
+__global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a) {
+    const int b = blockIdx.x;
+    for (int l = 0; l < a.n; ++l) {
+        const WarpSeg& L = a.lv[l];
+        if (b >= L.gat_begin && b < L.gat_begin + L.gat_blocks) {
+            warp_bwd_gather_body(L.dout, L.ld_out, L.out_off, L.C, L.h, L.w, L.samp, L.dinp, L.ld_in, L.T, L.nacc, L.qslices,
+                                 b - L.gat_begin);
+            return;
+        }
+    }
+    if (b >= a.dfield_begin && b < a.dfield_begin + a.dfield_blocks) {
+        const long total = (long)a.N * a.hf * a.wf;
+        for (long i = (long)(b - a.dfield_begin) * 256 + threadIdx.x; i < total; i += (long)a.dfield_blocks * 256) {
+            const int xs = (int)(i % a.wf);
+            const long t = i / a.wf;
+            const int ys = (int)(t % a.hf);
+            const long n = t / a.hf;
+            const int me = ys * a.wf + xs;
+            float sx = 0.f, sy = 0.f;
+            for (int l = 0; l < a.n; ++l) {
+                const WarpSeg& L = a.lv[l];
+                const long npix = (long)a.N * L.h * L.w;
+                int h_lo, h_hi, w_lo, w_hi;
+                field_window(ys, a.hf, L.h, a.mode, h_lo, h_hi);
+                field_window(xs, a.wf, L.w, a.mode, w_lo, w_hi);
+                for (int y = h_lo; y <= h_hi; ++y)
+                    for (int x = w_lo; x <= w_hi; ++x) {
+                        FieldAt fa;
+                        fa.setup(a.hf, a.wf, y, x, L.h, L.w, a.mode);
+                        float wsum = 0.f;
+                        bool any = false;
+                        for (int j = 0; j < fa.n; ++j)
+                            if (fa.idx[j] == me) wsum = any ? wsum + fa.wgt[j] : fa.wgt[j], any = true;
+                        if (!any) continue;
+                        const long np = (n * L.h + y) * L.w + x;
+                        float gx = 0.f, gy = 0.f;
+                        for (int sl = 0; sl < L.slices; ++sl) {
+                            gx += L.gpart[((long)sl * npix + np) * 2];
+                            gy += L.gpart[((long)sl * npix + np) * 2 + 1];
+                        }
+                        sx += gx * wsum;
+                        sy += gy * wsum;
+                    }
+            }
+            if (a.dfield_accumulate) {
+                a.dfield[i * 2] += sx;
+                a.dfield[i * 2 + 1] += sy;
+            } else {
+                a.dfield[i * 2] = sx;
+                a.dfield[i * 2 + 1] = sy;
+            }
+        }
+        return;
     }
     if (b >= a.demb_begin && b < a.demb_begin + a.demb_blocks) {
         // gradient of the embedding: every element gathers, level after level (the order of the per-level launches), the
@@ -1130,33 +1325,11 @@ int mnk_deform_fwd(const float* inp, int ld_in, int C, int h, int w, const float
     return MNK_OK;
 }
 
-int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
-                   const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, void* stream) {
-    MNK_REQUIRE(inp && field && dout && N > 0 && C > 0 && h > 0 && w > 0 && hf > 0 && wf > 0 && (mode == 0 || mode == 1));
-    MNK_REQUIRE(ld_in % 4 == 0 && ld_in >= round_up(C, 4) && out_off >= 0 && out_off + C <= ld_out);
-    MNK_REQUIRE(dinp || dfield);
-    hipStream_t s = (hipStream_t)stream;
-    int CL = 1;
-    while (CL < C && CL < 64) CL <<= 1;
-    const long iters = ((long)N * h * w + (256 / CL) - 1) / (256 / CL);
-    ProfScope prof(K_DEFORM, s, (double)N * h * w * C * 12);
-    // channel slices (multiples of CL) until the launch has ~2048 blocks; every slice adds its share of the field gradient
-    // atomically, like the pixels that share a field texel do
-    int slices = 1;
-    const int max_slices = (C + CL - 1) / CL;
-    while (slices < max_slices && iters * slices < g_deform_bwd_blocks) slices <<= 1;
-    if (slices > max_slices) slices = max_slices;
-    const int cslice = ((C + slices - 1) / slices + CL - 1) / CL * CL;
-    slices = (C + cslice - 1) / cslice;
-    hipLaunchKernelGGL(deform_bwd_kernel, dim3((int)(iters < 16384 ? iters : 16384), slices), dim3(256), 0, s, inp, ld_in, C, h, w,
-                       field, hf, wf, mode, dout, ld_out, out_off, dinp, dfield, N, CL, cslice);
-    MNK_LAUNCH_CHECK();
-    return MNK_OK;
-}
 static void warp_bwd_plan(int C, long npix, int& CL, int& cslice, int& gx, int& slices) {
     CL = 1;
     while (CL < C && CL < 64) CL <<= 1;
     const long iters = (npix + (256 / CL) - 1) / (256 / CL);
+    // channel slices (multiples of CL) until the launch has ~2048 blocks; every slice leaves its share of the field gradient
     slices = 1;
     const int max_slices = (C + CL - 1) / CL;
     while (slices < max_slices && iters * slices < g_deform_bwd_blocks) slices <<= 1;
@@ -1164,6 +1337,92 @@ static void warp_bwd_plan(int C, long npix, int& CL, int& cslice, int& gx, int& 
     cslice = ((C + slices - 1) / slices + CL - 1) / CL * CL;
     slices = (C + cslice - 1) / cslice;
     gx = (int)(iters < 16384 ? iters : 16384);
+}
+
+// tile edge of the gather pass: every block scans its frame's sampling points, so big maps take big tiles (a 256 x 256 map
+// in 8 x 8 tiles would read its 512 KB of sampling points 1024 times per frame); small maps take small tiles so that the
+// 256 threads split the channels instead of idling
+static void warp_gather_plan(int ld_in, int h, int w, int& T, int& nacc, int& qslices, int& tiles) {
+    const long P = (long)h * w;
+    T = P >= 16384 ? 16 : P >= 1024 ? 8 : P >= 64 ? 4 : P >= 16 ? 2 : 1;
+    const int QL = 256 / (T * T), nq = ld_in / 4;
+    nacc = ceil_div(nq, QL);
+    if (nacc > WG_MAXACC) nacc = WG_MAXACC;
+    qslices = ceil_div(nq, nacc * QL);
+    tiles = ceil_div(w, T) * ceil_div(h, T);
+}
+
+static size_t warp_level_ws_floats(int C, int h, int w, int N) {
+    int CL, cslice, gx, slices;
+    const long npix = (long)N * h * w;
+    warp_bwd_plan(C, npix, CL, cslice, gx, slices);
+    return (size_t)npix * 2 * (1 + slices);
+}
+
+// fills the plans and workspace pointers of a.lv[0 .. a.n) (inp, dout, dinp, ld_in, C, h, w, ld_out, out_off, ke, emb_off set by
+// the caller) and launches the two passes
+static int warp_bwd_launch(WarpSegs& a, float* ws, size_t ws_floats, double bytes, hipStream_t s) {
+    size_t need = 0;
+    for (int l = 0; l < a.n; ++l) need += warp_level_ws_floats(a.lv[l].C, a.lv[l].h, a.lv[l].w, a.N);
+    if (!ws || ws_floats < need) {
+        set_error("warp backward: workspace too small");
+        return MNK_EWORKSPACE;
+    }
+    int blocks_a = 0, blocks_b = 0;
+    float* wp = ws;
+    for (int l = 0; l < a.n; ++l) {
+        WarpSeg& L = a.lv[l];
+        const long npix = (long)a.N * L.h * L.w;
+        warp_bwd_plan(L.C, npix, L.CL, L.cslice, L.gx, L.slices);
+        L.samp = wp;
+        L.gpart = wp + npix * 2;
+        wp += npix * 2 * (1 + L.slices);
+        L.warp_begin = blocks_a;
+        L.warp_blocks = L.gx * (a.dfield ? L.slices : 1);
+        blocks_a += L.warp_blocks;
+        L.gat_begin = blocks_b;
+        L.gat_blocks = 0;
+        if (L.dinp) {
+            int tiles;
+            warp_gather_plan(L.ld_in, L.h, L.w, L.T, L.nacc, L.qslices, tiles);
+            const long nb = (long)a.N * tiles * L.qslices;
+            MNK_REQUIRE(nb < (1l << 30));
+            L.gat_blocks = (int)nb;
+        }
+        blocks_b += L.gat_blocks;
+    }
+    a.dfield_begin = blocks_b;
+    a.dfield_blocks = a.dfield ? grid_for((long)a.N * a.hf * a.wf) : 0;
+    blocks_b += a.dfield_blocks;
+    a.demb_begin = blocks_b;
+    a.demb_blocks = a.demb ? grid_for((long)a.N * a.He * a.We * a.ld_emb) : 0;
+    blocks_b += a.demb_blocks;
+    MNK_REQUIRE(blocks_b > 0);
+    ProfScope prof(K_DEFORM, s, bytes);
+    if (blocks_a > 0 && (a.dfield || blocks_b > a.dfield_blocks + a.demb_blocks))
+        hipLaunchKernelGGL(warp_levels_bwd_pixel_kernel, dim3(blocks_a), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(warp_levels_bwd_gather_kernel, dim3(blocks_b), dim3(256), 0, s, a);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+size_t mnk_deform_bwd_workspace_floats(int C, int h, int w, int N) {
+    if (C <= 0 || h <= 0 || w <= 0 || N <= 0) return 0;
+    return warp_level_ws_floats(C, h, w, N);
+}
+
+int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float* field, int hf, int wf, int mode,
+                   const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, float* ws, size_t ws_floats,
+                   void* stream) {
+    MNK_REQUIRE(inp && field && dout && N > 0 && C > 0 && h > 0 && w > 0 && hf > 0 && wf > 0 && (mode == 0 || mode == 1));
+    MNK_REQUIRE(ld_in % 4 == 0 && ld_in >= round_up(C, 4) && out_off >= 0 && out_off + C <= ld_out);
+    MNK_REQUIRE(dinp || dfield);
+    WarpSegs a = {};
+    a.n = 1, a.N = N, a.hf = hf, a.wf = wf, a.mode = mode;
+    a.field = field, a.dfield = dfield, a.dfield_accumulate = 1;
+    WarpSeg& L = a.lv[0];
+    L.inp = inp, L.dout = dout, L.dinp = dinp, L.ld_in = ld_in, L.C = C, L.h = h, L.w = w, L.ld_out = ld_out, L.out_off = out_off;
+    return warp_bwd_launch(a, ws, ws_floats, (double)N * h * w * C * 12, (hipStream_t)stream);
 }
 
 static int warp_levels_check(const MnkWarpLevel* lv, int n, const float* field, int hf, int wf, int mode, int He, int We,
@@ -1208,38 +1467,31 @@ int mnk_warp_levels_fwd(const MnkWarpLevel* levels, int nlevels, const float* fi
     return MNK_OK;
 }
 
+size_t mnk_warp_levels_bwd_workspace_floats(const MnkWarpLevel* levels, int nlevels, int N) {
+    if (!levels || nlevels <= 0 || nlevels > MAX_WARP_LEVELS || N <= 0) return 0;
+    size_t need = 0;
+    for (int l = 0; l < nlevels; ++l) {
+        if (levels[l].C <= 0 || levels[l].h <= 0 || levels[l].w <= 0) return 0;
+        need += warp_level_ws_floats(levels[l].C, levels[l].h, levels[l].w, N);
+    }
+    return need;
+}
+
 int mnk_warp_levels_bwd(const MnkWarpLevel* levels, int nlevels, const float* field, int hf, int wf, int mode, float* dfield,
-                        float* demb, int ld_emb, int He, int We, int N, void* stream) {
+                        float* demb, int ld_emb, int He, int We, int N, float* ws, size_t ws_floats, void* stream) {
     if (int rc = warp_levels_check(levels, nlevels, field, hf, wf, mode, He, We, ld_emb, N)) return rc;
     WarpSegs a = {};
     a.n = nlevels, a.N = N, a.hf = hf, a.wf = wf, a.mode = mode, a.ld_emb = ld_emb, a.He = He, a.We = We;
-    a.field = field, a.dfield = dfield, a.demb = demb;
-    int blocks = 0;
+    a.field = field, a.dfield = dfield, a.demb = demb, a.dfield_accumulate = 0;
     double bytes = 0;
     for (int l = 0; l < nlevels; ++l) {
         const MnkWarpLevel& m = levels[l];
         MNK_REQUIRE(m.dout);
         WarpSeg& L = a.lv[l];
         L.inp = m.inp, L.dout = m.dout, L.dinp = m.dinp, L.ld_in = m.ld_in, L.C = m.C, L.h = m.h, L.w = m.w,
-        L.ld_out = m.ld_out, L.ke = m.ke, L.emb_off = m.emb_off;
-        L.warp_begin = blocks;
-        L.warp_blocks = 0;
-        if (m.dinp || dfield) {
-            int slices;
-            warp_bwd_plan(m.C, (long)N * m.h * m.w, L.CL, L.cslice, L.gx, slices);
-            L.warp_blocks = L.gx * slices;
-        }
-        blocks += L.warp_blocks;
+        L.ld_out = m.ld_out, L.out_off = 0, L.ke = m.ke, L.emb_off = m.emb_off;
         bytes += (double)N * m.h * m.w * m.C * 12;
     }
-    a.demb_begin = blocks;
-    a.demb_blocks = demb ? grid_for((long)N * He * We * ld_emb) : 0;
-    blocks += a.demb_blocks;
-    MNK_REQUIRE(blocks > 0);
-    hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(K_DEFORM, s, bytes);
-    hipLaunchKernelGGL(warp_levels_bwd_kernel, dim3(blocks), dim3(256), 0, s, a);
-    MNK_LAUNCH_CHECK();
-    return MNK_OK;
+    return warp_bwd_launch(a, ws, ws_floats, bytes, (hipStream_t)stream);
 }
 }

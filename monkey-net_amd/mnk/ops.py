@@ -1666,11 +1666,12 @@ class WarpSkipFn(_Fn):
         dout = dout.contiguous()
         n, h, w, ld_in = inp.shape
         _, hf, wf, _ = field.shape
-        dinp = torch.zeros_like(inp) if ctx.needs_input_grad[0] else None
-        dfield = torch.zeros_like(field) if ctx.needs_input_grad[1] else None
+        dinp = torch.empty_like(inp) if ctx.needs_input_grad[0] else None       # written by the gather pass
+        dfield = torch.zeros_like(field) if ctx.needs_input_grad[1] else None    # added to
         if dinp is not None or dfield is not None:
+            nws = _query("mnk_deform_bwd_workspace_floats", c, h, w, n)
             _call("mnk_deform_bwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(dout), dout.shape[-1], 0,
-                  _p(dinp), _p(dfield), n)
+                  _p(dinp), _p(dfield), n, _p(SCRATCH.get("ws", nws, inp)), nws)
         demb = None
         if emb is not None and ctx.needs_input_grad[2]:
             # nearest: the adjoint is a gather that writes every source pixel; with c a multiple of 4 it also reads the
@@ -1689,8 +1690,8 @@ WARP_LEVEL = np.dtype([("inp", "<u8"), ("out", "<u8"), ("dout", "<u8"), ("dinp",
 class WarpAllFn(_Fn):
     """Every deform_input of one generator forward (generator.py:66-73 the skips, :78 the source frame) as ONE autograd node.
     They all read the same deformation field, so as separate nodes each backward zero-fills its own field gradient and
-    autograd adds the eight of them up; here the warp backward kernels accumulate into one zeroed buffer (they add
-    atomically anyway).  forward(field, emb, mode, specs, *inps) with specs = ((c, ke), ...) per input; returns one
+    autograd adds the eight of them up; here one gather per field texel sums the levels in order (mnk_warp_levels_bwd:
+    deterministic, nothing is zero-filled).  forward(field, emb, mode, specs, *inps) with specs = ((c, ke), ...) per input; returns one
     [warp(inp) | resize(emb)] act per input (ke = 0: no embedding behind it)."""
 
     @staticmethod
@@ -1737,13 +1738,13 @@ class WarpAllFn(_Fn):
         inps = ctx.saved_tensors[2:]
         mode, specs = ctx.meta
         _, hf, wf, _ = field.shape
-        # the scatter-add targets of all warps (d input of every level, d field) are slices of ONE zeroed buffer: one fill launch
-        # instead of one per level.  The acts come first (their sizes are multiples of 4 floats: every slice stays 16-byte
-        # aligned for the float4 readers downstream), the field last.
+        # the gradients of all warps (d input of every level, d field) are slices of ONE buffer.  The acts come first (their
+        # sizes are multiples of 4 floats: every slice stays 16-byte aligned for the float4 readers downstream), the field
+        # last.  The one-launch form writes every element; the per-level form adds the levels' field gradients up.
         want_field = ctx.needs_input_grad[0] and any(d is not None for d in douts)
         want = [ctx.needs_input_grad[4 + i] and douts[i] is not None for i in range(len(inps))]
         sizes = [inp.numel() if wnt else 0 for inp, wnt in zip(inps, want)] + [field.numel() if want_field else 0]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=field.device) if sum(sizes) else None
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=field.device) if sum(sizes) else None
         offs = [sum(sizes[:k]) for k in range(len(sizes))]
         dfield = flat[offs[-1]:offs[-1] + sizes[-1]].view_as(field) if want_field else None
         demb = None
@@ -1764,10 +1765,13 @@ class WarpAllFn(_Fn):
                          dout.shape[-1], ke if want_emb else 0, c, 0)
             if want_emb:
                 demb = torch.empty_like(emb)
+            nws = _query("mnk_warp_levels_bwd_workspace_floats", lv.ctypes.data, len(live), inps[0].shape[0])
             _call("mnk_warp_levels_bwd", field, lv.ctypes.data, len(live), _p(field), hf, wf, mode, _p(dfield), _p(demb),
                   emb.shape[-1] if emb is not None else 0, emb.shape[1] if emb is not None else 0,
-                  emb.shape[2] if emb is not None else 0, inps[0].shape[0])
+                  emb.shape[2] if emb is not None else 0, inps[0].shape[0], _p(SCRATCH.get("ws", nws, field)), nws)
             return (dfield, demb, None, None) + tuple(dinps)
+        if dfield is not None:
+            dfield.zero_()
         for i, (inp, (c, ke), dout) in enumerate(zip(inps, specs, douts)):
             if dout is None:
                 dinps.append(None)
@@ -1776,8 +1780,9 @@ class WarpAllFn(_Fn):
             n, h, w, ld_in = inp.shape
             dinp = flat[offs[i]:offs[i] + sizes[i]].view_as(inp) if want[i] else None
             if dinp is not None or dfield is not None:
+                nws = _query("mnk_deform_bwd_workspace_floats", c, h, w, n)
                 _call("mnk_deform_bwd", inp, _p(inp), ld_in, c, h, w, _p(field), hf, wf, mode, _p(dout), dout.shape[-1], 0,
-                      _p(dinp), _p(dfield), n)
+                      _p(dinp), _p(dfield), n, _p(SCRATCH.get("ws", nws, inp)), nws)
             dinps.append(dinp)
             if ke and emb is not None and ctx.needs_input_grad[1]:
                 # the first contribution writes demb (nearest: a gather over the source pixels that, with c a multiple of 4,
@@ -1787,7 +1792,7 @@ class WarpAllFn(_Fn):
                 if first:
                     demb = torch.empty_like(emb) if whole else torch.zeros_like(emb)
                 name = ("mnk_resize_nearest_bwd" if first else "mnk_resize_nearest_bwd_accumulate") if mode == 0 \
-                    else "mnk_resize_bilinear_bwd"                  # (bilinear: atomic adds into the zeroed buffer)
+                    else "mnk_resize_bilinear_bwd"                  # (bilinear: added to the zeroed buffer by a gather)
                 _call(name, inp, _p(dout), dout.shape[-1], c, h, w, _p(demb), emb.shape[-1], emb.shape[1], emb.shape[2], n,
                       emb.shape[-1] if whole else ke)
         return (dfield, demb, None, None) + tuple(dinps)

@@ -16,6 +16,21 @@ import _util  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "trajectory: long multi-iteration training runs; collected LAST so that a failure "
+                            "there (pytest -x) cannot hide the kernel / module / oracle tests")
+
+
+# files whose tests run several full-size training iterations: they go to the end of the collection, after every kernel,
+# module and oracle test (the driver runs `pytest -x`: in round 4 one such test stopped the run in front of 361 others)
+_LATE_FILES = ("test_fullsize.py", "test_dist_graph_gpu.py", "test_p2p_gpu.py", "test_train_sanity.py", "test_bench_guard.py")
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        if item.get_closest_marker("trajectory") is not None:
+            return 2
+        return 1 if os.path.basename(str(item.fspath)) in _LATE_FILES else 0
+    items.sort(key=rank)            # stable: the order inside each class stays the collection order
 
 
 @pytest.hookimpl(tryfirst=True)

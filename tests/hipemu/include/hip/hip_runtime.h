@@ -112,6 +112,23 @@ static inline T __shfl_down(T v, unsigned delta, int width = 64) {
     return __shfl(v, (int)(s < (unsigned)width ? s : l), width);
 }
 
+// wave64 vote + the "set bits below my lane" pair (v_mbcnt_lo / v_mbcnt_hi)
+static inline unsigned long long __ballot(int pred) {
+    const uint32_t* all = hipemu::wave_publish(pred ? 1u : 0u, 0);
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) m |= (unsigned long long)(all[i] & 1u) << i;
+    return m;
+}
+static inline int __popcll(unsigned long long m) { return __builtin_popcountll(m); }
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned add) {
+    const unsigned l = hipemu::lane_id();
+    return add + (unsigned)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u)));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add) {
+    const unsigned l = hipemu::lane_id();
+    return add + (l > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0u);
+}
+
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }

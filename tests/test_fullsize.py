@@ -94,12 +94,31 @@ def test_eval_generation_is_frame_independent_at_batch_32():
         assert float((full[k] - joined).abs().max()) < 2e-5, k
 
 
+def _param_sample(mods):
+    """A fixed 256-element sample of every parameter and buffer (fp32 bits)."""
+    out = []
+    for m in mods:
+        for t in list(m.parameters()) + list(m.buffers()):
+            flat = t.detach().reshape(-1)
+            if flat.dtype != torch.float32:
+                continue
+            out.append(flat[:: max(1, flat.numel() // 256)][:256].clone())
+    return torch.cat(out).cpu()
+
+
+@pytest.mark.trajectory
 @pytest.mark.parametrize("mnk_adam", [True, False], ids=["mnk-adam", "torch-adam-capturable"])
 def test_full_size_training_iterations_graph_replay_equals_eager(mnk_adam):
     """Same initial weights and inputs: TrainStep(use_graph=True) runs three eager warm-up iterations, captures the
-    iteration, puts parameters / running statistics / optimiser state back and replays -- so replay k must give the
-    losses of eager iteration k: the first call applies exactly one update (same kernels in the same order, the
-    optimiser included; the fp32 atomics of the warp backward are the only non-deterministic sums)."""
+    iteration, puts parameters / running statistics / optimiser state back and replays -- so replay k must BE eager
+    iteration k: the same kernels in the same order on the same data.  Every sum of the library has a fixed order (split-K
+    and weight-gradient reductions, the statistics' two stages, and -- since round 5 -- the gather-form warp backward, which
+    was the one place fp32 atomics chose the order), so there is no noise to allow for:
+      * two eager runs are bit-identical (losses of every iteration, a sample of every parameter after every step);
+      * replay 0 equals eager iteration 0 BIT FOR BIT (losses and the parameters after the three Adam steps);
+      * replays 1-3 equal eager iterations 1-3 to 1e-5 relative (they are bit-equal too wherever the captured iteration and
+        the eager one run the same reduction forms; the bound only leaves room for MnkAdam.tap_direct, which reads the same
+        partial sums through another kernel)."""
     from mnk import engine, configs
     cfg = configs.get("moving-gif")
     src, drv = cases.synthetic_pair(32, 64, 64)
@@ -107,24 +126,33 @@ def test_full_size_training_iterations_graph_replay_equals_eager(mnk_adam):
 
     def run(use_graph, n):
         gen, disc, kpd = _models()
-        # the same (capturable, fused) Adam in both runs: Adam's first updates are sign-like, so two optimiser
-        # implementations separate quickly (tests/test_step.py) -- here only the launch mechanism may differ
+        # the same Adam in both runs -- only the launch mechanism differs
         step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=mnk_adam, use_graph=True)
-        out = []
+        losses, params = [], []
         for _ in range(n):
             g_l, d_l, _ = step.step(x) if use_graph else step._eager_step(x)
             torch.cuda.synchronize()
-            out.append([float(v) for v in g_l] + [float(v) for v in d_l])
-        return out
+            losses.append(torch.stack([v.detach().reshape(()).float() for v in list(g_l) + list(d_l)]).cpu())
+            params.append(_param_sample((gen, disc, kpd)))
+        return losses, params
 
-    def dev(p, q):
-        return max(abs(u - v) / max(1.0, abs(v)) for u, v in zip(p, q))
+    def bits(t):
+        return t.contiguous().view(torch.int32)
 
-    eager, eager2 = run(False, 5), run(False, 5)     # two identical eager runs: the yard-stick.  The fp32 atomics of
-    graph = run(True, 4)                             # the warp backward + Adam's sign-like first updates make them
-    for k in range(4):                               # separate by ~1e-2 within three iterations (measured: 2.1e-2)
-        a = graph[k]
-        assert all(v == v and abs(v) < 1e6 for v in a), ("non-finite loss in replay", k, a)
-        noise = dev(eager[k], eager2[k])
-        assert dev(a, eager[k]) <= 4 * noise + 5e-3, (k, dev(a, eager[k]), noise)
-        assert dev(a, eager[k]) < dev(a, eager[k + 1]), "replay k must be iteration k: the warm-up updates are undone"
+    def rel(p, q):
+        return float(((p.double() - q.double()).abs() / q.double().abs().clamp_min(1.0)).max())
+
+    (e_l, e_p), (e2_l, e2_p) = run(False, 4), run(False, 4)
+    for k in range(4):
+        assert torch.equal(bits(e_l[k]), bits(e2_l[k])), ("two eager runs differ in the losses of iteration", k, e_l[k], e2_l[k])
+        assert torch.equal(bits(e_p[k]), bits(e2_p[k])), ("two eager runs differ in the parameters after iteration", k)
+    g_l, g_p = run(True, 4)
+    for k in range(4):
+        assert bool(torch.isfinite(g_l[k]).all()) and float(g_l[k].abs().max()) < 1e6, ("non-finite loss in replay", k, g_l[k])
+    assert torch.equal(bits(g_l[0]), bits(e_l[0])), ("replay 0 != eager iteration 0 (losses)", g_l[0], e_l[0])
+    assert torch.equal(bits(g_p[0]), bits(e_p[0])), \
+        ("replay 0 != eager iteration 0 (parameters after the step)", float((g_p[0] - e_p[0]).abs().max()))
+    for k in range(1, 4):
+        assert rel(g_l[k], e_l[k]) <= 1e-5, ("replay k != eager iteration k (losses)", k, g_l[k], e_l[k])
+        assert rel(g_l[k], e_l[k]) < rel(g_l[k], e_l[k - 1]) or torch.equal(bits(g_l[k]), bits(e_l[k])), \
+            "replay k must be iteration k: the warm-up updates are undone"

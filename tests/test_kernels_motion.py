@@ -161,14 +161,82 @@ def test_deform(be, tag, shape, mode):
     be.call("mnk_deform_fwd", X, ld, c, h, w, FL, hf, wf, mode, OUT, ldo, off, n)
     DO = be.zeros(n, h, w, ldo)
     DO[..., off:off + c] = be.t(dout[:, :, 0].float().permute(0, 2, 3, 1))
-    DI, DF = be.zeros(n, h, w, ld), be.zeros(n, hf, wf, 2)
-    be.call("mnk_deform_bwd", X, ld, c, h, w, FL, hf, wf, mode, DO, ldo, off, DI, DF, n)
+    DI, DF = be.empty(n, h, w, ld), be.zeros(n, hf, wf, 2)
+    DI.fill_(float("nan"))                     # d input is WRITTEN by the gather pass (pad channels 0): no zero fill
+    nws = be.query("mnk_deform_bwd_workspace_floats", c, h, w, n)
+    WS = be.empty(nws)
+    be.call("mnk_deform_bwd", X, ld, c, h, w, FL, hf, wf, mode, DO, ldo, off, DI, DF, n, WS, nws)
     be.sync()
+    assert torch.all(DI.cpu()[..., c:] == 0)
     # white-noise image x (w-1)/2 coordinate scaling amplifies fp32 coordinate rounding to a few 1e-6
     assert maxerr(OUT.cpu()[..., off:off + c].permute(0, 3, 1, 2), ref[:, :, 0]) < 1e-5
     assert torch.all(OUT.cpu()[..., :off] == 0) and torch.all(OUT.cpu()[..., off + c:] == 0)
     assert relerr(from_nhwc(DI.cpu(), c), i64.grad[:, :, 0]) < 1e-5
     assert relerr(DF.cpu(), f64.grad[:, 0, :, :, :2]) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["collapse", "stripes", "far", "random"])
+@pytest.mark.parametrize("shape,mode", [((2, 5, 16, 16), 0), ((2, 70, 8, 8), 0), ((1, 4, 40, 24), 0), ((2, 6, 32, 32), 1),
+                                        ((1, 3, 1, 1), 0), ((1, 300, 2, 2), 0), ((1, 5, 128, 128), 0)])
+def test_deform_backward_is_deterministic_and_order_exact(be, kind, shape, mode):
+    """grid_sample's adjoint with colliding sampling points (the reference's CPU backward, generator.py:51-58, is a loop over
+    output pixels: a fixed-order sum per source texel).  The gather form must (a) give the same BITS on every run, also for
+    fields that send many pixels to one texel, and (b) equal an fp32 restatement of that pixel-ordered loop bit for bit --
+    nothing is summed in an order of the hardware's choosing."""
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w = shape
+    hf, wf = (16, 16) if h != 40 else (20, 12)
+    grid = restate.make_coordinate_grid(hf, wf).view(1, hf, wf, 2).repeat(n, 1, 1, 1)
+    if kind == "collapse":       # every pixel samples (nearly) the same point: one texel quad receives everything
+        field = torch.zeros(n, hf, wf, 2) + 0.13 + 1e-3 * torch.randn(n, hf, wf, 2, generator=g)
+    elif kind == "stripes":      # all rows sample one source row
+        field = grid.clone()
+        field[..., 1] = -0.31
+    elif kind == "far":          # most points outside [-1, 1] (zeros padding), some non-finite
+        field = grid * 3.0 + torch.randn(n, hf, wf, 2, generator=g)
+        field[0, 0, 0, 0] = float("inf")
+        field[0, 1, 1, 1] = float("nan")
+    else:
+        field = grid + 0.5 * torch.randn(n, hf, wf, 2, generator=g)
+    inp = torch.rand(n, h, w, ceil4(c), generator=g)
+    inp[..., c:] = 0
+    ld, ldo = ceil4(c), ceil4(c) + 4
+    dout = torch.randn(n, h, w, ldo, generator=g)
+    X, FL, DO = be.t(inp), be.t(field), be.t(dout)
+    nws = be.query("mnk_deform_bwd_workspace_floats", c, h, w, n)
+    runs = []
+    for _ in range(3):
+        DI, DF, WS = be.empty(n, h, w, ld), be.zeros(n, hf, wf, 2), be.empty(nws)
+        DI.fill_(float("nan"))
+        be.call("mnk_deform_bwd", X, ld, c, h, w, FL, hf, wf, mode, DO, ldo, 0, DI, DF, n, WS, nws)
+        be.sync()
+        runs.append((DI.cpu(), DF.cpu()))
+    for di, df in runs[1:]:
+        assert torch.equal(di.view(torch.int32), runs[0][0].view(torch.int32))
+        assert torch.equal(df.view(torch.int32), runs[0][1].view(torch.int32))
+    if kind == "far" or h * w > 4096 or mode != 0:
+        return
+    # (b) the pixel-ordered loop in fp32 with the kernels' own sampling arithmetic (nearest pick of the field: exact)
+    fl = restate.resize_field(torch.cat([field, torch.zeros(n, hf, wf, 1)], -1).view(n, 1, hf, wf, 3), (h, w),
+                              "nearest")[:, 0, :, :, :2].float()
+    want = torch.zeros(n, h, w, ld)
+    for b in range(n):
+        ix = ((fl[b, ..., 0] + 1.0) / 2.0) * float(w - 1)
+        iy = ((fl[b, ..., 1] + 1.0) / 2.0) * float(h - 1)
+        fx, fy = torch.floor(ix), torch.floor(iy)
+        for py in range(h):
+            for px in range(w):
+                x0, y0 = int(fx[py, px]), int(fy[py, px])
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        yy, xx = y0 + dy, x0 + dx
+                        if 0 <= yy < h and 0 <= xx < w:
+                            wx = (ix[py, px] - fx[py, px]) if dx else ((fx[py, px] + 1.0) - ix[py, px])
+                            wy = (iy[py, px] - fy[py, px]) if dy else ((fy[py, px] + 1.0) - iy[py, px])
+                            want[b, yy, xx, :c] += dout[b, py, px, :c] * (wx * wy)
+    got = runs[0][0]
+    # fused multiply-add contraction is the compiler's choice: equal to the last bit or two, not necessarily the same bits
+    assert maxerr(got, want) <= 4e-7 * float(want.abs().max() + 1)
 
 
 def test_deform_matches_reference_golden(be):
