@@ -86,6 +86,9 @@ def parse():
                          "statement sequence (three torch.optim.Adam, host dict batches through DataParallelWithCallback("
                          "device_ids=[0]), two discriminator passes, per-iteration .cpu() of the losses) -- reported as "
                          "`dropin`, never as `value`; 0: skip")
+    ap.add_argument("--taichi-leg", type=int, default=1,
+                    help="1 (default, one GPU): also time the taichi @ 64x64 batch-32 hot path (the stack BASELINE.json's 0.5-of-"
+                         "roofline target is worded on) -> `extra.taichi_b32`; 0: skip")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the iteration as one captured hipGraph, 0: eager launches, -1: graph on 1 GPU")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -256,7 +259,52 @@ def cpu_baseline(cfg, batch, size, steps, cfg_name=""):
                       "profiles/r04_reference_cpu_timing.json): %s" % (steps, batch, cores, dt, reference_cpu_row(cfg_name, batch, size))}
 
 
-def hot_path_only(step, x, iters, device):
+def prof_collect(lib, fn, steps):
+    """fn() `steps` times as real launches under the library's per-launch HIP-event recorder (mnk_prof_*): per kernel group
+    {launches, ms, algorithmic work, executed work} per call of fn."""
+    import ctypes
+    lib.cdll.mnk_prof_reset()
+    lib.cdll.mnk_prof_enable(1)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    lib.cdll.mnk_prof_enable(0)
+    kernels = {}
+    for k in range(lib.cdll.mnk_prof_num_kernels()):
+        n, ms, work, issued = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        lib.cdll.mnk_prof_query(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work))
+        lib.cdll.mnk_prof_query_executed(k, ctypes.byref(issued))
+        if n.value:
+            kernels[lib.cdll.mnk_prof_kernel_name(k).decode()] = {
+                "launches_per_step": n.value / steps, "ms_per_step": ms.value / steps,
+                "avg_us": ms.value / n.value * 1e3, "work_per_step": work.value / steps,
+                "executed_work_per_step": issued.value / steps}
+    lib.cdll.mnk_prof_reset()
+    return kernels
+
+
+def hot_path_record(hot_ms, hot_launch, hot_kernels, flops_total, batch):
+    """The `hot_path_only` object of the JSON line: algorithmic rate (3 x the forward's FLOPs of the true convolutions / time)
+    AND the executed one (the multiply-adds the GEMM launches of these very iterations issue -- the sub-pixel forms of the
+    up-sampled convolutions run 4/9 of the algorithmic ones) side by side."""
+    alg = 3 * flops_total * batch / (hot_ms * 1e-3) / 1e12
+    rec = {"what": "KPDetector + generator forward and backward (all weight gradients), no discriminator / losses / optimiser",
+           "launch": hot_launch, "ms": round(hot_ms, 3), "conv_tflops": round(alg, 2),
+           "counts": "algorithmic FLOPs (3 x forward) over the replay's wall time; executed_*: what the matrix pipe issues",
+           "frac_of_fp32_mfma_peak": round(alg / FP32_MFMA_PEAK_TFLOPS, 4)}
+    if hot_kernels:
+        conv = [hot_kernels[k] for k in ("conv3x3_igemm", "conv3x3_wgrad") if k in hot_kernels]
+        issued = sum(g["executed_work_per_step"] for g in conv)
+        counted = sum(g["work_per_step"] for g in conv)
+        rec["executed_tflops"] = round(issued / (hot_ms * 1e-3) / 1e12, 2)
+        rec["executed_frac"] = round(issued / (hot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+        rec["executed_gflop"] = round(issued / 1e9, 1)
+        rec["algorithmic_gflop_counted_by_the_launches"] = round(counted / 1e9, 1)
+        rec["gemm_kernel_ms"] = round(sum(g["ms_per_step"] for g in conv), 3)
+    return rec
+
+
+def hot_path_only(step, x, iters, device, lib=None):
     """the hot path alone -- KPDetector (source + driving frame) + generator forward, and their
     backward incl. every weight gradient, seeded with a fixed random dL/d(prediction); no discriminator, no losses, no
     optimiser.  Captured as one hipGraph like the full iteration and timed with HIP events over `iters` replays."""
@@ -300,7 +348,55 @@ def hot_path_only(step, x, iters, device):
         run()
     e1.record()
     torch.cuda.synchronize(device)
-    return e0.elapsed_time(e1) / iters, launch
+    ms = e0.elapsed_time(e1) / iters
+    if lib is None:
+        return ms, launch
+    return ms, launch, prof_collect(lib, one, 2)      # the same iteration as real launches: what its GEMMs issue
+
+
+def taichi_b32_leg(lib, device, steps):
+    """BASELINE.json's target is worded on "the 64x64 generator conv stack at batch 32" with the taichi hyper-parameters
+    (174.9 GFLOP forward); the headline workload of this file is moving-gif (configs[1]).  This leg puts
+    that stack on the same clock: the hot path alone as a hipGraph replay, algorithmic and executed fraction of the fp32 MFMA
+    peak side by side, and the whole training iteration of the configuration next to it."""
+    from mnk import configs, engine, workload
+    cfg = configs.get("taichi")
+    gen, disc, kpd = build_models(cfg, device)
+    src, drv = workload.synthetic_pair(32, 64, 64, seed=4321)
+    x = {"source": src.to(device), "video": drv.to(device)}
+    eager = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+    for _ in range(2):
+        eager.step(x)
+    torch.cuda.synchronize(device)
+    hot_ms, hot_launch, hot_k = hot_path_only(eager, x, max(steps, 10), device, lib)
+    flops = workload.conv_flops_hot_path(cfg, 64, 64)
+    out = {"workload": "taichi model params @ 64x64, batch 32, one GPU",
+           "hot_path_conv_gflop_fwd_per_pair": round(flops["total"] / 1e9, 3),
+           "hot_path_only": hot_path_record(hot_ms, hot_launch, hot_k, flops["total"], 32)}
+    conv = hot_k.get("conv3x3_igemm")
+    if conv:
+        out["roofline"] = {"kernel": "conv3x3_igemm*: forward + data-gradient launches of the hot path", "bound": "mfma",
+                           "achieved": round(conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12, 2),
+                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "executed_frac": round(conv["executed_work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12
+                                                  / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "launches": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2)}
+    try:
+        gen2, disc2, kpd2 = build_models(cfg, device)
+        step = engine.TrainStep(gen2, disc2, kpd2, cfg["train_params"], use_graph=True)
+        for _ in range(3):
+            step.step(x)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(max(steps, 10)):
+            step.step(x)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / max(steps, 10)
+        out["full_iteration"] = {"ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(32 / dt, 1), "launch": "hipGraph replay"}
+    except Exception as e:    # never lose the leg to the extra number
+        out["full_iteration"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
 def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):
@@ -543,27 +639,11 @@ def main():
     roofline = None
     kernels = {}
     if not args.no_profile:      # every rank runs the profiled steps (they contain the SyncBN / gradient collectives)
-        import ctypes
-        lib.cdll.mnk_prof_reset()
-        lib.cdll.mnk_prof_enable(1)
-        prof_steps = 2
         for o in (getattr(eager, "opt_g", None), getattr(eager, "opt_d", None), getattr(eager, "opt_k", None)):
             if hasattr(o, "reducer"):
                 o.reducer.bg_macs = 0.0      # as in a captured iteration: no weight-gradient GEMMs running under other kernels
-        for _ in range(prof_steps):
-            eager.step(x)      # event timing needs real launches (a graph replay bypasses the recorder)
-        torch.cuda.synchronize(device)
-        lib.cdll.mnk_prof_enable(0)
-        for k in range(lib.cdll.mnk_prof_num_kernels()):
-            n, ms, work, issued = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-            lib.cdll.mnk_prof_query(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work))
-            lib.cdll.mnk_prof_query_executed(k, ctypes.byref(issued))
-            if n.value:
-                kernels[lib.cdll.mnk_prof_kernel_name(k).decode()] = {
-                    "launches_per_step": n.value / prof_steps, "ms_per_step": ms.value / prof_steps,
-                    "avg_us": ms.value / n.value * 1e3, "work_per_step": work.value / prof_steps,
-                    "executed_work_per_step": issued.value / prof_steps}
-        lib.cdll.mnk_prof_reset()
+        # event timing needs real launches (a graph replay bypasses the recorder)
+        kernels = prof_collect(lib, lambda: eager.step(x), 2)
         conv = kernels.get("conv3x3_igemm")
         traffic, traffic_src = None, None
         pmc_file = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s_b%d.json" % (PMC_ROUND, args.config, args.batch))
@@ -635,12 +715,19 @@ def main():
                 dropin["eval_frame_loop"] = frame_loop(cfg, args.size, device)
             except Exception as e:
                 dropin["eval_frame_loop"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    hot_ms, hot_launch = None, None
+    hot_ms, hot_launch, hot_kernels = None, None, None
+    extra = {}
     if not args.no_profile and not dist_mode:
         try:
-            hot_ms, hot_launch = hot_path_only(eager, x, max(args.steps, 10), device)
+            hot_ms, hot_launch, hot_kernels = hot_path_only(eager, x, max(args.steps, 10), device, lib)
         except Exception as e:   # never lose the bench line to the extra measurement
             sys.stderr.write("hot-path-only measurement failed: %s: %s\n" % (type(e).__name__, e))
+        if args.taichi_leg and rank == 0 and not (args.config == "taichi" and args.batch == 32 and args.size == 64):
+            try:
+                extra["taichi_b32"] = taichi_b32_leg(lib, device, args.steps)
+            except Exception as e:
+                extra["taichi_b32"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
     if world > 1 or force_dist:
         dist.barrier()
 
@@ -666,13 +753,9 @@ def main():
                        "launch": launch,
                        "hot_path_conv_gflop_fwd_per_pair": round(flops["total"] / 1e9, 3)},
             "hot_path_only_ms": None if hot_ms is None else round(hot_ms, 3),
-            "hot_path_only": None if hot_ms is None else {
-                "what": "KPDetector + generator forward and backward (all weight gradients), no discriminator / losses / "
-                        "optimiser", "launch": hot_launch,
-                "conv_tflops": round(3 * flops["total"] * args.batch / (hot_ms * 1e-3) / 1e12, 2),
-                "counts": "algorithmic FLOPs (3 x forward); see roofline.executed_frac for what the matrix pipe issues",
-                "frac_of_fp32_mfma_peak": round(3 * flops["total"] * args.batch / (hot_ms * 1e-3) / 1e12
-                                                / FP32_MFMA_PEAK_TFLOPS, 4)},
+            "hot_path_only": None if hot_ms is None else hot_path_record(hot_ms, hot_launch, hot_kernels, flops["total"],
+                                                                          args.batch),
+            "extra": extra,
             "roofline": roofline, "roofline_all_conv": roofline_all, "cpu_baseline": cpu, "kernels": kernels,
             "capture_failed": bool(capture_failed),
             "dropin": dropin,

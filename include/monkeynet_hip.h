@@ -328,6 +328,9 @@ int mnk_wgrad_reduce_blocks(int splits, int Cout, int C);
  * kernel sources, e.g. "split_tiles", "wgroup_chunk", "wtap_target", "bn_rpt") are not environment switches: a tuning script
  * sets one by name here; an A/B visit may pass them all in ONE environment variable, MNK_TUNING="name=value,name=value" */
 int mnk_set_tuning(const char* name, int value);
+/* the live value (whatever set it: the default, MNK_TUNING or mnk_set_tuning) -- host code that must follow a tuning value
+ * (mnk.ops.subpixel: "up_subpixel") reads it here instead of parsing the environment */
+int mnk_get_tuning(const char* name, int* value);
 /* the forward / data-gradient GEMM's launch plan is a rule (tile by channel count, 64-row tiles and split-K for few-tile
  * layers) overridden, for the benchmark configurations' layer shapes, by plans measured on the MI355X (csrc/plan_table.h;
  * "plan_table" = 0 ignores it).  "force_bm" / "force_bn" / "force_splits" (mnk_set_tuning, 0 = off) force a plan for the

@@ -9,6 +9,10 @@ namespace mnk {
 constexpr int P2P_SLOTS = 4;
 constexpr int P2P_MAXF = 2048 + 64;       // floats per message: [sum, sum of squares] of <= 1024 channels (+ slack)
 constexpr int P2P_MAX_WORLD = 16;
+// what an exchange that gave up on a peer (timeout) reads in place of that peer's value: a quiet NaN.  The statistics -- and
+// with them the losses -- of every rank that waited become NaN instead of silently wrong; the handle's error word says which
+// rank was missing (mnk_p2p_error), and mnk.engine.TrainStep polls it.
+constexpr unsigned long long P2P_POISON = 0x7fc00000ull;
 
 struct PeerTable {
     unsigned long long* box[P2P_MAX_WORLD];      // every rank's mailbox as mapped into THIS process (box[rank] = the local one)
@@ -30,7 +34,8 @@ __device__ __forceinline__ unsigned long long* row_of(unsigned long long* box, i
 
 // one value of exchange `seq`: push it into row `rank` of every mailbox (lane q of the calling wave serves peer q), then poll the
 // own mailbox's row q (lane q) and add the `world` values in rank order.  Called by one whole wavefront; returns the sum in every
-// lane.  `gave_up` is raised (and state[1] set) when a peer's word did not arrive within timeout_ticks of the 100 MHz wall clock.
+// lane.  state[1] is set -- and the peer's value replaced by NaN -- when its word did not arrive within timeout_ticks of the 100 MHz
+// wall clock.
 __device__ __forceinline__ float p2p_exchange_value(const PeerTable& peers, int rank, int world, int slot, unsigned seq, int index,
                                                     float value, unsigned* state, unsigned long long timeout_ticks) {
     const int lane = threadIdx.x & 63;
@@ -41,10 +46,13 @@ __device__ __forceinline__ float p2p_exchange_value(const PeerTable& peers, int 
                            __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long* w = row_of(peers.box[rank], world, slot, lane) + index;
         const unsigned long long t0 = wall_clock64();
+        // a handle that already gave a peer up does not wait again: every later exchange of the run ends at once (poisoned)
+        const unsigned long long limit = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0ull : timeout_ticks;
         unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while ((unsigned)(v >> 32) != seq) {
-            if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+            if ((unsigned long long)wall_clock64() - t0 > limit) {
                 __hip_atomic_store(state + 1, 1u + (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = P2P_POISON;       // a stale word must never pass for the peer's value: the sum becomes NaN
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -72,10 +80,13 @@ __device__ __forceinline__ float p2p_exchange_values(const PeerTable& peers, int
                            __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long* w = row_of(peers.box[rank], world, slot, q) + index;
         const unsigned long long t0 = wall_clock64();
+        // a handle that already gave a peer up does not wait again: every later exchange of the run ends at once (poisoned)
+        const unsigned long long limit = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0ull : timeout_ticks;
         unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while ((unsigned)(v >> 32) != seq) {
-            if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+            if ((unsigned long long)wall_clock64() - t0 > limit) {
                 __hip_atomic_store(state + 1, 1u + (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                v = P2P_POISON;       // a stale word must never pass for the peer's value: the sum becomes NaN
                 break;
             }
             __builtin_amdgcn_s_sleep(1);

@@ -22,7 +22,8 @@
 // Slot reuse: a rank finishes exchange q + 1 only after every peer pushed q + 1, which a peer does only after it finished
 // READING q -- so when a rank pushes q + 2 nobody reads slot q any more: two slots suffice, four are used.
 // A peer that never arrives would hang the GPU: the polling gives up after `timeout_ms` (wall clock), raises the handle's
-// device error word (mnk_p2p_error) and lets the kernel finish with whatever it has.
+// device error word (mnk_p2p_error), puts NaN in place of the missing values (never a stale word) and lets the kernel finish;
+// once the error word is set no later exchange waits again.
 #include <string.h>
 
 #include <vector>
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int
     // ---- poll + sum in rank order (every rank: the same order, the same bits)
     const unsigned long long t0 = wall_clock64();
     bool gave_up = false;
+    if (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) timeout_ticks = 0;    // (see p2p.h: no second wait)
 #pragma unroll
     for (int k = 0; k < (P2P_MAXF + 255) / 256; ++k) {
         const int i = t + 256 * k;
@@ -80,6 +82,7 @@ __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int
                 __builtin_amdgcn_s_sleep(1);
                 v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            if ((unsigned)(v >> 32) != seq) v = P2P_POISON;     // gave up: NaN, never a stale word
             s += __uint_as_float((unsigned)v);
         }
         out[i] = s;

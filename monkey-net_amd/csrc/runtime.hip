@@ -150,6 +150,17 @@ int mnk_set_tuning(const char* name, int value) {
     return MNK_EINVAL;
 }
 
+int mnk_get_tuning(const char* name, int* value) {
+    MNK_REQUIRE(name && value);
+    for (const mnk::Knob& k : mnk::knob_registry())
+        if (strcmp(k.name, name) == 0) {
+            *value = *k.slot;
+            return MNK_OK;
+        }
+    mnk::set_error("mnk_get_tuning: unknown tuning value %s", name);
+    return MNK_EINVAL;
+}
+
 int mnk_version(void) { return 100; }
 const char* mnk_last_error(void) { return mnk::g_err; }
 int mnk_is_device_build(void) {

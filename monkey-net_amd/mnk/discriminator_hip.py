@@ -1,10 +1,10 @@
 """Patch discriminator of the training step (modules/discriminator.py), first "next" row of SURVEY.md section 8f, on the
-same gfx950 kernels as the hot path; `modules.discriminator.Discriminator` resolves to this class (MNK_NATIVE_DISC=0
-selects the stock-op twin).
+same gfx950 kernels as the hot path; `modules.discriminator.Discriminator` resolves to this class (the only backend: the
+stock-op twin of round 1 and its switch were deleted in round 3).
 
-Measured on the MI355X (profiles/README.md): its layers are tiny (61x61x13 -> ... -> 2x2x256 at batch 32), so with four
-separate passes per iteration it only matched the stock-op network (MIOpen Winograd / implicit-GEMM kernels): 16.48 vs
-16.47 ms per moving-gif iteration.  With the generated and the real frames of a pass batched into one call
+Measured on the MI355X in round 1 (profiles/README.md): its layers are tiny (61x61x13 -> ... -> 2x2x256 at batch 32), so
+with four separate passes per iteration it only matched a stock-op network (MIOpen Winograd / implicit-GEMM kernels):
+16.48 vs 16.47 ms per moving-gif iteration.  With the generated and the real frames of a pass batched into one call
 (mnk.engine.discriminate_pair -- every layer here is per sample) it wins: 15.41 vs 15.62 ms.
 
 Kernels: the (1,4,4) convolutions without padding run on the implicit-GEMM conv kernels

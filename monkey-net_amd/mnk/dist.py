@@ -93,7 +93,11 @@ def direct_comm(kind="main"):
 # carries the 64-byte IPC handles once.  Used when every rank of the group runs on this host (one process per GPU of one node:
 # the deployment BASELINE.json names); otherwise -- or with MNK_SYNCBN_P2P=0 -- the RCCL path below.
 _P2P = {"tried": False, "handle": None, "max": 0}
-P2P_TIMEOUT_MS = 20000
+# How long a rank's kernel polls for a peer's word (wall clock).  Long: a rank that is merely late -- a checkpoint or the
+# visualiser on rank 0, the first iteration's capture -- must not be given up on; bounded: a dead peer must not hang the
+# GPU for good.  A give-up is never silent: the exchanged sums become NaN (csrc/p2p.h: P2P_POISON), every later exchange
+# gives up at once (the error word is set), and TrainStep / check_p2p() raise.
+P2P_TIMEOUT_MS = int(knobs.get("MNK_P2P_TIMEOUT_MS"))
 
 
 def p2p_comm(force=False):
@@ -185,6 +189,16 @@ def p2p_error():
     flag = ctypes.c_int(0)
     _lib.lib().call("mnk_p2p_error", ctypes.c_void_p(_P2P["handle"]), ctypes.byref(flag))
     return int(flag.value)
+
+
+def check_p2p():
+    """Raise if a peer-to-peer exchange gave a rank up (synchronises the device; TrainStep calls it every few iterations, a
+    user-owned loop may call it before it writes a checkpoint)."""
+    code = p2p_error()
+    if code:
+        raise RuntimeError("SyncBN peer-to-peer exchange: rank %d did not deliver its statistics within %d ms; the sums of "
+                           "this rank were poisoned with NaN (MNK_P2P_TIMEOUT_MS, MNK_SYNCBN_P2P=0 for the RCCL path)"
+                           % (code - 1, P2P_TIMEOUT_MS))
 
 
 def _p2p_sum(t, out):

@@ -153,6 +153,7 @@ class TrainStep:
         self._static_out = None
         self._weights_touched = True          # packed weights must be (re)made before the next iteration
         self._shard_checked = None            # batch size the ranks were last found to agree on (mnk.dist.check_equal_shards)
+        self._iterations = 0
         if self.mnk_adam:
             from . import optim as moptim
             self.opt_g = moptim.MnkAdam(generator.parameters(), lr=lr, betas=(0.5, 0.999))
@@ -197,6 +198,9 @@ class TrainStep:
         optimiser state back, so that every call -- the first one included -- applies exactly one update.  With
         use_graph the returned losses and `generated` are static buffers that the next call overwrites: clone what
         must survive."""
+        self._iterations += 1
+        if mdist._P2P["handle"] is not None and self._iterations % 32 == 0:
+            mdist.check_p2p()                 # a peer that an exchange gave up on: raise, do not train on poisoned statistics
         if not self.use_graph:
             return self._eager_step(x)
         if self._graph is None:

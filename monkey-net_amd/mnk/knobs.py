@@ -19,6 +19,8 @@ KNOBS = {
                              "communicator on the kernels' stream (0: through torch.distributed)"),
     "MNK_SYNCBN_P2P": ("1", "one node, nccl backend: the SyncBN sums are exchanged by the library's own peer-to-peer kernel over "
                             "IPC-mapped buffers (csrc/p2p.hip) instead of one RCCL all-reduce per norm layer and direction"),
+    "MNK_P2P_TIMEOUT_MS": ("120000", "peer-to-peer SyncBN exchange: milliseconds a rank waits for a peer's word before it gives the "
+                                     "peer up (the sums then become NaN and mnk.dist.p2p_error() names the rank; TrainStep raises)"),
     "MNK_DP_SCATTER": ("broadcast", "DataParallelWithCallback under a process group: rank 0's batch is broadcast and every rank "
                                      "takes its slice (DataParallel's scatter); slice: trust identical batches; off: no scatter"),
     "MNK_GRAPH_DEADLINE_S": ("", "bench.py under a process group: seconds the hipGraph capture may take before the eager time stands"),

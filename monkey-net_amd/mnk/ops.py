@@ -296,6 +296,9 @@ def _after_optimizer_step(opt, args, kwargs):
     `Tensor._version`, so the version check alone cannot see it).  An optimiser that wrote the packed layouts itself
     (mnk.optim.MnkAdam) hands its entries over to be stamped fresh."""
     _PACK_EPOCH[0] += 1
+    # hand-overs of a backward pass that nobody picked up (a gradient that autograd summed with another one first) hold GPU
+    # tensors: a user-owned loop -- the reference's train.py on these modules -- never calls clear_dz_stats() (ADVICE r4)
+    _DZ_STATS.clear()
     for g in opt.param_groups:
         for p in g["params"]:
             e = _PACK_REG.get(id(p))
@@ -349,17 +352,17 @@ def pack_entry_of(p):
     return None
 
 
-_SUBPIXEL_TOLD = [None, None]       # (library object, value) the library's own "up_subpixel" tuning value was last set to
-
-
 def subpixel(ups):
     """UpBlock3D convolutions run in their sub-pixel forms (mnk_conv3x3_up_*) -- 13.87 -> 12.62 ms per step in round 2; the 3x3
     convolution over the up-sampled view stays for the operands the sub-pixel kernels do not take (a residual input) and, for
-    A/B runs, behind the library's "up_subpixel" tuning value (MNK_TUNING=up_subpixel=0), which this function follows."""
-    lib = _lib.lib()
-    if _SUBPIXEL_TOLD[0] is not lib:
-        _SUBPIXEL_TOLD[0], _SUBPIXEL_TOLD[1] = lib, "up_subpixel=0" not in knobs.get("MNK_TUNING").replace(" ", "")
-    return bool(ups) and _SUBPIXEL_TOLD[1]
+    A/B runs, behind the library's "up_subpixel" tuning value (MNK_TUNING=up_subpixel=0 or mnk_set_tuning), whose LIVE value
+    this function reads (mnk_get_tuning: the library's weight-gradient plans follow the same integer)."""
+    if not ups:
+        return False
+    import ctypes
+    v = ctypes.c_int(1)
+    _lib.lib().call("mnk_get_tuning", b"up_subpixel", ctypes.byref(v))
+    return bool(v.value)
 
 
 def _packed_fwd_weight(weight, cout, c0, c1, up=False):
@@ -557,11 +560,11 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
             sums = st                          # per-block partials: finished together with the finalisation (bn_act)
         elif nst:
             sums = torch.empty(2 * cout, dtype=torch.float32, device=x0.device)
-            h = _sync_handle()
-            if h is not None:                  # second stage + exchange over the ranks in one launch
-                _call("mnk_bn_stats_finish_sync", x0, h, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, None, _p(sums),
+            sh = _sync_handle(cout)
+            if sh is not None:                 # second stage + exchange over the ranks in one launch
+                _call("mnk_bn_stats_finish_sync", x0, sh, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, None, _p(sums),
                       mdist.P2P_TIMEOUT_MS)
-                _REDUCED.add(sums.data_ptr())
+                _mark_reduced(sums)
             else:
                 _call("mnk_bn_stats_finish", x0, _p(st), nst // (2 * y.shape[-1]), y.shape[-1], cout, _p(sums))
         elif mdist.active():
@@ -571,16 +574,31 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
     return y, sums
 
 
-_REDUCED = set()       # data pointers of statistics vectors that already hold the sums over the ranks (see _sync_handle)
+# statistics vectors that already hold the sums over the ranks (see _sync_handle): data pointer -> weak reference to the
+# tensor.  The entry dies WITH the tensor (its finaliser removes it), so an unconsumed entry -- an exception mid-forward, a
+# norm layer whose .training differs from the block's -- can never mark whatever the allocator puts at that address next
+# (ADVICE r4).
+_REDUCED = {}
 
 
-def _sync_handle():
+def _mark_reduced(t):
+    key = t.data_ptr()
+    _REDUCED[key] = weakref.ref(t, lambda _r, key=key: _REDUCED.pop(key, None))
+
+
+def _take_reduced(t):
+    return _REDUCED.pop(t.data_ptr(), None) is not None
+
+
+def _sync_handle(c=0):
     """The connected peer-to-peer exchange (csrc/p2p.hip) when the BatchNorm statistics of this process are exchanged by it: the
-    statistics' second stage then carries the exchange itself (mnk_bn_*_sync: one launch instead of second stage + collective)."""
+    statistics' second stage then carries the exchange itself (mnk_bn_*_sync: one launch instead of second stage + collective).
+    c: the layer's channel count -- 2c sums must fit a mailbox row (mnk_p2p_max_floats: 1056 channels), wider layers take the
+    collective path."""
     if not mdist.active():
         return None
     h = mdist.p2p_comm()
-    if h is None:
+    if h is None or 2 * c > mdist._P2P["max"]:
         return None
     import ctypes
     return ctypes.c_void_p(h)
@@ -594,10 +612,10 @@ def channel_sums(a, c, sync=False):
     nws = _query("mnk_bn_workspace_floats", rows, ld)
     ws = SCRATCH.get("ws", nws, a)
     sums = torch.empty(2 * c, dtype=torch.float32, device=a.device)
-    h = _sync_handle() if sync else None
+    h = _sync_handle(c) if sync else None
     if h is not None:
         _call("mnk_bn_stats_sync", a, h, _p(a), ld, rows, c, None, _p(sums), _p(ws), nws, mdist.P2P_TIMEOUT_MS)
-        _REDUCED.add(sums.data_ptr())
+        _mark_reduced(sums)
         return sums
     _call("mnk_bn_stats", a, _p(a), ld, rows, c, _p(sums), _p(ws), nws)
     return sums
@@ -891,8 +909,8 @@ class BNActFn(_Fn):
                                  "(sync_batchnorm/batchnorm.py:116)")
             if mdist.active():
                 sums = pre_sums if pre_sums is not None and pre_sums.numel() == 2 * c else channel_sums(y, c, sync=True)
-                if sums.data_ptr() in _REDUCED:          # the statistics' second stage carried the exchange
-                    _REDUCED.discard(sums.data_ptr())
+                if _take_reduced(sums):                  # the statistics' second stage carried the exchange
+                    pass
                 else:
                     sums = mdist.all_reduce_sum(sums) if sums is pre_sums else mdist.all_reduce_sum_(sums)
                 count *= mdist.world_size()
@@ -958,7 +976,7 @@ class BNActFn(_Fn):
             else:
                 _DY_SUMS[0] = (dy, None)
             return dy, sums[c:], sums[:c], None, None, None, None, None, None, None, None, None
-        sync = _sync_handle() if training else None      # several ranks: the second stage carries the exchange of the sums
+        sync = _sync_handle(c) if training else None      # several ranks: the second stage carries the exchange of the sums
         if (sync is not None and _small_sync(rows) and ld == ceil4(c) and 2 * c <= mdist._P2P["max"]
                 and (not pool or (h % 2 == 0 and w % 2 == 0))):
             # a small layer on one rank of several: statistics, their exchange and the apply pass in ONE launch, as the
