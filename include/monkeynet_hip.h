@@ -143,7 +143,7 @@ int mnk_bn_act_bwd_apply_add_colsum(const float* y, int ld_y, const float* dz, i
  * channels over all rows, so the column sums never leave it.  Forward: optionally sums the split-K partials `ws`
  * ([split][phase][M][ldw], what mnk_conv3x3_fwd / mnk_conv3x3_up_fwd leave behind under MNK_CONV_DEFER_SPLITK) + bias into y
  * first; then statistics, mean / inv-std / scale, running statistics (batchnorm.py:113-125) and the apply pass
- * (util.py:56-57,81-87,100-107).  Backward: sums = [dbeta | dgamma], dy.  Not for SyncBN over several ranks. */
+ * (util.py:56-57,81-87,100-107).  Backward: sums = [dbeta | dgamma], dy.  Several ranks: mnk_bn_small_fwd_sync / _bwd_sync. */
 int mnk_bn_small_rows(void);
 int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const float* bias, float* y, int ld_y, int N, int H, int W,
                      int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
@@ -452,6 +452,14 @@ int mnk_bn_act_bwd_stats_sync(void* p2p, const float* y, int ld_y, const float* 
 int mnk_bn_small_bwd_sync(void* p2p, const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,
                           const float* scale, const float* beta, double count_all_ranks, int N, int H, int W, int C, int relu,
                           int pool, float* sums_local, float* dy, int ld_dy, int timeout_ms, void* stream);
+/* mnk_bn_small_fwd for one rank of a data-parallel run (round 5, the forward twin): split-K reduction + bias, this rank's column
+ * sums, their exchange (eight per channel quad, one round trip), mean / inv-std / scale and the running statistics from the sums
+ * over ALL ranks (count = N*H*W * world), and the apply pass -- one launch.  Replaces sync_batchnorm/batchnorm.py:55-78 with its
+ * reduce-to-master + broadcast (:95-111) for the few-pixel layers. */
+int mnk_bn_small_fwd_sync(void* p2p, const float* ws, int splits, int ldw, int phases, const float* bias, float* y, int ld_y, int N,
+                          int H, int W, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale, float* z, int ld_z, int relu, int pool,
+                          int timeout_ms, void* stream);
 int mnk_p2p_max_floats(void);
 int mnk_p2p_create(int rank, int world, void** handle_out);
 int mnk_p2p_export(void* handle, void* ipc_handle64);

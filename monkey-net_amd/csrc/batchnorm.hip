@@ -643,7 +643,16 @@ struct SmallFwdArgs {
     int ld_z, relu, pool, tx_n;
 };
 
-__global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) {
+// Exchange: what happens to the block's column sums before they become statistics -- nothing on one GPU (SmallNoExchange), the
+// peer-to-peer exchange over the ranks of the node (SmallP2PExchange: one channel quad per block, tx_n = 1)
+struct SmallNoExchange {
+    __device__ __forceinline__ int world_size() const { return 1; }
+    __device__ __forceinline__ void all_ranks(float4&, float4&, int, int) const {}
+    __device__ __forceinline__ void finish() const {}
+};
+
+template <class Exchange>
+__device__ __forceinline__ void bn_small_fwd_body(const SmallFwdArgs& a, const Exchange& xch) {
     __shared__ float4 red0[1024], red1[1024];
     const int tx_n = a.tx_n, ty_n = blockDim.x / tx_n;
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
@@ -704,7 +713,8 @@ __global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) {
         }
     }
     small_tree_sum2(red0, red1, s1, s2, tx_n, ty_n, tx, ty);       // also orders the y writes of the block before the reads below
-    const double count = (double)rows;
+    xch.all_ranks(s1, s2, q, a.C);                                 // (several ranks: the sums over all of them, in rank order)
+    const double count = (double)rows * xch.world_size();
     float mq[4], sq[4], iq[4];
     const float t1[4] = {s1.x, s1.y, s1.z, s1.w}, t2[4] = {s2.x, s2.y, s2.z, s2.w};
 #pragma unroll
@@ -726,7 +736,10 @@ __global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) {
             a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
         }
     }
-    if (!qok) return;
+    if (!qok) {
+        xch.finish();
+        return;
+    }
     const float4 be = ld4_guard(a.beta, q, a.C);
     const float slope = a.relu ? 0.f : -1.f;
     const float4 m = make_float4(mq[0], mq[1], mq[2], mq[3]), sc = make_float4(sq[0], sq[1], sq[2], sq[3]);
@@ -759,7 +772,10 @@ __global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) {
             *reinterpret_cast<float4*>(a.z + (long)r * a.ld_z + q * 4) = o;
         }
     }
+    xch.finish();
 }
+
+__global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) { bn_small_fwd_body(a, SmallNoExchange()); }
 
 __global__ void __launch_bounds__(1024) bn_small_bwd_kernel(BwdLoader L, double count, int rows, int nv, int tx_n,
                                                             float* __restrict__ sums, float* __restrict__ dy, int ld_dy) {
@@ -877,6 +893,48 @@ __global__ void __launch_bounds__(256) bn_small_bwd_sync_kernel(BwdLoader L, dou
         *reinterpret_cast<float4*>(dy + (long)r * ld_dy + q * 4) = o;
     }
     p2p_finish_launch(state, seq);
+}
+
+// bn_small_fwd_kernel of one rank of a data-parallel run (the forward twin of the kernel above, round 5): ONE channel quad per
+// block; after the block's tree sum wave 0 exchanges the quad's eight sums (sum, sum of squares of four channels) with every rank
+// of the node in one round trip, and the statistics, the running statistics and the apply pass are made from the sums over ALL
+// ranks (count = rows * world) -- split-K reduction, statistics, exchange, finalisation and apply of a small layer in one
+// launch, as on a single GPU.  Replaces sync_batchnorm/batchnorm.py:55-78 (+ the reduce / broadcast of :95-111) for these layers.
+struct SmallP2PExchange {
+    PeerTable peers;
+    int rank, world;
+    unsigned* state;
+    unsigned long long timeout_ticks;
+    unsigned seq;
+    __device__ __forceinline__ int world_size() const { return world; }
+    __device__ __forceinline__ void all_ranks(float4& s1, float4& s2, int q, int C) const {
+        __shared__ float glob[8];
+        const int t = threadIdx.x, slot = (int)(seq % P2P_SLOTS);
+        const float av[4] = {s1.x, s1.y, s1.z, s1.w}, bv[4] = {s2.x, s2.y, s2.z, s2.w};
+        if (t < 64) {                                          // wave 0: value j = lane / W of {s1.xyzw, s2.xyzw}
+            const int W = world <= 8 ? 8 : 16, per = 64 / W;
+            for (int j0 = 0; j0 < 8; j0 += per) {
+                const int j = j0 + t / W, e = j & 3, c = q * 4 + e;
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e == k) v = j < 4 ? av[k] : bv[k];
+                const int index = (j < 8 && c < C) ? (j < 4 ? c : C + c) : -1;
+                const float all = p2p_exchange_values(peers, rank, world, slot, seq, index, v, state, timeout_ticks);
+                if ((t & (W - 1)) == 0 && j < 8) glob[j] = all;
+            }
+        }
+        __syncthreads();
+        s1 = make_float4(glob[0], glob[1], glob[2], glob[3]);
+        s2 = make_float4(glob[4], glob[5], glob[6], glob[7]);
+    }
+    __device__ __forceinline__ void finish() const { p2p_finish_launch(state, seq); }
+};
+
+__global__ void __launch_bounds__(256) bn_small_fwd_sync_kernel(SmallFwdArgs a, PeerTable peers, int rank, int world, unsigned* state,
+                                                                unsigned long long timeout_ticks) {
+    SmallP2PExchange x{peers, rank, world, state, timeout_ticks, state[0] + 1};
+    bn_small_fwd_body(a, x);
 }
 #endif
 
@@ -1241,6 +1299,35 @@ int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const flo
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(ld_y / 4, a.tx_n)), dim3(threads), 0, s, a);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
+}
+
+int mnk_bn_small_fwd_sync(void* p2p, const float* ws, int splits, int ldw, int phases, const float* bias, float* y, int ld_y, int N,
+                          int H, int W, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          float momentum, float eps, float* mean, float* invstd, float* scale, float* z, int ld_z, int relu, int pool,
+                          int timeout_ms, void* stream) {
+    MNK_REQUIRE(p2p && y && gamma && beta && running_mean && running_var && mean && invstd && scale && z && N > 0 && H > 0 && W > 0);
+    MNK_REQUIRE(C > 0 && ld_y % 4 == 0 && ld_y == round_up(C, 4) && ld_z == ld_y && (long)N * H * W <= 4096 && timeout_ms > 0);
+    MNK_REQUIRE(!ws || (splits >= 1 && ldw == ld_y && (phases == 1 || (phases == 4 && H % 2 == 0 && W % 2 == 0))));
+    MNK_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0));
+#ifdef HIPEMU
+    return MNK_ECOMM;
+#else
+    PeerTable peers;
+    int rank = 0, world = 0;
+    unsigned* state = nullptr;
+    if (!p2p_launch_info(p2p, &peers, &rank, &world, &state) || 2 * C > P2P_MAXF) {
+        set_error("mnk_bn_small_fwd_sync: the peer-to-peer exchange is not connected, or more than %d channels", P2P_MAXF / 2);
+        return MNK_ECOMM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_APPLY, s, (double)N * H * W * C * 4 * 3.0);
+    SmallFwdArgs a{ws, splits, ldw, phases, bias, y, ld_y, N, H, W, C, gamma, beta, running_mean, running_var, momentum, eps,
+                   mean, invstd, scale, z, ld_z, relu, pool, 1};
+    hipLaunchKernelGGL(bn_small_fwd_sync_kernel, dim3(ld_y / 4), dim3(256), 0, s, a, peers, rank, world, state,
+                       (unsigned long long)timeout_ms * 100000ull);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+#endif
 }
 
 int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,

@@ -504,9 +504,13 @@ def _small_sync(rows):
     return mdist.active() and 1 < rows <= _query("mnk_bn_small_rows") and _sync_handle() is not None
 
 
-def small_bn(rows, training=True):
-    """the one-launch BatchNorm forms of small layers apply: single rank, training statistics, few pixel rows"""
-    return (training and not mdist.active() and 1 < rows <= _query("mnk_bn_small_rows"))
+def small_bn(rows, training=True, c=0):
+    """the one-launch BatchNorm forms of small layers apply: training statistics, few pixel rows (per rank), and either a
+    single rank or -- several ranks -- the peer-to-peer exchange up (mnk_bn_small_fwd_sync / _bwd_sync carry it inside the
+    launch; a layer of c channels must fit a mailbox row)"""
+    if not (training and 1 < rows <= _query("mnk_bn_small_rows")):
+        return False
+    return not mdist.active() or _sync_handle(c) is not None
 
 
 def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_stats=False, up=False):
@@ -518,7 +522,7 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
     # when this convolution is split along K, also sums the partials -- no separate reduction, no epilogue statistics
     # (even sizes only: a pooling BatchNorm on an odd map -- 96 x 96 frames reach 3 x 3 -- takes the general kernels, and this
     # function does not know whether the BatchNorm that follows pools)
-    small = want_stats and residual is None and small_bn(n * h * w) and h % 2 == 0 and w % 2 == 0
+    small = want_stats and residual is None and small_bn(n * h * w, True, cout) and h % 2 == 0 and w % 2 == 0
     if _SPLIT_PENDING:
         # the BatchNorm of an earlier deferred split-K convolution never ran: an exception between the two launches (the entry
         # is popped by that BatchNorm; nothing else may run in between).  The partial sums are gone with the scratch buffer;
@@ -722,7 +726,7 @@ class Conv3x3Fn(_Fn):
             # the source is the output of a norm layer (no pooling) and (presumably) has no other consumer: this launch also
             # leaves that layer's backward statistics (see _BN_OF); rows = the geometry both tensors share
             rec = ctx.src_bn[i]
-            if rec is not None and (rec.c != cc or rec.y.shape[-1] != ceil4(cc) or small_bn(rec.y.numel() // rec.y.shape[-1])
+            if rec is not None and (rec.c != cc or rec.y.shape[-1] != ceil4(cc) or small_bn(rec.y.numel() // rec.y.shape[-1], True, cc)
                                     or _small_sync(rec.y.numel() // rec.y.shape[-1])):
                 rec = None               # (small layers make their backward statistics inside their own one-launch kernel)
             if ctx.up:
@@ -889,14 +893,21 @@ class BNActFn(_Fn):
         count = float(rows)
         pending = _SPLIT_PENDING.pop(y.data_ptr(), None)
         ctx.small = False
-        if small_bn(rows, training) and ld == ceil4(c) and h % (2 if pool else 1) == 0 and w % (2 if pool else 1) == 0:
-            # the whole layer in one launch (csrc/batchnorm.hip: bn_small_fwd_kernel)
+        if small_bn(rows, training, c) and ld == ceil4(c) and h % (2 if pool else 1) == 0 and w % (2 if pool else 1) == 0:
+            # the whole layer in one launch (csrc/batchnorm.hip: bn_small_fwd_kernel; several ranks: bn_small_fwd_sync_kernel,
+            # the exchange of the sums inside the launch, statistics over the rows of ALL ranks)
             ho, wo = (h // 2, w // 2) if pool else (h, w)
             z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
             ws_, splits, phases, bias = pending if pending is not None else (None, 0, 1, None)
-            _call("mnk_bn_small_fwd", y, _p(ws_), splits, ld, phases, _p(bias), _p(y), ld, n, h, w, c, _p(gamma), _p(beta),
-                  _p(running_mean), _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(z),
-                  z.shape[-1], int(relu), int(pool))
+            if mdist.active():
+                count *= mdist.world_size()
+                _call("mnk_bn_small_fwd_sync", y, _sync_handle(c), _p(ws_), splits, ld, phases, _p(bias), _p(y), ld, n, h, w, c,
+                      _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd),
+                      _p(scale), _p(z), z.shape[-1], int(relu), int(pool), mdist.P2P_TIMEOUT_MS)
+            else:
+                _call("mnk_bn_small_fwd", y, _p(ws_), splits, ld, phases, _p(bias), _p(y), ld, n, h, w, c, _p(gamma), _p(beta),
+                      _p(running_mean), _p(running_var), float(momentum), float(eps), _p(mean), _p(invstd), _p(scale), _p(z),
+                      z.shape[-1], int(relu), int(pool))
             ctx.save_for_backward(y, mean, invstd, scale, beta)
             ctx.meta = (c, training, relu, pool, count)
             ctx.small = True
@@ -965,7 +976,7 @@ class BNActFn(_Fn):
         if dskip is not None:
             dskip = dskip.contiguous()
             assert dskip.shape == y.shape, "the skip gradient of a residual block has the shape of the block's input"
-        if ctx.small:
+        if ctx.small and not mdist.active():
             sums = torch.empty(2 * c, dtype=torch.float32, device=y.device)
             dy = torch.empty(n, h, w, ld, dtype=torch.float32, device=y.device)
             _call("mnk_bn_small_bwd", y, _p(y), ld, _p(dz), dz.shape[-1], _p(mean), _p(invstd), _p(scale), _p(beta), count, n, h,

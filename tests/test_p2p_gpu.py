@@ -193,3 +193,131 @@ def test_peer_to_peer_syncbn_exchange_between_processes_on_one_device(world, tmp
     if os.path.isdir(out):
         with open(os.path.join(out, "p2p_timing_world%d.txt" % world), "w") as f:
             f.write(t + "\n")
+
+
+# ---- a WHOLE training iteration of several processes on one device: SyncBN through the peer-to-peer kernels (the general second
+# stage with the exchange inside AND the one-launch small-layer forms, forward and backward), gradients averaged over gloo --
+# against one process on the whole batch (verdict r4 item 5: the first multi-GPU run must not be a first run) ----------------------
+def _step_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "monkey-net_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import threading
+    threading.Timer(170.0, lambda: os._exit(17)).start()
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from mnk import dist as mdist, engine, ops
+    from oracle import cases
+    from test_modules import build
+    mdist.P2P_TIMEOUT_MS = 8000
+    assert mdist.p2p_comm(force=True) is not None, "the peer-to-peer exchange did not come up"
+    cfg = cases.TINY2
+    gen, disc, kpd = build(cfg)
+    for i, m in enumerate((gen, disc, kpd)):
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 7 + i)
+        m.load_state_dict(sd)
+    gen.to(dev), disc.to(dev), kpd.to(dev)
+    src, drv = cases.smooth_pair(2 * world, 32, 32)
+    x = {"source": mdist.shard_batch(src).contiguous().to(dev), "video": mdist.shard_batch(drv).contiguous().to(dev)}
+    calls = {"fwd": 0, "bwd": 0, "general": 0}
+    real = ops._call
+
+    def counting(name, *a):                 # which exchange forms the iteration really used
+        if name == "mnk_bn_small_fwd_sync":
+            calls["fwd"] += 1
+        elif name == "mnk_bn_small_bwd_sync":
+            calls["bwd"] += 1
+        elif name.endswith("_sync"):
+            calls["general"] += 1
+        return real(name, *a)
+
+    ops._call = counting
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=True)
+    hist = []
+    for _ in range(2):
+        g_losses, d_losses, _ = step.step(x)
+        lv = torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64)
+        dist.all_reduce(lv)
+        hist.append(lv / world)
+    torch.cuda.synchronize()
+    mdist.check_p2p()
+    assert calls["fwd"] > 0 and calls["bwd"] > 0 and calls["general"] > 0, calls
+    torch.save({"losses": torch.stack(hist), "calls": calls,
+                "gen": {k: v.cpu() for k, v in gen.state_dict().items()},
+                "kp": {k: v.cpu() for k, v in kpd.state_dict().items()},
+                "disc": {k: v.cpu() for k, v in disc.state_dict().items()}}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+    os._exit(0)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_whole_training_iterations_of_several_processes_through_the_peer_to_peer_syncbn(world, tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    for p in (ROOT, os.path.join(ROOT, "monkey-net_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mnk import engine
+    from oracle import cases
+    from test_modules import build
+    # one process, the whole batch
+    cfg = cases.TINY2
+    gen, disc, kpd = build(cfg)
+    for i, m in enumerate((gen, disc, kpd)):
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 7 + i)
+        m.load_state_dict(sd)
+    dev = torch.device("cuda", 0)
+    gen.to(dev), disc.to(dev), kpd.to(dev)
+    src, drv = cases.smooth_pair(2 * world, 32, 32)
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=True)
+    ref_hist = []
+    for _ in range(2):
+        g_losses, d_losses, _ = step.step({"source": src.to(dev), "video": drv.to(dev)})
+        ref_hist.append(torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64))
+    torch.cuda.synchronize()
+    ref = {"losses": torch.stack(ref_hist), "gen": {k: v.cpu() for k, v in gen.state_dict().items()},
+           "kp": {k: v.cpu() for k, v in kpd.state_dict().items()}, "disc": {k: v.cpu() for k, v in disc.state_dict().items()}}
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_step_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(220)
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert codes == [0] * world, "worker exit codes %s (17 = the worker's own deadline)" % codes
+    ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    # replicas stay bit-identical (rank-ordered sums of the statistics on every rank, the same averaged gradients)
+    for r in ranks[1:]:
+        for key in ("gen", "kp", "disc"):
+            for k in ranks[0][key]:
+                assert torch.equal(ranks[0][key][k], r[key][k]), (key, k)
+    # N ranks x B/N == one rank x B: the losses of both iterations (the second one sees the first one's update and running
+    # statistics), the running statistics and the updated parameters (Adam's first steps are sign-like: bounds of test_dist_gloo)
+    r0 = ranks[0]
+    assert float((r0["losses"][0] - ref["losses"][0]).abs().max()) < 5e-5 * float(ref["losses"][0].abs().max() + 1)
+    assert float((r0["losses"][1] - ref["losses"][1]).abs().max()) < 2e-2 * float(ref["losses"][1].abs().max() + 1)
+    lr = cfg["train_params"]["lr"]
+    for key in ("gen", "kp", "disc"):
+        for k, v in ref[key].items():
+            if "running" in k:
+                assert float((r0[key][k] - v).abs().max()) < 1e-4 * (1 + float(v.abs().max())), (key, k)
+            elif v.is_floating_point() and not cases.is_noise_bias(k):
+                d = (r0[key][k] - v).abs()
+                assert float(d.max()) <= 4.2 * lr, (key, k, float(d.max()))
+    print("exchange forms used by rank 0:", r0["calls"])
