@@ -590,12 +590,13 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
                    const float* dout, int ld_out, int out_off, float* dinp, float* dfield, int N, float* ws, size_t ws_floats,
                    void* stream);
 /* All warps of one generator pass in ONE launch each way (generator.py:60-78: every decoder level's appearance skip is
- * warped by the same field, nearest-resized (mode 0), and the key-point embedding is resized into the channels behind it):
+ * warped by the same field, resized per level (mode 0: nearest pick, mode 1: bilinear -- 'trilinear' with unchanged depth, the
+ * vox configs), and the key-point embedding is resized the same way into the channels behind it):
  *   out_l[n][y][x][c] = grid_sample(inp_l, resize(field))[c]                    for c < C_l            (mnk_deform_fwd)
- *   out_l[n][y][x][emb_off_l + c] = emb[n][nearest(y)][nearest(x)][c]         for c < ke_l           (mnk_resize_nearest)
+ *   out_l[n][y][x][emb_off_l + c] = resize(emb)[n][y][x][c]                    for c < ke_l           (mnk_resize_nearest / _bilinear)
  * backward (two launches, deterministic -- see mnk_deform_bwd): dinp_l (may be NULL), dfield (may be NULL: the sum over the
- * levels in order) and demb[N][He][We][ld_emb] (may be NULL: the gathers of mnk_resize_nearest_bwd summed level after level,
- * pad channels 0) are all WRITTEN, nothing needs a zero fill.  ws: mnk_warp_levels_bwd_workspace_floats floats.  nlevels <= 8. */
+ * levels in order) and demb[N][He][We][ld_emb] (may be NULL: the gathers of mnk_resize_nearest_bwd / mnk_resize_bilinear_bwd summed level after level,
+ * pad channels 0) are all WRITTEN, nothing needs a zero fill.  ws: mnk_warp_levels_bwd_workspace_floats floats.  nlevels <= 12. */
 typedef struct MnkWarpLevel {
     const float* inp;   /* [N][h][w][ld_in] */
     float* out;         /* forward: [N][h][w][ld_out] */

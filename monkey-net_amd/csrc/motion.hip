@@ -4,6 +4,8 @@
 //   mnk_motion_field_*      : mask softmax, sum_k m_k*delta_k + correction + identity grid (dense_motion_module.py:52-76)
 //   mnk_deform_*            : MotionTransferGenerator.deform_input (generator.py:51-58): field resize + grid_sample
 // All HBM-bound element-wise / small-reduction kernels.
+#include <algorithm>
+
 #include "mnk_common.h"
 
 using namespace mnk;
@@ -760,7 +762,8 @@ __global__ void __launch_bounds__(256) deform_fwd_kernel(const float* __restrict
 //   The field gradient of a field texel is a gather as well (warp_bwd_field_gather): over the levels in order, the pixels
 //     of each level that read the texel (nearest pick or the bilinear footprint) in pixel order, the channel slices in order.
 constexpr int WG_BATCH = 1024;   // sampling points scanned per round (4 per thread)
-constexpr int WG_MAXACC = 8;     // channel quads a thread accumulates (float4 each)
+constexpr int WG_MAXACC = 4;     // channel quads a thread accumulates (float4 each)
+constexpr int WG_PEND = 4;       // hits a thread collects before it fetches their gradients (all loads of a flush are in flight together)
 
 __device__ __forceinline__ int lane_prefix_count(unsigned long long m) {     // set bits of m below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -840,7 +843,7 @@ __device__ __forceinline__ void warp_bwd_gather_body(const float* __restrict__ d
                                                      int ld_in, int T, int nacc, int qslices, int vb) {
     __shared__ float s_ix[WG_BATCH], s_iy[WG_BATCH];
     __shared__ int s_p[WG_BATCH];
-    __shared__ int s_cnt[WG_BATCH / 64];
+    __shared__ int s_cnt[2 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (w + T - 1) / T, tiles = tiles_x * ((h + T - 1) / T);
     const int slice = vb % qslices;
@@ -859,68 +862,108 @@ __device__ __forceinline__ void warp_bwd_gather_body(const float* __restrict__ d
     float4 acc[WG_MAXACC];
 #pragma unroll
     for (int a = 0; a < WG_MAXACC; ++a) acc[a] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0; base < P; base += WG_BATCH) {
-        float ix[4], iy[4];
+    int pend_p[WG_PEND], npend = 0;
+    float pend_w[WG_PEND];
+#pragma unroll
+    for (int k = 0; k < WG_PEND; ++k) pend_p[k] = 0, pend_w[k] = 0.f;
+    auto flush = [&]() {
+        float4 v[WG_PEND][WG_MAXACC];
+#pragma unroll
+        for (int k = 0; k < WG_PEND; ++k) {
+            const float* gp = db + (long)pend_p[k] * ld_out;
+#pragma unroll
+            for (int a = 0; a < WG_MAXACC; ++a) {
+                const int q = qbase + a * QL + ql;
+                v[k][a] = (k < npend && a < nacc && q < nq) ? load4_channels(gp, q * 4, C, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < WG_PEND; ++k)
+            if (k < npend) {
+#pragma unroll
+                for (int a = 0; a < WG_MAXACC; ++a) {
+                    acc[a].x += v[k][a].x * pend_w[k];
+                    acc[a].y += v[k][a].y * pend_w[k];
+                    acc[a].z += v[k][a].z * pend_w[k];
+                    acc[a].w += v[k][a].w * pend_w[k];
+                }
+            }
+        npend = 0;
+    };
+    // the sampling points of the next round are fetched while this round is worked on; an empty round (no point of the 1024
+    // touches the tile -- most rounds of a large map) costs one barrier: the per-wave counts are double-buffered, and the
+    // barrier in front of a list write also is the one behind the previous list's readers
+    float2 nxt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = j * 256 + tid;
+        nxt[j] = p < P ? *reinterpret_cast<const float2*>(sb + 2 * (long)p) : make_float2(0.f, 0.f);
+    }
+    const float x_lo = (float)(tx0 - 1), x_hi = (float)(tx0 + T - 1), y_lo = (float)(ty0 - 1), y_hi = (float)(ty0 + T - 1);
+    int round = 0;
+    for (int base = 0; base < P; base += WG_BATCH, ++round) {
+        float2 cur[4];
         bool hit[4];
         int pre[4];
 #pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        if (base + WG_BATCH < P) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = base + WG_BATCH + j * 256 + tid;
+                nxt[j] = p < P ? *reinterpret_cast<const float2*>(sb + 2 * (long)p) : make_float2(0.f, 0.f);
+            }
+        }
+        int* cnt = s_cnt + (round & 1) * 16;
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = base + j * 256 + tid;
-            hit[j] = false;
-            ix[j] = iy[j] = 0.f;
-            if (p < P) {
-                const float2 sp = *reinterpret_cast<const float2*>(sb + 2 * (long)p);
-                ix[j] = sp.x, iy[j] = sp.y;
-                const float fx = floorf(sp.x), fy = floorf(sp.y);
-                // (non-finite and far-away points fail the comparisons: Bilin::setup's clamp)
-                hit[j] = fx >= (float)(tx0 - 1) && fx <= (float)(tx0 + T - 1) && fy >= (float)(ty0 - 1) && fy <= (float)(ty0 + T - 1);
-            }
+            const float fx = floorf(cur[j].x), fy = floorf(cur[j].y);
+            // (non-finite and far-away points fail the comparisons: Bilin::setup's clamp)
+            hit[j] = p < P && fx >= x_lo && fx <= x_hi && fy >= y_lo && fy <= y_hi;
             const unsigned long long m = __ballot(hit[j]);
             pre[j] = lane_prefix_count(m);
-            if (lane == 0) s_cnt[j * 4 + wave] = __popcll(m);
+            if (lane == 0) cnt[j * 4 + wave] = __popcll(m);
         }
         __syncthreads();
         int off[4], total = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if ((k & 3) == wave) off[k >> 2] = total;
-            total += s_cnt[k];
+            total += cnt[k];
         }
+        if (total == 0) continue;              // (uniform: every thread read the same sixteen counts)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (hit[j]) {
                 const int pos = off[j] + pre[j];
                 s_p[pos] = base + j * 256 + tid;
-                s_ix[pos] = ix[j];
-                s_iy[pos] = iy[j];
+                s_ix[pos] = cur[j].x;
+                s_iy[pos] = cur[j].y;
             }
         __syncthreads();
-        if (active)
-            for (int e = 0; e < total; ++e) {
-                const float eix = s_ix[e], eiy = s_iy[e];
-                const float fx = floorf(eix), fy = floorf(eiy);
-                const int dx = tx - (int)fx, dy = ty - (int)fy;
-                if ((unsigned)dx < 2u && (unsigned)dy < 2u) {
-                    // the forward's corner weights: (ex - ix | ix - fx) * (ey - iy | iy - fy), ex = fx + 1
-                    const float wx = dx ? eix - fx : (fx + 1.f) - eix;
-                    const float wy = dy ? eiy - fy : (fy + 1.f) - eiy;
-                    const float wgt = wx * wy;
-                    const float* gp = db + (long)s_p[e] * ld_out;
+        for (int e = 0; e < total; ++e) {
+            const float eix = s_ix[e], eiy = s_iy[e];
+            const float fx = floorf(eix), fy = floorf(eiy);
+            const int dx = tx - (int)fx, dy = ty - (int)fy;
+            if (active && (unsigned)dx < 2u && (unsigned)dy < 2u) {
+                // the forward's corner weights: (ex - ix | ix - fx) * (ey - iy | iy - fy), ex = fx + 1
+                const float wx = dx ? eix - fx : (fx + 1.f) - eix;
+                const float wy = dy ? eiy - fy : (fy + 1.f) - eiy;
+                const float wgt = wx * wy;
+                const int pe = s_p[e];
 #pragma unroll
-                    for (int a = 0; a < WG_MAXACC; ++a) {
-                        const int q = qbase + a * QL + ql;
-                        if (a < nacc && q < nq) {
-                            const float4 v = load4_channels(gp, q * 4, C, vec);
-                            acc[a].x += v.x * wgt;
-                            acc[a].y += v.y * wgt;
-                            acc[a].z += v.z * wgt;
-                            acc[a].w += v.w * wgt;
-                        }
-                    }
-                }
+                for (int k = 0; k < WG_PEND; ++k)
+                    if (npend == k) pend_p[k] = pe, pend_w[k] = wgt;
+                ++npend;
             }
-        __syncthreads();
+            // a hit is not fetched at once: one exposed memory latency per hit was the whole kernel (a wavefront meets a hit of
+            // SOME lane at almost every entry).  When any lane of the wavefront holds WG_PEND hits, every lane fetches all of
+            // its pending ones together and adds them in entry order.
+            if (__ballot(npend == WG_PEND)) flush();
+        }
     }
+    flush();
     if (active) {
         float* op = dinp + (((long)n * h + ty) * w + tx) * ld_in;
 #pragma unroll
@@ -936,9 +979,10 @@ __device__ __forceinline__ void field_window(int s, int in_size, int out_size, i
     if (mode == 0) {
         lo = (int)((long)s * out_size / in_size) - 1;
         hi = (int)(((long)s + 1) * out_size / in_size) + 1;
-    } else {     // Lin1D: i0 in {s-1, s} <=> in/out*(dst+0.5)-0.5 in [s-1, s+1)
-        lo = (int)(((long)s - 1) * out_size / in_size) - 2;
-        hi = (int)((((long)s + 2) * out_size + in_size - 1) / in_size) + 1;
+    } else {     // Lin1D: i0 in {s-1, s} <=> in/out*(dst+0.5)-0.5 in [s-1, s+1) <=> dst in [((2s-1)out-in)/(2in), ((2s+3)out-in)/(2in))
+        const long a = (2l * s - 1) * out_size - in_size, b = (2l * s + 3) * out_size - in_size, d = 2l * in_size;
+        lo = (int)(a >= 0 ? a / d : -((-a + d - 1) / d)) - 1;
+        hi = (int)(b >= 0 ? (b + d - 1) / d : -((-b) / d)) + 1;
     }
     if (lo < 0) lo = 0;
     if (hi > out_size - 1) hi = out_size - 1;
@@ -946,7 +990,7 @@ __device__ __forceinline__ void field_window(int s, int in_size, int out_size, i
 
 // ---- all warps of a generator pass in ONE launch (generator.py:60-78: the appearance skips of every decoder level are
 // warped by the same field, and the key-point embedding is resized into each of them) -----------------------------------
-constexpr int MAX_WARP_LEVELS = 8;
+constexpr int MAX_WARP_LEVELS = 12;    // (the vox generator warps nine tensors; the struct travels as kernel arguments: < 4 KB)
 struct WarpSeg {          // one level's share of the launch
     const float* inp;
     float* out;           // forward: [N][h][w][ld_out]
@@ -981,7 +1025,7 @@ __global__ void __launch_bounds__(256) warp_levels_fwd_kernel(WarpSegs a) {
             return;
         }
         if (b >= L.emb_begin && b < L.emb_begin + L.emb_blocks) {
-            // nearest resize of the embedding into channels [emb_off, emb_off + ke) (resize_nearest_kernel of layout.hip)
+            // resize of the embedding into channels [emb_off, emb_off + ke) (resize_nearest_kernel / resize_bilinear_kernel of layout.hip)
             const long total = (long)a.N * L.h * L.w * L.ke;
             for (long i = (long)(b - L.emb_begin) * 256 + threadIdx.x; i < total; i += (long)L.emb_blocks * 256) {
                 const int c = (int)(i % L.ke);
@@ -990,8 +1034,18 @@ __global__ void __launch_bounds__(256) warp_levels_fwd_kernel(WarpSegs a) {
                 const long t = p / L.w;
                 const int y = (int)(t % L.h);
                 const int n = (int)(t / L.h);
-                const int ys = nearest_src(y, a.He, L.h), xs = nearest_src(x, a.We, L.w);
-                L.out[p * L.ld_out + L.emb_off + c] = a.emb[(((long)n * a.He + ys) * a.We + xs) * a.ld_emb + c];
+                if (a.mode == 0) {
+                    const int ys = nearest_src(y, a.He, L.h), xs = nearest_src(x, a.We, L.w);
+                    L.out[p * L.ld_out + L.emb_off + c] = a.emb[(((long)n * a.He + ys) * a.We + xs) * a.ld_emb + c];
+                } else {          // 'trilinear' with unchanged depth (vox configs): resize_bilinear_kernel of layout.hip
+                    Lin1D ly, lx;
+                    ly.setup(y, a.He, L.h);
+                    lx.setup(x, a.We, L.w);
+                    const float* sb = a.emb + (long)n * a.He * a.We * a.ld_emb + c;
+                    const float v00 = sb[((long)ly.i0 * a.We + lx.i0) * a.ld_emb], v01 = sb[((long)ly.i0 * a.We + lx.i1) * a.ld_emb];
+                    const float v10 = sb[((long)ly.i1 * a.We + lx.i0) * a.ld_emb], v11 = sb[((long)ly.i1 * a.We + lx.i1) * a.ld_emb];
+                    L.out[p * L.ld_out + L.emb_off + c] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+                }
             }
             return;
         }
@@ -1014,94 +1068,293 @@ __global__ void __launch_bounds__(256) warp_levels_bwd_pixel_kernel(WarpSegs a) 
 
 // pass B: d input of every level (texel tiles), the field gradient (one thread per field texel) and the gradient of the
 // embedding (one thread per element)
+// one level's share of the gradient of field texel (n, ys, xs): the pixels of the level that read the texel (nearest pick or
+// the bilinear footprint, with the forward's weights in the forward's order) in pixel order, the channel slices in order
+__device__ __forceinline__ void field_grad_of_level(const WarpSegs& a, const WarpSeg& L, long n, int ys, int xs, int part, int parts,
+                                                    float& sx, float& sy) {
+    const long npix = (long)a.N * L.h * L.w;
+    int h_lo, h_hi, w_lo, w_hi;
+    field_window(ys, a.hf, L.h, a.mode, h_lo, h_hi);
+    field_window(xs, a.wf, L.w, a.mode, w_lo, w_hi);
+    for (int y = h_lo + part; y <= h_hi; y += parts) {        // (parts > 1: the window's rows are dealt out to `parts` lanes)
+        Lin1D ly;
+        bool y0, y1;
+        if (a.mode == 0) {
+            y0 = nearest_src(y, a.hf, L.h) == ys, y1 = false;
+            ly.l0 = 1.f, ly.l1 = 0.f;
+        } else {
+            ly.setup(y, a.hf, L.h);
+            y0 = ly.i0 == ys, y1 = ly.i1 == ys;
+        }
+        if (!y0 && !y1) continue;
+        for (int x = w_lo; x <= w_hi; ++x) {
+            Lin1D lx;
+            bool x0, x1;
+            if (a.mode == 0) {
+                x0 = nearest_src(x, a.wf, L.w) == xs, x1 = false;
+                lx.l0 = 1.f, lx.l1 = 0.f;
+            } else {
+                lx.setup(x, a.wf, L.w);
+                x0 = lx.i0 == xs, x1 = lx.i1 == xs;
+            }
+            if (!x0 && !x1) continue;
+            // FieldAt::setup's (index, weight) pairs in its order: (i0y,i0x) (i0y,i1x) (i1y,i0x) (i1y,i1x)
+            float wsum = 0.f;
+            bool any = false;
+            if (y0 && x0) wsum = ly.l0 * lx.l0, any = true;
+            if (y0 && x1) wsum = any ? wsum + ly.l0 * lx.l1 : ly.l0 * lx.l1, any = true;
+            if (y1 && x0) wsum = any ? wsum + ly.l1 * lx.l0 : ly.l1 * lx.l0, any = true;
+            if (y1 && x1) wsum = any ? wsum + ly.l1 * lx.l1 : ly.l1 * lx.l1, any = true;
+            const long np = (n * L.h + y) * L.w + x;
+            float gx = 0.f, gy = 0.f;
+            for (int sl = 0; sl < L.slices; ++sl) {
+                gx += L.gpart[((long)sl * npix + np) * 2];
+                gy += L.gpart[((long)sl * npix + np) * 2 + 1];
+            }
+            sx += gx * wsum;
+            sy += gy * wsum;
+        }
+    }
+}
+
+constexpr int EMB_CH = 16;      // embedding channels a lane accumulates per pass
+
+// one level's share of the gradient of embedding texel (n, ys, xs), channels [c0, c0 + EMB_CH): the gathers of
+// resize_nearest_bwd_kernel / resize_bilinear_bwd_kernel (layout.hip), the same order of the additions
+__device__ __forceinline__ void emb_grad_of_level(const WarpSegs& a, const WarpSeg& L, int n, int ys, int xs, int c0, int part, int parts,
+                                                  float* acc) {
+    int h_lo, h_hi, w_lo, w_hi;
+    field_window(ys, a.He, L.h, a.mode, h_lo, h_hi);
+    field_window(xs, a.We, L.w, a.mode, w_lo, w_hi);
+    const int cn = L.ke - c0 < EMB_CH ? L.ke - c0 : EMB_CH;
+    const bool vec = ((L.emb_off + c0) & 3) == 0 && (L.ld_out & 3) == 0;
+    for (int y = h_lo + part; y <= h_hi; y += parts) {
+        Lin1D ly;
+        bool y0, y1;
+        if (a.mode == 0) {
+            y0 = nearest_src(y, a.He, L.h) == ys, y1 = false;
+            ly.l0 = 1.f, ly.l1 = 0.f;
+        } else {
+            ly.setup(y, a.He, L.h);
+            y0 = ly.i0 == ys, y1 = ly.i1 == ys;
+        }
+        if (!y0 && !y1) continue;
+        for (int x = w_lo; x <= w_hi; ++x) {
+            Lin1D lx;
+            bool x0, x1;
+            if (a.mode == 0) {
+                x0 = nearest_src(x, a.We, L.w) == xs, x1 = false;
+                lx.l0 = 1.f, lx.l1 = 0.f;
+            } else {
+                lx.setup(x, a.We, L.w);
+                x0 = lx.i0 == xs, x1 = lx.i1 == xs;
+            }
+            if (!x0 && !x1) continue;
+            const float* gp = L.dout + (((long)n * L.h + y) * L.w + x) * L.ld_out + L.emb_off + c0;
+            float gv[EMB_CH];
+            if (vec) {           // (the row's pad channels behind the embedding are zeros and lie inside the row)
+#pragma unroll
+                for (int c = 0; c < EMB_CH; c += 4) {
+                    const float4 t = c < cn ? *reinterpret_cast<const float4*>(gp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    gv[c] = t.x, gv[c + 1] = t.y, gv[c + 2] = t.z, gv[c + 3] = t.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < EMB_CH; ++c) gv[c] = c < cn ? gp[c] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < EMB_CH; ++c) {
+                if (c >= cn) continue;
+                const float g = gv[c];
+                if (a.mode == 0) {
+                    acc[c] += g;
+                } else {
+                    if (y0 && x0) acc[c] += g * ly.l0 * lx.l0;
+                    if (y0 && x1) acc[c] += g * ly.l0 * lx.l1;
+                    if (y1 && x0) acc[c] += g * ly.l1 * lx.l0;
+                    if (y1 && x1) acc[c] += g * ly.l1 * lx.l1;
+                }
+            }
+        }
+    }
+}
+
+// ---- the embedding's gradient under a BILINEAR resize (mode 1: the vox configurations) ----------------------------------------
+// A 64 x 64 embedding under a 256 x 256 map: every texel is read by ~64 pixels of that level, by 16 of the next ...
+// One lane per level (the nearest form below) then walks 64 scattered pixels alone -- every load instruction of the wavefront
+// touches as many cache lines as it has lanes.  Here a WAVEFRONT owns the texel and walks (level, window row) in order; the
+// lanes of a row step are (x candidate 0..15) x (4-float column q of the pixel's record): one coalesced read of the row
+// segment, weight = the forward's own products for the texel (zero for a pixel that does not read it), a lane accumulates its
+// (x, q) column over the rows in order, the sixteen x lanes are summed by a fixed shuffle tree, the levels in order.  All
+// control flow is uniform over the wavefront.
+__device__ __forceinline__ float xlanes_sum(float v) {       // the sixteen x lanes of a column (lane = x * 4 + q), fixed tree
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ void emb_grad_bilinear(const WarpSegs& a, long i, int lane) {
+    const int xs = (int)(i % a.We);
+    const long t = i / a.We;
+    const int ys = (int)(t % a.He), n = (int)(t / a.He);
+    const int xi = lane >> 2, q = lane & 3;
+    for (int c0 = 0; c0 < a.ld_emb; c0 += 16) {
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool first = true;
+        for (int l = 0; l < a.n; ++l) {
+            const WarpSeg& L = a.lv[l];
+            if (L.ke <= c0) continue;
+            const int cn = L.ke - c0;                         // channels [c0, c0 + cn) of this level exist
+            const bool vec = ((L.emb_off + c0) & 3) == 0 && (L.ld_out & 3) == 0;
+            int h_lo, h_hi, w_lo, w_hi;
+            field_window(ys, a.He, L.h, 1, h_lo, h_hi);
+            field_window(xs, a.We, L.w, 1, w_lo, w_hi);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int xb = w_lo; xb <= w_hi; xb += 16) {
+                const int x = xb + xi;
+                Lin1D lx;                                   // this lane's column: the same for every row
+                lx.setup(x <= w_hi ? x : w_hi, a.We, L.w);
+                const bool x0 = lx.i0 == xs, x1 = lx.i1 == xs;
+                for (int y = h_lo; y <= h_hi; ++y) {
+                    Lin1D ly;
+                    ly.setup(y, a.He, L.h);
+                    const bool y0 = ly.i0 == ys, y1 = ly.i1 == ys;
+                    if (x <= w_hi && 4 * q < cn && (x0 || x1) && (y0 || y1)) {
+                        // FieldAt::setup's (index, weight) pairs in its order: (i0y,i0x) (i0y,i1x) (i1y,i0x) (i1y,i1x)
+                        float wgt = 0.f;
+                        bool any = false;
+                        if (y0 && x0) wgt = ly.l0 * lx.l0, any = true;
+                        if (y0 && x1) wgt = any ? wgt + ly.l0 * lx.l1 : ly.l0 * lx.l1, any = true;
+                        if (y1 && x0) wgt = any ? wgt + ly.l1 * lx.l0 : ly.l1 * lx.l0, any = true;
+                        if (y1 && x1) wgt = any ? wgt + ly.l1 * lx.l1 : ly.l1 * lx.l1, any = true;
+                        const float* gp = L.dout + (((long)n * L.h + y) * L.w + x) * L.ld_out + L.emb_off + c0 + 4 * q;
+                        // (the row's pad channels behind the embedding are zeros and lie inside the row)
+                        const float4 g = load4_channels(gp, 0, cn - 4 * q, vec);
+                        s.x += g.x * wgt;
+                        s.y += g.y * wgt;
+                        s.z += g.z * wgt;
+                        s.w += g.w * wgt;
+                    }
+                }
+            }
+            s.x = xlanes_sum(s.x), s.y = xlanes_sum(s.y), s.z = xlanes_sum(s.z), s.w = xlanes_sum(s.w);
+            // (a channel beyond this level's ke got zeros from it: adding them changes nothing)
+            tot = first ? s : make_float4(tot.x + s.x, tot.y + s.y, tot.z + s.z, tot.w + s.w);
+            first = false;
+        }
+        if (xi == 0) {
+            const float tv[4] = {tot.x, tot.y, tot.z, tot.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + 4 * q + e < a.ld_emb) a.demb[i * a.ld_emb + c0 + 4 * q + e] = tv[e];
+        }
+    }
+}
+
+// pass B: the field gradient and the gradient of the embedding -- a GROUP of lanes per texel, one lane (nearest) or four
+// (bilinear: the rows of the level's window dealt out) per level: the levels' footprints differ by orders of magnitude (a
+// 64 x 64 field under a 256 x 256 map has 121 candidate pixels per texel and level); the lanes' sums are added in part, then
+// level order -- and d input of every level (texel tiles).  The long-running texel blocks come FIRST in the grid so that they
+// run under the tile gathers instead of behind them.
 __global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a) {
     const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (a.mode == 1 && b >= a.demb_begin && b < a.demb_begin + a.demb_blocks) {    // bilinear resize of the embedding: a
+        const long total = (long)a.N * a.He * a.We;                                    // wavefront per texel (see above)
+        for (long i = (long)(b - a.demb_begin) * 4 + (threadIdx.x >> 6); i < total; i += (long)a.demb_blocks * 4)
+            emb_grad_bilinear(a, i, lane);
+        return;
+    }
+    // the field gradient (both resize modes) and the embedding under a nearest resize: sixteen lanes per texel, one per level
+    const int G = 16, P = 1, per_block = 256 / G;
+    const int lane_g = threadIdx.x & (G - 1), group = threadIdx.x / G, gbase = lane & ~(G - 1);
+    const int lvl = lane_g / P, part = lane_g % P;
+    // a lane picks ITS level: the level table moves from the kernel arguments (uniform access only -- a per-lane index makes
+    // the compiler walk the distinct values one after the other) into LDS
+    __shared__ WarpSeg s_lv[MAX_WARP_LEVELS];
+    const bool texel_block = b < a.demb_begin + a.demb_blocks;      // (the two texel gathers are the first blocks of the grid)
+    if (texel_block) {
+        for (int l = 0; l < a.n; ++l)
+            if (threadIdx.x == 0) s_lv[l] = a.lv[l];
+        __syncthreads();
+    }
+    if (b >= a.dfield_begin && b < a.dfield_begin + a.dfield_blocks) {
+        const long total = (long)a.N * a.hf * a.wf;
+        const long iters = (total + per_block - 1) / per_block;
+        for (long it = b - a.dfield_begin; it < iters; it += a.dfield_blocks) {
+            const long i = it * per_block + group;
+            float sx = 0.f, sy = 0.f;
+            if (i < total && lvl < a.n) {
+                const int xs = (int)(i % a.wf);
+                const long t = i / a.wf;
+                field_grad_of_level(a, s_lv[lvl], t / a.hf, (int)(t % a.hf), xs, part, P, sx, sy);
+            }
+            float tx = 0.f, ty = 0.f;
+            for (int l = 0; l < a.n; ++l) {
+                float vx = 0.f, vy = 0.f;
+                for (int j = 0; j < P; ++j) {                    // the level's parts, then the levels, in order
+                    const float px = __shfl(sx, gbase + l * P + j), py = __shfl(sy, gbase + l * P + j);
+                    vx = j ? vx + px : px;
+                    vy = j ? vy + py : py;
+                }
+                tx = l ? tx + vx : vx;
+                ty = l ? ty + vy : vy;
+            }
+            if (i < total && lane_g == 0) {
+                if (a.dfield_accumulate) {
+                    a.dfield[i * 2] += tx;
+                    a.dfield[i * 2 + 1] += ty;
+                } else {
+                    a.dfield[i * 2] = tx;
+                    a.dfield[i * 2 + 1] = ty;
+                }
+            }
+        }
+        return;
+    }
+    if (b >= a.demb_begin && b < a.demb_begin + a.demb_blocks) {
+        // pad channels (>= every level's ke) are written 0
+        const long total = (long)a.N * a.He * a.We;
+        const long iters = (total + per_block - 1) / per_block;
+        for (long it = b - a.demb_begin; it < iters; it += a.demb_blocks) {
+            const long i = it * per_block + group;
+            const int xs = (int)(i % a.We);
+            const long t = i / a.We;
+            const int ys = (int)(t % a.He), n = (int)(t / a.He);
+            for (int c0 = 0; c0 < a.ld_emb; c0 += EMB_CH) {
+                float acc[EMB_CH];
+#pragma unroll
+                for (int c = 0; c < EMB_CH; ++c) acc[c] = 0.f;
+                const bool mine = i < total && lvl < a.n && s_lv[lvl < a.n ? lvl : 0].ke > c0;
+                if (mine) emb_grad_of_level(a, s_lv[lvl], n, ys, xs, c0, part, P, acc);
+#pragma unroll
+                for (int c = 0; c < EMB_CH; ++c) {
+                    float tot = 0.f;
+                    bool first = true;
+                    for (int l = 0; l < a.n; ++l) {
+                        float v = 0.f;
+                        for (int j = 0; j < P; ++j) {
+                            const float pv = __shfl(acc[c], gbase + l * P + j);
+                            v = j ? v + pv : pv;
+                        }
+                        if (a.lv[l].ke <= c0 + c) continue;          // (uniform: the level has no such channel)
+                        tot = first ? v : tot + v;
+                        first = false;
+                    }
+                    if (i < total && lane_g == 0 && c0 + c < a.ld_emb) a.demb[i * a.ld_emb + c0 + c] = tot;
+                }
+            }
+        }
+        return;
+    }
     for (int l = 0; l < a.n; ++l) {
         const WarpSeg& L = a.lv[l];
         if (b >= L.gat_begin && b < L.gat_begin + L.gat_blocks) {
             warp_bwd_gather_body(L.dout, L.ld_out, L.out_off, L.C, L.h, L.w, L.samp, L.dinp, L.ld_in, L.T, L.nacc, L.qslices,
                                  b - L.gat_begin);
             return;
-        }
-    }
-    if (b >= a.dfield_begin && b < a.dfield_begin + a.dfield_blocks) {
-        const long total = (long)a.N * a.hf * a.wf;
-        for (long i = (long)(b - a.dfield_begin) * 256 + threadIdx.x; i < total; i += (long)a.dfield_blocks * 256) {
-            const int xs = (int)(i % a.wf);
-            const long t = i / a.wf;
-            const int ys = (int)(t % a.hf);
-            const long n = t / a.hf;
-            const int me = ys * a.wf + xs;
-            float sx = 0.f, sy = 0.f;
-            for (int l = 0; l < a.n; ++l) {
-                const WarpSeg& L = a.lv[l];
-                const long npix = (long)a.N * L.h * L.w;
-                int h_lo, h_hi, w_lo, w_hi;
-                field_window(ys, a.hf, L.h, a.mode, h_lo, h_hi);
-                field_window(xs, a.wf, L.w, a.mode, w_lo, w_hi);
-                for (int y = h_lo; y <= h_hi; ++y)
-                    for (int x = w_lo; x <= w_hi; ++x) {
-                        FieldAt fa;
-                        fa.setup(a.hf, a.wf, y, x, L.h, L.w, a.mode);
-                        float wsum = 0.f;
-                        bool any = false;
-                        for (int j = 0; j < fa.n; ++j)
-                            if (fa.idx[j] == me) wsum = any ? wsum + fa.wgt[j] : fa.wgt[j], any = true;
-                        if (!any) continue;
-                        const long np = (n * L.h + y) * L.w + x;
-                        float gx = 0.f, gy = 0.f;
-                        for (int sl = 0; sl < L.slices; ++sl) {
-                            gx += L.gpart[((long)sl * npix + np) * 2];
-                            gy += L.gpart[((long)sl * npix + np) * 2 + 1];
-                        }
-                        sx += gx * wsum;
-                        sy += gy * wsum;
-                    }
-            }
-            if (a.dfield_accumulate) {
-                a.dfield[i * 2] += sx;
-                a.dfield[i * 2 + 1] += sy;
-            } else {
-                a.dfield[i * 2] = sx;
-                a.dfield[i * 2 + 1] = sy;
-            }
-        }
-        return;
-    }
-    if (b >= a.demb_begin && b < a.demb_begin + a.demb_blocks) {
-        // gradient of the embedding: every element gathers, level after level (the order of the per-level launches), the
-        // pixels whose nearest source it is (resize_nearest_bwd_kernel of layout.hip); pad channels are written 0
-        const long total = (long)a.N * a.He * a.We * a.ld_emb;
-        for (long i = (long)(b - a.demb_begin) * 256 + threadIdx.x; i < total; i += (long)a.demb_blocks * 256) {
-            const int c = (int)(i % a.ld_emb);
-            const long p = i / a.ld_emb;
-            const int xs = (int)(p % a.We);
-            const long t = p / a.We;
-            const int ys = (int)(t % a.He);
-            const int n = (int)(t / a.He);
-            float tot = 0.f;
-            bool first = true;
-            for (int l = 0; l < a.n; ++l) {
-                const WarpSeg& L = a.lv[l];
-                if (L.ke <= 0 || c >= L.ke) continue;
-                int h_lo = (int)((long)ys * L.h / a.He) - 1, h_hi = (int)(((long)ys + 1) * L.h / a.He) + 1;
-                int w_lo = (int)((long)xs * L.w / a.We) - 1, w_hi = (int)(((long)xs + 1) * L.w / a.We) + 1;
-                if (h_lo < 0) h_lo = 0;
-                if (w_lo < 0) w_lo = 0;
-                if (h_hi > L.h - 1) h_hi = L.h - 1;
-                if (w_hi > L.w - 1) w_hi = L.w - 1;
-                float acc = 0.f;
-                for (int y = h_lo; y <= h_hi; ++y) {
-                    if (nearest_src(y, a.He, L.h) != ys) continue;
-                    for (int x = w_lo; x <= w_hi; ++x) {
-                        if (nearest_src(x, a.We, L.w) != xs) continue;
-                        acc += L.dout[(((long)n * L.h + y) * L.w + x) * L.ld_out + L.emb_off + c];
-                    }
-                }
-                tot = first ? acc : tot + acc;
-                first = false;
-            }
-            a.demb[i] = tot;
         }
     }
 }
@@ -1342,9 +1595,23 @@ static void warp_bwd_plan(int C, long npix, int& CL, int& cslice, int& gx, int& 
 // tile edge of the gather pass: every block scans its frame's sampling points, so big maps take big tiles (a 256 x 256 map
 // in 8 x 8 tiles would read its 512 KB of sampling points 1024 times per frame); small maps take small tiles so that the
 // 256 threads split the channels instead of idling
+static int g_warp_gather_tile = tuning_knob("warp_gather_tile", &g_warp_gather_tile, 0);    // 0: by map size; 1 / 2 / 4 / 8 / 16 forces the edge (A/B)
+static int g_warp_gather_rule = tuning_knob("warp_gather_rule", &g_warp_gather_rule, 1);    // 1: lanes per texel by channel count (vox 1243 -> 1040 us per pass, moving-gif 223 -> 214); 0: tile edge by map size
 static void warp_gather_plan(int ld_in, int h, int w, int& T, int& nacc, int& qslices, int& tiles) {
     const long P = (long)h * w;
     T = P >= 16384 ? 16 : P >= 1024 ? 8 : P >= 64 ? 4 : P >= 16 ? 2 : 1;
+    if (g_warp_gather_rule == 1) {
+        // as many lanes per texel as the level has channel quads (every lane busy), the tile as large as that leaves
+        int ql = 1;
+        while (ql * 2 <= ld_in / 4 && ql < 256) ql <<= 1;
+        T = 16;
+        while (T > 1 && T * T * ql > 256) T >>= 1;
+        while (T > 1 && (long)(T / 2) * (T / 2) >= P) T >>= 1;
+    }
+    if (g_warp_gather_tile == 1 || g_warp_gather_tile == 2 || g_warp_gather_tile == 4 || g_warp_gather_tile == 8 || g_warp_gather_tile == 16) {
+        T = g_warp_gather_tile;
+        while (T > 1 && (long)(T / 2) * (T / 2) >= P) T >>= 1;      // (never a tile of mostly idle texel threads)
+    }
     const int QL = 256 / (T * T), nq = ld_in / 4;
     nacc = ceil_div(nq, QL);
     if (nacc > WG_MAXACC) nacc = WG_MAXACC;
@@ -1370,6 +1637,15 @@ static int warp_bwd_launch(WarpSegs& a, float* ws, size_t ws_floats, double byte
     }
     int blocks_a = 0, blocks_b = 0;
     float* wp = ws;
+    // pass B's grid: the texel gathers of the field and the embedding first (few, long-running), then the tiles of d input
+    a.dfield_begin = blocks_b;
+    const int per_block = a.mode ? 4 : 16;       // texels per block of the embedding gather (warp_levels_bwd_gather_kernel)
+    a.dfield_blocks = a.dfield ? (int)std::min<long>(((long)a.N * a.hf * a.wf + 15) / 16, 32768) : 0;
+    blocks_b += a.dfield_blocks;
+    a.demb_begin = blocks_b;
+    a.demb_blocks = a.demb ? (int)std::min<long>(((long)a.N * a.He * a.We + per_block - 1) / per_block, 32768) : 0;
+    blocks_b += a.demb_blocks;
+    const int small_blocks = blocks_b;
     for (int l = 0; l < a.n; ++l) {
         WarpSeg& L = a.lv[l];
         const long npix = (long)a.N * L.h * L.w;
@@ -1391,15 +1667,9 @@ static int warp_bwd_launch(WarpSegs& a, float* ws, size_t ws_floats, double byte
         }
         blocks_b += L.gat_blocks;
     }
-    a.dfield_begin = blocks_b;
-    a.dfield_blocks = a.dfield ? grid_for((long)a.N * a.hf * a.wf) : 0;
-    blocks_b += a.dfield_blocks;
-    a.demb_begin = blocks_b;
-    a.demb_blocks = a.demb ? grid_for((long)a.N * a.He * a.We * a.ld_emb) : 0;
-    blocks_b += a.demb_blocks;
     MNK_REQUIRE(blocks_b > 0);
     ProfScope prof(K_DEFORM, s, bytes);
-    if (blocks_a > 0 && (a.dfield || blocks_b > a.dfield_blocks + a.demb_blocks))
+    if (blocks_a > 0 && (a.dfield || blocks_b > small_blocks))
         hipLaunchKernelGGL(warp_levels_bwd_pixel_kernel, dim3(blocks_a), dim3(256), 0, s, a);
     hipLaunchKernelGGL(warp_levels_bwd_gather_kernel, dim3(blocks_b), dim3(256), 0, s, a);
     MNK_LAUNCH_CHECK();
@@ -1427,7 +1697,7 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
 
 static int warp_levels_check(const MnkWarpLevel* lv, int n, const float* field, int hf, int wf, int mode, int He, int We,
                              int ld_emb, int N) {
-    MNK_REQUIRE(lv && n > 0 && n <= MAX_WARP_LEVELS && field && hf > 0 && wf > 0 && mode == 0 && N > 0);
+    MNK_REQUIRE(lv && n > 0 && n <= MAX_WARP_LEVELS && field && hf > 0 && wf > 0 && (mode == 0 || mode == 1) && N > 0);
     for (int l = 0; l < n; ++l) {
         MNK_REQUIRE(lv[l].inp && lv[l].C > 0 && lv[l].h > 0 && lv[l].w > 0 && lv[l].ld_in % 4 == 0 &&
                     lv[l].ld_in >= round_up(lv[l].C, 4) && lv[l].C <= lv[l].ld_out && lv[l].ke >= 0);

@@ -1728,7 +1728,7 @@ class WarpAllFn(_Fn):
         _check_device(field)
         _, hf, wf, _ = field.shape
         outs = []
-        ctx.multi = mode == 0 and len(inps) <= 8 and knobs.form("WARP_LEVELS")
+        ctx.multi = len(inps) <= 12 and knobs.form("WARP_LEVELS")
         if ctx.multi:         # one launch for the warps and embedding copies of all levels (mnk_warp_levels_fwd)
             lv = np.zeros(len(inps), dtype=WARP_LEVEL)
             for i, (inp, (c, ke)) in enumerate(zip(inps, specs)):

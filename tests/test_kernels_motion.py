@@ -253,8 +253,9 @@ def test_deform_matches_reference_golden(be):
         assert maxerr(from_nhwc(OUT.cpu(), c), ref[:, :, 0]) < 1e-5, tag
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("emb_ch", [0, 6, 8])
-def test_all_warps_in_one_launch_equal_the_per_level_launches(be, monkeypatch, emb_ch):
+def test_all_warps_in_one_launch_equal_the_per_level_launches(be, monkeypatch, emb_ch, mode):
     """ops.WarpAllFn with mnk_warp_levels_fwd / _bwd (MNK_WARP_LEVELS=1: every level's warp and embedding copy in one launch
     each way) against one launch per level: outputs and the embedding gradient to the bit (same gathers in the same order),
     the scatter-added gradients (atomics) to rounding."""
@@ -279,7 +280,7 @@ def test_all_warps_in_one_launch_equal_the_per_level_launches(be, monkeypatch, e
         f = field.clone().requires_grad_(True)
         e = emb.clone().requires_grad_(True) if emb is not None else None
         xs = [t.clone().requires_grad_(True) for t in inps]
-        outs = ops.WarpAllFn.apply(f, e, 0, specs, *xs)
+        outs = ops.WarpAllFn.apply(f, e, mode, specs, *xs)
         used = [i for i in range(len(outs)) if i != 1]             # level 1's output goes nowhere (no gradient reaches it)
         torch.autograd.backward([outs[i] for i in used], [be.t(douts[i]) for i in used])
         be.sync()
@@ -288,10 +289,10 @@ def test_all_warps_in_one_launch_equal_the_per_level_launches(be, monkeypatch, e
 
     o0, gf0, ge0, gx0 = run("0")
     o1, gf1, ge1, gx1 = run("1")
-    for a, b in zip(o0, o1):
-        assert torch.equal(a, b)
+    for a, b in zip(o0, o1):          # (mode 1: the bilinear blends are the same expressions in two kernels -- equal up to the
+        assert torch.equal(a, b) if mode == 0 else maxerr(a, b) < 1e-6        # compiler's choice of fused multiply-adds)
     if emb is not None:
-        assert torch.equal(ge0, ge1)
+        assert torch.equal(ge0, ge1) if mode == 0 else relerr(ge1, ge0) < 1e-6
     assert relerr(gf1, gf0) < 1e-5
     for a, b in zip(gx0, gx1):
         assert relerr(b, a) < 1e-5

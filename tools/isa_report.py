@@ -16,6 +16,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1].startswith("-"):     # (an option is not an output path: `--help` once became a file)
+        print(__doc__)
+        return
     lines = ["# kernel: vgpr+agpr (accumulator offset) sgpr scratch-bytes lds-bytes   [hipcc %s]" % " ".join(FLAGS[:3])]
     spills = 0
     with tempfile.TemporaryDirectory() as tmp:
