@@ -13,8 +13,11 @@ horizontal flip, edge padding + random crop, gray / RGBA handling, uint8 -> floa
 non-integer augmentations of config/moving-gif.yaml and actions.yaml -- `rotation_param` (skimage.transform.rotate),
 `resize_param` (skimage.transform.resize, bilinear, ratios >= 0.8) and `jitter_param` with `hue` (img_as_ubyte -> PIL HSV ->
 torchvision adjust_hue -> img_as_float) -- in one launch per batch (mnk_frames_augment), in the arithmetic of the package
-versions the reference pins; those packages are not in this image, so that path is checked against a numpy restatement of
-their published algorithms (oracle/augment_restate.py, "parity unpinned"), not against the packages themselves.  brightness /
+versions the reference pins; scikit-image and torchvision are not in this image (and not installable offline), so rotation and
+resize are checked against a numpy restatement of skimage 0.14's published algorithm (oracle/augment_restate.py: that part is
+"parity unpinned"); the hue jitter's colour conversions ARE pinned to a real library since round 5: the restatement equals the
+installed Pillow's Image.convert RGB <-> HSV on all 2^24 triples of both directions, and kernel and restatement reproduce a
+golden made by that Pillow (oracle/make_golden_hue.py, tests/golden/hue_pillow.npz).  brightness /
 contrast / saturation jitter (no shipped config sets them) raise.  `.gif` files (the moving-gif data set) are decoded with
 Pillow (read_gif); `.mp4` / `.mov` need a decoder this image does not have; PNG strips are read by the small decoder below
 (zlib + the five PNG filters), or by PIL when it is importable.

@@ -4,10 +4,14 @@ tests/test_frames.py for csrc/frames.hip::frames_augment_kernel; nothing in monk
 The reference's RandomResize / RandomRotation / ColorJitter (augmentation.py:105-133,175-214,217-320) are thin wrappers around
 third-party functions that are NOT in this image and not vendored by the reference (requirements.txt pins scikit-image==0.14.0,
 Pillow==5.2.0, torchvision==0.2.1, numpy==1.15.0), so this file restates the published algorithms of exactly those versions,
-function by function, and says where each statement comes from.  **Parity unpinned**: there is no way to execute skimage /
-PIL here, so nothing checks this restatement against the real packages; what IS checked (tests/test_frames.py) is that the
-device kernel reproduces this file, and that the integer-exact parts of the pipeline around it still reproduce the reference
-(tests/golden/frames_shapes.npz, made by the unmodified reference).
+function by function, and says where each statement comes from.  **Parity unpinned for the skimage half** (resize / rotate /
+warp / img_as_ubyte / img_as_float): scikit-image is neither installed nor installable offline, so nothing checks those
+statements against the real package.  **The Pillow half is pinned (round 5)**: rgb2hsv_u8 / hsv2rgb_u8 equal the installed
+Pillow's (12.2.0) Image.convert on ALL 2^24 RGB and ALL 2^24 HSV triples, and adjust_hue reproduces a golden made with that
+Pillow under torchvision 0.2.1's five adjust_hue statements (oracle/make_golden_hue.py -> tests/golden/hue_pillow.npz,
+HUE_PILLOW_REPORT.txt; tests/test_frames.py::test_hue_*).  What is checked besides (tests/test_frames.py): the device kernel
+reproduces this file, and the integer-exact parts of the pipeline around it reproduce the unmodified reference
+(tests/golden/frames_shapes.npz).
 
     skimage.transform.resize(img, (rows, cols), order=1, preserve_range=True, mode='constant', anti_aliasing=True)
         0.14.0 transform/_warps.py::resize: image.astype(double); anti-aliasing = ndi.gaussian_filter with

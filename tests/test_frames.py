@@ -255,6 +255,61 @@ def test_resize_rotation_and_hue_jitter_equal_the_restated_library_arithmetic(be
     print("%s: %d values, %d differ by more than 1e-6, largest difference %.3e" % (tag, total, differ, worst))
 
 
+def test_hue_restatement_equals_the_golden_of_the_real_pillow():
+    """oracle/make_golden_hue.py ran the REAL Pillow (Image.convert RGB <-> HSV; every one of the 2^24 triples of both directions
+    equals the restatement: tests/golden/HUE_PILLOW_REPORT.txt) under torchvision 0.2.1's five adjust_hue statements and
+    recorded the uint8 output for 24 images x 10 hue factors: the numpy restatement that checks the device kernel must
+    reproduce it exactly -- the colour-conversion half of the hue jitter is pinned to a real library, not only to its
+    description."""
+    from oracle import augment_restate as ar
+    g = np.load(os.path.join(GOLD, "hue_pillow.npz"))
+    bad = 0
+    for k, f in enumerate(g["factors"]):
+        for i, im in enumerate(g["images"]):
+            got = np.rint(ar.adjust_hue(ar.img_as_float(im).astype(np.float32), float(f)).astype(np.float64) * 255.0).astype(np.uint8)
+            bad += int((got != g["out"][k, i]).sum())
+    assert bad == 0
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    # live, where a Pillow is installed (whatever its version): a slice of the exhaustive comparison
+    r, gg, b = np.meshgrid(np.arange(0, 256, 1, dtype=np.uint8), np.arange(0, 256, 3, dtype=np.uint8),
+                           np.arange(0, 256, 5, dtype=np.uint8), indexing="ij")
+    cube = np.ascontiguousarray(np.stack([r, gg, b], -1).reshape(256, -1, 3))
+    assert np.array_equal(np.asarray(Image.fromarray(cube, "RGB").convert("HSV")), ar.rgb2hsv_u8(cube))
+    assert np.array_equal(np.asarray(Image.fromarray(cube, "HSV").convert("RGB")), ar.hsv2rgb_u8(cube))
+
+
+def test_hue_jitter_kernel_equals_the_golden_of_the_real_pillow(be, tmp_path, monkeypatch):
+    """the device pipeline (mnk_frames_augment, hue only) on the golden's images with the golden's hue factors: every uint8
+    level the real Pillow produced, times 1 / 255 (skimage's img_as_float, float64 -> float32)"""
+    from mnk import frames
+    g = np.load(os.path.join(GOLD, "hue_pillow.npz"))
+    imgs, factors, out = g["images"], g["factors"], g["out"]
+    os.makedirs(os.path.join(tmp_path, "train"))
+    os.makedirs(os.path.join(tmp_path, "test"))
+    names = []
+    for v in range(len(imgs) // 2):                           # videos of two frames: strips (H, 2 W, 3)
+        names.append("%03d.png" % v)
+        for sub in ("train", "test"):
+            _write_png(os.path.join(tmp_path, sub, names[-1]), np.concatenate([imgs[2 * v], imgs[2 * v + 1]], axis=1))
+    ds = frames.DeviceFramesDataset(str(tmp_path), {"jitter_param": {"hue": 0.5}}, image_shape=(32, 32, 3), is_train=True,
+                                    device=be.device, files=names)
+    bad = total = 0
+    for k, f in enumerate(factors):
+        monkeypatch.setattr(ds, "_draw", lambda frame_count, f=float(f): ([0, 1], 0, 0, 0, 0, 0, 32, 32, None, None, f))
+        b = ds.batch(list(range(len(names))))
+        be.sync()
+        got = torch.cat([b["source"], b["video"]], dim=2).cpu().numpy()           # (V, C, 2, H, W)
+        for v in range(len(names)):
+            for d in range(2):
+                want = np.multiply(out[k, 2 * v + d], 1.0 / 255, dtype=np.float64).astype(np.float32)     # (H, W, 3)
+                bad += int((got[v, :, d].transpose(1, 2, 0) != want).sum())
+                total += want.size
+    assert bad == 0, (bad, total)
+
+
 def test_the_draw_order_of_the_full_augmentation_matches_the_reference_statement_order():
     """AllAugmentationTransform (augmentation.py:369-389) runs select -> flip -> rotation -> resize -> crop -> jitter; a replay of
     exactly those `random` / `numpy.random` calls must leave both generators where DeviceFramesDataset._draw leaves them"""
