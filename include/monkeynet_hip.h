@@ -59,6 +59,14 @@ int mnk_nhwc_to_ncdhw(const float* src, int ld_src, float* dst, int B, int C, in
 /* dst[r, dst_off + c] = src[r, src_off + c], c < C (torch.cat / slicing: modules/util.py:185, generator.py:73) */
 int mnk_copy_channels(const float* src, int ld_src, int src_off, float* dst, int ld_dst, int dst_off, int C,
                       long rows, int accumulate, void* stream);
+/* torch.cat([a, b], dim=channel) on acts in one launch, pad channels written (modules/util.py:185 the last decoder stage;
+ * discriminator.py:50-52 the key-point heat-maps behind the frame): out[n][p] = [a[n][p][0..ca) | b[n mod Nb][p][0..cb) | 0...],
+ * Nb = N, or N / 2 for the batched [generated | real] discriminator pass that embeds the same key points for both halves.
+ * Adjoint: ga = [g[..][0..ca) | 0...]; gb (may be NULL) [m][p] = [g[m][p][ca..) + g[m + Nb][p][ca..) + ... | 0...]. */
+int mnk_concat2_fwd(const float* a, int ld_a, int ca, const float* b, int ld_b, int cb, int Nb, float* out, int ld_out, int N,
+                    long rows_per_frame, void* stream);
+int mnk_concat2_bwd(const float* g, int ld_g, int ca, int cb, int Nb, float* ga, int ld_a, float* gb, int ld_b, int N,
+                    long rows_per_frame, void* stream);
 /* dst[n,h,w,c] = sum of the 2x2 block of src (backward of the nearest x2 up-sampling, modules/util.py:84) */
 int mnk_sumpool2x2(const float* src, int ld_src, float* dst, int ld_dst, int N, int Hs, int Ws, int C, void* stream);
 /* nearest resize of a channel block into a slice of another tensor (generator.py:72 kp_skips) and its adjoint */
@@ -594,6 +602,7 @@ int mnk_deform_bwd(const float* inp, int ld_in, int C, int h, int w, const float
  * vox configs), and the key-point embedding is resized the same way into the channels behind it):
  *   out_l[n][y][x][c] = grid_sample(inp_l, resize(field))[c]                    for c < C_l            (mnk_deform_fwd)
  *   out_l[n][y][x][emb_off_l + c] = resize(emb)[n][y][x][c]                    for c < ke_l           (mnk_resize_nearest / _bilinear)
+ * forward: EVERY channel of out_l is written (pad channels behind C_l / behind the embedding: 0) -- no zero fill by the caller;
  * backward (two launches, deterministic -- see mnk_deform_bwd): dinp_l (may be NULL), dfield (may be NULL: the sum over the
  * levels in order) and demb[N][He][We][ld_emb] (may be NULL: the gathers of mnk_resize_nearest_bwd / mnk_resize_bilinear_bwd summed level after level,
  * pad channels 0) are all WRITTEN, nothing needs a zero fill.  ws: mnk_warp_levels_bwd_workspace_floats floats.  nlevels <= 12. */

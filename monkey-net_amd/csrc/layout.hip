@@ -59,6 +59,51 @@ __global__ void __launch_bounds__(256) copy_channels_kernel(const float* __restr
     }
 }
 
+// torch.cat([a, b], channel) on acts in ONE launch, pad channels included: out[n][p] = [a[n][p][0..ca) | b[n mod Nb][p][0..cb) | 0...]
+// (Nb < N: the batched discriminator pass [generated | real] embeds the same key points for both halves)
+__global__ void __launch_bounds__(256) concat2_fwd_kernel(const float* __restrict__ a, int ld_a, int ca,
+                                                          const float* __restrict__ b, int ld_b, int cb, int Nb,
+                                                          float* __restrict__ out, int ld_out, int N, long rpf) {
+    const long total = (long)N * rpf * ld_out;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % ld_out);
+        const long r = i / ld_out;
+        float v = 0.f;
+        if (c < ca) {
+            v = a[r * ld_a + c];
+        } else if (c < ca + cb) {
+            const long n = r / rpf, p = r - n * rpf;
+            v = b[((n % Nb) * rpf + p) * ld_b + c - ca];
+        }
+        out[i] = v;
+    }
+}
+
+// its adjoint, one launch: ga[n][p] = [g[n][p][0..ca) | 0...], gb[m][p] = [sum over the frames n = m, m + Nb, ... in order of
+// g[n][p][ca..ca+cb) | 0...]
+__global__ void __launch_bounds__(256) concat2_bwd_kernel(const float* __restrict__ g, int ld_g, int ca, int cb, int Nb,
+                                                          float* __restrict__ ga, int ld_a, float* __restrict__ gb, int ld_b,
+                                                          int N, long rpf) {
+    const long na = (long)N * rpf * ld_a, nb = gb ? (long)Nb * rpf * ld_b : 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (long)gridDim.x * blockDim.x) {
+        if (i < na) {
+            const int c = (int)(i % ld_a);
+            const long r = i / ld_a;
+            ga[i] = c < ca ? g[r * ld_g + c] : 0.f;
+        } else {
+            const long j = i - na;
+            const int c = (int)(j % ld_b);
+            const long r = j / ld_b;              // (m, p)
+            float v = 0.f;
+            if (c < cb) {
+                v = g[r * ld_g + ca + c];
+                for (long n = Nb; n < N; n += Nb) v += g[(n * rpf + r) * ld_g + ca + c];
+            }
+            gb[j] = v;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) sumpool2x2_kernel(const float* __restrict__ src, int ld_src,
                                                          float* __restrict__ dst, int ld_dst, int N, int Hs, int Ws,
                                                          int C) {
@@ -262,6 +307,32 @@ int mnk_copy_channels(const float* src, int ld_src, int src_off, float* dst, int
     ProfScope prof(K_LAYOUT, s, (double)rows * C * 8);
     hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, src, ld_src, src_off, dst,
                        ld_dst, dst_off, C, rows, accumulate);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_concat2_fwd(const float* a, int ld_a, int ca, const float* b, int ld_b, int cb, int Nb, float* out, int ld_out, int N,
+                    long rows_per_frame, void* stream) {
+    MNK_REQUIRE(a && b && out && ca > 0 && cb > 0 && ca <= ld_a && cb <= ld_b && ca + cb <= ld_out && N > 0 && Nb > 0 &&
+                N % Nb == 0 && rows_per_frame > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * rows_per_frame * ld_out;
+    ProfScope prof(K_LAYOUT, s, (double)total * 8);
+    hipLaunchKernelGGL(concat2_fwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, a, ld_a, ca, b, ld_b, cb, Nb, out, ld_out, N,
+                       rows_per_frame);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_concat2_bwd(const float* g, int ld_g, int ca, int cb, int Nb, float* ga, int ld_a, float* gb, int ld_b, int N,
+                    long rows_per_frame, void* stream) {
+    MNK_REQUIRE(g && ga && ca > 0 && cb > 0 && ca <= ld_a && ca + cb <= ld_g && N > 0 && Nb > 0 && N % Nb == 0 &&
+                rows_per_frame > 0 && (!gb || cb <= ld_b));
+    hipStream_t s = (hipStream_t)stream;
+    const long total = (long)N * rows_per_frame * ld_a + (gb ? (long)Nb * rows_per_frame * ld_b : 0);
+    ProfScope prof(K_LAYOUT, s, (double)total * 8);
+    hipLaunchKernelGGL(concat2_bwd_kernel, dim3(grid_for(total, 8192)), dim3(256), 0, s, g, ld_g, ca, cb, Nb, ga, ld_a, gb, ld_b, N,
+                       rows_per_frame);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

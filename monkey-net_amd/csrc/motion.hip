@@ -693,7 +693,9 @@ struct Bilin {
 // sub-range of the blocks of a multi-level launch (warp_levels_*_kernel)
 __device__ __forceinline__ void deform_fwd_body(const float* __restrict__ inp, int ld_in, int C, int h, int w,
                                                 const float* __restrict__ field, int hf, int wf, int mode,
-                                                float* __restrict__ out, int ld_out, int out_off, int N, int vb, int vgrid) {
+                                                float* __restrict__ out, int ld_out, int out_off, int N, int vb, int vgrid,
+                                                bool zero_tail = false) {
+    // zero_tail: nothing follows the C channels in the row (no embedding): the last quad's pad channels are written 0
     const int nq = (C + 3) / 4;
     const long P = (long)h * w;
     const long total = (long)N * P * nq;
@@ -735,6 +737,9 @@ __device__ __forceinline__ void deform_fwd_body(const float* __restrict__ inp, i
             if (rem > 1) op[1] = o.y;
             if (rem > 2) op[2] = o.z;
             if (rem > 3) op[3] = o.w;
+            if (zero_tail)
+                for (int k = rem > 0 ? rem : 0; k < 4; ++k)
+                    if (out_off + q * 4 + k < ld_out) op[k] = 0.f;
         }
     }
 }
@@ -1021,15 +1026,20 @@ __global__ void __launch_bounds__(256) warp_levels_fwd_kernel(WarpSegs a) {
         const WarpSeg& L = a.lv[l];
         if (b >= L.warp_begin && b < L.warp_begin + L.warp_blocks) {
             deform_fwd_body(L.inp, L.ld_in, L.C, L.h, L.w, a.field, a.hf, a.wf, a.mode, L.out, L.ld_out, 0, a.N, b - L.warp_begin,
-                            L.warp_blocks);
+                            L.warp_blocks, L.ke == 0);
             return;
         }
         if (b >= L.emb_begin && b < L.emb_begin + L.emb_blocks) {
             // resize of the embedding into channels [emb_off, emb_off + ke) (resize_nearest_kernel / resize_bilinear_kernel of layout.hip)
-            const long total = (long)a.N * L.h * L.w * L.ke;
+            const int kz = L.ld_out - L.emb_off;              // the embedding's ke channels and the row's pad channels behind them
+            const long total = (long)a.N * L.h * L.w * kz;
             for (long i = (long)(b - L.emb_begin) * 256 + threadIdx.x; i < total; i += (long)L.emb_blocks * 256) {
-                const int c = (int)(i % L.ke);
-                const long p = i / L.ke;
+                const int c = (int)(i % kz);
+                const long p = i / kz;
+                if (c >= L.ke) {
+                    L.out[p * L.ld_out + L.emb_off + c] = 0.f;
+                    continue;
+                }
                 const int x = (int)(p % L.w);
                 const long t = p / L.w;
                 const int y = (int)(t % L.h);
@@ -1718,6 +1728,7 @@ int mnk_warp_levels_fwd(const MnkWarpLevel* levels, int nlevels, const float* fi
     for (int l = 0; l < nlevels; ++l) {
         const MnkWarpLevel& m = levels[l];
         MNK_REQUIRE(m.out && (m.ke == 0 || emb));
+        MNK_REQUIRE(m.ke > 0 || m.ld_out == round_up(m.C, 4));       // (ke = 0: the warp itself writes the row's pad channels)
         WarpSeg& L = a.lv[l];
         L.inp = m.inp, L.out = m.out, L.ld_in = m.ld_in, L.C = m.C, L.h = m.h, L.w = m.w, L.ld_out = m.ld_out, L.ke = m.ke,
         L.emb_off = m.emb_off;
@@ -1726,7 +1737,7 @@ int mnk_warp_levels_fwd(const MnkWarpLevel* levels, int nlevels, const float* fi
         L.warp_blocks = grid_for(px * ((m.C + 3) / 4));
         blocks += L.warp_blocks;
         L.emb_begin = blocks;
-        L.emb_blocks = m.ke > 0 ? grid_for(px * m.ke) : 0;
+        L.emb_blocks = m.ke > 0 ? grid_for(px * (m.ld_out - m.emb_off)) : 0;
         blocks += L.emb_blocks;
         bytes += (double)px * (m.C + m.ke) * 8;
     }

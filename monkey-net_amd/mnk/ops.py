@@ -210,13 +210,8 @@ class Concat2PairFn(_Fn):
     def forward(ctx, a, ca, b, cb):
         n, h, w, _ = a.shape
         assert b.shape[0] * 2 == n and b.shape[1:3] == a.shape[1:3]
-        whole = ca % 4 == 0 and b.shape[-1] == ceil4(cb)
-        out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)
-        rows = n * h * w
-        _call("mnk_copy_channels", a, _p(a), a.shape[-1], 0, _p(out), out.shape[-1], 0, ca, rows, 0)
-        for half in (out[:n // 2], out[n // 2:]):
-            _call("mnk_copy_channels", a, _p(b), b.shape[-1], 0, _p(half), out.shape[-1], ca, ceil4(cb) if whole else cb,
-                  rows // 2, 0)
+        out = torch.empty(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)
+        _call("mnk_concat2_fwd", a, _p(a), a.shape[-1], ca, _p(b), b.shape[-1], cb, n // 2, _p(out), out.shape[-1], n, h * w)
         ctx.meta = (ca, cb, a.shape[-1], b.shape[-1])
         return out
 
@@ -225,14 +220,9 @@ class Concat2PairFn(_Fn):
         ca, cb, lda, ldb = ctx.meta
         g = g.contiguous()
         n, h, w, ld = g.shape
-        rows = n * h * w
-        whole = ca % 4 == 0 and lda == ca and ldb == ceil4(cb) and ld == ca + ldb
-        alloc = torch.empty if whole else torch.zeros
-        ga = alloc(n, h, w, lda, dtype=torch.float32, device=g.device)
-        gb = alloc(n // 2, h, w, ldb, dtype=torch.float32, device=g.device)
-        _call("mnk_copy_channels", g, _p(g), ld, 0, _p(ga), lda, 0, ca, rows, 0)
-        for i, half in enumerate((g[:n // 2], g[n // 2:])):
-            _call("mnk_copy_channels", g, _p(half), ld, ca, _p(gb), ldb, 0, ldb if whole else cb, rows // 2, i)
+        ga = torch.empty(n, h, w, lda, dtype=torch.float32, device=g.device)
+        gb = torch.empty(n // 2, h, w, ldb, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        _call("mnk_concat2_bwd", g, _p(g), ld, ca, cb, n // 2, _p(ga), lda, _p(gb), ldb, n, h * w)
         return ga, None, gb, None
 
 
@@ -242,12 +232,8 @@ class Concat2Fn(_Fn):
     @staticmethod
     def forward(ctx, a, ca, b, cb):
         n, h, w, _ = a.shape
-        # ca a multiple of 4: copying b with its (zero) pad channels writes every column of the output -- no zero fill
-        whole = ca % 4 == 0 and b.shape[-1] == ceil4(cb)
-        out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)
-        rows = n * h * w
-        _call("mnk_copy_channels", a, _p(a), a.shape[-1], 0, _p(out), out.shape[-1], 0, ca, rows, 0)
-        _call("mnk_copy_channels", a, _p(b), b.shape[-1], 0, _p(out), out.shape[-1], ca, ceil4(cb) if whole else cb, rows, 0)
+        out = torch.empty(n, h, w, ceil4(ca + cb), dtype=torch.float32, device=a.device)       # one launch, pads included
+        _call("mnk_concat2_fwd", a, _p(a), a.shape[-1], ca, _p(b), b.shape[-1], cb, n, _p(out), out.shape[-1], n, h * w)
         ctx.meta = (ca, cb, a.shape[-1], b.shape[-1])
         return out
 
@@ -256,14 +242,9 @@ class Concat2Fn(_Fn):
         ca, cb, lda, ldb = ctx.meta
         g = g.contiguous()
         n, h, w, ld = g.shape
-        rows = n * h * w
-        # (the incoming gradient is an act of this library: its pad channels are zero)
-        whole = ca % 4 == 0 and lda == ca and ldb == ceil4(cb) and ld == ca + ldb
-        alloc = torch.empty if whole else torch.zeros
-        ga = alloc(n, h, w, lda, dtype=torch.float32, device=g.device)
-        gb = alloc(n, h, w, ldb, dtype=torch.float32, device=g.device)
-        _call("mnk_copy_channels", g, _p(g), ld, 0, _p(ga), lda, 0, ca, rows, 0)
-        _call("mnk_copy_channels", g, _p(g), ld, ca, _p(gb), ldb, 0, ldb if whole else cb, rows, 0)
+        ga = torch.empty(n, h, w, lda, dtype=torch.float32, device=g.device)
+        gb = torch.empty(n, h, w, ldb, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        _call("mnk_concat2_bwd", g, _p(g), ld, ca, cb, n, _p(ga), lda, _p(gb), ldb, n, h * w)
         return ga, None, gb, None
 
 
@@ -1734,10 +1715,9 @@ class WarpAllFn(_Fn):
             for i, (inp, (c, ke)) in enumerate(zip(inps, specs)):
                 n, h, w, ld_in = inp.shape
                 e = emb if ke else None
-                whole = c % 4 == 0 and (e is None or e.shape[-1] == ceil4(ke))
-                out = (torch.empty if whole else torch.zeros)(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
-                lv[i] = (inp.data_ptr(), out.data_ptr(), 0, 0, ld_in, c, h, w, out.shape[-1],
-                         (ceil4(ke) if whole else ke) if e is not None else 0, c, 0)
+                # (the launch writes every channel of every row -- warp, embedding, pad channels: no zero fill)
+                out = torch.empty(n, h, w, ceil4(c + ke), dtype=torch.float32, device=inp.device)
+                lv[i] = (inp.data_ptr(), out.data_ptr(), 0, 0, ld_in, c, h, w, out.shape[-1], ke if e is not None else 0, c, 0)
                 outs.append(out)
             _call("mnk_warp_levels_fwd", field, lv.ctypes.data, len(inps), _p(field), hf, wf, mode, _p(emb),
                   emb.shape[-1] if emb is not None else 0, emb.shape[1] if emb is not None else 0,

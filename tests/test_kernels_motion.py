@@ -296,3 +296,33 @@ def test_all_warps_in_one_launch_equal_the_per_level_launches(be, monkeypatch, e
     assert relerr(gf1, gf0) < 1e-5
     for a, b in zip(gx0, gx1):
         assert relerr(b, a) < 1e-5
+
+
+@pytest.mark.parametrize("ca,cb,halves", [(3, 11, 1), (3, 11, 2), (8, 6, 1), (5, 4, 2), (64, 10, 1)])
+def test_concat_of_two_acts_and_its_adjoint_in_one_launch_each(be, ca, cb, halves):
+    """torch.cat([a, b], channel) on acts (modules/util.py:185; discriminator.py:50-52) with the pad channels written by the
+    same launch; halves = 2: the batched discriminator pass, b holds half the frames and its gradient is the sum of both halves"""
+    from mnk import ops
+    g = torch.Generator().manual_seed(2)
+    n, h, w = 4, 5, 7
+    a = torch.zeros(n, h, w, ceil4(ca))
+    a[..., :ca] = torch.randn(n, h, w, ca, generator=g)
+    b = torch.zeros(n // halves, h, w, ceil4(cb))
+    b[..., :cb] = torch.randn(n // halves, h, w, cb, generator=g)
+    A, B = be.t(a).requires_grad_(True), be.t(b).requires_grad_(True)
+    fn = ops.Concat2PairFn if halves == 2 else ops.Concat2Fn
+    out = fn.apply(A, ca, B, cb)
+    want = torch.zeros(n, h, w, ceil4(ca + cb))
+    want[..., :ca] = a[..., :ca]
+    want[..., ca:ca + cb] = torch.cat([b] * halves, 0)[..., :cb]
+    be.sync()
+    assert torch.equal(out.detach().cpu(), want)
+    go = torch.zeros_like(want)
+    go[..., :ca + cb] = torch.randn(n, h, w, ca + cb, generator=g)
+    out.backward(be.t(go))
+    be.sync()
+    ga, gb = A.grad.cpu(), B.grad.cpu()
+    assert torch.equal(ga[..., :ca], go[..., :ca]) and torch.all(ga[..., ca:] == 0)
+    wb = go[..., ca:ca + cb]
+    wb = wb[:n // 2] + wb[n // 2:] if halves == 2 else wb
+    assert torch.equal(gb[..., :cb], wb) and torch.all(gb[..., cb:] == 0)
