@@ -53,7 +53,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PMC_ROUND = "r04"               # profiles/<round>_pmc_traffic_<config>_b<batch>.json: the PMC passes `roofline.traffic` is read from
+PMC_ROUND = "r05"               # profiles/<round>_pmc_traffic_<config>_b<batch>.json: the PMC passes `roofline.traffic` is read from
 
 
 def kernel_source_stamp():

@@ -321,3 +321,73 @@ def test_whole_training_iterations_of_several_processes_through_the_peer_to_peer
                 d = (r0[key][k] - v).abs()
                 assert float(d.max()) <= 4.2 * lr, (key, k, float(d.max()))
     print("exchange forms used by rank 0:", r0["calls"])
+
+
+# ---- a peer that does not arrive: the waiting rank must not train on stale mailbox words --------------------------------
+def _dead_peer_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "monkey-net_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import threading
+    import time
+    threading.Timer(120.0, lambda: os._exit(17)).start()
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    from mnk import dist as mdist
+    assert mdist.p2p_comm(force=True) is not None, "the peer-to-peer exchange did not come up"
+    mdist.P2P_TIMEOUT_MS = 400
+    x = torch.arange(1, 33, dtype=torch.float32, device=dev) * (rank + 1)
+    ok = mdist.all_reduce_sum(x)                       # both ranks: a complete exchange
+    torch.cuda.synchronize()
+    assert torch.equal(ok.cpu(), torch.arange(1, 33, dtype=torch.float32) * 3) and mdist.p2p_error() == 0
+    dist.barrier()
+    if rank == 0:                                      # rank 1 stays away from the next two exchanges
+        t0 = time.perf_counter()
+        bad = mdist.all_reduce_sum(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        again = mdist.all_reduce_sum(x)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        assert bool(torch.isnan(bad).all()), "a given-up peer's value must be NaN, never a stale word: %s" % bad[:4]
+        assert bool(torch.isnan(again).all())
+        assert mdist.p2p_error() == 2, mdist.p2p_error()           # 1 + the rank that was given up on
+        assert 0.3 < t1 - t0 < 5.0, t1 - t0                         # waited for the timeout once ...
+        assert t2 - t1 < 0.2, t2 - t1                               # ... and never again
+        try:
+            mdist.check_p2p()
+            raise AssertionError("check_p2p() must raise after a give-up")
+        except RuntimeError as e:
+            assert "rank 1" in str(e)
+        with open(os.path.join(out_dir, "ok.txt"), "w") as f:
+            f.write("first wait %.3f s, second exchange %.4f s\n" % (t1 - t0, t2 - t1))
+    dist.barrier()
+    dist.destroy_process_group()
+    os._exit(0)
+
+
+def test_a_peer_that_does_not_arrive_poisons_the_sums_and_is_reported(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_dead_peer_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert codes == [0, 0], "worker exit codes %s (17 = the worker's own deadline)" % codes
+    print(open(os.path.join(tmp_path, "ok.txt")).read().strip())
