@@ -13,6 +13,7 @@ constexpr int P2P_MAX_WORLD = 16;
 // with them the losses -- of every rank that waited become NaN instead of silently wrong; the handle's error word says which
 // rank was missing (mnk_p2p_error), and mnk.engine.TrainStep polls it.
 constexpr unsigned long long P2P_POISON = 0x7fc00000ull;
+constexpr unsigned long long P2P_RECHECK_TICKS = 100000ull;      // 1 ms of the 100 MHz wall clock
 
 struct PeerTable {
     unsigned long long* box[P2P_MAX_WORLD];      // every rank's mailbox as mapped into THIS process (box[rank] = the local one)
@@ -46,11 +47,14 @@ __device__ __forceinline__ float p2p_exchange_value(const PeerTable& peers, int 
                            __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long* w = row_of(peers.box[rank], world, slot, lane) + index;
         const unsigned long long t0 = wall_clock64();
-        // a handle that already gave a peer up does not wait again: every later exchange of the run ends at once (poisoned)
-        const unsigned long long limit = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0ull : timeout_ticks;
         unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while ((unsigned)(v >> 32) != seq) {
-            if ((unsigned long long)wall_clock64() - t0 > limit) {
+            // a handle that already gave a peer up does not wait the whole timeout again -- but the error word is looked at only
+            // after a millisecond of waiting: read in front of the poll it put one more memory round trip into EVERY exchange
+            // (84 per iteration: +0.1 ms on the forced-rank step)
+            const unsigned long long waited = (unsigned long long)wall_clock64() - t0;
+            if (waited > timeout_ticks ||
+                (waited > P2P_RECHECK_TICKS && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(state + 1, 1u + (unsigned)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 v = P2P_POISON;       // a stale word must never pass for the peer's value: the sum becomes NaN
                 break;
@@ -80,11 +84,14 @@ __device__ __forceinline__ float p2p_exchange_values(const PeerTable& peers, int
                            __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long* w = row_of(peers.box[rank], world, slot, q) + index;
         const unsigned long long t0 = wall_clock64();
-        // a handle that already gave a peer up does not wait again: every later exchange of the run ends at once (poisoned)
-        const unsigned long long limit = __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0ull : timeout_ticks;
         unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         while ((unsigned)(v >> 32) != seq) {
-            if ((unsigned long long)wall_clock64() - t0 > limit) {
+            // a handle that already gave a peer up does not wait the whole timeout again -- but the error word is looked at only
+            // after a millisecond of waiting: read in front of the poll it put one more memory round trip into EVERY exchange
+            // (84 per iteration: +0.1 ms on the forced-rank step)
+            const unsigned long long waited = (unsigned long long)wall_clock64() - t0;
+            if (waited > timeout_ticks ||
+                (waited > P2P_RECHECK_TICKS && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(state + 1, 1u + (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 v = P2P_POISON;       // a stale word must never pass for the peer's value: the sum becomes NaN
                 break;

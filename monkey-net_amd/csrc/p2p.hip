@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int
     // ---- poll + sum in rank order (every rank: the same order, the same bits)
     const unsigned long long t0 = wall_clock64();
     bool gave_up = false;
-    if (__hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) timeout_ticks = 0;    // (see p2p.h: no second wait)
+
 #pragma unroll
     for (int k = 0; k < (P2P_MAXF + 255) / 256; ++k) {
         const int i = t + 256 * k;
@@ -74,7 +74,9 @@ __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int
             const unsigned long long* w = row_of(peers.box[rank], world, slot, q) + i;
             unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             while ((unsigned)(v >> 32) != seq && !gave_up) {
-                if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+                const unsigned long long waited = (unsigned long long)wall_clock64() - t0;
+                if (waited > timeout_ticks ||          // (see p2p.h: no second full wait after a give-up)
+                    (waited > P2P_RECHECK_TICKS && __hip_atomic_load(state + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     gave_up = true;
                     __hip_atomic_store(state + 1, 1u + (unsigned)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
