@@ -1080,13 +1080,12 @@ __global__ void __launch_bounds__(256) warp_levels_bwd_pixel_kernel(WarpSegs a) 
 // embedding (one thread per element)
 // one level's share of the gradient of field texel (n, ys, xs): the pixels of the level that read the texel (nearest pick or
 // the bilinear footprint, with the forward's weights in the forward's order) in pixel order, the channel slices in order
-__device__ __forceinline__ void field_grad_of_level(const WarpSegs& a, const WarpSeg& L, long n, int ys, int xs, int part, int parts,
-                                                    float& sx, float& sy) {
+__device__ __forceinline__ void field_grad_of_level(const WarpSegs& a, const WarpSeg& L, long n, int ys, int xs, float& sx, float& sy) {
     const long npix = (long)a.N * L.h * L.w;
     int h_lo, h_hi, w_lo, w_hi;
     field_window(ys, a.hf, L.h, a.mode, h_lo, h_hi);
     field_window(xs, a.wf, L.w, a.mode, w_lo, w_hi);
-    for (int y = h_lo + part; y <= h_hi; y += parts) {        // (parts > 1: the window's rows are dealt out to `parts` lanes)
+    for (int y = h_lo; y <= h_hi; ++y) {
         Lin1D ly;
         bool y0, y1;
         if (a.mode == 0) {
@@ -1131,14 +1130,13 @@ constexpr int EMB_CH = 16;      // embedding channels a lane accumulates per pas
 
 // one level's share of the gradient of embedding texel (n, ys, xs), channels [c0, c0 + EMB_CH): the gathers of
 // resize_nearest_bwd_kernel / resize_bilinear_bwd_kernel (layout.hip), the same order of the additions
-__device__ __forceinline__ void emb_grad_of_level(const WarpSegs& a, const WarpSeg& L, int n, int ys, int xs, int c0, int part, int parts,
-                                                  float* acc) {
+__device__ __forceinline__ void emb_grad_of_level(const WarpSegs& a, const WarpSeg& L, int n, int ys, int xs, int c0, float* acc) {
     int h_lo, h_hi, w_lo, w_hi;
     field_window(ys, a.He, L.h, a.mode, h_lo, h_hi);
     field_window(xs, a.We, L.w, a.mode, w_lo, w_hi);
     const int cn = L.ke - c0 < EMB_CH ? L.ke - c0 : EMB_CH;
     const bool vec = ((L.emb_off + c0) & 3) == 0 && (L.ld_out & 3) == 0;
-    for (int y = h_lo + part; y <= h_hi; y += parts) {
+    for (int y = h_lo; y <= h_hi; ++y) {
         Lin1D ly;
         bool y0, y1;
         if (a.mode == 0) {
@@ -1263,11 +1261,10 @@ __device__ __forceinline__ void emb_grad_bilinear(const WarpSegs& a, long i, int
     }
 }
 
-// pass B: the field gradient and the gradient of the embedding -- a GROUP of lanes per texel, one lane (nearest) or four
-// (bilinear: the rows of the level's window dealt out) per level: the levels' footprints differ by orders of magnitude (a
-// 64 x 64 field under a 256 x 256 map has 121 candidate pixels per texel and level); the lanes' sums are added in part, then
-// level order -- and d input of every level (texel tiles).  The long-running texel blocks come FIRST in the grid so that they
-// run under the tile gathers instead of behind them.
+// pass B: the field gradient and the gradient of the embedding -- SIXTEEN lanes per texel, lane l works on level l (the levels'
+// footprints differ by orders of magnitude), the lanes' sums are added in level order; under a bilinear resize the embedding
+// takes the wavefront-per-texel form above -- and d input of every level (texel tiles).  The long-running texel blocks come
+// FIRST in the grid so that they run under the tile gathers instead of behind them.
 __global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1278,9 +1275,8 @@ __global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a)
         return;
     }
     // the field gradient (both resize modes) and the embedding under a nearest resize: sixteen lanes per texel, one per level
-    const int G = 16, P = 1, per_block = 256 / G;
-    const int lane_g = threadIdx.x & (G - 1), group = threadIdx.x / G, gbase = lane & ~(G - 1);
-    const int lvl = lane_g / P, part = lane_g % P;
+    const int G = 16, per_block = 256 / G;
+    const int lvl = threadIdx.x & (G - 1), group = threadIdx.x / G, gbase = lane & ~(G - 1);
     // a lane picks ITS level: the level table moves from the kernel arguments (uniform access only -- a per-lane index makes
     // the compiler walk the distinct values one after the other) into LDS
     __shared__ WarpSeg s_lv[MAX_WARP_LEVELS];
@@ -1299,20 +1295,15 @@ __global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a)
             if (i < total && lvl < a.n) {
                 const int xs = (int)(i % a.wf);
                 const long t = i / a.wf;
-                field_grad_of_level(a, s_lv[lvl], t / a.hf, (int)(t % a.hf), xs, part, P, sx, sy);
+                field_grad_of_level(a, s_lv[lvl], t / a.hf, (int)(t % a.hf), xs, sx, sy);
             }
             float tx = 0.f, ty = 0.f;
-            for (int l = 0; l < a.n; ++l) {
-                float vx = 0.f, vy = 0.f;
-                for (int j = 0; j < P; ++j) {                    // the level's parts, then the levels, in order
-                    const float px = __shfl(sx, gbase + l * P + j), py = __shfl(sy, gbase + l * P + j);
-                    vx = j ? vx + px : px;
-                    vy = j ? vy + py : py;
-                }
+            for (int l = 0; l < a.n; ++l) {                       // the levels' sums in level order
+                const float vx = __shfl(sx, gbase + l), vy = __shfl(sy, gbase + l);
                 tx = l ? tx + vx : vx;
                 ty = l ? ty + vy : vy;
             }
-            if (i < total && lane_g == 0) {
+            if (i < total && lvl == 0) {
                 if (a.dfield_accumulate) {
                     a.dfield[i * 2] += tx;
                     a.dfield[i * 2 + 1] += ty;
@@ -1338,22 +1329,18 @@ __global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a)
 #pragma unroll
                 for (int c = 0; c < EMB_CH; ++c) acc[c] = 0.f;
                 const bool mine = i < total && lvl < a.n && s_lv[lvl < a.n ? lvl : 0].ke > c0;
-                if (mine) emb_grad_of_level(a, s_lv[lvl], n, ys, xs, c0, part, P, acc);
+                if (mine) emb_grad_of_level(a, s_lv[lvl], n, ys, xs, c0, acc);
 #pragma unroll
                 for (int c = 0; c < EMB_CH; ++c) {
                     float tot = 0.f;
                     bool first = true;
                     for (int l = 0; l < a.n; ++l) {
-                        float v = 0.f;
-                        for (int j = 0; j < P; ++j) {
-                            const float pv = __shfl(acc[c], gbase + l * P + j);
-                            v = j ? v + pv : pv;
-                        }
+                        const float v = __shfl(acc[c], gbase + l);
                         if (a.lv[l].ke <= c0 + c) continue;          // (uniform: the level has no such channel)
                         tot = first ? v : tot + v;
                         first = false;
                     }
-                    if (i < total && lane_g == 0 && c0 + c < a.ld_emb) a.demb[i * a.ld_emb + c0 + c] = tot;
+                    if (i < total && lvl == 0 && c0 + c < a.ld_emb) a.demb[i * a.ld_emb + c0 + c] = tot;
                 }
             }
         }
