@@ -191,6 +191,14 @@ def p2p_error():
     return int(flag.value)
 
 
+def disable_p2p():
+    """Leave the peer-to-peer exchange for the rest of the process (every rank must call it at the same point): the SyncBN
+    sums travel through the collective path from now on.  The mailboxes stay mapped -- a peer may still be inside a kernel."""
+    _P2P["tried"] = True
+    _P2P["handle"] = None
+    _P2P["max"] = 0
+
+
 def check_p2p():
     """Raise if a peer-to-peer exchange gave a rank up (synchronises the device; TrainStep calls it every few iterations, a
     user-owned loop may call it before it writes a checkpoint)."""
