@@ -6,12 +6,10 @@
 #include <stdlib.h>
 
 #include "mnk_common.h"
-#ifndef HIPEMU
 #include "p2p.h"
 namespace mnk {
 bool p2p_launch_info(void* handle, PeerTable* peers, int* rank, int* world, unsigned** state);      // p2p.hip
 }
-#endif
 
 using namespace mnk;
 
@@ -180,7 +178,6 @@ __global__ void __launch_bounds__(256) colsum2_final_kernel(const float* __restr
     }
 }
 
-#ifndef HIPEMU
 // colsum2_final_kernel with the SyncBN exchange of one node inside (csrc/p2p.hip's protocol): the wavefront that finishes the
 // sum of column i pushes it into every rank's mailbox and adds the `world` contributions in rank order -- the second stage of
 // the statistics and their all-reduce are ONE launch, so a norm layer of a data-parallel run costs as many launches as on one
@@ -235,7 +232,6 @@ static int launch_final_sync(void* p2p, const float* partial, int row_blocks, in
                        global_sums, peers, rank, world, state, (unsigned long long)timeout_ms * 100000ull);
     return MNK_OK;
 }
-#endif
 
 struct StatsLoader {
     const float* x;
@@ -826,7 +822,6 @@ __global__ void __launch_bounds__(1024) bn_small_bwd_kernel(BwdLoader L, double 
     }
 }
 
-#ifndef HIPEMU
 // bn_small_bwd_kernel of one rank of a data-parallel run: ONE channel quad per block (256 threads over the rows); after the
 // block's own sums (= this rank's dbeta / dgamma contributions, written to `sums`) wave 0 exchanges the eight of them with every
 // rank of the node in one round trip (p2p_exchange_values) and the apply pass runs with the sums over all ranks -- statistics,
@@ -936,7 +931,6 @@ __global__ void __launch_bounds__(256) bn_small_fwd_sync_kernel(SmallFwdArgs a, 
     SmallP2PExchange x{peers, rank, world, state, timeout_ticks, state[0] + 1};
     bn_small_fwd_body(a, x);
 }
-#endif
 
 static inline int small_txn(int nv) { return g_small_txn ? g_small_txn : (nv >= 128 ? 4 : (nv >= 64 ? 2 : 1)); }
 
@@ -1153,23 +1147,16 @@ int mnk_bn_stats_finish(const float* partial, int row_blocks, int ld, int C, flo
 int mnk_bn_stats_finish_sync(void* p2p, const float* partial, int row_blocks, int ld, int C, float* sums_local, float* sums_global,
                              int timeout_ms, void* stream) {
     MNK_REQUIRE(p2p && partial && sums_global && row_blocks > 0 && C > 0 && ld >= C);
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BN_STATS, s, (double)row_blocks * 2 * C * 4);
     const int rc = launch_final_sync(p2p, partial, row_blocks, ld, C, sums_local, sums_global, timeout_ms, s);
     if (rc != MNK_OK) return rc;
     MNK_LAUNCH_CHECK();
     return MNK_OK;
-#endif
 }
 int mnk_bn_stats_sync(void* p2p, const float* x, int ld, long rows, int C, float* sums_local, float* sums_global, float* ws,
                       size_t ws_floats, int timeout_ms, void* stream) {
     MNK_REQUIRE(p2p && x && sums_global && ws && rows > 0 && C > 0 && ld % 4 == 0 && ld >= C);
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     Map2D m = make_map(rows, ld);
     if (ws_floats < (size_t)m.row_blocks * 2 * ld) {
         set_error("mnk_bn_stats_sync: workspace too small");
@@ -1184,7 +1171,6 @@ int mnk_bn_stats_sync(void* p2p, const float* x, int ld, long rows, int C, float
     if (rc != MNK_OK) return rc;
     MNK_LAUNCH_CHECK();
     return MNK_OK;
-#endif
 }
 int mnk_bn_act_bwd_stats_sync(void* p2p, const float* y, int ld_y, const float* dz, int ld_dz, int dz_off, const float* mean,
                               const float* invstd, const float* scale, const float* beta, int N, int H, int W, int C, int relu,
@@ -1193,9 +1179,6 @@ int mnk_bn_act_bwd_stats_sync(void* p2p, const float* y, int ld_y, const float* 
     MNK_REQUIRE(p2p && y && dz && mean && invstd && scale && beta && sums_global && ws && N > 0 && H > 0 && W > 0 && C > 0);
     MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && dz_off >= 0 && dz_off + C <= ld_dz);
     MNK_REQUIRE((!pool || (H >= 2 && W >= 2)) && (long)N * H * W < (1L << 31));
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     const long rows = (long)N * H * W;
     const int ldc = round_up(C, 4);
     Map2D m = make_map(rows, ldc);
@@ -1212,7 +1195,6 @@ int mnk_bn_act_bwd_stats_sync(void* p2p, const float* y, int ld_y, const float* 
     if (rc != MNK_OK) return rc;
     MNK_LAUNCH_CHECK();
     return MNK_OK;
-#endif
 }
 
 int mnk_bn_finalize(const float* sums, double count, const float* gamma, float* running_mean, float* running_var,
@@ -1309,9 +1291,6 @@ int mnk_bn_small_fwd_sync(void* p2p, const float* ws, int splits, int ldw, int p
     MNK_REQUIRE(C > 0 && ld_y % 4 == 0 && ld_y == round_up(C, 4) && ld_z == ld_y && (long)N * H * W <= 4096 && timeout_ms > 0);
     MNK_REQUIRE(!ws || (splits >= 1 && ldw == ld_y && (phases == 1 || (phases == 4 && H % 2 == 0 && W % 2 == 0))));
     MNK_REQUIRE(!pool || (H % 2 == 0 && W % 2 == 0));
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     PeerTable peers;
     int rank = 0, world = 0;
     unsigned* state = nullptr;
@@ -1327,7 +1306,6 @@ int mnk_bn_small_fwd_sync(void* p2p, const float* ws, int splits, int ldw, int p
                        (unsigned long long)timeout_ms * 100000ull);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
-#endif
 }
 
 int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,
@@ -1355,9 +1333,6 @@ int mnk_bn_small_bwd_sync(void* p2p, const float* y, int ld_y, const float* dz, 
     MNK_REQUIRE(count_all_ranks > 1 && timeout_ms > 0);
     MNK_REQUIRE(ld_y % 4 == 0 && ld_y >= round_up(C, 4) && ld_dy % 4 == 0 && ld_dy >= round_up(C, 4) && ld_dz >= C);
     MNK_REQUIRE((long)N * H * W <= 4096 && (!pool || (H % 2 == 0 && W % 2 == 0)));
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     PeerTable peers;
     int rank = 0, world = 0;
     unsigned* state = nullptr;
@@ -1373,6 +1348,5 @@ int mnk_bn_small_bwd_sync(void* p2p, const float* y, int ld_y, const float* dz, 
                        peers, rank, world, state, (unsigned long long)timeout_ms * 100000ull);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
-#endif
 }
 }

@@ -29,13 +29,10 @@
 #include <vector>
 
 #include "mnk_common.h"
-#ifndef HIPEMU
 #include "p2p.h"
-#endif
 
 using namespace mnk;
 
-#ifndef HIPEMU
 namespace {
 
 __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int rank, int world, unsigned* __restrict__ state,
@@ -94,9 +91,7 @@ __global__ void __launch_bounds__(256) p2p_allreduce_kernel(PeerTable peers, int
 }
 
 }  // namespace
-#endif
 
-#ifndef HIPEMU
 namespace mnk {
 // what a kernel of another file needs to carry an exchange (batchnorm.hip's synchronised second stage)
 bool p2p_launch_info(void* handle, PeerTable* peers, int* rank, int* world, unsigned** state) {
@@ -108,24 +103,15 @@ bool p2p_launch_info(void* handle, PeerTable* peers, int* rank, int* world, unsi
     return true;
 }
 }  // namespace mnk
-#endif
 
 extern "C" {
 
 int mnk_p2p_max_floats(void) {
-#ifdef HIPEMU
-    return 0;
-#else
     return P2P_MAXF;
-#endif
 }
 
 int mnk_p2p_create(int rank, int world, void** handle_out) {
     MNK_REQUIRE(handle_out && world >= 1 && rank >= 0 && rank < world);
-#ifdef HIPEMU
-    set_error("mnk_p2p_create: the peer-to-peer exchange needs the HIP runtime (not available in the CPU emulation)");
-    return MNK_ECOMM;
-#else
     MNK_REQUIRE(world <= P2P_MAX_WORLD);
     P2P* p = new P2P();
     memset(p, 0, sizeof(*p));
@@ -162,14 +148,10 @@ int mnk_p2p_create(int rank, int world, void** handle_out) {
     p->peers.box[rank] = p->local;
     *handle_out = p;
     return MNK_OK;
-#endif
 }
 
 int mnk_p2p_export(void* handle, void* ipc_handle64) {
     MNK_REQUIRE(handle && ipc_handle64);
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     P2P* p = (P2P*)handle;
     hipIpcMemHandle_t h;
     static_assert(sizeof(hipIpcMemHandle_t) <= 64, "the exported handle travels as 64 bytes");
@@ -182,14 +164,10 @@ int mnk_p2p_export(void* handle, void* ipc_handle64) {
     memset(ipc_handle64, 0, 64);
     memcpy(ipc_handle64, &h, sizeof(h));
     return MNK_OK;
-#endif
 }
 
 int mnk_p2p_connect(void* handle, const void* all_handles) {
     MNK_REQUIRE(handle && all_handles);
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     P2P* p = (P2P*)handle;
     for (int q = 0; q < p->world; ++q) {
         if (q == p->rank) continue;
@@ -205,14 +183,10 @@ int mnk_p2p_connect(void* handle, const void* all_handles) {
         p->opened[q] = true;
     }
     return MNK_OK;
-#endif
 }
 
 int mnk_p2p_allreduce(void* handle, const float* in, float* out, int n, int timeout_ms, void* stream) {
     MNK_REQUIRE(handle && in && out && n > 0 && timeout_ms > 0);
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     P2P* p = (P2P*)handle;
     MNK_REQUIRE(n <= P2P_MAXF);
     for (int q = 0; q < p->world; ++q) MNK_REQUIRE(p->peers.box[q] != nullptr);
@@ -221,35 +195,23 @@ int mnk_p2p_allreduce(void* handle, const float* in, float* out, int n, int time
                        (unsigned long long)timeout_ms * 100000ull);      // wall_clock64: 100 MHz
     MNK_LAUNCH_CHECK();
     return MNK_OK;
-#endif
 }
 
 int mnk_p2p_error(void* handle, int* flag_out) {
     MNK_REQUIRE(handle && flag_out);
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     P2P* p = (P2P*)handle;
     unsigned st[2] = {0, 0};
     if (hipMemcpy(st, p->state, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return MNK_ELAUNCH;
     *flag_out = (int)st[1];
     return MNK_OK;
-#endif
 }
 
 int mnk_p2p_memory_kind(void* handle) {
-#ifdef HIPEMU
-    return -1;
-#else
     return handle ? ((P2P*)handle)->memory_kind : -1;
-#endif
 }
 
 int mnk_p2p_destroy(void* handle) {
     MNK_REQUIRE(handle);
-#ifdef HIPEMU
-    return MNK_ECOMM;
-#else
     P2P* p = (P2P*)handle;
     (void)hipDeviceSynchronize();
     for (int q = 0; q < p->world; ++q)
@@ -258,6 +220,5 @@ int mnk_p2p_destroy(void* handle) {
     if (p->state) (void)hipFree(p->state);
     delete p;
     return MNK_OK;
-#endif
 }
 }

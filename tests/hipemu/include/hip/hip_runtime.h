@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <functional>
 
 #define HIPEMU 1
@@ -82,6 +83,37 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuc
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+
+// ---- what the peer-to-peer SyncBN exchange (csrc/p2p.hip, the *_sync kernels of batchnorm.hip) uses -----------------------------
+// "Device memory" is host memory here; one process has no peer to map, so the IPC calls fail (mnk_p2p_export reports it) -- but a
+// handle of world size 1 is complete after mnk_p2p_create, and the kernels that carry an exchange run on it (a rank pushes into
+// its own mailbox and reads it back): their indexing, reductions and the exchange protocol are checked on the CPU too.
+enum { hipDeviceMallocUncached = 3, hipDeviceMallocFinegrained = 1, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1,
+       hipIpcMemLazyEnablePeerAccess = 1 };
+struct hipIpcMemHandle_t { char reserved[64]; };
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorInvalidValue; }
+static inline hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorInvalidValue; }
+static inline hipError_t hipIpcCloseMemHandle(void*) { return hipErrorInvalidValue; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+template <typename T, typename V>
+static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
+template <typename T>
+static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline long long wall_clock64() {          // 100 MHz, like the device's constant-rate counter
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 100000000ll + ts.tv_nsec / 10;
+}
 
 static inline void __syncthreads() { hipemu::sync_block(); }
 

@@ -410,3 +410,120 @@ def test_concat_with_an_embedding_shared_by_both_batch_halves(be, ca, cb):
     be.sync()
     assert torch.equal(from_nhwc(A.grad.cpu(), ca), go[:, :ca])
     assert maxerr(from_nhwc(E.grad.cpu(), cb), go[:b2 // 2, ca:] + go[b2 // 2:, ca:]) < 1e-6
+
+
+# ---- the kernels that carry the SyncBN exchange, on a handle of world size 1 ---------------------------------------------------------
+# (round 5: the emulator has stand-ins for the peer-to-peer primitives -- tests/hipemu/include/hip/hip_runtime.h -- so the product
+# sources need no emulator switch around these kernels and their indexing / reductions / exchange protocol run in the CPU suite
+# too: a rank pushes its sums into its own mailbox and adds "all one" ranks in order: 0.f + x = x, the plain kernels' numbers)
+def _one_rank_handle(be):
+    import ctypes
+    h = ctypes.c_void_p()
+    be.lib.call("mnk_p2p_create", 0, 1, ctypes.byref(h))
+    return h
+
+
+@pytest.mark.parametrize("n", [1, 7, 256, 2112])
+def test_one_rank_exchange_is_the_identity(be, n):
+    import ctypes
+    h = _one_rank_handle(be)
+    try:
+        g = torch.Generator().manual_seed(n)
+        x = be.t(torch.randn(n, generator=g))
+        for _ in range(6):                       # more exchanges than mailbox slots: the sequence number advances
+            out = be.empty(n)
+            be.lib.call("mnk_p2p_allreduce", h, x.data_ptr(), out.data_ptr(), n, 2000, be.stream())
+            be.sync()
+            assert torch.equal(out.cpu(), x.cpu())
+        flag = ctypes.c_int(-1)
+        be.lib.call("mnk_p2p_error", h, ctypes.byref(flag))
+        assert flag.value == 0
+    finally:
+        be.lib.call("mnk_p2p_destroy", h)
+
+
+@pytest.mark.parametrize("shape,pool", [((2, 10, 8, 8), 0), ((3, 37, 4, 6), 1), ((2, 64, 16, 16), 0)])
+def test_synchronised_statistics_of_one_rank_equal_the_plain_ones(be, shape, pool):
+    """mnk_bn_stats_sync / mnk_bn_stats_finish_sync / mnk_bn_act_bwd_stats_sync (the statistics' second stage with the exchange
+    inside) against mnk_bn_stats / mnk_bn_stats_finish / mnk_bn_act_bwd_stats: bit for bit on one rank"""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    ld, rows = ceil4(c), n * h * w
+    X = be.t(to_nhwc(torch.randn(n, c, h, w, generator=g) * 1.5 + 0.2))
+    nws = be.query("mnk_bn_workspace_floats", rows, ld)
+    hnd = _one_rank_handle(be)
+    try:
+        plain, ws = be.empty(2 * c), be.empty(nws)
+        be.call("mnk_bn_stats", X, ld, rows, c, plain, ws, nws)
+        loc, glob, ws2 = be.empty(2 * c), be.empty(2 * c), be.empty(nws)
+        be.call("mnk_bn_stats_sync", hnd, X, ld, rows, c, loc, glob, ws2, nws, 2000)
+        be.sync()
+        assert torch.equal(glob.cpu(), plain.cpu()) and torch.equal(loc.cpu(), plain.cpu())
+        # second stage alone, on synthetic per-block partials [row_blocks][2][ld]
+        rb = 37
+        part = be.t(torch.randn(rb, 2, ld, generator=g))
+        p1, l2, g2 = be.empty(2 * c), be.empty(2 * c), be.empty(2 * c)
+        be.call("mnk_bn_stats_finish", part, rb, ld, c, p1)
+        be.call("mnk_bn_stats_finish_sync", hnd, part, rb, ld, c, l2, g2, 2000)
+        be.sync()
+        assert torch.equal(g2.cpu(), p1.cpu()) and torch.equal(l2.cpu(), p1.cpu())
+        # backward statistics
+        mean, invstd = be.t(torch.randn(c, generator=g) * 0.1), be.t(torch.rand(c, generator=g) + 0.5)
+        scale, beta = be.t(torch.rand(c, generator=g) + 0.5), be.t(torch.randn(c, generator=g) * 0.3)
+        ho, wo = (h // 2, w // 2) if pool else (h, w)
+        DZ = be.t(to_nhwc(torch.randn(n, c, ho, wo, generator=g)))
+        b1, ws3 = be.empty(2 * c), be.empty(nws)
+        be.call("mnk_bn_act_bwd_stats", X, ld, DZ, ld, 0, mean, invstd, scale, beta, n, h, w, c, 1, pool, b1, ws3, nws)
+        bl, bg, ws4 = be.empty(2 * c), be.empty(2 * c), be.empty(nws)
+        be.call("mnk_bn_act_bwd_stats_sync", hnd, X, ld, DZ, ld, 0, mean, invstd, scale, beta, n, h, w, c, 1, pool, bl, bg, ws4,
+                nws, 2000)
+        be.sync()
+        assert torch.equal(bg.cpu(), b1.cpu()) and torch.equal(bl.cpu(), b1.cpu())
+    finally:
+        be.lib.call("mnk_p2p_destroy", hnd)
+
+
+@pytest.mark.parametrize("shape,pool", [((2, 10, 4, 4), 0), ((4, 37, 4, 6), 1), ((2, 130, 2, 2), 0)])
+def test_one_launch_small_layer_forms_with_the_exchange_inside(be, shape, pool):
+    """mnk_bn_small_fwd_sync / mnk_bn_small_bwd_sync on one rank against F.batch_norm(training) + relu + avg_pool2d in fp64 (the
+    bounds of the single-process forms) and against mnk_bn_small_fwd / _bwd (another thread map: equal to rounding)"""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    rm0, rv0 = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rm, rv = rm0.double().clone(), rv0.double().clone()
+    z = F.relu(F.batch_norm(xd, rm, rv, gd, bd, True, 0.1, 1e-5))
+    if pool:
+        z = F.avg_pool2d(z, 2)
+    dz = torch.randn(z.shape, generator=g, dtype=torch.float64)
+    z.backward(dz)
+    ld = ceil4(c)
+    X = be.t(to_nhwc(x))
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    G, Bt = be.t(gamma), be.t(beta)
+    hnd = _one_rank_handle(be)
+    try:
+        outs = {}
+        for name in ("mnk_bn_small_fwd", "mnk_bn_small_fwd_sync"):
+            mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+            RM, RV, Z = be.t(rm0.clone()), be.t(rv0.clone()), be.empty(n, ho, wo, ld)
+            args = (None, 0, ld, 1, None, X, ld, n, h, w, c, G, Bt, RM, RV, 0.1, 1e-5, mean, invstd, scale, Z, ld, 1, pool)
+            be.call(name, *(((hnd,) + args + (2000,)) if name.endswith("_sync") else args))
+            be.sync()
+            outs[name] = (Z.cpu(), RM.cpu(), RV.cpu(), mean, invstd, scale)
+            assert maxerr(from_nhwc(Z.cpu(), c), z) < 2e-5 and torch.all(Z.cpu()[..., c:] == 0)
+            assert maxerr(RM.cpu(), rm) < 1e-5 and maxerr(RV.cpu(), rv) < 1e-4
+        assert maxerr(outs["mnk_bn_small_fwd"][0], outs["mnk_bn_small_fwd_sync"][0]) < 5e-6
+        mean, invstd, scale = outs["mnk_bn_small_fwd_sync"][3:]
+        DZ = be.t(to_nhwc(dz.float()))
+        bs, DY = be.empty(2 * c), be.empty(n, h, w, ld)
+        be.call("mnk_bn_small_bwd_sync", hnd, X, ld, DZ, ld, mean, invstd, scale, Bt, float(n * h * w), n, h, w, c, 1, pool, bs, DY,
+                ld, 2000)
+        be.sync()
+        assert relerr(bs.cpu()[:c], bd.grad) < 1e-4 and relerr(bs.cpu()[c:], gd.grad) < 1e-4
+        assert relerr(from_nhwc(DY.cpu(), c), xd.grad) < 1e-4 and torch.all(DY.cpu()[..., c:] == 0)
+    finally:
+        be.lib.call("mnk_p2p_destroy", hnd)
