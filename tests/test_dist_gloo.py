@@ -127,6 +127,75 @@ def test_ranks_equal_one_rank_big_batch(mnk_adam, world):
                 assert flipped <= max(2, 0.03 * d.numel()), (key, k, flipped, d.numel())
 
 
+def _forced_single_rank_worker(rank, port, emu_path, out_dir):
+    """one process, a gloo group of world size 1 with MNK_DIST_FORCE=1: every multi-rank branch of the host code runs, and the
+    SyncBN sums go through the kernels that carry the peer-to-peer exchange -- on a one-rank handle that this TEST builds (the
+    product's own bring-up, mnk.dist.p2p_comm, needs a device and peers to map; the emulator has neither)"""
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", MNK_DIST_FORCE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.set_num_threads(2)
+    import ctypes
+    from mnk import dist as mdist, engine, ops
+    import _util
+    from oracle import cases
+    from test_modules import build
+    lib = _util.set_library(emu_path, strict=False)
+    h = ctypes.c_void_p()
+    lib.call("mnk_p2p_create", 0, 1, ctypes.byref(h))
+    mdist._P2P.update(tried=True, handle=h.value, max=int(lib.query("mnk_p2p_max_floats")))
+    assert mdist.active() and ops._sync_handle(8) is not None
+    cfg = cases.TINY2
+    gen, disc, kpd = build(cfg)
+    for i, m in enumerate((gen, disc, kpd)):
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 7 + i)
+        m.load_state_dict(sd)
+    src, drv = cases.smooth_pair(4, 32, 32)
+    calls = {"fwd": 0, "bwd": 0, "general": 0}
+    real = ops._call
+
+    def counting(name, *a):
+        if name == "mnk_bn_small_fwd_sync":
+            calls["fwd"] += 1
+        elif name == "mnk_bn_small_bwd_sync":
+            calls["bwd"] += 1
+        elif name.endswith("_sync"):
+            calls["general"] += 1
+        return real(name, *a)
+
+    ops._call = counting
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=True)
+    g_losses, d_losses, _ = step.step({"source": src, "video": drv})
+    mdist.check_p2p()
+    assert calls["fwd"] > 0 and calls["bwd"] > 0 and calls["general"] > 0, calls
+    assert not ops._REDUCED, "every 'already reduced' mark must have been consumed"
+    torch.save({"losses": torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64), "calls": calls,
+                "gen": gen.state_dict(), "kp": kpd.state_dict(), "disc": disc.state_dict()}, os.path.join(out_dir, "forced.pt"))
+    dist.destroy_process_group()
+
+
+def test_forced_single_rank_iteration_runs_through_the_exchange_kernels_and_equals_the_plain_one():
+    from conftest import emu_library_path
+    from oracle import cases
+    emu = emu_library_path()
+    ref = _single(emu, True)
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_forced_single_rank_worker, args=(29500 + (os.getpid() % 2000) + 17, emu, tmp), nprocs=1, join=True)
+        got = torch.load(os.path.join(tmp, "forced.pt"), weights_only=False)
+    # one rank's exchange adds 0.f + x: the sums are the plain ones; the small layers run another thread map (rounding)
+    assert float((got["losses"] - ref["losses"]).abs().max()) < 2e-5 * float(ref["losses"].abs().max() + 1)
+    lr = cases.TINY2["train_params"]["lr"]
+    for key in ("gen", "kp", "disc"):
+        for k, v in ref[key].items():
+            if "running" in k:
+                assert float((got[key][k] - v).abs().max()) < 1e-5 * (1 + float(v.abs().max())), (key, k)
+            elif v.is_floating_point() and not cases.is_noise_bias(k):
+                d = (got[key][k] - v).abs()
+                assert float(d.max()) <= 2.1 * lr, (key, k, float(d.max()))
+                assert int((d > 0.05 * lr).sum()) <= max(2, 0.03 * d.numel()), (key, k)
+
+
 def test_grad_averager_and_shard_batch_single_process():
     _setup_paths()
     from mnk import dist as mdist
