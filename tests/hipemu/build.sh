@@ -21,6 +21,6 @@ NEED=0
 [ -f "$OUT/libmnk_emu.so" ] || NEED=1
 for o in $OBJS; do [ "$o" -nt "$OUT/libmnk_emu.so" ] && NEED=1; done
 if [ "$NEED" = 1 ]; then
-  g++ -shared -o "$OUT/libmnk_emu.so.tmp.$$" $OBJS -ldl && mv -f "$OUT/libmnk_emu.so.tmp.$$" "$OUT/libmnk_emu.so"
+  g++ -shared -o "$OUT/libmnk_emu.so.tmp.$$" $OBJS -ldl -lrt && mv -f "$OUT/libmnk_emu.so.tmp.$$" "$OUT/libmnk_emu.so"
 fi
 echo "$OUT/libmnk_emu.so"

@@ -243,3 +243,99 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 }
 
 }  // namespace hipemu
+
+// ---- "device" allocations that another process can map (the peer-to-peer mailboxes): named POSIX shared memory ---------------------
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <map>
+#include <string>
+
+namespace {
+struct ShmBlock {
+    std::string name;      // empty: mapped from another process (not ours to unlink)
+    size_t bytes;
+};
+struct ShmRegistry : std::map<void*, ShmBlock> {
+    ~ShmRegistry() {           // a process that exits without mnk_p2p_destroy must not leave its objects in /dev/shm
+        for (auto& kv : *this)
+            if (!kv.second.name.empty()) shm_unlink(kv.second.name.c_str());
+    }
+};
+ShmRegistry& shm_blocks() {
+    static ShmRegistry m;
+    return m;
+}
+int g_shm_counter = 0;
+}  // namespace
+
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) {
+    if (!p || !n) return hipErrorInvalidValue;
+    char name[48];
+    snprintf(name, sizeof(name), "/hipemu_%d_%d", (int)getpid(), g_shm_counter++);
+    const int fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return hipErrorInvalidValue;
+    if (ftruncate(fd, (off_t)n) != 0) {
+        close(fd);
+        shm_unlink(name);
+        return hipErrorInvalidValue;
+    }
+    void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        shm_unlink(name);
+        return hipErrorInvalidValue;
+    }
+    shm_blocks()[m] = ShmBlock{name, n};
+    *p = m;
+    return hipSuccess;
+}
+
+hipError_t hipFree(void* p) {
+    auto it = shm_blocks().find(p);
+    if (it == shm_blocks().end()) {
+        free(p);
+        return hipSuccess;
+    }
+    munmap(p, it->second.bytes);
+    if (!it->second.name.empty()) shm_unlink(it->second.name.c_str());
+    shm_blocks().erase(it);
+    return hipSuccess;
+}
+
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+    auto it = shm_blocks().find(p);
+    if (!h || it == shm_blocks().end() || it->second.name.empty()) return hipErrorInvalidValue;
+    memset(h, 0, sizeof(*h));
+    snprintf(h->reserved, 48, "%s", it->second.name.c_str());
+    unsigned long long bytes = it->second.bytes;
+    memcpy(h->reserved + 48, &bytes, 8);
+    return hipSuccess;
+}
+
+hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+    if (!p || h.reserved[0] != '/') return hipErrorInvalidValue;
+    unsigned long long bytes = 0;
+    memcpy(&bytes, h.reserved + 48, 8);
+    h.reserved[47] = 0;
+    const int fd = shm_open(h.reserved, O_RDWR, 0600);
+    if (fd < 0 || !bytes) return hipErrorInvalidValue;
+    void* m = mmap(nullptr, (size_t)bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return hipErrorInvalidValue;
+    shm_blocks()[m] = ShmBlock{std::string(), (size_t)bytes};
+    *p = m;
+    return hipSuccess;
+}
+
+hipError_t hipIpcCloseMemHandle(void* p) {
+    auto it = shm_blocks().find(p);
+    if (it == shm_blocks().end() || !it->second.name.empty()) return hipErrorInvalidValue;
+    munmap(p, it->second.bytes);
+    shm_blocks().erase(it);
+    return hipSuccess;
+}
+
+void hipemu_yield() { sched_yield(); }

@@ -85,28 +85,32 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 
 // ---- what the peer-to-peer SyncBN exchange (csrc/p2p.hip, the *_sync kernels of batchnorm.hip) uses -----------------------------
-// "Device memory" is host memory here; one process has no peer to map, so the IPC calls fail (mnk_p2p_export reports it) -- but a
-// handle of world size 1 is complete after mnk_p2p_create, and the kernels that carry an exchange run on it (a rank pushes into
-// its own mailbox and reads it back): their indexing, reductions and the exchange protocol are checked on the CPU too.
+// "Device memory" is host memory here.  Memory from hipExtMallocWithFlags (the exchange's mailboxes) lives in a named POSIX
+// shared-memory object, hipIpcGetMemHandle hands its name out and hipIpcOpenMemHandle maps it: the PROCESSES of a gloo test on
+// the CPU exchange through each other's mailboxes exactly as the processes of a data-parallel run do through IPC-mapped HBM
+// (hipemu.cpp).  The atomic stores / loads of the protocol are real atomics (the polling loops read memory another process
+// writes); the kernels that carry an exchange therefore run -- protocol, slots, sequence numbers, rank-ordered sums -- in the
+// CPU suite, with one rank and with several.
 enum { hipDeviceMallocUncached = 3, hipDeviceMallocFinegrained = 1, hipMemcpyDeviceToHost = 2, hipMemcpyHostToDevice = 1,
        hipIpcMemLazyEnablePeerAccess = 1 };
 struct hipIpcMemHandle_t { char reserved[64]; };
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned flags);
+hipError_t hipFree(void* p);
+hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p);
+hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned flags);
+hipError_t hipIpcCloseMemHandle(void* p);
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorInvalidValue; }
-static inline hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
-static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t*, void*) { return hipErrorInvalidValue; }
-static inline hipError_t hipIpcOpenMemHandle(void**, hipIpcMemHandle_t, unsigned) { return hipErrorInvalidValue; }
-static inline hipError_t hipIpcCloseMemHandle(void*) { return hipErrorInvalidValue; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <typename T, typename V>
-static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
+static inline void __hip_atomic_store(T* p, V v, int, int) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
 template <typename T>
-static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
-static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+void hipemu_yield();                              // a polling wavefront lets the peer PROCESS run
+static inline void __builtin_amdgcn_s_sleep(int) { hipemu_yield(); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline long long wall_clock64() {          // 100 MHz, like the device's constant-rate counter

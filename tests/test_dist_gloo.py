@@ -20,7 +20,29 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
+def _bring_up_exchange(lib, mdist, rank, world):
+    """The peer-to-peer SyncBN exchange between the PROCESSES of this test (TEST INFRASTRUCTURE mirroring mnk.dist.p2p_comm, which
+    needs a device): the emulator's mailboxes are POSIX shared memory, its IPC handles their names (tests/hipemu/hipemu.cpp) --
+    create, export, gather, connect, self-test, then hand the handle to mnk.dist as p2p_comm would."""
+    import ctypes
+    h = ctypes.c_void_p()
+    mine = (ctypes.c_ubyte * 64)()
+    lib.call("mnk_p2p_create", rank, world, ctypes.byref(h))
+    lib.call("mnk_p2p_export", h, mine)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, bytes(mine))
+    lib.call("mnk_p2p_connect", h, ctypes.c_char_p(b"".join(gathered)))
+    dist.barrier()
+    probe = torch.arange(1, 65, dtype=torch.float32) * float(rank + 1)
+    got = torch.empty_like(probe)
+    lib.call("mnk_p2p_allreduce", h, probe.data_ptr(), got.data_ptr(), 64, 20000, 0)
+    assert torch.equal(got, torch.arange(1, 65, dtype=torch.float32) * float(world * (world + 1) // 2))
+    mdist.P2P_TIMEOUT_MS = 60000
+    mdist._P2P.update(tried=True, handle=h.value, max=int(lib.query("mnk_p2p_max_floats")))
+    return h
+
+
+def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False, p2p=False):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,7 +51,21 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
     import _util
     from oracle import cases
     from test_modules import build
-    _util.set_library(emu_path, strict=False)
+    lib = _util.set_library(emu_path, strict=False)
+    calls = {"fwd": 0, "bwd": 0, "general": 0}
+    if p2p:
+        from mnk import ops
+        exchange = _bring_up_exchange(lib, mdist, rank, world)
+        real = ops._call
+
+        def counting(name, *a):
+            key = "fwd" if name == "mnk_bn_small_fwd_sync" else "bwd" if name == "mnk_bn_small_bwd_sync" else \
+                "general" if name.endswith("_sync") else None
+            if key:
+                calls[key] += 1
+            return real(name, *a)
+
+        ops._call = counting
     cfg = cases.TINY2
     gen, disc, kpd = build(cfg)
     for i, m in enumerate((gen, disc, kpd)):
@@ -44,6 +80,9 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
     lv = torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64)
     dist.all_reduce(lv)
     lv /= world
+    if p2p:
+        mdist.check_p2p()
+        assert calls["fwd"] > 0 and calls["bwd"] > 0 and calls["general"] > 0, calls
     torch.save({"losses": lv, "gen": {k: v.clone() for k, v in gen.state_dict().items()},
                 "kp": {k: v.clone() for k, v in kpd.state_dict().items()},
                 "disc": {k: v.clone() for k, v in disc.state_dict().items()}},
@@ -70,6 +109,10 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False):
         assert "different numbers of samples" in str(e)
     sums, count = mdist.combine_bn_stats(torch.tensor([1.0 * (rank + 1), 2.0]), 10)
     assert count == 10 * world and torch.equal(sums, torch.tensor([tri, 2.0 * world]))
+    if p2p:
+        dist.barrier()                       # nobody unmaps a mailbox a peer may still be reading
+        mdist.disable_p2p()
+        lib.call("mnk_p2p_destroy", exchange)
     dist.destroy_process_group()
 
 
@@ -95,16 +138,21 @@ def _single(emu_path, mnk_adam=False):
     return out
 
 
-@pytest.mark.parametrize("mnk_adam,world", [(False, 2), (True, 2), (True, 4)],
-                         ids=["torch-adam+GradAverager", "mnk-adam-flat-buffer", "mnk-adam-flat-buffer-4-ranks"])
-def test_ranks_equal_one_rank_big_batch(mnk_adam, world):
+@pytest.mark.parametrize("mnk_adam,world,p2p", [(False, 2, False), (True, 2, False), (True, 4, False), (True, 2, True), (True, 4, True)],
+                         ids=["torch-adam+GradAverager", "mnk-adam-flat-buffer", "mnk-adam-flat-buffer-4-ranks",
+                              "peer-to-peer-syncbn-2-ranks", "peer-to-peer-syncbn-4-ranks"])
+def test_ranks_equal_one_rank_big_batch(mnk_adam, world, p2p):
+    """p2p: the SyncBN sums of the ranks travel through the library's own exchange -- the kernels of csrc/p2p.hip and the *_sync
+    kernels of batchnorm.hip, mailboxes mapped between the PROCESSES of the test (shared memory standing in for IPC-mapped HBM) --
+    instead of torch.distributed all-reduces: the multi-rank protocol (slots, sequence numbers, rank-ordered sums, the exchange
+    inside the statistics' second stage and inside the one-launch small-layer kernels) runs in the CPU suite."""
     from conftest import emu_library_path
     from oracle import cases
     emu = emu_library_path()
     ref = _single(emu, mnk_adam)
     with tempfile.TemporaryDirectory() as tmp:
-        port = 29500 + (os.getpid() % 2000) + (1 if mnk_adam else 0) + world
-        mp.spawn(_worker, args=(world, port, emu, tmp, mnk_adam), nprocs=world, join=True)
+        port = 29500 + (os.getpid() % 2000) + (1 if mnk_adam else 0) + world + (7 if p2p else 0)
+        mp.spawn(_worker, args=(world, port, emu, tmp, mnk_adam, p2p), nprocs=world, join=True)
         r0 = torch.load(os.path.join(tmp, "rank0.pt"), weights_only=False)
         r1 = torch.load(os.path.join(tmp, "rank1.pt"), weights_only=False)
     # ranks stay bit-identical replicas after the step (same averaged gradients, same all-reduced BN statistics)
