@@ -244,6 +244,49 @@ def test_forced_single_rank_iteration_runs_through_the_exchange_kernels_and_equa
                 assert int((d > 0.05 * lr).sum()) <= max(2, 0.03 * d.numel()), (key, k)
 
 
+def _absent_peer_worker(rank, world, port, emu_path, out_dir):
+    _setup_paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    from mnk import dist as mdist
+    import _util
+    lib = _util.set_library(emu_path, strict=False)
+    h = _bring_up_exchange(lib, mdist, rank, world)
+    mdist.P2P_TIMEOUT_MS = 300
+    dist.barrier()
+    if rank == 0:                                     # rank 1 stays away from the next two exchanges
+        x = torch.arange(1, 9, dtype=torch.float32)
+        t0 = time.perf_counter()
+        bad = torch.empty_like(x)
+        lib.call("mnk_p2p_allreduce", h, x.data_ptr(), bad.data_ptr(), 8, mdist.P2P_TIMEOUT_MS, 0)
+        t1 = time.perf_counter()
+        again = torch.empty_like(x)
+        lib.call("mnk_p2p_allreduce", h, x.data_ptr(), again.data_ptr(), 8, mdist.P2P_TIMEOUT_MS, 0)
+        t2 = time.perf_counter()
+        assert bool(torch.isnan(bad).all()) and bool(torch.isnan(again).all()), (bad, again)     # never a stale mailbox word
+        assert mdist.p2p_error() == 2                                                              # 1 + the absent rank
+        assert t1 - t0 > 0.25 and t2 - t1 < 0.2, (t1 - t0, t2 - t1)                                # waited once, not twice
+        try:
+            mdist.check_p2p()
+            raise AssertionError("check_p2p() must raise after a give-up")
+        except RuntimeError as e:
+            assert "rank 1" in str(e)
+    dist.barrier()
+    mdist.disable_p2p()
+    lib.call("mnk_p2p_destroy", h)
+    dist.destroy_process_group()
+
+
+def test_a_peer_that_stays_away_poisons_the_sums_and_is_reported():
+    """ADVICE r4 (also tests/test_p2p_gpu.py on the device): an exchange that gives a peer up returns NaN, sets the error word,
+    does not wait the timeout a second time, and mnk.dist.check_p2p() raises"""
+    from conftest import emu_library_path
+    emu = emu_library_path()
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_absent_peer_worker, args=(2, 29500 + (os.getpid() % 2000) + 23, emu, tmp), nprocs=2, join=True)
+
+
 def test_grad_averager_and_shard_batch_single_process():
     _setup_paths()
     from mnk import dist as mdist
