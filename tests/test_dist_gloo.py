@@ -72,7 +72,7 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False, p2p=False):
         sd = m.state_dict()
         cases.perturb_state_dict(sd, 7 + i)
         m.load_state_dict(sd)
-    src, drv = cases.smooth_pair(4, 32, 32)
+    src, drv = cases.smooth_pair(max(4, world), 32, 32)
     x = {"source": mdist.shard_batch(src).contiguous(), "video": mdist.shard_batch(drv).contiguous()}
     step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=mnk_adam)
     g_losses, d_losses, _ = step.step(x)
@@ -116,7 +116,7 @@ def _worker(rank, world, port, emu_path, out_dir, mnk_adam=False, p2p=False):
     dist.destroy_process_group()
 
 
-def _single(emu_path, mnk_adam=False):
+def _single(emu_path, mnk_adam=False, batch=4):
     _setup_paths()
     from mnk import _lib, engine
     import _util
@@ -129,7 +129,7 @@ def _single(emu_path, mnk_adam=False):
         sd = m.state_dict()
         cases.perturb_state_dict(sd, 7 + i)
         m.load_state_dict(sd)
-    src, drv = cases.smooth_pair(4, 32, 32)
+    src, drv = cases.smooth_pair(batch, 32, 32)
     step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], fused_adam=mnk_adam)
     g_losses, d_losses, _ = step.step({"source": src, "video": drv})
     out = {"losses": torch.tensor([float(v) for v in g_losses + d_losses], dtype=torch.float64),
@@ -138,9 +138,10 @@ def _single(emu_path, mnk_adam=False):
     return out
 
 
-@pytest.mark.parametrize("mnk_adam,world,p2p", [(False, 2, False), (True, 2, False), (True, 4, False), (True, 2, True), (True, 4, True)],
+@pytest.mark.parametrize("mnk_adam,world,p2p", [(False, 2, False), (True, 2, False), (True, 4, False), (True, 2, True), (True, 4, True),
+                                                (True, 8, True)],
                          ids=["torch-adam+GradAverager", "mnk-adam-flat-buffer", "mnk-adam-flat-buffer-4-ranks",
-                              "peer-to-peer-syncbn-2-ranks", "peer-to-peer-syncbn-4-ranks"])
+                              "peer-to-peer-syncbn-2-ranks", "peer-to-peer-syncbn-4-ranks", "peer-to-peer-syncbn-8-ranks"])
 def test_ranks_equal_one_rank_big_batch(mnk_adam, world, p2p):
     """p2p: the SyncBN sums of the ranks travel through the library's own exchange -- the kernels of csrc/p2p.hip and the *_sync
     kernels of batchnorm.hip, mailboxes mapped between the PROCESSES of the test (shared memory standing in for IPC-mapped HBM) --
@@ -149,7 +150,7 @@ def test_ranks_equal_one_rank_big_batch(mnk_adam, world, p2p):
     from conftest import emu_library_path
     from oracle import cases
     emu = emu_library_path()
-    ref = _single(emu, mnk_adam)
+    ref = _single(emu, mnk_adam, max(4, world))
     with tempfile.TemporaryDirectory() as tmp:
         port = 29500 + (os.getpid() % 2000) + (1 if mnk_adam else 0) + world + (7 if p2p else 0)
         mp.spawn(_worker, args=(world, port, emu, tmp, mnk_adam, p2p), nprocs=world, join=True)
