@@ -677,7 +677,8 @@ int mnk_frames_gather(const unsigned char* pool, const MnkFrameJob* jobs_device,
  * PIL RGB -> HSV -> uint8 hue shift -> RGB -> img_as_float), in the arithmetic of the versions requirements.txt pins
  * (scikit-image 0.14.0, Pillow 5.2.0, torchvision 0.2.1; restated in oracle/augment_restate.py).  flags: 1 rotate (rot = the
  * inverse map  col = rot[0] c + rot[1] r + rot[2], row = rot[3] c + rot[4] r + rot[5]), 2 resize to (new_h, new_w) with order 1
- * (interpolation='bilinear'), 8 the same with order 0 (RandomResize's default 'nearest': what the shipped configs run), 4 hue.
+ * (interpolation='bilinear'), 8 the same with order 0 (RandomResize's default 'nearest': what the shipped configs run), 4 colour
+ * jitter (round 4: the hue term; round 5: all four terms of ColorJitter in their shuffled order, see jit_* below).
  * vmin / vmax: min / max of the float32 source frame over its channels (skimage clips a warp's output to its input's range);
  * rot_range: njobs x 2 doubles of scratch when any job rotates (the range of the rotated frame, which clips the resize). */
 typedef struct MnkAugJob {
@@ -690,9 +691,18 @@ typedef struct MnkAugJob {
     int pad_top, pad_left, new_h, new_w;
     int flags, hue_shift;
     float vmin, vmax;
+    /* ColorJitter (flags & 4): jit_n terms in the order the reference's random.shuffle left them; jit_op: 1 brightness, 2 saturation,
+     * 3 hue (hue_shift above), 4 contrast; jit_f: the factors (brightness / saturation / contrast: Pillow's ImageEnhance blend
+     * factor as a C float) */
+    int jit_n;
+    int jit_op[4];
+    float jit_f[4];
+    int reserved;
 } MnkAugJob;
+/* any_contrast / contrast_mean (njobs ints of scratch): a job with a contrast term needs int(mean(luma) + 0.5) of its output frame
+ * as it stands in front of that term -- one more pre-pass launch (ImageEnhance.Contrast blends with that constant). */
 int mnk_frames_augment(const unsigned char* pool, const MnkAugJob* jobs_device, int njobs, int any_rotation, double* rot_range,
-                       int H, int W, int Cout, float* out, void* stream);
+                       int any_contrast, int* contrast_mean, int H, int W, int Cout, float* out, void* stream);
 
 #ifdef __cplusplus
 }

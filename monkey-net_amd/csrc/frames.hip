@@ -203,21 +203,40 @@ __device__ __forceinline__ void aug_hue(unsigned char rgb[3], int shift) {
     }
 }
 
-// one thread per (job, output pixel): grid (ceil(H * W / 256), jobs); (H, W) = the output (crop) size
-__global__ void __launch_bounds__(256) frames_augment_kernel(const unsigned char* __restrict__ pool,
-                                                             const MnkAugJob* __restrict__ jobs,
-                                                             const double* __restrict__ rot_range, int H, int W, int Cout,
-                                                             float* __restrict__ out) {
-    const MnkAugJob j = jobs[blockIdx.y];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= H * W) return;
-    const int h = p / W, w = p - h * W;
-    const AugSrc s{pool + j.strip_offset + (size_t)j.frame * j.in_w * j.channels, j.strip_w, j.in_h, j.in_w, j.channels, j.hflip};
+// ---- the other terms of ColorJitter (round 5): Pillow's ImageEnhance on one pixel -- what torchvision 0.2.1's adjust_brightness /
+// adjust_saturation / adjust_contrast call.  Image.convert('L') = (19595 R + 38470 G + 7471 B + 0x8000) >> 16; Image.blend(a, v, f)
+// = a + f * (v - a) in C float arithmetic (two roundings: no fused multiply-add), truncated inside [0, 1], clipped outside.
+// Pinned to the installed Pillow by oracle/make_golden_hue.py (all 2^24 RGB triples, all 256 x 256 blend pairs x 204 factors).
+__device__ __forceinline__ int aug_luma(const unsigned char rgb[3]) {
+    return (rgb[0] * 19595 + rgb[1] * 38470 + rgb[2] * 7471 + 0x8000) >> 16;
+}
+__device__ __forceinline__ unsigned char aug_blend(int a, int v, float f) {
+    const float t = __fadd_rn((float)a, __fmul_rn(f, (float)(v - a)));
+    if (f >= 0.f && f <= 1.f) return (unsigned char)(int)t;
+    return (unsigned char)(t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t));
+}
+// terms [0, upto) of the job's shuffled sequence; contrast_mean: int(mean(luma of the frame at that point) + 0.5)
+__device__ __forceinline__ void aug_jitter(unsigned char rgb[3], const MnkAugJob& j, int upto, int contrast_mean) {
+    for (int k = 0; k < upto; ++k) {
+        const int op = j.jit_op[k];
+        const float f = j.jit_f[k];
+        if (op == 3) {
+            aug_hue(rgb, j.hue_shift);
+            continue;
+        }
+        const int lum = op == 2 ? aug_luma(rgb) : (op == 4 ? contrast_mean : 0);        // brightness blends with black
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rgb[i] = aug_blend(lum, rgb[i], f);
+    }
+}
+
+// the frame value under output pixel (h, w) of job j, before the colour jitter: crop o (resize of (rotation of the source))
+__device__ __forceinline__ bool aug_value(const MnkAugJob& j, const AugSrc& s, const double* __restrict__ rot_range, int job, int h,
+                                          int w, double v[3]) {
     // RandomCrop: position inside the edge-padded (rotated, resized) frame -> clamped position inside that frame
     int ry = h + j.y1 - j.pad_top, rx = w + j.x1 - j.pad_left;
     ry = ry < 0 ? 0 : (ry > j.new_h - 1 ? j.new_h - 1 : ry);
     rx = rx < 0 ? 0 : (rx > j.new_w - 1 ? j.new_w - 1 : rx);
-    double v[3];
     const bool warped = (j.flags & 11) != 0;         // float64 values from here on (skimage converts to double), else float32
     if (j.flags & 8) {
         // order 0 (RandomResize's default interpolation 'nearest' -- what every shipped config runs): the pixel at
@@ -232,23 +251,77 @@ __global__ void __launch_bounds__(256) frames_augment_kernel(const unsigned char
         const double c = col_scale * (double)rx + 0.0 * (double)ry + (col_scale / 2.0 - 0.5);
         const double r = 0.0 * (double)rx + row_scale * (double)ry + (row_scale / 2.0 - 0.5);
         aug_bilinear(r, c, [&](long y, long x, double* o) { aug_rotated(j, s, y, x, o); }, v);
-        const double lo = (j.flags & 1) ? rot_range[2 * blockIdx.y] : (double)j.vmin;
-        const double hi = (j.flags & 1) ? rot_range[2 * blockIdx.y + 1] : (double)j.vmax;
+        const double lo = (j.flags & 1) ? rot_range[2 * job] : (double)j.vmin;
+        const double hi = (j.flags & 1) ? rot_range[2 * job + 1] : (double)j.vmax;
 #pragma unroll
         for (int i = 0; i < 3; ++i) v[i] = aug_clip(v[i], lo, hi);
     } else {
         aug_rotated(j, s, ry, rx, v);
     }
+    return warped;
+}
+
+__device__ __forceinline__ void aug_ubyte(const double v[3], bool warped, unsigned char rgb[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                    // img_as_ubyte: clip(rint(x * 255)) in the image's own float type
+        double y = warped ? v[i] * 255.0 : (double)((float)v[i] * 255.f);
+        y = rint(y);
+        rgb[i] = (unsigned char)(y < 0.0 ? 0 : (y > 255.0 ? 255 : (int)y));
+    }
+}
+
+// per job with a contrast term: int(mean(luma) + 0.5) of the OUTPUT frame as it stands in front of that term (ImageEnhance.Contrast
+// blends with this constant; ImageStat's mean = sum / count in double).  The sum is an integer: any order of addition gives it.
+__global__ void __launch_bounds__(256) frames_contrast_mean_kernel(const unsigned char* __restrict__ pool,
+                                                                   const MnkAugJob* __restrict__ jobs,
+                                                                   const double* __restrict__ rot_range, int H, int W,
+                                                                   int* __restrict__ contrast_mean) {
+    __shared__ unsigned long long part[256];
+    const MnkAugJob j = jobs[blockIdx.x];
+    int kc = -1;
+    for (int k = 0; k < j.jit_n; ++k)
+        if (j.jit_op[k] == 4) kc = k;
+    if (kc < 0) {
+        if (threadIdx.x == 0) contrast_mean[blockIdx.x] = 0;
+        return;
+    }
+    const AugSrc s{pool + j.strip_offset + (size_t)j.frame * j.in_w * j.channels, j.strip_w, j.in_h, j.in_w, j.channels, j.hflip};
+    unsigned long long sum = 0;
+    for (int p = threadIdx.x; p < H * W; p += 256) {
+        double v[3];
+        const bool warped = aug_value(j, s, rot_range, blockIdx.x, p / W, p % W, v);
+        unsigned char rgb[3];
+        aug_ubyte(v, warped, rgb);
+        aug_jitter(rgb, j, kc, 0);
+        sum += (unsigned long long)aug_luma(rgb);
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) part[threadIdx.x] += part[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) contrast_mean[blockIdx.x] = (int)((double)part[0] / (double)((long)H * W) + 0.5);
+}
+
+// one thread per (job, output pixel): grid (ceil(H * W / 256), jobs); (H, W) = the output (crop) size
+__global__ void __launch_bounds__(256) frames_augment_kernel(const unsigned char* __restrict__ pool,
+                                                             const MnkAugJob* __restrict__ jobs,
+                                                             const double* __restrict__ rot_range,
+                                                             const int* __restrict__ contrast_mean, int H, int W, int Cout,
+                                                             float* __restrict__ out) {
+    const MnkAugJob j = jobs[blockIdx.y];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= H * W) return;
+    const int h = p / W, w = p - h * W;
+    const AugSrc s{pool + j.strip_offset + (size_t)j.frame * j.in_w * j.channels, j.strip_w, j.in_h, j.in_w, j.channels, j.hflip};
+    double v[3];
+    const bool warped = aug_value(j, s, rot_range, blockIdx.y, h, w, v);
     float o3[3];
     if (j.flags & 4) {
         unsigned char rgb[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                // img_as_ubyte: clip(rint(x * 255)) in the image's own float type
-            double y = warped ? v[i] * 255.0 : (double)((float)v[i] * 255.f);
-            y = rint(y);
-            rgb[i] = (unsigned char)(y < 0.0 ? 0 : (y > 255.0 ? 255 : (int)y));
-        }
-        aug_hue(rgb, j.hue_shift);
+        aug_ubyte(v, warped, rgb);
+        aug_jitter(rgb, j, j.jit_n, contrast_mean ? contrast_mean[blockIdx.y] : 0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) o3[i] = (float)((double)rgb[i] * (1.0 / 255));          // img_as_float, then float32
     } else {
@@ -264,14 +337,16 @@ __global__ void __launch_bounds__(256) frames_augment_kernel(const unsigned char
 extern "C" {
 
 int mnk_frames_augment(const unsigned char* pool, const MnkAugJob* jobs_device, int njobs, int any_rotation, double* rot_range,
-                       int H, int W, int Cout, float* out, void* stream) {
+                       int any_contrast, int* contrast_mean, int H, int W, int Cout, float* out, void* stream) {
     MNK_REQUIRE(pool && jobs_device && out && njobs > 0 && njobs <= 65535 && H > 0 && W > 0 && Cout >= 1 && Cout <= 3);
-    MNK_REQUIRE(!any_rotation || rot_range);
+    MNK_REQUIRE((!any_rotation || rot_range) && (!any_contrast || contrast_mean));
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_LAYOUT, s, (double)njobs * H * W * (16.0 * 3 + 4.0 * Cout));
     if (any_rotation) hipLaunchKernelGGL(frames_rotated_range_kernel, dim3(njobs), dim3(256), 0, s, pool, jobs_device, rot_range);
-    hipLaunchKernelGGL(frames_augment_kernel, dim3((H * W + 255) / 256, njobs), dim3(256), 0, s, pool, jobs_device, rot_range, H, W,
-                       Cout, out);
+    if (any_contrast)
+        hipLaunchKernelGGL(frames_contrast_mean_kernel, dim3(njobs), dim3(256), 0, s, pool, jobs_device, rot_range, H, W, contrast_mean);
+    hipLaunchKernelGGL(frames_augment_kernel, dim3((H * W + 255) / 256, njobs), dim3(256), 0, s, pool, jobs_device, rot_range,
+                       any_contrast ? contrast_mean : (const int*)nullptr, H, W, Cout, out);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

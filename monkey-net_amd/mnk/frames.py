@@ -17,8 +17,9 @@ versions the reference pins; scikit-image and torchvision are not in this image 
 resize are checked against a numpy restatement of skimage 0.14's published algorithm (oracle/augment_restate.py: that part is
 "parity unpinned"); the hue jitter's colour conversions ARE pinned to a real library since round 5: the restatement equals the
 installed Pillow's Image.convert RGB <-> HSV on all 2^24 triples of both directions, and kernel and restatement reproduce a
-golden made by that Pillow (oracle/make_golden_hue.py, tests/golden/hue_pillow.npz).  brightness /
-contrast / saturation jitter (no shipped config sets them) raise.  `.gif` files (the moving-gif data set) are decoded with
+golden made by that Pillow (oracle/make_golden_hue.py, tests/golden/hue_pillow.npz).  Round 5 also: brightness / contrast /
+saturation -- all four terms of ColorJitter in the reference's shuffled order (Pillow's ImageEnhance arithmetic per pixel, the
+contrast term's frame mean by a pre-pass), pinned the same way (40 shuffled sequences x 8 images from the real library).  `.gif` files (the moving-gif data set) are decoded with
 Pillow (read_gif); `.mp4` / `.mov` need a decoder this image does not have; PNG strips are read by the small decoder below
 (zlib + the five PNG filters), or by PIL when it is importable.
 `DevicePairedDataset` is frames_dataset.py:91-131's PairedDataset over a DeviceFramesDataset."""
@@ -41,7 +42,9 @@ JOB = np.dtype([("strip_offset", "<u8"), ("out_offset", "<u8"), ("chan_stride", 
 AUGJOB = np.dtype([("strip_offset", "<u8"), ("out_offset", "<u8"), ("chan_stride", "<u8"), ("rot", "<f8", (6,)),
                    ("strip_w", "<i4"), ("in_h", "<i4"), ("in_w", "<i4"), ("channels", "<i4"), ("frame", "<i4"), ("hflip", "<i4"),
                    ("x1", "<i4"), ("y1", "<i4"), ("pad_top", "<i4"), ("pad_left", "<i4"), ("new_h", "<i4"), ("new_w", "<i4"),
-                   ("flags", "<i4"), ("hue_shift", "<i4"), ("vmin", "<f4"), ("vmax", "<f4")])
+                   ("flags", "<i4"), ("hue_shift", "<i4"), ("vmin", "<f4"), ("vmax", "<f4"), ("jit_n", "<i4"),
+                   ("jit_op", "<i4", (4,)), ("jit_f", "<f4", (4,)), ("reserved", "<i4")])
+JIT_BRIGHTNESS, JIT_SATURATION, JIT_HUE, JIT_CONTRAST = 1, 2, 3, 4      # MnkAugJob.jit_op (the order ColorJitter appends them in)
 
 
 # ---- PNG (8 bit, non-interlaced; gray, gray + alpha, RGB, RGBA): what `skimage.io.imread` returns for those files -------
@@ -188,7 +191,7 @@ class DeviceFramesDataset:
         else:
             self.crop = None
         # the non-integer augmentations (augmentation.py:105-133,175-214,217-320)
-        self.rotation = self.resize = self.hue = None
+        self.rotation = self.resize = self.hue = self.jitter = None
         self.resize_order = 0
         if is_train and p.get("rotation_param") is not None:
             deg = p["rotation_param"]["degrees"]
@@ -210,10 +213,12 @@ class DeviceFramesDataset:
             self.resize = (float(ratio[0]), float(ratio[1]))
         if is_train and p.get("jitter_param") is not None:
             jp = dict(p["jitter_param"])
-            if any(jp.get(k, 0) for k in ("brightness", "contrast", "saturation")):
-                raise NotImplementedError("ColorJitter brightness / contrast / saturation (no shipped config sets them)")
             if jp.get("hue", 0) > 0:
                 self.hue = float(jp["hue"])
+            # (round 5) the other three terms: ColorJitter(brightness, contrast, saturation, hue), augmentation.py:217-235
+            self.jitter = {k: float(jp.get(k, 0)) for k in ("brightness", "contrast", "saturation")}
+            if not any(v > 0 for v in self.jitter.values()):
+                self.jitter = None
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         # ---- decode once, keep resident -----------------------------------------------------------------------------
         H, W, C = self.image_shape
@@ -242,12 +247,13 @@ class DeviceFramesDataset:
 
     # ---- the random choices of one sample, in the reference's draw order ------------------------------------------------
     def _draw(self, frame_count):
-        """-> (frames [source, driving...], hflip, x1, y1, pad_top, pad_left, out_h, out_w, angle, new_hw, hue_factor): the
+        """-> (frames [source, driving...], hflip, x1, y1, pad_top, pad_left, out_h, out_w, angle, new_hw, hue_factor, jitter terms
+        [(code, factor), ...] in applied order or None): the
         random choices of AllAugmentationTransform (augmentation.py:369-389) in ITS draw order -- select, flip, rotation,
         resize, crop, jitter"""
         H, W, _ = self.image_shape
         if not self.is_train:                                   # VideoToTensor: every frame, no augmentation
-            return list(range(frame_count)), 0, 0, 0, 0, 0, H, W, None, None, None
+            return list(range(frame_count)), 0, 0, 0, 0, 0, H, W, None, None, None, None
         # SelectRandomFrames (augmentation.py:324-345): two indices with replacement, sorted
         sel = list(np.sort(np.random.choice(range(frame_count), replace=True, size=2)))
         hflip = 0
@@ -273,9 +279,22 @@ class DeviceFramesDataset:
             im_w = rw if ow < rw else rw + (ow - rw) // 2 + (ow - rw + 1) // 2
             x1 = 0 if oh == im_h else random.randint(0, im_w - ow)      # (sic: the height decides whether x is drawn)
             y1 = 0 if ow == im_w else random.randint(0, im_h - oh)
-        # ColorJitter.get_params (:238-262) with only `hue` set; random.shuffle of the one-element transform list draws nothing
-        hue = random.uniform(-self.hue, self.hue) if self.hue is not None else None
-        return sel, hflip, x1, y1, pt, pl, oh, ow, angle, new_hw, hue
+        # ColorJitter.get_params (:238-262): brightness, contrast, saturation, hue are drawn in THAT order; __call__ (:271-282) appends
+        # the terms as brightness, saturation, hue, contrast and random.shuffle()s the list (a list of one element draws nothing)
+        jit = None
+        if self.jitter is None:
+            hue = random.uniform(-self.hue, self.hue) if self.hue is not None else None
+            if hue is not None:
+                jit = [(JIT_HUE, hue)]
+        else:
+            jb, jc, js = self.jitter["brightness"], self.jitter["contrast"], self.jitter["saturation"]
+            fb = random.uniform(max(0, 1 - jb), 1 + jb) if jb > 0 else None
+            fc = random.uniform(max(0, 1 - jc), 1 + jc) if jc > 0 else None
+            fs = random.uniform(max(0, 1 - js), 1 + js) if js > 0 else None
+            hue = random.uniform(-self.hue, self.hue) if self.hue is not None else None
+            jit = [t for t in ((JIT_BRIGHTNESS, fb), (JIT_SATURATION, fs), (JIT_HUE, hue), (JIT_CONTRAST, fc)) if t[1] is not None]
+            random.shuffle(jit)
+        return sel, hflip, x1, y1, pt, pl, oh, ow, angle, new_hw, hue, jit
 
     def _jobs(self, indices):
         """draw every sample of a batch -> (job rows, per-tensor frame counts, output size)"""
@@ -285,10 +304,10 @@ class DeviceFramesDataset:
         return drawn, sizes.pop()
 
     def _launch(self, rows, total_floats, oh, ow):
-        """rows: (frames_gather fields ..., video index, angle, new_hw, hue_factor) per output frame"""
+        """rows: (frames_gather fields ..., video index, angle, new_hw, jitter terms) per output frame"""
         C = self.image_shape[2]
         out = torch.empty(total_floats, dtype=torch.float32, device=self.device)
-        augment = self.rotation is not None or self.resize is not None or self.hue is not None
+        augment = self.rotation is not None or self.resize is not None or self.hue is not None or self.jitter is not None
         if not augment:
             rec = np.zeros(len(rows), dtype=JOB)
             for k, r in enumerate(rows):
@@ -301,8 +320,9 @@ class DeviceFramesDataset:
             return out
         rec = np.zeros(len(rows), dtype=AUGJOB)
         k32 = np.float32(1.0 / 255)
+        any_contrast = False
         for k, r in enumerate(rows):
-            (off, out_off, cstride, wf, H, W, ch, frame, hflip, x1, y1, pt, pl, _, _, vid, angle, new_hw, hue) = r
+            (off, out_off, cstride, wf, H, W, ch, frame, hflip, x1, y1, pt, pl, _, _, vid, angle, new_hw, jit) = r
             j = rec[k]
             j["strip_offset"], j["out_offset"], j["chan_stride"] = off, out_off, cstride
             j["strip_w"], j["in_h"], j["in_w"], j["channels"] = wf, H, W, ch
@@ -319,9 +339,15 @@ class DeviceFramesDataset:
                 j["new_h"], j["new_w"] = new_hw
             else:
                 j["new_h"], j["new_w"] = H, W
-            if hue is not None:
+            if jit:
                 flags |= 4
-                j["hue_shift"] = int(math.trunc(hue * 255)) % 256          # np.uint8(hue_factor * 255): truncation, wrap-around
+                j["jit_n"] = len(jit)
+                for t, (code, f) in enumerate(jit):
+                    j["jit_op"][t] = code
+                    j["jit_f"][t] = np.float32(f)              # Image.blend takes its factor as a C float
+                    if code == JIT_HUE:
+                        j["hue_shift"] = int(math.trunc(f * 255)) % 256      # np.uint8(hue_factor * 255): truncation, wrap-around
+                any_contrast = any_contrast or any(code == JIT_CONTRAST for code, _ in jit)
             j["flags"] = flags
             lo, hi = self.ranges[vid]
             j["vmin"], j["vmax"] = np.float32(lo[frame]) * k32, np.float32(hi[frame]) * k32
@@ -330,8 +356,9 @@ class DeviceFramesDataset:
         for k0 in range(0, len(rows), 65535):
             n = min(65535, len(rows) - k0)
             rng = torch.empty(2 * n, dtype=torch.float64, device=self.device) if any_rot else None
+            cmean = torch.empty(n, dtype=torch.int32, device=self.device) if any_contrast else None
             mops._call("mnk_frames_augment", out, mops._p(self.pool), table.data_ptr() + k0 * AUGJOB.itemsize, n, any_rot,
-                       mops._p(rng), oh, ow, C, mops._p(out))
+                       mops._p(rng), int(any_contrast), mops._p(cmean), oh, ow, C, mops._p(out))
         return out
 
     def batch(self, indices):
@@ -349,21 +376,21 @@ class DeviceFramesDataset:
         if self.is_train:
             d_drv = nf - 1
             src_floats = B * C * plane
-            for b, (i, sel, hflip, x1, y1, pt, pl, _, _, angle, new_hw, hue) in enumerate(drawn):
+            for b, (i, sel, hflip, x1, y1, pt, pl, _, _, angle, new_hw, _hue, jit) in enumerate(drawn):
                 off, wf, ch, _ = self.meta[i]
                 rows.append((off, b * C * plane, plane, wf, H, W, ch, int(sel[0]), hflip, x1, y1, pt, pl, 0, 0, i, angle, new_hw,
-                             hue))
+                             jit))
                 for d, f in enumerate(sel[1:]):
                     rows.append((off, src_floats + (b * C * d_drv + d) * plane, d_drv * plane, wf, H, W, ch, int(f), hflip, x1,
-                                 y1, pt, pl, 0, 0, i, angle, new_hw, hue))
+                                 y1, pt, pl, 0, 0, i, angle, new_hw, jit))
             out = self._launch(rows, src_floats + B * C * d_drv * plane, oh, ow)
             return {"source": out[:src_floats].view(B, C, 1, oh, ow), "video": out[src_floats:].view(B, C, d_drv, oh, ow),
                     "name": [self.images[i] for i in indices]}
-        for b, (i, sel, hflip, x1, y1, pt, pl, _, _, angle, new_hw, hue) in enumerate(drawn):
+        for b, (i, sel, hflip, x1, y1, pt, pl, _, _, angle, new_hw, _hue, jit) in enumerate(drawn):
             off, wf, ch, _ = self.meta[i]
             for d, f in enumerate(sel):
                 rows.append((off, (b * C * nf + d) * plane, nf * plane, wf, H, W, ch, int(f), hflip, x1, y1, pt, pl, 0, 0, i,
-                             angle, new_hw, hue))
+                             angle, new_hw, jit))
         out = self._launch(rows, B * C * nf * plane, oh, ow)
         return {"video": out.view(B, C, nf, oh, ow), "name": [self.images[i] for i in indices]}
 

@@ -177,6 +177,55 @@ def hue_shift_u8(hue_factor):
     return int(math.trunc(hue_factor * 255)) % 256
 
 
+# ---- Pillow ImageEnhance (what torchvision 0.2.1's adjust_brightness / adjust_saturation / adjust_contrast call) -------------------
+# Pinned against the installed Pillow by oracle/make_golden_hue.py: rgb2l_u8 on all 2^24 triples, blend_u8 on all 256 x 256 value
+# pairs for a ladder of factors, the three enhancers on random images.
+JIT_BRIGHTNESS, JIT_SATURATION, JIT_HUE, JIT_CONTRAST = 1, 2, 3, 4      # (the order ColorJitter.__call__ appends them in)
+
+
+def rgb2l_u8(rgb):
+    """Image.convert('L') of an RGB image: libImaging/Convert.c L24(rgb) >> 16 = ITU-R 601-2 luma in 16-bit fixed point"""
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def blend_u8(a, v, factor):
+    """Image.blend(a, v, factor) (libImaging/Blend.c): a + factor * (v - a) in C float arithmetic; inside [0, 1] the result is cast
+    (truncated), outside it is clipped to [0, 255] first"""
+    f = np.float32(factor)
+    t = (a.astype(np.int32).astype(np.float32) + f * (v.astype(np.int32) - a.astype(np.int32)).astype(np.float32)).astype(np.float32)
+    if 0 <= f <= 1:
+        return t.astype(np.int32).astype(np.uint8)
+    return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int32))).astype(np.uint8)
+
+
+def jitter_u8(u8, ops):
+    """ops: [(code, factor), ...] in the order they are applied (ColorJitter shuffles them): ImageEnhance.Brightness = blend with
+    black, .Color = blend with the image's own luma, .Contrast = blend with the constant int(mean(luma) + 0.5); hue as adjust_hue"""
+    for code, f in ops:
+        if code == JIT_BRIGHTNESS:
+            u8 = blend_u8(np.zeros_like(u8), u8, f)
+        elif code == JIT_SATURATION:
+            u8 = blend_u8(np.repeat(rgb2l_u8(u8)[..., None], 3, -1), u8, f)
+        elif code == JIT_CONTRAST:
+            lum = rgb2l_u8(u8)
+            mean = int(int(lum.astype(np.int64).sum()) / lum.size + 0.5)          # ImageStat: sum / count as Python floats, then int()
+            u8 = blend_u8(np.full_like(u8, mean), u8, f)
+        elif code == JIT_HUE:
+            hsv = rgb2hsv_u8(u8)
+            hsv[..., 0] = (hsv[..., 0].astype(np.int64) + hue_shift_u8(f)) % 256
+            u8 = hsv2rgb_u8(hsv)
+        else:
+            raise ValueError(code)
+    return u8
+
+
+def adjust_jitter(img_float, ops):
+    """ColorJitter.__call__ for one image (augmentation.py:269-300): img_as_ubyte -> ToPILImage -> the shuffled enhancers ->
+    np.array -> img_as_float -> astype('float32')"""
+    return img_as_float(jitter_u8(img_as_ubyte(img_float), ops)).astype(np.float32)
+
+
 def adjust_hue(img_float, hue_factor):
     """ColorJitter.__call__ for one image with only `hue` set (augmentation.py:269-300): img_as_ubyte -> ToPILImage ->
     torchvision adjust_hue -> np.array -> img_as_float -> astype('float32')"""
@@ -195,7 +244,7 @@ def pad_clip_edge(clip, h, w):
     return np.pad(np.asarray(clip), ((0, 0), pad_h, pad_w, (0, 0)), mode="edge")
 
 
-def pipeline(frames_u8, sel, hflip, angle, new_hw, crop, x1, y1, hue_factor, resize_order=0):
+def pipeline(frames_u8, sel, hflip, angle, new_hw, crop, x1, y1, hue_factor, resize_order=0, jitter=None):
     """frames_u8 (F, H, W, 3) uint8 of one video; the draws of mnk.frames.DeviceFramesDataset._draw -> (C, D, h, w) float32 in
     SplitSourceDriving's layout (source first).  angle / new_hw / crop / hue_factor: None = that transform is not configured."""
     clip = [np.multiply(frames_u8[f], 1.0 / 255, dtype=np.float32) for f in sel]          # img_as_float32, selection (+ time flip)
@@ -209,6 +258,8 @@ def pipeline(frames_u8, sel, hflip, angle, new_hw, crop, x1, y1, hue_factor, res
         h, w = crop
         clip = pad_clip_edge(clip, h, w)
         clip = [img[y1:y1 + h, x1:x1 + w, :] for img in clip]
-    if hue_factor is not None:
+    if jitter:                                   # [(code, factor), ...] in applied order (ColorJitter with more than the hue term)
+        clip = [adjust_jitter(np.asarray(img), jitter) for img in clip]
+    elif hue_factor is not None:
         clip = [adjust_hue(np.asarray(img), hue_factor) for img in clip]
     return np.array(clip, dtype="float32").transpose((3, 0, 1, 2))

@@ -59,8 +59,49 @@ def main():
             bad += int((got != out[k, i]).sum())
     lines.append("adjust_hue ladder (%d images x %d factors): %d values differ from the restatement" % (len(imgs), len(factors), bad))
     assert bad == 0
+    # ---- the other three terms of ColorJitter: ImageEnhance.Brightness / Color / Contrast (torchvision 0.2.1's adjust_brightness /
+    # adjust_saturation / adjust_contrast are one-line wrappers around them), alone and in shuffled sequences with the hue term
+    from PIL import ImageEnhance
+    ok = int((np.asarray(Image.fromarray(cube, "RGB").convert("L")) != ar.rgb2l_u8(cube)).sum())
+    lines.append("RGB -> L, all 2^24 triples: %d differ from oracle/augment_restate.py::rgb2l_u8" % ok)
+    assert ok == 0
+    a, v = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    A, V = Image.fromarray(np.ascontiguousarray(a), "L"), Image.fromarray(np.ascontiguousarray(v), "L")
+    blend_f = np.concatenate([rng.uniform(0, 2.5, size=200), [0.0, 1.0, 0.5, 2.0]])
+    ok = sum(int((np.asarray(Image.blend(A, V, float(f))) != ar.blend_u8(a, v, f)).sum()) for f in blend_f)
+    lines.append("Image.blend, all 256 x 256 value pairs x %d factors: %d differ from blend_u8" % (len(blend_f), ok))
+    assert ok == 0
+
+    def pil_jitter(img_u8, ops):
+        img = Image.fromarray(img_u8, "RGB")
+        for code, f in ops:
+            if code == ar.JIT_BRIGHTNESS:
+                img = ImageEnhance.Brightness(img).enhance(f)
+            elif code == ar.JIT_SATURATION:
+                img = ImageEnhance.Color(img).enhance(f)
+            elif code == ar.JIT_CONTRAST:
+                img = ImageEnhance.Contrast(img).enhance(f)
+            else:
+                img = Image.fromarray(pil_adjust_hue_u8(np.asarray(img), f), "RGB")
+        return np.asarray(img)
+
+    seqs = []
+    for k in range(40):
+        n = 1 + k % 4
+        codes = list(rng.permutation([ar.JIT_BRIGHTNESS, ar.JIT_SATURATION, ar.JIT_HUE, ar.JIT_CONTRAST])[:n])
+        seqs.append([(int(c), float(rng.uniform(-0.5, 0.5)) if c == ar.JIT_HUE else float(rng.uniform(0.2, 1.9))) for c in codes])
+    jit_out = np.stack([np.stack([pil_jitter(im, ops) for im in imgs[:8]]) for ops in seqs])
+    bad = sum(int((ar.jitter_u8(im.copy(), ops) != jit_out[k, i]).sum()) for k, ops in enumerate(seqs) for i, im in enumerate(imgs[:8]))
+    lines.append("ColorJitter sequences (%d shuffled sequences of 1-4 terms x 8 images): %d values differ from jitter_u8" % (len(seqs), bad))
+    assert bad == 0
+    jit_codes = np.zeros((len(seqs), 4), dtype=np.int32)
+    jit_factors = np.zeros((len(seqs), 4), dtype=np.float64)
+    for k, ops in enumerate(seqs):
+        for i, (c, f) in enumerate(ops):
+            jit_codes[k, i], jit_factors[k, i] = c, f
     gold = os.path.join(ROOT, "tests", "golden")
-    np.savez_compressed(os.path.join(gold, "hue_pillow.npz"), images=imgs, factors=factors, out=out, pillow=PIL.__version__)
+    np.savez_compressed(os.path.join(gold, "hue_pillow.npz"), images=imgs, factors=factors, out=out, pillow=PIL.__version__,
+                        jit_codes=jit_codes, jit_factors=jit_factors, jit_out=jit_out)
     with open(os.path.join(gold, "HUE_PILLOW_REPORT.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))

@@ -174,6 +174,8 @@ static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __frcp_rn(float a) { return 1.0f / a; }
 static inline float rsqrtf(float a) { return 1.0f / sqrtf(a); }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline int __float2int_rd(float a) { return (int)floorf(a); }
 static inline int __builtin_amdgcn_sbfe(int v, unsigned off, unsigned width) {   // signed bit-field extract
     off &= 31u;

@@ -200,8 +200,7 @@ def test_random_train_test_split_is_scikit_learns(be, shapes, tmp_path):
 def test_transforms_without_a_device_form_raise(shapes):
     from mnk import frames
     fx, root, names = shapes
-    for bad in ({"resize_param": {"ratio": [0.5, 1.1]}}, {"jitter_param": {"brightness": 0.2}},
-                {"jitter_param": {"hue": 0.1, "contrast": 0.3}}):
+    for bad in ({"resize_param": {"ratio": [0.5, 1.1]}},):           # (round 5: every term of ColorJitter has a device form)
         with pytest.raises(NotImplementedError):
             frames.DeviceFramesDataset(root, bad, device="cpu", files=names)
 
@@ -214,6 +213,9 @@ AUG = {   # config/moving-gif.yaml:5-14 (at the 64x64 frames of the fixture), co
     "bilinear": {"crop_param": {"size": [56, 72]}, "resize_param": {"ratio": [0.85, 1.2], "interpolation": "bilinear"},
                  "rotation_param": {"degrees": 25}},
     "hue-only": {"jitter_param": {"hue": 0.3}},
+    "full-jitter": {"crop_param": {"size": [64, 64]}, "resize_param": {"ratio": [0.9, 1.1]},
+                    "jitter_param": {"brightness": 0.4, "contrast": 0.5, "saturation": 0.6, "hue": 0.2}},
+    "contrast-rotated": {"rotation_param": {"degrees": 15}, "jitter_param": {"contrast": 0.8, "brightness": 0.9}},
 }
 
 
@@ -238,10 +240,10 @@ def test_resize_rotation_and_hue_jitter_equal_the_restated_library_arithmetic(be
             random.seed(100 * seed + idx), np.random.seed(100 * seed + idx)
             item = ds[idx]
             random.seed(100 * seed + idx), np.random.seed(100 * seed + idx)
-            sel, hflip, x1, y1, pt, pl, oh, ow, angle, new_hw, hue = ds._draw(ds.meta[idx][3])
+            sel, hflip, x1, y1, pt, pl, oh, ow, angle, new_hw, hue, jit = ds._draw(ds.meta[idx][3])
             strip = strips[idx][:, :, :3]
             frames_u8 = np.moveaxis(strip.reshape(64, -1, 64, 3), 1, 0)          # read_video: (F, H, W, 3)
-            ref = ar.pipeline(frames_u8, sel, hflip, angle, new_hw, ds.crop, x1, y1, hue, resize_order=ds.resize_order)
+            ref = ar.pipeline(frames_u8, sel, hflip, angle, new_hw, ds.crop, x1, y1, hue, resize_order=ds.resize_order, jitter=jit)
             got = torch.cat([item["source"], item["video"]], dim=1).cpu().numpy()
             assert got.shape == ref.shape, (got.shape, ref.shape)
             d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
@@ -298,7 +300,7 @@ def test_hue_jitter_kernel_equals_the_golden_of_the_real_pillow(be, tmp_path, mo
                                     device=be.device, files=names)
     bad = total = 0
     for k, f in enumerate(factors):
-        monkeypatch.setattr(ds, "_draw", lambda frame_count, f=float(f): ([0, 1], 0, 0, 0, 0, 0, 32, 32, None, None, f))
+        monkeypatch.setattr(ds, "_draw", lambda frame_count, f=float(f): ([0, 1], 0, 0, 0, 0, 0, 32, 32, None, None, f, [(3, f)]))
         b = ds.batch(list(range(len(names))))
         be.sync()
         got = torch.cat([b["source"], b["video"]], dim=2).cpu().numpy()           # (V, C, 2, H, W)
@@ -310,6 +312,63 @@ def test_hue_jitter_kernel_equals_the_golden_of_the_real_pillow(be, tmp_path, mo
     assert bad == 0, (bad, total)
 
 
+def test_colour_jitter_restatement_and_kernel_equal_the_golden_of_the_real_pillow(be, tmp_path, monkeypatch):
+    """all four terms of ColorJitter (augmentation.py:217-320) in shuffled sequences: oracle/make_golden_hue.py ran the REAL Pillow's
+    ImageEnhance.Brightness / Color / Contrast (what torchvision 0.2.1's adjust_* call) and the hue path for 40 sequences x 8
+    images; the numpy restatement and the device pipeline (mnk_frames_augment: the enhancers per pixel, the contrast term's
+    frame mean by a pre-pass) must both reproduce every uint8 level"""
+    from mnk import frames
+    from oracle import augment_restate as ar
+    g = np.load(os.path.join(GOLD, "hue_pillow.npz"))
+    imgs, codes, factors, out = g["images"][:8], g["jit_codes"], g["jit_factors"], g["jit_out"]
+    seqs = [[(int(c), float(f)) for c, f in zip(cs, fs) if c] for cs, fs in zip(codes, factors)]
+    assert sum(int((ar.jitter_u8(im.copy(), ops) != out[k, i]).sum()) for k, ops in enumerate(seqs) for i, im in enumerate(imgs)) == 0
+    for sub in ("train", "test"):
+        os.makedirs(os.path.join(tmp_path, sub))
+    names = []
+    for v in range(len(imgs) // 2):
+        names.append("%03d.png" % v)
+        for sub in ("train", "test"):
+            _write_png(os.path.join(tmp_path, sub, names[-1]), np.concatenate([imgs[2 * v], imgs[2 * v + 1]], axis=1))
+    ds = frames.DeviceFramesDataset(str(tmp_path), {"jitter_param": {"brightness": 0.5, "contrast": 0.5, "saturation": 0.5, "hue": 0.5}},
+                                    image_shape=(32, 32, 3), is_train=True, device=be.device, files=names)
+    bad = total = 0
+    for k, ops in enumerate(seqs):
+        monkeypatch.setattr(ds, "_draw", lambda frame_count, ops=ops: ([0, 1], 0, 0, 0, 0, 0, 32, 32, None, None, None, ops))
+        b = ds.batch(list(range(len(names))))
+        be.sync()
+        got = torch.cat([b["source"], b["video"]], dim=2).cpu().numpy()
+        for v in range(len(names)):
+            for d in range(2):
+                want = np.multiply(out[k, 2 * v + d], 1.0 / 255, dtype=np.float64).astype(np.float32)
+                bad += int((got[v, :, d].transpose(1, 2, 0) != want).sum())
+                total += want.size
+    assert bad == 0, (bad, total)
+
+
+def test_the_draws_of_the_full_colour_jitter_follow_the_reference_statements():
+    """ColorJitter.get_params draws brightness, contrast, saturation, hue in that order; __call__ appends brightness, saturation,
+    hue, contrast and random.shuffle()s the list (augmentation.py:236-282)"""
+    from mnk import frames
+    ds = frames.DeviceFramesDataset.__new__(frames.DeviceFramesDataset)
+    ds.image_shape, ds.is_train = (64, 64, 3), True
+    ds.flip = ds.crop = ds.rotation = ds.resize = None
+    ds.hue, ds.jitter, ds.resize_order = 0.3, {"brightness": 0.4, "contrast": 0.0, "saturation": 0.6}, 0
+    for seed in range(20):
+        random.seed(seed), np.random.seed(seed)
+        got = ds._draw(16)
+        after = (random.random(), np.random.rand())
+        random.seed(seed), np.random.seed(seed)
+        sel = list(np.sort(np.random.choice(range(16), replace=True, size=2)))
+        fb = random.uniform(max(0, 1 - 0.4), 1 + 0.4)
+        fs = random.uniform(max(0, 1 - 0.6), 1 + 0.6)
+        hue = random.uniform(-0.3, 0.3)
+        terms = [(frames.JIT_BRIGHTNESS, fb), (frames.JIT_SATURATION, fs), (frames.JIT_HUE, hue)]       # contrast = 0: no term
+        random.shuffle(terms)
+        assert (random.random(), np.random.rand()) == after
+        assert got[0] == sel and got[10] == hue and got[11] == terms
+
+
 def test_the_draw_order_of_the_full_augmentation_matches_the_reference_statement_order():
     """AllAugmentationTransform (augmentation.py:369-389) runs select -> flip -> rotation -> resize -> crop -> jitter; a replay of
     exactly those `random` / `numpy.random` calls must leave both generators where DeviceFramesDataset._draw leaves them"""
@@ -317,7 +376,7 @@ def test_the_draw_order_of_the_full_augmentation_matches_the_reference_statement
     ds = frames.DeviceFramesDataset.__new__(frames.DeviceFramesDataset)
     ds.image_shape, ds.is_train = (64, 64, 3), True
     ds.flip, ds.crop = {"time_flip": True, "horizontal_flip": True}, (64, 64)
-    ds.rotation, ds.resize, ds.hue, ds.resize_order = (-10.0, 10.0), (0.9, 1.1), 0.5, 0
+    ds.rotation, ds.resize, ds.hue, ds.resize_order, ds.jitter = (-10.0, 10.0), (0.9, 1.1), 0.5, 0, None
     for seed in range(20):
         random.seed(seed), np.random.seed(seed)
         got = ds._draw(32)
