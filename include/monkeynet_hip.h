@@ -672,15 +672,16 @@ typedef struct MnkFrameJob {
 int mnk_frames_gather(const unsigned char* pool, const MnkFrameJob* jobs_device, int njobs, int H, int W, int Cout, float* out,
                       void* stream);
 /* The same batch path with the reference's non-integer augmentations in front of the crop (round 4): RandomRotation
- * (augmentation.py:175-214 = skimage.transform.rotate), RandomResize (:105-133 = skimage.transform.resize, order 1, mode
- * 'constant', anti_aliasing=True with ratios >= 0.8: a one-tap filter) and ColorJitter's hue term (:217-320 = img_as_ubyte ->
+ * (augmentation.py:175-214 = skimage.transform.rotate), RandomResize (:105-133 = skimage.transform.resize, mode 'constant',
+ * anti_aliasing=True: one tap for ratios >= 0.8, the multi-tap Gaussian below that -- round 5, flags & 16) and ColorJitter's hue term (:217-320 = img_as_ubyte ->
  * PIL RGB -> HSV -> uint8 hue shift -> RGB -> img_as_float), in the arithmetic of the versions requirements.txt pins
  * (scikit-image 0.14.0, Pillow 5.2.0, torchvision 0.2.1; restated in oracle/augment_restate.py).  flags: 1 rotate (rot = the
  * inverse map  col = rot[0] c + rot[1] r + rot[2], row = rot[3] c + rot[4] r + rot[5]), 2 resize to (new_h, new_w) with order 1
  * (interpolation='bilinear'), 8 the same with order 0 (RandomResize's default 'nearest': what the shipped configs run), 4 colour
  * jitter (round 4: the hue term; round 5: all four terms of ColorJitter in their shuffled order, see jit_* below).
  * vmin / vmax: min / max of the float32 source frame over its channels (skimage clips a warp's output to its input's range);
- * rot_range: njobs x 2 doubles of scratch when any job rotates (the range of the rotated frame, which clips the resize). */
+ * rot_range: njobs x 2 doubles of scratch when any job rotates or anti-alias-filters (any_rotation != 0: the range of the frame the
+ * resize samples, which clips an order-1 resize). */
 typedef struct MnkAugJob {
     unsigned long long strip_offset;
     unsigned long long out_offset;
@@ -698,6 +699,11 @@ typedef struct MnkAugJob {
     int jit_op[4];
     float jit_f[4];
     int reserved;
+    /* anti-aliasing of a down-scaling resize (flags & 16; skimage's resize filters with sigma = (in / out - 1) / 2 per axis before it
+     * samples): radii int(4 sigma + 0.5) <= 4 of the row / column pass and the half kernels w[0 .. radius] (w[radius] = centre) as
+     * scipy.ndimage's gaussian_filter1d makes them */
+    int aa_rr, aa_rc;
+    double aa_wr[5], aa_wc[5];
 } MnkAugJob;
 /* any_contrast / contrast_mean (njobs ints of scratch): a job with a contrast term needs int(mean(luma) + 0.5) of its output frame
  * as it stands in front of that term -- one more pre-pass launch (ImageEnhance.Contrast blends with that constant). */

@@ -124,7 +124,54 @@ __device__ __forceinline__ void aug_rotated(const MnkAugJob& j, const AugSrc& s,
     for (int i = 0; i < 3; ++i) v[i] = aug_clip(v[i], (double)j.vmin, (double)j.vmax);
 }
 
-// per job: min / max of the rotated frame over its three channels (the clip range of the resize that follows a rotation)
+// pixel (r, c) of the frame the resize samples: the (rotated) frame behind skimage's anti-aliasing filter (flags & 16) --
+// ndi.gaussian_filter(image, (sigma_r, sigma_c, 0), mode='constant', cval=0), i.e. scipy's correlate1d along the rows, then along
+// the columns of that result, each in its symmetric-kernel form  out[l] = in[l] w[mid] + sum_{jj=-R..-1} (in[l+jj] + in[l-jj]) w[jj+mid]
+// (the additions in that order; zeros beyond the line's ends).  aa_wr / aa_wc hold w[0 .. R] (w[R] = the centre weight), made on
+// the host as scipy makes them.  Pinned against the installed scipy bit for bit (oracle/augment_restate.py::gaussian_aa).
+__device__ __forceinline__ void aug_filtered(const MnkAugJob& j, const AugSrc& s, long r, long c, double v[3]) {
+    if (!(j.flags & 16)) {
+        aug_rotated(j, s, r, c, v);
+        return;
+    }
+    if (r < 0 || r >= s.in_h || c < 0 || c >= s.in_w) {
+        v[0] = v[1] = v[2] = 0.0;
+        return;
+    }
+    const int Rr = j.aa_rr, Rc = j.aa_rc;
+    // T(r, cc): the row pass at column cc (0 outside the image: the column pass pads ITS input line with zeros)
+    auto rowpass = [&](long cc, double t[3]) {
+        if (cc < 0 || cc >= s.in_w) {
+            t[0] = t[1] = t[2] = 0.0;
+            return;
+        }
+        double x0[3];
+        aug_rotated(j, s, r, cc, x0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = x0[i] * j.aa_wr[Rr];
+        for (int jj = -Rr; jj < 0; ++jj) {
+            double a[3], b[3];
+            aug_rotated(j, s, r + jj, cc, a);        // (0 outside the frame)
+            aug_rotated(j, s, r - jj, cc, b);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t[i] = t[i] + (a[i] + b[i]) * j.aa_wr[jj + Rr];
+        }
+    };
+    double t0[3];
+    rowpass(c, t0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = t0[i] * j.aa_wc[Rc];
+    for (int jj = -Rc; jj < 0; ++jj) {
+        double a[3], b[3];
+        rowpass(c + jj, a);
+        rowpass(c - jj, b);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v[i] = v[i] + (a[i] + b[i]) * j.aa_wc[jj + Rc];
+    }
+}
+
+// per job: min / max over the three channels of the frame the resize samples -- the rotated and / or anti-alias-filtered frame
+// (skimage clips a warp's output to the range of its INPUT image)
 __global__ void __launch_bounds__(256) frames_rotated_range_kernel(const unsigned char* __restrict__ pool,
                                                                    const MnkAugJob* __restrict__ jobs,
                                                                    double* __restrict__ range) {
@@ -134,7 +181,7 @@ __global__ void __launch_bounds__(256) frames_rotated_range_kernel(const unsigne
     double lo = 1e300, hi = -1e300;
     for (int p = threadIdx.x; p < j.in_h * j.in_w; p += 256) {
         double v[3];
-        aug_rotated(j, s, p / j.in_w, p % j.in_w, v);
+        aug_filtered(j, s, p / j.in_w, p % j.in_w, v);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             lo = v[i] < lo ? v[i] : lo;
@@ -237,7 +284,7 @@ __device__ __forceinline__ bool aug_value(const MnkAugJob& j, const AugSrc& s, c
     int ry = h + j.y1 - j.pad_top, rx = w + j.x1 - j.pad_left;
     ry = ry < 0 ? 0 : (ry > j.new_h - 1 ? j.new_h - 1 : ry);
     rx = rx < 0 ? 0 : (rx > j.new_w - 1 ? j.new_w - 1 : rx);
-    const bool warped = (j.flags & 11) != 0;         // float64 values from here on (skimage converts to double), else float32
+    const bool warped = (j.flags & 27) != 0;         // float64 values from here on (skimage converts to double), else float32
     if (j.flags & 8) {
         // order 0 (RandomResize's default interpolation 'nearest' -- what every shipped config runs): the pixel at
         // (round(r), round(c)), C round(), cval outside, no clipping
@@ -245,14 +292,14 @@ __device__ __forceinline__ bool aug_value(const MnkAugJob& j, const AugSrc& s, c
         const double c = col_scale * (double)rx + 0.0 * (double)ry + (col_scale / 2.0 - 0.5);
         const double r = 0.0 * (double)rx + row_scale * (double)ry + (row_scale / 2.0 - 0.5);
         const double rr = r >= 0.0 ? floor(r + 0.5) : ceil(r - 0.5), cc = c >= 0.0 ? floor(c + 0.5) : ceil(c - 0.5);
-        aug_rotated(j, s, (long)rr, (long)cc, v);
+        aug_filtered(j, s, (long)rr, (long)cc, v);
     } else if (j.flags & 2) {
         const double row_scale = (double)j.in_h / (double)j.new_h, col_scale = (double)j.in_w / (double)j.new_w;
         const double c = col_scale * (double)rx + 0.0 * (double)ry + (col_scale / 2.0 - 0.5);
         const double r = 0.0 * (double)rx + row_scale * (double)ry + (row_scale / 2.0 - 0.5);
-        aug_bilinear(r, c, [&](long y, long x, double* o) { aug_rotated(j, s, y, x, o); }, v);
-        const double lo = (j.flags & 1) ? rot_range[2 * job] : (double)j.vmin;
-        const double hi = (j.flags & 1) ? rot_range[2 * job + 1] : (double)j.vmax;
+        aug_bilinear(r, c, [&](long y, long x, double* o) { aug_filtered(j, s, y, x, o); }, v);
+        const double lo = (j.flags & 17) ? rot_range[2 * job] : (double)j.vmin;
+        const double hi = (j.flags & 17) ? rot_range[2 * job + 1] : (double)j.vmax;
 #pragma unroll
         for (int i = 0; i < 3; ++i) v[i] = aug_clip(v[i], lo, hi);
     } else {

@@ -11,7 +11,8 @@ generators, so with equal seeds a sample is bit-identical to `FramesDataset.__ge
 Supported, integer-exact and parity-tested against the unmodified reference transforms: frame selection, time flip,
 horizontal flip, edge padding + random crop, gray / RGBA handling, uint8 -> float32, (C, D, H, W) layout.  Round 4: the
 non-integer augmentations of config/moving-gif.yaml and actions.yaml -- `rotation_param` (skimage.transform.rotate),
-`resize_param` (skimage.transform.resize, bilinear, ratios >= 0.8) and `jitter_param` with `hue` (img_as_ubyte -> PIL HSV ->
+`resize_param` (skimage.transform.resize, order 0 / 1; round 5: with the multi-tap anti-aliasing filter of ratios < 0.8 -- RandomResize's
+DEFAULT ratio (3/4, 4/3) included -- down to ratio 0.32; the filter is scipy's gaussian_filter, pinned to the installed scipy) and `jitter_param` with `hue` (img_as_ubyte -> PIL HSV ->
 torchvision adjust_hue -> img_as_float) -- in one launch per batch (mnk_frames_augment), in the arithmetic of the package
 versions the reference pins; scikit-image and torchvision are not in this image (and not installable offline), so rotation and
 resize are checked against a numpy restatement of skimage 0.14's published algorithm (oracle/augment_restate.py: that part is
@@ -43,7 +44,8 @@ AUGJOB = np.dtype([("strip_offset", "<u8"), ("out_offset", "<u8"), ("chan_stride
                    ("strip_w", "<i4"), ("in_h", "<i4"), ("in_w", "<i4"), ("channels", "<i4"), ("frame", "<i4"), ("hflip", "<i4"),
                    ("x1", "<i4"), ("y1", "<i4"), ("pad_top", "<i4"), ("pad_left", "<i4"), ("new_h", "<i4"), ("new_w", "<i4"),
                    ("flags", "<i4"), ("hue_shift", "<i4"), ("vmin", "<f4"), ("vmax", "<f4"), ("jit_n", "<i4"),
-                   ("jit_op", "<i4", (4,)), ("jit_f", "<f4", (4,)), ("reserved", "<i4")])
+                   ("jit_op", "<i4", (4,)), ("jit_f", "<f4", (4,)), ("reserved", "<i4"), ("aa_rr", "<i4"), ("aa_rc", "<i4"),
+                   ("aa_wr", "<f8", (5,)), ("aa_wc", "<f8", (5,))])
 JIT_BRIGHTNESS, JIT_SATURATION, JIT_HUE, JIT_CONTRAST = 1, 2, 3, 4      # MnkAugJob.jit_op (the order ColorJitter appends them in)
 
 
@@ -208,8 +210,9 @@ class DeviceFramesDataset:
             # resize_clip (augmentation.py:55) runs skimage's resize with order=1 ONLY for interpolation == 'bilinear'; the
             # default 'nearest' -- every shipped config -- is order 0
             self.resize_order = 1 if rp.get("interpolation", "nearest") == "bilinear" else 0
-            if min(ratio) < 0.8:
-                raise NotImplementedError("resize ratios below 0.8 need skimage's multi-tap anti-aliasing filter (ratio %s)" % (ratio,))
+            # (round 5) ratios below 0.8 run skimage's multi-tap anti-aliasing filter on the device (radius <= 4: ratio >= ~0.31)
+            if min(ratio) < 0.32:
+                raise NotImplementedError("resize ratios below 0.32 need an anti-aliasing kernel wider than 9 taps (ratio %s)" % (ratio,))
             self.resize = (float(ratio[0]), float(ratio[1]))
         if is_train and p.get("jitter_param") is not None:
             jp = dict(p["jitter_param"])
@@ -320,7 +323,7 @@ class DeviceFramesDataset:
             return out
         rec = np.zeros(len(rows), dtype=AUGJOB)
         k32 = np.float32(1.0 / 255)
-        any_contrast = False
+        any_contrast = any_aa = False
         for k, r in enumerate(rows):
             (off, out_off, cstride, wf, H, W, ch, frame, hflip, x1, y1, pt, pl, _, _, vid, angle, new_hw, jit) = r
             j = rec[k]
@@ -337,6 +340,22 @@ class DeviceFramesDataset:
             if new_hw is not None:
                 flags |= 2 if self.resize_order == 1 else 8
                 j["new_h"], j["new_w"] = new_hw
+                # skimage's resize: ndi.gaussian_filter(sigma = max(0, (in / out - 1) / 2)) in front of the sampling; scipy's kernel:
+                # radius int(4 sigma + 0.5), exp(-0.5 / sigma^2 * x^2) normalised -- made here as scipy makes it, bit for bit
+                for axis, scale in (("r", float(H) / new_hw[0]), ("c", float(W) / new_hw[1])):
+                    sigma = max(0.0, (scale - 1.0) / 2.0)
+                    radius = int(4.0 * sigma + 0.5) if sigma > 1e-15 else 0
+                    if radius > 4:
+                        raise NotImplementedError("anti-aliasing kernel of radius %d (a resize to %s)" % (radius, new_hw))
+                    w = np.ones(1)
+                    if radius > 0:
+                        xk = np.arange(-radius, radius + 1)
+                        w = np.exp(-0.5 / (sigma * sigma) * xk ** 2)
+                        w = w / w.sum()
+                        flags |= 16
+                        any_aa = True
+                    j["aa_r" + axis] = radius
+                    j["aa_w" + axis][:radius + 1] = w[:radius + 1]
             else:
                 j["new_h"], j["new_w"] = H, W
             if jit:
@@ -352,7 +371,7 @@ class DeviceFramesDataset:
             lo, hi = self.ranges[vid]
             j["vmin"], j["vmax"] = np.float32(lo[frame]) * k32, np.float32(hi[frame]) * k32
         table = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(self.device, non_blocking=True)
-        any_rot = int(self.rotation is not None)
+        any_rot = int(self.rotation is not None or any_aa)          # the range pre-pass of the frame the resize samples
         for k0 in range(0, len(rows), 65535):
             n = min(65535, len(rows) - k0)
             rng = torch.empty(2 * n, dtype=torch.float64, device=self.device) if any_rot else None

@@ -73,6 +73,41 @@ def _c_round_half_away(x):
     return np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5))
 
 
+def gaussian_kernel1d(sigma):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius) with gaussian_filter1d's radius = int(truncate * sigma + 0.5),
+    truncate = 4.0: the weights scipy hands to correlate1d (symmetric: the reversal is a no-op)"""
+    radius = int(4.0 * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+def _correlate1d_constant(img, w, radius, axis):
+    """ni_filters.c::NI_Correlate1D, its branch for symmetric weights, mode 'constant' with cval 0:
+    out[l] = in[l] * w[mid] + sum over jj = -radius .. -1 of (in[l + jj] + in[l - jj]) * w[jj + mid], added in that order"""
+    a = np.moveaxis(img, axis, 0)
+    n = a.shape[0]
+    pad = np.zeros((radius,) + a.shape[1:])
+    ext = np.concatenate([pad, a, pad], 0)
+    out = ext[radius:radius + n] * w[radius]
+    for jj in range(-radius, 0):
+        out = out + (ext[radius + jj:radius + jj + n] + ext[radius - jj:radius - jj + n]) * w[jj + radius]
+    return np.moveaxis(out, 0, axis)
+
+
+def gaussian_aa(image, row_scale, col_scale):
+    """the anti-aliasing step of skimage 0.14's resize: ndi.gaussian_filter(image, (sigma_r, sigma_c, 0), cval=0, mode='constant')
+    with sigma = max(0, (in / out - 1) / 2) per axis -- rows first, then columns, each a correlate1d; an axis with sigma <= 1e-15 is
+    skipped.  Pinned (round 5) against the installed scipy's gaussian_filter, bit for bit (tests/test_frames.py)."""
+    out = image
+    for axis, f in ((0, row_scale), (1, col_scale)):
+        sigma = max(0.0, (f - 1.0) / 2.0)
+        if sigma > 1e-15:
+            w, radius = gaussian_kernel1d(sigma)
+            out = _correlate1d_constant(out, w, radius, axis)
+    return out
+
+
 def resize(img, new_rows, new_cols, order):
     """skimage.transform.resize(img, (new_rows, new_cols), order=order, preserve_range=True, mode='constant',
     anti_aliasing=True), order 1 (bilinear) or 0 -- resize_clip (augmentation.py:55) passes order=1 ONLY for
@@ -84,9 +119,7 @@ def resize(img, new_rows, new_cols, order):
     image = img.astype(np.float64)
     rows, cols = image.shape[:2]
     row_scale, col_scale = float(rows) / new_rows, float(cols) / new_cols
-    for f in (row_scale, col_scale):
-        if int(4.0 * max(0.0, (f - 1.0) / 2.0) + 0.5) > 0:
-            raise NotImplementedError("down-scaling by more than 1.25 (ratio < 0.8) needs the multi-tap anti-aliasing filter")
+    image = gaussian_aa(image, row_scale, col_scale)          # (one tap -- the identity -- for ratios >= 0.8)
     tfr, tfc = np.meshgrid(np.arange(new_rows, dtype=np.float64), np.arange(new_cols, dtype=np.float64), indexing="ij")
     c = col_scale * tfc + 0.0 * tfr + (col_scale / 2.0 - 0.5)
     r = 0.0 * tfc + row_scale * tfr + (row_scale / 2.0 - 0.5)
@@ -101,9 +134,7 @@ def resize_bilinear(img, new_rows, new_cols):
     image = img.astype(np.float64)
     rows, cols = image.shape[:2]
     row_scale, col_scale = float(rows) / new_rows, float(cols) / new_cols
-    for f in (row_scale, col_scale):                   # anti-aliasing: scipy's gaussian_filter1d truncates at int(4 sigma + .5)
-        if int(4.0 * max(0.0, (f - 1.0) / 2.0) + 0.5) > 0:
-            raise NotImplementedError("down-scaling by more than 1.25 (ratio < 0.8) needs the multi-tap anti-aliasing filter")
+    image = gaussian_aa(image, row_scale, col_scale)   # anti-aliasing: scipy's gaussian_filter1d truncates at int(4 sigma + .5)
     m = np.array([[col_scale, 0.0, col_scale / 2.0 - 0.5], [0.0, row_scale, row_scale / 2.0 - 0.5], [0.0, 0.0, 1.0]])
     return _warp_affine(image, m, new_rows, new_cols)
 

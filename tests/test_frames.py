@@ -200,7 +200,8 @@ def test_random_train_test_split_is_scikit_learns(be, shapes, tmp_path):
 def test_transforms_without_a_device_form_raise(shapes):
     from mnk import frames
     fx, root, names = shapes
-    for bad in ({"resize_param": {"ratio": [0.5, 1.1]}},):           # (round 5: every term of ColorJitter has a device form)
+    for bad in ({"resize_param": {"ratio": [0.2, 1.1]}},):           # (round 5: every term of ColorJitter and the anti-aliased
+        # resize down to ratio 0.32 have device forms; below that the Gaussian needs more than nine taps)
         with pytest.raises(NotImplementedError):
             frames.DeviceFramesDataset(root, bad, device="cpu", files=names)
 
@@ -216,6 +217,11 @@ AUG = {   # config/moving-gif.yaml:5-14 (at the 64x64 frames of the fixture), co
     "full-jitter": {"crop_param": {"size": [64, 64]}, "resize_param": {"ratio": [0.9, 1.1]},
                     "jitter_param": {"brightness": 0.4, "contrast": 0.5, "saturation": 0.6, "hue": 0.2}},
     "contrast-rotated": {"rotation_param": {"degrees": 15}, "jitter_param": {"contrast": 0.8, "brightness": 0.9}},
+    # RandomResize's DEFAULT ratio (3/4, 4/3) and stronger down-scalings: skimage's multi-tap anti-aliasing filter (round 5)
+    "aa-default-ratio": {"crop_param": {"size": [64, 64]}, "resize_param": {}},
+    "aa-nearest": {"crop_param": {"size": [48, 40]}, "resize_param": {"ratio": [0.4, 0.78]}, "jitter_param": {"hue": 0.2}},
+    "aa-bilinear-rotated": {"crop_param": {"size": [40, 56]}, "resize_param": {"ratio": [0.35, 0.75], "interpolation": "bilinear"},
+                            "rotation_param": {"degrees": 20}},
 }
 
 
@@ -255,6 +261,22 @@ def test_resize_rotation_and_hue_jitter_equal_the_restated_library_arithmetic(be
     else:
         assert worst <= 1e-6, (tag, worst)
     print("%s: %d values, %d differ by more than 1e-6, largest difference %.3e" % (tag, total, differ, worst))
+
+
+def test_anti_aliasing_restatement_equals_the_installed_scipy():
+    """skimage 0.14's resize calls scipy.ndimage.gaussian_filter before it samples; oracle/augment_restate.py::gaussian_aa restates
+    that filter (kernel construction, the symmetric correlate1d's order of additions, rows then columns, zero padding) and must
+    equal the REAL scipy bit for bit -- the filter half of the anti-aliased resize is pinned to a real library (the sampling
+    half, skimage's warp, is not installable here)"""
+    ndi = pytest.importorskip("scipy.ndimage")
+    from oracle import augment_restate as ar
+    rng = np.random.RandomState(3)
+    for trial in range(24):
+        h, w = rng.randint(12, 60, size=2)
+        img = rng.rand(h, w, 3)
+        fr, fc = rng.uniform(0.8, 3.2, size=2)
+        want = ndi.gaussian_filter(img, (max(0.0, (fr - 1) / 2), max(0.0, (fc - 1) / 2), 0), cval=0, mode="constant")
+        assert np.array_equal(ar.gaussian_aa(img, fr, fc), want), (trial, fr, fc)
 
 
 def test_hue_restatement_equals_the_golden_of_the_real_pillow():
