@@ -1016,7 +1016,7 @@ struct WarpSegs {
     const float* emb;
     float* dfield;
     float* demb;
-    int dfield_begin, dfield_blocks, dfield_accumulate;
+    int dfield_begin, dfield_blocks, dfield_accumulate, dfield_serial;
     int demb_begin, demb_blocks;
 };
 
@@ -1126,67 +1126,6 @@ __device__ __forceinline__ void field_grad_of_level(const WarpSegs& a, const War
     }
 }
 
-constexpr int EMB_CH = 16;      // embedding channels a lane accumulates per pass
-
-// one level's share of the gradient of embedding texel (n, ys, xs), channels [c0, c0 + EMB_CH): the gathers of
-// resize_nearest_bwd_kernel / resize_bilinear_bwd_kernel (layout.hip), the same order of the additions
-__device__ __forceinline__ void emb_grad_of_level(const WarpSegs& a, const WarpSeg& L, int n, int ys, int xs, int c0, float* acc) {
-    int h_lo, h_hi, w_lo, w_hi;
-    field_window(ys, a.He, L.h, a.mode, h_lo, h_hi);
-    field_window(xs, a.We, L.w, a.mode, w_lo, w_hi);
-    const int cn = L.ke - c0 < EMB_CH ? L.ke - c0 : EMB_CH;
-    const bool vec = ((L.emb_off + c0) & 3) == 0 && (L.ld_out & 3) == 0;
-    for (int y = h_lo; y <= h_hi; ++y) {
-        Lin1D ly;
-        bool y0, y1;
-        if (a.mode == 0) {
-            y0 = nearest_src(y, a.He, L.h) == ys, y1 = false;
-            ly.l0 = 1.f, ly.l1 = 0.f;
-        } else {
-            ly.setup(y, a.He, L.h);
-            y0 = ly.i0 == ys, y1 = ly.i1 == ys;
-        }
-        if (!y0 && !y1) continue;
-        for (int x = w_lo; x <= w_hi; ++x) {
-            Lin1D lx;
-            bool x0, x1;
-            if (a.mode == 0) {
-                x0 = nearest_src(x, a.We, L.w) == xs, x1 = false;
-                lx.l0 = 1.f, lx.l1 = 0.f;
-            } else {
-                lx.setup(x, a.We, L.w);
-                x0 = lx.i0 == xs, x1 = lx.i1 == xs;
-            }
-            if (!x0 && !x1) continue;
-            const float* gp = L.dout + (((long)n * L.h + y) * L.w + x) * L.ld_out + L.emb_off + c0;
-            float gv[EMB_CH];
-            if (vec) {           // (the row's pad channels behind the embedding are zeros and lie inside the row)
-#pragma unroll
-                for (int c = 0; c < EMB_CH; c += 4) {
-                    const float4 t = c < cn ? *reinterpret_cast<const float4*>(gp + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    gv[c] = t.x, gv[c + 1] = t.y, gv[c + 2] = t.z, gv[c + 3] = t.w;
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < EMB_CH; ++c) gv[c] = c < cn ? gp[c] : 0.f;
-            }
-#pragma unroll
-            for (int c = 0; c < EMB_CH; ++c) {
-                if (c >= cn) continue;
-                const float g = gv[c];
-                if (a.mode == 0) {
-                    acc[c] += g;
-                } else {
-                    if (y0 && x0) acc[c] += g * ly.l0 * lx.l0;
-                    if (y0 && x1) acc[c] += g * ly.l0 * lx.l1;
-                    if (y1 && x0) acc[c] += g * ly.l1 * lx.l0;
-                    if (y1 && x1) acc[c] += g * ly.l1 * lx.l1;
-                }
-            }
-        }
-    }
-}
-
 // ---- the embedding's gradient under a BILINEAR resize (mode 1: the vox configurations) ----------------------------------------
 // A 64 x 64 embedding under a 256 x 256 map: every texel is read by ~64 pixels of that level, by 16 of the next ...
 // One lane per level (the nearest form below) then walks 64 scattered pixels alone -- every load instruction of the wavefront
@@ -1286,6 +1225,29 @@ __global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a)
             if (threadIdx.x == 0) s_lv[l] = a.lv[l];
         __syncthreads();
     }
+    if (a.dfield_serial && b >= a.dfield_begin && b < a.dfield_begin + a.dfield_blocks) {
+        // one thread per field texel, the levels one after the other (tuning value "warp_field_lanes" = 1)
+        const long total = (long)a.N * a.hf * a.wf;
+        for (long i = (long)(b - a.dfield_begin) * 256 + threadIdx.x; i < total; i += (long)a.dfield_blocks * 256) {
+            const int xs = (int)(i % a.wf);
+            const long t = i / a.wf;
+            float tx = 0.f, ty = 0.f;
+            for (int l = 0; l < a.n; ++l) {
+                float sx = 0.f, sy = 0.f;
+                field_grad_of_level(a, a.lv[l], t / a.hf, (int)(t % a.hf), xs, sx, sy);
+                tx = l ? tx + sx : sx;
+                ty = l ? ty + sy : sy;
+            }
+            if (a.dfield_accumulate) {
+                a.dfield[i * 2] += tx;
+                a.dfield[i * 2 + 1] += ty;
+            } else {
+                a.dfield[i * 2] = tx;
+                a.dfield[i * 2 + 1] = ty;
+            }
+        }
+        return;
+    }
     if (b >= a.dfield_begin && b < a.dfield_begin + a.dfield_blocks) {
         const long total = (long)a.N * a.hf * a.wf;
         const long iters = (total + per_block - 1) / per_block;
@@ -1316,33 +1278,38 @@ __global__ void __launch_bounds__(256) warp_levels_bwd_gather_kernel(WarpSegs a)
         return;
     }
     if (b >= a.demb_begin && b < a.demb_begin + a.demb_blocks) {
-        // pad channels (>= every level's ke) are written 0
-        const long total = (long)a.N * a.He * a.We;
-        const long iters = (total + per_block - 1) / per_block;
-        for (long it = b - a.demb_begin; it < iters; it += a.demb_blocks) {
-            const long i = it * per_block + group;
-            const int xs = (int)(i % a.We);
-            const long t = i / a.We;
-            const int ys = (int)(t % a.He), n = (int)(t / a.He);
-            for (int c0 = 0; c0 < a.ld_emb; c0 += EMB_CH) {
-                float acc[EMB_CH];
-#pragma unroll
-                for (int c = 0; c < EMB_CH; ++c) acc[c] = 0.f;
-                const bool mine = i < total && lvl < a.n && s_lv[lvl < a.n ? lvl : 0].ke > c0;
-                if (mine) emb_grad_of_level(a, s_lv[lvl], n, ys, xs, c0, acc);
-#pragma unroll
-                for (int c = 0; c < EMB_CH; ++c) {
-                    float tot = 0.f;
-                    bool first = true;
-                    for (int l = 0; l < a.n; ++l) {
-                        const float v = __shfl(acc[c], gbase + l);
-                        if (a.lv[l].ke <= c0 + c) continue;          // (uniform: the level has no such channel)
-                        tot = first ? v : tot + v;
-                        first = false;
+        // nearest resize: every embedding ELEMENT gathers, level after level, the few pixels whose nearest source it is
+        // (resize_nearest_bwd_kernel of layout.hip; pad channels are written 0).  One thread per element: the windows are one to
+        // four pixels per level -- the lane-per-level form that pays under a bilinear resize cost 3.7x the instructions here
+        // (taichi: 0.15 -> 0.27 ms for the pass, profiles/r05_knob_ab_log.txt)
+        const long total = (long)a.N * a.He * a.We * a.ld_emb;
+        for (long i = (long)(b - a.demb_begin) * 256 + threadIdx.x; i < total; i += (long)a.demb_blocks * 256) {
+            const int c = (int)(i % a.ld_emb);
+            const long p = i / a.ld_emb;
+            const int xs = (int)(p % a.We);
+            const long t = p / a.We;
+            const int ys = (int)(t % a.He);
+            const int n = (int)(t / a.He);
+            float tot = 0.f;
+            bool first = true;
+            for (int l = 0; l < a.n; ++l) {
+                const WarpSeg& L = a.lv[l];
+                if (L.ke <= 0 || c >= L.ke) continue;
+                int h_lo, h_hi, w_lo, w_hi;
+                field_window(ys, a.He, L.h, 0, h_lo, h_hi);
+                field_window(xs, a.We, L.w, 0, w_lo, w_hi);
+                float acc = 0.f;
+                for (int y = h_lo; y <= h_hi; ++y) {
+                    if (nearest_src(y, a.He, L.h) != ys) continue;
+                    for (int x = w_lo; x <= w_hi; ++x) {
+                        if (nearest_src(x, a.We, L.w) != xs) continue;
+                        acc += L.dout[(((long)n * L.h + y) * L.w + x) * L.ld_out + L.emb_off + c];
                     }
-                    if (i < total && lvl == 0 && c0 + c < a.ld_emb) a.demb[i * a.ld_emb + c0 + c] = tot;
                 }
+                tot = first ? acc : tot + acc;
+                first = false;
             }
+            a.demb[i] = tot;
         }
         return;
     }
@@ -1593,6 +1560,7 @@ static void warp_bwd_plan(int C, long npix, int& CL, int& cslice, int& gx, int& 
 // in 8 x 8 tiles would read its 512 KB of sampling points 1024 times per frame); small maps take small tiles so that the
 // 256 threads split the channels instead of idling
 static int g_warp_gather_tile = tuning_knob("warp_gather_tile", &g_warp_gather_tile, 0);    // 0: by map size; 1 / 2 / 4 / 8 / 16 forces the edge (A/B)
+static int g_warp_field_lanes = tuning_knob("warp_field_lanes", &g_warp_field_lanes, 1);      // nearest resize: 1 = a thread per field texel (taichi levels 223 -> 182 us per pass, moving-gif 158 -> 146), 16 = a lane per level (the bilinear form)
 static int g_warp_gather_rule = tuning_knob("warp_gather_rule", &g_warp_gather_rule, 1);    // 1: lanes per texel by channel count (vox 1243 -> 1040 us per pass, moving-gif 223 -> 214); 0: tile edge by map size
 static void warp_gather_plan(int ld_in, int h, int w, int& T, int& nacc, int& qslices, int& tiles) {
     const long P = (long)h * w;
@@ -1636,11 +1604,13 @@ static int warp_bwd_launch(WarpSegs& a, float* ws, size_t ws_floats, double byte
     float* wp = ws;
     // pass B's grid: the texel gathers of the field and the embedding first (few, long-running), then the tiles of d input
     a.dfield_begin = blocks_b;
-    const int per_block = a.mode ? 4 : 16;       // texels per block of the embedding gather (warp_levels_bwd_gather_kernel)
-    a.dfield_blocks = a.dfield ? (int)std::min<long>(((long)a.N * a.hf * a.wf + 15) / 16, 32768) : 0;
+    a.dfield_serial = (a.mode == 0 && g_warp_field_lanes == 1) ? 1 : 0;
+    a.dfield_blocks = a.dfield ? (int)std::min<long>(((long)a.N * a.hf * a.wf + (a.dfield_serial ? 255 : 15)) / (a.dfield_serial ? 256 : 16), 32768) : 0;
     blocks_b += a.dfield_blocks;
     a.demb_begin = blocks_b;
-    a.demb_blocks = a.demb ? (int)std::min<long>(((long)a.N * a.He * a.We + per_block - 1) / per_block, 32768) : 0;
+    // embedding gather: a thread per element (nearest) / a wavefront per texel (bilinear)
+    a.demb_blocks = !a.demb ? 0 : a.mode ? (int)std::min<long>(((long)a.N * a.He * a.We + 3) / 4, 32768)
+                                         : grid_for((long)a.N * a.He * a.We * a.ld_emb);
     blocks_b += a.demb_blocks;
     const int small_blocks = blocks_b;
     for (int l = 0; l < a.n; ++l) {
