@@ -63,7 +63,7 @@ struct BlockRed {
 };
 
 // one block per frame and group of kg channels; the channels of a pixel are contiguous (NHWC): a pixel is one 4..64 B read
-__global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __restrict__ heat, int ld, int H, int W,
+__global__ void __launch_bounds__(256) softmax_kp_fwd_multipass_kernel(const float* __restrict__ heat, int ld, int H, int W,
                                                              int Kall, int kg, float temperature,
                                                              float* __restrict__ mean, float* __restrict__ var,
                                                              float* __restrict__ stat) {
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __rest
     }
 }
 
-__global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __restrict__ heat, int ld, int H, int W,
+__global__ void __launch_bounds__(256) softmax_kp_bwd_multipass_kernel(const float* __restrict__ heat, int ld, int H, int W,
                                                              int Kall, int kg, float temperature,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ stat,
@@ -210,6 +210,147 @@ __global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __rest
             }
         if (last_group)
             for (int k = K; k < ld_d - k0; ++k) dp[(long)p * ld_d + k] = 0.f;
+    }
+}
+
+// ---- one-pass soft-argmax (round 6) ------------------------------------------------------------------------------------
+// One WAVEFRONT per (frame, key-point channel): the channel's whole heat-map is held in registers (PPT pixels per lane,
+// pixel p = j * 64 + lane, so a load instruction's lanes touch neighbouring pixels), every element is divided by the
+// temperature once and exponentiated once, and the nine sums (max; S, Sx, Sy and the two grid sums; the three centred
+// second moments) are wavefront shuffles -- no LDS, no barrier, one read of the heat-map.  frames x K wavefronts
+// (640 for the 64 frames x 10 key points of a batch-32 iteration) instead of frames x 2 blocks that walked global
+// memory three times.  Same formulas as the multi-pass kernels above (keypoint_detector.py:43-78,103-107), which stay for
+// heat-maps beyond 64 x 64.
+template <int PPT>
+__global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __restrict__ heat, int ld, int H, int W, int K,
+                                                             int pairs, float temperature, float* __restrict__ mean,
+                                                             float* __restrict__ var, float* __restrict__ stat) {
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= pairs) return;                       // wave-uniform
+    const int n = pair / K, k = pair - n * K;
+    const int P = H * W;
+    const float* hp = heat + (long)n * P * ld + k;
+    const float invW = 1.f / (float)W;
+    float v[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * 64 + lane;
+        v[j] = p < P ? hp[(long)p * ld] : -INFINITY;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        v[j] = v[j] / temperature;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = wave_max(mx);
+    float S = 0.f, Sx = 0.f, Sy = 0.f, gsx = 0.f, gsy = 0.f;
+    float gxs[PPT], gys[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * 64 + lane;
+        // p / W for p < 4096: (p + 0.5) / W is at least 0.5 / W away from an integer, far beyond the rounding of the product
+        const int py = (int)(((float)p + 0.5f) * invW), px = p - py * W;
+        const bool in = p < P;
+        const float gx = in ? grid_coord(px, W) : 0.f, gy = in ? grid_coord(py, H) : 0.f;
+        const float e = in ? expf(v[j] - mx) : 0.f;
+        v[j] = e;
+        gxs[j] = gx;
+        gys[j] = gy;
+        S += e;
+        Sx += e * gx;
+        Sy += e * gy;
+        gsx += gx;
+        gsy += gy;
+    }
+    S = wave_sum(S);
+    Sx = wave_sum(Sx);
+    Sy = wave_sum(Sy);
+    gsx = wave_sum(gsx);
+    gsy = wave_sum(gsy);
+    const float invS = 1.f / S;
+    const float mux = Sx * invS + 1e-7f * gsx, muy = Sy * invS + 1e-7f * gsy;
+    // centred second moments with weight p + 1e-7 (keypoint_detector.py:49,57-60) from the held exponentials
+    float vxx = 0.f, vxy = 0.f, vyy = 0.f;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * 64 + lane;
+        const float wgt = p < P ? v[j] * invS + 1e-7f : 0.f;
+        const float dx = gxs[j] - mux, dy = gys[j] - muy;
+        vxx += wgt * dx * dx;
+        vxy += wgt * dx * dy;
+        vyy += wgt * dy * dy;
+    }
+    vxx = wave_sum(vxx);
+    vxy = wave_sum(vxy);
+    vyy = wave_sum(vyy);
+    if (lane == 0) {
+        const long o = pair;
+        mean[o * 2 + 0] = mux;
+        mean[o * 2 + 1] = muy;
+        var[o * 4 + 0] = vxx;
+        var[o * 4 + 1] = vxy;
+        var[o * 4 + 2] = vxy;
+        var[o * 4 + 3] = vyy;
+        stat[o * 2 + 0] = mx;
+        stat[o * 2 + 1] = S;
+    }
+}
+
+template <int PPT>
+__global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __restrict__ heat, int ld, int H, int W, int K,
+                                                             int pairs, float temperature, const float* __restrict__ mean,
+                                                             const float* __restrict__ stat, const float* __restrict__ dmean,
+                                                             const float* __restrict__ dvar, float* __restrict__ dheat,
+                                                             int ld_d) {
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= pairs) return;
+    const int n = pair / K, k = pair - n * K;
+    const int P = H * W;
+    const float* hp = heat + (long)n * P * ld + k;
+    const float invW = 1.f / (float)W;
+    float s[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * 64 + lane;
+        s[j] = p < P ? hp[(long)p * ld] : 0.f;
+    }
+    const long o = pair;
+    const float mux = mean[o * 2], muy = mean[o * 2 + 1], mx = stat[o * 2], invS = 1.f / stat[o * 2 + 1];
+    const float d00 = dvar[o * 4], d01 = dvar[o * 4 + 1], d10 = dvar[o * 4 + 2], d11 = dvar[o * 4 + 3];
+    // c = sum_i w_i (g_i - mu) = -mu * P * 1e-7 (weights sum to 1 + P*1e-7); the centring of var feeds back into mean:
+    // dmu_total = dmean - (dvar + dvar^T) c
+    const float cx = -mux * (float)P * 1e-7f, cy = -muy * (float)P * 1e-7f;
+    const float gmx = dmean[o * 2] - (2.f * d00 * cx + (d01 + d10) * cy);
+    const float gmy = dmean[o * 2 + 1] - ((d01 + d10) * cx + 2.f * d11 * cy);
+    const float v00 = d00, v01 = d01 + d10, v11 = d11;
+    float ai[PPT];
+    float A = 0.f;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * 64 + lane;
+        const int py = (int)(((float)p + 0.5f) * invW), px = p - py * W;
+        const bool in = p < P;
+        const float gx = grid_coord(px, W), gy = grid_coord(py, H);
+        const float sj = in ? expf(s[j] / temperature - mx) * invS : 0.f;
+        const float dx = gx - mux, dy = gy - muy;
+        const float a = gmx * gx + gmy * gy + v00 * dx * dx + v01 * dx * dy + v11 * dy * dy;
+        s[j] = sj;
+        ai[j] = a;
+        A += sj * a;
+    }
+    A = wave_sum(A);
+    float* dp = dheat + (long)n * P * ld_d + k;
+    const int npad = k == K - 1 ? ld_d - K : 0;      // the wavefront of the last channel also zeroes the pad channels
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * 64 + lane;
+        if (p < P) {
+            dp[(long)p * ld_d] = s[j] * (ai[j] - A) / temperature;
+            for (int q = 1; q <= npad; ++q) dp[(long)p * ld_d + q] = 0.f;
+        }
     }
 }
 
@@ -684,6 +825,8 @@ __global__ void __launch_bounds__(256) kp_normalize_kernel(const float* __restri
 // blocks of one wave per SIMD for the 64 frames of an iteration, each doing 3 passes x 10 expf / divisions per pixel; 5 / 2 / 1
 // channels per block measured -0.05 / -0.04 / -0.05 ms per iteration against that (visit 45) -> 5
 static int g_kp_group = tuning_knob("kp_group", &g_kp_group, 5);
+// 1: heat-maps up to 64 x 64 take the one-pass wavefront-per-(frame, key point) kernels; 0: the multi-pass block kernels
+static int g_kp_onepass = tuning_knob("kp_onepass", &g_kp_onepass, 1);
 static int kp_group(int K) {
     int kg = g_kp_group < 1 ? 1 : g_kp_group;
     return kg > K ? K : kg;
@@ -775,10 +918,21 @@ int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, fl
     MNK_REQUIRE(heat && mean && var && stat && N > 0 && H > 1 && W > 1 && K > 0 && K <= MAXK && ld >= K);
     MNK_REQUIRE(temperature > 0.f);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4 * 3);
-    const int kg = kp_group(K);
-    hipLaunchKernelGGL(softmax_kp_fwd_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg, temperature, mean,
-                       var, stat);
+    // algorithmic bytes: one read of the K heat-map channels + the 8 output floats per key point
+    ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4 + (double)N * K * 32);
+    const int P = H * W, pairs = N * K;
+    const dim3 grid((unsigned)((pairs + 3) / 4));
+    if (g_kp_onepass && P <= 256)
+        hipLaunchKernelGGL(softmax_kp_fwd_kernel<4>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
+    else if (g_kp_onepass && P <= 1024)
+        hipLaunchKernelGGL(softmax_kp_fwd_kernel<16>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
+    else if (g_kp_onepass && P <= 4096)
+        hipLaunchKernelGGL(softmax_kp_fwd_kernel<64>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
+    else {
+        const int kg = kp_group(K);
+        hipLaunchKernelGGL(softmax_kp_fwd_multipass_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg,
+                           temperature, mean, var, stat);
+    }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }
@@ -806,10 +960,24 @@ int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, fl
     MNK_REQUIRE(heat && mean && stat && dmean && dvar && dheat && N > 0 && H > 1 && W > 1 && K > 0 && K <= MAXK);
     MNK_REQUIRE(ld >= K && ld_d >= K && temperature > 0.f);
     hipStream_t s = (hipStream_t)stream;
-    ProfScope prof(K_KEYPOINT, s, (double)N * H * W * K * 4 * 3);
-    const int kg = kp_group(K);
-    hipLaunchKernelGGL(softmax_kp_bwd_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg, temperature, mean,
-                       stat, dmean, dvar, dheat, ld_d);
+    // algorithmic bytes: one read of the K heat-map channels, one write of the ld_d gradient channels
+    ProfScope prof(K_KEYPOINT, s, (double)N * H * W * (K + ld_d) * 4);
+    const int P = H * W, pairs = N * K;
+    const dim3 grid((unsigned)((pairs + 3) / 4));
+    if (g_kp_onepass && P <= 256)
+        hipLaunchKernelGGL(softmax_kp_bwd_kernel<4>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat, dmean,
+                           dvar, dheat, ld_d);
+    else if (g_kp_onepass && P <= 1024)
+        hipLaunchKernelGGL(softmax_kp_bwd_kernel<16>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat, dmean,
+                           dvar, dheat, ld_d);
+    else if (g_kp_onepass && P <= 4096)
+        hipLaunchKernelGGL(softmax_kp_bwd_kernel<64>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat, dmean,
+                           dvar, dheat, ld_d);
+    else {
+        const int kg = kp_group(K);
+        hipLaunchKernelGGL(softmax_kp_bwd_multipass_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg,
+                           temperature, mean, stat, dmean, dvar, dheat, ld_d);
+    }
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

@@ -7,7 +7,9 @@ from _util import to_nhwc, from_nhwc, ceil4, relerr, maxerr
 from oracle import restate, cases
 
 
-@pytest.mark.parametrize("shape", [(2, 4, 8, 12), (3, 10, 16, 16), (1, 16, 9, 7)])
+# 8x12 / 16x16 / 9x7: the one-pass kernel with 4 pixels per lane; 32x32: 16; 64x64 and 40x50: 64; 72x64: the multi-pass kernels
+@pytest.mark.parametrize("shape", [(2, 4, 8, 12), (3, 10, 16, 16), (1, 16, 9, 7), (2, 10, 32, 32), (1, 3, 64, 64), (2, 5, 40, 50),
+                                   (1, 2, 72, 64)])
 @pytest.mark.parametrize("temperature", [0.1, 1.0])
 def test_softmax_kp(be, shape, temperature):
     n, k, h, w = shape
