@@ -8,7 +8,7 @@ TAG="${MNK_BUILD_TAG:-}"
 OUT="$HERE/build$TAG"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-unused-variable ${MNK_EXTRA_FLAGS}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$ROOT/include -I$HERE -Wall -Wno-unused-function -Wno-unused-variable ${MNK_EXTRA_FLAGS}"
 OBJS=""
 pids=""
 NEWEST_H="$(ls -t "$HERE"/*.h "$ROOT/include/monkeynet_hip.h" | head -1)"

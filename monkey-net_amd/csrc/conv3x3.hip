@@ -1252,10 +1252,9 @@ struct WgradArgs {
     long M;              // pixels
     long pix_per_split;  // multiple of 16
     int NT;              // ntaps * C
-    float* out;          // direct / atomic: dw + c_start*9 (row stride ld_out); else partials [splits][Cout][NT]
+    float* out;          // unsplit: dw + c_start*9 (row stride ld_out); else partials [splits][Cout][NT]
     long ld_out;
     int splits;
-    int atomic;          // splits > 1: accumulate into the zeroed gradient with fp32 atomics (no partial buffer)
 };
 
 template <int BM>
@@ -1380,10 +1379,9 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
         __syncthreads();
     }
     // rows = co, cols = n (contiguous in the parameter layout): 32 lanes write 128 consecutive bytes
-    const bool partial = a.splits > 1 && !a.atomic;
+    const bool partial = a.splits > 1;       // split partials are summed in a fixed order by the reduction (no fp32 atomics)
     float* outp = partial ? a.out + (long)split * a.Cout * a.NT : a.out;
     const long ldo = partial ? (long)a.NT : a.ld_out;
-    const bool use_atomic = a.splits > 1 && a.atomic;
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -1392,12 +1390,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wm * (32 * TMW) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fk;
-                if (co < a.Cout && n < a.NT) {
-                    if (use_atomic)
-                        atomicAdd(outp + (long)co * ldo + n, acc[i][j][r]);
-                    else
-                        outp[(long)co * ldo + n] = acc[i][j][r];
-                }
+                if (co < a.Cout && n < a.NT) outp[(long)co * ldo + n] = acc[i][j][r];
             }
         }
 }
@@ -2396,10 +2389,8 @@ struct Plan {
 // mnk_set_tuning / MNK_TUNING for tuning runs, no environment switch of their own)
 static int g_split_tiles = tuning_knob("split_tiles", &g_split_tiles, 192), g_split_target = tuning_knob("split_target", &g_split_target, 512),
            g_split_minsteps = tuning_knob("split_minsteps", &g_split_minsteps, 6);
-// 0 (default): deterministic split-K partials + reduce kernel; 1: accumulate the partial tiles with fp32 atomics into
-// the zeroed gradient (no partial buffer / reduce launch).  Measured equal on the MI355X (21.74 ms per training
-// iteration either way: the atomics cost the wgrad kernel what the reduce kernel saves), so determinism wins.
-static int g_wgrad_atomic = tuning_knob("wgrad_atomic", &g_wgrad_atomic, 0);
+// (the weight-gradient splits are deterministic partials + a reduce kernel; an fp32-atomic form measured equal in round 1 and
+// was removed in round 6 together with -munsafe-fp-atomics: no floating-point atomic exists in this library)
 // 1 (default): a split-K forward launch that was asked for BatchNorm statistics sums its partials with
 // conv3x3_splitk_reduce_stats_kernel (one launch for reduction + statistics pass); 0: no statistics from split launches
 static int g_splitk_stats = tuning_knob("splitk_stats", &g_splitk_stats, 1);
@@ -3018,12 +3009,12 @@ size_t mnk_conv2d_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout,
         }
         if (np.use) {
             WPlan p = make_wplan((long)N * Ho * Wo, Cout, C, ntaps);
-            const size_t ng = (p.splits > 1 && !g_wgrad_atomic) ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
+            const size_t ng = p.splits > 1 ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
             return ng > need ? ng : need;
         }
     }
     WPlan p = make_wplan((long)N * Ho * Wo, Cout, C, ntaps);
-    return (p.splits > 1 && !g_wgrad_atomic) ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
+    return p.splits > 1 ? (size_t)(p.splits + split_groups(p.splits)) * Cout * ntaps * C : 0;
 }
 
 size_t mnk_conv3x3_up_wgrad_workspace_floats(int N, int Ho, int Wo, int C, int Cout) {
@@ -3313,8 +3304,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
     float* dst = dw + (long)c_start * ntaps;
     const long ld_out = (long)Cin_total * ntaps;
     hipStream_t s = (hipStream_t)stream;
-    a.atomic = defer ? 0 : g_wgrad_atomic;
-    if (p.splits > 1 && !a.atomic) {
+    if (p.splits > 1) {
         if (!ws || ws_floats < (size_t)(p.splits + (defer ? 0 : split_groups(p.splits))) * Cout * a.NT) {
             set_error("mnk_conv2d_wgrad: workspace too small");
             return MNK_EWORKSPACE;
@@ -3324,11 +3314,6 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
     } else {
         a.out = dst;
         a.ld_out = ld_out;
-        if (p.splits > 1 &&
-            hipMemset2DAsync(dst, (size_t)ld_out * 4, 0, (size_t)a.NT * 4, (size_t)Cout, s) != hipSuccess) {
-            set_error("mnk_conv2d_wgrad: hipMemset2DAsync failed");
-            return MNK_ELAUNCH;
-        }
     }
     {
         ProfScope prof(K_CONV_WGRAD, s, 2.0 * (double)a.M * Cout * (double)ntaps * C);
@@ -3339,7 +3324,7 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
         else
             hipLaunchKernelGGL((conv3x3_wgrad_kernel<32>), dim3(p.gm, p.gn, p.splits), dim3(256), 0, s, a);
     }
-    if (p.splits > 1 && !a.atomic && !defer) {
+    if (p.splits > 1 && !defer) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * Cout * a.NT * 4);
         launch_wgrad_reduce(ws, p.splits, Cout, a.NT, dst, ld_out, s);
     }

@@ -214,20 +214,63 @@ __global__ void __launch_bounds__(256) softmax_kp_bwd_multipass_kernel(const flo
 }
 
 // ---- one-pass soft-argmax (round 6) ------------------------------------------------------------------------------------
-// One WAVEFRONT per (frame, key-point channel): the channel's whole heat-map is held in registers (PPT pixels per lane,
-// pixel p = j * 64 + lane, so a load instruction's lanes touch neighbouring pixels), every element is divided by the
-// temperature once and exponentiated once, and the nine sums (max; S, Sx, Sy and the two grid sums; the three centred
-// second moments) are wavefront shuffles -- no LDS, no barrier, one read of the heat-map.  frames x K wavefronts
-// (640 for the 64 frames x 10 key points of a batch-32 iteration) instead of frames x 2 blocks that walked global
-// memory three times.  Same formulas as the multi-pass kernels above (keypoint_detector.py:43-78,103-107), which stay for
-// heat-maps beyond 64 x 64.
-template <int PPT>
+// One WAVEFRONT (heat-maps up to 32 x 32) or one four-wavefront block (up to 64 x 64) per (frame, key-point channel): the
+// channel's whole heat-map is held in registers (<= 16 pixels per lane, pixel p = j * lanes + lane, so a load instruction's
+// lanes touch neighbouring pixels), every element is divided by the temperature once and exponentiated once, and the nine sums
+// (max; S, Sx, Sy and the two grid sums; the three centred second moments) are wavefront shuffles (+ one LDS hop between the
+// four wavefronts of the large form) -- one read of the heat-map.  frames x K wavefronts (640 for the 64 frames x 10 key
+// points of a batch-32 iteration) instead of frames x 2 blocks that walked global memory three times.  Same formulas as the
+// multi-pass kernels above (keypoint_detector.py:43-78,103-107), which stay for heat-maps beyond 64 x 64.
+template <int WAVES>
+struct PairRed {      // sums / maxima over the WAVES wavefronts that share a (frame, key point) pair; every lane gets the result
+    float* red;       // [WAVES][8] (WAVES > 1 only)
+    template <int N>
+    __device__ __forceinline__ void sum(float (&v)[N]) {
+        static_assert(N <= 8, "eight values per round");
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+        if constexpr (WAVES > 1) {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            __syncthreads();
+            if (lane == 0)
+#pragma unroll
+                for (int k = 0; k < N; ++k) red[wave * 8 + k] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                float t = red[k];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) t += red[w * 8 + k];
+                v[k] = t;
+            }
+        }
+    }
+    __device__ __forceinline__ float max(float v) {
+        v = wave_max(v);
+        if constexpr (WAVES > 1) {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            __syncthreads();
+            if (lane == 0) red[wave * 8] = v;
+            __syncthreads();
+            v = red[0];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) v = fmaxf(v, red[w * 8]);
+        }
+        return v;
+    }
+};
+
+// WAVES = 1: four pairs per 256-thread block (no barrier anywhere); WAVES = 4: one pair per block
+template <int PPT, int WAVES>
 __global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __restrict__ heat, int ld, int H, int W, int K,
                                                              int pairs, float temperature, float* __restrict__ mean,
                                                              float* __restrict__ var, float* __restrict__ stat) {
-    const int lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pair >= pairs) return;                       // wave-uniform
+    __shared__ float red_mem[WAVES > 1 ? WAVES * 8 : 1];
+    PairRed<WAVES> pr{red_mem};
+    constexpr int LANES = 64 * WAVES;
+    const int tl = threadIdx.x % LANES;                                  // position inside the pair's thread group
+    const int pair = blockIdx.x * (4 / WAVES) + threadIdx.x / LANES;
+    if (pair >= pairs) return;                                           // (WAVES = 1 only: wave-uniform, no barrier follows)
     const int n = pair / K, k = pair - n * K;
     const int P = H * W;
     const float* hp = heat + (long)n * P * ld + k;
@@ -235,7 +278,7 @@ __global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __rest
     float v[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int p = j * 64 + lane;
+        const int p = j * LANES + tl;
         v[j] = p < P ? hp[(long)p * ld] : -INFINITY;
     }
     float mx = -INFINITY;
@@ -244,68 +287,63 @@ __global__ void __launch_bounds__(256) softmax_kp_fwd_kernel(const float* __rest
         v[j] = v[j] / temperature;
         mx = fmaxf(mx, v[j]);
     }
-    mx = wave_max(mx);
-    float S = 0.f, Sx = 0.f, Sy = 0.f, gsx = 0.f, gsy = 0.f;
-    float gxs[PPT], gys[PPT];
+    mx = pr.max(mx);
+    float s5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};      // S, Sx, Sy, sum gx, sum gy
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int p = j * 64 + lane;
+        const int p = j * LANES + tl;
         // p / W for p < 4096: (p + 0.5) / W is at least 0.5 / W away from an integer, far beyond the rounding of the product
         const int py = (int)(((float)p + 0.5f) * invW), px = p - py * W;
         const bool in = p < P;
         const float gx = in ? grid_coord(px, W) : 0.f, gy = in ? grid_coord(py, H) : 0.f;
         const float e = in ? expf(v[j] - mx) : 0.f;
         v[j] = e;
-        gxs[j] = gx;
-        gys[j] = gy;
-        S += e;
-        Sx += e * gx;
-        Sy += e * gy;
-        gsx += gx;
-        gsy += gy;
+        s5[0] += e;
+        s5[1] += e * gx;
+        s5[2] += e * gy;
+        s5[3] += gx;
+        s5[4] += gy;
     }
-    S = wave_sum(S);
-    Sx = wave_sum(Sx);
-    Sy = wave_sum(Sy);
-    gsx = wave_sum(gsx);
-    gsy = wave_sum(gsy);
-    const float invS = 1.f / S;
-    const float mux = Sx * invS + 1e-7f * gsx, muy = Sy * invS + 1e-7f * gsy;
+    pr.sum(s5);
+    const float S = s5[0], invS = 1.f / S;
+    const float mux = s5[1] * invS + 1e-7f * s5[3], muy = s5[2] * invS + 1e-7f * s5[4];
     // centred second moments with weight p + 1e-7 (keypoint_detector.py:49,57-60) from the held exponentials
-    float vxx = 0.f, vxy = 0.f, vyy = 0.f;
+    float m3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int p = j * 64 + lane;
+        const int p = j * LANES + tl;
+        const int py = (int)(((float)p + 0.5f) * invW), px = p - py * W;
         const float wgt = p < P ? v[j] * invS + 1e-7f : 0.f;
-        const float dx = gxs[j] - mux, dy = gys[j] - muy;
-        vxx += wgt * dx * dx;
-        vxy += wgt * dx * dy;
-        vyy += wgt * dy * dy;
+        const float dx = grid_coord(px, W) - mux, dy = grid_coord(py, H) - muy;
+        m3[0] += wgt * dx * dx;
+        m3[1] += wgt * dx * dy;
+        m3[2] += wgt * dy * dy;
     }
-    vxx = wave_sum(vxx);
-    vxy = wave_sum(vxy);
-    vyy = wave_sum(vyy);
-    if (lane == 0) {
+    pr.sum(m3);
+    if (tl == 0) {
         const long o = pair;
         mean[o * 2 + 0] = mux;
         mean[o * 2 + 1] = muy;
-        var[o * 4 + 0] = vxx;
-        var[o * 4 + 1] = vxy;
-        var[o * 4 + 2] = vxy;
-        var[o * 4 + 3] = vyy;
+        var[o * 4 + 0] = m3[0];
+        var[o * 4 + 1] = m3[1];
+        var[o * 4 + 2] = m3[1];
+        var[o * 4 + 3] = m3[2];
         stat[o * 2 + 0] = mx;
         stat[o * 2 + 1] = S;
     }
 }
 
-template <int PPT>
+template <int PPT, int WAVES>
 __global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __restrict__ heat, int ld, int H, int W, int K,
                                                              int pairs, float temperature, const float* __restrict__ mean,
                                                              const float* __restrict__ stat, const float* __restrict__ dmean,
                                                              const float* __restrict__ dvar, float* __restrict__ dheat,
                                                              int ld_d) {
-    const int lane = threadIdx.x & 63;
-    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ float red_mem[WAVES > 1 ? WAVES * 8 : 1];
+    PairRed<WAVES> pr{red_mem};
+    constexpr int LANES = 64 * WAVES;
+    const int tl = threadIdx.x % LANES;
+    const int pair = blockIdx.x * (4 / WAVES) + threadIdx.x / LANES;
     if (pair >= pairs) return;
     const int n = pair / K, k = pair - n * K;
     const int P = H * W;
@@ -314,7 +352,7 @@ __global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __rest
     float s[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int p = j * 64 + lane;
+        const int p = j * LANES + tl;
         s[j] = p < P ? hp[(long)p * ld] : 0.f;
     }
     const long o = pair;
@@ -326,29 +364,28 @@ __global__ void __launch_bounds__(256) softmax_kp_bwd_kernel(const float* __rest
     const float gmx = dmean[o * 2] - (2.f * d00 * cx + (d01 + d10) * cy);
     const float gmy = dmean[o * 2 + 1] - ((d01 + d10) * cx + 2.f * d11 * cy);
     const float v00 = d00, v01 = d01 + d10, v11 = d11;
-    float ai[PPT];
-    float A = 0.f;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int p = j * 64 + lane;
+    auto a_of = [&](int p) __attribute__((always_inline)) {
         const int py = (int)(((float)p + 0.5f) * invW), px = p - py * W;
-        const bool in = p < P;
         const float gx = grid_coord(px, W), gy = grid_coord(py, H);
-        const float sj = in ? expf(s[j] / temperature - mx) * invS : 0.f;
         const float dx = gx - mux, dy = gy - muy;
-        const float a = gmx * gx + gmy * gy + v00 * dx * dx + v01 * dx * dy + v11 * dy * dy;
-        s[j] = sj;
-        ai[j] = a;
-        A += sj * a;
-    }
-    A = wave_sum(A);
-    float* dp = dheat + (long)n * P * ld_d + k;
-    const int npad = k == K - 1 ? ld_d - K : 0;      // the wavefront of the last channel also zeroes the pad channels
+        return gmx * gx + gmy * gy + v00 * dx * dx + v01 * dx * dy + v11 * dy * dy;
+    };
+    float A[1] = {0.f};
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int p = j * 64 + lane;
+        const int p = j * LANES + tl;
+        const float sj = p < P ? expf(s[j] / temperature - mx) * invS : 0.f;
+        s[j] = sj;
+        A[0] += sj * a_of(p);
+    }
+    pr.sum(A);
+    float* dp = dheat + (long)n * P * ld_d + k;
+    const int npad = k == K - 1 ? ld_d - K : 0;      // the threads of the last channel also zero the pad channels
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int p = j * LANES + tl;
         if (p < P) {
-            dp[(long)p * ld_d] = s[j] * (ai[j] - A) / temperature;
+            dp[(long)p * ld_d] = s[j] * (a_of(p) - A[0]) / temperature;
             for (int q = 1; q <= npad; ++q) dp[(long)p * ld_d + q] = 0.f;
         }
     }
@@ -923,11 +960,12 @@ int mnk_softmax_kp_fwd(const float* heat, int ld, int N, int H, int W, int K, fl
     const int P = H * W, pairs = N * K;
     const dim3 grid((unsigned)((pairs + 3) / 4));
     if (g_kp_onepass && P <= 256)
-        hipLaunchKernelGGL(softmax_kp_fwd_kernel<4>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
+        hipLaunchKernelGGL((softmax_kp_fwd_kernel<4, 1>), grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
     else if (g_kp_onepass && P <= 1024)
-        hipLaunchKernelGGL(softmax_kp_fwd_kernel<16>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
+        hipLaunchKernelGGL((softmax_kp_fwd_kernel<16, 1>), grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
     else if (g_kp_onepass && P <= 4096)
-        hipLaunchKernelGGL(softmax_kp_fwd_kernel<64>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, var, stat);
+        hipLaunchKernelGGL((softmax_kp_fwd_kernel<16, 4>), dim3((unsigned)pairs), dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature,
+                           mean, var, stat);
     else {
         const int kg = kp_group(K);
         hipLaunchKernelGGL(softmax_kp_fwd_multipass_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg,
@@ -965,14 +1003,14 @@ int mnk_softmax_kp_bwd(const float* heat, int ld, int N, int H, int W, int K, fl
     const int P = H * W, pairs = N * K;
     const dim3 grid((unsigned)((pairs + 3) / 4));
     if (g_kp_onepass && P <= 256)
-        hipLaunchKernelGGL(softmax_kp_bwd_kernel<4>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat, dmean,
+        hipLaunchKernelGGL((softmax_kp_bwd_kernel<4, 1>), grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat, dmean,
                            dvar, dheat, ld_d);
     else if (g_kp_onepass && P <= 1024)
-        hipLaunchKernelGGL(softmax_kp_bwd_kernel<16>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat, dmean,
-                           dvar, dheat, ld_d);
+        hipLaunchKernelGGL((softmax_kp_bwd_kernel<16, 1>), grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat,
+                           dmean, dvar, dheat, ld_d);
     else if (g_kp_onepass && P <= 4096)
-        hipLaunchKernelGGL(softmax_kp_bwd_kernel<64>, grid, dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature, mean, stat, dmean,
-                           dvar, dheat, ld_d);
+        hipLaunchKernelGGL((softmax_kp_bwd_kernel<16, 4>), dim3((unsigned)pairs), dim3(256), 0, s, heat, ld, H, W, K, pairs, temperature,
+                           mean, stat, dmean, dvar, dheat, ld_d);
     else {
         const int kg = kp_group(K);
         hipLaunchKernelGGL(softmax_kp_bwd_multipass_kernel, dim3(N, (K + kg - 1) / kg), dim3(256), 0, s, heat, ld, H, W, K, kg,

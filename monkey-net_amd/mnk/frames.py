@@ -15,9 +15,11 @@ non-integer augmentations of config/moving-gif.yaml and actions.yaml -- `rotatio
 DEFAULT ratio (3/4, 4/3) included -- down to ratio 0.32; the filter is scipy's gaussian_filter, pinned to the installed scipy) and `jitter_param` with `hue` (img_as_ubyte -> PIL HSV ->
 torchvision adjust_hue -> img_as_float) -- in one launch per batch (mnk_frames_augment), in the arithmetic of the package
 versions the reference pins; scikit-image and torchvision are not in this image (and not installable offline), so rotation and
-resize are checked against a numpy restatement of skimage 0.14's published algorithm (oracle/augment_restate.py: that part is
-"parity unpinned"); the hue jitter's colour conversions ARE pinned to a real library since round 5: the restatement equals the
-installed Pillow's Image.convert RGB <-> HSV on all 2^24 triples of both directions, and kernel and restatement reproduce a
+resize are checked against a numpy restatement of skimage 0.14's published algorithm (oracle/augment_restate.py) AND, since
+round 6, directly against scipy.ndimage.affine_transform / gaussian_filter on every pixel whose taps lie inside the source frame
+(an independent third-party implementation of the same interior arithmetic; the border rule stays a restatement); the hue
+jitter's colour conversions are pinned to the INSTALLED Pillow (12.2; the reference pins 5.2.0) since round 5: the restatement equals
+its Image.convert RGB <-> HSV on all 2^24 triples of both directions, and kernel and restatement reproduce a
 golden made by that Pillow (oracle/make_golden_hue.py, tests/golden/hue_pillow.npz).  Round 5 also: brightness / contrast /
 saturation -- all four terms of ColorJitter in the reference's shuffled order (Pillow's ImageEnhance arithmetic per pixel, the
 contrast term's frame mean by a pre-pass), pinned the same way (40 shuffled sequences x 8 images from the real library).  `.gif` files (the moving-gif data set) are decoded with
@@ -213,6 +215,15 @@ class DeviceFramesDataset:
             # (round 5) ratios below 0.8 run skimage's multi-tap anti-aliasing filter on the device (radius <= 4: ratio >= ~0.31)
             if min(ratio) < 0.32:
                 raise NotImplementedError("resize ratios below 0.32 need an anti-aliasing kernel wider than 9 taps (ratio %s)" % (ratio,))
+            # the per-axis scale is size / int(size * f), not 1 / f: for small frames it can exceed 1 / 0.32 although f >= 0.32
+            # (H = 30, f = 0.32: int(9.6) = 9 rows, scale 3.33, radius 5).  Refuse here, with the launch's own arithmetic, not
+            # from inside a training batch
+            for size in self.image_shape[:2]:
+                new = int(size * min(ratio))
+                worst = int(4.0 * max(0.0, (float(size) / max(new, 1) - 1.0) / 2.0) + 0.5)
+                if new < 1 or worst > 4:
+                    raise NotImplementedError("resize ratio %s of a %d-pixel axis gives %d pixels: an anti-aliasing kernel of radius %d "
+                                              "(the device kernel holds 4)" % (ratio, size, new, worst))
             self.resize = (float(ratio[0]), float(ratio[1]))
         if is_train and p.get("jitter_param") is not None:
             jp = dict(p["jitter_param"])

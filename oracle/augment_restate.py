@@ -4,12 +4,23 @@ tests/test_frames.py for csrc/frames.hip::frames_augment_kernel; nothing in monk
 The reference's RandomResize / RandomRotation / ColorJitter (augmentation.py:105-133,175-214,217-320) are thin wrappers around
 third-party functions that are NOT in this image and not vendored by the reference (requirements.txt pins scikit-image==0.14.0,
 Pillow==5.2.0, torchvision==0.2.1, numpy==1.15.0), so this file restates the published algorithms of exactly those versions,
-function by function, and says where each statement comes from.  **Parity unpinned for the skimage half** (resize / rotate /
-warp / img_as_ubyte / img_as_float): scikit-image is neither installed nor installable offline, so nothing checks those
-statements against the real package.  **The Pillow half is pinned (round 5)**: rgb2hsv_u8 / hsv2rgb_u8 equal the installed
-Pillow's (12.2.0) Image.convert on ALL 2^24 RGB and ALL 2^24 HSV triples, and adjust_hue reproduces a golden made with that
-Pillow under torchvision 0.2.1's five adjust_hue statements (oracle/make_golden_hue.py -> tests/golden/hue_pillow.npz,
-HUE_PILLOW_REPORT.txt; tests/test_frames.py::test_hue_*).  What is checked besides (tests/test_frames.py): the device kernel
+function by function, and says where each statement comes from.  **The skimage half (resize / rotate / warp) is pinned on
+INTERIOR pixels to scipy.ndimage since round 6**: scikit-image is neither installed nor installable offline, but
+scipy.ndimage.affine_transform(order = 0 / 1, mode='constant') -- with scipy.ndimage.gaussian_filter in front for the
+anti-aliased resize -- is an independent third-party implementation of the same arithmetic wherever every tap lies inside the
+source frame; rotate_bilinear / resize equal it there (order 1 to 1e-13 in float64, order 0 exactly), and the device kernel
+equals scipy directly on the same pixels (tests/test_frames.py::test_rotation_and_resize_*_scipy_ndimage_*).  What stays a
+restatement of skimage 0.14 with nothing to check it against: the BORDER rule (out-of-image taps read cval one by one; scipy's
+'constant' mode drops the whole sample), the clip of a warp's output to its input's value range, and img_as_ubyte /
+img_as_float.  **The Pillow half is pinned (round 5) -- to the INSTALLED Pillow (12.2.0), not to the 5.2.0 the reference
+pins**: rgb2hsv_u8 / hsv2rgb_u8 equal the installed Pillow's Image.convert on ALL 2^24 RGB and ALL 2^24 HSV triples, and
+adjust_hue reproduces a golden made with that Pillow under torchvision 0.2.1's five adjust_hue statements
+(oracle/make_golden_hue.py -> tests/golden/hue_pillow.npz, HUE_PILLOW_REPORT.txt; tests/test_frames.py::test_hue_*).  Two known
+differences between the installed and the pinned versions (no shipped config reaches them): Pillow >= 7.1 rounds the
+16-bit fixed-point luma of convert('L') (+0x8000) where 5.2.0 truncates -- rgb2l_u8 below and csrc/frames.hip::aug_luma follow
+the INSTALLED library, so the saturation / contrast terms can differ from the reference's pinned Pillow by one level --, and
+scipy 1.1.0 evaluated the gaussian kernel's exponent as (c * x) * x where the installed scipy and gaussian_kernel1d below use
+c * x ** 2 (one ulp in a weight).  What is checked besides (tests/test_frames.py): the device kernel
 reproduces this file, and the integer-exact parts of the pipeline around it reproduce the unmodified reference
 (tests/golden/frames_shapes.npz).
 

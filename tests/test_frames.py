@@ -6,6 +6,7 @@ Plus: three training iterations of config/shapes.yaml on those REAL frames (BASE
 loss history, and a checkpoint written in the reference's Logger.save_cpk layout (logger.py:43-66) restored into the
 drop-in modules and optimisers."""
 import copy
+import math
 import os
 import random
 import struct
@@ -204,6 +205,10 @@ def test_transforms_without_a_device_form_raise(shapes):
         # resize down to ratio 0.32 have device forms; below that the Gaussian needs more than nine taps)
         with pytest.raises(NotImplementedError):
             frames.DeviceFramesDataset(root, bad, device="cpu", files=names)
+    # the per-axis scale is size / int(size * f): a 30-pixel axis at f = 0.32 is 9 pixels, scale 3.33, radius 5 -- refused by the
+    # constructor, not by a training batch; the same ratio on the fixture's 64-pixel frames is fine
+    with pytest.raises(NotImplementedError, match="radius 5"):
+        frames.DeviceFramesDataset(root, {"resize_param": {"ratio": [0.32, 1.0]}}, image_shape=(30, 30, 3), device="cpu", files=names)
 
 
 AUG = {   # config/moving-gif.yaml:5-14 (at the 64x64 frames of the fixture), config/actions.yaml:5-16, and the order-1 resize
@@ -277,6 +282,124 @@ def test_anti_aliasing_restatement_equals_the_installed_scipy():
         fr, fc = rng.uniform(0.8, 3.2, size=2)
         want = ndi.gaussian_filter(img, (max(0.0, (fr - 1) / 2), max(0.0, (fc - 1) / 2), 0), cval=0, mode="constant")
         assert np.array_equal(ar.gaussian_aa(img, fr, fc), want), (trial, fr, fc)
+
+
+def _ndi_rotate(ndi, img, angle_deg, order=1):
+    """skimage.transform.rotate's map (centre (cols/2 - 0.5, rows/2 - 0.5), augmentation.py:175-214) evaluated by
+    scipy.ndimage.affine_transform -- a third-party implementation of the same interior arithmetic -- plus the mask of the
+    output pixels whose taps all lie inside the source frame (the border rule, skimage's per-tap cval, is NOT scipy's)"""
+    rows, cols = img.shape[:2]
+    cx, cy = cols / 2.0 - 0.5, rows / 2.0 - 0.5
+    a = math.radians(angle_deg)
+    co, si = math.cos(a), math.sin(a)
+    tx, ty = cx - co * cx + si * cy, cy - si * cx - co * cy
+    m = np.array([[co, si], [-si, co]])                  # (row, col) order: r_in = si * c + co * r + ty, c_in = co * c - si * r + tx
+    out = np.stack([ndi.affine_transform(img[..., ch], m, offset=(ty, tx), output_shape=(rows, cols), order=order,
+                                         mode="constant", cval=0.0, prefilter=False) for ch in range(img.shape[2])], axis=-1)
+    rr, cc = np.meshgrid(np.arange(rows, dtype=np.float64), np.arange(cols, dtype=np.float64), indexing="ij")
+    r_in, c_in = si * cc + co * rr + ty, co * cc - si * rr + tx
+    inside = (r_in >= 0) & (r_in <= rows - 1) & (c_in >= 0) & (c_in <= cols - 1)
+    return out, inside
+
+
+def _ndi_resize(ndi, img, new_rows, new_cols, order):
+    """skimage.transform.resize (augmentation.py:42-57,105-133) from scipy.ndimage alone: gaussian_filter (the anti-aliasing step)
+    + affine_transform for the sampling map  in = scale * (out + 0.5) - 0.5, and the interior mask as above"""
+    rows, cols = img.shape[:2]
+    rs, cs = float(rows) / new_rows, float(cols) / new_cols
+    # the anti-aliasing filter of skimage 0.14's resize by the real scipy (one tap -- the identity -- for ratios > 0.8)
+    img = ndi.gaussian_filter(img, (max(0.0, (rs - 1) / 2), max(0.0, (cs - 1) / 2), 0), cval=0, mode="constant")
+    out = np.stack([ndi.affine_transform(img[..., ch], np.diag([rs, cs]), offset=(rs / 2.0 - 0.5, cs / 2.0 - 0.5),
+                                         output_shape=(new_rows, new_cols), order=order, mode="constant", cval=0.0,
+                                         prefilter=False) for ch in range(img.shape[2])], axis=-1)
+    r_in = rs * np.arange(new_rows, dtype=np.float64) + (rs / 2.0 - 0.5)
+    c_in = cs * np.arange(new_cols, dtype=np.float64) + (cs / 2.0 - 0.5)
+    # scipy's 'constant' mode treats a COORDINATE outside [0, n - 1] as outside, even one that rounds to an edge pixel (order 0):
+    # those are border pixels here
+    ok_r, ok_c = (r_in >= 0) & (r_in <= rows - 1), (c_in >= 0) & (c_in <= cols - 1)
+    return out, ok_r[:, None] & ok_c[None, :]
+
+
+def test_rotation_and_resize_restatement_equals_scipy_ndimage_on_interior_pixels():
+    """The pin of the sampling half of RandomRotation / RandomResize (augmentation.py:42-57,105-133,175-214): skimage 0.14 is not
+    installable here, but scipy.ndimage.affine_transform(order = 0 / 1, mode='constant') is an INDEPENDENT implementation of the
+    same arithmetic wherever every tap lies inside the source frame.  oracle/augment_restate.py's rotate / resize must equal it
+    there: order 1 to 1e-13 (float64; scipy forms the blend from spline weights, skimage as two nested lerps), order 0 exactly.
+    What stays a restatement: the border rule (skimage reads cval per out-of-image tap; scipy's 'constant' mode does not) and
+    the clip to the input's value range -- a no-op for interior blends."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    from oracle import augment_restate as ar
+    rng = np.random.RandomState(11)
+    checked = {"rotate": 0, "resize1": 0, "resize0": 0}
+    for trial in range(16):
+        h, w = rng.randint(20, 70, size=2)
+        img = rng.rand(h, w, 3)
+        angle = rng.uniform(-40, 40)
+        want, inside = _ndi_rotate(ndi, img, angle)
+        got = ar.rotate_bilinear(img, angle)
+        assert inside.mean() > 0.5
+        assert np.abs(got - want)[inside].max() <= 1e-13, (trial, angle)
+        checked["rotate"] += int(inside.sum())
+        ratio = rng.uniform(0.4, 1.3)                   # below 0.8: the multi-tap anti-aliasing filter in front of the sampling
+        nh, nw = int(h * ratio), int(w * ratio)
+        for order in (1, 0):
+            want, inside = _ndi_resize(ndi, img, nh, nw, order)
+            got = ar.resize(img, nh, nw, order)
+            assert inside.mean() > 0.8
+            if order == 1:
+                assert np.abs(got - want)[inside].max() <= 1e-13, (trial, ratio)
+            else:
+                assert np.array_equal(got[inside], want[inside]), (trial, ratio)
+            checked["resize%d" % order] += int(inside.sum())
+    print("interior pixels pinned to scipy.ndimage:", checked)
+
+
+ROT_ONLY = {"rotation_param": {"degrees": 25}}
+RES_ONLY = {"nearest": {"crop_param": {"size": [64, 64]}, "resize_param": {"ratio": [0.85, 1.2]}},
+            "bilinear": {"crop_param": {"size": [64, 64]}, "resize_param": {"ratio": [0.85, 1.2], "interpolation": "bilinear"}}}
+
+
+@pytest.mark.parametrize("tag", ["rotation", "resize-nearest", "resize-bilinear"])
+def test_rotation_and_resize_kernel_equals_scipy_ndimage_on_interior_pixels(be, shapes, tag):
+    """the DEVICE kernel (mnk_frames_augment through DeviceFramesDataset) against scipy.ndimage directly -- no
+    oracle/augment_restate.py in between -- on the pixels whose taps lie inside the source frame; float32 outputs of float64
+    warps: two float32 ulps (a nearest-neighbour resize: exact)."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    from mnk import frames
+    fx, root, names = shapes
+    params = ROT_ONLY if tag == "rotation" else RES_ONLY[tag.split("-")[1]]
+    ds = frames.DeviceFramesDataset(root, params, image_shape=(64, 64, 3), is_train=True, device=be.device, files=names)
+    strips = [fx["strip%d" % i] for i in range(len(names))]
+    pinned = 0
+    for seed in (0, 1):
+        for idx in range(len(names)):
+            random.seed(50 * seed + idx), np.random.seed(50 * seed + idx)
+            item = ds[idx]
+            random.seed(50 * seed + idx), np.random.seed(50 * seed + idx)
+            sel, hflip, x1, y1, pt, pl, oh, ow, angle, new_hw, hue, jit = ds._draw(ds.meta[idx][3])
+            frames_u8 = np.moveaxis(strips[idx][:, :, :3].reshape(64, -1, 64, 3), 1, 0)
+            got = torch.cat([item["source"], item["video"]], dim=1).cpu().numpy()            # (C, D, h, w)
+            for d, f in enumerate(sel):
+                img = np.multiply(frames_u8[f], 1.0 / 255, dtype=np.float32).astype(np.float64)
+                if hflip:
+                    img = np.fliplr(img)
+                if tag == "rotation":
+                    want, inside = _ndi_rotate(ndi, img, angle)
+                else:
+                    want, inside = _ndi_resize(ndi, img, new_hw[0], new_hw[1], ds.resize_order)
+                    h, w = ds.crop                      # pad_clip(mode='edge') + crop (augmentation.py:33-39,138-171): padded pixels
+                    ih, iw = want.shape[:2]             # are copies of border pixels -- not pinned
+                    ph = (0, 0) if h < ih else ((h - ih) // 2, (h - ih + 1) // 2)
+                    pw = (0, 0) if w < iw else ((w - iw) // 2, (w - iw + 1) // 2)
+                    want = np.pad(want, (ph, pw, (0, 0)), mode="edge")[y1:y1 + h, x1:x1 + w]
+                    inside = np.pad(inside, (ph, pw), mode="constant", constant_values=False)[y1:y1 + h, x1:x1 + w]
+                mine = got[:, d].transpose(1, 2, 0).astype(np.float64)
+                assert mine.shape == want.shape, (mine.shape, want.shape)
+                diff = np.abs(mine - want.astype(np.float32).astype(np.float64))[inside]
+                assert inside.mean() > 0.4, (tag, inside.mean())
+                assert diff.max() <= (0.0 if tag == "resize-nearest" else 1.2e-7), (tag, idx, float(diff.max()))
+                pinned += int(inside.sum())
+    print("%s: %d interior pixels of the kernel's output equal scipy.ndimage" % (tag, pinned))
 
 
 def test_hue_restatement_equals_the_golden_of_the_real_pillow():
