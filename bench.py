@@ -53,7 +53,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PMC_ROUND = "r05"               # profiles/<round>_pmc_traffic_<config>_b<batch>.json: the PMC passes `roofline.traffic` is read from
+PMC_ROUND = "r06"               # profiles/<round>_pmc_traffic_<config>_b<batch>.json: the PMC passes `roofline.traffic` is read from
 
 
 def kernel_source_stamp():
@@ -89,6 +89,9 @@ def parse():
     ap.add_argument("--taichi-leg", type=int, default=1,
                     help="1 (default, one GPU): also time the taichi @ 64x64 batch-32 hot path (the stack BASELINE.json's 0.5-of-"
                          "roofline target is worded on) -> `extra.taichi_b32`; 0: skip")
+    ap.add_argument("--extra-legs", type=int, default=1,
+                    help="1 (default): also measure BASELINE configs[3]'s per-GPU share (vox 256x256, batch 8: extra.vox256_b8) and "
+                         "configs[4] (bair batch-512 inference: extra.bair_b512_infer) in the default run")
     ap.add_argument("--graph", type=int, default=-1,
                     help="1: replay the iteration as one captured hipGraph, 0: eager launches, -1: graph on 1 GPU")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -397,6 +400,134 @@ def taichi_b32_leg(lib, device, steps):
     except Exception as e:    # never lose the leg to the extra number
         out["full_iteration"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E ~8 TB/s (about 6.3 TB/s is reachable by a streaming kernel)
+
+# kernel-name prefixes of each HIP-event group (csrc/runtime.hip::kNames): how the rows of a PMC traffic file map onto the groups
+HBM_GROUPS = {
+    "bn_stats": ("colsum2_", "bn_final_finalize", "bn_finalize", "bn_small_fwd"),
+    "bn_act_apply": ("bn_act_fwd", "inorm_act_fwd"),
+    "bn_act_bwd": ("bn_act_bwd", "bn_small_bwd", "inorm_act_bwd"),
+    "softmax_kp": ("softmax_kp_", "kp_clip_var", "heatmap_argmax", "kp_pixel_index"),
+    "movement_embedding": ("movement_embedding_", "gaussian_sums"),
+    "motion_field": ("motion_field_",),
+    "deform": ("warp_levels_", "deform_"),
+    "conv1x1": ("gconv1x1_", "conv1x1_"),
+    "adam_pack": ("adam_multi", "adam_tick"),
+    "layout": ("ncdhw_to_nhwc", "nhwc_to_ncdhw", "copy_channels", "concat2_", "sumpool2x2", "resize_", "pair_l1_"),
+    "losses": ("l1_mean_", "gan_terms_", "vec_means_"),
+}
+
+
+def all_source_stamp():
+    """hash of EVERY kernel source: what a PMC file must have been measured on for the traffic of the non-GEMM kernels to be quoted"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "monkey-net_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "monkey-net_amd", "csrc", "*.h"))):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def roofline_hbm(kernels, pmc=None, adam_params=0):
+    """One record per HBM-bound kernel group of the iteration (north_star: "evidenced by rocprof HBM GB/s"): ALGORITHMIC bytes
+    per iteration -- what each launch declares to the library's recorder (SURVEY.md section 8d's per-unit figures: 4 C B/pixel
+    read + written by an apply pass, one read of the heat-map for the soft-argmax, 28 B per parameter for Adam ...; DESIGN.md
+    section 4) -- over the HIP-event kernel time of THIS run, against the 8 TB/s HBM3E peak; `traffic`: counter bytes per
+    iteration from the round's PMC file when it was measured on these very sources, else null."""
+    out = []
+    for name, prefixes in HBM_GROUPS.items():
+        g = kernels.get(name)
+        if not g or not g["ms_per_step"]:
+            continue
+        work = g["work_per_step"]
+        if name == "adam_pack" and adam_params:
+            work = 28.0 * adam_params          # read p, g, m, v; write p, m, v (the packs it also emits are an artefact of the GEMM layouts)
+        gbps = work / (g["ms_per_step"] * 1e-3) / 1e9
+        rec = {"kernel": name, "bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+               "frac": round(gbps / HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_step": int(work),
+               "launches_per_step": g["launches_per_step"], "ms_per_step": round(g["ms_per_step"], 4),
+               "avg_launch_us": round(g["avg_us"], 2), "traffic": None}
+        if pmc:
+            n = t = 0.0
+            for k, v in pmc.items():
+                if isinstance(v, dict) and k.startswith(prefixes):
+                    n += v["launches"]
+                    t += (2 * v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch"]) * v["launches"]
+            if n and pmc.get("_iterations"):
+                rec["traffic"] = int(t / pmc["_iterations"])
+                rec["traffic_frac_of_peak"] = round(t / pmc["_iterations"] / (g["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        out.append(rec)
+    return out
+
+
+def vox256_b8_leg(lib, device, steps):
+    """BASELINE configs[3] (vox 256x256, batch 64 over 8 GPUs) on ONE GPU's share: batch 8 at 256x256, the whole training
+    iteration as a hipGraph replay + the forward / data-gradient GEMMs' roofline from two eager iterations."""
+    from mnk import configs, engine, workload
+    cfg = configs.get("vox")
+    gen, disc, kpd = build_models(cfg, device)
+    src, drv = workload.synthetic_pair(8, 256, 256, seed=777)
+    x = {"source": src.to(device), "video": drv.to(device)}
+    out = {"workload": "vox model params @ 256x256, batch 8 (one GPU's share of BASELINE configs[3]), full train.py:110-136 iteration"}
+    step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=True)
+    for _ in range(3):
+        step.step(x)
+    torch.cuda.synchronize(device)
+    n = max(5, min(steps, 10))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step.step(x)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / n
+    out["full_iteration"] = {"ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(8 / dt, 1), "launch": "hipGraph replay"}
+    eager = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+    eager.step(x)
+    k = prof_collect(lib, lambda: eager.step(x), 2)
+    conv = k.get("conv3x3_igemm")
+    if conv:
+        ach = conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "conv3x3_igemm*: forward + data-gradient launches", "bound": "mfma", "achieved": round(ach, 2),
+                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "executed_frac": round(conv["executed_work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                           "launches": conv["launches_per_step"], "avg_launch_us": round(conv["avg_us"], 2)}
+    out["roofline_hbm"] = roofline_hbm(k, adam_params=sum(p.numel() for m in (gen, disc, kpd) for p in m.parameters()))
+    flops = workload.conv_flops_hot_path(cfg, 256, 256)
+    out["hot_path_conv_gflop_fwd_per_pair"] = round(flops["total"] / 1e9, 3)
+    return out
+
+
+def bair_b512_infer_leg(device, iters=8):
+    """BASELINE configs[4]: bair 64x64 reconstruction-mode inference at batch 512 (reconstruction.py:12-25,57-62 batched by
+    mnk.engine.Reconstructor): eager launches and the hipGraph-captured forward.  35 ms of long launches per batch: a replay buys
+    nothing here (the eager loop already keeps the GPU busy), so both are reported and `value` is the better one."""
+    from mnk import configs, engine, workload
+    cfg = configs.get("bair")
+    gen, _, kpd = build_models(cfg, device)
+    g = torch.Generator().manual_seed(5)
+    src = torch.rand(512, 3, 1, 64, 64, generator=g).to(device)
+    drv = torch.rand(512, 3, 1, 64, 64, generator=g).to(device)
+    res = {"workload": "bair eval forward (kp detector on source + driving, generator), batch 512 @ 64x64 (BASELINE configs[4])"}
+    for mode in ("eager", "graph"):
+        r = engine.Reconstructor(kpd, gen, use_graph=(mode == "graph"))
+        for _ in range(2):
+            out = r(src, drv)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = r(src, drv)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / iters
+        res[mode] = {"ms_per_batch": round(dt * 1e3, 3), "frames_per_s": round(512 / dt, 1),
+                     "finite": bool(torch.isfinite(out["video_prediction"]).all())}
+    best = max(("eager", "graph"), key=lambda m: res[m]["frames_per_s"])
+    res["value"], res["unit"], res["launch"] = res[best]["frames_per_s"], "frames/s", best
+    flops = workload.conv_flops_hot_path(cfg, 64, 64)["total"]
+    res["conv_tflops"] = round(flops * 512 / (res[best]["ms_per_batch"] * 1e-3) / 1e12, 1)
+    res["frac_of_fp32_mfma_peak"] = round(res["conv_tflops"] / FP32_MFMA_PEAK_TFLOPS, 4)
+    return res
 
 
 def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):
@@ -718,6 +849,14 @@ def main():
                         "gflop_per_step": round(work / 1e9, 1), "executed_gflop_per_step": round(issued / 1e9, 1),
                         "ms_per_step": round(ms, 3),
                         "launches_per_step": sum(g["launches_per_step"] for g in groups)}
+    hbm = None
+    if kernels:
+        pm_all = None
+        if os.path.exists(pmc_file) and args.size == 64:
+            pm_all = json.load(open(pmc_file))
+            if pm_all.get("_all_source_stamp") != all_source_stamp():
+                pm_all = None               # measured on other kernel sources: the counter bytes are not quoted
+        hbm = roofline_hbm(kernels, pm_all, adam_params=sum(p.numel() for m in (gen, disc, kpd) for p in m.parameters()))
     dropin = None
     if args.dropin and not dist_mode and rank == 0:
         try:
@@ -746,6 +885,15 @@ def main():
             except Exception as e:
                 extra["taichi_b32"] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
+        default_workload = args.config == "moving-gif" and args.batch == 32 and args.size == 64
+        if args.extra_legs and rank == 0 and default_workload:
+            for name, leg in (("vox256_b8", lambda: vox256_b8_leg(lib, device, args.steps)),
+                              ("bair_b512_infer", lambda: bair_b512_infer_leg(device))):
+                try:
+                    extra[name] = leg()
+                except Exception as e:   # never lose the bench line to an extra leg
+                    extra[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
     if world > 1 or force_dist:
         dist.barrier()
 
@@ -774,7 +922,7 @@ def main():
             "hot_path_only": None if hot_ms is None else hot_path_record(hot_ms, hot_launch, hot_kernels, flops["total"],
                                                                           args.batch),
             "extra": extra,
-            "roofline": roofline, "roofline_all_conv": roofline_all, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "roofline_all_conv": roofline_all, "roofline_hbm": hbm, "cpu_baseline": cpu, "kernels": kernels,
             "capture_failed": bool(capture_failed),
             "dropin": dropin,
         }

@@ -26,6 +26,9 @@ try:
     import bench
     d = json.load(open(sys.argv[1])); d["_measured_on"] = "commit " + sys.argv[2]
     d["_kernel_source_stamp"] = bench.kernel_source_stamp()      # bench.py quotes the file only on these kernel sources
+    d["_all_source_stamp"] = bench.all_source_stamp()            # ... and the non-GEMM kernels' traffic (roofline_hbm) only on these
+    # iterations the passes saw: the soft-argmax forward runs once per training iteration
+    d["_iterations"] = max([v["launches"] for k, v in d.items() if isinstance(v, dict) and k.startswith("softmax_kp_fwd")] or [0])
     json.dump(d, open(sys.argv[1], "w"), indent=1)
 except Exception as e:
     print("pmc stamp:", e); sys.exit(1)
