@@ -579,11 +579,22 @@ def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
     b = int(x["source"].shape[0])
+    from mnk import dropin, optim as moptim
+    runner = dropin.runner_for(gpar.module)
+    served = None if runner is None else dict(runner.stats)
+    how = "the wrapped modules called as they are (two discriminator passes), eager launches"
+    if served and served["graph_calls"]:
+        how = ("forward / loss.backward() / discriminator pass served from three captured hipGraphs behind whole-model autograd "
+               "Functions (mnk.dropin.TrainPairRunner; one discriminator forward per iteration)")
+        if not mnk_adam:
+            how += "; the stock optimisers stepped by mnk_adam_multi on their own state tensors (mnk.optim.AdoptedAdam): %s" % (
+                [getattr(moptim.adopted(o), "steps_taken", 0) for o in (opt_g, opt_d, opt_k)],)
     return {"value": round(b / dt, 2), "unit": "frames/s", "ms_per_step": round(dt * 1e3, 3),
             "finite": bool(all(float(v) == float(v) for v in last)),
-            "what": "the reference's own loop on the drop-in modules: train.py:78-153 statement sequence (3x torch.optim.Adam, "
-                    "host batches through DataParallelWithCallback(device_ids=[0]), two discriminator passes, host copies of "
-                    "the losses every iteration), eager launches -- tests/test_dropin_replay.py is its parity test"}
+            "runner": served,
+            "what": "the reference's own loop on the drop-in modules: train.py:78-153 statement sequence (3x %s, "
+                    "host batches through DataParallelWithCallback(device_ids=[0]), host copies of the losses every iteration); %s "
+                    "-- tests/test_dropin_replay.py is its parity test" % ("mnk.optim.MnkAdam" if mnk_adam else "torch.optim.Adam", how)}
 
 
 def frame_loop(cfg, size, device, frames=40):
@@ -863,8 +874,17 @@ def main():
             dropin = dropin_loop(cfg, x, device, max(5, min(args.steps, 20)), 3)
             m = dropin_loop(cfg, x, device, max(5, min(args.steps, 20)), 3, mnk_adam=True)
             dropin["with_mnk_adam"] = {"value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"], "finite": m["finite"],
+                                       "runner": m["runner"],
                                        "what": "the same loop with train.py:81-83's three torch.optim.Adam replaced by "
                                                "mnk.optim.MnkAdam (INTEGRATION.md section 1.5)"}
+            # the same loop with the runner and the optimiser adoption switched off: what rounds 4-5 reported as `dropin`
+            os.environ["MNK_DROPIN_GRAPH"], os.environ["MNK_ADOPT_ADAM"] = "0", "0"
+            try:
+                e = dropin_loop(cfg, x, device, max(5, min(args.steps, 20)), 3)
+                dropin["modules_as_they_are"] = {"value": e["value"], "unit": e["unit"], "ms_per_step": e["ms_per_step"],
+                                                 "finite": e["finite"], "what": "MNK_DROPIN_GRAPH=0 MNK_ADOPT_ADAM=0: " + e["what"]}
+            finally:
+                os.environ.pop("MNK_DROPIN_GRAPH", None), os.environ.pop("MNK_ADOPT_ADAM", None)
         except Exception as e:   # never lose the bench line to the extra measurement
             dropin = {"error": "%s: %s" % (type(e).__name__, e)}
         if isinstance(dropin, dict) and "error" not in dropin:

@@ -27,6 +27,12 @@ KNOBS = {
     "MNK_TUNING": ("", "name=value,... for the library's tuning values (read by the library itself; A/B visits)"),
     "MNK_CLIP_VARIANCE_MODE": ("stable", "sigma_min of clip_variance: stable = |det| / sigma_max (finite on nearly singular "
                                          "covariances); reference = the reference's own fp32 sqrt((s1 - s2) / 2), NaNs included"),
+    "MNK_DROPIN_GRAPH": ("1", "DataParallelWithCallback around the reference's GeneratorFullModel / DiscriminatorFullModel "
+                              "(train.py:104-105): serve `out = generator_full_par(x)`, `loss.backward()` and the discriminator pass "
+                              "from three captured hipGraphs behind whole-model autograd Functions (mnk.dropin); phases: the same "
+                              "three phases as eager launches; 0: call the wrapped module as it is"),
+    "MNK_ADOPT_ADAM": ("1", "a stock torch.optim.Adam over a network whose gradients the drop-in runner keeps in one flat buffer is "
+                            "stepped by mnk_adam_multi on the optimiser's own state tensors (mnk.optim.AdoptedAdam); 0: the stock step"),
     "MNK_GRAD_OVERLAP": ("1", "MnkAdam: the generator-side gradient exchange runs next to the discriminator backward when there is "
                               "more than one rank (force: also on one rank); GradAverager: a bucket's all-reduce starts when its "
                               "last gradient is written; 0: in-order exchanges"),

@@ -268,19 +268,19 @@ class DeferredReducer:
         self.done.clear()
 
 
-class MnkAdam(torch.optim.Optimizer):
-    """torch.optim.Adam(params, lr, betas, eps) semantics (no amsgrad / weight decay), one kernel launch per step."""
+class FlatGrads:
+    """The gradient side of a parameter set without an optimiser attached: one flat fp32 buffer with a 16-byte aligned slice
+    ("sink") per parameter, the DeferredReducer that lands the convolution weight gradients there, and `materialize_grads()`,
+    after which every `p.grad` IS its slice.  MnkAdam is this plus the update; mnk.dropin.TrainPairRunner owns one per network
+    when the loop's optimisers are stock torch.optim objects (the reference's train.py:81-83)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super(MnkAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        if len(self.param_groups) != 1:
-            raise ValueError("MnkAdam takes one parameter group (train.py:81-83 builds one optimiser per network)")
-        ps = [p for p in self.param_groups[0]["params"] if p.requires_grad]
+    def _init_sinks(self, ps):
+        ps = [p for p in ps if p.requires_grad]
         if not ps:
             raise ValueError("no trainable parameters")
         dev = ps[0].device
         if any(p.device != dev or p.dtype != torch.float32 for p in ps):
-            raise ValueError("MnkAdam needs fp32 parameters on one device")
+            raise ValueError("fp32 parameters on one device are needed")
         mops._check_device(ps[0])
         self._params = ps
         self.device = dev
@@ -290,34 +290,18 @@ class MnkAdam(torch.optim.Optimizer):
             off += (p.numel() + 3) // 4 * 4                  # 16-byte aligned slices: float4 path of the kernel
         self.numel = off
         self.flat_grad = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
         self._sinks = {id(p): self.flat_grad[self._off[id(p)]:self._off[id(p)] + p.numel()].view_as(p) for p in ps}
-        g = self.param_groups[0]
-        b1, b2 = g["betas"]
-        self.hyper = torch.tensor([g["lr"], b1, b2, g["eps"], 0.0, 0.0, 1.0, 0.0, 1.0 - b1, 1.0 - b2],
-                                  dtype=torch.float64).float().to(dev)
-        self._lr_on_device = float(g["lr"])
-        self._gscale_on_device = 1.0
-        self.steps_taken = 0
         self.reducer = DeferredReducer(self)
         self._written = set()            # ids of parameters whose sink was written by a kernel since zero_grad
-        self._mnk_owns_exchange = True   # mnk.dist's generic pre-step gradient averaging skips this optimiser
-        self._table = None               # (key, device table, n, blocks, entries)
-        self._keep = []
-        self._mnk_fresh_entries = ()
-        self._exchange = None            # a gradient exchange started by begin_exchange(), finished by step()
         # True: the step kernel takes the gradients of the few-split tap-major layers (the deep levels: 330 of the generator's
         # 690 MB of partials ARE the gradient) straight from the partials, and mnk_wgrad_reduce_multi skips them -- `p.grad` of
         # those parameters is then NOT valid.  mnk.engine.TrainStep switches it on for a captured iteration of one process
         # (nobody can look at p.grad between the launches of a replay; several ranks exchange the flat buffer)
         self.tap_direct = False
-        self._exchanged = False          # ... or already finished by exchange_end(): step() must not sum again
         for p in ps:
             mops.register_grad_sink(p, self)
         weakref.finalize(self, mops.unregister_grad_sinks, [id(p) for p in ps], id(self))
 
-    # ---- gradient sinks ----------------------------------------------------------------------------------------------
     def sink(self, p):
         return self._sinks[id(p)]
 
@@ -330,7 +314,7 @@ class MnkAdam(torch.optim.Optimizer):
         self._written.add(id(p))
 
     def materialize_grads(self):
-        """After backward: every gradient of this optimiser's parameters in its slice of the flat buffer, `p.grad`
+        """After backward: every gradient of this set's parameters in its slice of the flat buffer, `p.grad`
         pointing at it.  Idempotent (a second call finds nothing pending and every p.grad already in place)."""
         self.reducer.flush()
         dsts, srcs = [], []
@@ -352,6 +336,46 @@ class MnkAdam(torch.optim.Optimizer):
             p.grad = s
         if dsts:
             torch._foreach_copy_(dsts, srcs)
+
+    def begin_pass(self):
+        """a new backward pass will write the sinks: forget what the last one recorded (what zero_grad() of an owning optimiser does,
+        without touching p.grad -- a stock optimiser's zero_grad() has already set it to None)"""
+        self.reducer.drop()
+        self._written.clear()
+
+
+class GradSinks(FlatGrads):
+    """FlatGrads of a network whose optimiser is not ours (see FlatGrads)."""
+
+    def __init__(self, params):
+        self._init_sinks(list(params))
+        self._mnk_owns_exchange = False
+
+
+class MnkAdam(torch.optim.Optimizer, FlatGrads):
+    """torch.optim.Adam(params, lr, betas, eps) semantics (no amsgrad / weight decay), one kernel launch per step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super(MnkAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        if len(self.param_groups) != 1:
+            raise ValueError("MnkAdam takes one parameter group (train.py:81-83 builds one optimiser per network)")
+        self._init_sinks(self.param_groups[0]["params"])
+        ps, dev, off = self._params, self.device, self.numel
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        g = self.param_groups[0]
+        b1, b2 = g["betas"]
+        self.hyper = torch.tensor([g["lr"], b1, b2, g["eps"], 0.0, 0.0, 1.0, 0.0, 1.0 - b1, 1.0 - b2],
+                                  dtype=torch.float64).float().to(dev)
+        self._lr_on_device = float(g["lr"])
+        self._gscale_on_device = 1.0
+        self.steps_taken = 0
+        self._mnk_owns_exchange = True   # mnk.dist's generic pre-step gradient averaging skips this optimiser
+        self._table = None               # (key, device table, n, blocks, entries)
+        self._keep = []
+        self._mnk_fresh_entries = ()
+        self._exchange = None            # a gradient exchange started by begin_exchange(), finished by step()
+        self._exchanged = False          # ... or already finished by exchange_end(): step() must not sum again
 
     def zero_grad(self, set_to_none=True):
         if self._exchange is not None:       # (never in TrainStep: an exchange is always consumed by the step)
@@ -501,3 +525,169 @@ class MnkAdam(torch.optim.Optimizer):
         self.hyper.copy_(torch.tensor([g["lr"], b1, b2, g["eps"], 0.0, 0.0, self._gscale_on_device, step, 1.0 - b1,
                                        1.0 - b2], dtype=torch.float64).float())
         self._lr_on_device = float(g["lr"])
+
+
+# ---- a stock torch.optim.Adam stepped by the library's kernel (round 6) ------------------------------------------------------
+# The reference's train.py builds three torch.optim.Adam objects (train.py:81-83).  On the drop-in path
+# (sync_batchnorm.DataParallelWithCallback -> mnk.dropin.TrainPairRunner) the gradients of a network live in ONE flat buffer
+# (GradSinks), and a stock optimiser's step would walk it with ~10 multi-tensor passes (7.8 GB of traffic for the 81 M parameters
+# of BASELINE configs[1]: 1.5 ms of a 10 ms iteration) and leave the GEMM layouts of the weights stale (one more pack launch that
+# reads every weight again).  A global pre-step hook therefore performs the update of such an optimiser with mnk_adam_multi ON
+# THE OPTIMISER'S OWN STATE TENSORS -- exp_avg / exp_avg_sq / step exactly where torch.optim.Adam keeps them, so state_dict(),
+# load_state_dict() and lr schedulers see nothing unusual -- and hands the stepped parameters' gradients back after the
+# (then empty) step.  Only the plain configuration is taken over (one group, no amsgrad / weight decay / maximize /
+# capturable / differentiable / fused); anything else steps the stock way.  MNK_ADOPT_ADAM=0 switches it off.
+_ADOPT = {"installed": False, "by_opt": weakref.WeakKeyDictionary()}
+
+
+class AdoptedAdam:
+    def __init__(self, opt, owner):
+        self.opt = weakref.ref(opt)
+        self.owner = weakref.ref(owner)
+        g = opt.param_groups[0]
+        b1, b2 = g["betas"]
+        self.device = owner.device
+        self.hyper = torch.tensor([g["lr"], b1, b2, g["eps"], 0.0, 0.0, 1.0, 0.0, 1.0 - b1, 1.0 - b2],
+                                  dtype=torch.float64).float().to(self.device)
+        self._host = (float(g["lr"]), float(b1), float(b2), float(g["eps"]))
+        self._step = 0.0                 # the step count the device scalars hold
+        self._table = None
+        self._keep = []
+        self._stash = None
+        self.steps_taken = 0
+
+    @staticmethod
+    def eligible(opt):
+        """the FlatGrads that owns exactly this optimiser's parameters, or None"""
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return None
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("weight_decay", 0) != 0 or g.get("maximize") or g.get("capturable") or \
+                g.get("differentiable") or g.get("fused") or g.get("decoupled_weight_decay"):
+            return None
+        if not isinstance(g["lr"], float) or any(not isinstance(b, float) for b in g["betas"]):
+            return None              # tensor hyper-parameters: the stock path
+        ps = [p for p in g["params"] if p.requires_grad]
+        owners = {id(mops.sink_owner(p)) for p in ps}
+        if len(owners) != 1 or not ps:
+            return None
+        owner = mops.sink_owner(ps[0])
+        if not isinstance(owner, GradSinks) or {id(p) for p in ps} != {id(p) for p in owner._params}:
+            return None
+        return owner
+
+    def _sync(self, opt, active):
+        """device scalars <- the optimiser's hyper-parameters and step count (a scheduler's new lr, a loaded checkpoint)"""
+        g = opt.param_groups[0]
+        host = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+        step = float(opt.state[active[0]]["step"])
+        if host == self._host and step == self._step:
+            return True
+        if step != self._step and any(float(opt.state[p]["step"]) != step for p in active):
+            return False             # parameters at different step counts: one bias correction cannot serve them
+        if host[1:] != self._host[1:] or step != self._step:
+            self.hyper.copy_(torch.tensor([host[0], host[1], host[2], host[3], 0.0, 0.0, 1.0, step, 1.0 - host[1], 1.0 - host[2]],
+                                          dtype=torch.float64).float())
+        else:
+            self.hyper[0:1].copy_(torch.tensor([host[0]], dtype=torch.float32))
+        self._host, self._step = host, step
+        return True
+
+    @torch.no_grad()
+    def pre_step(self):
+        opt, owner = self.opt(), self.owner()
+        if opt is None or owner is None or _capturing(self.device):
+            return False
+        active = [p for p in opt.param_groups[0]["params"] if p.grad is not None]
+        if not active:
+            return False
+        if any(p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.device != p.device for p in active):
+            return False
+        for p in active:                 # torch.optim.Adam._init_group's lazy state, where it keeps it
+            st = opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.get_default_dtype())
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif not (torch.is_tensor(st.get("step")) and st["step"].device.type == "cpu" and st["exp_avg"].is_contiguous()
+                      and st["exp_avg_sq"].is_contiguous() and st["exp_avg"].dtype == torch.float32):
+                return False
+        if not self._sync(opt, active):
+            return False
+        key = (tuple((p.data_ptr(), p.grad.data_ptr(), opt.state[p]["exp_avg"].data_ptr(), opt.state[p]["exp_avg_sq"].data_ptr())
+                     for p in active), mops.pack_registry_version())
+        if self._table is None or self._table[0] != key:
+            rows, blocks, entries = [], 0, []
+            for p in active:
+                st = opt.state[p]
+                e = mops.pack_entry_of(p)
+                if e is not None:
+                    cout, c0, c1, up = e.meta
+                    nb = _lib.lib().query("mnk_adam_blocks", 0, cout, c0, c1, 1)
+                    rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                 e.wp.data_ptr(), e.wd[0].data_ptr() if e.wd[0] is not None else 0,
+                                 e.wd[1].data_ptr() if e.wd[1] is not None else 0, cout, c0, c1, blocks, int(up), 0, 0, 0, 0, 0))
+                    entries.append(e)
+                else:
+                    nb = _lib.lib().query("mnk_adam_blocks", p.numel(), 0, 0, 0, 0)
+                    rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(),
+                                 0, 0, 0, 0, 0, 0, blocks, 0, 0, 0, 0, 0, 0))
+                blocks += nb
+            self._keep = []              # (nothing captures these tables: the previous one may go)
+            tab = _device_table(np.array(rows, dtype=ADAM_DESC), self.device, self._keep)
+            self._table = (key, tab, len(rows), blocks, tuple(entries))
+        _, tab, n, blocks, entries = self._table
+        mops._call("mnk_adam_tick", self.hyper, mops._p(self.hyper))
+        mops._call("mnk_adam_multi", self.hyper, mops._p(tab), n, blocks, mops._p(self.hyper))
+        torch._foreach_add_([opt.state[p]["step"] for p in active], 1.0)
+        self._step += 1.0
+        self.steps_taken += 1
+        opt._mnk_fresh_entries = entries         # stamped fresh by the global post-step hook of mnk.ops
+        # the stock step that follows must find nothing to do; post_step() hands the gradients back
+        self._stash = [(p, p.grad) for p in active]
+        for p in active:
+            p.grad = None
+        return True
+
+    def post_step(self):
+        if self._stash is not None:
+            for p, g in self._stash:
+                if p.grad is None:
+                    p.grad = g
+            self._stash = None
+
+
+def install_adam_adoption():
+    if _ADOPT["installed"]:
+        return False
+    from torch.optim.optimizer import register_optimizer_step_pre_hook, register_optimizer_step_post_hook
+
+    def pre_step(opt, args, kwargs):
+        # (args = (optimiser, closure?): a step with a closure is the stock step's business)
+        if type(opt) is not torch.optim.Adam or not mops.knobs.on("MNK_ADOPT_ADAM") or (len(args) > 1 and args[1] is not None) \
+                or kwargs.get("closure") is not None:
+            return
+        ad = _ADOPT["by_opt"].get(opt)
+        # (a refusal is remembered together with the size of the sink registry: a runner created later asks again)
+        if ad is None or (isinstance(ad, int) and ad != len(mops._SINKS)) or (isinstance(ad, AdoptedAdam) and ad.owner() is None):
+            owner = AdoptedAdam.eligible(opt)
+            ad = AdoptedAdam(opt, owner) if owner is not None else len(mops._SINKS)
+            _ADOPT["by_opt"][opt] = ad
+        if isinstance(ad, AdoptedAdam):
+            ad.pre_step()
+
+    def post_step(opt, args, kwargs):
+        ad = _ADOPT["by_opt"].get(opt)
+        if isinstance(ad, AdoptedAdam):
+            ad.post_step()
+
+    register_optimizer_step_pre_hook(pre_step)
+    register_optimizer_step_post_hook(post_step)
+    _ADOPT["installed"] = True
+    return True
+
+
+def adopted(opt):
+    """the AdoptedAdam of a stock optimiser (tests, bench.py), or None"""
+    ad = _ADOPT["by_opt"].get(opt)
+    return ad if isinstance(ad, AdoptedAdam) else None

@@ -130,3 +130,134 @@ def test_train_py_caller_sequence_replayed_on_the_drop_in_modules(be, tmp_path, 
         b = generator(xs, kp_driving=kp_detector(xd), kp_source=kp_detector(xs))['video_prediction']
     be.sync()
     assert torch.equal(a.cpu(), b.cpu())
+
+
+# ---- round 6: the loop above served by mnk.dropin.TrainPairRunner (hipGraphs on the MI355X, the same three phases as eager
+# launches on the CPU emulator) -------------------------------------------------------------------------------------------------
+def _reference_loop(be, adam, iterations, gold, batches=None):
+    """train.py:81-136 on the drop-in modules for `iterations` batches; returns (history, networks, optimisers, wrappers)"""
+    from mnk.engine import GeneratorFullModel, DiscriminatorFullModel
+    from mnk.optim import MnkAdam
+    from sync_batchnorm import DataParallelWithCallback
+    Adam = torch.optim.Adam if adam == "torch" else MnkAdam
+    config = copy.deepcopy(gold["cfg"])
+    tp = config["train_params"]
+    generator, discriminator, kp_detector = build(config)
+    generator.load_state_dict(gold["state"]["generator"])
+    discriminator.load_state_dict(gold["state"]["discriminator"])
+    kp_detector.load_state_dict(gold["state"]["kp_detector"])
+    for m in (generator, discriminator, kp_detector):
+        m.to(be.device)
+    og = Adam(generator.parameters(), lr=tp['lr'], betas=(0.5, 0.999))
+    od = Adam(discriminator.parameters(), lr=tp['lr'], betas=(0.5, 0.999))
+    ok = Adam(kp_detector.parameters(), lr=tp['lr'], betas=(0.5, 0.999))
+    gpar = DataParallelWithCallback(GeneratorFullModel(kp_detector, generator, discriminator, tp), device_ids=[0] if be.kind == "hip" else None)
+    dpar = DataParallelWithCallback(DiscriminatorFullModel(kp_detector, generator, discriminator, tp), device_ids=[0] if be.kind == "hip" else None)
+    src, drv = cases.smooth_pair(gold["batch"], gold["size"], gold["size"])
+    history = []
+    for it in range(iterations):
+        x = {"source": src.clone(), "video": drv.clone()} if batches is None else batches[it]
+        out = gpar(x)
+        loss_values = [val.mean() for val in out[:-2]]
+        generated, kp_joined = out[-2], out[-1]
+        sum(loss_values).backward(retain_graph=not tp['detach_kp_discriminator'])
+        og.step(), og.zero_grad(), od.zero_grad()
+        if tp['detach_kp_discriminator']:
+            ok.step(), ok.zero_grad()
+        g_host = [float(val.detach().cpu()) for val in loss_values]
+        loss_values = [val.mean() for val in dpar(x, kp_joined, generated)]
+        sum(loss_values).backward()
+        od.step(), od.zero_grad()
+        if not tp['detach_kp_discriminator']:
+            ok.step(), ok.zero_grad()
+        history.append(g_host + [float(val.detach().cpu()) for val in loss_values])
+    be.sync()
+    return history, (generator, discriminator, kp_detector), (og, od, ok), (gpar, dpar)
+
+
+@pytest.mark.parametrize("adam", ["torch", "mnk"])
+def test_the_loop_is_served_by_the_dropin_runner_and_equals_the_modules_run_as_they_are(be, monkeypatch, adam):
+    """The same loop twice: through mnk.dropin.TrainPairRunner (default: three captured hipGraphs on the MI355X, the same three
+    phases as eager launches on the emulator; stock optimisers stepped by mnk.optim.AdoptedAdam) and with MNK_DROPIN_GRAPH=0 (the
+    wrapped modules called as they are, two discriminator passes, the stock optimiser steps).  Same loss history and parameters
+    to fp32 summation-order level; every call of the loop was served (no fall-back); the stock optimisers' state_dict()s agree."""
+    from mnk import dropin, optim as moptim
+    gold = load("step_tiny")
+    monkeypatch.setenv("MNK_DROPIN_GRAPH", "0")
+    h0, nets0, opts0, _ = _reference_loop(be, adam, 3, gold)
+    monkeypatch.delenv("MNK_DROPIN_GRAPH")
+    h1, nets1, opts1, (gpar, dpar) = _reference_loop(be, adam, 3, gold)
+    runner = dropin.runner_for(gpar.module)
+    assert runner is not None and runner is dropin.runner_for(dpar.module)
+    served = runner.stats["graph_calls"] if be.kind == "hip" else runner.stats["phase_calls"]
+    assert served == 3 and runner.stats["fallbacks"] == 0 and runner.stats["d_fallbacks"] == 0, runner.stats
+    if be.kind == "hip":
+        assert runner.stats["captures"] == 1
+    for it, (a, b) in enumerate(zip(h1, h0)):
+        for va, vb in zip(a, b):
+            assert abs(va - vb) <= 2e-4 * max(1.0, abs(vb)), (it, a, b)
+    # Adam's first updates are sign-like: an element whose gradient is ~eps (the bias in front of a training-mode BatchNorm: an
+    # analytically zero gradient, i.e. rounding noise) moves by lr either way in every step.  Per network: the mean over ALL its
+    # elements stays a fraction of lr, and no element is further apart than the 2 x 3 steps allow
+    lr = gold["cfg"]["train_params"]["lr"]
+    for m1, m0 in zip(nets1, nets0):
+        tot = cnt = 0.0
+        for (n1, p1), (_, p0) in zip(m1.named_parameters(), m0.named_parameters()):
+            d = (p1.detach().cpu() - p0.detach().cpu()).abs()
+            tot, cnt = tot + float(d.sum()), cnt + d.numel()
+            assert float(d.max()) <= 6.5 * lr, (n1, float(d.max()))
+        assert tot / cnt <= 0.25 * lr, (type(m1).__name__, tot / cnt)
+    if adam == "torch":
+        for o1, o0 in zip(opts1, opts0):
+            ad = moptim.adopted(o1)
+            assert ad is not None and ad.steps_taken == 3 and moptim.adopted(o0) is None
+            s1, s0 = o1.state_dict(), o0.state_dict()
+            assert s1["param_groups"] == s0["param_groups"] and set(s1["state"]) == set(s0["state"])
+            for k in s1["state"]:
+                assert float(s1["state"][k]["step"]) == float(s0["state"][k]["step"]) == 3.0
+                assert s1["state"][k]["exp_avg"].shape == s0["state"][k]["exp_avg"].shape
+
+
+def test_the_dropin_runner_falls_back_on_what_it_does_not_serve(be, monkeypatch):
+    """gradients that were not zeroed, evaluation mode, a discriminator call on tensors that are not this iteration's outputs: the
+    wrapped modules run as they are (same values as MNK_DROPIN_GRAPH=0)"""
+    from mnk import dropin
+    gold = load("step_tiny")
+    _, nets, opts, (gpar, dpar) = _reference_loop(be, "torch", 1, gold)
+    runner = dropin.runner_for(gpar.module)
+    src, drv = cases.smooth_pair(gold["batch"], gold["size"], gold["size"])
+    x = {"source": src, "video": drv}
+    before = dict(runner.stats)
+    # 1. a stale gradient on one parameter
+    p = next(nets[0].parameters())
+    p.grad = torch.zeros_like(p)
+    out = gpar(x)
+    assert runner.stats["fallbacks"] == before["fallbacks"] + 1 and out[0].grad_fn is not None
+    p.grad = None
+    # 2. the discriminator pass on other tensors than this iteration's
+    out = gpar(x)
+    other = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out[-2].items()}
+    d = dpar(x, out[-1], other)
+    assert runner.stats["d_fallbacks"] == before["d_fallbacks"] + 1 and d[0].grad_fn is not None
+    d2 = dpar(x, out[-1], out[-2])
+    assert runner.stats["d_fallbacks"] == before["d_fallbacks"] + 1
+    be.sync()
+    assert abs(float(d[0].mean()) - float(d2[0].mean())) <= 1e-5 * max(1.0, abs(float(d2[0].mean())))
+    # 3. evaluation mode: the module itself
+    for m in nets:
+        m.eval()
+    gpar.eval()
+    n = runner.stats["fallbacks"]
+    with torch.no_grad():
+        gpar(x)
+    assert runner.stats["fallbacks"] in (n, n + 1)      # (an eval wrapper does not even ask the runner)
+    # 4. a backward pass through an earlier call's outputs is refused, not served wrongly
+    for m in nets:
+        m.train()
+    gpar.train()
+    for o in opts:
+        o.zero_grad()
+    first = gpar(x)
+    gpar(x)
+    with pytest.raises(RuntimeError, match="earlier"):
+        sum(v.mean() for v in first[:-2]).backward()
