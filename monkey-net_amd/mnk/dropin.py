@@ -427,3 +427,121 @@ def runner_for(module):
     _RUNNERS[key] = r
     weakref.finalize(gen, _RUNNERS.pop, key, None)      # (the runner holds the networks weakly: this fires)
     return r
+
+
+# ---- the reference's per-frame evaluation loops (reconstruction.py:45-62, transfer.py:65-79, demo.py) ------------------------------
+class EvalRunner:
+    """`DataParallelWithCallback(generator)` / `(kp_detector)` in evaluation mode under no_grad (reconstruction.py:45-49): the
+    wrapped network's forward captured ONCE per input signature as a hipGraph with frozen weights -- the packed GEMM layouts and
+    the evaluation-mode norm coefficients are made before the capture and only referenced by it (a captured forward of
+    mnk.engine.Reconstructor re-packs inside the graph: right for a batch of 512, most of the launches at batch 1) -- and replayed
+    per call: inputs are copied into static buffers, outputs are returned as fresh tensors (the loop keeps `kp_source` across
+    calls).  Re-captured when a parameter, a buffer or the optimiser epoch changed (load_state_dict between two videos)."""
+
+    MAX_PROGRAMS = 8
+
+    def __init__(self, module):
+        self._module = weakref.ref(module)
+        self.programs = {}
+        self.stats = {"replays": 0, "captures": 0}
+
+    @staticmethod
+    def _flatten(obj, out, path=()):
+        if torch.is_tensor(obj):
+            out.append((path, obj))
+            return ("T", tuple(obj.shape), obj.dtype)
+        if isinstance(obj, dict):
+            return ("D",) + tuple((k, EvalRunner._flatten(obj[k], out, path + (k,))) for k in sorted(obj, key=str))
+        if isinstance(obj, (list, tuple)):
+            return ("L", type(obj).__name__) + tuple(EvalRunner._flatten(v, out, path + (i,)) for i, v in enumerate(obj))
+        return ("V", repr(obj))
+
+    @staticmethod
+    def _rebuild(obj, leaves, path=()):
+        if torch.is_tensor(obj):
+            return leaves[path]
+        if isinstance(obj, dict):
+            return {k: EvalRunner._rebuild(v, leaves, path + (k,)) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(EvalRunner._rebuild(v, leaves, path + (i,)) for i, v in enumerate(obj))
+        return obj
+
+    def _fingerprint(self, module):
+        return (mops._PACK_EPOCH[0], mops._BN_EVAL_EPOCH[0], tuple(p._version for p in module.parameters()),
+                tuple(b._version for b in module.buffers()))
+
+    def __call__(self, inputs, kwargs, device):
+        module = self._module()
+        flat = []
+        key = self._flatten((inputs, kwargs), flat)
+        if not flat or any(t.dtype != torch.float32 for _, t in flat):
+            return NotImplemented
+        fp = self._fingerprint(module)
+        prog = self.programs.get(key)
+        if prog is None or prog["fp"] != fp:
+            if len(self.programs) >= self.MAX_PROGRAMS:
+                self.programs.clear()
+            prog = self.programs[key] = self._capture(module, inputs, kwargs, flat, device, fp)
+        for (path, t), s in zip(flat, prog["static"]):
+            s.copy_(t, non_blocking=True)
+        prog["graph"].replay()
+        self.stats["replays"] += 1
+        return _walk_clone(prog["out"])
+
+    def _capture(self, module, inputs, kwargs, flat, device, fp):
+        static = [t.to(device).clone() for _, t in flat]
+        leaves = {path: s for (path, _), s in zip(flat, static)}
+        s_in, s_kw = self._rebuild((inputs, kwargs), leaves)
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):         # the caches are keyed by stream: fill them on the stream the capture runs on
+            for _ in range(2):
+                module(*s_in, **s_kw)
+        torch.cuda.current_stream().wait_stream(cap)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        mops.FROZEN_CAPTURE[0] = True
+        try:
+            with torch.cuda.graph(graph, stream=cap):
+                out = module(*s_in, **s_kw)
+        finally:
+            mops.FROZEN_CAPTURE[0] = False
+        self.stats["captures"] += 1
+        return {"graph": graph, "static": static, "out": out, "fp": fp}
+
+
+def _walk_clone(obj):
+    if torch.is_tensor(obj):
+        return obj.clone()
+    if isinstance(obj, dict):
+        return {k: _walk_clone(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_walk_clone(v) for v in obj)
+    return obj
+
+
+def eval_runner_for(wrapper):
+    """the EvalRunner of an evaluation-mode wrapper around a KPDetector / MotionTransferGenerator on the device, or None"""
+    if not knobs.on("MNK_EVAL_GRAPH") or torch.is_grad_enabled() or mdist.initialized():
+        return None
+    module = wrapper.module
+    r = wrapper.__dict__.get("_mnk_eval_runner")
+    if r is not None:
+        return r if r._module() is module else None
+    from modules.generator import MotionTransferGenerator
+    from modules.keypoint_detector import KPDetector
+    if not isinstance(module, (MotionTransferGenerator, KPDetector)):
+        return None
+    try:
+        if next(module.parameters()).device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return None
+    except StopIteration:
+        return None
+    r = EvalRunner(module)
+    object.__setattr__(wrapper, "_mnk_eval_runner", r)
+    return r
+
+
+def eval_runner_for_wrapper(wrapper):
+    """the EvalRunner a wrapper has made (tests, bench.py), or None"""
+    return wrapper.__dict__.get("_mnk_eval_runner")

@@ -31,6 +31,9 @@ KNOBS = {
                               "(train.py:104-105): serve `out = generator_full_par(x)`, `loss.backward()` and the discriminator pass "
                               "from three captured hipGraphs behind whole-model autograd Functions (mnk.dropin); phases: the same "
                               "three phases as eager launches; 0: call the wrapped module as it is"),
+    "MNK_EVAL_GRAPH": ("1", "DataParallelWithCallback around a KPDetector / MotionTransferGenerator in evaluation mode under no_grad "
+                            "(reconstruction.py:45-62's per-frame loop): the forward is captured once per input signature as a "
+                            "hipGraph with frozen weights and replayed (mnk.dropin.EvalRunner); 0: eager launches"),
     "MNK_ADOPT_ADAM": ("1", "a stock torch.optim.Adam over a network whose gradients the drop-in runner keeps in one flat buffer is "
                             "stepped by mnk_adam_multi on the optimiser's own state tensors (mnk.optim.AdoptedAdam); 0: the stock step"),
     "MNK_GRAD_OVERLAP": ("1", "MnkAdam: the generator-side gradient exchange runs next to the discriminator backward when there is "

@@ -346,6 +346,12 @@ def subpixel(ups):
     return bool(v.value)
 
 
+# mnk.dropin.EvalRunner captures an evaluation forward with FROZEN weights: the cached packed weights / evaluation-mode norm
+# coefficients are used (and their addresses recorded) instead of re-made inside the graph; the runner re-captures when a
+# parameter, a buffer or the optimiser epoch changes
+FROZEN_CAPTURE = [False]
+
+
 def _packed_fwd_weight(weight, cout, c0, c1, up=False):
     """Packed [Cout][chunk][tap][16] copy of a conv weight for NO-GRAD forwards (inference loops), cached per parameter
     version, storage and optimiser epoch.  Training forwards never use this cache (they take the registry entry of
@@ -355,7 +361,7 @@ def _packed_fwd_weight(weight, cout, c0, c1, up=False):
     in-place write can never combine old packed weights with new normalisation parameters."""
     n = _query("mnk_conv3x3_up_packed_floats" if up else "mnk_conv3x3_packed_floats", cout, c0, c1)
     pack = "mnk_conv3x3_up_pack_fwd" if up else "mnk_conv3x3_pack_fwd"
-    if weight.is_cuda and torch.cuda.is_current_stream_capturing():
+    if weight.is_cuda and torch.cuda.is_current_stream_capturing() and not FROZEN_CAPTURE[0]:
         wp = torch.empty(n, dtype=torch.float32, device=weight.device)
         _call(pack, weight, _p(weight), _p(wp), cout, c0, c1)
         return wp
@@ -836,7 +842,7 @@ _BN_EVAL_EPOCH = [0]
 
 
 def _bn_eval_coeffs(y, gamma, running_mean, running_var, eps, c):
-    capturing = y.is_cuda and torch.cuda.is_current_stream_capturing()
+    capturing = y.is_cuda and torch.cuda.is_current_stream_capturing() and not FROZEN_CAPTURE[0]
     if not capturing:
         key = (0 if gamma is None else gamma.data_ptr(), 0 if gamma is None else gamma._version, running_mean.data_ptr(),
                running_mean._version, running_var.data_ptr(), running_var._version, float(eps), c, _stream(y),

@@ -122,6 +122,14 @@ class DataParallelWithCallback(nn.Module):
                 if out is not NotImplemented:
                     return out
         dev = self._device()
+        if not self.module.training and dev.type == "cuda":
+            # reconstruction.py:45-62 / transfer.py:65-79: the evaluation forward replayed from a hipGraph per input signature
+            from mnk import dropin
+            runner = dropin.eval_runner_for(self)
+            if runner is not None:
+                out = runner(inputs, kwargs, dev)
+                if out is not NotImplemented:
+                    return out
         inputs, kwargs = self._scatter(inputs, kwargs, dev)
         return self.module(*_to_device(inputs, dev), **_to_device(kwargs, dev))
 

@@ -156,3 +156,52 @@ def test_batched_transfer_equals_the_frame_loop_and_normalize_kp_its_formulas(be
     be.sync()
     assert got["video_prediction"].shape == loop.shape == (2, 3, 3, gold["size"], gold["size"])
     assert float((got["video_prediction"] - loop).abs().max()) < 2e-6
+
+
+@pytest.mark.gpu
+def test_eval_wrappers_replay_a_frozen_weight_graph_per_frame(monkeypatch):
+    """reconstruction.py:45-62's loop: kp_detector and generator behind DataParallelWithCallback in evaluation mode under no_grad,
+    one frame at a time.  The wrappers replay a hipGraph captured per input signature with frozen weights (mnk.dropin.EvalRunner):
+    same bits as eager launches; `kp_source` survives the later calls (outputs are fresh tensors); a load_state_dict between two
+    videos is seen (re-capture)."""
+    from conftest import Backend
+    from sync_batchnorm import DataParallelWithCallback
+    from mnk import dropin
+    be = Backend("hip")
+    gold = load("bair")
+    gen, kpd = _models(gold, be)
+    generator, kp_detector = DataParallelWithCallback(gen), DataParallelWithCallback(kpd)
+    generator.eval(), kp_detector.eval()
+    g = torch.Generator().manual_seed(5)
+    video = torch.rand(1, 3, 6, 64, 64, generator=g)
+
+    def loop():
+        outs = []
+        with torch.no_grad():
+            kp_source = kp_detector(video[:, :, :1])
+            keep = {k: v.clone() for k, v in kp_source.items()}
+            for i in range(video.shape[2]):
+                kp_driving = kp_detector(video[:, :, i:i + 1])
+                out = generator(source_image=video[:, :, :1], kp_driving=kp_driving, kp_source=kp_source)
+                outs.append(out["video_prediction"].clone())
+            torch.cuda.synchronize()
+            assert all(torch.equal(kp_source[k], keep[k]) for k in keep)          # not overwritten by the later detector calls
+        return torch.cat(outs, dim=2)
+
+    monkeypatch.setenv("MNK_EVAL_GRAPH", "0")
+    want = loop()
+    monkeypatch.delenv("MNK_EVAL_GRAPH")
+    got = loop()
+    rk, rg = dropin.eval_runner_for_wrapper(kp_detector), dropin.eval_runner_for_wrapper(generator)
+    assert rk is not None and rg is not None and rk.stats["captures"] == 1 and rg.stats["captures"] == 1
+    assert rk.stats["replays"] == 7 and rg.stats["replays"] == 6
+    assert torch.equal(got, want)
+    # other weights: the replay must follow them
+    sd = gen.state_dict()
+    cases.perturb_state_dict(sd, 99)
+    gen.load_state_dict(sd)
+    monkeypatch.setenv("MNK_EVAL_GRAPH", "0")
+    want2 = loop()
+    monkeypatch.delenv("MNK_EVAL_GRAPH")
+    got2 = loop()
+    assert rg.stats["captures"] == 2 and torch.equal(got2, want2) and not torch.equal(got2, got)
