@@ -1741,6 +1741,11 @@ struct WgradTapArgs {
     int xcd;             // re-chunk the launch order per XCD (xcd_tile)
     int clean;           // pad channels of x and dy hold zeros: the buffer-load fast path may be used
     int sw, sh, sn;      // fast path: one 16-pixel K step = sw columns + sh rows + sn frames
+    // small maps (H * W <= wtap_compact, MODE 0 / 3): K runs over the pixels whose tap lies INSIDE the source only -- on a 2 x 2 map
+    // a corner tap sees one pixel of four, an edge tap two (56 % of the (pixel, tap) pairs of a 3x3 pad-1 convolution are zeros
+    // there, 31 % on 4 x 4, 16 % on 8 x 8; three quarters of the sub-pixel form's pseudo taps on a 1 x 1 source).  The range of a
+    // tap is cut into `nsplits` equal pieces.
+    int compact, nsplits;
     // MODE 3 -- sub-pixel form of an up-sampled 3x3 convolution: H, W, M are the LOW resolution; the 16 "taps" are
     // t = 4 * (2a + b) + (2u + v): dWeff[t] = sum_{n,i,j} dy[n, 2i+a, 2j+b] (x) x[n, i+a-1+u, j+b-1+v]  (4/9 of the multiply-adds of
     // the nine-tap form; the reduction folds the 16 pseudo taps into the nine kernel taps)
@@ -1767,7 +1772,7 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
     const int co0 = bx * BM;
     const int tap = by / a.gn;
     const int ci0 = (by - tap * a.gn) * BN;
-    const long p_begin = (long)split * a.pix_per_split;
+    long p_begin = (long)split * a.pix_per_split;
     long p_end = p_begin + a.pix_per_split;
     if (p_end > a.M) p_end = a.M;
     const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
@@ -1776,7 +1781,39 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
     const int dyt = SUBPIX ? ph_a - 1 + ((tap >> 1) & 1) : tap / a.kw - a.pad;   // SUBPIX: low-resolution row / column offset
     const int dxt = SUBPIX ? ph_b - 1 + (tap & 1) : tap % a.kw - a.pad;
     const int hmax = a.Hi - 1, wmax = a.Wi - 1;
-    const unsigned plast = (unsigned)(a.M - 1), pend = (unsigned)p_end;
+    // compact K (small maps): the rectangle [ch0, ch0 + chh) x [cw0, cw0 + cww) of output pixels whose tap lies inside the source;
+    // K index k -> (frame, row, column) of that rectangle, Kt = frames * chh * cww entries
+    const bool compact = !FAST && a.compact;
+    int ch0 = 0, cw0 = 0, chh = a.H, cww = a.W;
+    float inv_chh = 0.f, inv_cww = 0.f;
+    long Klast = a.M - 1;
+    if (compact) {
+        ch0 = dyt < 0 ? -dyt : 0;
+        cw0 = dxt < 0 ? -dxt : 0;
+        int h1 = a.Hi - dyt, w1 = a.Wi - dxt;
+        h1 = h1 > a.H ? a.H : h1;
+        w1 = w1 > a.W ? a.W : w1;
+        chh = h1 > ch0 ? h1 - ch0 : 0;
+        cww = w1 > cw0 ? w1 - cw0 : 0;
+        const long frames = a.M / ((long)a.H * a.W);
+        const long Kt = frames * chh * cww;
+        const long per = ((Kt + a.nsplits - 1) / a.nsplits + BK - 1) / BK * BK;
+        p_begin = (long)split * per;
+        p_end = p_begin + per;
+        if (p_end > Kt) p_end = Kt;
+        if (p_begin > p_end) p_begin = p_end;
+        Klast = Kt > 0 ? Kt - 1 : 0;
+        inv_chh = chh > 0 ? 1.f / (float)chh : 0.f;
+        inv_cww = cww > 0 ? 1.f / (float)cww : 0.f;
+    }
+    const unsigned plast = (unsigned)Klast, pend = (unsigned)p_end;
+    // k -> (n, i, j) inside the rectangle; k < 2^20: (k + 0.5) / d is at least 0.5 / d away from an integer, far beyond the rounding
+    auto unpack = [&](unsigned k, unsigned& n, unsigned& i, unsigned& j) __attribute__((always_inline)) {
+        const unsigned q = (unsigned)(((float)k + 0.5f) * inv_cww);
+        j = k - q * (unsigned)cww + (unsigned)cw0;
+        n = (unsigned)(((float)q + 0.5f) * inv_chh);
+        i = q - n * (unsigned)chh + (unsigned)ch0;
+    };
 
     const int ar = t / A4, ac4 = t % A4, br = t / B4, bc4 = t % B4;
     const int coa = co0 + ac4 * 4, cib = ci0 + bc4 * 4;
@@ -1790,7 +1827,12 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
         tl = p < pend ? tail_a : 0;
         const unsigned pe = p < plast ? p : plast;
         unsigned long row = pe;
-        if constexpr (SUBPIX) {          // low-resolution pixel (n, i, j) -> pixel (2i + a, 2j + b) of the up-sampled dy
+        if (compact) {
+            unsigned n, i, j;
+            unpack(pe, n, i, j);
+            row = SUBPIX ? ((unsigned long)(n * (unsigned)a.H + i) * 2u + (unsigned)ph_a) * (2u * (unsigned)a.W) + 2u * j + (unsigned)ph_b
+                         : (unsigned long)(n * (unsigned)a.H + i) * (unsigned)a.W + j;
+        } else if constexpr (SUBPIX) {   // low-resolution pixel (n, i, j) -> pixel (2i + a, 2j + b) of the up-sampled dy
             const unsigned q = fast_div(pe, a.mulW, a.shW), n = fast_div(q, a.mulH, a.shH);
             const unsigned j = pe - q * (unsigned)a.W, i = q - n * (unsigned)a.H;
             row = ((unsigned long)(n * (unsigned)a.H + i) * 2u + (unsigned)ph_a) * (2u * (unsigned)a.W) + 2u * j + (unsigned)ph_b;
@@ -1799,6 +1841,14 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
     };
     auto load_b = [&](unsigned p, float4& v, int& tl) __attribute__((always_inline)) {
         const unsigned pe = p < plast ? p : plast;
+        if (compact) {                   // every entry of the range lies inside the source: no clamps, no masks but the range's end
+            unsigned n, i, j;
+            unpack(pe, n, i, j);
+            tl = p < pend ? tail_b : 0;
+            const unsigned pix = (n * (unsigned)Hs + (unsigned)((int)i + dyt)) * (unsigned)Ws + (unsigned)((int)j + dxt);
+            v = *reinterpret_cast<const float4*>(a.x + (unsigned long)pix * (unsigned)a.ld_x + cib_e);
+            return;
+        }
         const unsigned q = fast_div(pe, a.mulW, a.shW);
         const int w = (int)(pe - q * (unsigned)a.W);
         const unsigned n = fast_div(q, a.mulH, a.shH);
@@ -2700,6 +2750,19 @@ static void grouped_split(long M, int* splits, long* pix_per_split) {
     *splits = (int)((steps + steps_per - 1) / steps_per);
 }
 
+// small maps: the tap-major kernel's K runs over the (pixel, tap) pairs inside the source only (WgradTapArgs::compact);
+// wtap_compact = the largest H * W (of the dy geometry; the low resolution for the sub-pixel form) that takes this form, 0: off
+static int g_wtap_compact = tuning_knob("wtap_compact", &g_wtap_compact, 64);
+static bool tap_compact_ok(int H, int W, long M, int kh, int kw, int pad, int ups, int subpix) {
+    if (g_wtap_compact <= 0 || (long)H * W > g_wtap_compact || M >= (1L << 20)) return false;
+    return subpix || (!ups && kh == 3 && kw == 3 && pad == 1);
+}
+// (pixel, tap) pairs a compact job multiplies: 3x3 pad 1: (3H - 2)(3W - 2) per frame; sub-pixel form (offsets {-1, 0} / {0, +1}
+// per phase and axis): (4H - 2)(4W - 2) per frame
+static double tap_compact_pairs(long frames, int H, int W, int subpix) {
+    return subpix ? (double)frames * (4.0 * H - 2.0) * (4.0 * W - 2.0) : (double)frames * (3.0 * H - 2.0) * (3.0 * W - 2.0);
+}
+
 // variant id of a tap-major job: 4 * tile + mode; tile 0: 128x128, 1: 128x64, 2: 64x128, 3: 32x128; mode 3: sub-pixel form
 static int tap_tile_id(const TPlan& tp) {
     if (tp.bm == 128 && tp.bn == 128) return 0;
@@ -2714,6 +2777,10 @@ static int tap_mode(WgradTapArgs& g, int N, int H, int W, int Hi, int Wi, int kh
     if (subpix) {
         g.sw = g.sh = g.sn = 0;
         return 3;
+    }
+    if (tap_compact_ok(H, W, (long)N * H * W, kh, kw, pad, ups, 0)) {      // compact K lives in the generic loader
+        g.sw = g.sh = g.sn = 0;
+        return 0;
     }
     const long span_a = pix_per_split * (long)ld_dy * 4, span_b = (pix_per_split + 2L * W + 2 * BK) * ld_x * 4;
     bool walk = true;          // can a 16-pixel step be walked as columns / rows / frames with single wraps?
@@ -3059,13 +3126,15 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
             g.xcd = g_xcd_remap;
             g.clean = 1;
             g.sw = g.sh = g.sn = 0;
+            g.compact = tap_compact_ok(Hl, Wl, g.M, 3, 3, 1, 0, 1) ? 1 : 0;
+            g.nsplits = up.splits;
             fast_div_consts((unsigned)Wl, &g.mulW, &g.shW);
             fast_div_consts((unsigned)Hl, &g.mulH, &g.shH);
             hipStream_t st = (hipStream_t)stream;
             dim3 grid(up.gm, up.gn * 16, up.splits);
             {
-                ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)N * Ho * Wo * Cout * 9.0 * C,
-                               2.0 * (double)g.M * Cout * 16.0 * C);        // 16 pseudo taps at the low resolution
+                ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)N * Ho * Wo * Cout * 9.0 * C,       // 16 pseudo taps at the low resolution
+                               g.compact ? 2.0 * tap_compact_pairs(N, Hl, Wl, 1) * Cout * C : 2.0 * (double)g.M * Cout * 16.0 * C);
                 if (up.bm == 128 && up.bn == 128)
                     hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
                 else if (up.bm == 128)
@@ -3127,8 +3196,11 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
         fast_div_consts((unsigned)H, &g.mulH, &g.shH);
         hipStream_t st = (hipStream_t)stream;
         dim3 grid(tp.gm, tp.gn * ntaps, tp.splits);
+        g.compact = tap_compact_ok(H, W, g.M, kh, kw, pad, ups, 0) ? 1 : 0;
+        g.nsplits = tp.splits;
         {
-            ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)g.M * Cout * (double)ntaps * C);
+            ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)g.M * Cout * (double)ntaps * C,
+                           g.compact ? 2.0 * tap_compact_pairs(N, H, W, 0) * Cout * C : -1.0);
             // fast loader: 3x3 pad 1, clean pads, rows of >= 16 pixels, split ranges inside the 2^30-byte buffer window
             const int mode = tap_mode(g, N, H, W, Hi, Wi, kh, kw, pad, ups, clean, ld_x, ld_dy, tp.pix_per_split);
 #define MNK_WTAP(...)                                                                                            \
@@ -3506,6 +3578,8 @@ int mnk_wgrad_grouped_build(const MnkWgradJob* jobs, int n, void* host_table, si
             fast_div_consts((unsigned)H, &g.mulH, &g.shH);
             const int mode = tap_mode(g, j.N, j.Ho, j.Wo, j.Hi, j.Wi, j.kh, j.kw, j.pad, ups, clean, j.ld_x, j.ld_dy, pps, subpix);
             MNK_REQUIRE(mode == v % 4);
+            g.compact = tap_compact_ok(H, W, M, j.kh, j.kw, j.pad, subpix ? 0 : ups, subpix) ? 1 : 0;
+            g.nsplits = splits;
             r.gm = tp.gm;
             r.gnt = tp.gn * ntaps;
             r.splits = splits;
@@ -3534,7 +3608,8 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
         for (int i = 0; i < cnt; ++i) {
             const WgradTapArgs& g = hrecs[hd->first[v] + i].a;      // algorithmic: the sub-pixel form stands for 9 taps at 4 M pixels
             flop += v % 4 == 3 ? 2.0 * 4.0 * (double)g.M * g.Cout * 9.0 * g.C : 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
-            issued += 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
+            issued += g.compact ? 2.0 * tap_compact_pairs(g.M / ((long)g.H * g.W), g.H, g.W, v % 4 == 3) * g.Cout * g.C
+                                : 2.0 * (double)g.M * g.Cout * (double)g.ntaps * g.C;
         }
         ProfScope prof(K_CONV_WGRAD, st, flop, issued);
         const TapJobRec* rv = drecs + hd->first[v];

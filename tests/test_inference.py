@@ -197,7 +197,7 @@ def test_eval_wrappers_replay_a_frozen_weight_graph_per_frame(monkeypatch):
     assert rk.stats["replays"] == 7 and rg.stats["replays"] == 6
     assert torch.equal(got, want)
     # other weights: the replay must follow them
-    sd = gen.state_dict()
+    sd = {k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
     cases.perturb_state_dict(sd, 99)
     gen.load_state_dict(sd)
     monkeypatch.setenv("MNK_EVAL_GRAPH", "0")

@@ -143,8 +143,24 @@ WFAST_CASES = [
 ]
 
 
+# small maps through the tap-major kernel's COMPACT K (round 6): only the (pixel, tap) pairs inside the source are multiplied --
+# 1 x 1 ... 8 x 8 maps, non-square, two sources, several frames per K step, several pixel splits, and the sub-pixel form of
+# up-sampled layers down to a 1 x 1 source (12 of its 16 pseudo taps are empty there)
+COMPACT_CASES = [
+    (4, 2, 2, 80, 0, 72, 0, False, False),
+    (3, 1, 1, 70, 0, 130, 0, False, False),
+    (5, 4, 4, 96, 0, 80, 0, False, False),
+    (2, 2, 4, 40, 70, 68, 0, False, False),
+    (70, 2, 2, 72, 0, 48, 0, False, False),
+    (6, 2, 2, 72, 0, 40, 1, False, False),
+    (3, 4, 4, 130, 0, 72, 1, False, False),
+    (2, 8, 4, 70, 0, 130, 1, False, False),
+    (20, 4, 4, 72, 0, 48, 1, False, False),
+]
+
+
 @pytest.mark.parametrize("clean", [False, True])
-@pytest.mark.parametrize("case", CASES + HALO_CASES + WFAST_CASES)
+@pytest.mark.parametrize("case", CASES + HALO_CASES + WFAST_CASES + COMPACT_CASES)
 def test_conv3x3_wgrad(be, case, clean):
     """clean = False: NaN pad channels in x must be ignored (generic loaders); clean = True: MNK_CONV_CLEAN_PADS, zero
     pads -> the buffer-load loader of the tap-major kernel where the shape allows it (W >= 16)."""
