@@ -22,6 +22,7 @@ struct Map2D {
 
 static int g_bn_rpt = tuning_knob("bn_rpt", &g_bn_rpt, 4);            // rows per thread before a layer is cut (A/B: 8 -> 4: 11.51 -> 11.44 ms per step)
 static int g_bn_blocks = tuning_knob("bn_blocks", &g_bn_blocks, 1024);   // into more row blocks; block cap
+static int g_bn_exact_tx = tuning_knob("bn_exact_tx", &g_bn_exact_tx, 1);   // 0: power-of-two quad lanes per block (rounds 1-5)
 
 static Map2D make_map(long rows, int ld, int rows_per_thread = 0, int want_blocks = 0) {
     if (rows_per_thread <= 0) rows_per_thread = g_bn_rpt;
@@ -30,6 +31,10 @@ static Map2D make_map(long rows, int ld, int rows_per_thread = 0, int want_block
     int nv = ld / 4;
     int tx = 1;
     while (tx < nv && tx < 64) tx <<= 1;
+    // (round 6) a channel count whose quads are no power of two -- 45 -> 12 quads (the refinement stack: the largest tensors of a
+    // step), 44 -> 11, 66 -> 17 -- left a quarter to a half of every block idle with the power-of-two map: tx = the quad count
+    // itself, ty = floor(256 / tx) row lanes, the few left-over threads idle (252 of 256 work on 12 quads instead of 192)
+    if (g_bn_exact_tx && nv <= 64) tx = nv;
     m.tx = tx;
     m.ty = 256 / tx;
     m.col_tiles = (nv + tx - 1) / tx;
@@ -47,6 +52,13 @@ static Map2D make_map(long rows, int ld, int rows_per_thread = 0, int want_block
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
     return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+
+// first step of a halving tree over n entries: the largest power of two below n (n >= 2), 0 for n = 1
+__device__ __forceinline__ int tree_half(int n) {
+    int s = 1;
+    while (s * 2 < n) s <<= 1;
+    return n > 1 ? s : 0;
 }
 
 // per-channel parameter quad with a bounds guard (parameter vectors are exactly C long)
@@ -73,7 +85,7 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
     long r1 = r0 + rows_per_block;
     if (r1 > fbase + rows) r1 = fbase + rows;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (q < nv) {
+    if (q < nv && ty < ty_n) {        // (ty >= ty_n: the left-over threads of a map whose tx_n does not divide 256)
         typename F::State st;         // per-thread channel constants (the column quad q is fixed per thread)
         f.init(st);
 #pragma unroll 2
@@ -87,8 +99,8 @@ __global__ void __launch_bounds__(256) colsum2_partial_kernel(F f, long rows, in
     red[0][threadIdx.x] = a;
     red[1][threadIdx.x] = b;
     __syncthreads();
-    for (int s = ty_n >> 1; s > 0; s >>= 1) {
-        if (ty < s) {
+    for (int s = tree_half(ty_n); s > 0; s >>= 1) {       // any ty_n; the halving tree of rounds 1-5 when it is a power of two
+        if (ty < s && ty + s < ty_n) {
             red[0][threadIdx.x] = f4_add(red[0][threadIdx.x], red[0][threadIdx.x + s * tx_n]);
             red[1][threadIdx.x] = f4_add(red[1][threadIdx.x], red[1][threadIdx.x + s * tx_n]);
         }
@@ -426,7 +438,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(const float* __restrict
     const int nv = (C + 3) / 4;
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx;
-    if (q >= nv) return;
+    if (q >= nv || ty >= ty_n) return;
     const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
     const long rows = (long)N * Ho * Wo;              // output pixels, < 2^31 (host check)
     const unsigned HWo = (unsigned)(Ho * Wo);
@@ -531,7 +543,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
     const int tx = threadIdx.x % tx_n, ty = threadIdx.x / tx_n;
     const int q = blockIdx.x * tx_n + tx;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (q < nv) {
+    if (q < nv && ty < ty_n) {
     const long r0 = (long)blockIdx.y * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
@@ -574,8 +586,8 @@ __global__ void __launch_bounds__(256) bn_act_bwd_apply_kernel(BwdLoader L, cons
     if (dy_partial) {
         red[threadIdx.x] = csum;
         __syncthreads();
-        for (int s = ty_n >> 1; s > 0; s >>= 1) {
-            if (ty < s) red[threadIdx.x] = f4_add(red[threadIdx.x], red[threadIdx.x + s * tx_n]);
+        for (int s = tree_half(ty_n); s > 0; s >>= 1) {
+            if (ty < s && ty + s < ty_n) red[threadIdx.x] = f4_add(red[threadIdx.x], red[threadIdx.x + s * tx_n]);
             __syncthreads();
         }
         if (ty == 0 && q < nv)

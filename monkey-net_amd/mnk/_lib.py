@@ -90,6 +90,8 @@ class Library:
                         self.fast[name] = f
 
     def call(self, name, *args):
+        if name == "mnk_set_tuning":
+            self.tuning_epoch = getattr(self, "tuning_epoch", 0) + 1     # cached tuning values (mnk.ops.subpixel) are re-read
         f = self.fast.get(name)
         rc = f(*args) if f is not None else NotImplemented
         if rc is NotImplemented:

@@ -340,10 +340,17 @@ def subpixel(ups):
     this function reads (mnk_get_tuning: the library's weight-gradient plans follow the same integer)."""
     if not ups:
         return False
-    import ctypes
-    v = ctypes.c_int(1)
-    _lib.lib().call("mnk_get_tuning", b"up_subpixel", ctypes.byref(v))
-    return bool(v.value)
+    # read once per library handle and per mnk_set_tuning call made through it (ADVICE r5: a ctypes round trip per up-sampled
+    # convolution of every eager forward, and a value that could change between a forward and its backward)
+    lib = _lib.lib()
+    epoch = getattr(lib, "tuning_epoch", 0)
+    hit = getattr(lib, "_subpixel_cache", None)
+    if hit is None or hit[0] != epoch:
+        import ctypes
+        v = ctypes.c_int(1)
+        lib.call("mnk_get_tuning", b"up_subpixel", ctypes.byref(v))
+        hit = lib._subpixel_cache = (epoch, bool(v.value))
+    return hit[1]
 
 
 # mnk.dropin.EvalRunner captures an evaluation forward with FROZEN weights: the cached packed weights / evaluation-mode norm

@@ -219,3 +219,61 @@ def test_background_weight_gradients_equal_the_in_order_ones(monkeypatch):
         assert dist(a, b) <= 4 * dist(a, a2) + 1e-7, (dist(a, b), dist(a, a2))
     else:
         assert same(a, b)
+
+
+@pytest.mark.parametrize("mnk_adam", [False, True], ids=["torch-adam", "mnk-adam"])
+def test_two_independent_model_triples_interleaved_in_one_process(be, mnk_adam):
+    """the hand-overs between neighbouring kernels of mnk.ops (statistics out of a convolution's epilogue, the
+    backward statistics out of a data-gradient launch, the deferred weight-gradient jobs, packed-weight registry ...) live in
+    module-level state.  Two unrelated model triples A and B whose passes are INTERLEAVED in one process -- forward A, forward
+    B, backward A, backward B, then the optimiser steps -- must each get exactly what they get alone: losses and every updated
+    parameter, bit for bit."""
+    from mnk import engine
+    from mnk.optim import MnkAdam
+    gold = load("step_tiny")
+    cfg = gold["cfg"]
+    tp = cfg["train_params"]
+    Adam = MnkAdam if mnk_adam else torch.optim.Adam
+
+    def make(seed):
+        gen, disc, kpd = build(cfg)
+        for i, (m, k) in enumerate(((gen, "generator"), (disc, "discriminator"), (kpd, "kp_detector"))):
+            sd = {n: v.clone() for n, v in gold["state"][k].items()}
+            cases.perturb_state_dict(sd, seed + i)
+            m.load_state_dict(sd)
+            m.to(be.device)
+        opts = [Adam(m.parameters(), lr=tp["lr"], betas=(0.5, 0.999)) for m in (gen, kpd)]
+        g = torch.Generator().manual_seed(seed)
+        src, drv = cases.smooth_pair(gold["batch"], gold["size"], gold["size"])
+        x = {"source": be.t(src + 0.01 * torch.rand(src.shape, generator=g)), "video": be.t(drv)}
+        return engine.GeneratorFullModel(kpd, gen, disc, tp), opts, x
+
+    def forward(full, x):
+        out = full(x)
+        vals = [v.mean() for v in out[:-2]]
+        return sum(vals), [v.detach().clone() for v in vals]
+
+    def finish(full, opts):
+        for o in opts:
+            o.step()
+        be.sync()
+        return [p.detach().cpu().clone() for m in (full.generator, full.kp_extractor) for p in m.parameters()]
+
+    # each triple alone
+    alone = []
+    for seed in (11, 23):
+        full, opts, x = make(seed)
+        loss, vals = forward(full, x)
+        loss.backward()
+        alone.append((vals, finish(full, opts)))
+    # interleaved
+    fa, oa, xa = make(11)
+    fb, ob, xb = make(23)
+    la, va = forward(fa, xa)
+    lb, vb = forward(fb, xb)
+    la.backward()
+    lb.backward()
+    pa, pb = finish(fa, oa), finish(fb, ob)
+    for (vals, params), (v2, p2) in zip(alone, ((va, pa), (vb, pb))):
+        assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(vals, v2))
+        assert all(torch.equal(a, b) for a, b in zip(params, p2))
