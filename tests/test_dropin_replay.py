@@ -261,3 +261,123 @@ def test_the_dropin_runner_falls_back_on_what_it_does_not_serve(be, monkeypatch)
     gpar(x)
     with pytest.raises(RuntimeError, match="earlier"):
         sum(v.mean() for v in first[:-2]).backward()
+
+
+def test_adopted_adam_follows_schedulers_checkpoints_and_batch_size_changes(be, monkeypatch, tmp_path):
+    """The drop-in runner + AdoptedAdam under what train.py does around the loop: a MultiStepLR milestone between two iterations
+    (train.py:88-96,143-145), Logger.save_cpk / load_cpk of the three STOCK optimisers (logger.py:43-66) into a fresh set of
+    objects that then continues, and a last batch of another size (re-capture).  Reference run: the same statements with
+    MNK_DROPIN_GRAPH=0 MNK_ADOPT_ADAM=0 (stock steps on the modules as they are)."""
+    from mnk import dropin, optim as moptim
+    gold = load("step_tiny")
+    src, drv = cases.smooth_pair(gold["batch"], gold["size"], gold["size"])
+
+    def run(tag):
+        config = copy.deepcopy(gold["cfg"])
+        tp = config["train_params"]
+        from mnk.engine import GeneratorFullModel, DiscriminatorFullModel
+        from sync_batchnorm import DataParallelWithCallback
+
+        def fresh():
+            nets = build(config)
+            for m, k in zip(nets, ("generator", "discriminator", "kp_detector")):
+                m.load_state_dict(gold["state"][k])
+                m.to(be.device)
+            opts = [torch.optim.Adam(m.parameters(), lr=tp["lr"], betas=(0.5, 0.999)) for m in nets]
+            scheds = [MultiStepLR(o, [1], gamma=0.1, last_epoch=-1) for o in opts]
+            g, d, k = nets
+            ids = [0] if be.kind == "hip" else None
+            return nets, opts, scheds, (DataParallelWithCallback(GeneratorFullModel(k, g, d, tp), device_ids=ids),
+                                        DataParallelWithCallback(DiscriminatorFullModel(k, g, d, tp), device_ids=ids))
+
+        def iteration(nets, opts, pars, x):
+            og, od, ok = opts
+            out = pars[0](x)
+            vals = [v.mean() for v in out[:-2]]
+            sum(vals).backward(retain_graph=not tp["detach_kp_discriminator"])
+            og.step(), og.zero_grad(), od.zero_grad()
+            if tp["detach_kp_discriminator"]:
+                ok.step(), ok.zero_grad()
+            dv = [v.mean() for v in pars[1](x, out[-1], out[-2])]
+            sum(dv).backward()
+            od.step(), od.zero_grad()
+            if not tp["detach_kp_discriminator"]:
+                ok.step(), ok.zero_grad()
+            return [float(v.detach().cpu()) for v in vals + dv]
+
+        nets, opts, scheds, pars = fresh()
+        x = {"source": src, "video": drv}
+        hist = [iteration(nets, opts, pars, x)]
+        for s in scheds:                     # epoch boundary: lr 2e-4 -> 2e-5
+            s.step()
+        hist.append(iteration(nets, opts, pars, x))
+        cpk = {"g": nets[0].state_dict(), "d": nets[1].state_dict(), "k": nets[2].state_dict(), "o": [o.state_dict() for o in opts]}
+        path = os.path.join(tmp_path, tag + ".pth.tar")
+        torch.save(cpk, path)
+        nets2, opts2, _, pars2 = fresh()     # Logger.load_cpk into new objects
+        ck = torch.load(path, weights_only=False)
+        nets2[0].load_state_dict(ck["g"]), nets2[1].load_state_dict(ck["d"]), nets2[2].load_state_dict(ck["k"])
+        for o, sd in zip(opts2, ck["o"]):
+            o.load_state_dict(sd)
+        hist.append(iteration(nets2, opts2, pars2, x))
+        half = {"source": src[:2], "video": drv[:2]}          # a smaller last batch
+        hist.append(iteration(nets2, opts2, pars2, half))
+        hist.append(iteration(nets2, opts2, pars2, x))
+        be.sync()
+        steps = [float(opts2[0].state_dict()["state"][0]["step"]), opts2[0].param_groups[0]["lr"]]
+        return hist, steps, pars2, opts2
+
+    monkeypatch.setenv("MNK_DROPIN_GRAPH", "0")
+    monkeypatch.setenv("MNK_ADOPT_ADAM", "0")
+    want, wsteps, _, _ = run("stock")
+    monkeypatch.delenv("MNK_DROPIN_GRAPH")
+    monkeypatch.delenv("MNK_ADOPT_ADAM")
+    got, gsteps, pars, opts = run("runner")
+    runner = dropin.runner_for(pars[0].module)
+    assert runner.stats["fallbacks"] == 0 and runner.stats["d_fallbacks"] == 0
+    assert (runner.stats["graph_calls"] if be.kind == "hip" else runner.stats["phase_calls"]) == 3
+    if be.kind == "hip":
+        assert runner.stats["captures"] == 2               # batch 4 and batch 2
+    assert all(moptim.adopted(o) is not None and moptim.adopted(o).steps_taken == 3 for o in opts)
+    assert gsteps == wsteps == [5.0, gsteps[1]]
+    for it, (a, b) in enumerate(zip(got, want)):
+        for va, vb in zip(a, b):
+            # two fp32 trajectories under Adam's sign-like first updates separate step by step (tests/test_step.py): 5e-4 relative
+            # at the fifth iteration measured; the structure assertions above are the point of this test
+            assert abs(va - vb) <= 2e-4 * (it + 1) ** 2 * max(1.0, abs(vb)), (it, a, b)
+
+
+def test_adopted_adam_equals_the_stock_step(be):
+    """mnk.optim.AdoptedAdam (mnk_adam_multi on the stock optimiser's own state tensors) against torch.optim.Adam itself: same
+    parameters, exp_avg, exp_avg_sq and step after three steps on the same gradients (2e-6 relative, the bound of MnkAdam's test)"""
+    from mnk import optim as moptim
+    g = torch.Generator().manual_seed(2)
+    shapes = [(7,), (5, 3), (33, 17, 1, 3, 3), (1024,), (4099,)]
+
+    def params():
+        g2 = torch.Generator().manual_seed(9)
+        return [torch.nn.Parameter(be.t(torch.randn(s, generator=g2))) for s in shapes]
+
+    pa, pb = params(), params()
+    oa = torch.optim.Adam(pa, lr=3e-3, betas=(0.5, 0.999))
+    ob = torch.optim.Adam(pb, lr=3e-3, betas=(0.5, 0.999))
+    sinks = moptim.GradSinks(pb)
+    moptim.install_adam_adoption()
+    for it in range(3):
+        grads = [torch.randn(s, generator=g) * (10.0 ** (it - 1)) for s in shapes]
+        for p, gr in zip(pa, grads):
+            p.grad = be.t(gr)
+        for p, gr in zip(pb, grads):
+            sinks.sink(p).copy_(be.t(gr))
+            p.grad = sinks.sink(p)
+        oa.step(), ob.step()
+        assert all(p.grad is not None for p in pb)         # handed back after the (empty) stock step
+        oa.zero_grad(), ob.zero_grad()
+    be.sync()
+    assert moptim.adopted(ob).steps_taken == 3 and moptim.adopted(oa) is None
+    for a, b in zip(pa, pb):
+        assert float((a.detach().cpu() - b.detach().cpu()).abs().max()) <= 2e-6 * max(1.0, float(a.detach().abs().max()))
+        for k, tol in (("exp_avg", 1e-5), ("exp_avg_sq", 1e-5)):
+            x, y = oa.state[a][k].cpu(), ob.state[b][k].cpu()
+            assert float((x - y).abs().max()) <= tol * max(1e-30, float(x.abs().max())), k
+        assert float(oa.state[a]["step"]) == float(ob.state[b]["step"]) == 3.0
