@@ -28,10 +28,18 @@ One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one 
                    `executed` / `executed_frac`: the multiply-adds the launches actually issue (the sub-pixel forms of the
                    up-sampled convolutions run 4/9 of the algorithmic ones) / time / peak;
   dropin        -- the reference's OWN loop on the drop-in modules (train.py:78-153's statement sequence: three
-                   torch.optim.Adam, host batches through DataParallelWithCallback, two discriminator passes, per-iteration
-                   host copies of the losses; eager launches) and `with_mnk_adam`: the same loop with mnk.optim.MnkAdam in
-                   place of the three optimisers; `eval_frame_loop`: reconstruction.py:45-62's per-frame loop at batch 1 --
-                   reported beside `value`, never as it;
+                   torch.optim.Adam, host batches through DataParallelWithCallback, per-iteration host copies of the losses).
+                   Round 6: the wrappers serve it from three captured hipGraphs and step the stock optimisers with the library's
+                   Adam kernel (mnk.dropin, `runner` = what served the calls); `with_mnk_adam`: the same loop with
+                   mnk.optim.MnkAdam objects; `modules_as_they_are`: MNK_DROPIN_GRAPH=0 MNK_ADOPT_ADAM=0 (rounds 4-5's `dropin`:
+                   two discriminator passes, eager launches); `eval_frame_loop`: reconstruction.py:45-62's per-frame loop at
+                   batch 1 (frozen-weight hipGraph per wrapper) -- reported beside `value`, never as it;
+  roofline_hbm  -- one record per HBM-bound kernel group (norm statistics / apply / backward, soft-argmax, movement embedding,
+                   motion field, warps, 1x1 convolutions, Adam, layout, losses): algorithmic bytes per iteration / the HIP-event
+                   kernel time of this run / 8 TB/s, `traffic` = counter bytes of the round's PMC passes when they were made
+                   on these very sources;
+  extra         -- the other single-GPU BASELINE configurations on the same clock: taichi_b32 (the stack the 0.5 target is
+                   worded on), vox256_b8 (configs[3]'s per-GPU share), bair_b512_infer (configs[4]);
   hot_path_only_ms -- SURVEY section 8a alone (KPDetector + generator forward and backward with every weight gradient
                    materialised; no discriminator, losses or optimiser) as a hipGraph replay, next to the whole step;
   cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
@@ -599,8 +607,9 @@ def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):
 
 def frame_loop(cfg, size, device, frames=40):
     """The reference's per-frame evaluation loop on the drop-in modules (reconstruction.py:45-62: for every frame of a video,
-    kp_detector(frame) and generator(source, kp_driving, kp_source) at batch 1 under no_grad, behind DataParallelWithCallback),
-    eager launches: milliseconds per frame.  (mnk.engine.Reconstructor is the batched / hipGraph form of the same work.)"""
+    kp_detector(frame) and generator(source, kp_driving, kp_source) at batch 1 under no_grad, behind DataParallelWithCallback):
+    milliseconds per frame.  Round 6: each wrapper replays a frozen-weight hipGraph per input signature (mnk.dropin.EvalRunner;
+    MNK_EVAL_GRAPH=0: eager launches).  (mnk.engine.Reconstructor is the batched form of the same work.)"""
     from sync_batchnorm import DataParallelWithCallback
     gen, _, kpd = build_models(cfg, device)
     generator, kp_detector = DataParallelWithCallback(gen), DataParallelWithCallback(kpd)
@@ -621,9 +630,13 @@ def frame_loop(cfg, size, device, frames=40):
     last = loop()
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / frames
+    from mnk import dropin
+    runners = [dropin.eval_runner_for_wrapper(w) for w in (kp_detector, generator)]
+    served = all(r is not None and r.stats["replays"] > 0 for r in runners)
     return {"ms_per_frame": round(dt * 1e3, 3), "frames_per_s": round(1.0 / dt, 1), "finite": bool(torch.isfinite(last).all()),
+            "launch": "frozen-weight hipGraph replay per wrapper call (mnk.dropin.EvalRunner)" if served else "eager",
             "what": "reconstruction.py:45-62's loop on the drop-in modules: kp_detector + generator per frame at batch 1, "
-                    "no_grad, eager launches (host frames through DataParallelWithCallback)"}
+                    "no_grad, host frames through DataParallelWithCallback"}
 
 
 _JSON_FD = [None]
