@@ -420,7 +420,11 @@ __device__ unsigned long long mnk_phase_sclk[2 * 16384];      // the shader cloc
 #define MNK_PHASE(i) ((void)0)
 #endif
 
-template <int BM, int BN, int WM, int WN, int MODE>     // MODE: 0 generic loader, 1 / 2 the 3x3 fast loader (plain / x2 up-sampled)
+constexpr int LDS_H = 24;     // padded LDS row of the bf16 planes (16 + 8 halves = 48 bytes: conflict-free b128 fragment reads)
+
+// GM: 0 -- v_mfma_f32_32x32x2_f32 on fp32 tiles; 1 -- the same products on the bf16 matrix cores: the loaders split every fp32
+// operand into three bf16 planes on its way to LDS and a K step of 16 is six v_mfma_f32_32x32x16_bf16 per tile (mnk_common.h)
+template <int BM, int BN, int WM, int WN, int MODE, int GM = 0>     // MODE: 0 generic loader, 1 / 2 the 3x3 fast loader (plain / x2 up-sampled)
 __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvArgs a) {
     MNK_PHASE(0);
     constexpr int RA = BM / 64;               // A rows per thread per K step
@@ -434,8 +438,13 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     constexpr int NST = (BM * BN <= 64 * 128) ? MNK_IGEMM_NST : 1;     // 8 (16) registers per stage; the 128x128 tile has none to spare
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(NST == 1 || NST == 2, "one or two register stages");
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_K];
+    // one LDS image, two views: fp32 rows [2][rows][LDS_K] (GM 0) / three bf16 planes [2][3][rows][LDS_H] (GM 1)
+    constexpr int A_BYTES = GM ? 2 * 3 * BM * LDS_H * 2 : 2 * BM * LDS_K * 4, B_BYTES = GM ? 2 * 3 * BN * LDS_H * 2 : 2 * BN * LDS_K * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_a[A_BYTES], smem_b[B_BYTES];
+    float (*const As)[BM][LDS_K] = reinterpret_cast<float (*)[BM][LDS_K]>(smem_a);
+    float (*const Bs)[BN][LDS_K] = reinterpret_cast<float (*)[BN][LDS_K]>(smem_b);
+    unsigned short (*const Ah)[3][BM][LDS_H] = reinterpret_cast<unsigned short (*)[3][BM][LDS_H]>(smem_a);
+    unsigned short (*const Bh)[3][BN][LDS_H] = reinterpret_cast<unsigned short (*)[3][BN][LDS_H]>(smem_b);
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -482,10 +491,33 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     };
     auto store_step = [&](int buf, auto st_tag) __attribute__((always_inline)) {
         constexpr int ST = decltype(st_tag)::value;
+        if constexpr (GM == 0) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = L.template masked<ST>(j);
-        if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = ST == 0 ? rb0a : rb0b;
-        if constexpr (RB > 1) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64][lq * 4]) = ST == 0 ? rb1a : rb1b;
+            for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(&As[buf][lrow + 64 * j][lq * 4]) = L.template masked<ST>(j);
+            if (BN >= 64 || lrow < BN) *reinterpret_cast<float4*>(&Bs[buf][lrow][lq * 4]) = ST == 0 ? rb0a : rb0b;
+            if constexpr (RB > 1) *reinterpret_cast<float4*>(&Bs[buf][lrow + 64][lq * 4]) = ST == 0 ? rb1a : rb1b;
+        } else {
+            uint2 p0, p1, p2;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                mnk_split3(L.template masked<ST>(j), p0, p1, p2);
+                *reinterpret_cast<uint2*>(&Ah[buf][0][lrow + 64 * j][lq * 4]) = p0;
+                *reinterpret_cast<uint2*>(&Ah[buf][1][lrow + 64 * j][lq * 4]) = p1;
+                *reinterpret_cast<uint2*>(&Ah[buf][2][lrow + 64 * j][lq * 4]) = p2;
+            }
+            if (BN >= 64 || lrow < BN) {
+                mnk_split3(ST == 0 ? rb0a : rb0b, p0, p1, p2);
+                *reinterpret_cast<uint2*>(&Bh[buf][0][lrow][lq * 4]) = p0;
+                *reinterpret_cast<uint2*>(&Bh[buf][1][lrow][lq * 4]) = p1;
+                *reinterpret_cast<uint2*>(&Bh[buf][2][lrow][lq * 4]) = p2;
+            }
+            if constexpr (RB > 1) {
+                mnk_split3(ST == 0 ? rb1a : rb1b, p0, p1, p2);
+                *reinterpret_cast<uint2*>(&Bh[buf][0][lrow + 64][lq * 4]) = p0;
+                *reinterpret_cast<uint2*>(&Bh[buf][1][lrow + 64][lq * 4]) = p1;
+                *reinterpret_cast<uint2*>(&Bh[buf][2][lrow + 64][lq * 4]) = p2;
+            }
+        }
     };
 
     f32x16 acc[NACC][TM][TN];
@@ -502,6 +534,32 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     const int a_row0 = wm * (BM / WM) + fi, b_row0 = wn * (BN / WN) + fi;
 
     auto mfma_step = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (GM == 1) {
+            // lane (fi, fk) holds k = 8 fk .. 8 fk + 7 of its row in every plane: one b128 per plane and operand row
+            mnk_bf16x8 ha[3][TM], hb[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    ha[pl][i] = mnk_as_bf16x8(*reinterpret_cast<const uint4*>(&Ah[buf][pl][a_row0 + 32 * i][fk * 8]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    hb[pl][j] = mnk_as_bf16x8(*reinterpret_cast<const uint4*>(&Bh[buf][pl][b_row0 + 32 * j][fk * 8]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    constexpr int Q = NACC - 1;       // (two accumulator sets of a one-tile wave: neighbours independent)
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[1][i], hb[1][j], acc[0][i][j], 0, 0, 0);
+                    acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[2][i], hb[0][j], acc[Q][i][j], 0, 0, 0);
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[0][i], hb[2][j], acc[0][i][j], 0, 0, 0);
+                    acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[1][i], hb[0][j], acc[Q][i][j], 0, 0, 0);
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[0][i], hb[1][j], acc[0][i][j], 0, 0, 0);
+                    acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[0][i], hb[0][j], acc[Q][i][j], 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
             float4 fa[TM], fb[TN];
@@ -689,7 +747,7 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     // ---- fused BatchNorm statistics of the tensor just written (sync_batchnorm/batchnorm.py:60-62): per-block
     // column sums -> stats[blockIdx.x][2][ld_y]; the tiny final reduction over blocks is mnk_bn_stats_finish.
     if (a.stats && !split_out) {
-        float* red = &As[0][0][0];          // the main loop ended with a barrier: LDS is free
+        float* red = reinterpret_cast<float*>(smem_a);          // the main loop ended with a barrier: LDS is free
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
@@ -2460,6 +2518,9 @@ static int g_xcd_remap = tuning_knob("xcd_remap", &g_xcd_remap, 1);
 static int g_fast_loader = tuning_knob("fast_loader", &g_fast_loader, 1);
 static int g_kxk_fast = tuning_knob("kxk_fast", &g_kxk_fast, 1);     // buffer-load loader for K x K / any pad (MODE 3)
 static int g_mfma16 = tuning_knob("mfma16", &g_mfma16, 1);
+// 1: the 32x32-tile implicit-GEMM kernels (forward / data gradient) run their products on the bf16 matrix cores through the exact
+// three-way split of both fp32 operands (conv3x3_igemm_kernel<..., GM = 1>, mnk_common.h); 0: v_mfma_f32_32x32x2_f32
+static int g_gemm_bf16x3 = tuning_knob("gemm_bf16x3", &g_gemm_bf16x3, 0);
 
 struct PlanRow {
     long M;
@@ -3004,6 +3065,18 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
         if (timed) hipExtLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, ev0, ev1, 0, a); \
         else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE>), grid, dim3(256), dyn, s, a);                       \
     } while (0)
+#define MNK_IGEMM_MODE_H(KERNEL, MODE, ...)                                                                        \
+    do {                                                                                                           \
+        if (timed) hipExtLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE, 1>), grid, dim3(256), dyn, s, ev0, ev1, 0, a); \
+        else hipLaunchKernelGGL((KERNEL<__VA_ARGS__, MODE, 1>), grid, dim3(256), dyn, s, a);                       \
+    } while (0)
+#define MNK_IGEMM_H(KERNEL, ...)                                      \
+    do {                                                              \
+        if (mode == 1) MNK_IGEMM_MODE_H(KERNEL, 1, __VA_ARGS__);      \
+        else if (mode == 2) MNK_IGEMM_MODE_H(KERNEL, 2, __VA_ARGS__); \
+        else if (mode == 3) MNK_IGEMM_MODE_H(KERNEL, 3, __VA_ARGS__); \
+        else MNK_IGEMM_MODE_H(KERNEL, 0, __VA_ARGS__);                \
+    } while (0)
 #define MNK_IGEMM(KERNEL, ...)                                      \
     do {                                                            \
         if (mode == 1) MNK_IGEMM_MODE(KERNEL, 1, __VA_ARGS__);      \
@@ -3015,6 +3088,16 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
             MNK_IGEMM(conv3x3_igemm16_kernel, 16);
         else if (p.bn == 48)
             MNK_IGEMM(conv3x3_igemm16_kernel, 48);
+        else if (g_gemm_bf16x3 && p.bn == 128 && p.bm == 128)
+            MNK_IGEMM_H(conv3x3_igemm_kernel, 128, 128, 2, 2);
+        else if (g_gemm_bf16x3 && p.bn == 128)
+            MNK_IGEMM_H(conv3x3_igemm_kernel, 64, 128, 1, 4);
+        else if (g_gemm_bf16x3 && p.bn == 64 && p.bm == 128)
+            MNK_IGEMM_H(conv3x3_igemm_kernel, 128, 64, 2, 2);
+        else if (g_gemm_bf16x3 && p.bn == 64)
+            MNK_IGEMM_H(conv3x3_igemm_kernel, 64, 64, 2, 2);
+        else if (g_gemm_bf16x3)
+            MNK_IGEMM_H(conv3x3_igemm_kernel, 128, 32, 4, 1);
         else if (p.bn == 128 && p.bm == 128)
             MNK_IGEMM(conv3x3_igemm_kernel, 128, 128, 2, 2);
         else if (p.bn == 128)
@@ -3027,6 +3110,8 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
             MNK_IGEMM(conv3x3_igemm_kernel, 128, 32, 4, 1);
 #undef MNK_IGEMM
 #undef MNK_IGEMM_MODE
+#undef MNK_IGEMM_H
+#undef MNK_IGEMM_MODE_H
     }
     if (p.splits > 1 && !defer_splitk) {
         ProfScope prof(K_CONV_REDUCE, s, (double)p.splits * a.M * p.ldw * 4);

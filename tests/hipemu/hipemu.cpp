@@ -17,7 +17,7 @@ dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
 namespace {
 constexpr size_t kStack = 96 * 1024;
 constexpr int kMaxWaves = 16;
-constexpr int kSlots = 3;
+constexpr int kSlots = 11;      // 0: shuffles / ballots, 1-2: fp32 MFMA operands, 3-10: the eight dwords of a bf16 MFMA
 
 #if defined(__x86_64__)
 extern "C" void hipemu_switch(void** save_sp, void* load_sp);
@@ -97,7 +97,7 @@ struct Fiber {
     bool done = false;
     unsigned lin = 0;
     dim3 tid;
-    unsigned slot_ctr[kSlots] = {0, 0, 0};
+    unsigned slot_ctr[kSlots] = {};
 };
 
 struct BlockState {

@@ -41,6 +41,10 @@ struct int4 { int x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+struct uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 typedef void* hipStream_t;
 typedef struct hipemu_event* hipEvent_t;
@@ -226,6 +230,36 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float 
         int col = (int)(l & 31);
         float acc = c[r];
         for (int k = 0; k < 2; ++k) acc = fmaf(fa[row + 32 * k], fb[col + 32 * k], acc);
+        c[r] = acc;
+    }
+    return c;
+}
+// v_mfma_f32_32x32x16_bf16 (gfx950): lane l holds A[i = l&31][k = 8*(l>>5) .. +7] and B[k = 8*(l>>5) .. +7][j = l&31] as eight
+// bf16 (four dwords); D as the 32x32x2 form.  Every bf16 x bf16 product is exact in fp32; the matrix core adds the sixteen
+// products of an output element and the accumulator in fp32 -- modelled as a k-ordered fmaf chain (the hardware's internal
+// order is not documented; the kernels' tests compare against fp64 with tolerances, not bit for bit).
+typedef unsigned short hipemu_u16x8 __attribute__((vector_size(16)));
+static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_u16x8 a, hipemu_u16x8 b, hipemu_f32x16 c, int, int, int) {
+    uint32_t wa[4], wb[4];
+    memcpy(wa, &a, 16);
+    memcpy(wb, &b, 16);
+    unsigned l = hipemu::lane_id();
+    const uint32_t* pa[4];
+    const uint32_t* pb[4];
+    for (int d = 0; d < 4; ++d) pa[d] = hipemu::wave_publish(wa[d], 3 + d);
+    for (int d = 0; d < 4; ++d) pb[d] = hipemu::wave_publish(wb[d], 7 + d);
+    auto elem = [](const uint32_t* const* p, int lane, int e) {      // bf16 e (0..7) of a lane as float
+        const uint32_t w = p[e >> 1][lane];
+        const uint32_t u = (e & 1) ? (w & 0xffff0000u) : (w << 16);
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (int)(l >> 5);
+        int col = (int)(l & 31);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(elem(pa, row + 32 * (k >> 3), k & 7), elem(pb, col + 32 * (k >> 3), k & 7), acc);
         c[r] = acc;
     }
     return c;

@@ -6,6 +6,16 @@ import torch.nn.functional as F
 
 from _util import to_nhwc, from_nhwc, ceil4, relerr, maxerr
 
+@pytest.fixture(params=["f32-mfma", "bf16x3"], autouse=True)
+def gemm_mode(request, be):
+    """every test of this file runs twice: the forward / data-gradient GEMMs on v_mfma_f32_32x32x2_f32 and on the bf16 matrix
+    cores through the exact three-way split of both fp32 operands (tuning value gemm_bf16x3; csrc/mnk_common.h) -- the SAME
+    tolerances against fp64 in both modes: the split form is an fp32-accurate product, not a reduced-precision one"""
+    be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 1 if request.param == "bf16x3" else 0)
+    yield request.param
+    be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 0)
+
+
 CASES = [
     # N, H, W, C0, C1, Cout, ups, bias, residual
     (2, 8, 8, 3, 0, 20, 0, True, False),

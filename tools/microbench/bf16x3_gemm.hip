@@ -45,6 +45,22 @@ __device__ __forceinline__ void split3(float x, unsigned short& h, unsigned shor
     l = bf16_rn(r - bf16_f(m));
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// float4 -> three planes of four bf16 (two packed dwords each), a = h + m + l exactly up to the last plane's rounding
+__device__ __forceinline__ void split3_x4(float4 v, uint2 (&out)[3]) {
+    f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        const bf16x2 a = __builtin_convertvector(lo, bf16x2), b = __builtin_convertvector(hi, bf16x2);
+        out[pl] = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+        if (pl < 2) {
+            lo = lo - __builtin_convertvector(a, f32x2);
+            hi = hi - __builtin_convertvector(b, f32x2);
+        }
+    }
+}
+
 constexpr int BM = 64, BN = 64;
 
 // ---- fp32 MFMA ---------------------------------------------------------------------------------------------------------------
@@ -161,20 +177,16 @@ __global__ void __launch_bounds__(256) gemm_bf16x3(const void* __restrict__ Av, 
         } else {
 #pragma unroll
             for (int p = 0; p < PASS4; ++p) {
-                const float xa[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w}, xb[4] = {rb[p].x, rb[p].y, rb[p].z, rb[p].w};
-                unsigned short ha[3][4], hb[3][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    split3(xa[e], ha[0][e], ha[1][e], ha[2][e]);
-                    split3(xb[e], hb[0][e], hb[1][e], hb[2][e]);
-                }
+                // the hardware conversion (v_cvt_pk_bf16_f32, round to nearest even) on float pairs: 3 conversions, 4 and / shift
+                // and 2 packed subtractions per PAIR -- 4.5 vector instructions per element
+                uint2 ha[3], hb[3];
+                split3_x4(ra[p], ha);
+                split3_x4(rb[p], hb);
                 const int row = lr4 + p * ROWS4;
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) {
-                    *reinterpret_cast<uint2*>(&As[buf][pl][row][lc4 * 4]) =
-                        make_uint2(ha[pl][0] | ((unsigned)ha[pl][1] << 16), ha[pl][2] | ((unsigned)ha[pl][3] << 16));
-                    *reinterpret_cast<uint2*>(&Bs[buf][pl][row][lc4 * 4]) =
-                        make_uint2(hb[pl][0] | ((unsigned)hb[pl][1] << 16), hb[pl][2] | ((unsigned)hb[pl][3] << 16));
+                    *reinterpret_cast<uint2*>(&As[buf][pl][row][lc4 * 4]) = ha[pl];
+                    *reinterpret_cast<uint2*>(&Bs[buf][pl][row][lc4 * 4]) = hb[pl];
                 }
             }
         }
