@@ -2521,6 +2521,10 @@ static int g_mfma16 = tuning_knob("mfma16", &g_mfma16, 1);
 // 1: the 32x32-tile implicit-GEMM kernels (forward / data gradient) run their products on the bf16 matrix cores through the exact
 // three-way split of both fp32 operands (conv3x3_igemm_kernel<..., GM = 1>, mnk_common.h); 0: v_mfma_f32_32x32x2_f32
 static int g_gemm_bf16x3 = tuning_knob("gemm_bf16x3", &g_gemm_bf16x3, 0);
+// with gemm_bf16x3: 33 .. 48 output channels (the 45-channel refinement stack) take the 64-wide 32x32-tile kernel -- 45 of 64
+// columns at 2.67x the matrix rate -- instead of the 48-wide 16x16x4 fp32 kernel (0: keep that kernel)
+static int g_gemm_bf16x3_n48 = tuning_knob("gemm_bf16x3_n48", &g_gemm_bf16x3_n48, 1);
+static bool narrow48_on_wide_tiles() { return g_gemm_bf16x3 && g_gemm_bf16x3_n48; }
 
 struct PlanRow {
     long M;
@@ -2535,6 +2539,7 @@ static long g_last_plan[8];
 
 // block tiles the GEMM kernels are instantiated for (conv2d_fwd_impl's dispatch)
 static bool plan_tile_ok(int bm, int bn, int Cout, int phases) {
+    if (bn == 48 && narrow48_on_wide_tiles()) return false;
     if (bn == 16 || bn == 48) return bm == 128 && phases == 1 && g_mfma16 && Cout <= bn;
     if (bn == 32) return bm == 128;
     return (bn == 64 || bn == 128) && (bm == 64 || bm == 128);
@@ -2546,7 +2551,7 @@ static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 
     p.bn = Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
     if (g_mfma16 && phases == 1) {   // narrow outputs: 16x16x4 MFMA tiles (BN = 16 / 48), see conv3x3_igemm16_kernel
         if (Cout <= 16) p.bn = 16;
-        else if (Cout > 32 && Cout <= 48) p.bn = 48;
+        else if (Cout > 32 && Cout <= 48 && !narrow48_on_wide_tiles()) p.bn = 48;
     }
     // measured on the MI355X over both benchmark configurations' layer shapes (tools/plan_tune.py, profiles/r02_plan_tune_*.txt):
     // the 64x64 tile (56 registers, 20 KB of LDS: 8 blocks per CU) is the fastest instantiation for every layer wider than
