@@ -2521,9 +2521,10 @@ static int g_mfma16 = tuning_knob("mfma16", &g_mfma16, 1);
 // 1: the 32x32-tile implicit-GEMM kernels (forward / data gradient) run their products on the bf16 matrix cores through the exact
 // three-way split of both fp32 operands (conv3x3_igemm_kernel<..., GM = 1>, mnk_common.h); 0: v_mfma_f32_32x32x2_f32
 static int g_gemm_bf16x3 = tuning_knob("gemm_bf16x3", &g_gemm_bf16x3, 0);
-// with gemm_bf16x3: 33 .. 48 output channels (the 45-channel refinement stack) take the 64-wide 32x32-tile kernel -- 45 of 64
-// columns at 2.67x the matrix rate -- instead of the 48-wide 16x16x4 fp32 kernel (0: keep that kernel)
-static int g_gemm_bf16x3_n48 = tuning_knob("gemm_bf16x3_n48", &g_gemm_bf16x3_n48, 1);
+// with gemm_bf16x3, 1: 33 .. 48 output channels (the 45-channel refinement stack) take the 64-wide 32x32-tile kernel -- 45 of 64
+// columns at 2.67x the matrix rate -- instead of the 48-wide 16x16x4 fp32 kernel.  Measured SLOWER (10.08 vs 9.92 ms per step,
+// profiles/r06_knob_ab_log.txt): 0 keeps the 16x16 kernel
+static int g_gemm_bf16x3_n48 = tuning_knob("gemm_bf16x3_n48", &g_gemm_bf16x3_n48, 0);
 static bool narrow48_on_wide_tiles() { return g_gemm_bf16x3 && g_gemm_bf16x3_n48; }
 
 struct PlanRow {
