@@ -291,6 +291,23 @@ def test_full_training_iteration_mnk_adam_pipeline_against_reference_and_oracle(
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fullstep_moving-gif_b32", "fullstep_taichi_b32"])
+def test_full_training_iteration_with_the_gemms_on_the_bf16_matrix_cores(name):
+    """(round 6) the full-iteration checker through the benchmarked pipeline with `gemm_bf16x3` = 1: the forward / data-gradient
+    GEMMs of the 32x32-tile kernels as six bf16 MFMAs per K step on the exact three-way split of both fp32 operands
+    (csrc/mnk_common.h).  The SAME tolerances as the fp32-MFMA run above: losses, frames, key points, every parameter gradient
+    at each of the three optimiser steps against the reference's fp64 run."""
+    from conftest import Backend
+    be = Backend("hip")
+    be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 1)
+    try:
+        checked, report = _full_iteration(be, load(name), name + "_mnkadam_bf16x3", fused_adam=True)
+    finally:
+        be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 0)
+    assert checked > 120
+
+
+@pytest.mark.gpu
 def test_vox_at_256_batch_8():
     """config/vox.yaml at 256x256, batch 8 -- the per-GPU share of BASELINE configs[3] (batch 64 over 8 GPUs) that bench.py's
     vox line is quoted on (vox256.pt above is batch 2).  Golden frames are kept at every 2nd pixel (oracle/make_golden_full.py::

@@ -583,3 +583,4 @@ def test_data_gradient_leaves_the_backward_statistics_of_the_norm_layer_in_front
     assert float((got - want).abs().max()) <= tol, (float((got - want).abs().max()), tol)
     if slope in (0.0, -1.0):
         assert float((got - ref_sums.cpu().double()).abs().max()) <= tol
+
