@@ -39,7 +39,8 @@ One JSON line is printed by rank 0:  metric = train frames/sec (one frame = one 
                    kernel time of this run / 8 TB/s, `traffic` = counter bytes of the round's PMC passes when they were made
                    on these very sources;
   extra         -- the other single-GPU BASELINE configurations on the same clock: taichi_b32 (the stack the 0.5 target is
-                   worded on), vox256_b8 (configs[3]'s per-GPU share), bair_b512_infer (configs[4]);
+                   worded on), vox256_b8 (configs[3]'s per-GPU share), bair_b512_infer (configs[4]); bf16x3_gemm: the headline
+                   workload with the opt-in fp32-accurate GEMM form on the bf16 matrix cores (tuning value gemm_bf16x3);
   hot_path_only_ms -- SURVEY section 8a alone (KPDetector + generator forward and backward with every weight gradient
                    materialised; no discriminator, losses or optimiser) as a hipGraph replay, next to the whole step;
   cpu_baseline  -- the CPU oracle (oracle/restate.py, a torch-CPU restatement of the reference; "port") timed on this
@@ -538,6 +539,48 @@ def bair_b512_infer_leg(device, iters=8):
     return res
 
 
+def bf16x3_leg(lib, cfg, x, device, steps):
+    """The SAME workload as the headline with the library's tuning value `gemm_bf16x3` = 1: the forward / data-gradient GEMMs of the
+    32x32-tile implicit-GEMM kernels run their fp32 products on the bf16 matrix cores -- both fp32 operands split exactly into
+    three bf16 terms by the loaders, six v_mfma_f32_32x32x16_bf16 per K step, fp32 accumulation (csrc/mnk_common.h).  An
+    fp32-accurate product (same error against fp64 as the fp32 MFMA chain: tests/test_kernels_conv*.py, tools/microbench/
+    bf16x3_gemm.hip), reported BESIDE the headline, which stays on v_mfma_f32_32x32x2_f32: opt-in until the weight-gradient and
+    16x16-tile kernels have their forms too."""
+    from mnk import engine
+    lib.call("mnk_set_tuning", b"gemm_bf16x3", 1)
+    try:
+        gen, disc, kpd = build_models(cfg, device)
+        step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=True)
+        for _ in range(3):
+            step.step(x)
+        torch.cuda.synchronize(device)
+        n = max(steps, 10)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step.step(x)
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / n
+        b = int(x["source"].shape[0])
+        rec = {"ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(b / dt, 1), "launch": "hipGraph replay",
+               "finite": bool(all(float(v) == float(v) for v in out[0])),
+               "what": "MNK_TUNING=gemm_bf16x3=1: forward / data-gradient GEMMs of the 32x32-tile kernels as six bf16 MFMAs per K step "
+                       "on the exact three-way bf16 split of both fp32 operands (fp32 accumulation; fp32-accurate: same error "
+                       "against fp64 as the fp32 MFMA chain).  Not the headline: opt-in this round"}
+        eager = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
+        eager.step(x)
+        k = prof_collect(lib, lambda: eager.step(x), 2)
+        conv = k.get("conv3x3_igemm")
+        if conv:
+            rec["conv3x3_igemm"] = {"ms_per_step": round(conv["ms_per_step"], 3), "launches_per_step": conv["launches_per_step"],
+                                    "algorithmic_tflops": round(conv["work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12, 2),
+                                    "executed_tflops": round(conv["executed_work_per_step"] / (conv["ms_per_step"] * 1e-3) / 1e12, 2),
+                                    "note": "fp32-equivalent FLOPs; the group still holds the 16x16-tile fp32 launches (45-channel "
+                                            "refinement stack, narrow heads)"}
+        return rec
+    finally:
+        lib.call("mnk_set_tuning", b"gemm_bf16x3", 0)
+
+
 def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):
     """What a user of the reference gets by putting monkey-net_amd/ in front of the reference root and running the reference's
     unmodified train.py: its loop (train.py:78-153), statement for statement as tests/test_dropin_replay.py restates it --
@@ -921,7 +964,8 @@ def main():
         default_workload = args.config == "moving-gif" and args.batch == 32 and args.size == 64
         if args.extra_legs and rank == 0 and default_workload:
             for name, leg in (("vox256_b8", lambda: vox256_b8_leg(lib, device, args.steps)),
-                              ("bair_b512_infer", lambda: bair_b512_infer_leg(device))):
+                              ("bair_b512_infer", lambda: bair_b512_infer_leg(device)),
+                              ("bf16x3_gemm", lambda: bf16x3_leg(lib, cfg, x, device, args.steps))):
                 try:
                     extra[name] = leg()
                 except Exception as e:   # never lose the bench line to an extra leg
