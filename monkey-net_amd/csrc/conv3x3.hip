@@ -2534,6 +2534,9 @@ struct PlanRow {
 static const PlanRow g_tuned_rows[] = {
 #include "plan_table.h"
     {0, 0, 0, 0, 0, 0, 0, 0}};
+static const PlanRow g_tuned_rows_bf16x3[] = {
+#include "plan_table_bf16x3.h"
+    {0, 0, 0, 0, 0, 0, 0, 0}};
 static int g_plan_table = tuning_knob("plan_table", &g_plan_table, 1), g_force_bm = tuning_knob("force_bm", &g_force_bm, 0),
            g_force_bn = tuning_knob("force_bn", &g_force_bn, 0), g_force_splits = tuning_knob("force_splits", &g_force_splits, 0);
 static long g_last_plan[8];
@@ -2588,12 +2591,15 @@ static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 
     // a forced plan (mnk_set_tuning MNK_FORCE_BM / _BN / _SPLITS) is what that sweep drives.  Anything the kernels have no
     // instantiation for keeps the rule's choice.
     int want_bm = 0, want_bn = 0, want_splits = 0;
-    if (g_plan_table)
-        for (const PlanRow* r = g_tuned_rows; r->M; ++r)
-            if (r->M == M && r->Cout == Cout && r->chunks == chunks && r->ntaps == ntaps && r->phases == phases) {
-                want_bm = r->bm, want_bn = r->bn, want_splits = r->splits;
-                break;
-            }
+    if (g_plan_table) {
+        const PlanRow* tables[2] = {g_gemm_bf16x3 ? g_tuned_rows_bf16x3 : g_tuned_rows, g_gemm_bf16x3 ? g_tuned_rows : nullptr};
+        for (int ti = 0; ti < 2 && !want_bm && !want_splits; ++ti)
+            for (const PlanRow* r = tables[ti]; r && r->M; ++r)
+                if (r->M == M && r->Cout == Cout && r->chunks == chunks && r->ntaps == ntaps && r->phases == phases) {
+                    want_bm = r->bm, want_bn = r->bn, want_splits = r->splits;
+                    break;
+                }
+    }
     if (g_force_bm) want_bm = g_force_bm;
     if (g_force_bn) want_bn = g_force_bn;
     if (g_force_splits) want_splits = g_force_splits;
