@@ -2091,6 +2091,234 @@ __device__ __forceinline__ void wgrad_tap_body(const WgradTapArgs& a, const int 
         emit(FalseTag{});
 }
 
+// ---- the tap-major weight gradient on the bf16 matrix cores (round 6; GM = 1 of the forward kernel, mnk_common.h) -------------
+// K = pixels here, and both operands are K-STRIDED in memory (dy [pixel][co], x [pixel][ci]) while a lane of
+// v_mfma_f32_32x32x16_bf16 wants eight consecutive k of ONE channel.  The loader therefore transposes on its way to LDS: a
+// loader thread owns four consecutive pixels x four consecutive channels (four float4 loads, lanes along the channels: coalesced
+// rows), regroups them per channel, splits each float4-of-pixels into three bf16 planes and writes four halves (8 bytes) per
+// plane and channel.  LDS image per plane: 16-byte chunks [k group of 8][channel], chunk(kg, m) = kg * BMP + m + (m >> 4) (one pad
+// chunk per 16 channels: conflict-free b128 fragment reads, 2-way on the writes).  Threads [0, BM) load dy, [BM, BM + BN) load x.
+// Generic addressing only (magic-number divisions, clamps, masks, the compact K of small maps): the split dominates the loader.
+template <int BM, int BN, int WM, int WN, bool SUBPIX>
+__device__ __forceinline__ void wgrad_tap_body_h(const WgradTapArgs& a, const int bx, const int by, const int split) {
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(BM + BN <= 256, "one loader thread per (pixel group, channel quad) of both operands");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int BMP = BM + BM / 16, BNP = BN + BN / 16;
+    __shared__ __attribute__((aligned(16))) uint4 Ah[2][3][2 * BMP];
+    __shared__ __attribute__((aligned(16))) uint4 Bh[2][3][2 * BNP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int co0 = bx * BM;
+    const int tap = by / a.gn;
+    const int ci0 = (by - tap * a.gn) * BN;
+    long p_begin = (long)split * a.pix_per_split;
+    long p_end = p_begin + a.pix_per_split;
+    if (p_end > a.M) p_end = a.M;
+    const int Hs = a.ups ? a.Hi >> 1 : a.Hi, Ws = a.ups ? a.Wi >> 1 : a.Wi;
+    const int ph_a = (tap >> 3) & 1, ph_b = (tap >> 2) & 1;
+    const int dyt = SUBPIX ? ph_a - 1 + ((tap >> 1) & 1) : tap / a.kw - a.pad;
+    const int dxt = SUBPIX ? ph_b - 1 + (tap & 1) : tap % a.kw - a.pad;
+    const int hmax = a.Hi - 1, wmax = a.Wi - 1;
+    const bool compact = a.compact;
+    int ch0 = 0, cw0 = 0, chh = a.H, cww = a.W;
+    float inv_chh = 0.f, inv_cww = 0.f;
+    long Klast = a.M - 1;
+    if (compact) {          // (see wgrad_tap_body)
+        ch0 = dyt < 0 ? -dyt : 0;
+        cw0 = dxt < 0 ? -dxt : 0;
+        int h1 = a.Hi - dyt, w1 = a.Wi - dxt;
+        h1 = h1 > a.H ? a.H : h1;
+        w1 = w1 > a.W ? a.W : w1;
+        chh = h1 > ch0 ? h1 - ch0 : 0;
+        cww = w1 > cw0 ? w1 - cw0 : 0;
+        const long frames = a.M / ((long)a.H * a.W);
+        const long Kt = frames * chh * cww;
+        const long per = ((Kt + a.nsplits - 1) / a.nsplits + BK - 1) / BK * BK;
+        p_begin = (long)split * per;
+        p_end = p_begin + per;
+        if (p_end > Kt) p_end = Kt;
+        if (p_begin > p_end) p_begin = p_end;
+        Klast = Kt > 0 ? Kt - 1 : 0;
+        inv_chh = chh > 0 ? 1.f / (float)chh : 0.f;
+        inv_cww = cww > 0 ? 1.f / (float)cww : 0.f;
+    }
+    const unsigned plast = (unsigned)Klast, pend = (unsigned)p_end;
+    auto unpack = [&](unsigned k, unsigned& n, unsigned& i, unsigned& j) __attribute__((always_inline)) {
+        const unsigned q = (unsigned)(((float)k + 0.5f) * inv_cww);
+        j = k - q * (unsigned)cww + (unsigned)cw0;
+        n = (unsigned)(((float)q + 0.5f) * inv_chh);
+        i = q - n * (unsigned)chh + (unsigned)ch0;
+    };
+    // loader role: A (dy) threads [0, BM), B (x) threads [BM, BM + BN)
+    const bool is_a = t < BM, is_b = !is_a && t < BM + BN;
+    const int u = is_a ? t : t - BM;
+    const int quads = is_a ? BM / 4 : BN / 4;
+    const int cq = u % quads, pg = u / quads;                 // channel quad, pixel group (4 pixels) of the 16-pixel K step
+    const int ch = (is_a ? co0 : ci0) + cq * 4;
+    const int tail = (is_a ? a.Cout : a.C) - ch;               // real channels of the quad (<= 0: none)
+    const unsigned ch_e = tail > 0 ? (unsigned)ch : 0u;
+
+    float4 rv[4];
+    int rt[4];
+    auto load_one = [&](unsigned p, float4& v, int& tl) __attribute__((always_inline)) {
+        const unsigned pe = p < plast ? p : plast;
+        tl = p < pend ? tail : 0;
+        unsigned n, i, j;
+        if (compact) {
+            unpack(pe, n, i, j);
+        } else {
+            const unsigned q = fast_div(pe, a.mulW, a.shW);
+            j = pe - q * (unsigned)a.W;
+            n = fast_div(q, a.mulH, a.shH);
+            i = q - n * (unsigned)a.H;
+        }
+        if (is_a) {
+            const unsigned long row = SUBPIX ? ((unsigned long)(n * (unsigned)a.H + i) * 2u + (unsigned)ph_a) * (2u * (unsigned)a.W) + 2u * j + (unsigned)ph_b
+                                             : (unsigned long)(n * (unsigned)a.H + i) * (unsigned)a.W + j;
+            v = *reinterpret_cast<const float4*>(a.dy + row * (unsigned)a.ld_dy + ch_e);
+        } else {
+            int hh = (int)i + dyt, ww = (int)j + dxt;
+            const bool ok = hh >= 0 && hh <= hmax && ww >= 0 && ww <= wmax;
+            hh = hh < 0 ? 0 : (hh > hmax ? hmax : hh);
+            ww = ww < 0 ? 0 : (ww > wmax ? wmax : ww);
+            if (!ok) tl = 0;
+            const unsigned pix = (n * (unsigned)Hs + (unsigned)(hh >> a.ups)) * (unsigned)Ws + (unsigned)(ww >> a.ups);
+            v = *reinterpret_cast<const float4*>(a.x + (unsigned long)pix * (unsigned)a.ld_x + ch_e);
+        }
+    };
+    auto load_step = [&](long p0) __attribute__((always_inline)) {
+        if (is_a || is_b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_one((unsigned)p0 + 4 * pg + i, rv[i], rt[i]);
+        }
+    };
+    auto store_step = [&](int buf) __attribute__((always_inline)) {
+        if (!(is_a || is_b)) return;
+        float m[4][4];          // [pixel][channel of the quad], masked
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[i][0] = rt[i] < 1 ? 0.f : rv[i].x;
+            m[i][1] = rt[i] < 2 ? 0.f : rv[i].y;
+            m[i][2] = rt[i] < 3 ? 0.f : rv[i].z;
+            m[i][3] = rt[i] < 4 ? 0.f : rv[i].w;
+        }
+        const int rowbase = cq * 4, kg = pg >> 1, half = pg & 1;
+        uint4* const planes = is_a ? &Ah[buf][0][0] : &Bh[buf][0][0];
+        const int pstride = is_a ? 2 * BMP : 2 * BNP, kstride = is_a ? BMP : BNP;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint2 p0, p1, p2;
+            mnk_split3(make_float4(m[0][e], m[1][e], m[2][e], m[3][e]), p0, p1, p2);
+            const int row = rowbase + e;
+            const int chunk = kg * kstride + row + (row >> 4);
+            reinterpret_cast<uint2*>(planes + chunk)[half] = p0;
+            reinterpret_cast<uint2*>(planes + pstride + chunk)[half] = p1;
+            reinterpret_cast<uint2*>(planes + 2 * pstride + chunk)[half] = p2;
+        }
+    };
+
+    constexpr int NACC = (TM * TN == 1) ? 2 : 1;
+    f32x16 acc[NACC][TM][TN];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+    const int fi = lane & 31, fk = lane >> 5;
+    auto mfma_step = [&](int buf) __attribute__((always_inline)) {
+        mnk_bf16x8 ha[3][TM], hb[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * (32 * TM) + 32 * i + fi;
+                ha[pl][i] = mnk_as_bf16x8(Ah[buf][pl][fk * BMP + row + (row >> 4)]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (32 * TN) + 32 * j + fi;
+                hb[pl][j] = mnk_as_bf16x8(Bh[buf][pl][fk * BNP + row + (row >> 4)]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                constexpr int Q = NACC - 1;
+                acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[1][i], hb[1][j], acc[0][i][j], 0, 0, 0);
+                acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[2][i], hb[0][j], acc[Q][i][j], 0, 0, 0);
+                acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[0][i], hb[2][j], acc[0][i][j], 0, 0, 0);
+                acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[1][i], hb[0][j], acc[Q][i][j], 0, 0, 0);
+                acc[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[0][i], hb[1][j], acc[0][i][j], 0, 0, 0);
+                acc[Q][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[0][i], hb[0][j], acc[Q][i][j], 0, 0, 0);
+            }
+    };
+
+    if (p_begin < p_end) {
+        load_step(p_begin);
+        store_step(0);
+        if (p_begin + BK < p_end) load_step(p_begin + BK);
+    }
+    __syncthreads();
+    long p0 = p_begin;
+    int it = 0;
+    for (; p0 + 2 * BK < p_end; p0 += BK, ++it) {
+        const int buf = it & 1;
+        store_step(buf ^ 1);
+        load_step(p0 + 2 * BK);
+        mfma_step(buf);
+        __syncthreads();
+    }
+    if (p0 + BK < p_end) {
+        const int buf = it & 1;
+        store_step(buf ^ 1);
+        mfma_step(buf);
+        __syncthreads();
+        p0 += BK;
+        ++it;
+    }
+    if (p0 < p_end) mfma_step(it & 1);
+    if constexpr (NACC == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][0][r] += acc[1][0][0][r];
+    }
+
+    float* outp = a.part + ((long)split * a.ntaps + tap) * a.Cout * a.C;
+    const unsigned Cu = (unsigned)a.C, corow0 = (unsigned)co0 + wm * (32 * TM) + 4 * fk;
+    auto emit = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const unsigned ci = (unsigned)ci0 + wn * (32 * TN) + 32 * j + fi;
+                const unsigned cb = corow0 + 32 * i, off0 = cb * Cu + ci;
+                if (ci < Cu) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned ro = (r & 3) + 8 * (r >> 2);
+                        if (FULL || cb + ro < (unsigned)a.Cout) outp[off0 + ro * Cu] = acc[0][i][j][r];
+                    }
+                }
+            }
+    };
+    if (co0 + BM <= a.Cout)
+        emit(TrueTag{});
+    else
+        emit(FalseTag{});
+}
+
+template <int BM, int BN, int WM, int WN, bool SUBPIX>
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_tap_h_kernel(WgradTapArgs a) {
+    int bx, by;
+    xcd_tile(a.xcd, bx, by);
+    wgrad_tap_body_h<BM, BN, WM, WN, SUBPIX>(a, bx, by, (int)blockIdx.z);
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_kernel(WgradTapArgs a) {
     int bx, by;
@@ -2129,6 +2357,24 @@ __global__ void __launch_bounds__(256, 3) conv3x3_wgrad_tap_grouped_kernel(const
     const int bx = local % gm, rest = local / gm;
     const int by = rest % gnt, split = rest / gnt;
     wgrad_tap_body<BM, BN, WM, WN, MODE>(a, bx, by, split);
+}
+
+template <int BM, int BN, int WM, int WN, bool SUBPIX>
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_tap_grouped_h_kernel(const TapJobRec* __restrict__ recs, int n) {
+    __shared__ int sh_idx;
+    int b = blockIdx.x;
+    {
+        const unsigned total = gridDim.x, L = blockIdx.x, c = L & 7u, base = total >> 3, rem = total & 7u;
+        if (total >= 64) b = (int)(c * base + (c < rem ? c : rem) + (L >> 3));
+    }
+    const int di = find_desc(&recs[0].block_begin, (int)(sizeof(TapJobRec) / sizeof(int)), n, b, &sh_idx);
+    const TapJobRec* __restrict__ rp = recs + __builtin_amdgcn_readfirstlane(di);
+    const WgradTapArgs a = rp->a;
+    const int local = b - rp->block_begin;
+    const int gm = rp->gm, gnt = rp->gnt;
+    const int bx = local % gm, rest = local / gm;
+    const int by = rest % gnt, split = rest / gnt;
+    wgrad_tap_body_h<BM, BN, WM, WN, SUBPIX>(a, bx, by, split);
 }
 
 // the nine-tap 16x16 kernel for MANY narrow layers in one launch (the eight 45 -> 45 convolutions of the refinement stack:
@@ -2524,6 +2770,8 @@ static int g_gemm_bf16x3 = tuning_knob("gemm_bf16x3", &g_gemm_bf16x3, 0);
 // with gemm_bf16x3, 1: 33 .. 48 output channels (the 45-channel refinement stack) take the 64-wide 32x32-tile kernel -- 45 of 64
 // columns at 2.67x the matrix rate -- instead of the 48-wide 16x16x4 fp32 kernel.  Measured SLOWER (10.08 vs 9.92 ms per step,
 // profiles/r06_knob_ab_log.txt): 0 keeps the 16x16 kernel
+// 1: the tap-major weight-gradient kernels on the bf16 matrix cores too (wgrad_tap_body_h: transposing loader)
+static int g_wgrad_bf16x3 = tuning_knob("wgrad_bf16x3", &g_wgrad_bf16x3, 0);
 static int g_gemm_bf16x3_n48 = tuning_knob("gemm_bf16x3_n48", &g_gemm_bf16x3_n48, 0);
 static bool narrow48_on_wide_tiles() { return g_gemm_bf16x3 && g_gemm_bf16x3_n48; }
 
@@ -3232,7 +3480,16 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
             {
                 ProfScope prof(K_CONV_WGRAD, st, 2.0 * (double)N * Ho * Wo * Cout * 9.0 * C,       // 16 pseudo taps at the low resolution
                                g.compact ? 2.0 * tap_compact_pairs(N, Hl, Wl, 1) * Cout * C : 2.0 * (double)g.M * Cout * 16.0 * C);
-                if (up.bm == 128 && up.bn == 128)
+                if (g_wgrad_bf16x3) {
+                    if (up.bm == 128 && up.bn == 128)
+                        hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, g);
+                    else if (up.bm == 128)
+                        hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<128, 64, 2, 2, true>), grid, dim3(256), 0, st, g);
+                    else if (up.bm == 64)
+                        hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<64, 128, 1, 4, true>), grid, dim3(256), 0, st, g);
+                    else
+                        hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<32, 128, 1, 4, true>), grid, dim3(256), 0, st, g);
+                } else if (up.bm == 128 && up.bn == 128)
                     hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
                 else if (up.bm == 128)
                     hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<128, 64, 2, 2, 3>), grid, dim3(256), 0, st, g);
@@ -3306,7 +3563,16 @@ int mnk_conv2d_wgrad(const float* x, int ld_x, int C, int flags, int Hi, int Wi,
         else if (mode == 2) hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<__VA_ARGS__, 2>), grid, dim3(256), 0, st, g); \
         else hipLaunchKernelGGL((conv3x3_wgrad_tap_kernel<__VA_ARGS__, 0>), grid, dim3(256), 0, st, g);                \
     } while (0)
-            if (tp.bm == 128 && tp.bn == 128)
+            if (g_wgrad_bf16x3) {       // (one generic-loader form per tile: `mode` only selects among the fp32 kernels)
+                if (tp.bm == 128 && tp.bn == 128)
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, g);
+                else if (tp.bm == 128)
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<128, 64, 2, 2, false>), grid, dim3(256), 0, st, g);
+                else if (tp.bm == 64)
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<64, 128, 1, 4, false>), grid, dim3(256), 0, st, g);
+                else
+                    hipLaunchKernelGGL((conv3x3_wgrad_tap_h_kernel<32, 128, 1, 4, false>), grid, dim3(256), 0, st, g);
+            } else if (tp.bm == 128 && tp.bn == 128)
                 MNK_WTAP(128, 128, 2, 2);
             else if (tp.bm == 128)
                 MNK_WTAP(128, 64, 2, 2);
@@ -3718,12 +3984,26 @@ int mnk_wgrad_grouped_launch(const void* device_table, const void* host_table, v
         else if (mode == 3) hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 3>), dim3(blocks), dim3(256), 0, st, rv, cnt); \
         else hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_kernel<__VA_ARGS__, 0>), dim3(blocks), dim3(256), 0, st, rv, cnt);                \
     } while (0)
+#define MNK_WGROUP_H(...)                                                                                                     \
+    do {                                                                                                                      \
+        if (mode == 3) hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_h_kernel<__VA_ARGS__, true>), dim3(blocks), dim3(256), 0, st, rv, cnt);  \
+        else hipLaunchKernelGGL((conv3x3_wgrad_tap_grouped_h_kernel<__VA_ARGS__, false>), dim3(blocks), dim3(256), 0, st, rv, cnt);           \
+    } while (0)
+        if (g_wgrad_bf16x3) {
+            switch (v / 4) {
+                case 0: MNK_WGROUP_H(128, 128, 2, 2); break;
+                case 1: MNK_WGROUP_H(128, 64, 2, 2); break;
+                case 2: MNK_WGROUP_H(64, 128, 1, 4); break;
+                default: MNK_WGROUP_H(32, 128, 1, 4); break;
+            }
+        } else
         switch (v / 4) {
             case 0: MNK_WGROUP(128, 128, 2, 2); break;
             case 1: MNK_WGROUP(128, 64, 2, 2); break;
             case 2: MNK_WGROUP(64, 128, 1, 4); break;
             default: MNK_WGROUP(32, 128, 1, 4); break;
         }
+#undef MNK_WGROUP_H
 #undef MNK_WGROUP
     }
     for (int v = 16; v < 25; ++v) {

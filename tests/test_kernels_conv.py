@@ -11,9 +11,12 @@ def gemm_mode(request, be):
     """every test of this file runs twice: the forward / data-gradient GEMMs on v_mfma_f32_32x32x2_f32 and on the bf16 matrix
     cores through the exact three-way split of both fp32 operands (tuning value gemm_bf16x3; csrc/mnk_common.h) -- the SAME
     tolerances against fp64 in both modes: the split form is an fp32-accurate product, not a reduced-precision one"""
-    be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 1 if request.param == "bf16x3" else 0)
+    on = 1 if request.param == "bf16x3" else 0
+    be.lib.call("mnk_set_tuning", b"gemm_bf16x3", on)
+    be.lib.call("mnk_set_tuning", b"wgrad_bf16x3", on)       # the tap-major weight-gradient kernels' form (transposing loader)
     yield request.param
     be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 0)
+    be.lib.call("mnk_set_tuning", b"wgrad_bf16x3", 0)
 
 
 CASES = [
