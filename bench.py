@@ -546,14 +546,16 @@ def bair_b512_infer_leg(device, iters=8):
 
 
 def bf16x3_leg(lib, cfg, x, device, steps):
-    """The SAME workload as the headline with the library's tuning value `gemm_bf16x3` = 1: the forward / data-gradient GEMMs of the
-    32x32-tile implicit-GEMM kernels run their fp32 products on the bf16 matrix cores -- both fp32 operands split exactly into
+    """The SAME workload as the headline with the library's tuning values `gemm_bf16x3` = `wgrad_bf16x3` = 1: the forward /
+    data-gradient GEMMs of the 32x32-tile implicit-GEMM kernels and the tap-major weight-gradient GEMMs run their fp32 products on
+    the bf16 matrix cores -- both fp32 operands split exactly into
     three bf16 terms by the loaders, six v_mfma_f32_32x32x16_bf16 per K step, fp32 accumulation (csrc/mnk_common.h).  An
     fp32-accurate product (same error against fp64 as the fp32 MFMA chain: tests/test_kernels_conv*.py, tools/microbench/
     bf16x3_gemm.hip), reported BESIDE the headline, which stays on v_mfma_f32_32x32x2_f32: opt-in until the weight-gradient and
     16x16-tile kernels have their forms too."""
     from mnk import engine
     lib.call("mnk_set_tuning", b"gemm_bf16x3", 1)
+    lib.call("mnk_set_tuning", b"wgrad_bf16x3", 1)
     try:
         gen, disc, kpd = build_models(cfg, device)
         step = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=True)
@@ -569,9 +571,10 @@ def bf16x3_leg(lib, cfg, x, device, steps):
         b = int(x["source"].shape[0])
         rec = {"ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(b / dt, 1), "launch": "hipGraph replay",
                "finite": bool(all(float(v) == float(v) for v in out[0])),
-               "what": "MNK_TUNING=gemm_bf16x3=1: forward / data-gradient GEMMs of the 32x32-tile kernels as six bf16 MFMAs per K step "
-                       "on the exact three-way bf16 split of both fp32 operands (fp32 accumulation; fp32-accurate: same error "
-                       "against fp64 as the fp32 MFMA chain).  Not the headline: opt-in this round"}
+               "what": "MNK_TUNING=gemm_bf16x3=1,wgrad_bf16x3=1: the forward / data-gradient GEMMs of the 32x32-tile kernels and the "
+                       "tap-major weight-gradient GEMMs as six bf16 MFMAs per K step on the exact three-way bf16 split of both fp32 "
+                       "operands (fp32 accumulation; fp32-accurate: same error against fp64 as the fp32 MFMA chain).  Not the "
+                       "headline: opt-in this round"}
         eager = engine.TrainStep(gen, disc, kpd, cfg["train_params"], use_graph=False)
         for o in (eager.opt_g, eager.opt_d, eager.opt_k):
             if hasattr(o, "reducer"):
@@ -588,6 +591,7 @@ def bf16x3_leg(lib, cfg, x, device, steps):
         return rec
     finally:
         lib.call("mnk_set_tuning", b"gemm_bf16x3", 0)
+        lib.call("mnk_set_tuning", b"wgrad_bf16x3", 0)
 
 
 def dropin_loop(cfg, x, device, steps, warmup, mnk_adam=False):

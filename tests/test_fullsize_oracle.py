@@ -300,10 +300,12 @@ def test_full_training_iteration_with_the_gemms_on_the_bf16_matrix_cores(name):
     from conftest import Backend
     be = Backend("hip")
     be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 1)
+    be.lib.call("mnk_set_tuning", b"wgrad_bf16x3", 1)        # ... and the tap-major weight-gradient GEMMs
     try:
         checked, report = _full_iteration(be, load(name), name + "_mnkadam_bf16x3", fused_adam=True)
     finally:
         be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 0)
+        be.lib.call("mnk_set_tuning", b"wgrad_bf16x3", 0)
     assert checked > 120
 
 
