@@ -787,11 +787,20 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
 // 32x32 kernel above.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BN, int MODE>
+// GM = 1 (round 6): the products on the bf16 matrix cores (mnk_common.h).  v_mfma_f32_16x16x32_bf16 spans K = 32 = TWO K steps:
+// the loop works on PAIRS of steps -- step 2p lands in LDS buffer 0, step 2p + 1 in buffer 1 (zeros behind an odd count), lane
+// (fi, fk) reads k = 8 fk .. 8 fk + 7 of its row from buffer fk >> 1 -- six MFMAs per 16x16 tile and pair.  Two register stages
+// hold the next pair while the MFMAs of this one run; two barriers per pair.
+template <int BN, int MODE, int GM = 0>
 __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     constexpr int BM = 128, RA = 2, TM = 2, TN = BN / 16;
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_K];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_K];
+    constexpr int NSTG = GM ? 2 : 1;
+    constexpr int A_BYTES = GM ? 2 * 3 * BM * LDS_H * 2 : 2 * BM * LDS_K * 4, B_BYTES = GM ? 2 * 3 * BN * LDS_H * 2 : 2 * BN * LDS_K * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_a[A_BYTES], smem_b[B_BYTES];
+    float (*const As)[BM][LDS_K] = reinterpret_cast<float (*)[BM][LDS_K]>(smem_a);
+    float (*const Bs)[BN][LDS_K] = reinterpret_cast<float (*)[BN][LDS_K]>(smem_b);
+    unsigned short (*const Ah)[3][BM][LDS_H] = reinterpret_cast<unsigned short (*)[3][BM][LDS_H]>(smem_a);
+    unsigned short (*const Bh)[3][BN][LDS_H] = reinterpret_cast<unsigned short (*)[3][BN][LDS_H]>(smem_b);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int bx, by;
     xcd_tile(a.xcd, bx, by);
@@ -802,12 +811,12 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     int s_end = s_begin + a.ksteps_per_split;
     if (s_end > a.ksteps) s_end = a.ksteps;
     const int lrow = t >> 2, lq = t & 3;
-    typename LoaderSel<RA, MODE>::type L;
+    typename LoaderSel<RA, MODE, NSTG>::type L;
     L.setup(a, m0, lrow, lq, s_begin, a.pad, a.pad_x < 0 ? a.pad : a.pad_x);
     const long KT = (long)a.ksteps * BK;
     const int wco = n0 + (lrow < BN ? lrow : 0);           // rows beyond BN / Cout: clamped, never stored
     const unsigned woff = (unsigned)((wco < a.Cout ? wco : a.Cout - 1) * KT) + lq * 4;
-    float4 rb;
+    float4 rb, rb1;
     auto load_step = [&](int s) __attribute__((always_inline)) {
         L.load(a);
         rb = *reinterpret_cast<const float4*>(a.wp + (long)s * BK + woff);
@@ -827,6 +836,71 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     const int fi = lane & 15, fk = lane >> 4;     // row/col inside a 16-tile, k group 0..3
+    if constexpr (GM == 1) {
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        // loads of K step s into register stage ST (the activation loader keeps its own cursor: steps in order)
+        auto load_h = [&](int s, auto st_tag) __attribute__((always_inline)) {
+            constexpr int ST = decltype(st_tag)::value;
+            L.template load<ST>(a);
+            const float4 w = *reinterpret_cast<const float4*>(a.wp + (long)s * BK + woff);
+            if constexpr (ST == 0) rb = w; else rb1 = w;
+        };
+        // stage ST -> the three planes of LDS buffer ST (zero: the missing second half of an odd pair)
+        auto store_h = [&](auto st_tag, bool zero) __attribute__((always_inline)) {
+            constexpr int ST = decltype(st_tag)::value;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 p0, p1, p2;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                mnk_split3(zero ? z : L.template masked<ST>(j), p0, p1, p2);
+                *reinterpret_cast<uint2*>(&Ah[ST][0][lrow + 64 * j][lq * 4]) = p0;
+                *reinterpret_cast<uint2*>(&Ah[ST][1][lrow + 64 * j][lq * 4]) = p1;
+                *reinterpret_cast<uint2*>(&Ah[ST][2][lrow + 64 * j][lq * 4]) = p2;
+            }
+            if (lrow < BN) {
+                mnk_split3(zero ? z : (ST == 0 ? rb : rb1), p0, p1, p2);
+                *reinterpret_cast<uint2*>(&Bh[ST][0][lrow][lq * 4]) = p0;
+                *reinterpret_cast<uint2*>(&Bh[ST][1][lrow][lq * 4]) = p1;
+                *reinterpret_cast<uint2*>(&Bh[ST][2][lrow][lq * 4]) = p2;
+            }
+        };
+        const int kb = fk >> 1, ko = (fk & 1) * 8;      // this lane's k group: LDS buffer and offset inside the step
+        auto mfma_pair = [&]() __attribute__((always_inline)) {
+            mnk_bf16x8 ha[3][TM], hb[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    ha[pl][i] = mnk_as_bf16x8(*reinterpret_cast<const uint4*>(&Ah[kb][pl][wave * 32 + 16 * i + fi][ko]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) hb[pl][j] = mnk_as_bf16x8(*reinterpret_cast<const uint4*>(&Bh[kb][pl][16 * j + fi][ko]));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[1][i], hb[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[2][i], hb[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[0][i], hb[2][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[1][i], hb[0][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[0][i], hb[1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[0][i], hb[0][j], acc[i][j], 0, 0, 0);
+                }
+        };
+        const int n = s_end - s_begin;
+        if (n > 0) load_h(s_begin, S0{});
+        if (n > 1) load_h(s_begin + 1, S1{});
+        for (int s = 0; s < n; s += 2) {
+            store_h(S0{}, false);
+            store_h(S1{}, s + 1 >= n);
+            __syncthreads();
+            if (s + 2 < n) load_h(s_begin + s + 2, S0{});
+            if (s + 3 < n) load_h(s_begin + s + 3, S1{});
+            mfma_pair();
+            __syncthreads();                      // (also in front of the epilogue's reuse of the LDS image)
+        }
+    } else {
     auto mfma_step = [&](int buf) __attribute__((always_inline)) {
         float4 fa[TM], fb[TN];
 #pragma unroll
@@ -868,6 +942,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     }
     if (s < s_end) mfma_step((s - s_begin) & 1);
     __syncthreads();                          // the epilogue reuses As for the column sums
+    }
     const bool split_out = a.splits > 1;
     const unsigned ldo = split_out ? (unsigned)a.ldw : (unsigned)a.ld_y;          // 32-bit element offsets (host check)
     float* const obase = split_out ? a.ws + (long)split * a.M * a.ldw : a.y;
@@ -933,7 +1008,7 @@ __global__ void __launch_bounds__(256) conv3x3_igemm16_kernel(ConvArgs a) {
     else
         emit(FalseTag{});
     if (a.stats && !split_out) {
-        float* red = &As[0][0][0];
+        float* red = reinterpret_cast<float*>(smem_a);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             s1[j] += __shfl_xor(s1[j], 16);
@@ -2770,6 +2845,8 @@ static int g_gemm_bf16x3 = tuning_knob("gemm_bf16x3", &g_gemm_bf16x3, 0);
 // with gemm_bf16x3, 1: 33 .. 48 output channels (the 45-channel refinement stack) take the 64-wide 32x32-tile kernel -- 45 of 64
 // columns at 2.67x the matrix rate -- instead of the 48-wide 16x16x4 fp32 kernel.  Measured SLOWER (10.08 vs 9.92 ms per step,
 // profiles/r06_knob_ab_log.txt): 0 keeps the 16x16 kernel
+// 1: the 16x16-tile kernels (Cout <= 16, 33 .. 48: the 45-channel refinement stack) too: pairs of K steps on v_mfma_f32_16x16x32_bf16
+static int g_gemm16_bf16x3 = tuning_knob("gemm16_bf16x3", &g_gemm16_bf16x3, 0);
 // 1: the tap-major weight-gradient kernels on the bf16 matrix cores too (wgrad_tap_body_h: transposing loader)
 static int g_wgrad_bf16x3 = tuning_knob("wgrad_bf16x3", &g_wgrad_bf16x3, 0);
 static int g_gemm_bf16x3_n48 = tuning_knob("gemm_bf16x3_n48", &g_gemm_bf16x3_n48, 0);
@@ -3344,7 +3421,11 @@ static int conv2d_fwd_impl(const float* x0, int ld0, int C0, const float* x1, in
         else if (mode == 3) MNK_IGEMM_MODE(KERNEL, 3, __VA_ARGS__); \
         else MNK_IGEMM_MODE(KERNEL, 0, __VA_ARGS__);                \
     } while (0)
-        if (p.bn == 16)
+        if (p.bn == 16 && g_gemm16_bf16x3)
+            MNK_IGEMM_H(conv3x3_igemm16_kernel, 16);
+        else if (p.bn == 48 && g_gemm16_bf16x3)
+            MNK_IGEMM_H(conv3x3_igemm16_kernel, 48);
+        else if (p.bn == 16)
             MNK_IGEMM(conv3x3_igemm16_kernel, 16);
         else if (p.bn == 48)
             MNK_IGEMM(conv3x3_igemm16_kernel, 48);

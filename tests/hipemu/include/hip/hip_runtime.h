@@ -264,6 +264,32 @@ static inline hipemu_f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(hipemu_u16x8
     }
     return c;
 }
+// v_mfma_f32_16x16x32_bf16 (gfx950): lane l holds A[i = l&15][k = 8*(l>>4) .. +7], B[k = 8*(l>>4) .. +7][j = l&15]; D as 16x16x4
+static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(hipemu_u16x8 a, hipemu_u16x8 b, hipemu_f32x4 c, int, int, int) {
+    uint32_t wa[4], wb[4];
+    memcpy(wa, &a, 16);
+    memcpy(wb, &b, 16);
+    unsigned l = hipemu::lane_id();
+    const uint32_t* pa[4];
+    const uint32_t* pb[4];
+    for (int d = 0; d < 4; ++d) pa[d] = hipemu::wave_publish(wa[d], 3 + d);
+    for (int d = 0; d < 4; ++d) pb[d] = hipemu::wave_publish(wb[d], 7 + d);
+    auto elem = [](const uint32_t* const* p, int lane, int e) {
+        const uint32_t w = p[e >> 1][lane];
+        const uint32_t u = (e & 1) ? (w & 0xffff0000u) : (w << 16);
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    for (int r = 0; r < 4; ++r) {
+        int row = 4 * (int)(l >> 4) + r;
+        int col = (int)(l & 15);
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc = fmaf(elem(pa, row + 16 * (k >> 3), k & 7), elem(pb, col + 16 * (k >> 3), k & 7), acc);
+        c[r] = acc;
+    }
+    return c;
+}
 // v_mfma_f32_16x16x4_f32: A[i][k] from lane i+16k, B[k][j] from lane j+16k,
 // D: col = lane&15, row = 4*(lane>>4) + reg.
 static inline hipemu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c, int, int, int) {

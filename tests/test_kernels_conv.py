@@ -14,9 +14,11 @@ def gemm_mode(request, be):
     on = 1 if request.param == "bf16x3" else 0
     be.lib.call("mnk_set_tuning", b"gemm_bf16x3", on)
     be.lib.call("mnk_set_tuning", b"wgrad_bf16x3", on)       # the tap-major weight-gradient kernels' form (transposing loader)
+    be.lib.call("mnk_set_tuning", b"gemm16_bf16x3", on)      # the 16x16-tile kernels' form (pairs of K steps)
     yield request.param
     be.lib.call("mnk_set_tuning", b"gemm_bf16x3", 0)
     be.lib.call("mnk_set_tuning", b"wgrad_bf16x3", 0)
+    be.lib.call("mnk_set_tuning", b"gemm16_bf16x3", 0)
 
 
 CASES = [
