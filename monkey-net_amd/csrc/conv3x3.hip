@@ -435,7 +435,9 @@ __global__ void __launch_bounds__(256, MNK_IGEMM_OCC) conv3x3_igemm_kernel(ConvA
     // pair.  Two accumulator sets fed by alternating K elements make neighbours independent; they are added once at the end
     // (which also halves the length of the fp32 summation chain: K = 9 * Cin <= 18 522 terms).
     constexpr int NACC = (TM * TN == 1) ? MNK_IGEMM_NACC : 1;
-    constexpr int NST = (BM * BN <= 64 * 128) ? MNK_IGEMM_NST : 1;     // 8 (16) registers per stage; the 128x128 tile has none to spare
+    // 8 (16) registers per stage; the 128x128 tile has none to spare, and the bf16x3 form measured 0.05 ms per iteration
+    // faster with one stage (profiles/r06_knob_ab_log.txt, v16): its six MFMAs per K step already cover the load latency
+    constexpr int NST = (BM * BN <= 64 * 128 && GM == 0) ? MNK_IGEMM_NST : 1;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(NST == 1 || NST == 2, "one or two register stages");
     // one LDS image, two views: fp32 rows [2][rows][LDS_K] (GM 0) / three bf16 planes [2][3][rows][LDS_H] (GM 1)
