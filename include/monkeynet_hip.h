@@ -156,6 +156,14 @@ int mnk_bn_small_rows(void);
 int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const float* bias, float* y, int ld_y, int N, int H, int W,
                      int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, float* mean, float* invstd, float* scale, float* z, int ld_z, int relu, int pool, void* stream);
+/* (round 6) an EVALUATION-mode norm layer (running statistics: mean / scale from mnk_bn_eval_coeffs) straight from the split-K
+ * partials of the convolution in front (MNK_CONV_DEFER_SPLITK, `ws` = [split][phase][M][ldw]): partial sums + bias, affine, ReLU,
+ * 2x2 average pool -> z in ONE launch; y is never written.  (H, W) = the convolution's output size (the up-sampled size when
+ * phases == 4); ld_z == ldw == round_up(C, 4).  Bit-identical to the split reduction followed by mnk_bn_act_fwd.  What the
+ * per-frame loops of reconstruction.py:45-62 / transfer.py run at batch 1 (sync_batchnorm/batchnorm.py:57-59 in eval mode,
+ * util.py:56-57,81-87,100-107). */
+int mnk_bn_eval_split_fwd(const float* ws, int splits, int ldw, int phases, const float* bias, const float* mean, const float* scale,
+                          const float* beta, float* z, int ld_z, int N, int H, int W, int C, int relu, int pool, void* stream);
 int mnk_bn_small_bwd(const float* y, int ld_y, const float* dz, int ld_dz, const float* mean, const float* invstd,
                      const float* scale, const float* beta, double count, int N, int H, int W, int C, int relu, int pool,
                      float* sums, float* dy, int ld_dy, void* stream);

@@ -785,6 +785,98 @@ __device__ __forceinline__ void bn_small_fwd_body(const SmallFwdArgs& a, const E
 
 __global__ void __launch_bounds__(1024) bn_small_fwd_kernel(SmallFwdArgs a) { bn_small_fwd_body(a, SmallNoExchange()); }
 
+// Evaluation-mode norm layer straight from the split-K partials of the convolution in front (MNK_CONV_DEFER_SPLITK): sums the
+// partials, adds the bias, applies the running-statistics affine + ReLU (+ 2x2 average pool) and writes z -- one launch instead of
+// split reduction + apply, and y never exists.  The reference's per-frame evaluation loops (reconstruction.py:45-62, batch 1) run
+// every convolution split along K, so this is one launch less per norm layer of a frame.  Arithmetic = what the two launches do,
+// bit for bit: the splits in conv3x3_splitk_reduce_stats_kernel's order (four interleaved groups, (g0 + g1) + (g2 + g3), then
+// the bias), then bn_act_fwd_kernel's fmaf / activation / pooling order.
+struct EvalSplitArgs {
+    const float* ws;       // [split][phase][M][ldw]
+    int splits, ldw, phases;
+    const float *bias, *mean, *scale, *beta;
+    float* z;
+    int ld_z, N, H, W, C;  // (H, W): the size of the convolution's output (the up-sampled size for the sub-pixel form)
+    int relu, pool, tx_n, ty_n;
+};
+
+__device__ __forceinline__ float4 eval_split_pixel(const EvalSplitArgs& a, int n, int Y, int X, int q, float4 bv, int rem) {
+    long pr, prows;
+    if (a.phases > 1) {          // output pixel (n, Y, X) <- row (n, Y>>1, X>>1) of phase 2 (Y&1) + (X&1)
+        const int Hl = a.H >> 1, Wl = a.W >> 1;
+        const long Mlow = (long)a.N * Hl * Wl;
+        prows = 4 * Mlow;
+        pr = (long)((Y & 1) * 2 + (X & 1)) * Mlow + ((long)n * Hl + (Y >> 1)) * Wl + (X >> 1);
+    } else {
+        prows = (long)a.N * a.H * a.W;
+        pr = ((long)n * a.H + Y) * a.W + X;
+    }
+    const float* p = a.ws + pr * a.ldw + q * 4;
+    const long sstride = prows * a.ldw;
+    float4 g[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 4 <= a.splits; s += 4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = f4_add(g[e], *reinterpret_cast<const float4*>(p + (long)(s + e) * sstride));
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+        if (s + e < a.splits) g[e] = f4_add(g[e], *reinterpret_cast<const float4*>(p + (long)(s + e) * sstride));
+    float4 r;
+    r.x = (g[0].x + g[1].x) + (g[2].x + g[3].x);
+    r.y = (g[0].y + g[1].y) + (g[2].y + g[3].y);
+    r.z = (g[0].z + g[1].z) + (g[2].z + g[3].z);
+    r.w = (g[0].w + g[1].w) + (g[2].w + g[3].w);
+    if (a.bias) r = f4_add(r, bv);
+    r.x = rem > 0 ? r.x : 0.f;   // columns beyond Cout hold the results of clamped weight rows
+    r.y = rem > 1 ? r.y : 0.f;
+    r.z = rem > 2 ? r.z : 0.f;
+    r.w = rem > 3 ? r.w : 0.f;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) bn_eval_split_fwd_kernel(EvalSplitArgs a) {
+    const int tx = threadIdx.x % a.tx_n, ty = threadIdx.x / a.tx_n;
+    const int nv = a.ld_z / 4, q = blockIdx.x * a.tx_n + tx;
+    if (q >= nv || ty >= a.ty_n) return;
+    const int Ho = a.pool ? a.H / 2 : a.H, Wo = a.pool ? a.W / 2 : a.W;
+    const int orows = a.N * Ho * Wo;
+    const int p = blockIdx.y * a.ty_n + ty;
+    if (p >= orows) return;
+    const int rem = a.C - q * 4;
+    const float4 bv = a.bias ? ld4_guard(a.bias, q, a.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 m = ld4_guard(a.mean, q, a.C), sc = ld4_guard(a.scale, q, a.C), be = ld4_guard(a.beta, q, a.C);
+    const float slope = a.relu ? 0.f : -1.f;
+    const int wo = p % Wo, t = p / Wo, ho = t % Ho, n = t / Ho;
+    float4 o;
+    if (a.pool) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = eval_split_pixel(a, n, 2 * ho + (k >> 1), 2 * wo + (k & 1), q, bv, rem);
+        o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o.x += act_apply(fmaf(v[k].x - m.x, sc.x, be.x), slope);
+            o.y += act_apply(fmaf(v[k].y - m.y, sc.y, be.y), slope);
+            o.z += act_apply(fmaf(v[k].z - m.z, sc.z, be.z), slope);
+            o.w += act_apply(fmaf(v[k].w - m.w, sc.w, be.w), slope);
+        }
+        o.x *= 0.25f;
+        o.y *= 0.25f;
+        o.z *= 0.25f;
+        o.w *= 0.25f;
+    } else {
+        const float4 v = eval_split_pixel(a, n, ho, wo, q, bv, rem);
+        o.x = act_apply(fmaf(v.x - m.x, sc.x, be.x), slope);
+        o.y = act_apply(fmaf(v.y - m.y, sc.y, be.y), slope);
+        o.z = act_apply(fmaf(v.z - m.z, sc.z, be.z), slope);
+        o.w = act_apply(fmaf(v.w - m.w, sc.w, be.w), slope);
+    }
+    *reinterpret_cast<float4*>(a.z + (long)p * a.ld_z + q * 4) = o;      // guarded parameter loads make the pad lanes zero
+}
+
 __global__ void __launch_bounds__(1024) bn_small_bwd_kernel(BwdLoader L, double count, int rows, int nv, int tx_n,
                                                             float* __restrict__ sums, float* __restrict__ dy, int ld_dy) {
     __shared__ float4 red0[1024], red1[1024];
@@ -1291,6 +1383,30 @@ int mnk_bn_small_fwd(const float* ws, int splits, int ldw, int phases, const flo
     small_shape(ld_y / 4, &threads, &a.tx_n);
     MNK_REQUIRE(a.tx_n >= 1 && a.tx_n <= 64 && (a.tx_n & (a.tx_n - 1)) == 0);
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(ceil_div(ld_y / 4, a.tx_n)), dim3(threads), 0, s, a);
+    MNK_LAUNCH_CHECK();
+    return MNK_OK;
+}
+
+int mnk_bn_eval_split_fwd(const float* ws, int splits, int ldw, int phases, const float* bias, const float* mean, const float* scale,
+                          const float* beta, float* z, int ld_z, int N, int H, int W, int C, int relu, int pool, void* stream) {
+    MNK_REQUIRE(ws && mean && scale && beta && z && splits >= 1 && (phases == 1 || phases == 4) && N > 0 && H > 0 && W > 0 && C > 0);
+    MNK_REQUIRE(ldw % 4 == 0 && ldw >= C && ld_z == ldw && (size_t)ws % 16 == 0 && (size_t)z % 16 == 0);
+    MNK_REQUIRE((phases == 1 || (H % 2 == 0 && W % 2 == 0)) && (!pool || (H % 2 == 0 && W % 2 == 0)));
+    MNK_REQUIRE((long)N * H * W * phases < (1L << 31));
+    hipStream_t s = (hipStream_t)stream;
+    EvalSplitArgs a;
+    a.ws = ws, a.splits = splits, a.ldw = ldw, a.phases = phases;
+    a.bias = bias, a.mean = mean, a.scale = scale, a.beta = beta;
+    a.z = z, a.ld_z = ld_z, a.N = N, a.H = H, a.W = W, a.C = C, a.relu = relu, a.pool = pool;
+    const int nv = ld_z / 4;
+    int tx = 1;
+    while (tx < nv && tx < 64) tx <<= 1;
+    if (nv <= 64) tx = nv;               // exact quad lanes (see make_map)
+    a.tx_n = tx;
+    a.ty_n = 256 / tx;
+    const long orows = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W);
+    ProfScope prof(K_BN_APPLY, s, ((double)splits * N * H * W * ldw + (double)orows * ld_z) * 4);
+    hipLaunchKernelGGL(bn_eval_split_fwd_kernel, dim3(ceil_div(nv, tx), ceil_div(orows, a.ty_n)), dim3(256), 0, s, a);
     MNK_LAUNCH_CHECK();
     return MNK_OK;
 }

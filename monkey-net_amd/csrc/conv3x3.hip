@@ -2835,7 +2835,8 @@ static int g_wsplit_tiles = tuning_knob("wsplit_tiles", &g_wsplit_tiles, 512), g
 // has a second wave to overlap loads with MFMA, and less (or no) split-K
 static int g_bm64_tiles = tuning_knob("bm64_tiles", &g_bm64_tiles, 512);
 static int g_split64_tiles = tuning_knob("split64_tiles", &g_split64_tiles, 384), g_split64_target = tuning_knob("split64_target", &g_split64_target, 1024),
-           g_split64_deep = tuning_knob("split64_deep", &g_split64_deep, 32), g_split64_minsteps = tuning_knob("split64_minsteps", &g_split64_minsteps, 16);
+           g_split64_deep = tuning_knob("split64_deep", &g_split64_deep, 32), g_split64_minsteps = tuning_knob("split64_minsteps", &g_split64_minsteps, 16),
+           g_split64_tiny = tuning_knob("split64_tiny", &g_split64_tiny, 4);      // K steps per split of the tiny-problem rule; 0: off
 static int g_bn128_kwork = tuning_knob("bn128_kwork", &g_bn128_kwork, 8388);   // 1000 pixels x channels from which 128-wide tiles are used
 static int g_xcd_remap = tuning_knob("xcd_remap", &g_xcd_remap, 1);
 static int g_fast_loader = tuning_knob("fast_loader", &g_fast_loader, 1);
@@ -2907,6 +2908,15 @@ static Plan make_plan(long M, int Cout, int chunks, int ntaps = 9, int phases = 
             if (splits > p.ksteps / g_split64_minsteps) splits = p.ksteps / g_split64_minsteps;
             if (splits < 1) splits = 1;
             if (tiles >= 192 && p.ksteps / splits < g_split64_deep) splits = 1;
+            // (round 6) tiny problems -- the per-frame evaluation loops at batch 1 (reconstruction.py:45-62): 4 ... 32 tiles with
+            // 36 ... 150 K steps -- are one serial K loop per block on a mostly idle chip: a launch's time is its loop length, so
+            // splits as short as 4 steps pay until ~256 blocks exist (tools/plan_tune.py --eval, profiles/r06_plan_tune_eval_*:
+            // 18.4 -> 13.2 us for conv + reduction of a 256-pixel layer).  Plans that already fill half the chip are left alone.
+            if (g_split64_tiny && tiles < 64 && tiles * splits < 128) {
+                int s2 = (int)(256 / tiles);
+                if (s2 > p.ksteps / g_split64_tiny) s2 = p.ksteps / g_split64_tiny;
+                if (s2 > splits) splits = s2;
+            }
         }
     } else if (tiles < g_split_tiles) {
         splits = (int)((g_split_target + tiles - 1) / tiles);

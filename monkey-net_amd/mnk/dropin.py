@@ -482,11 +482,36 @@ class EvalRunner:
             if len(self.programs) >= self.MAX_PROGRAMS:
                 self.programs.clear()
             prog = self.programs[key] = self._capture(module, inputs, kwargs, flat, device, fp)
-        for (path, t), s in zip(flat, prog["static"]):
+        for i, ((path, t), s) in enumerate(zip(flat, prog["static"])):
+            if t.device.type == "cpu" and not t.is_pinned():
+                # a host frame (reconstruction.py:52-58 slices them from the loader's batch): a copy from pageable memory waits for
+                # everything queued on the stream -- the previous frame's replay -- before the host may go on.  Through a ring of
+                # page-locked staging buffers the copy is asynchronous and the host statements of frame i + 1 overlap frame i.
+                buf, ev = self._stage(prog, i, t)
+                s.copy_(buf, non_blocking=True)
+                ev.record()
+                continue
             s.copy_(t, non_blocking=True)
         prog["graph"].replay()
         self.stats["replays"] += 1
         return _walk_clone(prog["out"])
+
+    STAGES = 4
+
+    @staticmethod
+    def _stage(prog, i, t):
+        ring = prog.setdefault("ring", {}).get(i)
+        if ring is None:
+            ring = prog["ring"][i] = {"buf": [torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(EvalRunner.STAGES)],
+                                      "ev": [None] * EvalRunner.STAGES, "next": 0}
+        k = ring["next"]
+        ring["next"] = (k + 1) % EvalRunner.STAGES
+        if ring["ev"][k] is not None:
+            ring["ev"][k].synchronize()          # the copy that last read this slot (STAGES calls ago) is done
+        else:
+            ring["ev"][k] = torch.cuda.Event()
+        ring["buf"][k].copy_(t)
+        return ring["buf"][k], ring["ev"][k]
 
     def _capture(self, module, inputs, kwargs, flat, device, fp):
         static = [t.to(device).clone() for _, t in flat]

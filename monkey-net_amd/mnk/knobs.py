@@ -55,6 +55,7 @@ FORMS = {
     "SKIP_GRAD_FUSED": True,    # hourglass levels: the skip gradient rides in the next data-gradient GEMM's epilogue
     "RES_SKIP_FUSED": True,     # residual blocks: the skip gradient is added inside the first norm layer's dy pass
     "DGRAD_BN_STATS": True,     # the data-gradient GEMM behind a (non-pooling) norm layer leaves that layer's backward statistics
+    "EVAL_SPLIT_FUSED": True,   # no_grad + eval: a norm layer behind a split-K convolution sums the partials itself (one launch)
 }
 
 

@@ -491,6 +491,7 @@ def repack_registered(only_if_stale=False):
 
 # a split-K convolution whose partials a small-layer BatchNorm will sum: y.data_ptr() -> (ws, splits, phases, bias)
 _SPLIT_PENDING = {}
+_EVAL_DEFER = [False]                     # conv3x3(eval_bn=True) -> _conv_launch
 
 
 def _small_sync(rows):
@@ -517,6 +518,8 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
     # (even sizes only: a pooling BatchNorm on an odd map -- 96 x 96 frames reach 3 x 3 -- takes the general kernels, and this
     # function does not know whether the BatchNorm that follows pools)
     small = want_stats and residual is None and small_bn(n * h * w, True, cout) and h % 2 == 0 and w % 2 == 0
+    # evaluation mode, conv3x3(eval_bn=True): the norm layer that follows sums a split launch's partials itself (one-shot flag)
+    evald, _EVAL_DEFER[0] = (_EVAL_DEFER[0] and not want_stats and residual is None and h % 2 == 0 and w % 2 == 0), False
     if _SPLIT_PENDING:
         # the BatchNorm of an earlier deferred split-K convolution never ran: an exception between the two launches (the entry
         # is popped by that BatchNorm; nothing else may run in between).  The partial sums are gone with the scratch buffer;
@@ -532,7 +535,7 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
         ws = SCRATCH.get("ws", nws, x0) if nws else None
         nst = _query("mnk_conv3x3_up_stats_floats", n, hl, wl, c0, c1, cout) if want_stats and not small else 0
         st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None
-        defer = 4 if small and nws else 0
+        defer = 4 if (small or evald) and nws else 0
         _call("mnk_conv3x3_up_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1, defer,
               _p(wp), _p(bias), _p(y), y.shape[-1], n, hl, wl, cout, _p(ws), nws, _p(st))
         if defer:
@@ -542,7 +545,7 @@ def _conv_launch(x0, c0, x1, c1, ups, wp, bias, residual, n, h, w, cout, want_st
         ws = SCRATCH.get("ws", nws, x0) if nws else None
         nst = _query("mnk_conv3x3_stats_floats", n, h, w, c0, c1, cout) if want_stats and not small else 0
         st = torch.empty(nst, dtype=torch.float32, device=x0.device) if nst else None   # lives until the norm layer reads it
-        defer = 4 if small and nws else 0
+        defer = 4 if (small or evald) and nws else 0
         # flags: bit 0 = nearest x2 up-sampled view, bit 1 = MNK_CONV_CLEAN_PADS -- every act this module produces has zero
         # pad channels (tests/test_modules.py::test_pad_channels_are_written pins that), so the fast 3x3 loader applies
         _call("mnk_conv3x3_fwd", x0, _p(x0), x0.shape[-1], c0, _p(x1), x1.shape[-1] if x1 is not None else 0, c1,
@@ -821,11 +824,16 @@ class Conv3x3SkipFn(_Fn):
         return Conv3x3Fn._backward(ctx, dy, dskip)
 
 
-def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False, skip=False):
+def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, want_stats=False, skip=False, eval_bn=False):
     """-> (y, sums): sums = fused BatchNorm statistics [sum, sum of squares] of y when want_stats, else None.
-    skip: -> (y, sums, x0 handed through for x0's other consumer), see Conv3x3SkipFn."""
+    skip: -> (y, sums, x0 handed through for x0's other consumer), see Conv3x3SkipFn.
+    eval_bn: the caller vouches that y's ONLY consumer is the evaluation-mode norm layer it calls next (bn_act): under no_grad a
+    split-K launch then leaves its partials to that layer (mnk_bn_eval_split_fwd: reduction + affine + ReLU + pool in one launch)
+    and y is never written."""
     track = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (x0, x1, weight, bias, residual))
+    _EVAL_DEFER[0] = bool(eval_bn and not want_stats and residual is None and not torch.is_grad_enabled()
+                          and knobs.form("EVAL_SPLIT_FUSED"))
     if track:       # the norm layers whose outputs the sources are (see _BN_OF): picked up by Conv3x3Fn.forward
         _SRC_BN[0] = (_bn_of(x0), _bn_of(x1))
     if skip and track and x0.requires_grad and knobs.form("SKIP_GRAD_FUSED"):
@@ -905,6 +913,16 @@ class BNActFn(_Fn):
             ctx.save_for_backward(y, mean, invstd, scale, beta)
             ctx.meta = (c, training, relu, pool, count)
             ctx.small = True
+            return z
+        if pending is not None and not training and ld == ceil4(c) and h % 2 == 0 and w % 2 == 0:
+            # evaluation mode behind a split-K convolution (conv3x3(eval_bn=True), no_grad): reduction + affine + ReLU + pool in
+            # one launch; y was never written and nothing is saved for a backward pass
+            mean, invstd, scale = _bn_eval_coeffs(y, gamma, running_mean, running_var, eps, c)
+            ws_, splits, phases, bias = pending
+            ho, wo = (h // 2, w // 2) if pool else (h, w)
+            z = torch.empty(n, ho, wo, ceil4(c), dtype=torch.float32, device=dev)
+            _call("mnk_bn_eval_split_fwd", y, _p(ws_), splits, ld, phases, _p(bias), _p(mean), _p(scale), _p(beta), _p(z),
+                  z.shape[-1], n, h, w, c, int(relu), int(pool))
             return z
         if pending is not None:
             raise RuntimeError("split-K partials were deferred to a BatchNorm that does not take the small-layer path")

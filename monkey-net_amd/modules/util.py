@@ -101,7 +101,8 @@ class ResBlock3D(nn.Module):
         # skip=True: x comes back from the norm node, so that node alone consumes the block's input and adds the gradient of
         # `out += x` inside its own backward pass (ops.BNActSkipFn)
         out, x = ops.bn_act(x, c, self.norm1, relu=True, sums=x_sums, skip=True)
-        out, s = ops.conv3x3(out, c, self.conv1.weight, self.conv1.bias, want_stats=self.norm2.training)
+        out, s = ops.conv3x3(out, c, self.conv1.weight, self.conv1.bias, want_stats=self.norm2.training,
+                             eval_bn=not self.norm2.training)
         out = ops.bn_act(out, c, self.norm2, relu=True, sums=s)
         out, s = ops.conv3x3(out, c, self.conv2.weight, self.conv2.bias, residual=x, want_stats=want_stats)
         return (out, c, s) if want_stats else (out, c)
@@ -123,7 +124,7 @@ class UpBlock3D(nn.Module):
 
     def forward_act(self, x0, c0, x1=None, c1=0):
         out, s = ops.conv3x3(x0, c0, self.conv.weight, self.conv.bias, x1=x1, c1=c1, ups=True,
-                             want_stats=self.norm.training)
+                             want_stats=self.norm.training, eval_bn=not self.norm.training)
         return ops.bn_act(out, self.out_features, self.norm, relu=True, sums=s), self.out_features
 
     def forward(self, x):
@@ -145,9 +146,11 @@ class DownBlock3D(nn.Module):
     def forward_act(self, x, c, skip=False):
         """skip: -> ((out, channels), x handed through) for an input that has a second consumer (Encoder.forward_act)."""
         if skip:
-            out, s, x = ops.conv3x3(x, c, self.conv.weight, self.conv.bias, want_stats=self.norm.training, skip=True)
+            out, s, x = ops.conv3x3(x, c, self.conv.weight, self.conv.bias, want_stats=self.norm.training, skip=True,
+                                    eval_bn=not self.norm.training)
             return (ops.bn_act(out, self.out_features, self.norm, relu=True, pool=True, sums=s), self.out_features), x
-        out, s = ops.conv3x3(x, c, self.conv.weight, self.conv.bias, want_stats=self.norm.training)
+        out, s = ops.conv3x3(x, c, self.conv.weight, self.conv.bias, want_stats=self.norm.training,
+                             eval_bn=not self.norm.training)
         return ops.bn_act(out, self.out_features, self.norm, relu=True, pool=True, sums=s), self.out_features
 
     def forward(self, x):

@@ -205,3 +205,63 @@ def test_eval_wrappers_replay_a_frozen_weight_graph_per_frame(monkeypatch):
     monkeypatch.delenv("MNK_EVAL_GRAPH")
     got2 = loop()
     assert rg.stats["captures"] == 2 and torch.equal(got2, want2) and not torch.equal(got2, got)
+
+
+@pytest.mark.parametrize("config,batch", [("moving-gif", 1), ("moving-gif", 3), ("taichi", 1)])
+def test_eval_norm_layers_sum_the_split_partials_themselves_bit_for_bit(be, monkeypatch, config, batch):
+    if be.kind == "emu" and (config, batch) != ("moving-gif", 1):
+        pytest.skip("the other shapes run on the device only (CPU suite budget)")
+    _eval_split_case(be, monkeypatch, config, batch, 64, with_generator=be.kind == "hip")
+
+
+def kpd_mean_of(a, b, src, kpd):
+    with torch.no_grad():
+        return kpd(src)["mean"]
+
+
+def _eval_split_case(be, monkeypatch, config, batch, size, with_generator):
+    """(the CPU emulator runs the key-point detector only: down blocks with the pool, sub-pixel up blocks -- CPU suite budget)"""
+    """reconstruction.py:45-62 runs the networks frame by frame at batch 1: every convolution is split along K there, and in
+    evaluation mode under no_grad the norm layer behind it takes the partials (mnk_bn_eval_split_fwd: reduction + bias + affine +
+    ReLU + pool in one launch, y never written).  Same bits as the two-launch form (split reduction, then mnk_bn_act_fwd), and
+    the fused form is what ran."""
+    from mnk import configs, knobs, ops
+    cfg = configs.get(config)
+    gen, disc, kpd = build(cfg)
+    for i, m in enumerate((gen, disc, kpd)):
+        sd = m.state_dict()
+        cases.perturb_state_dict(sd, 11 + i)
+        m.load_state_dict(sd)
+    gen.to(be.device).eval(), kpd.to(be.device).eval()
+    src, drv = cases.synthetic_pair(batch, size, size)
+    src, drv = be.t(src), be.t(drv)
+    calls = {}
+    real = ops._call
+
+    def counting(name, *a):
+        calls[name] = calls.get(name, 0) + 1
+        return real(name, *a)
+
+    monkeypatch.setattr(ops, "_call", counting)
+
+    def run(fused):
+        monkeypatch.setitem(knobs.FORMS, "EVAL_SPLIT_FUSED", fused)
+        calls.clear()
+        with torch.no_grad():
+            kp_s, kp_d = kpd(src), kpd(drv)
+            out = gen(source_image=src, kp_driving=kp_d, kp_source=kp_s) if with_generator else {}
+        be.sync()
+        return {"mean": kp_d["mean"], "var": kp_d["var"], **out}, dict(calls)
+
+    a, ca = run(True)
+    b, cb = run(False)
+    assert ca.get("mnk_bn_eval_split_fwd", 0) > 0 and cb.get("mnk_bn_eval_split_fwd", 0) == 0
+    assert ca.get("mnk_bn_act_fwd", 0) + ca["mnk_bn_eval_split_fwd"] == cb["mnk_bn_act_fwd"]
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # with gradients enabled nothing is deferred (a backward pass needs y)
+    monkeypatch.setitem(knobs.FORMS, "EVAL_SPLIT_FUSED", True)
+    calls.clear()
+    out = kpd(src)
+    assert calls.get("mnk_bn_eval_split_fwd", 0) == 0 and calls.get("mnk_bn_act_fwd", 0) > 0
+    assert torch.equal(out["mean"].detach(), kpd_mean_of(a, b, src, kpd))

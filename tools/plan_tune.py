@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--iters", type=int, default=12)
     ap.add_argument("--gain", type=float, default=0.03)
+    ap.add_argument("--eval", action="store_true",
+                    help="evaluation-mode shapes: the key-point detector sees `batch` frames (not source + driving), no BatchNorm "
+                         "statistics are asked of the convolutions, forward only (reconstruction.py:45-62 at batch 1)")
     args = ap.parse_args()
     cfg = configs.get(args.config)
     layers = workload.conv_flops_hot_path(cfg, args.size, args.size)["layers"]
@@ -88,7 +91,7 @@ def main():
     for name, cin, cout, h, w, k, flops in layers:
         if k != 3:
             continue
-        frames = args.batch * (2 if name.startswith("kp") else 1)
+        frames = args.batch * (2 if name.startswith("kp") and not args.eval else 1)
         ups = ".dec" in name
         key = (cin, cout, h, w, frames, ups)
         if key in seen:
@@ -101,7 +104,7 @@ def main():
         dy = torch.randn(frames, h, w, ops.ceil4(cout), device=dev)
         up = ops.subpixel(ups)
         wp = ops._packed_fwd_weight(wt, cout, cin, 0, up)
-        want_stats = not name.endswith(".last")
+        want_stats = not name.endswith(".last") and not args.eval
         small = want_stats and ops.small_bn(frames * h * w)
 
         def fwd():
@@ -127,7 +130,7 @@ def main():
                 ops._conv_launch(dy, cout, None, 0, 0, wpd, None, None, frames, h, w, cin)
 
         for direction, fn, n_out in (("fwd", fwd, cout), ("dgrad", dgrad, cin)):
-            if direction == "fwd" and small:
+            if (direction == "fwd" and small) or (args.eval and direction == "dgrad"):
                 continue                      # the one-launch BatchNorm sums these layers' split partials itself
             force(0, 0, 0)
             _lib.lib().call("mnk_set_tuning", b"plan_table", 0)
