@@ -495,6 +495,8 @@ class MnkAdam(torch.optim.Optimizer, FlatGrads):
         return self.flat_m[o:o + p.numel()].view_as(p), self.flat_v[o:o + p.numel()].view_as(p)
 
     def state_dict(self):
+        if mdist._P2P["handle"] is not None:
+            mdist.check_p2p()          # never checkpoint moments that were made from NaN-poisoned statistics
         step = float(self.hyper[7].item())
         for p in self._params:
             m, v = self._views(p)

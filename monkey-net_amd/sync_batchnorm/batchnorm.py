@@ -11,9 +11,18 @@ from torch.nn.modules.batchnorm import _BatchNorm
 from mnk import ops
 
 
+def _check_exchange(module, prefix, keep_vars):
+    from mnk import dist as mdist
+    if mdist._P2P["handle"] is not None:
+        mdist.check_p2p()
+
+
 class _SynchronizedBatchNorm(_BatchNorm):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
         super(_SynchronizedBatchNorm, self).__init__(num_features, eps=eps, momentum=momentum, affine=affine)
+        # a checkpoint written by a user-owned loop (train.py:138-143 -> logger.py:51-55: state_dict() of every network) must not
+        # carry running statistics that a given-up peer-to-peer exchange poisoned with NaN: raise instead (mnk.dist.check_p2p)
+        self.register_state_dict_pre_hook(_check_exchange)
 
     def forward(self, input):
         self._check_input_dim(input)

@@ -273,6 +273,27 @@ def _absent_peer_worker(rank, world, port, emu_path, out_dir):
             raise AssertionError("check_p2p() must raise after a give-up")
         except RuntimeError as e:
             assert "rank 1" in str(e)
+        # a user-owned loop never reaches TrainStep's poll -- the checkpoint helpers and the wrapper's forward raise too
+        from sync_batchnorm import SynchronizedBatchNorm3d, DataParallelWithCallback
+        from mnk.optim import MnkAdam
+        mdist._P2P["handle"] = h.value
+        bn = SynchronizedBatchNorm3d(4)
+        net = torch.nn.Sequential(torch.nn.Conv3d(3, 4, 1), bn)
+        for what in (net.state_dict, MnkAdam(net.parameters(), lr=1e-3).state_dict):
+            try:
+                what()
+                raise AssertionError("state_dict() must raise after a give-up")
+            except RuntimeError as e:
+                assert "rank 1" in str(e)
+        wrapper = DataParallelWithCallback(torch.nn.Identity())
+        wrapper._calls = 31
+        try:
+            wrapper(torch.zeros(1))
+            raise AssertionError("the wrapper's 32nd call must raise after a give-up")
+        except RuntimeError as e:
+            assert "rank 1" in str(e)
+        mdist._P2P["handle"] = None
+        assert net.state_dict() is not None          # (no exchange connected: nothing is polled)
     dist.barrier()
     mdist.disable_p2p()
     lib.call("mnk_p2p_destroy", h)
