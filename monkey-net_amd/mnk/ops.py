@@ -664,6 +664,26 @@ def clear_dz_stats():
     _REDUCED.clear()
 
 
+def handover_state():
+    """The ONE-SHOT hand-overs between two adjacent calls of this module (producer -> the very next consumer), by name, with what
+    is left in them.  Between two forward / backward passes every one of them is empty: anything left over is a producer whose
+    consumer never ran (an exception in between, a caller that broke the `conv3x3(..., eval_bn=True)` -> `bn_act` contract) and
+    would be picked up by an unrelated later call.  tests/test_step.py and tests/test_inference.py assert {} after whole passes.
+    (Not listed: caches and registries keyed by tensor identity + version -- _PACK_*, _BN_EVAL, _BN_OF, _SINKS, _REDUCED,
+    _DZ_STATS: entries die with their tensors or at clear_dz_stats().)"""
+    slots = {
+        "_SPLIT_PENDING (split-K convolution -> the norm layer that sums its partials)": len(_SPLIT_PENDING),
+        "_EVAL_DEFER (conv3x3(eval_bn=True) -> _conv_launch)": _EVAL_DEFER[0],
+        "_SRC_BN (conv3x3 -> Conv3x3Fn.forward)": _SRC_BN[0],
+        "_LAST_BN (BNActFn.forward -> bn_act)": _LAST_BN[0],
+        "_DY_SUMS (BNActFn.backward -> Conv3x3Fn.backward)": _DY_SUMS[0],
+        "_SKIP_PARAM_GRADS (no_param_grads)": _SKIP_PARAM_GRADS[0],
+        "_SKIP_LEAF_INPUT_GRADS (no_leaf_input_grads)": _SKIP_LEAF_INPUT_GRADS[0],
+        "FROZEN_CAPTURE (mnk.dropin.EvalRunner._capture)": FROZEN_CAPTURE[0],
+    }
+    return {k: v for k, v in slots.items() if v}
+
+
 _SRC_BN = [None]                          # conv3x3() -> Conv3x3Fn.forward: (record of x0's norm layer or None, of x1's)
 
 

@@ -254,6 +254,7 @@ def _eval_split_case(be, monkeypatch, config, batch, size, with_generator):
         return {"mean": kp_d["mean"], "var": kp_d["var"], **out}, dict(calls)
 
     a, ca = run(True)
+    assert ops.handover_state() == {}
     b, cb = run(False)
     assert ca.get("mnk_bn_eval_split_fwd", 0) > 0 and cb.get("mnk_bn_eval_split_fwd", 0) == 0
     assert ca.get("mnk_bn_act_fwd", 0) + ca["mnk_bn_eval_split_fwd"] == cb["mnk_bn_act_fwd"]

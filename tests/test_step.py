@@ -274,6 +274,8 @@ def test_two_independent_model_triples_interleaved_in_one_process(be, mnk_adam):
     la.backward()
     lb.backward()
     pa, pb = finish(fa, oa), finish(fb, ob)
+    from mnk import ops
+    assert ops.handover_state() == {}            # every one-shot hand-over of the passes found its consumer
     for (vals, params), (v2, p2) in zip(alone, ((va, pa), (vb, pb))):
         assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(vals, v2))
         assert all(torch.equal(a, b) for a, b in zip(params, p2))
