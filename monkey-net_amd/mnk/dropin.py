@@ -482,6 +482,7 @@ class EvalRunner:
             if len(self.programs) >= self.MAX_PROGRAMS:
                 self.programs.clear()
             prog = self.programs[key] = self._capture(module, inputs, kwargs, flat, device, fp)
+        dsts, srcs = [], []
         for i, ((path, t), s) in enumerate(zip(flat, prog["static"])):
             if t.device.type == "cpu" and not t.is_pinned():
                 # a host frame (reconstruction.py:52-58 slices them from the loader's batch): a copy from pageable memory waits for
@@ -490,11 +491,16 @@ class EvalRunner:
                 buf, ev = self._stage(prog, i, t)
                 s.copy_(buf, non_blocking=True)
                 ev.record()
-                continue
-            s.copy_(t, non_blocking=True)
+            elif t.device == s.device and t.is_contiguous():
+                dsts.append(s)
+                srcs.append(t)
+            else:
+                s.copy_(t, non_blocking=True)
+        if dsts:                                  # the key points of a generator call (four tensors + the source frame): one launch
+            torch._foreach_copy_(dsts, srcs)
         prog["graph"].replay()
         self.stats["replays"] += 1
-        return _walk_clone(prog["out"])
+        return _clone_all(prog["out"])
 
     STAGES = 4
 
@@ -533,6 +539,17 @@ class EvalRunner:
             mops.FROZEN_CAPTURE[0] = False
         self.stats["captures"] += 1
         return {"graph": graph, "static": static, "out": out, "fp": fp}
+
+
+def _clone_all(obj):
+    """fresh tensors with the values of a program's static outputs, copied in ONE launch (a dict of two to four small tensors)"""
+    flat = []
+    EvalRunner._flatten(obj, flat)
+    if len(flat) < 2 or any(not t.is_contiguous() for _, t in flat):
+        return _walk_clone(obj)
+    fresh = [torch.empty_like(t) for _, t in flat]
+    torch._foreach_copy_(fresh, [t for _, t in flat])
+    return EvalRunner._rebuild(obj, {path: f for (path, _), f in zip(flat, fresh)})
 
 
 def _walk_clone(obj):
