@@ -527,3 +527,50 @@ def test_one_launch_small_layer_forms_with_the_exchange_inside(be, shape, pool):
         assert relerr(from_nhwc(DY.cpu(), c), xd.grad) < 1e-4 and torch.all(DY.cpu()[..., c:] == 0)
     finally:
         be.lib.call("mnk_p2p_destroy", hnd)
+
+
+@pytest.mark.parametrize("splits", [1, 2, 3, 4, 5, 8, 13, 33])
+@pytest.mark.parametrize("phases,pool,relu,c", [(1, 0, 1, 22), (1, 1, 1, 45), (4, 0, 1, 3), (4, 1, 0, 66), (1, 1, 0, 7)])
+def test_eval_norm_layer_on_split_partials(be, splits, phases, pool, relu, c):
+    """mnk_bn_eval_split_fwd on synthetic partials ([split][M][ldw], or [split][phase][M][ldw] of a sub-pixel form): z must be,
+    BIT FOR BIT, what the library's own two launches make of them -- the split reduction's summation order (four interleaved
+    groups, (g0 + g1) + (g2 + g3), then the bias; restated here in torch fp32) followed by mnk_bn_act_fwd on that y -- and close to
+    the fp64 evaluation-mode BatchNorm (+ ReLU, + 2x2 average pool) of sync_batchnorm/batchnorm.py:57-59 / util.py:56-57,100-107."""
+    n, h, w = 2, 4, 6                                   # (h, w): the convolution's output size
+    ld, rows = ceil4(c), n * h * w
+    g = torch.Generator().manual_seed(100 * splits + c)
+    part = torch.randn(splits, rows, ld, generator=g)   # row index = pixel (phases 1) / phase-major low-resolution pixel (4)
+    b = torch.randn(c, generator=g)
+    gr = [torch.zeros(rows, ld) for _ in range(4)]
+    s = 0
+    while s + 4 <= splits:
+        for e in range(4):
+            gr[e] = gr[e] + part[s + e]
+        s += 4
+    for e in range(3):
+        if s + e < splits:
+            gr[e] = gr[e] + part[s + e]
+    y = (gr[0] + gr[1]) + (gr[2] + gr[3])
+    y[:, :c] = y[:, :c] + b
+    y[:, c:] = 0
+    if phases == 4:                                     # phase-major rows -> the (n, h, w) pixel order of y
+        hl, wl = h // 2, w // 2
+        y = y.reshape(2, 2, n, hl, wl, ld).permute(2, 3, 0, 4, 1, 5).reshape(rows, ld)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    rm, rv = torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5
+    mean, invstd, scale = be.empty(c), be.empty(c), be.empty(c)
+    be.call("mnk_bn_eval_coeffs", be.t(gamma), be.t(rm), be.t(rv), 1e-5, c, mean, invstd, scale)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    Z, Z2 = be.empty(n, ho, wo, ld), be.empty(n, ho, wo, ld)
+    be.call("mnk_bn_eval_split_fwd", be.t(part), splits, ld, phases, be.t(b), mean, scale, be.t(beta), Z, ld, n, h, w, c, relu, pool)
+    be.call("mnk_bn_act_fwd", be.t(y.reshape(n, h, w, ld)), ld, mean, scale, be.t(beta), Z2, ld, 0, n, h, w, c, relu, pool)
+    be.sync()
+    assert torch.equal(Z.cpu(), Z2.cpu())
+    assert float(Z.cpu()[..., c:].abs().max()) == 0.0 if ld > c else True
+    yd = y[:, :c].double().reshape(n, h, w, c).permute(0, 3, 1, 2)
+    zref = F.batch_norm(yd, rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    if relu:
+        zref = F.relu(zref)
+    if pool:
+        zref = F.avg_pool2d(zref, 2)
+    assert maxerr(from_nhwc(Z.cpu(), c), zref) < 2e-5
