@@ -856,10 +856,16 @@ def conv3x3(x0, c0, weight, bias=None, x1=None, c1=0, ups=False, residual=None, 
                           and knobs.form("EVAL_SPLIT_FUSED"))
     if track:       # the norm layers whose outputs the sources are (see _BN_OF): picked up by Conv3x3Fn.forward
         _SRC_BN[0] = (_bn_of(x0), _bn_of(x1))
-    if skip and track and x0.requires_grad and knobs.form("SKIP_GRAD_FUSED"):
-        y, sums, through = Conv3x3SkipFn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
-        return y, (sums if want_stats else None), through
-    y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
+    try:
+        if skip and track and x0.requires_grad and knobs.form("SKIP_GRAD_FUSED"):
+            y, sums, through = Conv3x3SkipFn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
+            return y, (sums if want_stats else None), through
+        y, sums = Conv3x3Fn.apply(x0, x1, weight, bias, residual, c0, c1, bool(ups), bool(want_stats), track)
+    finally:
+        # one-shot hand-overs of THIS call: an exception in front of their consumer must not leave them for an unrelated launch
+        # (a data-gradient launch of a later backward also goes through _conv_launch)
+        _EVAL_DEFER[0] = False
+        _SRC_BN[0] = None
     return (y, (sums if want_stats else None), x0) if skip else (y, (sums if want_stats else None))
 
 

@@ -266,3 +266,21 @@ def _eval_split_case(be, monkeypatch, config, batch, size, with_generator):
     out = kpd(src)
     assert calls.get("mnk_bn_eval_split_fwd", 0) == 0 and calls.get("mnk_bn_act_fwd", 0) > 0
     assert torch.equal(out["mean"].detach(), kpd_mean_of(a, b, src, kpd))
+
+
+def test_an_exception_inside_a_convolution_call_leaves_no_hand_over_behind(be, monkeypatch):
+    """conv3x3(eval_bn=True) raises one-shot flags for the launch it is about to make; if the call dies first (here: the weight
+    pack fails) the flags must be gone -- the next launch through _conv_launch may be a data-gradient launch of an unrelated
+    backward pass, which must write its output."""
+    from mnk import ops
+    x = be.t(torch.randn(1, 8, 8, 8))
+    w = be.t(torch.randn(8, 8, 1, 3, 3) * 0.1)
+
+    def boom(*a, **k):
+        raise RuntimeError("pack failed")
+
+    monkeypatch.setattr(ops, "_packed_fwd_weight", boom)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="pack failed"):
+            ops.conv3x3(x, 8, w, None, eval_bn=True)
+    assert ops.handover_state() == {}
